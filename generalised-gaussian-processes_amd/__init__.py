@@ -1,0 +1,14 @@
+"""MI355X-native sparse-GP inference core (collapsed / VFE bound) behind the reference's model-class API.
+
+The directory name follows the project naming (``generalised-gaussian-processes_amd``), which is not a
+valid Python identifier: import it through the repo-root shim ``ggp_amd`` (``import ggp_amd``).
+"""
+from ._lib import KERNEL_IDS, SgpLibraryError, SgpStatusError, load_library  # noqa: F401
+from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, shard_rows  # noqa: F401
+
+
+def __getattr__(name):  # lazy: importing the package must work without a GPU (build / symbol checks)
+    if name == "HipEngine":
+        from .engine import HipEngine
+        return HipEngine
+    raise AttributeError(name)

@@ -1,0 +1,95 @@
+"""ctypes binding of libsgp_hip.so -- one Python prototype per entry point of include/sgp.h.
+
+There is deliberately no fallback: if the HIP library is missing or does not export a symbol the
+import fails loudly (``SgpLibraryError``).  The product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libsgp_hip.so")
+
+SGP_ABI_VERSION = 1
+SGP_MAX_DIM = 32
+SGP_MAX_INDUCING = 4096
+KERNEL_IDS = {"rbf": 0, "matern32": 1, "matern52": 2}
+OUT_F, OUT_LOGMARG, OUT_TRACE, OUT_LOGDETB, OUT_QUAD, OUT_TRW, OUT_S2BAR, OUT_KAPPABAR, OUT_LEN = range(9)
+
+
+class SgpLibraryError(RuntimeError):
+    pass
+
+
+class SgpStatusError(RuntimeError):
+    def __init__(self, fn, status, text):
+        super().__init__("%s returned %d: %s" % (fn, status, text))
+        self.status = status
+
+
+_vp, _i64, _i32, _dbl, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes) ; mirrors include/sgp.h line by line
+PROTOTYPES = {
+    "sgp_abi_version": (_i32, []),
+    "sgp_status_string": (C.c_char_p, [_i32]),
+    "sgp_suffstats_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_suffstats_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,
+                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_kuu": (_i32, [_vp, _i64, _dp, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp]),
+    "sgp_chol_workspace_bytes": (_sz, [_i32]),
+    "sgp_chol_lower": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "sgp_trsm_workspace_bytes": (_sz, [_i32, _i32]),
+    "sgp_trsm_lower": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "sgp_logdiag_sum": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "sgp_bound_workspace_bytes": (_sz, [_i32, _i32]),
+    "sgp_bound_factors_len": (_sz, [_i32]),
+    "sgp_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_suffstats_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _i64, _i32, _i32, _i32,
+                                 _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_kuu_bwd_workspace_bytes": (_sz, [_i32, _i32]),
+    "sgp_kuu_bwd": (_i32, [_vp, _i64, _dp, _dbl, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_predict_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "sgp_predict": (_i32, [_vp, _i64, _i64, _vp, _i64, _dp, _dbl, _dbl, _vp, _i32, _i32, _i32, _i32,
+                           _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_LIB = None
+
+
+def load_library(path: str | None = None):
+    """dlopen the HIP library and bind every prototype; raises SgpLibraryError when anything is missing."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SgpLibraryError(
+            "%s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc); this package has no CPU fallback." % p)
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # pragma: no cover - depends on the ROCm runtime being present
+        raise SgpLibraryError("cannot load %s: %s" % (p, e)) from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SgpLibraryError("%s does not export %s" % (p, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgp_abi_version() != SGP_ABI_VERSION:
+        raise SgpLibraryError("ABI version mismatch: library %d, binding %d" % (lib.sgp_abi_version(), SGP_ABI_VERSION))
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def check(fn_name: str, status: int):
+    if status != 0:
+        lib = load_library()
+        raise SgpStatusError(fn_name, status, lib.sgp_status_string(status).decode())

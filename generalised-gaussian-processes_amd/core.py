@@ -1,0 +1,226 @@
+"""CollapsedBound: the hot path as one object -- F(theta, Z), its gradient and the predictive.
+
+Reference call sites this replaces (paths relative to the reference repo):
+  * ``-mll(model(train_x), train_y)`` on ``SparseGPR``            models/sgpr.py:123-125
+  * ``pm.gp.MarginalSparse(approx="VFE").marginal_likelihood``   models/bayesian_sgpr_hmc.py:66,71
+  * ``likelihood(model(test_x))``                                 models/sgpr.py:150-160
+
+Data layout: X (N_local x d) and y (N_local) are resident on this rank's GPU for the whole run
+(row-sharded contiguously across ranks, never moved); Z (M x d) and the hyper-parameters are
+replicated.  One evaluation =
+    pass 1 on the local rows  ->  ONE all-reduce of the packed [Phi | b | yy | kappa] buffer
+    (RCCL over xGMI when world_size > 1)  ->  O(M^3) tail replicated on every rank (deterministic,
+    so no broadcast)  [-> pass 2 on the local rows -> one small all-reduce of the gradients].
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+try:  # torch.distributed is plumbing; single-process use never touches it
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+from ._lib import OUT_F, OUT_KAPPABAR, OUT_LOGMARG, OUT_S2BAR, OUT_TRACE
+
+
+class NotPositiveDefiniteError(RuntimeError):
+    """Raised (Adam path) when a Cholesky pivot is non-positive; ``info`` is the LAPACK-style index."""
+
+    def __init__(self, info):
+        super().__init__("matrix not positive definite: leading minor of order %d (1..M: Kuu, M+1..2M: B)" % info)
+        self.info = info
+
+
+def _world(group):
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group)
+
+
+class CollapsedBound:
+    """Collapsed (Titsias/VFE) sparse-GP bound over a resident row shard.
+
+    Parameters
+    ----------
+    X, y : local shard, float64, on the engine's device.
+    engine : object with the ``HipEngine`` interface; defaults to ``HipEngine()`` (the only product engine).
+    jitter : added to diag(Kuu): 0.0 = GPyTorch parity, 1e-6 = PyMC3 ``stabilize`` parity.
+    group : torch.distributed process group (None = default group when initialised).
+    """
+
+    def __init__(self, X, y, kernel="rbf", jitter=0.0, engine=None, group=None):
+        if engine is None:
+            from .engine import HipEngine
+            engine = HipEngine(X.device if X.is_cuda else None)
+        self.engine = engine
+        if X.dim() == 1:
+            X = X[:, None]
+        self.X = X.to(dtype=torch.float64, device=engine.device).contiguous()
+        self.y = y.to(dtype=torch.float64, device=engine.device).reshape(-1).contiguous()
+        if self.X.shape[0] != self.y.shape[0]:
+            raise ValueError("X has %d rows, y has %d" % (self.X.shape[0], self.y.shape[0]))
+        self.d = int(self.X.shape[1])
+        self.kernel = kernel
+        self.jitter = float(jitter)
+        self.group = group
+        self.world = _world(group)
+        n_local = int(self.X.shape[0])
+        if self.world > 1:
+            t = torch.tensor([n_local], dtype=torch.int64, device=engine.device)
+            dist.all_reduce(t, group=group)
+            self.N = int(t.item())
+        else:
+            self.N = n_local
+        self.n_evals = 0
+        self.n_grads = 0
+
+    # ------------------------------------------------------------------ internals
+    def _allreduce(self, buf):
+        if self.world > 1:
+            dist.all_reduce(buf, group=self.group)
+        return buf
+
+    @staticmethod
+    def _fetch(out, info):
+        """One host round trip for the scalars of an evaluation."""
+        o = out.detach().to("cpu")
+        i = int(info.detach().to("cpu").item())
+        return o, i
+
+    def _prep_Z(self, Z):
+        if Z.dim() == 1:
+            Z = Z[:, None]
+        return Z.detach().to(dtype=torch.float64, device=self.engine.device).contiguous()
+
+    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False):
+        e = self.engine
+        packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel)
+        self._allreduce(packed)
+        Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
+        res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors)
+        res["packed"] = packed
+        return res
+
+    # ------------------------------------------------------------------ public
+    def value(self, Z, ls, sf2, s2, raise_on_fail=True):
+        """F (not divided by N).  Returns (F, parts) with parts = dict(logmarg, trace_term, info)."""
+        Z = self._prep_Z(Z)
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=False)
+        o, info = self._fetch(res["out"], res["info"])
+        self.n_evals += 1
+        if info != 0:
+            if raise_on_fail:
+                raise NotPositiveDefiniteError(info)
+            return float("nan"), {"info": info}
+        return float(o[OUT_F]), {"logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE]), "info": 0}
+
+    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True):
+        """F and dF/d{lengthscale_j, sf2, s2[, Z]} (natural parameters, not their raw transforms).
+
+        Returns (F, grads) with grads = dict(ls=tensor[d] (cpu), sf2=float, s2=float, Z=device tensor or None).
+        """
+        e = self.engine
+        Z = self._prep_Z(Z)
+        M, d = Z.shape
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=True)
+        o, info = self._fetch(res["out"], res["info"])
+        self.n_evals += 1
+        self.n_grads += 1
+        if info != 0:
+            if raise_on_fail:
+                raise NotPositiveDefiniteError(info)
+            return float("nan"), {"info": info}
+        g = e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], float(o[OUT_KAPPABAR]),
+                            self.kernel, want_gz=want_gz)
+        self._allreduce(g)
+        e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
+        gh = g[: d + 1].detach().to("cpu")
+        grads = {"ls": gh[:d].clone(), "sf2": float(gh[d]), "s2": float(o[OUT_S2BAR]),
+                 "Z": g[d + 1:].reshape(M, d) if want_gz else None, "info": 0,
+                 "logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE])}
+        return float(o[OUT_F]), grads
+
+    def factors(self, Z, ls, sf2, s2):
+        """Device tensor [Linv | G | q] for ``predict`` (computed from the current statistics)."""
+        Z = self._prep_Z(Z)
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True)
+        _, info = self._fetch(res["out"], res["info"])
+        if info != 0:
+            raise NotPositiveDefiniteError(info)
+        return res["factors"]
+
+    def predict(self, Xs, Z, ls, sf2, s2, pred_noise=True, full_cov=False, factors=None):
+        """Posterior predictive mean / variance (/ covariance) at Xs -- models/sgpr.py:150-160, 256-286."""
+        Z = self._prep_Z(Z)
+        if Xs.dim() == 1:
+            Xs = Xs[:, None]
+        Xs = Xs.detach().to(dtype=torch.float64, device=self.engine.device).contiguous()
+        if factors is None:
+            factors = self.factors(Z, ls, sf2, s2)
+        return self.engine.predict(Xs, Z, ls, sf2, s2, factors, self.kernel, pred_noise=pred_noise, full_cov=full_cov)
+
+
+def shard_rows(N: int, rank: int, world: int):
+    """Contiguous row block [lo, hi) of rank ``rank`` (X[g N/G : (g+1) N/G])."""
+    base, rem = divmod(N, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+# ---------------------------------------------------------------------------------------------
+# HMC target: VFE logp + priors + log-Jacobians  (reference models/bayesian_sgpr_hmc.py:60-71)
+# ---------------------------------------------------------------------------------------------
+class HmcTarget:
+    """logp(theta_unc) and its gradient, theta_unc = [log ls_1..d, log sig_f, log sig_n].
+
+    ls ~ Gamma(alpha=2, beta=1), sig_f ~ HalfCauchy(1), sig_n ~ HalfCauchy(1), all log-transformed
+    as PyMC3 does for positive variables; covariance sig_f**2 * ExpQuad(ls), noise sig_n, Kuu jitter
+    1e-6 (``stabilize``).  A failed Cholesky gives logp = -inf (PyMC3: ``on_error='nan'``), which the
+    sampler treats as a divergence, never an exception.
+    """
+
+    def __init__(self, bound: CollapsedBound, Z):
+        self.bound = bound
+        self.Z = bound._prep_Z(Z)
+        self.d = bound.d
+        self.ndim = self.d + 2
+
+    @staticmethod
+    def _prior(ls, sf, sn):
+        lp = sum(math.log(v) - v for v in ls)
+        g_ls = [1.0 / v - 1.0 for v in ls]
+        c = math.log(2.0) - math.log(math.pi)
+        lp += (c - math.log1p(sf * sf)) + (c - math.log1p(sn * sn))
+        return lp, g_ls, -2.0 * sf / (1.0 + sf * sf), -2.0 * sn / (1.0 + sn * sn)
+
+    def constrain(self, theta):
+        th = [float(v) for v in theta]
+        return {"ls": [math.exp(v) for v in th[: self.d]], "sig_f": math.exp(th[self.d]), "sig_n": math.exp(th[self.d + 1])}
+
+    def logp(self, theta):
+        p = self.constrain(theta)
+        F, parts = self.bound.value(self.Z, p["ls"], p["sig_f"] ** 2, p["sig_n"] ** 2, raise_on_fail=False)
+        if parts.get("info", 0) != 0 or not math.isfinite(F):
+            return -math.inf
+        lp, _, _, _ = self._prior(p["ls"], p["sig_f"], p["sig_n"])
+        return F + lp + sum(float(v) for v in theta)
+
+    def logp_and_grad(self, theta):
+        """Returns (logp, grad list[d+2]).  One call = one HMC leapfrog's worth of device work."""
+        p = self.constrain(theta)
+        ls, sf, sn = p["ls"], p["sig_f"], p["sig_n"]
+        F, g = self.bound.value_and_grad(self.Z, ls, sf * sf, sn * sn, want_gz=False, raise_on_fail=False)
+        if g.get("info", 0) != 0 or not math.isfinite(F):
+            return -math.inf, [0.0] * self.ndim
+        lp, pg_ls, pg_sf, pg_sn = self._prior(ls, sf, sn)
+        grad = []
+        for j in range(self.d):  # d/d log ls = ls * d/d ls ; + Jacobian term 1
+            grad.append(ls[j] * (float(g["ls"][j]) + pg_ls[j]) + 1.0)
+        grad.append(sf * (2.0 * sf * g["sf2"] + pg_sf) + 1.0)
+        grad.append(sn * (2.0 * sn * g["s2"] + pg_sn) + 1.0)
+        return F + lp + sum(float(v) for v in theta), grad

@@ -1,0 +1,98 @@
+// Shared device helpers for the gfx950 (CDNA4) sparse-GP kernels.
+// fp64 throughout; wavefront = 64 lanes; MFMA = v_mfma_f64_16x16x4_f64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sgp.h"
+
+namespace sgp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+constexpr int PADM = 128;  // every M x M matrix handled inside the library is padded to a multiple of this
+
+__host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+inline int padded_m(int M) { return round_up(M, PADM); }
+
+// D(16x16) += A(16x4) * B(4x16).  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+// it receives D[(l>>4) + 4r][l&15] in element r of the accumulator (r = 0..3).
+__device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Hyper-parameters travel as kernel arguments (no device round trip per leapfrog).
+struct KernArgs {
+  double inv_ls[SGP_MAX_DIM];
+  double sf2;
+  int d;
+};
+
+// k'(r2): the stationary profile WITHOUT the sf2 factor; r2 = scaled squared distance.
+// Also returns h = dk'/d(r2) when asked (used by the backward pass).
+template <int KID>
+__device__ __forceinline__ double kprofile(double r2) {
+  if constexpr (KID == SGP_KERNEL_RBF) {
+    return exp(-0.5 * r2);
+  } else if constexpr (KID == SGP_KERNEL_MATERN32) {
+    const double a = 1.7320508075688772 * sqrt(r2);
+    return (1.0 + a) * exp(-a);
+  } else {
+    const double a = 2.23606797749979 * sqrt(r2);
+    return (1.0 + a + a * a * (1.0 / 3.0)) * exp(-a);
+  }
+}
+
+template <int KID>
+__device__ __forceinline__ void kprofile_grad(double r2, double& k, double& h) {
+  if constexpr (KID == SGP_KERNEL_RBF) {
+    k = exp(-0.5 * r2);
+    h = -0.5 * k;
+  } else if constexpr (KID == SGP_KERNEL_MATERN32) {
+    const double a = 1.7320508075688772 * sqrt(r2);
+    const double e = exp(-a);
+    k = (1.0 + a) * e;
+    h = -1.5 * e;
+  } else {
+    const double a = 2.23606797749979 * sqrt(r2);
+    const double e = exp(-a);
+    k = (1.0 + a + a * a * (1.0 / 3.0)) * e;
+    h = -(5.0 / 6.0) * (1.0 + a) * e;
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread.  `red` = 4 doubles of LDS.
+__device__ __forceinline__ double block_sum256(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// Workspace carving: 256-byte aligned bump allocator over the caller's scratch buffer.
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* r = reinterpret_cast<T*>(base ? base + off : nullptr);
+    off += n * sizeof(T);
+    return r;
+  }
+  size_t used() const { return (off + 255) & ~size_t(255); }
+};
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? SGP_OK : SGP_ERR_LAUNCH; }
+
+}  // namespace sgp

@@ -1,0 +1,495 @@
+// M x M dense back end on gfx950: fp64 MFMA GEMM, blocked Cholesky, triangular inverse.
+// Replaces what the reference reaches through torch.linalg / LAPACK / Theano for the two M x M
+// factorizations and solves of the collapsed bound (psd_safe_cholesky, triangular_solve inside
+// gpytorch's InducingPointKernel / ExactMarginalLogLikelihood -- reference models/sgpr.py:37,125 --
+// and cholesky / solve_lower inside pymc3 MarginalSparse -- reference models/bayesian_sgpr_hmc.py:71).
+//
+// Design: everything O(M^3) is phrased as 64 x 64-tiled GEMMs on v_mfma_f64_16x16x4_f64 so the only
+// latency-bound pieces are the 64 x 64 diagonal blocks, which one workgroup factors and inverts in LDS.
+//   potrf  : right-looking, per 64-column block  { diag factor+invert | panel = A21 Linv_kk^T | A22 -= P P^T }
+//   trtri  : recursive doubling on the inverted diagonal blocks, Inv21 = -Inv22 (L21 Inv11), batched GEMMs
+// Triangular structure is exploited by clipping each output tile's k-range (GemmDesc::klo/khi masks).
+#include "sgp_dense.hpp"
+
+namespace sgp {
+
+constexpr int GT = 64;    // GEMM tile edge
+constexpr int GK = 16;    // k-chunk
+constexpr int GLD = GT + 16;  // LDS row stride (80 doubles: +128 B bank shift per k)
+
+struct GemmP {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc, sA, sB, sC;
+  int m, n, k;
+  double alpha, beta;
+  int klo_mask, khi_mask, lower_only;
+};
+
+// op(A) tile -> As[k][row]; "K-contiguous" source (A not transposed / B transposed) or
+// "MN-contiguous" source (A transposed / B not transposed).
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_fetch(const double* P, int64_t ld, int r0, int k0, double (&v)[4]) {
+  const int t = threadIdx.x;
+  if constexpr (KCONTIG) {
+    const int row = t >> 2, kq = (t & 3) * 4;
+    const double* s = P + (int64_t)(r0 + row) * ld + k0 + kq;
+    const d2 x0 = *reinterpret_cast<const d2*>(s);
+    const d2 x1 = *reinterpret_cast<const d2*>(s + 2);
+    v[0] = x0[0]; v[1] = x0[1]; v[2] = x1[0]; v[3] = x1[1];
+  } else {
+    const int kk = t >> 4, mq = (t & 15) * 4;
+    const double* s = P + (int64_t)(k0 + kk) * ld + r0 + mq;
+    const d2 x0 = *reinterpret_cast<const d2*>(s);
+    const d2 x1 = *reinterpret_cast<const d2*>(s + 2);
+    v[0] = x0[0]; v[1] = x0[1]; v[2] = x1[0]; v[3] = x1[1];
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_stash(double (*S)[GLD], const double (&v)[4]) {
+  const int t = threadIdx.x;
+  if constexpr (KCONTIG) {
+    const int row = t >> 2, kq = (t & 3) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[kq + e][row] = v[e];
+  } else {
+    const int kk = t >> 4, mq = (t & 15) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[kk][mq + e] = v[e];
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
+  __shared__ double As[GK][GLD];
+  __shared__ double Bs[GK][GLD];
+  const int bj = blockIdx.x, bi = blockIdx.y;
+  if (p.lower_only && bj > bi) return;
+  const int64_t bz = blockIdx.z;
+  const double* A = p.A + bz * p.sA;
+  const double* B = p.B + bz * p.sB;
+  double* C = p.C + bz * p.sC;
+
+  int klo = 0, khi = p.k;
+  if (p.klo_mask & 1) klo = max(klo, bi * GT);
+  if (p.klo_mask & 2) klo = max(klo, bj * GT);
+  if (p.khi_mask & 1) khi = min(khi, (bi + 1) * GT);
+  if (p.khi_mask & 2) khi = min(khi, (bj + 1) * GT);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  const int r0 = bi * GT, c0 = bj * GT;
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+
+  if (klo < khi) {
+    double va[4], vb[4];
+    tile_fetch<!TA>(A, p.lda, r0, klo, va);
+    tile_fetch<TB>(B, p.ldb, c0, klo, vb);
+    for (int k0 = klo; k0 < khi; k0 += GK) {
+      tile_stash<!TA>(As, va);
+      tile_stash<TB>(Bs, vb);
+      __syncthreads();
+      if (k0 + GK < khi) {
+        tile_fetch<!TA>(A, p.lda, r0, k0 + GK, va);
+        tile_fetch<TB>(B, p.ldb, c0, k0 + GK, vb);
+      }
+#pragma unroll
+      for (int ks = 0; ks < GK / 4; ++ks) {
+        const int kr = ks * 4 + l4;
+        const double a0 = As[kr][wi * 32 + l15], a1 = As[kr][wi * 32 + 16 + l15];
+        const double b0 = Bs[kr][wj * 32 + l15], b1 = Bs[kr][wj * 32 + 16 + l15];
+        acc[0][0] = mfma16(a0, b0, acc[0][0]);
+        acc[0][1] = mfma16(a0, b1, acc[0][1]);
+        acc[1][0] = mfma16(a1, b0, acc[1][0]);
+        acc[1][1] = mfma16(a1, b1, acc[1][1]);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + wi * 32 + u * 16 + l4 + 4 * r;
+        const int col = c0 + wj * 32 + v * 16 + l15;
+        double* dst = C + (int64_t)row * p.ldc + col;
+        const double val = p.alpha * acc[u][v][r];
+        *dst = (p.beta == 0.0) ? val : fma(p.beta, *dst, val);
+      }
+}
+
+void gemm(const GemmDesc& g, hipStream_t st) {
+  if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return;
+  GemmP p{g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.sA, g.sB, g.sC, g.m, g.n, g.k,
+          g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? 1 : 0};
+  dim3 grid(g.n / GT, g.m / GT, g.batch);
+  if (!g.ta && !g.tb) gemm64_kernel<false, false><<<grid, 256, 0, st>>>(p);
+  else if (!g.ta && g.tb) gemm64_kernel<false, true><<<grid, 256, 0, st>>>(p);
+  else if (g.ta && !g.tb) gemm64_kernel<true, false><<<grid, 256, 0, st>>>(p);
+  else gemm64_kernel<true, true><<<grid, 256, 0, st>>>(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64 x 64 diagonal block: Cholesky + inverse of the factor, one workgroup, all in LDS
+// ---------------------------------------------------------------------------------------------
+constexpr int DB = 64;
+constexpr int DLD = DB + 1;
+
+// Inv[o+s .. o+2s)[o .. o+s) = -Inv22 * (S21 * Inv11) for `npairs` pairs at o = 0, 2s, ...
+__device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD], double (*T)[DLD], int s, int npairs) {
+  const int tid = threadIdx.x;
+  const int per = s * s;
+  for (int e = tid; e < npairs * per; e += 256) {
+    const int pr = e / per, r = e - pr * per;
+    const int i = r / s, j = r - i * s;
+    const int o = pr * 2 * s;
+    double acc = 0.0;
+    for (int q = j; q < s; ++q) acc = fma(S[o + s + i][o + q], Inv[o + q][o + j], acc);  // Inv11 lower: q >= j
+    T[o + s + i][o + j] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < npairs * per; e += 256) {
+    const int pr = e / per, r = e - pr * per;
+    const int i = r / s, j = r - i * s;
+    const int o = pr * 2 * s;
+    double acc = 0.0;
+    for (int q = 0; q <= i; ++q) acc = fma(Inv[o + s + i][o + s + q], T[o + s + q][o + j], acc);  // Inv22 lower: q <= i
+    Inv[o + s + i][o + j] = -acc;
+  }
+  __syncthreads();
+}
+
+// Inv = S^-1 for a 64 x 64 lower-triangular S in LDS (Inv must be zero on entry):
+// four 16 x 16 diagonal blocks by forward substitution, then two doubling steps 16 -> 32 -> 64.
+__device__ __forceinline__ void block_inverse64(double (*S)[DLD], double (*Inv)[DLD], double (*T)[DLD]) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int b16 = (tid >> 4) * 16, c = tid & 15;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) s = fma(-S[b16 + r][b16 + q], x[q], s);
+      x[r] = s / S[b16 + r][b16 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Inv[b16 + r][b16 + c] = x[r];
+  }
+  __syncthreads();
+  inv_combine(S, Inv, T, 16, 2);
+  inv_combine(S, Inv, T, 32, 1);
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Linv, int64_t ld, int k0, int* info, int info_base) {
+  __shared__ double S[DB][DLD];
+  __shared__ double Inv[DB][DLD];
+  __shared__ double T[DB][DLD];
+  __shared__ double dg[DB];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    S[i][j] = (j <= i) ? A[(int64_t)(k0 + i) * ld + k0 + j] : 0.0;
+    Inv[i][j] = 0.0;
+  }
+  __syncthreads();
+  const int i = tid & 63, pg = tid >> 6;
+  for (int j = 0; j < DB; ++j) {
+    double ajj = S[j][j];
+    if (!(ajj > 0.0)) {  // non-positive or NaN pivot: report LAPACK-style, keep going on a unit pivot
+      if (tid == 0 && bad == 0) bad = j + 1;
+      ajj = 1.0;
+    }
+    const double d = sqrt(ajj);
+    if (tid > j && tid < DB) S[tid][j] /= d;
+    if (tid == j) dg[j] = d;
+    __syncthreads();
+    if (i > j) {
+      const double lij = S[i][j];
+      for (int p = j + 1 + pg; p <= i; p += 4) S[i][p] = fma(-lij, S[p][j], S[i][p]);
+    }
+    __syncthreads();
+  }
+  if (tid < DB) S[tid][tid] = dg[tid];
+  __syncthreads();
+
+  block_inverse64(S, Inv, T);
+
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    A[(int64_t)(k0 + r) * ld + k0 + c] = S[r][c];
+    Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
+  }
+  if (tid == 0 && bad != 0 && *info == 0) *info = info_base + bad;
+}
+
+// inverses of the 64 x 64 diagonal blocks of an already-factored L (one workgroup per block)
+__global__ __launch_bounds__(256) void tri_diag_inv_kernel(const double* L, double* Linv, int64_t ld) {
+  __shared__ double S[DB][DLD];
+  __shared__ double Inv[DB][DLD];
+  __shared__ double T[DB][DLD];
+  const int tid = threadIdx.x, k0 = blockIdx.x * DB;
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    S[i][j] = (j <= i) ? L[(int64_t)(k0 + i) * ld + k0 + j] : 0.0;
+    Inv[i][j] = 0.0;
+  }
+  __syncthreads();
+  block_inverse64(S, Inv, T);
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
+  }
+}
+void tri_diag_inverse(const double* L, double* Linv, int64_t ld, int Mp, hipStream_t st) {
+  tri_diag_inv_kernel<<<Mp / DB, 256, 0, st>>>(L, Linv, ld);
+}
+
+// zero the strictly-upper 64-blocks of row block kb (the diagonal block is handled by the diag kernel)
+__global__ void zero_upper_blocks_kernel(double* A, int64_t ld, int Mp) {
+  const int rb = blockIdx.y;              // row block
+  const int cb = blockIdx.x;              // column block
+  if (cb <= rb) return;
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
+    A[(int64_t)(rb * 64 + r) * ld + cb * 64 + c] = 0.0;
+  }
+}
+
+void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, hipStream_t st) {
+  const int nb = Mp / DB;
+  fill_zero(Linv, (size_t)Mp * ld, st);
+  for (int kb = 0; kb < nb; ++kb) {
+    const int k0 = kb * DB;
+    potrf_diag_kernel<<<1, 256, 0, st>>>(A, Linv, ld, k0, info, info_base + k0);
+    const int rem = Mp - (kb + 1) * DB;
+    if (rem > 0) {
+      double* panel = A + (int64_t)(k0 + DB) * ld + k0;
+      GemmDesc g;
+      g.A = panel; g.lda = ld;
+      g.B = Linv + (int64_t)k0 * (ld + 1); g.ldb = ld; g.tb = true;
+      g.C = panel; g.ldc = ld;
+      g.m = rem; g.n = DB; g.k = DB;
+      g.khi_mask = 0;
+      gemm(g, st);
+      GemmDesc u;
+      u.A = panel; u.lda = ld;
+      u.B = panel; u.ldb = ld; u.tb = true;
+      u.C = A + (int64_t)(k0 + DB) * (ld + 1); u.ldc = ld;
+      u.m = rem; u.n = rem; u.k = DB;
+      u.alpha = -1.0; u.beta = 1.0; u.lower_only = true;
+      gemm(u, st);
+    }
+  }
+  if (nb > 1) zero_upper_blocks_kernel<<<dim3(nb, nb), 256, 0, st>>>(A, ld, Mp);
+}
+
+void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {
+  for (int s = DB; s < Mp; s *= 2) {
+    const int np = Mp / (2 * s);
+    const int rem = Mp - np * 2 * s;
+    const int64_t pstride = (int64_t)2 * s * (ld + 1);
+    auto level = [&](int64_t o, int batch, int n2) {
+      // T = L21 * Inv11   (n2 x s) = (n2 x s)(s x s), Inv11 lower-triangular -> k >= column tile start
+      GemmDesc a;
+      a.A = L + o * (ld + 1) + (int64_t)s * ld; a.lda = ld; a.sA = pstride;
+      a.B = Linv + o * (ld + 1); a.ldb = ld; a.sB = pstride;
+      a.C = tmp + o * (ld + 1) + (int64_t)s * ld; a.ldc = ld; a.sC = pstride;
+      a.m = n2; a.n = s; a.k = s; a.batch = batch; a.klo_mask = 2;
+      gemm(a, st);
+      // Inv21 = -Inv22 * T   (n2 x s) = (n2 x n2)(n2 x s), Inv22 lower-triangular -> k <= row tile end
+      GemmDesc b;
+      b.A = Linv + o * (ld + 1) + (int64_t)s * (ld + 1); b.lda = ld; b.sA = pstride;
+      b.B = tmp + o * (ld + 1) + (int64_t)s * ld; b.ldb = ld; b.sB = pstride;
+      b.C = Linv + o * (ld + 1) + (int64_t)s * ld; b.ldc = ld; b.sC = pstride;
+      b.m = n2; b.n = s; b.k = n2; b.batch = batch; b.alpha = -1.0; b.khi_mask = 1;
+      gemm(b, st);
+    };
+    if (np > 0) level(0, np, s);
+    if (rem > s) level((int64_t)np * 2 * s, 1, rem - s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int64_t ld, int Mp,
+                                                        const double* __restrict__ x, double* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= Mp) return;
+  double s = 0.0;
+  for (int j = lane; j < Mp; j += 64) s = fma(A[(int64_t)row * ld + j], x[j], s);
+  s = wave_sum(s);
+  if (lane == 0) y[row] = s;
+}
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const double* __restrict__ A, int64_t ld, int Mp,
+                                                        const double* __restrict__ x, double* __restrict__ y) {
+  // y[i] = sum_j A[j][i] x[j]; a block owns 64 columns, its 4 waves split the rows
+  __shared__ double part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int j = w; j < Mp; j += 4) s = fma(A[(int64_t)j * ld + col], x[j], s);
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0) y[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+void gemv(const double* A, int64_t ld, int Mp, bool trans, const double* x, double* y, hipStream_t st) {
+  if (!trans) gemv_rows_kernel<<<Mp / 4, 256, 0, st>>>(A, ld, Mp, x, y);
+  else gemv_cols_kernel<<<Mp / 64, 256, 0, st>>>(A, ld, Mp, x, y);
+}
+
+__global__ void pad_copy_kernel(const double* __restrict__ src, int64_t lds, int rs, int cs, double* __restrict__ dst,
+                                int64_t ldd, int rows, int cols, double diag_pad) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+    double v = 0.0;
+    if (r < rs && c < cs) v = src[(int64_t)r * lds + c];
+    else if (r == c) v = diag_pad;
+    dst[(int64_t)r * ldd + c] = v;
+  }
+}
+void pad_copy(const double* src, int64_t lds, int rs, int cs, double* dst, int64_t ldd, int rows, int cols,
+              double diag_pad, hipStream_t st) {
+  const int64_t total = (int64_t)rows * cols;
+  const int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  pad_copy_kernel<<<g, 256, 0, st>>>(src, lds, rs, cs, dst, ldd, rows, cols, diag_pad);
+}
+__global__ void crop_copy_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int rs, int cs) {
+  const int64_t total = (int64_t)rs * cs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cs), c = (int)(e - (int64_t)r * cs);
+    dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c];
+  }
+}
+void crop_copy(const double* src, int64_t lds, double* dst, int64_t ldd, int rs, int cs, hipStream_t st) {
+  const int64_t total = (int64_t)rs * cs;
+  if (total <= 0) return;
+  const int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  crop_copy_kernel<<<g, 256, 0, st>>>(src, lds, dst, ldd, rs, cs);
+}
+__global__ void fill_zero_kernel(double* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+void fill_zero(double* p, size_t n, hipStream_t st) {
+  if (n == 0) return;
+  const int g = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  fill_zero_kernel<<<g, 256, 0, st>>>(p, n);
+}
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* A, int64_t ld, int Mp) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[ty + 8 * k][tx] = A[(int64_t)(bi * 32 + ty + 8 * k) * ld + bj * 32 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = bj * 32 + ty + 8 * k, c = bi * 32 + tx;  // upper-triangle destination
+    if (c > r) A[(int64_t)r * ld + c] = t[tx][ty + 8 * k];
+  }
+}
+void mirror_lower(double* A, int64_t ld, int Mp, hipStream_t st) {
+  mirror_lower_kernel<<<dim3(Mp / 32, Mp / 32), 256, 0, st>>>(A, ld, Mp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// public M x M entry points (sgp.h)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__ L, int64_t ld, int M, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < M; i += 256) s += log(L[(int64_t)i * ld + i]);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) *out = s;
+}
+
+}  // namespace sgp
+
+using namespace sgp;
+
+extern "C" size_t sgp_chol_workspace_bytes(int M) {
+  if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = padded_m(M);
+  Carver c(nullptr);
+  c.take<double>(Mp * Mp);
+  c.take<double>(Mp * Mp);
+  return c.used();
+}
+
+extern "C" int sgp_chol_lower(double* A, int64_t lda, int M, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!A || !info || M <= 0 || lda < M) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (!ws || ws_bytes < sgp_chol_workspace_bytes(M)) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mp = padded_m(M);
+  Carver c(ws);
+  double* Ap = c.take<double>((size_t)Mp * Mp);
+  double* Li = c.take<double>((size_t)Mp * Mp);
+  hipMemsetAsync(info, 0, sizeof(int), st);
+  pad_copy(A, lda, M, M, Ap, Mp, Mp, Mp, 1.0, st);
+  potrf_lower(Ap, Li, Mp, Mp, info, 0, st);
+  crop_copy(Ap, Mp, A, lda, M, M, st);
+  return check_launch();
+}
+
+extern "C" size_t sgp_trsm_workspace_bytes(int M, int k) {
+  if (M <= 0 || k <= 0 || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = padded_m(M), kp = round_up(k, 64);
+  Carver c(nullptr);
+  c.take<double>(Mp * Mp);  // L padded
+  c.take<double>(Mp * Mp);  // Linv
+  c.take<double>(Mp * Mp);  // tmp
+  c.take<double>(Mp * kp);  // B padded
+  c.take<double>(Mp * kp);  // result
+  return c.used();
+}
+
+// B <- L^-1 B or L^-T B through the explicit blocked inverse (same machinery as the bound's tail).
+extern "C" int sgp_trsm_lower(const double* L, int64_t ldl, double* B, int64_t ldb, int trans, int M, int k,
+                              void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!L || !B || M <= 0 || k <= 0 || ldl < M || ldb < k) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (!ws || ws_bytes < sgp_trsm_workspace_bytes(M, k)) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mp = padded_m(M), kp = round_up(k, 64);
+  Carver c(ws);
+  double* Lp = c.take<double>((size_t)Mp * Mp);
+  double* Li = c.take<double>((size_t)Mp * Mp);
+  double* tmp = c.take<double>((size_t)Mp * Mp);
+  double* Bp = c.take<double>((size_t)Mp * kp);
+  double* R = c.take<double>((size_t)Mp * kp);
+  pad_copy(L, ldl, M, M, Lp, Mp, Mp, Mp, 1.0, st);
+  fill_zero(Li, (size_t)Mp * Mp, st);
+  tri_diag_inverse(Lp, Li, Mp, Mp, st);
+  tri_inverse(Lp, Li, tmp, Mp, Mp, st);
+  pad_copy(B, ldb, M, k, Bp, kp, Mp, kp, 0.0, st);
+  GemmDesc g;
+  g.A = Li; g.lda = Mp; g.ta = (trans != 0);
+  g.B = Bp; g.ldb = kp;
+  g.C = R; g.ldc = kp;
+  g.m = Mp; g.n = kp; g.k = Mp;
+  if (!trans) g.khi_mask = 1; else g.klo_mask = 1;
+  gemm(g, st);
+  crop_copy(R, kp, B, ldb, M, k, st);
+  return check_launch();
+}
+
+extern "C" int sgp_logdiag_sum(const double* L, int64_t ldl, int M, double* out, sgp_stream_t stream) {
+  if (!L || !out || M <= 0 || ldl < M) return SGP_ERR_ARG;
+  logdiag_kernel<<<1, 256, 0, (hipStream_t)stream>>>(L, ldl, M, out);
+  return check_launch();
+}

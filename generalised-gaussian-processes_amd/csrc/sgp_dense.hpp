@@ -1,0 +1,50 @@
+// Internal interface of the M x M dense back end (all matrices row-major fp64, every dimension a
+// multiple of 64 -- callers pad to sgp::PADM = 128 -- leading dimensions in elements).
+#pragma once
+#include "sgp_common.hpp"
+
+namespace sgp {
+
+// C = alpha * op(A) * op(B) + beta * C, optionally batched (blockIdx.z) with element strides.
+// klo/khi masks restrict the k-range of an output tile to where triangular operands are non-zero:
+//   bit 0 -> bound by the tile's row range, bit 1 -> bound by the tile's column range
+//   klo = max(enabled starts), khi = min(enabled ends)
+// lower_only skips tiles strictly above the diagonal (they are left untouched).
+struct GemmDesc {
+  const double* A = nullptr;
+  const double* B = nullptr;
+  double* C = nullptr;
+  int64_t lda = 0, ldb = 0, ldc = 0;
+  int64_t sA = 0, sB = 0, sC = 0;
+  int m = 0, n = 0, k = 0, batch = 1;
+  double alpha = 1.0, beta = 0.0;
+  bool ta = false, tb = false;
+  int klo_mask = 0, khi_mask = 0;
+  bool lower_only = false;
+};
+void gemm(const GemmDesc& g, hipStream_t st);
+
+// In-place lower Cholesky of the Mp x Mp matrix A (Mp multiple of 64); strictly-upper part of the
+// result is zeroed.  Linv (Mp x Mp, same ld) receives the inverses of the 64 x 64 diagonal blocks of
+// L (and is zero elsewhere) -- level 0 of tri_inverse().  info_base offsets the reported pivot index
+// (info is only written when still 0, so two factorizations can share one flag).
+void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, hipStream_t st);
+
+// Completes Linv (diagonal 64-blocks already inverted by potrf_lower) to the full inverse of L.
+// tmp: Mp x Mp scratch with the same ld.
+void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st);
+
+// y = op(A) x for a lower-triangular (or general) Mp x Mp matrix; one wave per row.
+void gemv(const double* A, int64_t ld, int Mp, bool trans, const double* x, double* y, hipStream_t st);
+
+// dst (rows x cols, ld ldd) <- src (rs x cs, ld lds) zero padded; diag_pad: value put on the padded
+// part of the diagonal (1.0 keeps padded Cholesky factors the identity).
+void pad_copy(const double* src, int64_t lds, int rs, int cs, double* dst, int64_t ldd, int rows, int cols,
+              double diag_pad, hipStream_t st);
+// dst (rs x cs, ld ldd) <- top-left corner of src (ld lds)
+void crop_copy(const double* src, int64_t lds, double* dst, int64_t ldd, int rs, int cs, hipStream_t st);
+void fill_zero(double* p, size_t n, hipStream_t st);
+// upper triangle <- transpose of lower triangle
+void mirror_lower(double* A, int64_t ld, int Mp, hipStream_t st);
+
+}  // namespace sgp

@@ -1,0 +1,565 @@
+// The O(M^3) tail of the collapsed bound, its adjoints, the Kuu block and the predictive.
+//
+//   L = chol(Kuu) ; W = L^-1 Phi L^-T ; B = I + W/s2 ; LB = chol(B) ; q = LB^-1 L^-1 b
+//   F = -[ N/2 log 2pi + N/2 log s2 + sum log diag LB + (yy/s2 - q.q/s2^2)/2 + (kappa - tr W)/(2 s2) ]
+//
+// This is the op order of pymc3's MarginalSparse VFE logp (reference models/bayesian_sgpr_hmc.py:66,71)
+// applied to the streamed sufficient statistics, and equals gpytorch's
+// ExactMarginalLogLikelihood + InducingPointKernelAddedLossTerm on the reference's SparseGPR
+// (models/sgpr.py:37,114,125) times N.  Everything runs on padded Mp x Mp matrices (Mp = 128-multiple;
+// padding rows are identity for Kuu / zero for Phi so factors stay exact) through the MFMA GEMM,
+// blocked Cholesky and recursive triangular inverse of sgp_dense.hip; no host round trip.
+#include "sgp_dense.hpp"
+
+namespace sgp {
+
+// ---------------------------------------------------------------------------------------------
+// Kuu
+// ---------------------------------------------------------------------------------------------
+template <int KID>
+__global__ __launch_bounds__(256) void kuu_kernel(const double* __restrict__ Z, int64_t ldz, KernArgs ka, double jitter,
+                                                  int M, double* __restrict__ Kuu) {
+  const int64_t total = (int64_t)M * M;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / M), j = (int)(e - (int64_t)i * M);
+    double r2 = 0.0;
+    for (int q = 0; q < ka.d; ++q) {
+      const double df = (Z[i * ldz + q] - Z[j * ldz + q]) * ka.inv_ls[q];
+      r2 = fma(df, df, r2);
+    }
+    double v = ka.sf2 * kprofile<KID>(r2);
+    if (i == j) v += jitter;
+    Kuu[e] = v;
+  }
+}
+
+// per-row partials of  sum_{m,m'} Kuubar[m][m'] dKuu[m][m']/d(.)  (Kuubar treated as symmetric)
+//   part[m][0..d)  = sum_m' E (z~_mj - z~_m'j)^2         (E = Kuubar sf2 dk'/dr2)
+//   part[m][d]     = sum_m' Kuubar k'
+//   gz[m][j]       = sum_m' E (z~_mj - z~_m'j)
+template <int KID>
+__global__ __launch_bounds__(256) void kuu_bwd_kernel(const double* __restrict__ Z, int64_t ldz, KernArgs ka,
+                                                      const double* __restrict__ Kb, int M,
+                                                      double* __restrict__ part, double* __restrict__ gzraw) {
+  __shared__ double red[4];
+  const int m = blockIdx.x;
+  const int d = ka.d;
+  constexpr int MAXC = SGP_MAX_INDUCING / 256;
+  double E[MAXC], KK[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int mp = c * 256 + threadIdx.x;
+    E[c] = 0.0;
+    KK[c] = 0.0;
+    if (mp < M) {
+      double r2 = 0.0;
+      for (int q = 0; q < d; ++q) {
+        const double df = (Z[m * ldz + q] - Z[mp * ldz + q]) * ka.inv_ls[q];
+        r2 = fma(df, df, r2);
+      }
+      double kp, hp;
+      kprofile_grad<KID>(r2, kp, hp);
+      const double kb = Kb[(int64_t)m * M + mp];
+      E[c] = kb * ka.sf2 * hp;
+      KK[c] = kb * kp;
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) s += KK[c];
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) part[(size_t)m * (d + 1) + d] = s;
+  for (int q = 0; q < d; ++q) {
+    double s2 = 0.0, s1 = 0.0;
+    const double zm = Z[m * ldz + q];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int mp = c * 256 + threadIdx.x;
+      if (mp < M) {
+        const double df = (zm - Z[mp * ldz + q]) * ka.inv_ls[q];
+        s1 = fma(E[c], df, s1);
+        s2 = fma(E[c] * df, df, s2);
+      }
+    }
+    s2 = block_sum256(s2, red);
+    s1 = block_sum256(s1, red);
+    if (threadIdx.x == 0) {
+      part[(size_t)m * (d + 1) + q] = s2;
+      gzraw[(size_t)m * d + q] = s1;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __restrict__ part, const double* __restrict__ gzraw,
+                                                             int M, KernArgs ka, double* g_ls, double* g_sf2, double* g_Z) {
+  const int d = ka.d;
+  if (blockIdx.x == 0 && (int)threadIdx.x <= d) {
+    const int q = threadIdx.x;
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s += part[(size_t)m * (d + 1) + q];
+    if (q == d) *g_sf2 += s;
+    else g_ls[q] += -2.0 * ka.inv_ls[q] * s;
+  }
+  if (g_Z) {
+    const int64_t total = (int64_t)M * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+      const int q = (int)(e % d);
+      // d r2[m][m'] / d z_mq = 2 diff inv_ls ; row m and column m of the symmetric Kuubar both contribute
+      g_Z[e] += 4.0 * ka.inv_ls[q] * gzraw[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small kernels of the tail
+// ---------------------------------------------------------------------------------------------
+// Bm = I + W / s2 (full matrix) ; sc[SC_TRW] = tr W
+enum { SC_TRW = 0, SC_LOGDET = 1, SC_QQ = 2, SC_TRSP = 3, SC_BA = 4, SC_APA = 5, SC_N = 8 };
+
+__global__ __launch_bounds__(256) void make_B_kernel(const double* __restrict__ W, int Mp, double inv_s2, double* __restrict__ Bm) {
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    // symmetrise: the two triangles of L^-1 Phi L^-T differ by rounding only
+    const double w = 0.5 * (W[e] + W[(int64_t)c * Mp + r]);
+    Bm[e] = (r == c ? 1.0 : 0.0) + w * inv_s2;
+  }
+}
+__global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict__ A, int Mp, int take_log, double scale, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < Mp; i += 256) {
+    const double v = A[(int64_t)i * Mp + i];
+    s += take_log ? log(v) : v;
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) *out = s * scale;
+}
+__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, const double* __restrict__ b, int n, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s = fma(a[i], b[i], s);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) *out = s;
+}
+// partial[block] = sum over a slice of A o B ; fixed grid of 256 blocks, second stage = sum256_kernel
+__global__ __launch_bounds__(256) void frob_partial_kernel(const double* __restrict__ A, const double* __restrict__ B, int64_t n,
+                                                           double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fma(A[i], B[i], s);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum256_kernel(const double* __restrict__ partial, double* out) {
+  __shared__ double red[4];
+  double s = block_sum256(partial[threadIdx.x], red);
+  if (threadIdx.x == 0) *out = s;
+}
+
+__global__ void finalize_bound_kernel(const double* __restrict__ sc, const double* __restrict__ yy, const double* __restrict__ kappa,
+                                      double s2, double Nd, int with_adj, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double LOG2PI = 1.8378770664093453;
+  const double trW = sc[SC_TRW], logdetB = sc[SC_LOGDET], qq = sc[SC_QQ];
+  const double quad = *yy / s2 - qq / (s2 * s2);
+  const double logmarg = -(0.5 * Nd * LOG2PI + 0.5 * Nd * log(s2) + 0.5 * logdetB + 0.5 * quad);
+  const double trace_term = (*kappa - trW) / (2.0 * s2);
+  out[SGP_OUT_F] = logmarg - trace_term;
+  out[SGP_OUT_LOGMARG] = logmarg;
+  out[SGP_OUT_TRACE] = trace_term;
+  out[SGP_OUT_LOGDETB] = logdetB;
+  out[SGP_OUT_QUAD] = quad;
+  out[SGP_OUT_TRW] = trW;
+  if (with_adj) {
+    const double trSP = sc[SC_TRSP], ba = sc[SC_BA], aPa = sc[SC_APA];
+    const double s22 = s2 * s2;
+    out[SGP_OUT_S2BAR] = -0.5 * (-trSP / s22 + Nd / s2 - *yy / s22 + 2.0 * ba / (s22 * s2) - aPa / (s22 * s22)
+                                 - *kappa / s22 + trW / s22);
+    out[SGP_OUT_KAPPABAR] = -1.0 / (2.0 * s2);
+  } else {
+    out[SGP_OUT_S2BAR] = 0.0;
+    out[SGP_OUT_KAPPABAR] = 0.0;
+  }
+}
+
+// Phibar = (Kinv - Sinv - a a^T / s2^2) / (2 s2)
+// Kuubar = -1/2 (Sinv + a a^T / s2^2 - Kinv + KPK / s2)        (cropped to M x M, ld M)
+__global__ __launch_bounds__(256) void adjoint_out_kernel(const double* __restrict__ Kinv, const double* __restrict__ Sinv,
+                                                          const double* __restrict__ KPK, const double* __restrict__ alpha,
+                                                          int Mp, int M, double s2, double* __restrict__ Phibar,
+                                                          double* __restrict__ Kuubar, double* __restrict__ bbar) {
+  const int64_t total = (int64_t)M * M;
+  const double is22 = 1.0 / (s2 * s2);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+    const int64_t p = (int64_t)r * Mp + c, pt = (int64_t)c * Mp + r;
+    const double ki = 0.5 * (Kinv[p] + Kinv[pt]);
+    const double si = 0.5 * (Sinv[p] + Sinv[pt]);
+    const double kp = 0.5 * (KPK[p] + KPK[pt]);
+    const double aa = alpha[r] * alpha[c] * is22;
+    Phibar[e] = (ki - si - aa) / (2.0 * s2);
+    Kuubar[e] = -0.5 * (si + aa - ki + kp / s2);
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < M; i += 256) bbar[i] = alpha[i] * is22;
+}
+
+// ---------------------------------------------------------------------------------------------
+// predictive helpers
+// ---------------------------------------------------------------------------------------------
+// Ks[m][t] = sf2 k'(z_m, xs_t) for m < M, t < T (zero in the padding); Mp x Tp, ld Tp
+template <int KID>
+__global__ __launch_bounds__(256) void kus_kernel(const double* __restrict__ Z, int64_t ldz, const double* __restrict__ Xs,
+                                                  int64_t ldxs, KernArgs ka, int M, int Mp, int T, int Tp,
+                                                  double* __restrict__ Ks) {
+  const int64_t total = (int64_t)Mp * Tp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / Tp), t = (int)(e - (int64_t)m * Tp);
+    double v = 0.0;
+    if (m < M && t < T) {
+      double r2 = 0.0;
+      for (int q = 0; q < ka.d; ++q) {
+        const double df = (Z[m * ldz + q] - Xs[t * ldxs + q]) * ka.inv_ls[q];
+        r2 = fma(df, df, r2);
+      }
+      v = ka.sf2 * kprofile<KID>(r2);
+    }
+    Ks[e] = v;
+  }
+}
+// mean[t] = sum_m C[m][t] q[m] / s2 ; var[t] = sf2 - sum As^2 + sum C^2 (+ s2)
+__global__ __launch_bounds__(256) void pred_cols_kernel(const double* __restrict__ As, const double* __restrict__ Cm,
+                                                        const double* __restrict__ q, int Mp, int Tp, int T, double sf2,
+                                                        double s2, int pred_noise, double* __restrict__ mean,
+                                                        double* __restrict__ var) {
+  __shared__ double pm[4][64], pa[4][64], pc[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  double sm = 0.0, sa = 0.0, scc = 0.0;
+  for (int m = w; m < Mp; m += 4) {
+    const double a = As[(int64_t)m * Tp + col], c = Cm[(int64_t)m * Tp + col];
+    sm = fma(c, q[m], sm);
+    sa = fma(a, a, sa);
+    scc = fma(c, c, scc);
+  }
+  pm[w][threadIdx.x & 63] = sm;
+  pa[w][threadIdx.x & 63] = sa;
+  pc[w][threadIdx.x & 63] = scc;
+  __syncthreads();
+  if (w == 0 && col < T) {
+    const int l = threadIdx.x;
+    mean[col] = (pm[0][l] + pm[1][l] + pm[2][l] + pm[3][l]) / s2;
+    if (var)
+      var[col] = sf2 - (pa[0][l] + pa[1][l] + pa[2][l] + pa[3][l]) + (pc[0][l] + pc[1][l] + pc[2][l] + pc[3][l]) +
+                 (pred_noise ? s2 : 0.0);
+  }
+}
+// cov[t][t'] = k(xs_t, xs_t') - AtA[t][t'] + CtC[t][t'] (+ s2 on the diagonal)
+template <int KID>
+__global__ __launch_bounds__(256) void pred_cov_kernel(const double* __restrict__ Xs, int64_t ldxs, KernArgs ka,
+                                                       const double* __restrict__ AtA, const double* __restrict__ CtC,
+                                                       int Tp, int T, double s2, int pred_noise, double* __restrict__ cov) {
+  const int64_t total = (int64_t)T * T;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int a = (int)(e / T), b = (int)(e - (int64_t)a * T);
+    double r2 = 0.0;
+    for (int q = 0; q < ka.d; ++q) {
+      const double df = (Xs[a * ldxs + q] - Xs[b * ldxs + q]) * ka.inv_ls[q];
+      r2 = fma(df, df, r2);
+    }
+    const int64_t p = (int64_t)a * Tp + b, pt = (int64_t)b * Tp + a;
+    double v = ka.sf2 * kprofile<KID>(r2) - 0.5 * (AtA[p] + AtA[pt]) + 0.5 * (CtC[p] + CtC[pt]);
+    if (a == b && pred_noise) v += s2;
+    cov[e] = v;
+  }
+}
+
+static KernArgs make_ka(const double* inv_ls, double sf2, int d) {
+  KernArgs ka;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  ka.sf2 = sf2;
+  ka.d = d;
+  return ka;
+}
+static int grid_for(int64_t total, int cap = 2048) {
+  int64_t g = (total + 255) / 256;
+  if (g < 1) g = 1;
+  return (int)(g < cap ? g : cap);
+}
+
+struct BoundWs {
+  double *M0, *M1, *M2, *M3, *M4, *M5, *M6, *M7, *M8;
+  double *bp, *u, *q, *alpha, *t1, *sc, *partial;
+  size_t bytes;
+};
+static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
+  Carver c(ws);
+  BoundWs w;
+  const size_t mm = (size_t)Mp * Mp;
+  w.M0 = c.take<double>(mm);
+  w.M1 = c.take<double>(mm);
+  w.M2 = c.take<double>(mm);
+  w.M3 = c.take<double>(mm);
+  w.M4 = c.take<double>(mm);
+  w.M5 = c.take<double>(mm);
+  w.M6 = c.take<double>(mm);
+  w.M7 = c.take<double>(mm);
+  w.M8 = with_adj ? c.take<double>(mm) : nullptr;
+  w.bp = c.take<double>(Mp);
+  w.u = c.take<double>(Mp);
+  w.q = c.take<double>(Mp);
+  w.alpha = c.take<double>(Mp);
+  w.t1 = c.take<double>(Mp);
+  w.sc = c.take<double>(SC_N);
+  w.partial = c.take<double>(256);
+  w.bytes = c.used();
+  return w;
+}
+
+}  // namespace sgp
+
+using namespace sgp;
+
+extern "C" int sgp_abi_version(void) { return SGP_ABI_VERSION; }
+
+extern "C" const char* sgp_status_string(int status) {
+  switch (status) {
+    case SGP_OK: return "ok";
+    case SGP_ERR_ARG: return "invalid argument (null pointer, non-positive size or unknown kernel_id)";
+    case SGP_ERR_DIM: return "dimension out of range (d > SGP_MAX_DIM or M > SGP_MAX_INDUCING)";
+    case SGP_ERR_WORKSPACE: return "workspace missing or too small";
+    case SGP_ERR_LAUNCH: return "HIP launch failed";
+    default: return status > 0 ? "matrix not positive definite (LAPACK-style pivot index)" : "unknown status";
+  }
+}
+
+extern "C" int sgp_kuu(const double* Z, int64_t ldz, const double* inv_ls, double sf2, double jitter, int M, int d,
+                       int kernel_id, double* Kuu, sgp_stream_t stream) {
+  if (!Z || !inv_ls || !Kuu || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  hipStream_t st = (hipStream_t)stream;
+  const KernArgs ka = make_ka(inv_ls, sf2, d);
+  const int g = grid_for((int64_t)M * M);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: kuu_kernel<SGP_KERNEL_RBF><<<g, 256, 0, st>>>(Z, ldz, ka, jitter, M, Kuu); break;
+    case SGP_KERNEL_MATERN32: kuu_kernel<SGP_KERNEL_MATERN32><<<g, 256, 0, st>>>(Z, ldz, ka, jitter, M, Kuu); break;
+    default: kuu_kernel<SGP_KERNEL_MATERN52><<<g, 256, 0, st>>>(Z, ldz, ka, jitter, M, Kuu); break;
+  }
+  return check_launch();
+}
+
+extern "C" size_t sgp_kuu_bwd_workspace_bytes(int M, int d) {
+  if (M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  Carver c(nullptr);
+  c.take<double>((size_t)M * (d + 1));
+  c.take<double>((size_t)M * d);
+  return c.used();
+}
+
+extern "C" int sgp_kuu_bwd(const double* Z, int64_t ldz, const double* inv_ls, double sf2, const double* Kuubar, int M,
+                           int d, int kernel_id, double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
+                           sgp_stream_t stream) {
+  if (!Z || !inv_ls || !Kuubar || !g_ls || !g_sf2 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (!ws || ws_bytes < sgp_kuu_bwd_workspace_bytes(M, d)) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  Carver c(ws);
+  double* part = c.take<double>((size_t)M * (d + 1));
+  double* gzraw = c.take<double>((size_t)M * d);
+  const KernArgs ka = make_ka(inv_ls, sf2, d);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: kuu_bwd_kernel<SGP_KERNEL_RBF><<<M, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part, gzraw); break;
+    case SGP_KERNEL_MATERN32: kuu_bwd_kernel<SGP_KERNEL_MATERN32><<<M, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part, gzraw); break;
+    default: kuu_bwd_kernel<SGP_KERNEL_MATERN52><<<M, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part, gzraw); break;
+  }
+  kuu_bwd_reduce_kernel<<<grid_for((int64_t)M * d, 256), 256, 0, st>>>(part, gzraw, M, ka, g_ls, g_sf2, g_Z);
+  return check_launch();
+}
+
+extern "C" size_t sgp_bound_workspace_bytes(int M, int with_adjoints) {
+  (void)with_adjoints;  // one size for both modes: `factors` needs G as well
+  if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  return carve_bound(nullptr, padded_m(M), 1).bytes;
+}
+extern "C" size_t sgp_bound_factors_len(int M) { return M > 0 ? (size_t)2 * M * M + M : 0; }
+
+extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b, const double* yy,
+                                    const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
+                                    double* Phibar, double* bbar, double* Kuubar, double* factors, int* info, void* ws,
+                                    size_t ws_bytes, sgp_stream_t stream) {
+  if (!Kuu || !Phi || !b || !yy || !kappa || !out || !info || M <= 0 || N < 0 || !(s2 > 0.0)) return SGP_ERR_ARG;
+  if (with_adjoints && (!Phibar || !bbar || !Kuubar)) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  const int Mp = padded_m(M);
+  BoundWs w = carve_bound(ws, Mp, 1);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ld = Mp;
+  const size_t mm = (size_t)Mp * Mp;
+  const bool need_G = with_adjoints || factors;
+
+  hipMemsetAsync(info, 0, sizeof(int), st);
+  fill_zero(w.sc, SC_N, st);
+
+  // L = chol(Kuu) in M0, L^-1 in M1
+  pad_copy(Kuu, M, M, M, w.M0, ld, Mp, Mp, 1.0, st);
+  potrf_lower(w.M0, w.M1, ld, Mp, info, 0, st);
+  tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
+
+  // W = L^-1 Phi L^-T in M5 (V in M4)
+  pad_copy(Phi, M, M, M, w.M3, ld, Mp, Mp, 0.0, st);
+  {
+    GemmDesc g;
+    g.A = w.M1; g.lda = ld; g.B = w.M3; g.ldb = ld; g.C = w.M4; g.ldc = ld;
+    g.m = Mp; g.n = Mp; g.k = Mp; g.khi_mask = 1;
+    gemm(g, st);
+    GemmDesc h;
+    h.A = w.M4; h.lda = ld; h.B = w.M1; h.ldb = ld; h.tb = true; h.C = w.M5; h.ldc = ld;
+    h.m = Mp; h.n = Mp; h.k = Mp; h.khi_mask = 2;
+    gemm(h, st);
+  }
+  diag_sum_kernel<<<1, 256, 0, st>>>(w.M5, Mp, 0, 1.0, w.sc + SC_TRW);
+
+  // B = I + W/s2 in M6 -> LB ; LB^-1 in M7
+  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6);
+  potrf_lower(w.M6, w.M7, ld, Mp, info, M, st);
+  diag_sum_kernel<<<1, 256, 0, st>>>(w.M6, Mp, 1, 2.0, w.sc + SC_LOGDET);
+  tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
+
+  // q = LB^-1 L^-1 b
+  pad_copy(b, 1, M, 1, w.bp, 1, Mp, 1, 0.0, st);
+  gemv(w.M1, ld, Mp, false, w.bp, w.u, st);
+  gemv(w.M7, ld, Mp, false, w.u, w.q, st);
+  dot_kernel<<<1, 256, 0, st>>>(w.q, w.q, Mp, w.sc + SC_QQ);
+
+  if (need_G) {
+    // G = LB^-1 L^-1 in M4 (both lower triangular)
+    GemmDesc g;
+    g.A = w.M7; g.lda = ld; g.B = w.M1; g.ldb = ld; g.C = w.M4; g.ldc = ld;
+    g.m = Mp; g.n = Mp; g.k = Mp; g.khi_mask = 1; g.klo_mask = 2;
+    gemm(g, st);
+  }
+  if (factors) {
+    crop_copy(w.M1, ld, factors, M, M, M, st);
+    crop_copy(w.M4, ld, factors + (size_t)M * M, M, M, M, st);
+    crop_copy(w.q, 1, factors + (size_t)2 * M * M, 1, M, 1, st);
+  }
+  if (with_adjoints) {
+    // alpha = Sigma^-1 b = G^T q
+    gemv(w.M4, ld, Mp, true, w.q, w.alpha, st);
+    // Sinv = G^T G in M2 ; Kinv = L^-T L^-1 in M0
+    GemmDesc s;
+    s.A = w.M4; s.lda = ld; s.ta = true; s.B = w.M4; s.ldb = ld; s.C = w.M2; s.ldc = ld;
+    s.m = Mp; s.n = Mp; s.k = Mp; s.klo_mask = 3;
+    gemm(s, st);
+    GemmDesc k;
+    k.A = w.M1; k.lda = ld; k.ta = true; k.B = w.M1; k.ldb = ld; k.C = w.M0; k.ldc = ld;
+    k.m = Mp; k.n = Mp; k.k = Mp; k.klo_mask = 3;
+    gemm(k, st);
+    // KPK = Kinv Phi Kinv = L^-T W L^-1 : T1 = W L^-1 in M6, KPK = L^-T T1 in M8
+    GemmDesc t1;
+    t1.A = w.M5; t1.lda = ld; t1.B = w.M1; t1.ldb = ld; t1.C = w.M6; t1.ldc = ld;
+    t1.m = Mp; t1.n = Mp; t1.k = Mp; t1.klo_mask = 2;
+    gemm(t1, st);
+    GemmDesc t2;
+    t2.A = w.M1; t2.lda = ld; t2.ta = true; t2.B = w.M6; t2.ldb = ld; t2.C = w.M8; t2.ldc = ld;
+    t2.m = Mp; t2.n = Mp; t2.k = Mp; t2.klo_mask = 1;
+    gemm(t2, st);
+    // scalars for s2bar: tr(Sinv Phi), b.alpha, alpha^T Phi alpha
+    frob_partial_kernel<<<256, 256, 0, st>>>(w.M2, w.M3, (int64_t)mm, w.partial);
+    sum256_kernel<<<1, 256, 0, st>>>(w.partial, w.sc + SC_TRSP);
+    dot_kernel<<<1, 256, 0, st>>>(w.bp, w.alpha, Mp, w.sc + SC_BA);
+    gemv(w.M3, ld, Mp, false, w.alpha, w.t1, st);
+    dot_kernel<<<1, 256, 0, st>>>(w.t1, w.alpha, Mp, w.sc + SC_APA);
+    adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(w.M0, w.M2, w.M8, w.alpha, Mp, M, s2, Phibar, Kuubar, bbar);
+  }
+  finalize_bound_kernel<<<1, 64, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, out);
+  return check_launch();
+}
+
+extern "C" size_t sgp_predict_workspace_bytes(int64_t T, int M, int d, int want_cov) {
+  if (T <= 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = padded_m(M);
+  const size_t Tc = want_cov ? (size_t)round_up64(T, 64) : (size_t)(T < 16384 ? round_up64(T, 64) : 16384);
+  Carver c(nullptr);
+  c.take<double>(Mp * Mp);
+  c.take<double>(Mp * Mp);
+  c.take<double>(Mp);
+  c.take<double>(Mp * Tc);
+  c.take<double>(Mp * Tc);
+  c.take<double>(Mp * Tc);
+  if (want_cov) {
+    c.take<double>(Tc * Tc);
+    c.take<double>(Tc * Tc);
+  }
+  return c.used();
+}
+
+extern "C" int sgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, const double* inv_ls,
+                           double sf2, double s2, const double* factors, int M, int d, int kernel_id, int pred_noise,
+                           double* mean, double* var, double* cov, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!Xs || !Z || !inv_ls || !factors || !mean || T <= 0 || M <= 0 || d <= 0 || ldxs < d || ldz < d) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  const int want_cov = cov != nullptr;
+  if (want_cov && T > 32768) return SGP_ERR_DIM;
+  if (!ws || ws_bytes < sgp_predict_workspace_bytes(T, M, d, want_cov)) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mp = padded_m(M);
+  const int64_t Tc = want_cov ? round_up64(T, 64) : (T < 16384 ? round_up64(T, 64) : 16384);
+  Carver c(ws);
+  double* Li = c.take<double>((size_t)Mp * Mp);
+  double* G = c.take<double>((size_t)Mp * Mp);
+  double* q = c.take<double>(Mp);
+  double* Ks = c.take<double>((size_t)Mp * Tc);
+  double* As = c.take<double>((size_t)Mp * Tc);
+  double* Cm = c.take<double>((size_t)Mp * Tc);
+  double *AtA = nullptr, *CtC = nullptr;
+  if (want_cov) {
+    AtA = c.take<double>((size_t)Tc * Tc);
+    CtC = c.take<double>((size_t)Tc * Tc);
+  }
+  const KernArgs ka = make_ka(inv_ls, sf2, d);
+  pad_copy(factors, M, M, M, Li, Mp, Mp, Mp, 1.0, st);
+  pad_copy(factors + (size_t)M * M, M, M, M, G, Mp, Mp, Mp, 1.0, st);
+  pad_copy(factors + (size_t)2 * M * M, 1, M, 1, q, 1, Mp, 1, 0.0, st);
+
+  for (int64_t t0 = 0; t0 < T; t0 += Tc) {
+    const int Tn = (int)((T - t0) < Tc ? (T - t0) : Tc);
+    const int Tp = (int)round_up64(Tn, 64);
+    const double* xs = Xs + t0 * ldxs;
+    const int g = grid_for((int64_t)Mp * Tp);
+    switch (kernel_id) {
+      case SGP_KERNEL_RBF: kus_kernel<SGP_KERNEL_RBF><<<g, 256, 0, st>>>(Z, ldz, xs, ldxs, ka, M, Mp, Tn, Tp, Ks); break;
+      case SGP_KERNEL_MATERN32: kus_kernel<SGP_KERNEL_MATERN32><<<g, 256, 0, st>>>(Z, ldz, xs, ldxs, ka, M, Mp, Tn, Tp, Ks); break;
+      default: kus_kernel<SGP_KERNEL_MATERN52><<<g, 256, 0, st>>>(Z, ldz, xs, ldxs, ka, M, Mp, Tn, Tp, Ks); break;
+    }
+    GemmDesc a;
+    a.A = Li; a.lda = Mp; a.B = Ks; a.ldb = Tp; a.C = As; a.ldc = Tp;
+    a.m = Mp; a.n = Tp; a.k = Mp; a.khi_mask = 1;
+    gemm(a, st);
+    GemmDesc b;
+    b.A = G; b.lda = Mp; b.B = Ks; b.ldb = Tp; b.C = Cm; b.ldc = Tp;
+    b.m = Mp; b.n = Tp; b.k = Mp; b.khi_mask = 1;
+    gemm(b, st);
+    pred_cols_kernel<<<Tp / 64, 256, 0, st>>>(As, Cm, q, Mp, Tp, Tn, sf2, s2, pred_noise, mean + t0, var ? var + t0 : nullptr);
+    if (want_cov) {
+      GemmDesc x;
+      x.A = As; x.lda = Tp; x.ta = true; x.B = As; x.ldb = Tp; x.C = AtA; x.ldc = Tp;
+      x.m = Tp; x.n = Tp; x.k = Mp;
+      gemm(x, st);
+      GemmDesc y;
+      y.A = Cm; y.lda = Tp; y.ta = true; y.B = Cm; y.ldb = Tp; y.C = CtC; y.ldc = Tp;
+      y.m = Tp; y.n = Tp; y.k = Mp;
+      gemm(y, st);
+      const int gc = grid_for((int64_t)Tn * Tn);
+      switch (kernel_id) {
+        case SGP_KERNEL_RBF: pred_cov_kernel<SGP_KERNEL_RBF><<<gc, 256, 0, st>>>(xs, ldxs, ka, AtA, CtC, Tp, Tn, s2, pred_noise, cov); break;
+        case SGP_KERNEL_MATERN32: pred_cov_kernel<SGP_KERNEL_MATERN32><<<gc, 256, 0, st>>>(xs, ldxs, ka, AtA, CtC, Tp, Tn, s2, pred_noise, cov); break;
+        default: pred_cov_kernel<SGP_KERNEL_MATERN52><<<gc, 256, 0, st>>>(xs, ldxs, ka, AtA, CtC, Tp, Tn, s2, pred_noise, cov); break;
+      }
+    }
+  }
+  return check_launch();
+}

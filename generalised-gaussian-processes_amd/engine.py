@@ -1,0 +1,207 @@
+"""HipEngine: torch-tensor front end of the C ABI (include/sgp.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and (in ``core``) the
+RCCL process group.  All arithmetic happens inside libsgp_hip.so.  Every method takes / returns
+fp64 CUDA(=HIP) tensors; hyper-parameters are host floats (they travel as kernel arguments).
+
+The engine interface (``suffstats`` / ``bound`` / ``suffstats_bwd`` / ``kuu_bwd`` / ``predict``) is
+the seam the CPU-only tests use to exercise the host logic above it with a test double; the product
+constructs ``HipEngine`` and nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import KERNEL_IDS, OUT_LEN
+
+
+def _kernel_id(kernel) -> int:
+    if isinstance(kernel, int):
+        if kernel not in (0, 1, 2):
+            raise ValueError("unknown kernel id %r" % (kernel,))
+        return kernel
+    try:
+        return KERNEL_IDS[str(kernel).lower()]
+    except KeyError:
+        raise ValueError("unknown kernel %r (expected one of %s)" % (kernel, sorted(KERNEL_IDS))) from None
+
+
+class HipEngine:
+    """Calls the HIP library on ``device`` (default: current CUDA device).  No CPU fallback."""
+
+    def __init__(self, device: Optional[torch.device] = None):
+        self.lib = _lib.load_library()
+        if not torch.cuda.is_available():
+            raise _lib.SgpLibraryError("HipEngine needs a HIP device (torch.cuda.is_available() is False); "
+                                       "there is no CPU implementation of the sparse-GP core")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, name: str, nbytes: int) -> torch.Tensor:
+        buf = self._ws.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[name] = buf
+        return buf
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        if t.dtype != torch.float64 or t.device != self.device or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous float64 tensor on %s (got %s, %s)" % (name, self.device, t.dtype, t.device))
+        return t
+
+    @staticmethod
+    def _inv_ls(ls: Sequence[float], d: int):
+        vals = [float(v) for v in (ls.tolist() if hasattr(ls, "tolist") else ls)]
+        if len(vals) == 1 and d > 1:
+            vals = vals * d
+        if len(vals) != d:
+            raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), d))
+        return (C.c_double * d)(*[1.0 / v for v in vals])
+
+    @staticmethod
+    def _ptr(t: Optional[torch.Tensor]):
+        return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ pass 1
+    def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Packed local statistics [Phi (M*M) | b (M) | yy | kappa] -- the buffer the all-reduce sums."""
+        N, d = X.shape
+        M = Z.shape[0]
+        self._chk(Z, "Z")
+        if N > 0:
+            self._chk(X, "X"), self._chk(y, "y")
+        if out is None:
+            out = self.empty(M * M + M + 2)
+        nbytes = self.lib.sgp_suffstats_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("unsupported shape N=%d M=%d d=%d (d <= %d, M <= %d)" % (N, M, d, _lib.SGP_MAX_DIM, _lib.SGP_MAX_INDUCING))
+        ws = self._workspace("fwd", nbytes)
+        base = out.data_ptr()
+        st = self.lib.sgp_suffstats_fwd(
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), N, M, d, _kernel_id(kernel),
+            C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_suffstats_fwd", st)
+        return out
+
+    def kuu(self, Z, ls, sf2, jitter, kernel="rbf") -> torch.Tensor:
+        M, d = Z.shape
+        self._chk(Z, "Z")
+        K = self.empty(M, M)
+        st = self.lib.sgp_kuu(self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(jitter), M, d, _kernel_id(kernel),
+                              self._ptr(K), self._stream())
+        _lib.check("sgp_kuu", st)
+        return K
+
+    # ------------------------------------------------------------------ tail
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False):
+        """Runs the O(M^3) tail on (already all-reduced) packed statistics.
+
+        Returns dict(out=[8] device tensor, info=int32 device tensor, and when asked Phibar, bbar,
+        Kuubar, factors).  Nothing is synchronised.
+        """
+        M = Kuu.shape[0]
+        self._chk(Kuu, "Kuu"), self._chk(packed, "packed")
+        out = self.empty(OUT_LEN)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        res = {"out": out, "info": info}
+        Phibar = bbar = Kuubar = factors = None
+        if with_adjoints:
+            Phibar, bbar, Kuubar = self.empty(M, M), self.empty(M), self.empty(M, M)
+            res.update(Phibar=Phibar, bbar=bbar, Kuubar=Kuubar)
+        if want_factors:
+            factors = self.empty(self.lib.sgp_bound_factors_len(M))
+            res["factors"] = factors
+        nbytes = self.lib.sgp_bound_workspace_bytes(M, 1 if with_adjoints else 0)
+        ws = self._workspace("bound", nbytes)
+        base = packed.data_ptr()
+        st = self.lib.sgp_bound_from_stats(
+            self._ptr(Kuu), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+            C.c_void_p(base + 8 * (M * M + M + 1)), float(s2), int(N), M, 1 if with_adjoints else 0, self._ptr(out),
+            self._ptr(Phibar), self._ptr(bbar), self._ptr(Kuubar), self._ptr(factors), self._ptr(info),
+            self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_bound_from_stats", st)
+        return res
+
+    # ------------------------------------------------------------------ pass 2
+    def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Packed local gradients [g_ls (d) | g_sf2 | g_Z (M*d, only when want_gz)]."""
+        N, d = X.shape
+        M = Z.shape[0]
+        if out is None:
+            out = self.empty(d + 1 + (M * d if want_gz else 0))
+        nbytes = self.lib.sgp_suffstats_bwd_workspace_bytes(N, M, d)
+        ws = self._workspace("bwd", nbytes)
+        base = out.data_ptr()
+        st = self.lib.sgp_suffstats_bwd(
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), self._ptr(Phibar),
+            self._ptr(bbar), float(kappabar), N, M, d, _kernel_id(kernel), C.c_void_p(base), C.c_void_p(base + 8 * d),
+            C.c_void_p(base + 8 * (d + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_suffstats_bwd", st)
+        return out
+
+    def kuu_bwd(self, Z, ls, sf2, Kuubar, grads: torch.Tensor, kernel="rbf", want_gz=False) -> torch.Tensor:
+        """Adds the Kuu path into the packed gradient buffer produced by ``suffstats_bwd``."""
+        M, d = Z.shape
+        nbytes = self.lib.sgp_kuu_bwd_workspace_bytes(M, d)
+        ws = self._workspace("kuu_bwd", nbytes)
+        base = grads.data_ptr()
+        st = self.lib.sgp_kuu_bwd(
+            self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), self._ptr(Kuubar), M, d, _kernel_id(kernel),
+            C.c_void_p(base), C.c_void_p(base + 8 * d), C.c_void_p(base + 8 * (d + 1)) if want_gz else C.c_void_p(0),
+            self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_kuu_bwd", st)
+        return grads
+
+    # ------------------------------------------------------------------ predictive
+    def predict(self, Xs, Z, ls, sf2, s2, factors, kernel="rbf", pred_noise=True, full_cov=False):
+        T, d = Xs.shape
+        M = Z.shape[0]
+        self._chk(Xs, "Xs"), self._chk(factors, "factors")
+        mean, var = self.empty(T), self.empty(T)
+        cov = self.empty(T, T) if full_cov else None
+        nbytes = self.lib.sgp_predict_workspace_bytes(T, M, d, 1 if full_cov else 0)
+        ws = self._workspace("predict", nbytes)
+        st = self.lib.sgp_predict(
+            self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(s2), self._ptr(factors), M, d,
+            _kernel_id(kernel), 1 if pred_noise else 0, self._ptr(mean), self._ptr(var), self._ptr(cov),
+            self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_predict", st)
+        return mean, var, cov
+
+    # ------------------------------------------------------------------ stand-alone M x M entry points
+    def chol_lower(self, A: torch.Tensor):
+        M = A.shape[0]
+        A = A.clone().contiguous()
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = self._workspace("chol", self.lib.sgp_chol_workspace_bytes(M))
+        st = self.lib.sgp_chol_lower(self._ptr(A), M, M, self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_chol_lower", st)
+        return A, info
+
+    def trsm_lower(self, L: torch.Tensor, B: torch.Tensor, trans=False):
+        M, k = B.shape
+        B = B.clone().contiguous()
+        ws = self._workspace("trsm", self.lib.sgp_trsm_workspace_bytes(M, k))
+        st = self.lib.sgp_trsm_lower(self._ptr(L), M, self._ptr(B), k, 1 if trans else 0, M, k, self._ptr(ws), ws.numel(),
+                                     self._stream())
+        _lib.check("sgp_trsm_lower", st)
+        return B
+
+    def logdiag_sum(self, L: torch.Tensor):
+        out = self.empty(1)
+        st = self.lib.sgp_logdiag_sum(self._ptr(L), L.shape[1], L.shape[0], self._ptr(out), self._stream())
+        _lib.check("sgp_logdiag_sum", st)
+        return out

@@ -1,0 +1,148 @@
+/*
+ * sgp.h -- C ABI of the MI355X-native sparse-GP inference core (libsgp_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of vr308/Generalised-Gaussian-Processes: the
+ * collapsed (Titsias / VFE) sparse-GP bound that the reference re-evaluates on every SGPR Adam
+ * step and every HMC/NUTS leapfrog.  The reference has no FFI of its own for this path; the seam
+ * it replaces is the set of library calls below (paths relative to the reference repo root):
+ *
+ *   ScaleKernel(RBFKernel(ard_num_dims=d))(X, Z)          models/sgpr.py:36   models/bayesian_sgpr_hmc.py:41
+ *   sig_f**2 * pm.gp.cov.ExpQuad(input_dim, ls=ls)         models/bayesian_sgpr_hmc.py:65
+ *   InducingPointKernel(base, inducing_points=Z, lik)     models/sgpr.py:37   models/bayesian_sgpr_hmc.py:42
+ *   ExactMarginalLogLikelihood(lik, model)(output, y)     models/sgpr.py:114,125  models/bayesian_sgpr_hmc.py:92,111,130
+ *   pm.gp.MarginalSparse(approx="VFE").marginal_likelihood models/bayesian_sgpr_hmc.py:66,71
+ *   likelihood(model(test_x))  (posterior predictive)     models/sgpr.py:150-160  models/bayesian_sgpr_hmc.py:186-231
+ *
+ * Conventions
+ *   - every pointer named X, y, Z, Phi, ... is a DEVICE pointer to fp64 data (row-major, leading
+ *     dimension given in elements); `inv_ls` is a HOST pointer to d doubles (1/lengthscale_j);
+ *     scalars sf2 (= outputscale = sig_f^2), s2 (= noise = sig_n^2), jitter are passed by value.
+ *   - the caller owns every buffer.  The library never allocates or frees user-visible memory;
+ *     scratch comes from `ws` whose size the matching *_workspace_bytes() query returns.
+ *   - every call is asynchronous on `stream` (a hipStream_t; NULL = default stream).  Nothing is
+ *     synchronised, no host copies are made: results (including `info`) stay on the device.
+ *   - return value: 0 = launched; <0 = rejected before any launch (SGP_ERR_*).  Numerical failure
+ *     (non-positive Cholesky pivot) is reported LAPACK-style through the device int `*info`:
+ *     0 = ok, k>0 = leading minor of order k is not positive definite (1..M refer to Kuu,
+ *     M+1..2M to B = I + L^-1 Phi L^-T / s2).  No exceptions cross the boundary.
+ *   - kernel_id selects k(x,z): SGP_KERNEL_RBF     sf2 * exp(-r2/2)
+ *                               SGP_KERNEL_MATERN32 sf2 * (1+sqrt3 r) exp(-sqrt3 r)
+ *                               SGP_KERNEL_MATERN52 sf2 * (1+sqrt5 r+5r2/3) exp(-sqrt5 r)
+ *     with r2 = sum_j ((x_j - z_j) * inv_ls_j)^2.
+ */
+#ifndef SGP_H
+#define SGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sgp_stream_t; /* hipStream_t */
+
+#define SGP_ABI_VERSION 1
+#define SGP_MAX_DIM 32          /* largest input dimension d the streaming kernels accept */
+#define SGP_MAX_INDUCING 4096   /* largest M */
+
+#define SGP_KERNEL_RBF 0
+#define SGP_KERNEL_MATERN32 1
+#define SGP_KERNEL_MATERN52 2
+
+#define SGP_OK 0
+#define SGP_ERR_ARG (-1)        /* null pointer / non-positive size / bad kernel_id */
+#define SGP_ERR_DIM (-2)        /* d > SGP_MAX_DIM or M > SGP_MAX_INDUCING */
+#define SGP_ERR_WORKSPACE (-3)  /* ws == NULL or ws_bytes too small */
+#define SGP_ERR_LAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch */
+
+/* slots of the `out` vector written by sgp_bound_from_stats */
+#define SGP_OUT_F 0             /* F = logmarg - trace_term  (the collapsed bound, NOT divided by N) */
+#define SGP_OUT_LOGMARG 1       /* log N(y | 0, Qff + s2 I) */
+#define SGP_OUT_TRACE 2         /* tr(Kff - Qff) / (2 s2) */
+#define SGP_OUT_LOGDETB 3       /* log det B */
+#define SGP_OUT_QUAD 4          /* y^T (Qff + s2 I)^-1 y */
+#define SGP_OUT_TRW 5           /* tr(Kuu^-1 Phi) */
+#define SGP_OUT_S2BAR 6         /* dF/d s2      (with_adjoints only) */
+#define SGP_OUT_KAPPABAR 7      /* dF/d kappa   (with_adjoints only) */
+#define SGP_OUT_LEN 8
+
+int sgp_abi_version(void);
+const char* sgp_status_string(int status);
+
+/* ---- streaming pass 1: sufficient statistics over the local row shard -------------------------
+ * Phi = Kuf Kuf^T (M x M, ld M, full symmetric), b = Kuf y (M), yy = y^T y, kappa = sum_n k(x_n,x_n).
+ * Replaces the N x M kernel matrix + N M^2 contraction inside InducingPointKernel /
+ * ExactMarginalLogLikelihood (models/sgpr.py:37,125) and MarginalSparse (models/bayesian_sgpr_hmc.py:71).
+ * Kuf is never materialised.  On several GPUs every rank calls this on its own rows and the
+ * caller all-reduces [Phi | b | yy | kappa].  N == 0 is allowed (all outputs zero).             */
+size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d);
+int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y,
+                      const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                      int64_t N, int M, int d, int kernel_id,
+                      double* Phi, double* b, double* yy, double* kappa,
+                      void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* ---- inducing block: Kuu = k(Z,Z) + jitter I  (M x M, ld M) -----------------------------------
+ * ScaleKernel(RBFKernel)(Z,Z) (models/sgpr.py:36-37); jitter = 1e-6 reproduces PyMC3's stabilize(). */
+int sgp_kuu(const double* Z, int64_t ldz, const double* inv_ls, double sf2, double jitter,
+            int M, int d, int kernel_id, double* Kuu, sgp_stream_t stream);
+
+/* ---- M x M back end (usable on their own; all in place, lower triangle, row-major) ------------ */
+size_t sgp_chol_workspace_bytes(int M);
+int sgp_chol_lower(double* A, int64_t lda, int M, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* B <- L^-1 B (trans=0) or L^-T B (trans=1); B is M x k, ld ldb */
+size_t sgp_trsm_workspace_bytes(int M, int k);
+int sgp_trsm_lower(const double* L, int64_t ldl, double* B, int64_t ldb, int trans, int M, int k,
+                   void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* out[0] = sum_i log L[i][i] */
+int sgp_logdiag_sum(const double* L, int64_t ldl, int M, double* out, sgp_stream_t stream);
+
+/* ---- the whole O(M^3) tail in one call ---------------------------------------------------------
+ * L = chol(Kuu); W = L^-1 Phi L^-T; B = I + W/s2; LB = chol(B); q = LB^-1 L^-1 b
+ * F = -[ N/2 log 2pi + N/2 log s2 + sum log diag LB + (yy/s2 - q.q/s2^2)/2 + (kappa - tr W)/(2 s2) ]
+ * with_adjoints != 0 additionally writes Phibar, bbar, Kuubar (M x M / M / M x M, ld M) and the
+ * S2BAR / KAPPABAR slots of out.  `factors` (optional, may be NULL) receives what sgp_predict needs:
+ * [ Linv (M*M) | G = LB^-1 L^-1 (M*M) | q (M) ].  yy, kappa are device scalars.                     */
+size_t sgp_bound_workspace_bytes(int M, int with_adjoints);
+size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
+int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b,
+                         const double* yy, const double* kappa, double s2, int64_t N, int M,
+                         int with_adjoints, double* out,
+                         double* Phibar, double* bbar, double* Kuubar, double* factors,
+                         int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* ---- streaming pass 2: gradients through Kuf -------------------------------------------------------
+ * Kbar_uf = 2 Phibar Kuf + bbar y^T is formed tile by tile and contracted with dKuf/d(.) on the fly.
+ * Writes (overwrites) g_ls[d] = dF/d lengthscale_j, g_sf2[1] = dF/d sf2 (including the kappa term
+ * kappabar * N), g_Z[M*d] (ld d; skipped when g_Z == NULL).  Local shard only; caller all-reduces.  */
+size_t sgp_suffstats_bwd_workspace_bytes(int64_t N, int M, int d);
+int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y,
+                      const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                      const double* Phibar, const double* bbar, double kappabar,
+                      int64_t N, int M, int d, int kernel_id,
+                      double* g_ls, double* g_sf2, double* g_Z,
+                      void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* gradient through Kuu: ADDS sum(Kuubar o dKuu/d(.)) into g_ls, g_sf2, g_Z (g_Z may be NULL).
+ * Kuubar is used as a symmetric matrix.  Replicated on every rank (call it after the all-reduce of
+ * the streamed gradients, or on one rank before it).                                             */
+size_t sgp_kuu_bwd_workspace_bytes(int M, int d);
+int sgp_kuu_bwd(const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                const double* Kuubar, int M, int d, int kernel_id,
+                double* g_ls, double* g_sf2, double* g_Z,
+                void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* ---- posterior predictive at T test rows (models/sgpr.py:150-160, 256-286) ----------------------
+ * mean = K*u Sigma^-1 b / s2 ; var = k** - |L^-1 k_u*|^2 + |LB^-1 L^-1 k_u*|^2 (+ s2 if pred_noise)
+ * cov (T x T, optional, may be NULL) is the full predictive covariance with the base kernel K**.   */
+size_t sgp_predict_workspace_bytes(int64_t T, int M, int d, int want_cov);
+int sgp_predict(const double* Xs, int64_t ldxs, int64_t T,
+                const double* Z, int64_t ldz, const double* inv_ls, double sf2, double s2,
+                const double* factors, int M, int d, int kernel_id, int pred_noise,
+                double* mean, double* var, double* cov,
+                void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGP_H */
