@@ -1,0 +1,132 @@
+"""Test double for HipEngine: same interface, arithmetic delegated to the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY -- lets the CPU-only suite exercise the host logic above the C ABI
+(CollapsedBound, HmcTarget, the model classes, the NUTS driver, the gloo world_size-2 sharding)
+in a container without a GPU.  The product never constructs it.
+"""
+import math
+
+import torch
+
+from oracle import vfe_oracle as O
+
+KID = {"rbf": 0, "matern32": 1, "matern52": 2, 0: 0, 1: 1, 2: 2}
+OUT_LEN = 8
+
+
+class OracleEngine:
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.calls = {"suffstats": 0, "bound": 0, "suffstats_bwd": 0, "kuu_bwd": 0, "predict": 0}
+
+    @staticmethod
+    def _ls(ls, d):
+        t = torch.as_tensor([float(v) for v in (ls.tolist() if hasattr(ls, "tolist") else ls)], dtype=torch.float64)
+        return t.expand(d).clone() if t.numel() == 1 else t
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64)
+
+    def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out=None):
+        self.calls["suffstats"] += 1
+        M, d = Z.shape
+        if X.shape[0] == 0:
+            packed = torch.zeros(M * M + M + 2, dtype=torch.float64)
+        else:
+            st = O.suffstats(X, y, Z, self._ls(ls, d), float(sf2), KID[kernel])
+            packed = torch.cat([st.Phi.reshape(-1), st.b, torch.tensor([st.yy, st.kappa], dtype=torch.float64)])
+        if out is not None:
+            out.copy_(packed)
+            return out
+        return packed
+
+    def kuu(self, Z, ls, sf2, jitter, kernel="rbf"):
+        return O.kuu(Z, self._ls(ls, Z.shape[1]), float(sf2), float(jitter), KID[kernel])
+
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False):
+        self.calls["bound"] += 1
+        M = Kuu.shape[0]
+        st = O.SuffStats(packed[: M * M].reshape(M, M), packed[M * M: M * M + M], float(packed[M * M + M]),
+                         float(packed[M * M + M + 1]), int(N))
+        out = torch.zeros(OUT_LEN, dtype=torch.float64)
+        info = torch.zeros(1, dtype=torch.int32)
+        res = {"out": out, "info": info}
+        try:
+            r = O.bound_from_stats(Kuu, st, float(s2), with_adjoints=with_adjoints)
+        except Exception:  # torch.linalg.cholesky failure -> LAPACK-style info like the HIP path
+            info[0] = 1
+            if with_adjoints:
+                res.update(Phibar=torch.zeros(M, M, dtype=torch.float64), bbar=torch.zeros(M, dtype=torch.float64),
+                           Kuubar=torch.zeros(M, M, dtype=torch.float64))
+            return res
+        out[0], out[1], out[2] = r["F"], r["logmarg"], r["trace_term"]
+        if with_adjoints:
+            out[6], out[7] = r["s2bar"], r["kappabar"]
+            res.update(Phibar=r["Phibar"], bbar=r["bbar"], Kuubar=r["Kuubar"])
+        if want_factors:
+            I = torch.eye(M, dtype=torch.float64)
+            Linv = torch.linalg.solve_triangular(r["L"], I, upper=False)
+            G = torch.linalg.solve_triangular(r["LB"], Linv, upper=False)
+            res["factors"] = torch.cat([Linv.reshape(-1), G.reshape(-1), r["q"]])
+        return res
+
+    def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False, out=None):
+        self.calls["suffstats_bwd"] += 1
+        M, d = Z.shape
+        lst = self._ls(ls, d)
+        kid = KID[kernel]
+        g_ls = torch.zeros(d, dtype=torch.float64)
+        g_Z = torch.zeros(M, d, dtype=torch.float64)
+        g_sf2 = torch.zeros((), dtype=torch.float64)
+        Zs = Z / lst
+        for s in range(0, X.shape[0], 4096):
+            Xc = X[s:s + 4096]
+            r2 = O.sqdist(Z, Xc, lst)
+            K = O.kernel_from_r2(r2, float(sf2), kid)
+            Kbar = 2.0 * Phibar @ K + torch.outer(bbar, y[s:s + 4096])
+            g_sf2 = g_sf2 + (Kbar * K).sum() / sf2
+            E = Kbar * O._dk_factors(r2, K, float(sf2), kid)
+            diff = Zs[:, None, :] - (Xc / lst)[None, :, :]
+            g_ls = g_ls + (-2.0 * (E[:, :, None] * diff * diff).sum((0, 1)) / lst)
+            g_Z = g_Z + 2.0 * (E[:, :, None] * diff).sum(1) / lst
+        g_sf2 = g_sf2 + float(kappabar) * X.shape[0]
+        parts = [g_ls, g_sf2.reshape(1)] + ([g_Z.reshape(-1)] if want_gz else [])
+        packed = torch.cat(parts)
+        if out is not None:
+            out.copy_(packed)
+            return out
+        return packed
+
+    def kuu_bwd(self, Z, ls, sf2, Kuubar, grads, kernel="rbf", want_gz=False):
+        self.calls["kuu_bwd"] += 1
+        M, d = Z.shape
+        lst = self._ls(ls, d)
+        kid = KID[kernel]
+        Zs = Z / lst
+        r2u = O.sqdist(Z, Z, lst)
+        Ku = O.kernel_from_r2(r2u, float(sf2), kid)
+        Eu = Kuubar * O._dk_factors(r2u, Ku, float(sf2), kid)
+        diffu = Zs[:, None, :] - Zs[None, :, :]
+        grads[:d] += -2.0 * (Eu[:, :, None] * diffu * diffu).sum((0, 1)) / lst
+        grads[d] += (Kuubar * Ku).sum() / sf2
+        if want_gz:
+            grads[d + 1:] += (2.0 * ((Eu + Eu.T)[:, :, None] * diffu).sum(1) / lst).reshape(-1)
+        return grads
+
+    def predict(self, Xs, Z, ls, sf2, s2, factors, kernel="rbf", pred_noise=True, full_cov=False):
+        self.calls["predict"] += 1
+        M, d = Z.shape
+        lst = self._ls(ls, d)
+        Linv = factors[: M * M].reshape(M, M)
+        G = factors[M * M: 2 * M * M].reshape(M, M)
+        q = factors[2 * M * M:]
+        Kus = O.kernel_from_r2(O.sqdist(Z, Xs, lst), float(sf2), KID[kernel])
+        As, C = Linv @ Kus, G @ Kus
+        mean = C.T @ q / s2
+        var = sf2 - (As * As).sum(0) + (C * C).sum(0) + (s2 if pred_noise else 0.0)
+        cov = None
+        if full_cov:
+            cov = O.kernel_from_r2(O.sqdist(Xs, Xs, lst), float(sf2), KID[kernel]) - As.T @ As + C.T @ C
+            if pred_noise:
+                cov = cov + s2 * torch.eye(Xs.shape[0], dtype=torch.float64)
+        return mean, var, cov

@@ -1,0 +1,152 @@
+"""CPU: the host layer above the C ABI (CollapsedBound, HmcTarget, sharding helpers) driven through the
+oracle-backed test double, against the golden vectors.  Also the world_size-2 gloo run of the sharded path."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, golden_names, load_golden
+from fake_engine import OracleEngine
+
+import ggp_amd
+
+KNAME = {0: "rbf", 1: "matern32", 2: "matern52"}
+
+
+def T(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_collapsed_bound_value_and_grad(name):
+    G = load_golden(name)
+    eng = OracleEngine()
+    cb = ggp_amd.CollapsedBound(T(G["X"]), T(G["y"]), kernel=KNAME[int(G["kernel_id"])], jitter=float(G["jitter"]), engine=eng)
+    F, parts = cb.value(T(G["Z"]), G["ls"], float(G["sf2"]), float(G["s2"]))
+    tol = 1e-9 * max(1.0, abs(float(G["F"])))
+    rt, rz = float(G["grad_rtol"]), float(G["gz_rtol"])
+    ptol = tol * (1000.0 if rt > 1e-6 else 1.0)  # the two parts cancel to F; ill-conditioned fixtures pin them loosely
+    assert abs(F - float(G["F"])) < tol and abs(parts["trace_term"] - float(G["trace_term"])) < ptol
+    F2, g = cb.value_and_grad(T(G["Z"]), G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+    assert abs(F2 - F) < tol
+    assert float((g["ls"] - T(G["g_ls"])).abs().max()) < rt * max(1.0, float(T(G["g_ls"]).abs().max()))
+    assert abs(g["sf2"] - float(G["g_sf2"])) < rt * max(1.0, abs(float(G["g_sf2"])))
+    assert abs(g["s2"] - float(G["g_s2"])) < rt * max(1.0, abs(float(G["g_s2"])))
+    assert float((g["Z"] - T(G["g_Z"])).abs().max()) < rz * max(1.0, float(T(G["g_Z"]).abs().max()))
+    assert eng.calls["suffstats"] == 2 and eng.calls["suffstats_bwd"] == 1 and eng.calls["kuu_bwd"] == 1
+    mean, var, _ = cb.predict(T(G["Xs"]), T(G["Z"]), G["ls"], float(G["sf2"]), float(G["s2"]))
+    assert float((mean - T(G["pred_mean"])).abs().max()) < 1e-8 and float((var - T(G["pred_var"])).abs().max()) < 1e-8
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("rbf")])
+def test_hmc_target(name):
+    G = load_golden(name)
+    cb = ggp_amd.CollapsedBound(T(G["X"]), T(G["y"]), jitter=1e-6, engine=OracleEngine())
+    tgt = ggp_amd.HmcTarget(cb, T(G["Z"]))
+    assert tgt.ndim == G["X"].shape[1] + 2
+    rt = float(G["grad_rtol"])
+    for th, lp_ref, g_ref in zip(G["hmc_theta"], G["hmc_logp"], G["hmc_grad"]):
+        lp, gr = tgt.logp_and_grad(th)
+        ftol = (1e-9 if rt <= 1e-6 else 1e-7) * max(1.0, abs(lp_ref))  # duplicate-Z fixture: cond(Kuu) ~ 1e6
+        assert abs(lp - lp_ref) < ftol
+        assert float(np.abs(np.array(gr) - g_ref).max()) < rt * max(1.0, float(np.abs(g_ref).max()))
+        assert abs(tgt.logp(th) - lp_ref) < ftol
+
+
+def test_failed_cholesky_paths():
+    X = torch.randn(30, 2, dtype=torch.float64)
+    y = torch.randn(30, dtype=torch.float64)
+    Z = torch.zeros(5, 2, dtype=torch.float64)
+    cb = ggp_amd.CollapsedBound(X, y, jitter=0.0, engine=OracleEngine())
+    with pytest.raises(ggp_amd.NotPositiveDefiniteError):
+        cb.value(Z, [1.0, 1.0], 1.0, 0.1)
+    F, parts = cb.value(Z, [1.0, 1.0], 1.0, 0.1, raise_on_fail=False)
+    assert math.isnan(F) and parts["info"] > 0
+    tgt = ggp_amd.HmcTarget(cb, Z)  # PyMC3 semantics: non-finite energy, never an exception
+    lp, gr = tgt.logp_and_grad([0.0, 0.0, 0.0, -1.0])
+    assert lp == -math.inf and all(v == 0.0 for v in gr)
+
+
+def test_shard_rows_partition():
+    for N, W in ((10, 3), (1_000_000, 8), (7, 8), (0, 2)):
+        cuts = [ggp_amd.shard_rows(N, r, W) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == N
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_1d_inputs_are_accepted_like_the_reference_demo():
+    # experiments/demo_1d_regression.py:72 passes Z_init = torch.randn(25) (1-D) and X as N x 1
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(80, dtype=torch.float64, generator=g) * 2
+    y = torch.sin(3 * X)
+    Z = torch.linspace(-3, 3, 9, dtype=torch.float64)
+    cb = ggp_amd.CollapsedBound(X, y, jitter=1e-6, engine=OracleEngine())
+    F, _ = cb.value(Z, [0.7], 1.0, 0.1)
+    from oracle import vfe_oracle as O
+    assert abs(F - O.vfe_streaming(X[:, None], y, Z[:, None], torch.tensor([0.7], dtype=torch.float64), 1.0, 0.1, 1e-6)["F"]) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# world_size = 2 over gloo: row shards + one all-reduce reproduce the single-process result
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ggp_amd as pkg
+    from fake_engine import OracleEngine as Eng
+    from conftest import load_golden as lg
+    G = lg(name)
+    X, y, Z = T(G["X"]), T(G["y"]), T(G["Z"])
+    lo, hi = pkg.shard_rows(X.shape[0], rank, world)
+    cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=float(G["jitter"]), engine=Eng())
+    assert cb.N == X.shape[0]
+    F, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+    mean, var, _ = cb.predict(T(G["Xs"]), Z, G["ls"], float(G["sf2"]), float(G["s2"]))
+    q.put((rank, F, g["ls"].numpy(), g["sf2"], g["s2"], g["Z"].numpy(), mean.numpy(), var.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["rbf_d3_small", "rbf_d8_nojit"])
+def test_two_rank_gloo_matches_single_process(name):
+    G = load_golden(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    outs.sort(key=lambda t: t[0])
+    tol = 1e-9 * max(1.0, abs(float(G["F"])))
+    for rank, F, gls, gsf2, gs2, gZ, mean, var in outs:
+        assert abs(F - float(G["F"])) < tol
+        assert np.abs(gls - G["g_ls"]).max() < 1e-6 * max(1.0, np.abs(G["g_ls"]).max())
+        assert abs(gsf2 - float(G["g_sf2"])) < 1e-6 * max(1.0, abs(float(G["g_sf2"])))
+        assert abs(gs2 - float(G["g_s2"])) < 1e-6 * max(1.0, abs(float(G["g_s2"])))
+        assert np.abs(gZ - G["g_Z"]).max() < 1e-6 * max(1.0, np.abs(G["g_Z"]).max())
+        assert np.abs(mean - G["pred_mean"]).max() < 1e-8 and np.abs(var - G["pred_var"]).max() < 1e-8
+    # replicated tail: both ranks hold bit-identical results
+    assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][5], outs[1][5])
