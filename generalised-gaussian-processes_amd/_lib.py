@@ -36,8 +36,10 @@ PROTOTYPES = {
     "sgp_abi_version": (_i32, []),
     "sgp_status_string": (C.c_char_p, [_i32]),
     "sgp_suffstats_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_kfu_len": (_sz, [_i64, _i32]),
+    "sgp_set_kfu_budget_bytes": (None, [_sz]),
     "sgp_suffstats_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,
-                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_kuu": (_i32, [_vp, _i64, _dp, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp]),
     "sgp_chol_workspace_bytes": (_sz, [_i32]),
     "sgp_chol_lower": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
@@ -49,7 +51,7 @@ PROTOTYPES = {
     "sgp_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "sgp_suffstats_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _i64, _i32, _i32, _i32,
+    "sgp_suffstats_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_kuu_bwd_workspace_bytes": (_sz, [_i32, _i32]),
     "sgp_kuu_bwd": (_i32, [_vp, _i64, _dp, _dbl, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -77,6 +77,11 @@ class CollapsedBound:
             self.N = n_local
         self.n_evals = 0
         self.n_grads = 0
+        # K'_fu of the local shard stays resident between pass 1 and pass 2 of one evaluation when it
+        # fits the budget (default 64 GiB of the 288 GB HBM); otherwise the library streams it in
+        # 16 GiB super-chunks and pass 2 re-assembles.
+        self._kfu = None
+        self.kfu_budget_bytes = 64 << 30
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -96,13 +101,27 @@ class CollapsedBound:
             Z = Z[:, None]
         return Z.detach().to(dtype=torch.float64, device=self.engine.device).contiguous()
 
+    def _kfu_for(self, M):
+        e = self.engine
+        if not hasattr(e, "kfu_buffer"):
+            return None
+        n_local = int(self.X.shape[0])
+        need = ((max(n_local, 1) + 255) // 256 * 256) * ((M + 127) // 128 * 128)
+        if need * 8 > self.kfu_budget_bytes:
+            return None
+        if self._kfu is None or self._kfu.numel() < need:
+            self._kfu = e.kfu_buffer(n_local, M)
+        return self._kfu
+
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False):
         e = self.engine
-        packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel)
+        kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
+        packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu)
         self._allreduce(packed)
         Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
         res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors)
         res["packed"] = packed
+        res["kfu"] = kfu
         return res
 
     # ------------------------------------------------------------------ public
@@ -135,7 +154,7 @@ class CollapsedBound:
                 raise NotPositiveDefiniteError(info)
             return float("nan"), {"info": info}
         g = e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], float(o[OUT_KAPPABAR]),
-                            self.kernel, want_gz=want_gz)
+                            self.kernel, want_gz=want_gz, kfu=res["kfu"])
         self._allreduce(g)
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
         gh = g[: d + 1].detach().to("cpu")

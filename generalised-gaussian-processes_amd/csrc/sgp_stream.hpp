@@ -1,0 +1,63 @@
+// Shared geometry of the two streaming passes (sgp_suffstats_fwd.hip / sgp_suffstats_bwd.hip).
+#pragma once
+#include "sgp_common.hpp"
+
+namespace sgp {
+
+constexpr int TILE = 128;            // tile edge (inducing columns) of both passes
+constexpr int NB = 16;               // data rows per SYRK chunk
+constexpr int KROW = 2 * TILE + 16;  // LDS row stride of a SYRK chunk in doubles (272: +128 B bank shift per row)
+constexpr int ASM_ROWS = 256;        // data rows per assembly workgroup; K'_fu is padded to a multiple of this
+constexpr int TARGET_WGS = 2048;     // ~4 waves of the 512 resident workgroups (2 per CU)
+constexpr size_t KFU_BUDGET_DEFAULT = size_t(16) << 30;  // K'_fu bytes kept in flight when the library owns the buffer
+size_t stream_kfu_budget();  // current budget (sgp_set_kfu_budget_bytes); defined in sgp_suffstats_fwd.hip
+
+static inline int dp_for(int d) {
+  const int opts[] = {2, 4, 8, 16, 24, 32};
+  for (int o : opts)
+    if (d <= o) return o;
+  return -1;
+}
+
+struct StreamPlan {
+  int Mp, ntr, ntiles, DP;
+  int64_t Npad;     // N rounded up to ASM_ROWS
+  int64_t sc_rows;  // rows of K'_fu materialised at a time (multiple of ASM_ROWS)
+  int nsplit;       // pass 1: row-range splits per tile (multiple of 8: one XCD per residue)
+  int nmb;          // pass 2: 128-column blocks of Phibar
+  int nsplit_b;     // pass 2: row-range splits per column block
+};
+
+static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
+  StreamPlan p;
+  p.Mp = padded_m(M);
+  p.ntr = p.Mp / TILE;
+  p.ntiles = p.ntr * (p.ntr + 1) / 2;
+  p.DP = dp_for(d);
+  p.Npad = N > 0 ? round_up64(N, ASM_ROWS) : 0;
+  int64_t cap = (int64_t)(stream_kfu_budget() / ((size_t)p.Mp * 8)) / ASM_ROWS * ASM_ROWS;
+  if (cap < ASM_ROWS) cap = ASM_ROWS;
+  p.sc_rows = p.Npad < cap ? p.Npad : cap;
+  const int64_t nchunks = p.sc_rows / NB;
+  int64_t k = (TARGET_WGS + 8 * p.ntiles - 1) / (8 * p.ntiles);
+  int64_t ns = 8 * k;
+  const int64_t lim = round_up64(nchunks > 0 ? nchunks : 1, 8);
+  if (ns > lim) ns = lim;
+  p.nsplit = (int)ns;
+  p.nmb = p.Mp / TILE;
+  const int64_t nblocks = p.sc_rows / TILE;
+  int64_t nsb = (TARGET_WGS + p.nmb - 1) / p.nmb;
+  if (nsb > nblocks) nsb = nblocks;
+  if (nsb < 1) nsb = 1;
+  p.nsplit_b = (int)nsb;
+  return p;
+}
+
+// implemented in sgp_suffstats_fwd.hip
+void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, int64_t ldx, const double* y,
+                     const double* Z, int64_t ldz, int64_t N, int M, double* Xs, double* ys, double* Zs, double* yypart,
+                     hipStream_t st);
+void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0,
+                     int64_t rows, int64_t N, int M, double* Kfu, double* bpart, hipStream_t st);
+
+}  // namespace sgp

@@ -1,80 +1,37 @@
-// Streaming pass 1: fused kernel-matrix assembly + SYRK on the fp64 matrix cores.
+// Streaming pass 1: kernel-matrix assembly + SYRK on the fp64 matrix cores.
 //
 //   Phi = Kuf Kuf^T (M x M),  b = Kuf y,  yy = y^T y,  kappa = sum_n k(x_n, x_n)
 //
-// replaces the materialised N x M kernel matrix and the N M^2 contraction of
-// InducingPointKernel / ExactMarginalLogLikelihood (reference models/sgpr.py:37,125) and of
-// pm.gp.MarginalSparse (reference models/bayesian_sgpr_hmc.py:71).  Kuf never touches HBM:
+// replaces the N x M kernel matrix and the N M^2 contraction of InducingPointKernel /
+// ExactMarginalLogLikelihood (reference models/sgpr.py:37,125) and of pm.gp.MarginalSparse
+// (reference models/bayesian_sgpr_hmc.py:71).
 //
-//   * a prologue writes X~ = X * inv_ls (row-major, padded to DP columns / whole chunks) so the
-//     main kernel reads every data row through the SCALAR cache (the row index is wave-uniform);
-//   * each 256-thread workgroup owns one 128 x 128 tile of the lower triangle of Phi and one
-//     contiguous range of 16-row data chunks.  A thread keeps one scaled inducing row z~ in
-//     registers, generates k'(x_n, z_m) = profile(|x~_n - z~_m|^2) for its row against the 16 data
-//     rows of a chunk and drops them into an LDS tile laid out [n][row] (row stride 272 doubles so
-//     the MFMA operand reads of the two 16-lane halves fall in disjoint bank halves);
-//   * the four waves each hold a 64 x 64 accumulator block (16 MFMA tiles = 128 VGPRs) and feed
-//     v_mfma_f64_16x16x4_f64 straight from that LDS tile: both operands of the SYRK are the same
-//     K tile, lane l supplying K[row0 + (l&15)][n0 + (l>>4)];
-//   * LDS is double buffered: generation of chunk c+1 (VALU) is issued in the same loop body as the
-//     MFMAs of chunk c, one barrier per chunk; two workgroups fit per CU (69.6 KB LDS, <=256 VGPRs);
-//   * partial tiles go to a per-split slab and a second, deterministic kernel sums the splits in a
-//     fixed order, applies sf2^2 and mirrors the lower triangle (no fp64 atomics, bit-reproducible).
+// Measured on MI355X (profiles/r01_fp64_rates_microbench.txt): v_mfma_f64_16x16x4_f64 issues every
+// 64 cycles per SIMD (77 TFLOP/s chip-wide) and fp64 VALU work does NOT overlap with it -- the two
+// share the fp64 datapath (MFMA + n v_fma_f64 costs 64 + ~5n cycles).  Every exp() spent re-generating
+// a kernel value inside the contraction is therefore paid at full price, so the value is generated
+// exactly once:
+//
+//   1. `kfu_assemble_kernel` (HBM-write bound, "kernel assembly"): thread <-> inducing column m keeps
+//      z~_m in registers, walks 256 wave-uniform data rows (x~_n, y_n arrive through the scalar cache)
+//      and writes k'(x_n, z_m) = profile(|x~_n - z~_m|^2) into K'_fu [Npad x Mp] with 512-byte
+//      coalesced stores; the b = K^T y partial of its rows falls out of the same loop.
+//   2. `syrk_tile_kernel` (fp64-MFMA bound, "contraction"): workgroup <-> (128 x 128 tile of the lower
+//      triangle of Phi, split of the row range).  16-row chunks of K'_fu go global -> registers -> LDS
+//      (double buffered, [n][col] with a 272-double stride so the two 16-lane halves of an operand read
+//      hit disjoint bank halves); 4 waves x 16 MFMA tiles (64 x 64 per wave) accumulate in 128 VGPRs.
+//      Both SYRK operands are the same K' rows: lane l supplies K'[n0 + (l>>4)][col0 + (l&15)].
+//      Workgroup ids are laid out so that all tiles of one split land on one XCD (round-robin dispatch):
+//      its L2 then serves the 8-9 re-reads of every K' row block (speed only, never correctness).
+//   3. `reduce_phi_kernel`: sums the per-split slabs in a fixed order, applies sf2^2 and mirrors the
+//      lower triangle -- no fp64 atomics anywhere, results are bit-reproducible.
 #include "sgp_common.hpp"
+#include "sgp_stream.hpp"
 
 namespace sgp {
 
-constexpr int TILE = 128;          // Phi tile edge per workgroup
-constexpr int NB = 16;             // data rows per chunk
-constexpr int KROW = 2 * TILE + 16;  // LDS row stride in doubles (272: +128 B shift per n)
-constexpr int TARGET_WGS = 512;    // 2 workgroups per CU x 256 CUs
-
-static inline int dp_for(int d) {
-  const int opts[] = {2, 4, 8, 16, 24, 32};
-  for (int o : opts)
-    if (d <= o) return o;
-  return -1;
-}
-
-struct FwdPlan {
-  int Mp, ntr, ntiles, DP;
-  int64_t nchunks, Npad;
-  int nsplit, cps;
-};
-
-static FwdPlan make_plan(int64_t N, int M, int d) {
-  FwdPlan p;
-  p.Mp = padded_m(M);
-  p.ntr = p.Mp / TILE;
-  p.ntiles = p.ntr * (p.ntr + 1) / 2;
-  p.DP = dp_for(d);
-  p.nchunks = (N + NB - 1) / NB;
-  p.Npad = p.nchunks * NB;
-  int64_t want = (TARGET_WGS + p.ntiles - 1) / p.ntiles;
-  int64_t ns = p.nchunks < want ? p.nchunks : want;
-  if (ns < 1) ns = 1;
-  p.cps = (int)((p.nchunks + ns - 1) / ns);
-  if (p.cps < 1) p.cps = 1;
-  p.nsplit = p.nchunks > 0 ? (int)((p.nchunks + p.cps - 1) / p.cps) : 1;
-  return p;
-}
-
-struct FwdWs {
-  double *Xs, *ys, *Zs, *slab, *bpart, *yypart;
-  size_t bytes;
-};
-static FwdWs carve_fwd(void* ws, const FwdPlan& p) {
-  Carver c(ws);
-  FwdWs w;
-  w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
-  w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
-  w.Zs = c.take<double>((size_t)p.Mp * p.DP);
-  w.slab = c.take<double>((size_t)p.nsplit * p.ntiles * TILE * TILE);
-  w.bpart = c.take<double>((size_t)p.nsplit * p.Mp);
-  w.yypart = c.take<double>(256);
-  w.bytes = c.used();
-  return w;
-}
+static size_t g_kfu_budget = KFU_BUDGET_DEFAULT;
+size_t stream_kfu_budget() { return g_kfu_budget; }
 
 // ---------------------------------------------------------------------------------------------
 // prologue kernels
@@ -107,53 +64,87 @@ __global__ __launch_bounds__(256) void prep_y_kernel(const double* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// main kernel
+// 1. kernel assembly:  Kfu[n][m] = k'(x_n, z_m)   (no sf2; zero in the padding)
+//    grid = (rows / ASM_ROWS, Mp / 128): a workgroup owns 128 columns x 256 rows, its two thread halves
+//    take alternate data rows.  bpart[rowblock][m] = sum_n Kfu[n][m] y[n] over this block's rows.
 // ---------------------------------------------------------------------------------------------
-template <int DP, int KID, bool DIAG>
-__device__ __forceinline__ void fwd_tile(double (*Ks)[NB][KROW], const double* __restrict__ Xs,
-                                         const double* __restrict__ ys, const double* __restrict__ Zs,
-                                         int64_t N, int M, int Mp, int64_t c0, int64_t c1, int I0, int J0,
-                                         double* __restrict__ out, double* __restrict__ bout) {
+template <int DP, int KID>
+__global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
+                                                           const double* __restrict__ Zs, int64_t row0, int64_t N, int M,
+                                                           int Mp, double* __restrict__ Kfu, double* __restrict__ bpart) {
+  __shared__ double bsh[256];
+  const int tid = threadIdx.x;
+  const int nsub = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: which of the two row phases
+  const int m = blockIdx.y * TILE + (tid & 127);
+  const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;  // row inside this super-chunk's Kfu
+  const double zmask = m < M ? 1.0 : 0.0;
+
+  double zr[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) zr[j] = Zs[(size_t)m * DP + j];
+
+  double bacc = 0.0;
+#pragma unroll 4
+  for (int i = nsub; i < ASM_ROWS; i += 2) {
+    const int64_t n = row0 + rbase + i;                    // global data row, wave-uniform
+    const double* __restrict__ xr = Xs + n * DP;           // -> scalar loads
+    double r2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const double df = xr[j] - zr[j];
+      r2 = fma(df, df, r2);
+    }
+    const double msk = n < N ? zmask : 0.0;
+    const double kv = kprofile<KID>(r2) * msk;
+    Kfu[(rbase + i) * Mp + m] = kv;
+    bacc = fma(kv, ys[n], bacc);
+  }
+  bsh[tid] = bacc;
+  __syncthreads();
+  if (tid < TILE) bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bsh[tid] + bsh[tid + TILE];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. contraction: slab[split][tile] (+)= sum over this split's chunks of K'_I^T K'_J
+// ---------------------------------------------------------------------------------------------
+template <bool DIAG>
+__device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* __restrict__ Kfu, int Mp, int64_t c0,
+                                          int64_t c1, int I0, int J0, int accumulate, double* __restrict__ out) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
+  constexpr int boff = DIAG ? 0 : TILE;   // where the B-operand columns live in the LDS tile
+  constexpr int NQ = DIAG ? 4 : 8;        // 16-byte quads this thread moves per chunk
 
-  // generation role: off-diagonal tiles -> thread t owns LDS row t (I rows 0..127, J rows 128..255)
-  // and all 16 data rows of a chunk; diagonal tiles -> only 128 distinct rows, the two thread
-  // halves split the 16 data rows between them.
-  const int lrow = DIAG ? (tid & 127) : tid;
-  const int zrow = (lrow < TILE) ? I0 + lrow : J0 + lrow - TILE;
-  const int nbeg = DIAG ? (wave >> 1) * (NB / 2) : 0;
-  constexpr int NCNT = DIAG ? NB / 2 : NB;
-  const double zmask = zrow < M ? 1.0 : 0.0;
-  constexpr int boff = DIAG ? 0 : TILE;  // where the B-operand rows live in the LDS tile
-
-  double zr[DP];
+  // staging role: quad q = tid + 256 i -> LDS row n = q / 128 (off-diagonal) or q / 64 (diagonal),
+  // 64 consecutive threads cover one contiguous 1 KB row segment of K'_fu.
+  int srow[NQ], scol[NQ];
+  int64_t goff[NQ];
 #pragma unroll
-  for (int j = 0; j < DP; ++j) zr[j] = Zs[(size_t)zrow * DP + j];
-
-  double bacc = 0.0;
-
-  // branch-free generation of this thread's NCNT elements of chunk c into LDS buffer `buf`
-  auto gen = [&](int64_t c, int buf) {
-    const int64_t nbase = c * NB;
-#pragma unroll 4
-    for (int i = 0; i < NCNT; ++i) {
-      const int n = nbeg + i;
-      const double* __restrict__ xr = Xs + (nbase + n) * DP;  // wave-uniform -> scalar loads
-      double r2 = 0.0;
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const double df = xr[j] - zr[j];
-        r2 = fma(df, df, r2);
-      }
-      const double msk = (nbase + n) < N ? zmask : 0.0;
-      const double kv = kprofile<KID>(r2) * msk;
-      Ks[buf][n][lrow] = kv;
-      if constexpr (DIAG) bacc = fma(kv, ys[nbase + n], bacc);
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + 256 * i;
+    if (DIAG) {
+      srow[i] = q >> 6;
+      scol[i] = (q & 63) * 2;
+      goff[i] = (int64_t)srow[i] * Mp + I0 + scol[i];
+    } else {
+      srow[i] = q >> 7;
+      const int r = q & 127;
+      scol[i] = r < 64 ? r * 2 : TILE + (r - 64) * 2;
+      goff[i] = (int64_t)srow[i] * Mp + (r < 64 ? I0 + r * 2 : J0 + (r - 64) * 2);
     }
+  }
+  d2 stage[NQ];
+  auto fetch = [&](int64_t c) {
+    const double* base = Kfu + c * NB * Mp;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) stage[i] = *reinterpret_cast<const d2*>(base + goff[i]);
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) *reinterpret_cast<d2*>(&Ks[buf][srow[i]][scol[i]]) = stage[i];
   };
 
   d4 acc[4][4];
@@ -165,11 +156,12 @@ __device__ __forceinline__ void fwd_tile(double (*Ks)[NB][KROW], const double* _
   const bool skip_mfma = DIAG && wi == 0 && wj == 1;  // strictly-upper 64x64 block of a diagonal tile
 
   if (c0 < c1) {
-    gen(c0, 0);
+    fetch(c0);
+    stash(0);
     __syncthreads();
     for (int64_t c = c0; c < c1; ++c) {
       const int buf = (int)((c - c0) & 1);
-      if (c + 1 < c1) gen(c + 1, buf ^ 1);
+      if (c + 1 < c1) fetch(c + 1);
       if (!skip_mfma) {
 #pragma unroll
         for (int ks = 0; ks < NB / 4; ++ks) {
@@ -185,11 +177,11 @@ __device__ __forceinline__ void fwd_tile(double (*Ks)[NB][KROW], const double* _
             for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
         }
       }
+      if (c + 1 < c1) stash(buf ^ 1);
       __syncthreads();
     }
   }
 
-  // epilogue: accumulators -> slab[split][tile][128][128]
   if (!skip_mfma) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -199,44 +191,38 @@ __device__ __forceinline__ void fwd_tile(double (*Ks)[NB][KROW], const double* _
         for (int r = 0; r < 4; ++r) {
           const int row = wi * 64 + u * 16 + l4 + 4 * r;
           const int col = wj * 64 + v * 16 + l15;
-          out[row * TILE + col] = acc[u][v][r];
+          double* dst = out + row * TILE + col;
+          *dst = accumulate ? *dst + acc[u][v][r] : acc[u][v][r];
         }
-  }
-  if constexpr (DIAG) {
-    double* scratch = &Ks[0][0][0];
-    scratch[tid] = bacc;
-    __syncthreads();
-    if (tid < TILE) bout[I0 + tid] = scratch[tid] + scratch[tid + TILE];
   }
 }
 
-template <int DP, int KID>
-__global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void suffstats_fwd_kernel(
-    const double* __restrict__ Xs, const double* __restrict__ ys, const double* __restrict__ Zs,
-    int64_t N, int M, int Mp, int64_t nchunks, int cps, int ntiles,
-    double* __restrict__ slab, double* __restrict__ bpart) {
+__global__ __launch_bounds__(256, 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks, int cps,
+                                                           int ntiles, int accumulate, double* __restrict__ slab) {
   __shared__ double Ks[2][NB][KROW];
-
-  // lower-triangular tile index -> (ti, tj), tj <= ti
-  const int t = blockIdx.x;
+  // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch
+  const int id = blockIdx.x;
+  const int xcd = id & 7;
+  const int jj = id >> 3;
+  const int t = jj % ntiles;
+  const int split = (jj / ntiles) * 8 + xcd;
   int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while (ti * (ti + 1) / 2 > t) --ti;
   const int tj = t - ti * (ti + 1) / 2;
-  const int split = blockIdx.y;
   const int64_t c0 = (int64_t)split * cps;
-  const int64_t c1 = (c0 + cps < nchunks) ? c0 + cps : nchunks;
+  int64_t c1 = c0 + cps;
+  if (c1 > nchunks) c1 = nchunks;
   double* out = slab + ((size_t)split * ntiles + t) * (TILE * TILE);
-  double* bout = bpart + (size_t)split * Mp;
   if (ti == tj)
-    fwd_tile<DP, KID, true>(Ks, Xs, ys, Zs, N, M, Mp, c0, c1, ti * TILE, tj * TILE, out, bout);
+    syrk_tile<true>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, out);
   else
-    fwd_tile<DP, KID, false>(Ks, Xs, ys, Zs, N, M, Mp, c0, c1, ti * TILE, tj * TILE, out, bout);
+    syrk_tile<false>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, out);
 }
 
 // ---------------------------------------------------------------------------------------------
-// deterministic split reduction + symmetrisation:  Phi = sf2^2 * sum_s slab[s]
-// one block per 32 x 32 sub-block of the lower triangle (ti32 >= tj32)
+// 3. deterministic split reduction + symmetrisation:  Phi = sf2^2 * sum_s slab[s]
+//    one block per 32 x 32 sub-block of the lower triangle
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_phi_kernel(const double* __restrict__ slab, int nsplit, int ntiles,
                                                          int M, double scale, double* __restrict__ Phi) {
@@ -253,7 +239,7 @@ __global__ __launch_bounds__(256) void reduce_phi_kernel(const double* __restric
   const size_t sstride = (size_t)ntiles * (TILE * TILE);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int lr = ty + 8 * k;  // row inside the 32x32 block
+    const int lr = ty + 8 * k;
     const int gi = bi * 32 + lr, gj = bj * 32 + tx;
     double s = 0.0;
     if (gi >= gj) {  // computed part of the slab (lower triangle incl. diagonal)
@@ -268,20 +254,19 @@ __global__ __launch_bounds__(256) void reduce_phi_kernel(const double* __restric
     const int lr = ty + 8 * k;
     const int gi = bi * 32 + lr, gj = bj * 32 + tx;
     if (gi < M && gj < M && gi >= gj) Phi[(size_t)gi * M + gj] = tile[lr][tx];
-    // mirrored element: Phi[gj'][gi'] with roles swapped so the store is row-contiguous
-    const int mi = bj * 32 + lr, mj = bi * 32 + tx;  // (row, col) in the upper triangle
+    const int mi = bj * 32 + lr, mj = bi * 32 + tx;  // mirrored element, row-contiguous store
     if (mi < M && mj < M && mj > mi) Phi[(size_t)mi * M + mj] = tile[tx][lr];
   }
 }
 
-__global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ bpart, int nsplit, int Mp, int M,
+__global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ bpart, int64_t nrb, int Mp, int M,
                                                              const double* __restrict__ yypart, int nyy, double sf2,
                                                              double kappa_val, double* __restrict__ b,
                                                              double* __restrict__ yy, double* __restrict__ kappa) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m < M) {
     double s = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) s += bpart[(size_t)sp * Mp + m];
+    for (int64_t rb = 0; rb < nrb; ++rb) s += bpart[rb * Mp + m];
     b[m] = s * sf2;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -292,45 +277,88 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
   }
 }
 
-__global__ void zero_kernel(double* p, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
+template <int DP>
+static void launch_assemble(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
+                            int64_t row0, int64_t N, int M, int Mp, double* Kfu, double* bpart) {
+  switch (kid) {
+    case SGP_KERNEL_RBF: kfu_assemble_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    case SGP_KERNEL_MATERN32: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    default: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+  }
 }
 
-template <int DP>
-static void launch_fwd(int kid, dim3 grid, hipStream_t st, const FwdWs& w, int64_t N, int M, const FwdPlan& p) {
-  switch (kid) {
-    case SGP_KERNEL_RBF:
-      suffstats_fwd_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(w.Xs, w.ys, w.Zs, N, M, p.Mp, p.nchunks, p.cps, p.ntiles, w.slab, w.bpart);
-      break;
-    case SGP_KERNEL_MATERN32:
-      suffstats_fwd_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(w.Xs, w.ys, w.Zs, N, M, p.Mp, p.nchunks, p.cps, p.ntiles, w.slab, w.bpart);
-      break;
-    default:
-      suffstats_fwd_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(w.Xs, w.ys, w.Zs, N, M, p.Mp, p.nchunks, p.cps, p.ntiles, w.slab, w.bpart);
-      break;
+// Assemble rows [row0, row0 + rows) of K'_fu (rows a multiple of ASM_ROWS) into Kfu (which starts at row0).
+void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0,
+                     int64_t rows, int64_t N, int M, double* Kfu, double* bpart, hipStream_t st) {
+  dim3 grid((unsigned)(rows / ASM_ROWS), p.Mp / TILE);
+  switch (p.DP) {
+    case 2: launch_assemble<2>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 4: launch_assemble<4>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 8: launch_assemble<8>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 16: launch_assemble<16>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 24: launch_assemble<24>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    default: launch_assemble<32>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
   }
+}
+
+void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, int64_t ldx, const double* y,
+                     const double* Z, int64_t ldz, int64_t N, int M, double* Xs, double* ys, double* Zs, double* yypart,
+                     hipStream_t st) {
+  if (N > 0) {
+    const int64_t tot = p.Npad * p.DP;
+    const int gx = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    scale_rows_kernel<<<gx, 256, 0, st>>>(X, ldx, N, p.Npad, p.DP, ka, Xs);
+  }
+  scale_rows_kernel<<<(p.Mp * p.DP + 255) / 256, 256, 0, st>>>(Z, ldz, M, p.Mp, p.DP, ka, Zs);
+  prep_y_kernel<<<256, 256, 0, st>>>(y, N, p.Npad, ys, yypart);
+}
+
+struct FwdWs {
+  double *Xs, *ys, *Zs, *Kfu, *slab, *bpart, *yypart;
+  size_t bytes;
+};
+static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
+  Carver c(ws);
+  FwdWs w;
+  w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
+  w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
+  w.Zs = c.take<double>((size_t)p.Mp * p.DP);
+  w.slab = c.take<double>((size_t)p.nsplit * p.ntiles * TILE * TILE);
+  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
+  w.yypart = c.take<double>(256);
+  w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
+  w.bytes = c.used();
+  return w;
 }
 
 }  // namespace sgp
 
 using namespace sgp;
 
+extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { g_kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
+
+extern "C" size_t sgp_kfu_len(int64_t N, int M) {
+  if (N < 0 || M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  return (size_t)round_up64(N > 0 ? N : 1, ASM_ROWS) * padded_m(M);
+}
+
 extern "C" size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
-  FwdPlan p = make_plan(N, M, d);
-  return carve_fwd(nullptr, p).bytes;
+  StreamPlan p = make_stream_plan(N, M, d);
+  return carve_fwd(nullptr, p, true).bytes;
 }
 
 extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
                                  const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
-                                 double* Phi, double* b, double* yy, double* kappa, void* ws, size_t ws_bytes,
-                                 sgp_stream_t stream) {
+                                 double* Phi, double* b, double* yy, double* kappa, double* Kfu_out, void* ws,
+                                 size_t ws_bytes, sgp_stream_t stream) {
   if (!Z || !inv_ls || !Phi || !b || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
-  FwdPlan p = make_plan(N, M, d);
-  FwdWs w = carve_fwd(ws, p);
+  StreamPlan p = make_stream_plan(N, M, d);
+  if (Kfu_out) p.sc_rows = p.Npad;  // caller keeps the whole K'_fu: one super-chunk
+  FwdWs w = carve_fwd(ws, p, Kfu_out == nullptr);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
@@ -339,32 +367,23 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   ka.sf2 = sf2;
   ka.d = d;
 
-  if (N > 0) {
-    const int64_t tot = p.Npad * p.DP;
-    int gx = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
-    scale_rows_kernel<<<gx, 256, 0, st>>>(X, ldx, N, p.Npad, p.DP, ka, w.Xs);
+  stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
+  double* Kfu = Kfu_out ? Kfu_out : w.Kfu;
+  const int grid = p.ntiles * p.nsplit;
+  if (p.Npad == 0) {
+    // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
+    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, 1, p.ntiles, 0, w.slab);
   }
-  scale_rows_kernel<<<(p.Mp * p.DP + 255) / 256, 256, 0, st>>>(Z, ldz, M, p.Mp, p.DP, ka, w.Zs);
-  prep_y_kernel<<<256, 256, 0, st>>>(y, N, p.Npad, w.ys, w.yypart);
-
-  if (N > 0) {
-    dim3 grid(p.ntiles, p.nsplit);
-    switch (p.DP) {
-      case 2: launch_fwd<2>(kernel_id, grid, st, w, N, M, p); break;
-      case 4: launch_fwd<4>(kernel_id, grid, st, w, N, M, p); break;
-      case 8: launch_fwd<8>(kernel_id, grid, st, w, N, M, p); break;
-      case 16: launch_fwd<16>(kernel_id, grid, st, w, N, M, p); break;
-      case 24: launch_fwd<24>(kernel_id, grid, st, w, N, M, p); break;
-      default: launch_fwd<32>(kernel_id, grid, st, w, N, M, p); break;
-    }
-  } else {
-    const size_t n = (size_t)p.nsplit * p.ntiles * TILE * TILE;
-    zero_kernel<<<256, 256, 0, st>>>(w.slab, n);
-    zero_kernel<<<8, 256, 0, st>>>(w.bpart, (size_t)p.nsplit * p.Mp);
+  for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
+    const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
+    stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Kfu, w.bpart, st);
+    const int64_t nchunks = rows / NB;
+    const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
+    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, w.slab);
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, p.nsplit, p.ntiles, M, sf2 * sf2, Phi);
-  finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.bpart, p.nsplit, p.Mp, M, w.yypart, 256, sf2,
+  finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, M, w.yypart, 256, sf2,
                                                          sf2 * (double)N, b, yy, kappa);
   return check_launch();
 }

@@ -74,8 +74,15 @@ class HipEngine:
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
 
     # ------------------------------------------------------------------ pass 1
-    def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Packed local statistics [Phi (M*M) | b (M) | yy | kappa] -- the buffer the all-reduce sums."""
+    def kfu_buffer(self, N: int, M: int) -> torch.Tensor:
+        """Caller-owned K'_fu block (see include/sgp.h: sgp_kfu_len) for ``suffstats(..., kfu=)``."""
+        return self.empty(self.lib.sgp_kfu_len(N, M))
+
+    def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out: Optional[torch.Tensor] = None,
+                  kfu: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Packed local statistics [Phi (M*M) | b (M) | yy | kappa] -- the buffer the all-reduce sums.
+
+        ``kfu`` (optional, from ``kfu_buffer``) keeps the assembled kernel block for ``suffstats_bwd``."""
         N, d = X.shape
         M = Z.shape[0]
         self._chk(Z, "Z")
@@ -91,7 +98,7 @@ class HipEngine:
         st = self.lib.sgp_suffstats_fwd(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), N, M, d, _kernel_id(kernel),
             C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
-            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(ws), ws.numel(), self._stream())
+            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_fwd", st)
         return out
 
@@ -136,7 +143,7 @@ class HipEngine:
 
     # ------------------------------------------------------------------ pass 2
     def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      out: Optional[torch.Tensor] = None, kfu: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Packed local gradients [g_ls (d) | g_sf2 | g_Z (M*d, only when want_gz)]."""
         N, d = X.shape
         M = Z.shape[0]
@@ -147,7 +154,8 @@ class HipEngine:
         base = out.data_ptr()
         st = self.lib.sgp_suffstats_bwd(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), self._ptr(Phibar),
-            self._ptr(bbar), float(kappabar), N, M, d, _kernel_id(kernel), C.c_void_p(base), C.c_void_p(base + 8 * d),
+            self._ptr(bbar), float(kappabar), self._ptr(kfu), N, M, d, _kernel_id(kernel), C.c_void_p(base),
+            C.c_void_p(base + 8 * d),
             C.c_void_p(base + 8 * (d + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_bwd", st)
         return out

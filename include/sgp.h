@@ -74,13 +74,23 @@ const char* sgp_status_string(int status);
  * Phi = Kuf Kuf^T (M x M, ld M, full symmetric), b = Kuf y (M), yy = y^T y, kappa = sum_n k(x_n,x_n).
  * Replaces the N x M kernel matrix + N M^2 contraction inside InducingPointKernel /
  * ExactMarginalLogLikelihood (models/sgpr.py:37,125) and MarginalSparse (models/bayesian_sgpr_hmc.py:71).
- * Kuf is never materialised.  On several GPUs every rank calls this on its own rows and the
+ * Two kernels: "kernel assembly" (K'_fu written once, HBM-write bound) and "contraction" (SYRK on the
+ * fp64 matrix cores reading it back).  On several GPUs every rank calls this on its own rows and the
  * caller all-reduces [Phi | b | yy | kappa].  N == 0 is allowed (all outputs zero).             */
 size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d);
+/* doubles in the materialised K'_fu block of an N-row shard: roundup(N,256) x roundup(M,128), row-major.
+ * K'_fu[n][m] = k(x_n, z_m) / sf2 (zero in the padding) -- the reference's K_fu (N x M) without the
+ * output scale.  Optional: a caller that passes such a buffer as Kfu_out keeps the assembled block and
+ * can hand it to sgp_suffstats_bwd (same X, Z, inv_ls, kernel_id) so pass 2 does not re-assemble it.
+ * With Kfu_out == NULL the library assembles into `ws`, at most 16 GiB of rows at a time.            */
+size_t sgp_kfu_len(int64_t N, int M);
+/* bytes of K'_fu the library materialises at a time when it owns the buffer (default 16 GiB; 0 restores
+ * the default).  Process-wide; changes what the *_workspace_bytes queries return.                     */
+void sgp_set_kfu_budget_bytes(size_t bytes);
 int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y,
                       const double* Z, int64_t ldz, const double* inv_ls, double sf2,
                       int64_t N, int M, int d, int kernel_id,
-                      double* Phi, double* b, double* yy, double* kappa,
+                      double* Phi, double* b, double* yy, double* kappa, double* Kfu_out,
                       void* ws, size_t ws_bytes, sgp_stream_t stream);
 
 /* ---- inducing block: Kuu = k(Z,Z) + jitter I  (M x M, ld M) -----------------------------------
@@ -120,6 +130,7 @@ size_t sgp_suffstats_bwd_workspace_bytes(int64_t N, int M, int d);
 int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y,
                       const double* Z, int64_t ldz, const double* inv_ls, double sf2,
                       const double* Phibar, const double* bbar, double kappabar,
+                      const double* Kfu_in /* from sgp_suffstats_fwd's Kfu_out, or NULL */,
                       int64_t N, int M, int d, int kernel_id,
                       double* g_ls, double* g_sf2, double* g_Z,
                       void* ws, size_t ws_bytes, sgp_stream_t stream);

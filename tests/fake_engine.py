@@ -27,7 +27,7 @@ class OracleEngine:
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float64)
 
-    def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out=None):
+    def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out=None, kfu=None):
         self.calls["suffstats"] += 1
         M, d = Z.shape
         if X.shape[0] == 0:
@@ -70,7 +70,7 @@ class OracleEngine:
             res["factors"] = torch.cat([Linv.reshape(-1), G.reshape(-1), r["q"]])
         return res
 
-    def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False, out=None):
+    def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False, out=None, kfu=None):
         self.calls["suffstats_bwd"] += 1
         M, d = Z.shape
         lst = self._ls(ls, d)

@@ -229,3 +229,36 @@ def test_c5_bound_matches_chunked_oracle_on_subsample(engine):
     F, _ = cb.value(Z, [2.0] * 8, 1.0, 0.09)
     F_ref = O.vfe_pymc3_order_chunked(X.cpu(), y.cpu(), Z.cpu(), torch.full((8,), 2.0, dtype=torch.float64), 1.0, 0.3, 1e-6)
     assert abs(F - F_ref) < 1e-8 * abs(F_ref), (F, F_ref)
+
+
+def test_streaming_without_resident_kfu_and_with_super_chunks(engine):
+    """Three ways to hold K'_fu must agree bit for bit in pass 1 and to rounding in pass 2: caller-owned block,
+    library-owned single block, library-owned super-chunks (budget shrunk so 5 000 rows need several)."""
+    from oracle import vfe_oracle as O
+    g = torch.Generator().manual_seed(5)
+    N, M, d = 5000, 140, 3
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
+    ls = [1.1, 0.8, 1.4]
+    Pb = torch.randn(M, M, dtype=torch.float64, generator=g)
+    Pb = (Pb + Pb.T).to(engine.device).contiguous()
+    bb = torch.randn(M, dtype=torch.float64, generator=g).to(engine.device)
+    kfu = engine.kfu_buffer(N, M)
+    p_own = engine.suffstats(X, y, Z, ls, 1.3, "rbf", kfu=kfu).clone()
+    g_own = engine.suffstats_bwd(X, y, Z, ls, 1.3, Pb, bb, -0.7, "rbf", want_gz=True, kfu=kfu).clone()
+    p_lib = engine.suffstats(X, y, Z, ls, 1.3, "rbf").clone()
+    g_lib = engine.suffstats_bwd(X, y, Z, ls, 1.3, Pb, bb, -0.7, "rbf", want_gz=True).clone()
+    assert torch.equal(p_own, p_lib) and torch.equal(g_own, g_lib)
+    # K'_fu itself against the oracle's kernel matrix
+    Kref = O.kern(X.cpu(), Z.cpu(), torch.tensor(ls, dtype=torch.float64), 1.0)
+    Kdev = kfu.reshape(-1, 256)[:N, :M].cpu()
+    assert float((Kdev - Kref).abs().max()) < 1e-14
+    try:
+        engine.lib.sgp_set_kfu_budget_bytes(1024 * 256 * 8)  # 1024 rows of a 256-column block at a time
+        p_sc = engine.suffstats(X, y, Z, ls, 1.3, "rbf").clone()
+        g_sc = engine.suffstats_bwd(X, y, Z, ls, 1.3, Pb, bb, -0.7, "rbf", want_gz=True).clone()
+    finally:
+        engine.lib.sgp_set_kfu_budget_bytes(0)
+    assert float((p_sc - p_lib).abs().max() / p_lib.abs().max()) < 1e-13
+    assert float((g_sc - g_lib).abs().max() / g_lib.abs().max()) < 1e-12
