@@ -152,6 +152,7 @@ __device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD]
     const int i = r / s, j = r - i * s;
     const int o = pr * 2 * s;
     double acc = 0.0;
+#pragma unroll 8
     for (int q = j; q < s; ++q) acc = fma(S[o + s + i][o + q], Inv[o + q][o + j], acc);  // Inv11 lower: q >= j
     T[o + s + i][o + j] = acc;
   }
@@ -161,6 +162,7 @@ __device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD]
     const int i = r / s, j = r - i * s;
     const int o = pr * 2 * s;
     double acc = 0.0;
+#pragma unroll 8
     for (int q = 0; q <= i; ++q) acc = fma(Inv[o + s + i][o + s + q], T[o + s + q][o + j], acc);  // Inv22 lower: q <= i
     Inv[o + s + i][o + j] = -acc;
   }

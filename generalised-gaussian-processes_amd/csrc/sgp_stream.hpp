@@ -46,9 +46,9 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.nsplit = (int)ns;
   p.nmb = p.Mp / TILE;
   const int64_t nblocks = p.sc_rows / TILE;
-  int64_t nsb = (TARGET_WGS + p.nmb - 1) / p.nmb;
-  if (nsb > nblocks) nsb = nblocks;
-  if (nsb < 1) nsb = 1;
+  int64_t nsb = 8 * ((TARGET_WGS + 8 * p.nmb - 1) / (8 * p.nmb));  // multiple of 8: one XCD per residue
+  const int64_t limb = round_up64(nblocks > 0 ? nblocks : 1, 8);
+  if (nsb > limb) nsb = limb;
   p.nsplit_b = (int)nsb;
   return p;
 }

@@ -15,11 +15,11 @@
 //     double buffered; 4 waves x 16 MFMA tiles as in pass 1;
 //   * epilogue: C^T passes through LDS (re-using the main-loop buffers) in two 64-row halves so that every
 //     thread owns ONE inducing column m again (z~_m in registers) and walks 32 wave-uniform data rows
-//     (x~_n, y_n through the scalar cache, K'_fu[n][m] from memory, coalesced): it forms
-//     dF/dK = 2 sf2 C + bbar_m y_n, dF/dr2 = dF/dK sf2 dk'/dr2 (no exp: dk'/dr2 follows from k') and keeps
+//     (x~_n, y_n through the scalar cache): it recomputes k', dk'/dr2 for its own (n, m) -- once per
+//     element, no redundancy -- forms dF/dK = 2 sf2 C + bbar_m y_n, dF/dr2 = dF/dK sf2 dk'/dr2 and keeps
 //     its dF/dZ, dF/dl, dF/dsf2 sums in registers -- no atomics, per-split partials summed in a fixed order;
-//   * blockIdx.x enumerates mb fastest: with round-robin XCD dispatch all workgroups of one mb share one XCD
-//     whose L2 keeps that block's 1 MB slab of Phibar resident (speed only).
+//   * workgroup ids are laid out so that the column blocks of one split share an XCD (round-robin dispatch):
+//     its L2 then serves the re-reads of every K'_fu row block (speed only, never correctness).
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
 
@@ -67,15 +67,19 @@ template <int DP, int KID>
 __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     const double* __restrict__ Kfu, const double* __restrict__ Xs, const double* __restrict__ ys,
     const double* __restrict__ Zs, const double* __restrict__ Pb, const double* __restrict__ bb, double sf2,
-    int64_t row0, int64_t nblocks, int bps, int M, int Mp, int nmb, int want_gz, int accumulate,
-    double* __restrict__ gzpart, double* __restrict__ glpart) {
+    int64_t row0, int64_t nblocks, int bps, int64_t N, int M, int Mp, int nmb, int want_gz, int accumulate,
+    double* __restrict__ gacc, double* __restrict__ gzpart, double* __restrict__ glpart) {
   __shared__ double smem[BSM];
   double (*At)[TILE][ALD] = reinterpret_cast<double (*)[TILE][ALD]>(smem);               // [2][128][17]
   double (*Bt)[BK][BROW] = reinterpret_cast<double (*)[BK][BROW]>(smem + 2 * A_DBL);     // [2][16][144]
   double (*Ct)[CS] = reinterpret_cast<double (*)[CS]>(smem);                             // [64][129], epilogue only
 
-  const int mb = blockIdx.x % nmb;
-  const int split = blockIdx.x / nmb;
+  // id -> (xcd, column block, split group): the nmb column blocks of one split share id % 8, i.e. one XCD
+  // under round-robin dispatch, whose L2 then serves the nmb re-reads of every K'_fu row block
+  const int xcd = blockIdx.x & 7;
+  const int jj = blockIdx.x >> 3;
+  const int mb = jj % nmb;
+  const int split = (jj / nmb) * 8 + xcd;
   const int64_t nb0 = (int64_t)split * bps;
   const int64_t nb1 = (nb0 + bps < nblocks) ? nb0 + bps : nblocks;
   const int m0 = mb * TILE;
@@ -97,41 +101,46 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     acol[i] = (q & 7) * 2;
   }
 
-  double zrow[DP], gl[DP], gz[DP];
-#pragma unroll
-  for (int j = 0; j < DP; ++j) {
-    zrow[j] = Zs[(size_t)(m0 + erow) * DP + j];
-    gl[j] = 0.0;
-    gz[j] = 0.0;
-  }
-  double gs = 0.0;
+  // Raw gradient sums of this thread's inducing column (scaled by the reduce kernel).  They live in a
+  // per-workgroup global scratch line (L2 resident, touched once per 128-row block) instead of registers:
+  // with 128 accumulator VGPRs and two prefetch stages the main loop has no room for 2 DP + 1 more.
+  double* gmine = gacc + (size_t)blockIdx.x * (2 * DP + 1) * 256 + tid;
   const double bbm = bb[m0 + erow];
+  const double mmask = (m0 + erow) < M ? 1.0 : 0.0;
+
+  // per-thread element offsets (32-bit) relative to wave-uniform slab bases: one VGPR per address
+  int aoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = arow[i] * Mp + acol[i];
+  const int poff = prow * Mp + pcol;
 
   for (int64_t nb = nb0; nb < nb1; ++nb) {
     const int64_t r0 = nb * TILE;  // first row of this data block inside Kfu
     const double* Ablk = Kfu + r0 * Mp;
 
-    d2 av[4];
-    double pv[8];
-    auto fetch = [&](int ch) {
+    // K'_fu comes from HBM: two register stages (loads of slab ch+2 are issued before the MFMAs of slab
+    // ch and written to LDS after the MFMAs of slab ch+1).  Phibar is L2/MALL resident: one stage.
+    d2 avA[4], avB[4], pv[4];
+    auto fetchA = [&](int ch, d2 (&av)[4]) {
+      const double* ab = Ablk + ch * BK;  // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const d2*>(Ablk + (int64_t)arow[i] * Mp + ch * BK + acol[i]);
-      const double* s = Pb + (int64_t)(ch * BK + prow) * Mp + m0 + pcol;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const d2 x = *reinterpret_cast<const d2*>(s + 2 * e);
-        pv[2 * e] = x[0];
-        pv[2 * e + 1] = x[1];
-      }
+      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const d2*>(ab + aoff[i]);
     };
-    auto stash = [&](int buf) {
+    auto fetchP = [&](int ch) {
+      const double* pb = Pb + (int64_t)ch * BK * Mp + m0;  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pv[e] = *reinterpret_cast<const d2*>(pb + poff + 2 * e);
+    };
+    auto stashA = [&](int buf, const d2 (&av)[4]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         At[buf][arow[i]][acol[i]] = av[i][0];
         At[buf][arow[i]][acol[i] + 1] = av[i][1];
       }
+    };
+    auto stashP = [&](int buf) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Bt[buf][prow][pcol + e] = pv[e];
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<d2*>(&Bt[buf][prow][pcol + 2 * e]) = pv[e];
     };
 
     d4 acc[4][4];
@@ -140,12 +149,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < nchunks) fetch(ch + 1);
+    auto mfma_slab = [&](int buf) {
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         double a[4], bq[4];
@@ -158,11 +162,41 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
 #pragma unroll
           for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
       }
-      if (ch + 1 < nchunks) stash(buf ^ 1);
+    };
+
+    fetchA(0, avA);
+    fetchP(0);
+    stashA(0, avA);
+    stashP(0);
+    fetchA(1, avB);  // nchunks = Mp / 16 is a multiple of 8
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      if (ch + 2 < nchunks) fetchA(ch + 2, avA);
+      fetchP(ch + 1);
+      mfma_slab(0);
+      stashA(1, avB);
+      stashP(1);
+      __syncthreads();
+      if (ch + 3 < nchunks) fetchA(ch + 3, avB);
+      if (ch + 2 < nchunks) fetchP(ch + 2);
+      mfma_slab(1);
+      if (ch + 2 < nchunks) {
+        stashA(0, avA);
+        stashP(0);
+      }
       __syncthreads();
     }
 
     // ---- epilogue: two 64-row halves of C^T through LDS, thread <-> inducing column ----------------
+    double zrow[DP], gl[DP], gz[DP], gs;
+    const bool first = nb == nb0;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      zrow[j] = Zs[(size_t)(m0 + erow) * DP + j];
+      gl[j] = first ? 0.0 : gmine[(size_t)j * 256];
+      gz[j] = (first || !want_gz) ? 0.0 : gmine[(size_t)(DP + j) * 256];
+    }
+    gs = first ? 0.0 : gmine[(size_t)(2 * DP) * 256];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (wi == h) {
@@ -177,10 +211,8 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
 #pragma unroll 2
       for (int i = 0; i < 32; ++i) {
         const int nl = half * 32 + i;                       // wave-uniform row inside this half
-        const int64_t rr = r0 + h * 64 + nl;                // row inside Kfu
-        const int64_t n = row0 + rr;                        // global (padded) data row
+        const int64_t n = row0 + r0 + h * 64 + nl;          // global (padded) data row
         const double* __restrict__ xq = Xs + n * DP;        // -> scalar loads
-        const double kp = Kfu[rr * Mp + m0 + erow];         // k'(x_n, z_m); zero in the padding
         double df[DP];
         double r2 = 0.0;
 #pragma unroll
@@ -188,9 +220,14 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
           df[j] = zrow[j] - xq[j];
           r2 = fma(df[j], df[j], r2);
         }
-        const double kbar = 2.0 * sf2 * Ct[nl][erow] + bbm * ys[n];  // dF/dK[m][n]
+        // k' and dk'/dr2 are recomputed (one exp, ~22 fp64 VALU ops) rather than re-read from K'_fu:
+        // cheaper than a dependent 8-byte-per-lane global load in this loop
+        double kp, hp;
+        kprofile_grad<KID>(r2, kp, hp);
+        const double msk = n < N ? mmask : 0.0;
+        const double kbar = (2.0 * sf2 * Ct[nl][erow] + bbm * ys[n]) * msk;  // dF/dK[m][n]
         gs = fma(kbar, kp, gs);
-        const double E = kbar * sf2 * hprime_from_k<KID>(kp, r2);    // dF/d r2[m][n]
+        const double E = kbar * sf2 * hp;                                    // dF/d r2[m][n]
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
           const double t = E * df[j];
@@ -200,9 +237,25 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
       }
       __syncthreads();
     }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      gmine[(size_t)j * 256] = gl[j];
+      if (want_gz) gmine[(size_t)(DP + j) * 256] = gz[j];
+    }
+    gmine[(size_t)(2 * DP) * 256] = gs;
   }
 
   // ---- per-(split, mb) partials ----------------------------------------------------------------------
+  double gl[DP], gz[DP], gs;
+  {
+    const bool any = nb0 < nb1;  // this thread's own stores: no fence needed to read them back
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      gl[j] = any ? gmine[(size_t)j * 256] : 0.0;
+      gz[j] = (any && want_gz) ? gmine[(size_t)(DP + j) * 256] : 0.0;
+    }
+    gs = any ? gmine[(size_t)(2 * DP) * 256] : 0.0;
+  }
   double* scratch = smem;
   if (want_gz) {
 #pragma unroll
@@ -240,13 +293,18 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const double* __restric
                                                          double kappa_term, double* __restrict__ g_ls,
                                                          double* __restrict__ g_sf2, double* __restrict__ g_Z) {
   const int d = ka.d;
+  __shared__ double red[4];
   if (blockIdx.x == 0) {
-    if ((int)threadIdx.x <= d) {
-      const int j = (int)threadIdx.x == d ? DP : threadIdx.x;
+    const int np = nsplit * nmb;
+    for (int q = 0; q <= d; ++q) {  // fixed thread <-> partial mapping and a fixed tree: deterministic
+      const int j = q == d ? DP : q;
       double s = 0.0;
-      for (int p = 0; p < nsplit * nmb; ++p) s += glpart[(size_t)p * (DP + 1) + j];
-      if ((int)threadIdx.x == d) *g_sf2 = s + kappa_term;
-      else g_ls[threadIdx.x] = -2.0 * ka.inv_ls[threadIdx.x] * s;
+      for (int p = threadIdx.x; p < np; p += 256) s += glpart[(size_t)p * (DP + 1) + j];
+      s = block_sum256(s, red);
+      if (threadIdx.x == 0) {
+        if (q == d) *g_sf2 = s + kappa_term;
+        else g_ls[q] = -2.0 * ka.inv_ls[q] * s;
+      }
     }
   }
   if (g_Z) {
@@ -254,6 +312,7 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const double* __restric
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
       const int m = (int)(e / d), j = (int)(e - (int64_t)m * d);
       double s = 0.0;
+#pragma unroll 8
       for (int sp = 0; sp < nsplit; ++sp) s += gzpart[((size_t)sp * Mp + m) * DP + j];
       g_Z[e] = 2.0 * ka.inv_ls[j] * s;
     }
@@ -261,7 +320,7 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const double* __restric
 }
 
 struct BwdWs {
-  double *Xs, *ys, *Zs, *Pb, *bb, *gzpart, *glpart, *bpart, *yypart, *Kfu;
+  double *Xs, *ys, *Zs, *Pb, *bb, *gzpart, *glpart, *gacc, *bpart, *yypart, *Kfu;
   size_t bytes;
 };
 static BwdWs carve_bwd(void* ws, const StreamPlan& p, bool need_kfu) {
@@ -274,6 +333,7 @@ static BwdWs carve_bwd(void* ws, const StreamPlan& p, bool need_kfu) {
   w.bb = c.take<double>((size_t)p.Mp);
   w.gzpart = c.take<double>((size_t)p.nsplit_b * p.Mp * p.DP);
   w.glpart = c.take<double>((size_t)p.nsplit_b * p.nmb * (p.DP + 1));
+  w.gacc = c.take<double>((size_t)p.nsplit_b * p.nmb * (2 * p.DP + 1) * 256);
   w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
@@ -283,8 +343,8 @@ static BwdWs carve_bwd(void* ws, const StreamPlan& p, bool need_kfu) {
 
 template <int DP>
 static void launch_bwd(int kid, int grid, hipStream_t st, const double* Kfu, const BwdWs& w, double sf2, int64_t row0,
-                       int64_t nblocks, int bps, int M, const StreamPlan& p, int want_gz, int accumulate) {
-#define SGP_BWD_ARGS Kfu, w.Xs, w.ys, w.Zs, w.Pb, w.bb, sf2, row0, nblocks, bps, M, p.Mp, p.nmb, want_gz, accumulate, w.gzpart, w.glpart
+                       int64_t nblocks, int bps, int64_t N, int M, const StreamPlan& p, int want_gz, int accumulate) {
+#define SGP_BWD_ARGS Kfu, w.Xs, w.ys, w.Zs, w.Pb, w.bb, sf2, row0, nblocks, bps, N, M, p.Mp, p.nmb, want_gz, accumulate, w.gacc, w.gzpart, w.glpart
   switch (kid) {
     case SGP_KERNEL_RBF: kbar_contract_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;
     case SGP_KERNEL_MATERN32: kbar_contract_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;
@@ -335,12 +395,12 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
     int bps = (int)((nblocks + p.nsplit_b - 1) / p.nsplit_b);
     if (bps < 1) bps = 1;
     switch (p.DP) {
-      case 2: launch_bwd<2>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, M, p, want_gz, accumulate); break;
-      case 4: launch_bwd<4>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, M, p, want_gz, accumulate); break;
-      case 8: launch_bwd<8>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, M, p, want_gz, accumulate); break;
-      case 16: launch_bwd<16>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, M, p, want_gz, accumulate); break;
-      case 24: launch_bwd<24>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, M, p, want_gz, accumulate); break;
-      default: launch_bwd<32>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, M, p, want_gz, accumulate); break;
+      case 2: launch_bwd<2>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, N, M, p, want_gz, accumulate); break;
+      case 4: launch_bwd<4>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, N, M, p, want_gz, accumulate); break;
+      case 8: launch_bwd<8>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, N, M, p, want_gz, accumulate); break;
+      case 16: launch_bwd<16>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, N, M, p, want_gz, accumulate); break;
+      case 24: launch_bwd<24>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, N, M, p, want_gz, accumulate); break;
+      default: launch_bwd<32>(kernel_id, grid, st, Kfu, w, sf2, row0, nblocks, bps, N, M, p, want_gz, accumulate); break;
     }
   };
   if (p.Npad == 0) launch(nullptr, 0, 0, 0);  // empty shard: writes zero partials

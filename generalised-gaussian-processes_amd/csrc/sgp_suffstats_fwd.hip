@@ -65,17 +65,15 @@ __global__ __launch_bounds__(256) void prep_y_kernel(const double* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // 1. kernel assembly:  Kfu[n][m] = k'(x_n, z_m)   (no sf2; zero in the padding)
-//    grid = (rows / ASM_ROWS, Mp / 128): a workgroup owns 128 columns x 256 rows, its two thread halves
-//    take alternate data rows.  bpart[rowblock][m] = sum_n Kfu[n][m] y[n] over this block's rows.
+//    grid = (rows / ASM_ROWS, ceil(Mp / 256)): a workgroup owns 256 columns x 256 rows; every wave stores
+//    512 contiguous bytes per data row, a workgroup 2 KB.  bpart[rowblock][m] = sum_n Kfu[n][m] y[n].
 // ---------------------------------------------------------------------------------------------
 template <int DP, int KID>
 __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
                                                            const double* __restrict__ Zs, int64_t row0, int64_t N, int M,
                                                            int Mp, double* __restrict__ Kfu, double* __restrict__ bpart) {
-  __shared__ double bsh[256];
-  const int tid = threadIdx.x;
-  const int nsub = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: which of the two row phases
-  const int m = blockIdx.y * TILE + (tid & 127);
+  const int m = blockIdx.y * 256 + threadIdx.x;
+  if (m >= Mp) return;                                   // Mp is a multiple of 128: whole waves drop out
   const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;  // row inside this super-chunk's Kfu
   const double zmask = m < M ? 1.0 : 0.0;
 
@@ -85,7 +83,7 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
 
   double bacc = 0.0;
 #pragma unroll 4
-  for (int i = nsub; i < ASM_ROWS; i += 2) {
+  for (int i = 0; i < ASM_ROWS; ++i) {
     const int64_t n = row0 + rbase + i;                    // global data row, wave-uniform
     const double* __restrict__ xr = Xs + n * DP;           // -> scalar loads
     double r2 = 0.0;
@@ -99,9 +97,7 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
     Kfu[(rbase + i) * Mp + m] = kv;
     bacc = fma(kv, ys[n], bacc);
   }
-  bsh[tid] = bacc;
-  __syncthreads();
-  if (tid < TILE) bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bsh[tid] + bsh[tid + TILE];
+  bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bacc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -136,15 +132,17 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
       goff[i] = (int64_t)srow[i] * Mp + (r < 64 ? I0 + r * 2 : J0 + (r - 64) * 2);
     }
   }
-  d2 stage[NQ];
-  auto fetch = [&](int64_t c) {
+  // Two register stages: the loads of chunk c+2 are issued before the MFMAs of chunk c and consumed
+  // (written to LDS) after the MFMAs of chunk c+1 -- two MFMA phases of latency cover.
+  d2 stA[NQ], stB[NQ];
+  auto fetch = [&](int64_t c, d2 (&st)[NQ]) {
     const double* base = Kfu + c * NB * Mp;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) stage[i] = *reinterpret_cast<const d2*>(base + goff[i]);
+    for (int i = 0; i < NQ; ++i) st[i] = *reinterpret_cast<const d2*>(base + goff[i]);
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const d2 (&st)[NQ]) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) *reinterpret_cast<d2*>(&Ks[buf][srow[i]][scol[i]]) = stage[i];
+    for (int i = 0; i < NQ; ++i) *reinterpret_cast<d2*>(&Ks[buf][srow[i]][scol[i]]) = st[i];
   };
 
   d4 acc[4][4];
@@ -153,36 +151,47 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
-  const bool skip_mfma = DIAG && wi == 0 && wj == 1;  // strictly-upper 64x64 block of a diagonal tile
+  auto mfma_chunk = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      const double* kr = &Ks[buf][ks * 4 + l4][0];
+      double a[4], bq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = kr[wi * 64 + u * 16 + l15];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bq[v] = kr[boff + wj * 64 + v * 16 + l15];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
+    }
+  };
 
+  // Diagonal tiles compute their strictly-upper 64 x 64 block too (3 % extra flops): every workgroup of a
+  // split then takes the same time per chunk, the tiles of a split stay in step and re-reads of a K' row
+  // block by its 8-9 consumers hit the XCD's L2 instead of drifting apart.
   if (c0 < c1) {
-    fetch(c0);
-    stash(0);
+    fetch(c0, stA);
+    stash(0, stA);
+    if (c0 + 1 < c1) fetch(c0 + 1, stB);
     __syncthreads();
-    for (int64_t c = c0; c < c1; ++c) {
-      const int buf = (int)((c - c0) & 1);
-      if (c + 1 < c1) fetch(c + 1);
-      if (!skip_mfma) {
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-          const double* kr = &Ks[buf][ks * 4 + l4][0];
-          double a[4], bq[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) a[u] = kr[wi * 64 + u * 16 + l15];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) bq[v] = kr[boff + wj * 64 + v * 16 + l15];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
-        }
-      }
-      if (c + 1 < c1) stash(buf ^ 1);
+    // invariant at the top of iteration c: LDS buffer (c-c0)&1 holds chunk c; chunk c+1 is in flight / in
+    // stage B (even trips) or stage A (odd trips)
+    int64_t c = c0;
+    for (; c + 1 < c1; c += 2) {
+      if (c + 2 < c1) fetch(c + 2, stA);
+      mfma_chunk(0);
+      stash(1, stB);  // chunk c+1
+      __syncthreads();
+      if (c + 3 < c1) fetch(c + 3, stB);
+      mfma_chunk(1);
+      if (c + 2 < c1) stash(0, stA);  // chunk c+2
       __syncthreads();
     }
+    if (c < c1) mfma_chunk(0);  // odd chunk count: the last chunk sits in buffer 0
   }
 
-  if (!skip_mfma) {
+  {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -259,14 +268,30 @@ __global__ __launch_bounds__(256) void reduce_phi_kernel(const double* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ bpart, int64_t nrb, int Mp, int M,
+// stage 1 of the b reduction: tmp[g][m] = sum of bpart rows g, g + G, g + 2G, ...  (grid = (Mp / 64, G);
+// a block owns 64 columns, its 4 waves interleave the rows and combine through LDS in a fixed order)
+__global__ __launch_bounds__(256) void bpart_stage1_kernel(const double* __restrict__ bpart, int64_t nrb, int Mp, int G,
+                                                           double* __restrict__ tmp) {
+  __shared__ double part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, g = blockIdx.y;
+  double s = 0.0;
+  for (int64_t rb = g + (int64_t)w * G; rb < nrb; rb += 4 * (int64_t)G) s += bpart[rb * Mp + col];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0) {
+    const int l = threadIdx.x;
+    tmp[(size_t)g * Mp + col] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+  }
+}
+
+__global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ btmp, int G, int Mp, int M,
                                                              const double* __restrict__ yypart, int nyy, double sf2,
                                                              double kappa_val, double* __restrict__ b,
                                                              double* __restrict__ yy, double* __restrict__ kappa) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m < M) {
     double s = 0.0;
-    for (int64_t rb = 0; rb < nrb; ++rb) s += bpart[rb * Mp + m];
+    for (int g = 0; g < G; ++g) s += btmp[(size_t)g * Mp + m];
     b[m] = s * sf2;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -290,7 +315,7 @@ static void launch_assemble(int kid, dim3 grid, hipStream_t st, const double* Xs
 // Assemble rows [row0, row0 + rows) of K'_fu (rows a multiple of ASM_ROWS) into Kfu (which starts at row0).
 void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0,
                      int64_t rows, int64_t N, int M, double* Kfu, double* bpart, hipStream_t st) {
-  dim3 grid((unsigned)(rows / ASM_ROWS), p.Mp / TILE);
+  dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256);
   switch (p.DP) {
     case 2: launch_assemble<2>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
     case 4: launch_assemble<4>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
@@ -313,8 +338,9 @@ void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, i
   prep_y_kernel<<<256, 256, 0, st>>>(y, N, p.Npad, ys, yypart);
 }
 
+constexpr int BRED_G = 64;  // row groups of the two-stage b reduction
 struct FwdWs {
-  double *Xs, *ys, *Zs, *Kfu, *slab, *bpart, *yypart;
+  double *Xs, *ys, *Zs, *Kfu, *slab, *bpart, *btmp, *yypart;
   size_t bytes;
 };
 static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
@@ -325,6 +351,7 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
   w.Zs = c.take<double>((size_t)p.Mp * p.DP);
   w.slab = c.take<double>((size_t)p.nsplit * p.ntiles * TILE * TILE);
   w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
+  w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
   w.bytes = c.used();
@@ -383,7 +410,8 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, p.nsplit, p.ntiles, M, sf2 * sf2, Phi);
-  finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, M, w.yypart, 256, sf2,
+  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);
+  finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.btmp, BRED_G, p.Mp, M, w.yypart, 256, sf2,
                                                          sf2 * (double)N, b, yy, kappa);
   return check_launch();
 }

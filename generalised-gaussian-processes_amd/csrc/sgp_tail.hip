@@ -92,12 +92,17 @@ __global__ __launch_bounds__(256) void kuu_bwd_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __restrict__ part, const double* __restrict__ gzraw,
                                                              int M, KernArgs ka, double* g_ls, double* g_sf2, double* g_Z) {
   const int d = ka.d;
-  if (blockIdx.x == 0 && (int)threadIdx.x <= d) {
-    const int q = threadIdx.x;
-    double s = 0.0;
-    for (int m = 0; m < M; ++m) s += part[(size_t)m * (d + 1) + q];
-    if (q == d) *g_sf2 += s;
-    else g_ls[q] += -2.0 * ka.inv_ls[q] * s;
+  __shared__ double red[4];
+  if (blockIdx.x == 0) {
+    for (int q = 0; q <= d; ++q) {
+      double s = 0.0;
+      for (int m = threadIdx.x; m < M; m += 256) s += part[(size_t)m * (d + 1) + q];
+      s = block_sum256(s, red);
+      if (threadIdx.x == 0) {
+        if (q == d) *g_sf2 += s;
+        else g_ls[q] += -2.0 * ka.inv_ls[q] * s;
+      }
+    }
   }
   if (g_Z) {
     const int64_t total = (int64_t)M * d;
