@@ -28,6 +28,9 @@ M_IND = 1024
 DIM = 8
 LS, SF, SN, JITTER = 2.0, 1.0, 0.3, 1e-6
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= 256 CU x 2.4 GHz x 128 flop/clk/CU); see DESIGN.md
+# HBM bytes one syrk_tile_kernel launch moved at the default config (N=1M, M=1024, 1 GPU), from the PMC passes
+# committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); None for other configs.
+SYRK_TRAFFIC_BYTES_PMC = 4.93e10
 
 
 def synth(n_total, m, d):
@@ -124,23 +127,29 @@ def main():
     evals_per_s = args.steps / dt_val
     leap_per_s = max(2, args.steps // 2) / dt_grad
 
-    # dominant kernel, timed alone with HIP events on the launch stream (pass 1 on this rank's shard)
-    stream = torch.cuda.current_stream(dev)
+    # dominant kernel (the SYRK contraction of pass 1 on this rank's shard), timed alone: the library
+    # records HIP events on the launch stream right around that kernel (include/sgp.h: sgp_timing_*)
+    import ctypes
+    eng.lib.sgp_timing_enable(1)
     packed = eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf")
     torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(3, min(10, args.steps))
-    kern_ms = []
+    syrk_ms, asm_ms = [], []
     for _ in range(reps):
-        e0.record(stream)
         eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf", out=packed)
-        e1.record(stream)
-        e1.synchronize()
-        kern_ms.append(e0.elapsed_time(e1))
-    kern_ms.sort()
-    pass1_ms = kern_ms[len(kern_ms) // 2]
+        t = ctypes.c_float(0.0)
+        assert eng.lib.sgp_timing_last_ms(1, ctypes.byref(t)) == 0
+        syrk_ms.append(t.value)
+        assert eng.lib.sgp_timing_last_ms(0, ctypes.byref(t)) == 0
+        asm_ms.append(t.value)
+    eng.lib.sgp_timing_enable(0)
+    syrk_ms.sort()
+    asm_ms.sort()
+    pass1_ms = syrk_ms[len(syrk_ms) // 2]
+    assemble_ms = asm_ms[len(asm_ms) // 2]
     n_local = hi - lo
     achieved = algorithmic_flops_fwd(n_local, args.m, DIM) / (pass1_ms * 1e-3) / 1e12
+    kfu_bytes = 8.0 * ((n_local + 255) // 256 * 256) * ((args.m + 127) // 128 * 128)
 
     res = {
         "metric": "ELBO evals/sec", "value": evals_per_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
@@ -151,10 +160,15 @@ def main():
                    "theta": {"ls": LS, "sig_f": SF, "sig_n": SN}},
         "leapfrog_per_s": leap_per_s, "ms_per_leapfrog": 1e3 / leap_per_s,
         "F": last["F"], "F_per_datum": last["F"] / args.n,
-        "roofline": {"bound": "mfma", "kernel": "sgp::suffstats_fwd_kernel<8,0> (+ prologue/reduce, pass 1 as launched)",
+        "roofline": {"bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction, this rank's shard)",
                      "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None, "ms": pass1_ms,
-                     "algorithmic_flops": algorithmic_flops_fwd(n_local, args.m, DIM)},
+                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": SYRK_TRAFFIC_BYTES_PMC if (args.n, args.m, world) == (N_TOTAL, M_IND, 1) else None, "ms": pass1_ms,
+                     "algorithmic_flops": algorithmic_flops_fwd(n_local, args.m, DIM),
+                     "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
+                                     "profiles/r01_pmc_*.csv; collected in separate passes, not in this run"},
+        "assembly": {"bound": "hbm", "kernel": "sgp::kfu_assemble_kernel<8,0>", "ms": assemble_ms,
+                     "achieved": kfu_bytes / (assemble_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": kfu_bytes / (assemble_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": kfu_bytes},
     }
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n))

@@ -35,6 +35,8 @@ _dp = C.POINTER(C.c_double)
 PROTOTYPES = {
     "sgp_abi_version": (_i32, []),
     "sgp_status_string": (C.c_char_p, [_i32]),
+    "sgp_timing_enable": (None, [_i32]),
+    "sgp_timing_last_ms": (_i32, [_i32, C.POINTER(C.c_float)]),
     "sgp_suffstats_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_kfu_len": (_sz, [_i64, _i32]),
     "sgp_set_kfu_budget_bytes": (None, [_sz]),

@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Linv
   __shared__ double S[DB][DLD];
   __shared__ double Inv[DB][DLD];
   __shared__ double T[DB][DLD];
-  __shared__ double dg[DB];
   __shared__ int bad;
   const int tid = threadIdx.x;
   if (tid == 0) bad = 0;
@@ -205,24 +204,46 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Linv
     Inv[i][j] = 0.0;
   }
   __syncthreads();
-  const int i = tid & 63, pg = tid >> 6;
+  // Register-resident right-looking factorization: thread (i = tid & 63, g = tid >> 6) keeps the 16
+  // elements S[i][g + 4k] of its row; per column j the owning group publishes the raw column through a
+  // double-buffered LDS vector, everybody reads pivot / own-row / partner entries from it and updates
+  // its registers:  a[i][p] -= col[i] col[p] / col[j].   One barrier per column, fully unrolled so every
+  // register index is static.
+  const int i = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = S[i][g + 4 * k];
+  double* col = &T[0][0];  // 2 x 64 doubles of scratch inside T
+  __syncthreads();
+#pragma unroll
   for (int j = 0; j < DB; ++j) {
-    double ajj = S[j][j];
-    if (!(ajj > 0.0)) {  // non-positive or NaN pivot: report LAPACK-style, keep going on a unit pivot
+    const int jg = j & 3, jk = j >> 2;
+    double* cb = col + (j & 1) * 64;
+    if (g == jg) cb[i] = a[jk];
+    __syncthreads();
+    double d = cb[j];
+    if (!(d > 0.0)) {  // non-positive or NaN pivot: report LAPACK-style, keep going on a unit pivot
       if (tid == 0 && bad == 0) bad = j + 1;
-      ajj = 1.0;
+      d = 1.0;
     }
-    const double d = sqrt(ajj);
-    if (tid > j && tid < DB) S[tid][j] /= d;
-    if (tid == j) dg[j] = d;
-    __syncthreads();
-    if (i > j) {
-      const double lij = S[i][j];
-      for (int p = j + 1 + pg; p <= i; p += 4) S[i][p] = fma(-lij, S[p][j], S[i][p]);
+    const double ci = cb[i];
+    const double t = ci / d;
+    // columns p = g + 4k > j of this row
+    if (g > jg) a[jk] = fma(-t, cb[g + 4 * jk], a[jk]);
+#pragma unroll
+    for (int k = jk + 1; k < 16; ++k) a[k] = fma(-t, cb[g + 4 * k], a[k]);
+    if (g == jg) {  // final value of L[i][j]
+      const double l = sqrt(d);
+      a[jk] = (i == j) ? l : ci / l;
     }
-    __syncthreads();
   }
-  if (tid < DB) S[tid][tid] = dg[tid];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int p = g + 4 * k;
+    S[i][p] = (p <= i) ? a[k] : 0.0;
+  }
   __syncthreads();
 
   block_inverse64(S, Inv, T);

@@ -53,6 +53,12 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   return p;
 }
 
+// Optional per-kernel timing (sgp_timing_enable): HIP events recorded on the launch stream around the
+// dominant kernels.  Slots: 0 = kernel assembly, 1 = SYRK contraction, 2 = Kbar contraction (pass 2).
+enum { TIMING_ASSEMBLE = 0, TIMING_SYRK = 1, TIMING_KBAR = 2, TIMING_SLOTS = 3 };
+void timing_begin(int slot, hipStream_t st);
+void timing_end(int slot, hipStream_t st);
+
 // implemented in sgp_suffstats_fwd.hip
 void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, int64_t ldx, const double* y,
                      const double* Z, int64_t ldz, int64_t N, int M, double* Xs, double* ys, double* Zs, double* yypart,

@@ -411,7 +411,9 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
       stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Kfu, w.bpart, st);
       Kfu = w.Kfu;
     }
+    timing_begin(TIMING_KBAR, st);
     launch(Kfu, r0, rows / TILE, r0 > 0 ? 1 : 0);
+    timing_end(TIMING_KBAR, st);
   }
   const int64_t tot = (int64_t)M * d;
   const int rg = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);

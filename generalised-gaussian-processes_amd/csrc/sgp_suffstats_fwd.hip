@@ -33,6 +33,24 @@ namespace sgp {
 static size_t g_kfu_budget = KFU_BUDGET_DEFAULT;
 size_t stream_kfu_budget() { return g_kfu_budget; }
 
+static int g_timing = 0;
+static hipEvent_t g_ev[TIMING_SLOTS][2];
+static int g_ev_ready = 0, g_ev_used[TIMING_SLOTS] = {0, 0, 0};
+void timing_begin(int slot, hipStream_t st) {
+  if (!g_timing) return;
+  if (!g_ev_ready) {
+    for (int s = 0; s < TIMING_SLOTS; ++s)
+      for (int k = 0; k < 2; ++k) hipEventCreate(&g_ev[s][k]);
+    g_ev_ready = 1;
+  }
+  hipEventRecord(g_ev[slot][0], st);
+}
+void timing_end(int slot, hipStream_t st) {
+  if (!g_timing) return;
+  hipEventRecord(g_ev[slot][1], st);
+  g_ev_used[slot] = 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // prologue kernels
 // ---------------------------------------------------------------------------------------------
@@ -362,6 +380,15 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
 
 using namespace sgp;
 
+extern "C" void sgp_timing_enable(int on) { g_timing = on; }
+
+extern "C" int sgp_timing_last_ms(int slot, float* ms) {
+  if (slot < 0 || slot >= TIMING_SLOTS || !ms) return SGP_ERR_ARG;
+  if (!g_ev_ready || !g_ev_used[slot]) return SGP_ERR_ARG;
+  if (hipEventSynchronize(g_ev[slot][1]) != hipSuccess) return SGP_ERR_LAUNCH;
+  return hipEventElapsedTime(ms, g_ev[slot][0], g_ev[slot][1]) == hipSuccess ? SGP_OK : SGP_ERR_LAUNCH;
+}
+
 extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { g_kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
 
 extern "C" size_t sgp_kfu_len(int64_t N, int M) {
@@ -403,10 +430,14 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   }
   for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
     const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
+    timing_begin(TIMING_ASSEMBLE, st);
     stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Kfu, w.bpart, st);
+    timing_end(TIMING_ASSEMBLE, st);
     const int64_t nchunks = rows / NB;
     const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
+    timing_begin(TIMING_SYRK, st);
     syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, w.slab);
+    timing_end(TIMING_SYRK, st);
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, p.nsplit, p.ntiles, M, sf2 * sf2, Phi);

@@ -70,6 +70,13 @@ typedef void* sgp_stream_t; /* hipStream_t */
 int sgp_abi_version(void);
 const char* sgp_status_string(int status);
 
+/* Optional measurement aid: with timing enabled the library records HIP events on the launch stream
+ * around its dominant kernels (slot 0 = kernel assembly, 1 = SYRK contraction of pass 1, 2 = Kbar
+ * contraction of pass 2; with several super-chunks the last one).  sgp_timing_last_ms synchronises on
+ * the closing event of the slot and returns the elapsed device time of the most recent launch.        */
+void sgp_timing_enable(int on);
+int sgp_timing_last_ms(int slot, float* ms);
+
 /* ---- streaming pass 1: sufficient statistics over the local row shard -------------------------
  * Phi = Kuf Kuf^T (M x M, ld M, full symmetric), b = Kuf y (M), yy = y^T y, kappa = sum_n k(x_n,x_n).
  * Replaces the N x M kernel matrix + N M^2 contraction inside InducingPointKernel /
