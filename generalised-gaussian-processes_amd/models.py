@@ -1,0 +1,225 @@
+"""Model classes with the reference's signatures, running on the HIP core.
+
+Mirrors (same names, argument meaning, return shapes and error behaviour):
+  * ``SparseGPR``                      reference models/sgpr.py:22-160
+  * ``BayesianSparseGPR_HMC``          reference models/bayesian_sgpr_hmc.py:26-196
+  * ``mixture_posterior_predictive``   reference models/bayesian_sgpr_hmc.py:198-231
+
+Differences that are deliberate and documented: the device is taken from the inputs
+at construction (R16); ``model.inducing_points`` always tracks the optimised Z (R8); ``train_model``
+accepts ``num_steps`` as an alias of ``max_steps`` (R5); the bound subtracts the trace term (R1).
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError
+from .gp_shim import (ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, LazyPredictive,
+                      MultivariateNormal, RBFKernel, ScaleKernel, TrainPrior, ZeroMean)
+from .hmc import Trace, sample_nuts
+
+FULL_COV_MAX_T = 4096  # predictive covariance is T x T; beyond this only mean / variance are formed
+
+
+class SparseGPR(ExactGP):
+    """The sparse GP class for regression with the collapsed bound; q*(u) is implicit (reference models/sgpr.py:22)."""
+
+    def __init__(self, train_x, train_y, likelihood, Z_init, engine=None, jitter: float = 0.0, kernel=None):
+        super().__init__(train_x, train_y, likelihood)
+        if train_x.dim() == 1:
+            train_x = train_x[:, None]
+        self.train_x = train_x
+        self.train_y = train_y
+        self.num_inducing = len(Z_init)
+        self.likelihood = likelihood
+        self.mean_module = ZeroMean()
+        base = kernel if kernel is not None else RBFKernel(ard_num_dims=self.train_x.shape[-1])
+        self.base_covar_module = ScaleKernel(base)
+        self.covar_module = InducingPointKernel(self.base_covar_module, inducing_points=Z_init, likelihood=self.likelihood)
+        self.jitter = float(jitter)
+        self._engine = engine
+        self._cb: Optional[CollapsedBound] = None
+        dev = engine.device if engine is not None else train_x.device
+        self.to(dev)
+
+    # reference attribute: aliases the optimised inducing inputs (not the initial tensor)
+    @property
+    def inducing_points(self):
+        return self.covar_module.inducing_points.data
+
+    def _bound(self) -> CollapsedBound:
+        if self._cb is None:
+            self._cb = CollapsedBound(self.train_x, self.train_y, kernel=self.base_covar_module.base_kernel.kernel_name,
+                                      jitter=self.jitter, engine=self._engine)
+        return self._cb
+
+    def _hypers(self):
+        ls = self.base_covar_module.base_kernel.lengthscale.detach().reshape(-1).tolist()
+        return ls, float(self.base_covar_module.outputscale.detach()), float(self.likelihood.noise.detach())
+
+    def forward(self, x):
+        if self.training:
+            return TrainPrior(self)
+        return LazyPredictive(self, x)
+
+    def _predict(self, test_x, pred_noise=True):
+        if test_x.dim() == 1:
+            test_x = test_x[:, None]
+        ls, sf2, s2 = self._hypers()
+        full = test_x.shape[0] <= FULL_COV_MAX_T
+        mean, var, cov = self._bound().predict(test_x, self.covar_module.inducing_points, ls, sf2, s2,
+                                               pred_noise=pred_noise, full_cov=full)
+        return MultivariateNormal(mean, cov, variance=var)
+
+    def train_model(self, optimizer, combine_terms=True, n_restarts=10, max_steps=10000, num_steps=None, verbose=True):
+        """Full-batch optimisation of -ELBO/N (reference models/sgpr.py:110-144); one list entry per step."""
+        if num_steps is not None:
+            max_steps = num_steps
+        self.train()
+        self.likelihood.train()
+        mll = ExactMarginalLogLikelihood(self.likelihood, self)
+        losses = []
+        for j in range(max_steps):
+            optimizer.zero_grad()
+            output = self.forward(self.train_x)
+            loss = -mll(output, self.train_y).sum()
+            losses.append(loss.item())
+            loss.backward()
+            if verbose and j % 1000 == 0:
+                print('Iter %d/%d - Loss: %.3f   outputscale: %.3f  lengthscale: %s   noise: %.3f ' % (
+                    j + 1, max_steps, loss.item(), self.base_covar_module.outputscale.item(),
+                    self.base_covar_module.base_kernel.lengthscale, self.likelihood.noise.item()))
+            optimizer.step()
+        return losses
+
+    def optimal_q_u(self):
+        was = self.training
+        self.eval()
+        out = self._predict(self.covar_module.inducing_points.detach(), pred_noise=False)
+        self.train(was)
+        return out
+
+    def posterior_predictive(self, test_x):
+        """Returns the posterior predictive multivariate normal (observation noise included)."""
+        self.eval()
+        self.likelihood.eval()
+        with torch.no_grad():
+            y_star = self.likelihood(self(test_x))
+        return y_star
+
+
+class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
+    """Doubly collapsed SGPR: q(u) implicit, theta sampled with NUTS at scheduled iterations
+    (reference models/bayesian_sgpr_hmc.py:26)."""
+
+    def __init__(self, train_x, train_y, likelihood, Z_init, engine=None, jitter: float = 0.0, seed: Optional[int] = None):
+        super().__init__(train_x, train_y, likelihood, Z_init, engine=engine, jitter=jitter)
+        self.data_dim = self.train_x.shape[1]
+        self._hmc_cb: Optional[CollapsedBound] = None
+        self._seed = seed
+        self._n_hmc_calls = 0
+
+    def freeze_kernel_hyperparameters(self):
+        for name, parameter in self.named_hyperparameters():
+            if name != 'covar_module.inducing_points':
+                parameter.requires_grad = False
+
+    def _hmc_bound(self):
+        # PyMC3's MarginalSparse always stabilises Kuu with 1e-6 I (reference models/bayesian_sgpr_hmc.py:66)
+        if self._hmc_cb is None:
+            self._hmc_cb = CollapsedBound(self.train_x, self.train_y, kernel="rbf", jitter=1e-6, engine=self._bound().engine)
+        return self._hmc_cb
+
+    def sample_optimal_variational_hyper_dist(self, n_samples, input_dim, Z_opt, tune, sampler_params=None) -> Trace:
+        """NUTS over (ls, sig_f, sig_n) with Z fixed at Z_opt (reference models/bayesian_sgpr_hmc.py:58-80)."""
+        Z = torch.as_tensor(np.asarray(Z_opt), dtype=torch.float64)
+        target = HmcTarget(self._hmc_bound(), Z)
+        scale = 0.25 if not sampler_params else sampler_params.get('step_scale', 0.25)
+        seed = None if self._seed is None else self._seed + self._n_hmc_calls
+        self._n_hmc_calls += 1
+        return sample_nuts(target, n_samples, tune, seed=seed, step_scale=scale)
+
+    def update_model_to_hyper(self, elbo, hyper_sample):
+        elbo.likelihood.noise_covar.noise = hyper_sample['sig_n'] ** 2
+        elbo.model.base_covar_module.outputscale = hyper_sample['sig_f'] ** 2
+        elbo.model.base_covar_module.base_kernel.lengthscale = hyper_sample['ls']
+
+    def train_model(self, optimizer, max_steps=10000, hmc_scheduler=(200, 500, 1000, 1500), verbose=True,
+                    num_tune_long=100, num_samples_long=20, num_tune_short=25, num_samples_short=10):
+        """Alternates Adam on Z with NUTS on theta (reference models/bayesian_sgpr_hmc.py:88-158).
+        Returns (losses, trace_hyper, trace_step_size, trace_perf_time)."""
+        hmc_scheduler = list(hmc_scheduler)
+        self.train()
+        self.likelihood.train()
+        elbo = ExactMarginalLogLikelihood(self.likelihood, self)
+        losses, trace_hyper, trace_step_size, trace_perf_time = [], None, [], []
+        for n_iter in range(max_steps):
+            optimizer.zero_grad()
+            if n_iter < hmc_scheduler[0]:  # warm start: plain SGPR optimisation
+                output = self(self.train_x)
+                loss = -elbo(output, self.train_y)
+                losses.append(loss.item())
+                loss.backward()
+                optimizer.step()
+            else:
+                self.freeze_kernel_hyperparameters()
+                if trace_hyper is not None:  # stochastic ELBO: average over the current theta samples
+                    loss = 0.0
+                    for i in range(len(trace_hyper)):
+                        self.update_model_to_hyper(elbo, trace_hyper[i])
+                        output = self(self.train_x)
+                        loss = loss + (-elbo(output, self.train_y).sum() / len(trace_hyper))
+                    if verbose:
+                        print('Iter %d/%d - Loss: %.3f ' % (n_iter, max_steps, loss.item()))
+                    losses.append(loss.item())
+                    loss.backward()
+                    optimizer.step()
+                if n_iter in hmc_scheduler:
+                    Z_opt = self.inducing_points.detach().cpu().numpy()
+                    if n_iter in (hmc_scheduler[0], hmc_scheduler[-1]):
+                        num_tune, num_samples = num_tune_long, num_samples_long
+                    else:
+                        num_tune, num_samples = num_tune_short, num_samples_short
+                    trace_hyper = self.sample_optimal_variational_hyper_dist(num_samples, self.data_dim, Z_opt, num_tune,
+                                                                             sampler_params=None)
+                    trace_step_size.append(trace_hyper.get_sampler_stats('step_size')[0])
+                    trace_perf_time.append(trace_hyper.get_sampler_stats('perf_counter_diff').sum())
+        return losses, trace_hyper, trace_step_size, trace_perf_time
+
+    def train_fixed_model(self, num_tune=500, num_samples=500):
+        """HMC over theta with Z fixed at its initial value (reference models/bayesian_sgpr_hmc.py:160-180)."""
+        self.train()
+        self.likelihood.train()
+        Z_opt = self.inducing_points.detach().cpu().numpy()
+        trace_hyper = self.sample_optimal_variational_hyper_dist(num_samples, self.data_dim, Z_opt, num_tune, None)
+        return (trace_hyper, [trace_hyper.get_sampler_stats('step_size')[0]],
+                [trace_hyper.get_sampler_stats('perf_counter_diff').sum()])
+
+
+def mixture_posterior_predictive(model, test_x, trace_hyper):
+    """One predictive per theta sample; samples whose predictive covariance fails the reference's PSD gate
+    (cholesky(cov + 1e-4 I)) are skipped, never raised (reference models/bayesian_sgpr_hmc.py:198-231)."""
+    preds = []
+    for i in range(len(trace_hyper)):
+        hyper_sample = trace_hyper[i]
+        model.train()
+        model.likelihood.train()
+        model.likelihood.noise_covar.noise = hyper_sample['sig_n'] ** 2
+        model.base_covar_module.outputscale = hyper_sample['sig_f'] ** 2
+        model.base_covar_module.base_kernel.lengthscale = hyper_sample['ls']
+        with torch.no_grad():
+            model.eval()
+            model.likelihood.eval()
+            try:
+                pred = model.likelihood(model(test_x))
+                if pred.covariance_matrix is not None:
+                    cov = pred.covariance_matrix.detach().to("cpu")
+                    torch.linalg.cholesky(cov + torch.eye(cov.shape[0], dtype=cov.dtype) * 1e-4)
+                preds.append(pred)
+            except (RuntimeError, NotPositiveDefiniteError):
+                print('Not psd for sample ' + str(i))
+    return preds

@@ -262,3 +262,38 @@ def test_streaming_without_resident_kfu_and_with_super_chunks(engine):
         engine.lib.sgp_set_kfu_budget_bytes(0)
     assert float((p_sc - p_lib).abs().max() / p_lib.abs().max()) < 1e-13
     assert float((g_sc - g_lib).abs().max() / g_lib.abs().max()) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# model classes on the device (reference call pattern: construct -> train_model -> posterior_predictive)
+# ---------------------------------------------------------------------------------------------
+def test_sparse_gpr_training_trace_on_device(engine):
+    import ggp_amd
+    from test_models_hmc import demo_1d, reference_loss_trace
+    X, y, Xt, Z0 = demo_1d()
+    model = ggp_amd.SparseGPR(X.to(engine.device), y.to(engine.device), ggp_amd.GaussianLikelihood(), Z0, engine=engine, jitter=1e-6)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    losses = model.train_model(opt, max_steps=12, verbose=False)
+    ref = reference_loss_trace(X, y, Z0, 12, 0.01, jitter=1e-6)
+    assert np.max(np.abs(np.array(losses[:2]) - np.array(ref[:2]))) < 1e-10
+    assert np.max(np.abs(np.array(losses) - np.array(ref))) < 1e-6
+    pred = model.posterior_predictive(Xt.to(engine.device))
+    assert pred.loc.shape == (200,) and pred.covariance_matrix.shape == (200, 200)
+    assert math.isfinite(float(ggp_amd.nlpd(pred, torch.sin(Xt * 3), torch.tensor([1.0]))))
+
+
+def test_bayesian_sgpr_hmc_on_device(engine):
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    from test_models_hmc import small_problem
+    X, y, Z0, Xt = small_problem()
+    model = ggp_amd.BayesianSparseGPR_HMC(X.to(engine.device), y.to(engine.device), ggp_amd.GaussianLikelihood(), Z0,
+                                          engine=engine, seed=7)
+    trace, steps, perf = model.train_fixed_model(num_tune=40, num_samples=15)
+    assert len(trace) == 15 and np.all(trace["ls"] > 0)
+    th = trace[3]["theta_unc"]
+    lp_ref, _ = O.hmc_logp(torch.tensor(th), X, y, Z0[:, None])
+    assert abs(trace.get_sampler_stats("logp")[3] - lp_ref) < 1e-8 * max(1.0, abs(lp_ref))
+    preds = ggp_amd.mixture_posterior_predictive(model, Xt.to(engine.device), trace)
+    assert 1 <= len(preds) <= 15
+    assert math.isfinite(ggp_amd.nlpd_mixture(preds, torch.sin(Xt), torch.tensor([1.0])))
