@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""BASELINE config C5 as an end-to-end run (call pattern of experiments/large_scale_regression_SGHMC.py:55-206:
+construct -> train_model -> posterior_predictive -> metrics -> JSON), on synthetic N = 1M, d = 8, M = 1024 data
+instead of UCI Elevators (absent, no network).  Optionally continues with a short fixed-Z NUTS run."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ggp_amd  # noqa: E402
+from ggp_amd import BayesianSparseGPR_HMC, GaussianLikelihood, SparseGPR, nlpd_marginal, rmse  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--num_inducing", type=int, default=1024)
+    ap.add_argument("--dim", type=int, default=8)
+    ap.add_argument("--max_iters", type=int, default=50)
+    ap.add_argument("--hmc_samples", type=int, default=0, help="fixed-Z NUTS draws after training (0 = skip)")
+    ap.add_argument("--hmc_tune", type=int, default=10)
+    args = ap.parse_args()
+
+    g = torch.Generator().manual_seed(0)
+    n_test = 10_000
+    X = torch.randn(args.n + n_test, args.dim, dtype=torch.float64, generator=g)
+    w = torch.randn(args.dim, dtype=torch.float64, generator=g) / math.sqrt(args.dim)
+    y = torch.sin(X @ w) + 0.1 * torch.randn(args.n + n_test, dtype=torch.float64, generator=g)
+    mu, sd = y[: args.n].mean(), y[: args.n].std()
+    y = (y - mu) / sd
+    dev = torch.device("cuda", 0)
+    Xtr, ytr, Xte, yte = X[: args.n].to(dev), y[: args.n].to(dev), X[args.n:].to(dev), y[args.n:]
+    Z0 = X[torch.randperm(args.n, generator=g)[: args.num_inducing]].clone()
+
+    model = SparseGPR(Xtr, ytr, GaussianLikelihood(), Z0, jitter=1e-6)
+    model.base_covar_module.base_kernel.lengthscale = 2.0
+    opt = torch.optim.Adam(model.parameters(), lr=0.05)
+    t0 = time.time()
+    losses = model.train_model(opt, max_steps=args.max_iters, verbose=False)
+    wall = time.time() - t0
+    pred = model.posterior_predictive(Xte)
+    ystd = torch.tensor([float(sd)])
+    out = {"model": "SGPR", "N": args.n, "M": args.num_inducing, "d": args.dim, "max_iters": args.max_iters,
+           "wall_clock_secs": wall, "secs_per_step": wall / max(1, args.max_iters), "loss_first": losses[0], "loss_last": losses[-1],
+           "test_rmse": float(rmse(pred.loc, yte, ystd)), "test_nlpd": nlpd_marginal(pred, yte, ystd)}
+    if args.hmc_samples > 0:
+        hmc = BayesianSparseGPR_HMC(Xtr, ytr, GaussianLikelihood(), model.inducing_points.cpu(), jitter=1e-6, seed=1)
+        t0 = time.time()
+        trace, steps, perf = hmc.train_fixed_model(num_tune=args.hmc_tune, num_samples=args.hmc_samples)
+        wall = time.time() - t0
+        out["hmc"] = {"draws": len(trace), "tune": args.hmc_tune, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
+                      "leapfrogs_per_sec": trace.n_leapfrog / wall, "step_size": float(steps[0]),
+                      "sig_n_mean": float(trace["sig_n"].mean()), "ls_mean": trace["ls"].mean(0).tolist()}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

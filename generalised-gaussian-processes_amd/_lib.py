@@ -50,8 +50,11 @@ PROTOTYPES = {
     "sgp_logdiag_sum": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "sgp_bound_workspace_bytes": (_sz, [_i32, _i32]),
     "sgp_bound_factors_len": (_sz, [_i32]),
+    "sgp_kuu_factor_len": (_sz, [_i32]),
+    "sgp_kuu_factor_workspace_bytes": (_sz, [_i32]),
+    "sgp_kuu_factor": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _sz, _vp]),

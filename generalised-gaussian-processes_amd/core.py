@@ -82,6 +82,8 @@ class CollapsedBound:
         # 16 GiB super-chunks and pass 2 re-assembles.
         self._kfu = None
         self.kfu_budget_bytes = 64 << 30
+        self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
+        self._side = None
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -116,10 +118,27 @@ class CollapsedBound:
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False):
         e = self.engine
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
+        overlap = self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
+        if overlap:
+            # chol(Kuu) and its inverse depend on (Z, theta) only: run them on a side stream underneath pass 1
+            main = torch.cuda.current_stream(e.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=e.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
+                linv, kinfo = e.kuu_factor(Kuu)
+            for t in (Kuu, linv, kinfo):
+                t.record_stream(main)
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu)
         self._allreduce(packed)
-        Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
-        res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors)
+        if overlap:
+            main.wait_stream(self._side)
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv)
+            res["info"] = torch.where(kinfo != 0, kinfo, res["info"])
+        else:
+            Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors)
         res["packed"] = packed
         res["kfu"] = kfu
         return res
@@ -217,11 +236,19 @@ class HmcTarget:
         lp += (c - math.log1p(sf * sf)) + (c - math.log1p(sn * sn))
         return lp, g_ls, -2.0 * sf / (1.0 + sf * sf), -2.0 * sn / (1.0 + sn * sn)
 
+    @staticmethod
+    def _in_range(theta):
+        # exp() of the log-transformed variables must stay representable; beyond it the density is treated as
+        # zero (PyMC3: non-finite logp -> divergence), never an exception
+        return all(math.isfinite(float(v)) and abs(float(v)) < 300.0 for v in theta)
+
     def constrain(self, theta):
         th = [float(v) for v in theta]
         return {"ls": [math.exp(v) for v in th[: self.d]], "sig_f": math.exp(th[self.d]), "sig_n": math.exp(th[self.d + 1])}
 
     def logp(self, theta):
+        if not self._in_range(theta):
+            return -math.inf
         p = self.constrain(theta)
         F, parts = self.bound.value(self.Z, p["ls"], p["sig_f"] ** 2, p["sig_n"] ** 2, raise_on_fail=False)
         if parts.get("info", 0) != 0 or not math.isfinite(F):
@@ -231,6 +258,8 @@ class HmcTarget:
 
     def logp_and_grad(self, theta):
         """Returns (logp, grad list[d+2]).  One call = one HMC leapfrog's worth of device work."""
+        if not self._in_range(theta):
+            return -math.inf, [0.0] * self.ndim
         p = self.constrain(theta)
         ls, sf, sn = p["ls"], p["sig_f"], p["sig_n"]
         F, g = self.bound.value_and_grad(self.Z, ls, sf * sf, sn * sn, want_gz=False, raise_on_fail=False)

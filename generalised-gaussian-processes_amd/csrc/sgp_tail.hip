@@ -389,11 +389,44 @@ extern "C" size_t sgp_bound_workspace_bytes(int M, int with_adjoints) {
 }
 extern "C" size_t sgp_bound_factors_len(int M) { return M > 0 ? (size_t)2 * M * M + M : 0; }
 
+extern "C" size_t sgp_kuu_factor_len(int M) {
+  if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = padded_m(M);
+  return Mp * Mp;
+}
+extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
+  if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = padded_m(M);
+  Carver c(nullptr);
+  c.take<double>(Mp * Mp);
+  c.take<double>(Mp * Mp);
+  return c.used();
+}
+// L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
+// caller can run it on a second stream underneath pass 1.
+extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
+                              sgp_stream_t stream) {
+  if (!Kuu || !Linv_out || !info || M <= 0) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (!ws || ws_bytes < sgp_kuu_factor_workspace_bytes(M)) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mp = padded_m(M);
+  Carver c(ws);
+  double* L = c.take<double>((size_t)Mp * Mp);
+  double* tmp = c.take<double>((size_t)Mp * Mp);
+  hipMemsetAsync(info, 0, sizeof(int), st);
+  pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
+  potrf_lower(L, Linv_out, Mp, Mp, info, 0, st);
+  tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
+  return check_launch();
+}
+
 extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b, const double* yy,
                                     const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
-                                    double* Phibar, double* bbar, double* Kuubar, double* factors, int* info, void* ws,
-                                    size_t ws_bytes, sgp_stream_t stream) {
-  if (!Kuu || !Phi || !b || !yy || !kappa || !out || !info || M <= 0 || N < 0 || !(s2 > 0.0)) return SGP_ERR_ARG;
+                                    double* Phibar, double* bbar, double* Kuubar, double* factors,
+                                    const double* kuu_linv, int* info, void* ws, size_t ws_bytes,
+                                    sgp_stream_t stream) {
+  if ((!Kuu && !kuu_linv) || !Phi || !b || !yy || !kappa || !out || !info || M <= 0 || N < 0 || !(s2 > 0.0)) return SGP_ERR_ARG;
   if (with_adjoints && (!Phibar || !bbar || !Kuubar)) return SGP_ERR_ARG;
   if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   const int Mp = padded_m(M);
@@ -407,10 +440,14 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
   hipMemsetAsync(info, 0, sizeof(int), st);
   fill_zero(w.sc, SC_N, st);
 
-  // L = chol(Kuu) in M0, L^-1 in M1
-  pad_copy(Kuu, M, M, M, w.M0, ld, Mp, Mp, 1.0, st);
-  potrf_lower(w.M0, w.M1, ld, Mp, info, 0, st);
-  tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
+  // L = chol(Kuu) in M0, L^-1 in M1 -- or L^-1 handed over by sgp_kuu_factor (read-only from here on)
+  if (kuu_linv) {
+    w.M1 = const_cast<double*>(kuu_linv);
+  } else {
+    pad_copy(Kuu, M, M, M, w.M0, ld, Mp, Mp, 1.0, st);
+    potrf_lower(w.M0, w.M1, ld, Mp, info, 0, st);
+    tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
+  }
 
   // W = L^-1 Phi L^-T in M5 (V in M4)
   pad_copy(Phi, M, M, M, w.M3, ld, Mp, Mp, 0.0, st);

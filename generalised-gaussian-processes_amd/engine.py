@@ -112,7 +112,17 @@ class HipEngine:
         return K
 
     # ------------------------------------------------------------------ tail
-    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False):
+    def kuu_factor(self, Kuu):
+        """Padded L^-1 of chol(Kuu) and its info flag; independent of the streamed statistics (side-stream work)."""
+        M = Kuu.shape[0]
+        Linv = self.empty(self.lib.sgp_kuu_factor_len(M))
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = self._workspace("kuu_factor", self.lib.sgp_kuu_factor_workspace_bytes(M))
+        st = self.lib.sgp_kuu_factor(self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_kuu_factor", st)
+        return Linv, info
+
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None):
         """Runs the O(M^3) tail on (already all-reduced) packed statistics.
 
         Returns dict(out=[8] device tensor, info=int32 device tensor, and when asked Phibar, bbar,
@@ -136,8 +146,8 @@ class HipEngine:
         st = self.lib.sgp_bound_from_stats(
             self._ptr(Kuu), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), float(s2), int(N), M, 1 if with_adjoints else 0, self._ptr(out),
-            self._ptr(Phibar), self._ptr(bbar), self._ptr(Kuubar), self._ptr(factors), self._ptr(info),
-            self._ptr(ws), ws.numel(), self._stream())
+            self._ptr(Phibar), self._ptr(bbar), self._ptr(Kuubar), self._ptr(factors), self._ptr(kuu_linv),
+            self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_bound_from_stats", st)
         return res
 

@@ -43,7 +43,8 @@ class _PositiveParam(nn.Module):
         return F.softplus(self.raw) + self.floor
 
     def set(self, v):
-        v = torch.as_tensor(v, dtype=torch.float64, device=self.raw.device).reshape(self.raw.shape)
+        v = torch.as_tensor(v, dtype=torch.float64, device=self.raw.device)
+        v = v.expand(self.raw.shape) if v.numel() == 1 else v.reshape(self.raw.shape)  # scalars broadcast (ARD)
         with torch.no_grad():
             self.raw.copy_(_inv_softplus(torch.clamp(v - self.floor, min=1e-300)))
 

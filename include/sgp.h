@@ -123,10 +123,19 @@ int sgp_logdiag_sum(const double* L, int64_t ldl, int M, double* out, sgp_stream
  * [ Linv (M*M) | G = LB^-1 L^-1 (M*M) | q (M) ].  yy, kappa are device scalars.                     */
 size_t sgp_bound_workspace_bytes(int M, int with_adjoints);
 size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
+/* Optional split of the tail: chol(Kuu) and its inverse depend on (Z, theta) only, not on the streamed
+ * statistics.  sgp_kuu_factor writes the padded L^-1 (sgp_kuu_factor_len(M) doubles) and its own `info`
+ * (1..M); issued on a second stream it runs underneath pass 1.  Passing the result as `kuu_linv` makes
+ * sgp_bound_from_stats skip that part (Kuu may then be NULL).                                          */
+size_t sgp_kuu_factor_len(int M);
+size_t sgp_kuu_factor_workspace_bytes(int M);
+int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info,
+                   void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b,
                          const double* yy, const double* kappa, double s2, int64_t N, int M,
                          int with_adjoints, double* out,
                          double* Phibar, double* bbar, double* Kuubar, double* factors,
+                         const double* kuu_linv /* from sgp_kuu_factor, or NULL */,
                          int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 
 /* ---- streaming pass 2: gradients through Kuf -------------------------------------------------------

@@ -26,7 +26,7 @@ def lib():
 def test_every_declared_symbol_is_exported_and_bound(lib):
     import ggp_amd._lib as L
     names = header_functions()
-    assert len(names) >= 23
+    assert len(names) >= 26
     for n in names:
         assert hasattr(lib, n), "libsgp_hip.so does not export %s" % n
         assert n in L.PROTOTYPES, "python binding lacks a prototype for %s" % n
@@ -65,8 +65,10 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert lib.sgp_suffstats_fwd(one, 2, one, one, 2, inv, 1.0, 10, 4, 2, 0, one, one, one, one, null, null, 0, null) == -3
     assert lib.sgp_suffstats_fwd(one, 1, one, one, 2, inv, 1.0, 10, 4, 2, 0, one, one, one, one, null, one, 1 << 30, null) == -1  # ldx < d
     assert lib.sgp_kfu_len(1000, 100) == 1024 * 128 and lib.sgp_kfu_len(0, 5) == 256 * 128
-    assert lib.sgp_bound_from_stats(one, one, one, one, one, -1.0, 10, 4, 0, one, null, null, null, null, one, one, 1 << 30, null) == -1
-    assert lib.sgp_bound_from_stats(one, one, one, one, one, 0.1, 10, 4, 1, one, null, null, null, null, one, one, 1 << 30, null) == -1
+    assert lib.sgp_bound_from_stats(one, one, one, one, one, -1.0, 10, 4, 0, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
+    assert lib.sgp_bound_from_stats(one, one, one, one, one, 0.1, 10, 4, 1, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
+    assert lib.sgp_bound_from_stats(null, one, one, one, one, 0.1, 10, 4, 0, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
+    assert lib.sgp_kuu_factor(one, 4, one, one, null, 0, null) == -3 and lib.sgp_kuu_factor_len(100) == 128 * 128
     assert lib.sgp_chol_lower(one, 4, 4, one, null, 0, null) == -3
 
 

@@ -297,3 +297,23 @@ def test_bayesian_sgpr_hmc_on_device(engine):
     preds = ggp_amd.mixture_posterior_predictive(model, Xt.to(engine.device), trace)
     assert 1 <= len(preds) <= 15
     assert math.isfinite(ggp_amd.nlpd_mixture(preds, torch.sin(Xt), torch.tensor([1.0])))
+
+
+def test_side_stream_tail_overlap_matches_serial(engine):
+    """Kuu factorised on a second stream under pass 1 (default) vs everything on one stream: same numbers."""
+    import ggp_amd
+    G = load_golden("rbf_d18_mid")
+    cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=float(G["jitter"]), engine=engine)
+    Z = dev(G["Z"], engine)
+    outs = []
+    for ov in (True, False, True):
+        cb.overlap_tail = ov
+        F, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+        outs.append((F, g["ls"].clone(), g["Z"].clone()))
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    # a singular Kuu is still reported through the merged info flag
+    Zbad = torch.zeros(6, 18, dtype=torch.float64, device=engine.device)
+    cb0 = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=0.0, engine=engine)
+    F, parts = cb0.value(Zbad, G["ls"], 1.0, 0.1, raise_on_fail=False)
+    assert math.isnan(F) and 1 <= parts["info"] <= 6

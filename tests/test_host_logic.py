@@ -70,6 +70,8 @@ def test_failed_cholesky_paths():
     tgt = ggp_amd.HmcTarget(cb, Z)  # PyMC3 semantics: non-finite energy, never an exception
     lp, gr = tgt.logp_and_grad([0.0, 0.0, 0.0, -1.0])
     assert lp == -math.inf and all(v == 0.0 for v in gr)
+    # a leapfrog that flies off to where exp() overflows is a divergence too, not an OverflowError
+    assert tgt.logp_and_grad([1e4, 0.0, 0.0, 0.0])[0] == -math.inf and tgt.logp([0.0, float("nan"), 0.0, 0.0]) == -math.inf
 
 
 def test_shard_rows_partition():
