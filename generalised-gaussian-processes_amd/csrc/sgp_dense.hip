@@ -214,35 +214,33 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Linv
   double a[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = S[i][g + 4 * k];
-  double* col = &T[0][0];  // 2 x 64 doubles of scratch inside T
+  double* col = &T[0][0];   // 2 x 64 doubles of scratch inside T
+  double* piv = &T[2][0];   // the 64 pivots d_j = S[j][j] at elimination time
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < DB; ++j) {
     const int jg = j & 3, jk = j >> 2;
     double* cb = col + (j & 1) * 64;
-    if (g == jg) cb[i] = a[jk];
+    if (g == jg) cb[i] = a[jk];   // raw column j (the owner keeps it raw: scaled by 1/sqrt(d_j) after the loop)
     __syncthreads();
     double d = cb[j];
     if (!(d > 0.0)) {  // non-positive or NaN pivot: report LAPACK-style, keep going on a unit pivot
       if (tid == 0 && bad == 0) bad = j + 1;
       d = 1.0;
     }
-    const double ci = cb[i];
-    const double t = ci / d;
-    // columns p = g + 4k > j of this row
+    if (tid == 0) piv[j] = d;
+    const double t = cb[i] / d;
+    // columns p = g + 4k > j of this row; sqrt and the scaling of column j stay off this critical path
     if (g > jg) a[jk] = fma(-t, cb[g + 4 * jk], a[jk]);
 #pragma unroll
     for (int k = jk + 1; k < 16; ++k) a[k] = fma(-t, cb[g + 4 * k], a[k]);
-    if (g == jg) {  // final value of L[i][j]
-      const double l = sqrt(d);
-      a[jk] = (i == j) ? l : ci / l;
-    }
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int p = g + 4 * k;
-    S[i][p] = (p <= i) ? a[k] : 0.0;
+    const double l = sqrt(piv[p]);
+    S[i][p] = (p < i) ? a[k] / l : (p == i ? l : 0.0);
   }
   __syncthreads();
 

@@ -27,6 +27,7 @@
 //      lower triangle -- no fp64 atomics anywhere, results are bit-reproducible.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
+#include <cstdlib>
 
 namespace sgp {
 
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
 // ---------------------------------------------------------------------------------------------
 template <bool DIAG>
 __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* __restrict__ Kfu, int Mp, int64_t c0,
-                                          int64_t c1, int I0, int J0, int accumulate, double* __restrict__ out) {
+                                          int64_t c1, int I0, int J0, int accumulate, int skip_upper,
+                                          double* __restrict__ out) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,7 +171,9 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
+  const bool idle = DIAG && skip_upper && wi == 0 && wj == 1;  // tuning knob: strictly-upper block of a diagonal tile
   auto mfma_chunk = [&](int buf) {
+    if (idle) return;
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
       const double* kr = &Ks[buf][ks * 4 + l4][0];
@@ -225,7 +229,8 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 }
 
 __global__ __launch_bounds__(256, 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks, int cps,
-                                                           int ntiles, int accumulate, double* __restrict__ slab) {
+                                                           int ntiles, int accumulate, int skip_upper,
+                                                           double* __restrict__ slab) {
   __shared__ double Ks[2][NB][KROW];
   // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch
   const int id = blockIdx.x;
@@ -242,9 +247,9 @@ __global__ __launch_bounds__(256, 2) void syrk_tile_kernel(const double* __restr
   if (c1 > nchunks) c1 = nchunks;
   double* out = slab + ((size_t)split * ntiles + t) * (TILE * TILE);
   if (ti == tj)
-    syrk_tile<true>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, out);
+    syrk_tile<true>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
   else
-    syrk_tile<false>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, out);
+    syrk_tile<false>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,7 +431,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   const int grid = p.ntiles * p.nsplit;
   if (p.Npad == 0) {
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
-    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, 1, p.ntiles, 0, w.slab);
+    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, 1, p.ntiles, 0, 0, w.slab);
   }
   for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
     const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
@@ -436,7 +441,8 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     const int64_t nchunks = rows / NB;
     const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
     timing_begin(TIMING_SYRK, st);
-    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, w.slab);
+    static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // A/B on MI355X: 17.17 vs 17.29 ms
+    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
     timing_end(TIMING_SYRK, st);
   }
   const int nb32 = p.Mp / 32;

@@ -32,7 +32,7 @@ def unpack(packed, M):
 # ---------------------------------------------------------------------------------------------
 # dense back end
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M", [1, 8, 64, 100, 128, 130, 300, 520])
+@pytest.mark.parametrize("M", [1, 8, 64, 100, 128, 130, 300, 520, 1024, 2050])
 def test_chol_trsm_logdiag(engine, M):
     g = torch.Generator().manual_seed(M)
     R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
