@@ -26,11 +26,12 @@
 namespace sgp {
 
 constexpr int BK = 16;           // m' chunk
-constexpr int ALD = BK + 1;      // LDS row stride of the K'_fu slab  At[128 n][17]
+constexpr int ALD = BK + 2;      // LDS row stride of the K'_fu slab  At[128 n][18]: 18 r + k hits every bank pair once
+                                 // per half-wave operand read (17 left a 2-way conflict: SQ_LDS_BANK_CONFLICT 32 %)
 constexpr int BROW = TILE + 16;  // LDS row stride of the Phibar slab Bt[16 m'][144]
-constexpr int A_DBL = TILE * ALD;   // 2176
+constexpr int A_DBL = TILE * ALD;   // 2304
 constexpr int B_DBL = BK * BROW;    // 2304
-constexpr int BSM = 2 * (A_DBL + B_DBL);  // 8960 doubles = 71.7 KB: two workgroups per CU
+constexpr int BSM = 2 * (A_DBL + B_DBL);  // 9216 doubles = 73.7 KB: two workgroups per CU
 constexpr int CS = 129;                   // row stride of the epilogue image Ct[64 n][128 m]
 static_assert(64 * CS <= BSM, "epilogue image must fit in the main-loop buffers");
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     int64_t row0, int64_t nblocks, int bps, int64_t N, int M, int Mp, int nmb, int want_gz, int accumulate,
     double* __restrict__ gacc, double* __restrict__ gzpart, double* __restrict__ glpart) {
   __shared__ double smem[BSM];
-  double (*At)[TILE][ALD] = reinterpret_cast<double (*)[TILE][ALD]>(smem);               // [2][128][17]
+  double (*At)[TILE][ALD] = reinterpret_cast<double (*)[TILE][ALD]>(smem);               // [2][128][18]
   double (*Bt)[BK][BROW] = reinterpret_cast<double (*)[BK][BROW]>(smem + 2 * A_DBL);     // [2][16][144]
   double (*Ct)[CS] = reinterpret_cast<double (*)[CS]>(smem);                             // [64][129], epilogue only
 
@@ -133,10 +134,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     };
     auto stashA = [&](int buf, const d2 (&av)[4]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        At[buf][arow[i]][acol[i]] = av[i][0];
-        At[buf][arow[i]][acol[i] + 1] = av[i][1];
-      }
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(&At[buf][arow[i]][acol[i]]) = av[i];  // 16-B aligned: 144-B rows
     };
     auto stashP = [&](int buf) {
 #pragma unroll
