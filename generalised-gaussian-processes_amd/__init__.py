@@ -5,11 +5,11 @@ valid Python identifier: import it through the repo-root shim ``ggp_amd`` (``imp
 """
 from ._lib import KERNEL_IDS, SgpLibraryError, SgpStatusError, load_library  # noqa: F401
 from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, shard_rows  # noqa: F401
-from .gp_shim import (ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, MaternKernel,  # noqa: F401
+from .gp_shim import (BernoulliLikelihood, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, MaternKernel,  # noqa: F401
                       MultivariateNormal, RBFKernel, ScaleKernel, ZeroMean, settings)
 from .hmc import NUTS, Trace, sample_nuts  # noqa: F401
 from .metrics import nlpd, nlpd_marginal, nlpd_mixture, rmse  # noqa: F401
-from .models import BayesianSparseGPR_HMC, SparseGPR, mixture_posterior_predictive  # noqa: F401
+from .models import BayesianSparseGPR_HMC, SparseGPR, StochasticVariationalGP, mixture_posterior_predictive  # noqa: F401
 
 
 def __getattr__(name):  # lazy: importing the package must work without a GPU (build / symbol checks)

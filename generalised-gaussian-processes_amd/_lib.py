@@ -60,6 +60,12 @@ PROTOTYPES = {
                                  _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_kuu_bwd_workspace_bytes": (_sz, [_i32, _i32]),
     "sgp_kuu_bwd": (_i32, [_vp, _i64, _dp, _dbl, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_svgp_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_svgp_elbo": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _dp, _dbl, _dbl, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
+                             _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_svgp_predict": (_i32, [_vp, _i64, _i64, _vp, _i64, _dp, _dbl, _dbl, _vp, _vp, _i32, _i32, _i32,
+                                _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_gauss_hermite": (_i32, [_i32, _dp, _dp]),
     "sgp_predict_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_predict": (_i32, [_vp, _i64, _i64, _vp, _i64, _dp, _dbl, _dbl, _vp, _i32, _i32, _i32, _i32,
                            _vp, _vp, _vp, _vp, _sz, _vp]),

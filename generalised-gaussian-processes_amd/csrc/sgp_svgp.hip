@@ -1,0 +1,498 @@
+// Uncollapsed (SVGP) minibatch bound and its gradients -- SURVEY.md section 8 (f-3).
+//
+// Replaces, for one minibatch, what the reference obtains from GPyTorch's
+//   VariationalELBO(likelihood, model, num_data=N)(model(x_batch), y_batch)  +  loss.backward()
+// over VariationalStrategy(CholeskyVariationalDistribution(M), learn_inducing_locations=True)
+// (reference models/svgp.py:37,46,88-127; models/bayesian_svgp.py:144-181):
+//
+//   L = chol(Kuu + J I) ; A = L^-1 K_ub ; T = L_S^T A ; mu = A^T m ; v = k_bb - colsum(A o A) + colsum(T o T)
+//   ELBO / datum = mean_b E_{N(mu_b, v_b)} log p(y_b | f) - KL(N(m, L_S L_S^T) || N(0, I)) / N
+//
+// Likelihoods: Gaussian (closed form) and Bernoulli-probit (20-point Gauss-Hermite, y in {-1, +1}).
+// The shapes are small (M <= a few hundred, B = minibatch), so this path is launch-latency bound; every
+// O(M^2 B) / O(M^3) product runs on the fp64-MFMA GEMM of sgp_dense.hip and the reverse pass is the
+// closed-form adjoint (Cholesky adjoint  Kbar = sym(L^-T Phi(L^T Lbar) L^-1), Murray 2016) -- no autograd.
+#include "sgp_dense.hpp"
+
+namespace sgp {
+
+constexpr int GH_N = 20;
+struct GHTable {
+  double x[GH_N];  // nodes of  int f(x) N(x; 0, 1) dx
+  double w[GH_N];  // weights (sum to 1)
+};
+// Gauss-Hermite nodes / weights by Newton iteration on the orthonormal Hermite recurrence (host, once):
+// physicists' rule (weight exp(-x^2)) rescaled to the standard normal:  x * sqrt(2),  w / sqrt(pi).
+static void gauss_hermite_host(int n, double* xs, double* ws) {
+  const double PIM4 = 0.7511255444649425;  // pi^(-1/4)
+  double z = 0.0, pp = 1.0;
+  const int half = (n + 1) / 2;
+  for (int i = 0; i < half; ++i) {
+    if (i == 0) z = sqrt(2.0 * n + 1.0) - 1.85575 * pow(2.0 * n + 1.0, -0.16667);
+    else if (i == 1) z -= 1.14 * pow((double)n, 0.426) / z;
+    else if (i == 2) z = 1.86 * z - 0.86 * xs[0];
+    else if (i == 3) z = 1.91 * z - 0.91 * xs[1];
+    else z = 2.0 * z - xs[i - 2];
+    for (int its = 0; its < 200; ++its) {
+      double p1 = PIM4, p2 = 0.0;
+      for (int j = 1; j <= n; ++j) {
+        const double p3 = p2;
+        p2 = p1;
+        p1 = z * sqrt(2.0 / j) * p2 - sqrt((double)(j - 1) / j) * p3;
+      }
+      pp = sqrt(2.0 * n) * p2;
+      const double z1 = z;
+      z = z1 - p1 / pp;
+      if (fabs(z - z1) <= 1e-15 * (1.0 + fabs(z))) break;
+    }
+    xs[i] = z;
+    xs[n - 1 - i] = -z;
+    ws[i] = ws[n - 1 - i] = 2.0 / (pp * pp);
+  }
+  for (int i = 0; i < n; ++i) {
+    xs[i] *= 1.4142135623730951;
+    ws[i] *= 0.5641895835477563;
+  }
+}
+static GHTable make_gh() {
+  GHTable t;
+  gauss_hermite_host(GH_N, t.x, t.w);
+  return t;
+}
+
+// Kub[m][b] = sf2 k'(z_m, x_b) (zero in the padding), Mp x Bp
+template <int KID>
+__global__ __launch_bounds__(256) void svgp_kub_kernel(const double* __restrict__ Z, int64_t ldz, const double* __restrict__ Xb,
+                                                       int64_t ldx, KernArgs ka, int M, int Mp, int B, int Bp,
+                                                       double* __restrict__ Kub) {
+  const int64_t total = (int64_t)Mp * Bp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / Bp), b = (int)(e - (int64_t)m * Bp);
+    double v = 0.0;
+    if (m < M && b < B) {
+      double r2 = 0.0;
+      for (int q = 0; q < ka.d; ++q) {
+        const double df = (Z[m * ldz + q] - Xb[b * ldx + q]) * ka.inv_ls[q];
+        r2 = fma(df, df, r2);
+      }
+      v = ka.sf2 * kprofile<KID>(r2);
+    }
+    Kub[e] = v;
+  }
+}
+
+// mu[b] = sum_m A[m][b] mp[m] ; v[b] = kbb - sum A^2 + sum T^2   (block = 64 columns x 4 row groups)
+__global__ __launch_bounds__(256) void svgp_cols_kernel(const double* __restrict__ A, const double* __restrict__ T,
+                                                        const double* __restrict__ mp, int Mp, int Bp, int B, double kbb,
+                                                        double* __restrict__ mu, double* __restrict__ v) {
+  __shared__ double pm[4][64], pa[4][64], pt[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  double sm = 0.0, sa = 0.0, st = 0.0;
+  for (int m = w; m < Mp; m += 4) {
+    const double a = A[(int64_t)m * Bp + col], t = T[(int64_t)m * Bp + col];
+    sm = fma(a, mp[m], sm);
+    sa = fma(a, a, sa);
+    st = fma(t, t, st);
+  }
+  pm[w][l] = sm; pa[w][l] = sa; pt[w][l] = st;
+  __syncthreads();
+  if (w == 0) {
+    mu[col] = (pm[0][l] + pm[1][l]) + (pm[2][l] + pm[3][l]);
+    v[col] = col < B ? kbb - ((pa[0][l] + pa[1][l]) + (pa[2][l] + pa[3][l])) + ((pt[0][l] + pt[1][l]) + (pt[2][l] + pt[3][l])) : 1.0;
+  }
+}
+
+__device__ __forceinline__ double log_ndtr_dev(double z) { return log(0.5 * erfc(-z * 0.7071067811865476)); }
+// phi(z) / Phi(z), stable for the range Gauss-Hermite nodes reach
+__device__ __forceinline__ double mills_dev(double z) {
+  const double phi = 0.3989422804014327 * exp(-0.5 * z * z);
+  const double Phi = 0.5 * erfc(-z * 0.7071067811865476);
+  return Phi > 0.0 ? phi / Phi : -z;  // asymptote phi/Phi -> -z as z -> -inf
+}
+
+// per-point expected log-likelihood and its derivatives; fixed grid of 64 blocks, partial sums per block
+__global__ __launch_bounds__(256) void svgp_ell_kernel(const double* __restrict__ y, const double* __restrict__ mu,
+                                                       const double* __restrict__ v, int B, double s2, int lik, GHTable gh,
+                                                       double* __restrict__ dmu, double* __restrict__ dv,
+                                                       double* __restrict__ part /* [64][2]: ell, ds2 */) {
+  __shared__ double red[4];
+  double se = 0.0, ss = 0.0;
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+    const double yb = y[b], m = mu[b], vv = v[b];
+    double ell, gm, gv, gs = 0.0;
+    if (lik == 0) {
+      const double r = yb - m, q = r * r + vv;
+      ell = -0.9189385332046727 - 0.5 * log(s2) - q / (2.0 * s2);
+      gm = r / s2;
+      gv = -0.5 / s2;
+      gs = -0.5 / s2 + q / (2.0 * s2 * s2);
+    } else {
+      const double sd = sqrt(vv);
+      ell = 0.0; gm = 0.0; gv = 0.0;
+      for (int i = 0; i < GH_N; ++i) {
+        const double z = yb * (m + sd * gh.x[i]);
+        ell = fma(gh.w[i], log_ndtr_dev(z), ell);
+        const double r = gh.w[i] * yb * mills_dev(z);
+        gm += r;
+        gv = fma(r, gh.x[i], gv);
+      }
+      gv = gv / (2.0 * sd);
+    }
+    dmu[b] = gm;
+    dv[b] = gv;
+    se += ell;
+    ss += gs;
+  }
+  se = block_sum256(se, red);
+  ss = block_sum256(ss, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = se;
+    part[2 * blockIdx.x + 1] = ss;
+  }
+}
+
+// KL(N(m, LS LS^T) || N(0, I)) and, on request, its gradients into g_m / g_LS (scaled by kl_scale = -1/N)
+__global__ __launch_bounds__(256) void svgp_kl_kernel(const double* __restrict__ m, const double* __restrict__ LS, int M,
+                                                      double* __restrict__ kl_out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < M; i += 256) s += m[i] * m[i] - 2.0 * log(LS[(int64_t)i * M + i]);
+  for (int64_t e = threadIdx.x; e < (int64_t)M * M; e += 256) {
+    const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+    if (c <= r) s = fma(LS[e], LS[e], s);
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) *kl_out = 0.5 * (s - (double)M);
+}
+
+__global__ void svgp_finalize_kernel(const double* __restrict__ part, int nparts, const double* __restrict__ kl, int B,
+                                     double N_total, const double* __restrict__ dvbuf, double* __restrict__ out,
+                                     double* __restrict__ g_s2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double se = 0.0, ss = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    se += part[2 * i];
+    ss += part[2 * i + 1];
+  }
+  out[0] = se / (double)B - *kl / N_total;
+  out[1] = se;
+  out[2] = *kl;
+  if (g_s2) *g_s2 = ss / (double)B;
+}
+
+// Abar = mp mubar^T + 2 (U - A) diag(vbar), with mubar = dmu / B, vbar = dv / B ; Av = A diag(vbar)
+__global__ __launch_bounds__(256) void svgp_abar_kernel(const double* __restrict__ A, const double* __restrict__ U,
+                                                        const double* __restrict__ mp, const double* __restrict__ dmu,
+                                                        const double* __restrict__ dv, int Mp, int Bp, int B, double invB,
+                                                        double* __restrict__ Abar, double* __restrict__ Av) {
+  const int64_t total = (int64_t)Mp * Bp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / Bp), b = (int)(e - (int64_t)m * Bp);
+    double ab = 0.0, av = 0.0;
+    if (b < B) {
+      const double mb = dmu[b] * invB, vb = dv[b] * invB;
+      ab = mp[m] * mb + 2.0 * vb * (U[e] - A[e]);
+      av = A[e] * vb;
+    }
+    Abar[e] = ab;
+    Av[e] = av;
+  }
+}
+
+// g_m[m] = sum_b A[m][b] dmu[b] / B - m[m] / N      (one wave per row)
+__global__ __launch_bounds__(256) void svgp_gm_kernel(const double* __restrict__ A, const double* __restrict__ dmu,
+                                                      const double* __restrict__ m, int M, int Bp, int B, double invB,
+                                                      double invN, double* __restrict__ g_m) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  double s = 0.0;
+  for (int b = lane; b < B; b += 64) s = fma(A[(int64_t)row * Bp + b], dmu[b], s);
+  s = wave_sum(s);
+  if (lane == 0) g_m[row] = s * invB - m[row] * invN;
+}
+
+// g_LS = tril(2 G) - (LS - diag(1 / diag LS)) / N   (M x M, ld M; strictly-upper part zero)
+__global__ __launch_bounds__(256) void svgp_gls_kernel(const double* __restrict__ G, int Mp, const double* __restrict__ LS,
+                                                       int M, double invN, double* __restrict__ g_LS) {
+  const int64_t total = (int64_t)M * M;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+    double v = 0.0;
+    if (c <= r) {
+      v = 2.0 * G[(int64_t)r * Mp + c] - LS[e] * invN;
+      if (c == r) v += invN / LS[e];
+    }
+    g_LS[e] = v;
+  }
+}
+
+// in place: X <- -tril(X)   /  X <- tril(X) with halved diagonal
+__global__ __launch_bounds__(256) void svgp_tril_kernel(double* __restrict__ X, int Mp, double scale, int halve_diag) {
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    double v = X[e] * scale;
+    if (c > r) v = 0.0;
+    else if (c == r && halve_diag) v *= 0.5;
+    X[e] = v;
+  }
+}
+// Kuubar (M x M, ld M) = (P + P^T) / 2 cropped
+__global__ __launch_bounds__(256) void svgp_symcrop_kernel(const double* __restrict__ P, int Mp, int M, double* __restrict__ out) {
+  const int64_t total = (int64_t)M * M;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+    out[e] = 0.5 * (P[(int64_t)r * Mp + c] + P[(int64_t)c * Mp + r]);
+  }
+}
+
+// per-inducing-row partials of sum_{m,b} Kubbar[m][b] dKub[m][b]/d(.) :
+//   part[m][q] = sum_b E df_q^2 (q < d), part[m][d] = sum_b Kubbar k', gz[m][q] = sum_b E df_q, E = Kubbar sf2 dk'/dr2
+template <int KID>
+__global__ __launch_bounds__(256) void svgp_kub_bwd_kernel(const double* __restrict__ Z, int64_t ldz, const double* __restrict__ Xb,
+                                                           int64_t ldx, KernArgs ka, const double* __restrict__ Kbb, int Bp,
+                                                           int B, double* __restrict__ part, double* __restrict__ gzraw) {
+  __shared__ double red[4];
+  const int m = blockIdx.x, d = ka.d;
+  for (int q = 0; q <= d; ++q) {
+    double s2 = 0.0, s1 = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      double r2 = 0.0, dfq = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double df = (Z[m * ldz + j] - Xb[b * ldx + j]) * ka.inv_ls[j];
+        r2 = fma(df, df, r2);
+        if (j == q) dfq = df;
+      }
+      double kp, hp;
+      kprofile_grad<KID>(r2, kp, hp);
+      const double kb = Kbb[(int64_t)m * Bp + b];
+      if (q == d) {
+        s2 = fma(kb, kp, s2);
+      } else {
+        const double E = kb * ka.sf2 * hp;
+        s1 = fma(E, dfq, s1);
+        s2 = fma(E * dfq, dfq, s2);
+      }
+    }
+    s2 = block_sum256(s2, red);
+    s1 = block_sum256(s1, red);
+    if (threadIdx.x == 0) {
+      part[(size_t)m * (d + 1) + q] = s2;
+      if (q < d) gzraw[(size_t)m * d + q] = s1;
+    }
+  }
+}
+// g_ls[q] = -2 inv_ls_q sum_m part[m][q] ; g_sf2 = sum_m part[m][d] + sum_b dv[b] / B ; g_Z[m][q] = 2 inv_ls_q gz[m][q]
+__global__ __launch_bounds__(256) void svgp_kub_bwd_reduce_kernel(const double* __restrict__ part, const double* __restrict__ gzraw,
+                                                                  int M, KernArgs ka, const double* __restrict__ dv, int B,
+                                                                  double invB, double* g_ls, double* g_sf2, double* g_Z) {
+  __shared__ double red[4];
+  const int d = ka.d;
+  if (blockIdx.x == 0) {
+    for (int q = 0; q <= d; ++q) {
+      double s = 0.0;
+      for (int m = threadIdx.x; m < M; m += 256) s += part[(size_t)m * (d + 1) + q];
+      s = block_sum256(s, red);
+      if (q == d) {
+        double t = 0.0;
+        for (int b = threadIdx.x; b < B; b += 256) t += dv[b];
+        t = block_sum256(t, red);
+        if (threadIdx.x == 0) *g_sf2 = s + t * invB;
+      } else if (threadIdx.x == 0) {
+        g_ls[q] = -2.0 * ka.inv_ls[q] * s;
+      }
+    }
+  }
+  const int64_t total = (int64_t)M * d;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    g_Z[e] = 2.0 * ka.inv_ls[(int)(e % d)] * gzraw[e];
+}
+
+static int grid_for_s(int64_t total, int cap = 2048) {
+  int64_t g = (total + 255) / 256;
+  if (g < 1) g = 1;
+  return (int)(g < cap ? g : cap);
+}
+
+struct SvgpWs {
+  double *Kuu, *Kp, *Linv, *tmp, *LSp, *Kub, *A, *T, *U, *Abar, *Av, *S1, *Q, *P, *Kuubar;
+  double *mp, *mu, *v, *dmu, *dv, *part, *kl, *kpart, *gzraw;
+  void* kuu_ws;
+  size_t kuu_ws_bytes, bytes;
+};
+static SvgpWs carve_svgp(void* ws, int Mp, int Bp, int M, int d) {
+  Carver c(ws);
+  SvgpWs w;
+  const size_t mm = (size_t)Mp * Mp, mb = (size_t)Mp * Bp;
+  w.Kuu = c.take<double>((size_t)M * M);
+  w.Kp = c.take<double>(mm);
+  w.Linv = c.take<double>(mm);
+  w.tmp = c.take<double>(mm);
+  w.LSp = c.take<double>(mm);
+  w.S1 = c.take<double>(mm);
+  w.Q = c.take<double>(mm);
+  w.P = c.take<double>(mm);
+  w.Kuubar = c.take<double>((size_t)M * M);
+  w.Kub = c.take<double>(mb);
+  w.A = c.take<double>(mb);
+  w.T = c.take<double>(mb);
+  w.U = c.take<double>(mb);
+  w.Abar = c.take<double>(mb);
+  w.Av = c.take<double>(mb);
+  w.mp = c.take<double>(Mp);
+  w.mu = c.take<double>(Bp);
+  w.v = c.take<double>(Bp);
+  w.dmu = c.take<double>(Bp);
+  w.dv = c.take<double>(Bp);
+  w.part = c.take<double>(128);
+  w.kl = c.take<double>(8);
+  w.kpart = c.take<double>((size_t)M * (d + 1));
+  w.gzraw = c.take<double>((size_t)M * d);
+  w.kuu_ws_bytes = sgp_kuu_bwd_workspace_bytes(M, d);
+  w.kuu_ws = c.take<char>(w.kuu_ws_bytes);
+  w.bytes = c.used();
+  return w;
+}
+
+static KernArgs make_ka_s(const double* inv_ls, double sf2, int d) {
+  KernArgs ka;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  ka.sf2 = sf2;
+  ka.d = d;
+  return ka;
+}
+
+// shared forward: fills w.A, w.T, w.mu, w.v (and L in Kp, L^-1 in Linv, padded m, padded tril(LS))
+static void svgp_forward(const SvgpWs& w, const double* Xb, int64_t ldx, int64_t B, const double* Z, int64_t ldz,
+                         const double* inv_ls, double sf2, double jitter, const double* m, const double* LS, int M, int d,
+                         int kernel_id, int Mp, int Bp, int* info, hipStream_t st) {
+  const KernArgs ka = make_ka_s(inv_ls, sf2, d);
+  hipMemsetAsync(info, 0, sizeof(int), st);
+  sgp_kuu(Z, ldz, inv_ls, sf2, jitter, M, d, kernel_id, w.Kuu, st);
+  pad_copy(w.Kuu, M, M, M, w.Kp, Mp, Mp, Mp, 1.0, st);
+  potrf_lower(w.Kp, w.Linv, Mp, Mp, info, 0, st);
+  tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st);
+  pad_copy(LS, M, M, M, w.LSp, Mp, Mp, Mp, 1.0, st);
+  svgp_tril_kernel<<<grid_for_s((int64_t)Mp * Mp), 256, 0, st>>>(w.LSp, Mp, 1.0, 0);
+  pad_copy(m, 1, M, 1, w.mp, 1, Mp, 1, 0.0, st);
+  const int g = grid_for_s((int64_t)Mp * Bp);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: svgp_kub_kernel<SGP_KERNEL_RBF><<<g, 256, 0, st>>>(Z, ldz, Xb, ldx, ka, M, Mp, (int)B, Bp, w.Kub); break;
+    case SGP_KERNEL_MATERN32: svgp_kub_kernel<SGP_KERNEL_MATERN32><<<g, 256, 0, st>>>(Z, ldz, Xb, ldx, ka, M, Mp, (int)B, Bp, w.Kub); break;
+    default: svgp_kub_kernel<SGP_KERNEL_MATERN52><<<g, 256, 0, st>>>(Z, ldz, Xb, ldx, ka, M, Mp, (int)B, Bp, w.Kub); break;
+  }
+  GemmDesc a;  // A = L^-1 Kub
+  a.A = w.Linv; a.lda = Mp; a.B = w.Kub; a.ldb = Bp; a.C = w.A; a.ldc = Bp;
+  a.m = Mp; a.n = Bp; a.k = Mp; a.khi_mask = 1;
+  gemm(a, st);
+  GemmDesc t;  // T = LS^T A
+  t.A = w.LSp; t.lda = Mp; t.ta = true; t.B = w.A; t.ldb = Bp; t.C = w.T; t.ldc = Bp;
+  t.m = Mp; t.n = Bp; t.k = Mp; t.klo_mask = 1;
+  gemm(t, st);
+  svgp_cols_kernel<<<Bp / 64, 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, sf2, w.mu, w.v);
+}
+
+}  // namespace sgp
+
+using namespace sgp;
+
+extern "C" int sgp_gauss_hermite(int n, double* x, double* w) {
+  if (n <= 0 || n > 128 || !x || !w) return SGP_ERR_ARG;
+  gauss_hermite_host(n, x, w);
+  return SGP_OK;
+}
+
+extern "C" size_t sgp_svgp_workspace_bytes(int64_t B, int M, int d) {
+  if (B <= 0 || B > (1 << 20) || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  return carve_svgp(nullptr, padded_m(M), (int)round_up64(B, 64), M, d).bytes;
+}
+
+extern "C" int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                             const double* inv_ls, double sf2, double s2, double jitter, const double* m, const double* LS,
+                             int64_t N_total, int M, int d, int kernel_id, int likelihood_id, int with_grads, double* out,
+                             double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2, int* info,
+                             void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!Xb || !yb || !Z || !inv_ls || !m || !LS || !out || !info || B <= 0 || M <= 0 || d <= 0 || ldx < d || ldz < d ||
+      N_total <= 0)
+    return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52 || likelihood_id < 0 || likelihood_id > 1) return SGP_ERR_ARG;
+  if (likelihood_id == 0 && !(s2 > 0.0)) return SGP_ERR_ARG;
+  if (with_grads && (!g_m || !g_LS || !g_Z || !g_ls || !g_sf2 || !g_s2)) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || B > (1 << 20)) return SGP_ERR_DIM;
+  const int Mp = padded_m(M), Bp = (int)round_up64(B, 64);
+  SvgpWs w = carve_svgp(ws, Mp, Bp, M, d);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const KernArgs ka = make_ka_s(inv_ls, sf2, d);
+  static const GHTable gh = make_gh();
+  const double invB = 1.0 / (double)B, invN = 1.0 / (double)N_total;
+
+  svgp_forward(w, Xb, ldx, B, Z, ldz, inv_ls, sf2, jitter, m, LS, M, d, kernel_id, Mp, Bp, info, st);
+  svgp_ell_kernel<<<64, 256, 0, st>>>(yb, w.mu, w.v, (int)B, s2, likelihood_id, gh, w.dmu, w.dv, w.part);
+  svgp_kl_kernel<<<1, 256, 0, st>>>(m, LS, M, w.kl);
+  svgp_finalize_kernel<<<1, 64, 0, st>>>(w.part, 64, w.kl, (int)B, (double)N_total, w.dv, out, with_grads ? g_s2 : nullptr);
+  if (!with_grads) return check_launch();
+
+  // ---- reverse pass -------------------------------------------------------------------------------
+  GemmDesc u;  // U = LS T  (= LS LS^T A)
+  u.A = w.LSp; u.lda = Mp; u.B = w.T; u.ldb = Bp; u.C = w.U; u.ldc = Bp;
+  u.m = Mp; u.n = Bp; u.k = Mp; u.khi_mask = 1;
+  gemm(u, st);
+  svgp_abar_kernel<<<grid_for_s((int64_t)Mp * Bp), 256, 0, st>>>(w.A, w.U, w.mp, w.dmu, w.dv, Mp, Bp, (int)B, invB, w.Abar, w.Av);
+  svgp_gm_kernel<<<(M + 3) / 4, 256, 0, st>>>(w.A, w.dmu, m, M, Bp, (int)B, invB, invN, g_m);
+  GemmDesc gl;  // G = (A diag(vbar)) T^T  -> g_LS
+  gl.A = w.Av; gl.lda = Bp; gl.B = w.T; gl.ldb = Bp; gl.tb = true; gl.C = w.S1; gl.ldc = Mp;
+  gl.m = Mp; gl.n = Mp; gl.k = Bp;
+  gemm(gl, st);
+  svgp_gls_kernel<<<grid_for_s((int64_t)M * M), 256, 0, st>>>(w.S1, Mp, LS, M, invN, g_LS);
+  GemmDesc bb;  // Kubbar = L^-T Abar   (into U, no longer needed)
+  bb.A = w.Linv; bb.lda = Mp; bb.ta = true; bb.B = w.Abar; bb.ldb = Bp; bb.C = w.U; bb.ldc = Bp;
+  bb.m = Mp; bb.n = Bp; bb.k = Mp; bb.klo_mask = 1;
+  gemm(bb, st);
+  GemmDesc s1;  // S1 = Kubbar A^T ; Lbar = -tril(S1)
+  s1.A = w.U; s1.lda = Bp; s1.B = w.A; s1.ldb = Bp; s1.tb = true; s1.C = w.S1; s1.ldc = Mp;
+  s1.m = Mp; s1.n = Mp; s1.k = Bp;
+  gemm(s1, st);
+  svgp_tril_kernel<<<grid_for_s((int64_t)Mp * Mp), 256, 0, st>>>(w.S1, Mp, -1.0, 0);
+  GemmDesc q;  // Q = L^T Lbar ; Phi(Q)
+  q.A = w.Kp; q.lda = Mp; q.ta = true; q.B = w.S1; q.ldb = Mp; q.C = w.Q; q.ldc = Mp;
+  q.m = Mp; q.n = Mp; q.k = Mp; q.klo_mask = 3;
+  gemm(q, st);
+  svgp_tril_kernel<<<grid_for_s((int64_t)Mp * Mp), 256, 0, st>>>(w.Q, Mp, 1.0, 1);
+  GemmDesc p1;  // tmp = L^-T Phi(Q)
+  p1.A = w.Linv; p1.lda = Mp; p1.ta = true; p1.B = w.Q; p1.ldb = Mp; p1.C = w.tmp; p1.ldc = Mp;
+  p1.m = Mp; p1.n = Mp; p1.k = Mp; p1.klo_mask = 3;
+  gemm(p1, st);
+  GemmDesc p2;  // P = tmp L^-1
+  p2.A = w.tmp; p2.lda = Mp; p2.B = w.Linv; p2.ldb = Mp; p2.C = w.P; p2.ldc = Mp;
+  p2.m = Mp; p2.n = Mp; p2.k = Mp; p2.klo_mask = 2;
+  gemm(p2, st);
+  svgp_symcrop_kernel<<<grid_for_s((int64_t)M * M), 256, 0, st>>>(w.P, Mp, M, w.Kuubar);
+  // contraction of Kubbar and Kuubar with the kernel derivatives
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: svgp_kub_bwd_kernel<SGP_KERNEL_RBF><<<M, 256, 0, st>>>(Z, ldz, Xb, ldx, ka, w.U, Bp, (int)B, w.kpart, w.gzraw); break;
+    case SGP_KERNEL_MATERN32: svgp_kub_bwd_kernel<SGP_KERNEL_MATERN32><<<M, 256, 0, st>>>(Z, ldz, Xb, ldx, ka, w.U, Bp, (int)B, w.kpart, w.gzraw); break;
+    default: svgp_kub_bwd_kernel<SGP_KERNEL_MATERN52><<<M, 256, 0, st>>>(Z, ldz, Xb, ldx, ka, w.U, Bp, (int)B, w.kpart, w.gzraw); break;
+  }
+  svgp_kub_bwd_reduce_kernel<<<grid_for_s((int64_t)M * d, 256), 256, 0, st>>>(w.kpart, w.gzraw, M, ka, w.dv, (int)B, invB, g_ls, g_sf2, g_Z);
+  const int rc = sgp_kuu_bwd(Z, ldz, inv_ls, sf2, w.Kuubar, M, d, kernel_id, g_ls, g_sf2, g_Z, w.kuu_ws, w.kuu_ws_bytes, st);
+  if (rc != SGP_OK) return rc;
+  return check_launch();
+}
+
+extern "C" int sgp_svgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, const double* inv_ls,
+                                double sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,
+                                double* mean, double* var, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!Xs || !Z || !inv_ls || !m || !LS || !mean || !var || !info || T <= 0 || M <= 0 || d <= 0 || ldxs < d || ldz < d)
+    return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || T > (1 << 20)) return SGP_ERR_DIM;
+  const int Mp = padded_m(M), Bp = (int)round_up64(T, 64);
+  SvgpWs w = carve_svgp(ws, Mp, Bp, M, d);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  svgp_forward(w, Xs, ldxs, T, Z, ldz, inv_ls, sf2, jitter, m, LS, M, d, kernel_id, Mp, Bp, info, st);
+  crop_copy(w.mu, 1, mean, 1, (int)T, 1, st);
+  crop_copy(w.v, 1, var, 1, (int)T, 1, st);
+  return check_launch();
+}

@@ -199,6 +199,48 @@ class HipEngine:
         _lib.check("sgp_predict", st)
         return mean, var, cov
 
+    # ------------------------------------------------------------------ SVGP minibatch bound
+    def svgp_elbo(self, Xb, yb, Z, ls, sf2, s2, m, LS, N_total, jitter=1e-6, kernel="rbf", likelihood="gaussian",
+                  with_grads=False):
+        """One minibatch of the whitened SVGP bound.  Returns dict(out=[elbo/datum, sum ELL, KL], info, and with
+        ``with_grads`` g_m, g_LS (lower), g_Z, g_ls, g_sf2, g_s2 as device tensors).  Nothing is synchronised."""
+        B, d = Xb.shape
+        M = Z.shape[0]
+        for t, n in ((Xb, "Xb"), (yb, "yb"), (Z, "Z"), (m, "m"), (LS, "LS")):
+            self._chk(t, n)
+        lik = {"gaussian": 0, "bernoulli": 1, "bernoulli_probit": 1}[likelihood]
+        out = self.empty(3)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        res = {"out": out, "info": info}
+        g = {}
+        if with_grads:
+            g = {"g_m": self.empty(M), "g_LS": self.empty(M, M), "g_Z": self.empty(M, d), "g_ls": self.empty(d),
+                 "g_sf2": self.empty(1), "g_s2": self.empty(1)}
+            res.update(g)
+        nbytes = self.lib.sgp_svgp_workspace_bytes(B, M, d)
+        if nbytes == 0:
+            raise ValueError("unsupported SVGP shape B=%d M=%d d=%d" % (B, M, d))
+        ws = self._workspace("svgp", nbytes)
+        st = self.lib.sgp_svgp_elbo(
+            self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(s2), float(jitter),
+            self._ptr(m), self._ptr(LS), int(N_total), M, d, _kernel_id(kernel), lik, 1 if with_grads else 0, self._ptr(out),
+            self._ptr(g.get("g_m")), self._ptr(g.get("g_LS")), self._ptr(g.get("g_Z")), self._ptr(g.get("g_ls")),
+            self._ptr(g.get("g_sf2")), self._ptr(g.get("g_s2")), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_svgp_elbo", st)
+        return res
+
+    def svgp_predict(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
+        T, d = Xs.shape
+        M = Z.shape[0]
+        mean, var = self.empty(T), self.empty(T)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = self._workspace("svgp", self.lib.sgp_svgp_workspace_bytes(T, M, d))
+        st = self.lib.sgp_svgp_predict(self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(jitter),
+                                       self._ptr(m), self._ptr(LS), M, d, _kernel_id(kernel), self._ptr(mean), self._ptr(var),
+                                       self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_svgp_predict", st)
+        return mean, var, info
+
     # ------------------------------------------------------------------ stand-alone M x M entry points
     def chol_lower(self, A: torch.Tensor):
         M = A.shape[0]

@@ -112,6 +112,8 @@ class _NoiseCovar(nn.Module):
 
 
 class GaussianLikelihood(nn.Module):
+    name = "gaussian"
+
     def __init__(self):
         super().__init__()
         self.noise_covar = _NoiseCovar()
@@ -135,6 +137,20 @@ class GaussianLikelihood(nn.Module):
             return dist
         n = dist.loc.shape[0]
         return MultivariateNormal(dist.loc, dist.covariance_matrix + self.noise.to(dist.loc.device) * torch.eye(n, dtype=dist.loc.dtype, device=dist.loc.device))
+
+
+class BernoulliLikelihood(nn.Module):
+    """Probit link, labels in {-1, +1} inside the bound ({0, 1} inputs are mapped); no noise parameter
+    (the reference's classification scratch uses gpytorch.likelihoods.BernoulliLikelihood, scratch_pymc3.py:78-88)."""
+    name = "bernoulli"
+
+    def forward(self, dist):
+        return self(dist)
+
+    def __call__(self, dist):
+        # predictive class-1 probability  Phi(mu / sqrt(1 + v))
+        z = dist.loc / torch.sqrt(1.0 + dist.variance)
+        return 0.5 * torch.erfc(-z * 0.7071067811865476)
 
 
 class InducingPointKernel(nn.Module):

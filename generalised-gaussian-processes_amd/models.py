@@ -223,3 +223,122 @@ def mixture_posterior_predictive(model, test_x, trace_hyper):
             except (RuntimeError, NotPositiveDefiniteError):
                 print('Not psd for sample ' + str(i))
     return preds
+
+
+# ---------------------------------------------------------------------------------------------
+# SVGP
+# ---------------------------------------------------------------------------------------------
+class _SVGPBoundFn(torch.autograd.Function):
+    """ELBO per datum of one minibatch; forward and the whole reverse pass run in sgp_svgp_elbo."""
+
+    @staticmethod
+    def forward(ctx, ls, sf2, s2, Z, m, LS, model, xb, yb):
+        eng = model._engine_obj()
+        need = any(ctx.needs_input_grad[:6])
+        res = eng.svgp_elbo(xb, yb, Z.detach().contiguous(), ls.detach().reshape(-1).tolist(), float(sf2), float(s2),
+                            m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
+                            kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
+        info = int(res["info"].to("cpu").item())
+        if info != 0:
+            raise NotPositiveDefiniteError(info)
+        ctx.res = res if need else None
+        ctx.ls_shape = ls.shape
+        return res["out"][0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        r = ctx.res
+        n = ctx.needs_input_grad
+        return (r["g_ls"].reshape(ctx.ls_shape) * gout if n[0] else None,
+                (r["g_sf2"][0] * gout) if n[1] else None,
+                (r["g_s2"] * gout) if n[2] else None,
+                r["g_Z"] * gout if n[3] else None,
+                r["g_m"] * gout if n[4] else None,
+                r["g_LS"] * gout if n[5] else None, None, None, None)
+
+
+class StochasticVariationalGP(torch.nn.Module):
+    """The sparse GP class with the uncollapsed stochastic bound; q(u) = N(m, S) is learnt numerically
+    (reference models/svgp.py:24-141): whitened variational strategy, Cholesky variational distribution
+    (m = 0, L_S = I at start), learnable inducing locations, ScaleKernel(RBFKernel(ard)).  Minibatches run
+    through ``sgp_svgp_elbo`` on the device."""
+
+    def __init__(self, train_x, train_y, likelihood, Z_init, num_tasks=None, engine=None, jitter: float = 1e-6):
+        super().__init__()
+        if train_x.dim() == 1:
+            train_x = train_x[:, None]
+        self.train_x, self.train_y = train_x, train_y
+        self.likelihood = likelihood
+        self.num_inducing = len(Z_init)
+        self.num_data = int(train_y.shape[0])
+        self.jitter = float(jitter)
+        self.mean_module = ZeroMean()
+        self.covar_module = ScaleKernel(RBFKernel(ard_num_dims=train_x.shape[-1]))
+        Z = torch.as_tensor(Z_init).detach().clone().to(torch.float64)
+        self.inducing_inputs = torch.nn.Parameter(Z[:, None] if Z.dim() == 1 else Z)
+        self.variational_mean = torch.nn.Parameter(torch.zeros(self.num_inducing, dtype=torch.float64))
+        self.chol_variational_covar = torch.nn.Parameter(torch.eye(self.num_inducing, dtype=torch.float64))
+        self._engine = engine
+        self.to(engine.device if engine is not None else train_x.device)
+
+    def _engine_obj(self):
+        if self._engine is None:
+            from .engine import HipEngine
+            self._engine = HipEngine(self.train_x.device if self.train_x.is_cuda else None)
+        return self._engine
+
+    def _dev(self, t):
+        return t.detach().to(dtype=torch.float64, device=self._engine_obj().device).contiguous()
+
+    def elbo_minibatch(self, x_batch, y_batch):
+        """mean_b E_q log p(y_b | f_b) - KL / N  (GPyTorch ``VariationalELBO`` convention), differentiable."""
+        if x_batch.dim() == 1:
+            x_batch = x_batch[:, None]
+        yb = self._dev(y_batch).reshape(-1)
+        if getattr(self.likelihood, "name", "gaussian") == "bernoulli":
+            yb = torch.where(yb > 0, torch.ones_like(yb), -torch.ones_like(yb))
+            s2 = torch.ones(1, dtype=torch.float64, device=yb.device)
+        else:
+            s2 = self.likelihood.noise
+        return _SVGPBoundFn.apply(self.covar_module.base_kernel.lengthscale, self.covar_module.outputscale, s2,
+                                  self.inducing_inputs, self.variational_mean, self.chol_variational_covar, self,
+                                  self._dev(x_batch), yb)
+
+    def train_model(self, optimizer, train_loader, minibatch_size=100, num_epochs=25, combine_terms=True, verbose=False):
+        """Minibatch Adam on -ELBO (reference models/svgp.py:88-127); one loss entry per minibatch."""
+        losses = []
+        for i in range(num_epochs):
+            for x_batch, y_batch in train_loader:
+                self.train()
+                self.likelihood.train()
+                optimizer.zero_grad()
+                loss = -self.elbo_minibatch(x_batch, y_batch).sum()
+                losses.append(loss.item())
+                loss.backward()
+                optimizer.step()
+            if verbose:
+                print("Epoch %d  loss %.4f" % (i, losses[-1]))
+        return losses
+
+    def latent_predictive(self, test_x):
+        if test_x.dim() == 1:
+            test_x = test_x[:, None]
+        ls = self.covar_module.base_kernel.lengthscale.detach().reshape(-1).tolist()
+        mean, var, info = self._engine_obj().svgp_predict(self._dev(test_x), self._dev(self.inducing_inputs), ls,
+                                                          float(self.covar_module.outputscale.detach()),
+                                                          self._dev(self.variational_mean), self._dev(self.chol_variational_covar),
+                                                          jitter=self.jitter, kernel=self.covar_module.base_kernel.kernel_name)
+        if int(info.to("cpu").item()) != 0:
+            raise NotPositiveDefiniteError(int(info.to("cpu").item()))
+        return mean, var
+
+    def posterior_predictive(self, test_x):
+        """Predictive through the likelihood (reference models/svgp.py:132-141): a diagonal Gaussian with the
+        noise added, or class-1 probabilities for the Bernoulli likelihood."""
+        self.eval()
+        self.likelihood.eval()
+        with torch.no_grad():
+            mean, var = self.latent_predictive(test_x)
+            if getattr(self.likelihood, "name", "gaussian") == "bernoulli":
+                return self.likelihood(MultivariateNormal(mean, None, variance=var))
+            return MultivariateNormal(mean, None, variance=var + self.likelihood.noise.detach().to(var.device))

@@ -169,6 +169,29 @@ int sgp_predict(const double* Xs, int64_t ldxs, int64_t T,
                 double* mean, double* var, double* cov,
                 void* ws, size_t ws_bytes, sgp_stream_t stream);
 
+/* ---- uncollapsed (SVGP) minibatch bound: SURVEY section 8 f-3 ------------------------------------------
+ * VariationalELBO(likelihood, model, num_data=N)(model(x_batch), y_batch) over a whitened VariationalStrategy with
+ * a Cholesky variational distribution (models/svgp.py:37,46,88-127), and loss.backward() through it.
+ *   m[M], LS[M*M] (lower triangle used, ld M): q(u) = N(m, LS LS^T) in the whitened parametrisation
+ *   out[0] = mean_b E_q log p(y_b|f_b) - KL / N_total ; out[1] = sum_b E_q log p ; out[2] = KL
+ *   likelihood_id: SGP_LIK_GAUSSIAN (noise s2) or SGP_LIK_BERNOULLI_PROBIT (y in {-1,+1}, 20-point Gauss-Hermite)
+ *   with_grads: d out[0] / d{m, LS (lower), Z, lengthscale_j, sf2, s2}; info as for the collapsed bound (1..M).  */
+#define SGP_LIK_GAUSSIAN 0
+#define SGP_LIK_BERNOULLI_PROBIT 1
+size_t sgp_svgp_workspace_bytes(int64_t B, int M, int d);
+int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, int64_t B,
+                  const double* Z, int64_t ldz, const double* inv_ls, double sf2, double s2, double jitter,
+                  const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
+                  int with_grads, double* out,
+                  double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
+                  int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* latent predictive mean / variance of q(f*) at T rows (models/svgp.py:132-141 continues through the likelihood) */
+int sgp_svgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, const double* inv_ls,
+                     double sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,
+                     double* mean, double* var, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* host utility: n-point Gauss-Hermite rule for the standard normal (sum w_i f(x_i) ~ E f(N(0,1))) */
+int sgp_gauss_hermite(int n, double* x, double* w);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,3 +130,25 @@ class OracleEngine:
             if pred_noise:
                 cov = cov + s2 * torch.eye(Xs.shape[0], dtype=torch.float64)
         return mean, var, cov
+
+    # ---- SVGP (oracle.svgp_oracle) ----
+    def svgp_elbo(self, Xb, yb, Z, ls, sf2, s2, m, LS, N_total, jitter=1e-6, kernel="rbf", likelihood="gaussian",
+                  with_grads=False):
+        from oracle import svgp_oracle as S
+        lik = {"gaussian": 0, "bernoulli": 1, "bernoulli_probit": 1}[likelihood]
+        d = Z.shape[1]
+        info = torch.zeros(1, dtype=torch.int32)
+        if with_grads:
+            r = S.svgp_elbo_and_grads(Xb, yb, Z, self._ls(ls, d), float(sf2), float(s2), m, LS, N_total, jitter, KID[kernel], lik)
+            ell, kl, _, _ = S.svgp_terms(Xb, yb, Z, self._ls(ls, d), float(sf2), float(s2), m, LS, jitter, KID[kernel], lik)
+            out = torch.tensor([r["elbo"], float(ell.sum()), float(kl)], dtype=torch.float64)
+            return {"out": out, "info": info, "g_m": r["g_m"], "g_LS": r["g_LS"], "g_Z": r["g_Z"], "g_ls": r["g_ls"],
+                    "g_sf2": torch.tensor([r["g_sf2"]], dtype=torch.float64), "g_s2": torch.tensor([r["g_s2"]], dtype=torch.float64)}
+        ell, kl, _, _ = S.svgp_terms(Xb, yb, Z, self._ls(ls, d), float(sf2), float(s2), m, LS, jitter, KID[kernel], lik)
+        out = torch.tensor([float(ell.mean() - kl / N_total), float(ell.sum()), float(kl)], dtype=torch.float64)
+        return {"out": out, "info": info}
+
+    def svgp_predict(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
+        from oracle import svgp_oracle as S
+        mu, v = S.svgp_predict(Xs, Z, self._ls(ls, Z.shape[1]), float(sf2), m, LS, jitter, KID[kernel])
+        return mu, v, torch.zeros(1, dtype=torch.int32)

@@ -26,7 +26,7 @@ def lib():
 def test_every_declared_symbol_is_exported_and_bound(lib):
     import ggp_amd._lib as L
     names = header_functions()
-    assert len(names) >= 26
+    assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), "libsgp_hip.so does not export %s" % n
         assert n in L.PROTOTYPES, "python binding lacks a prototype for %s" % n
@@ -81,3 +81,17 @@ def test_product_has_no_cpu_fallback():
         ggp_amd.HipEngine()
     with pytest.raises(ggp_amd.SgpLibraryError):
         ggp_amd.CollapsedBound(torch.zeros(4, 2, dtype=torch.float64), torch.zeros(4, dtype=torch.float64))
+
+
+def test_gauss_hermite_rule_matches_numpy(lib):
+    """Host utility behind the Bernoulli-probit expectation: nodes / weights for the standard normal."""
+    import numpy as np
+    for n in (3, 10, 20):
+        x = (C.c_double * n)()
+        w = (C.c_double * n)()
+        assert lib.sgp_gauss_hermite(n, x, w) == 0
+        xr, wr = np.polynomial.hermite.hermgauss(n)
+        order = np.argsort(np.array(x[:]))
+        assert np.allclose(np.array(x[:])[order], np.sort(xr * np.sqrt(2.0)), atol=1e-13)
+        assert np.allclose(np.array(w[:])[order], (wr / np.sqrt(np.pi))[np.argsort(xr)], rtol=1e-11, atol=1e-300)
+        assert abs(sum(w[:]) - 1.0) < 1e-13

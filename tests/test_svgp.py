@@ -1,0 +1,144 @@
+"""SVGP minibatch path.  CPU: model class + autograd bridge through the test double against
+an independent torch-autograd loop on the oracle graph.  GPU: sgp_svgp_elbo / sgp_svgp_predict against the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ggp_amd
+from fake_engine import OracleEngine
+from oracle import svgp_oracle as S
+
+DT = torch.float64
+
+
+def problem(N=300, d=2, M=12, seed=0, classify=False):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(N, d, dtype=DT, generator=g)
+    f = torch.sin(X[:, 0] * 1.5) + 0.5 * X[:, 1 % d]
+    y = torch.sign(f + 0.3 * torch.randn(N, dtype=DT, generator=g)) if classify else f + 0.2 * torch.randn(N, dtype=DT, generator=g)
+    Z = X[torch.randperm(N, generator=g)[:M]].clone()
+    m = 0.3 * torch.randn(M, dtype=DT, generator=g)
+    LS = torch.tril(0.2 * torch.randn(M, M, dtype=DT, generator=g)) + torch.eye(M, dtype=DT)
+    ls = 0.8 + torch.rand(d, dtype=DT, generator=g)
+    return X, y, Z, m, LS, ls
+
+
+def reference_trace(X, y, Z0, batches, lr, lik, N):
+    """-ELBO under Adam on GPyTorch's raw parametrisation, torch autograd on the oracle graph."""
+    d, M = X.shape[1], Z0.shape[0]
+    raw_ls = torch.zeros(1, d, dtype=DT, requires_grad=True)
+    raw_os = torch.zeros((), dtype=DT, requires_grad=True)
+    raw_n = torch.zeros(1, dtype=DT, requires_grad=True)
+    Z = Z0.clone().requires_grad_(True)
+    m = torch.zeros(M, dtype=DT, requires_grad=True)
+    LS = torch.eye(M, dtype=DT, requires_grad=True)
+    params = ([raw_n] if lik == 0 else []) + [raw_os, raw_ls, Z, m, LS]
+    opt = torch.optim.Adam(params, lr=lr)
+    out = []
+    for xb, yb in batches:
+        opt.zero_grad()
+        s2 = F.softplus(raw_n)[0] + 1e-4 if lik == 0 else torch.tensor(1.0, dtype=DT)
+        loss = -S.svgp_elbo(xb, yb, Z, F.softplus(raw_ls).reshape(-1), F.softplus(raw_os), s2, m, LS, N, 1e-6, 0, lik)
+        out.append(float(loss.detach()))
+        loss.backward()
+        opt.step()
+    return out
+
+
+@pytest.mark.parametrize("classify", [False, True])
+def test_svgp_model_trace_matches_autograd_reference(classify):
+    X, y, Z0, _, _, _ = problem(classify=classify)
+    lik = ggp_amd.BernoulliLikelihood() if classify else ggp_amd.GaussianLikelihood()
+    model = ggp_amd.StochasticVariationalGP(X, y, lik, Z0, engine=OracleEngine())
+    assert model.num_inducing == 12 and model.num_data == 300
+    batches = [(X[i:i + 100], y[i:i + 100]) for i in (0, 100, 200)]
+    opt = torch.optim.Adam(model.parameters(), lr=0.02)
+    losses = model.train_model(opt, batches, minibatch_size=100, num_epochs=2)
+    ref = reference_trace(X, y, Z0, batches * 2, 0.02, 1 if classify else 0, 300)
+    assert len(losses) == 6
+    assert np.max(np.abs(np.array(losses) - np.array(ref))) < 1e-8, (losses, ref)
+    pred = model.posterior_predictive(X[:7])
+    if classify:
+        assert pred.shape == (7,) and torch.all((pred > 0) & (pred < 1))
+    else:
+        assert pred.loc.shape == (7,) and torch.all(pred.variance > 0)
+
+
+def test_oracle_svgp_kl_and_gaussian_ell_closed_forms():
+    X, y, Z, m, LS, ls = problem()
+    ell, kl, mu, v = S.svgp_terms(X, y, Z, ls, 1.3, 0.1, m, LS)
+    Smat = LS @ LS.T
+    kl_ref = 0.5 * (torch.trace(Smat) + m @ m - 12 - torch.logdet(Smat))
+    assert abs(float(kl - kl_ref)) < 1e-10
+    # Gaussian expectation by quadrature agrees with the closed form
+    x, w = S.gauss_hermite(40)
+    fq = mu[:, None] + torch.sqrt(v)[:, None] * x[None, :]
+    quad = ((-0.5 * math.log(2 * math.pi * 0.1) - (y[:, None] - fq) ** 2 / 0.2) * w[None, :]).sum(1)
+    assert float((quad - ell).abs().max()) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,M,lik,kern", [(300, 2, 12, "gaussian", "rbf"), (300, 2, 12, "bernoulli", "rbf"),
+                                            (4096, 2, 256, "bernoulli", "rbf"), (1000, 5, 130, "gaussian", "matern52"),
+                                            (65, 1, 5, "gaussian", "rbf")])
+def test_svgp_elbo_and_grads_vs_oracle(engine, N, d, M, lik, kern):
+    X, y, Z, m, LS, ls = problem(N, d, M, seed=N + M, classify=(lik == "bernoulli"))
+    kid = {"rbf": 0, "matern32": 1, "matern52": 2}[kern]
+    likid = 1 if lik == "bernoulli" else 0
+    N_total = 10 * N
+    if kid == 0:
+        ref = S.svgp_elbo_and_grads(X, y, Z, ls, 1.3, 0.1, m, LS, N_total, 1e-6, kid, likid)
+    else:
+        ref = None
+        ell, kl, _, _ = S.svgp_terms(X, y, Z, ls, 1.3, 0.1, m, LS, 1e-6, kid, likid)
+        elbo_ref = float(ell.mean() - kl / N_total)
+    D = lambda t: t.to(engine.device).contiguous()  # noqa: E731
+    res = engine.svgp_elbo(D(X), D(y), D(Z), ls.tolist(), 1.3, 0.1, D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
+                           likelihood=lik, with_grads=True)
+    assert int(res["info"].item()) == 0
+    out = res["out"].cpu()
+    if ref is None:
+        assert abs(float(out[0]) - elbo_ref) < 1e-10 * max(1.0, abs(elbo_ref))
+        return
+    assert abs(float(out[0]) - ref["elbo"]) < 1e-10 * max(1.0, abs(ref["elbo"]))
+
+    def close(a, b, rt=2e-7):
+        a, b = a.cpu().reshape(-1), torch.as_tensor(b).reshape(-1)
+        return float((a - b).abs().max()) < rt * max(1e-3, float(b.abs().max()))
+    assert close(res["g_m"], ref["g_m"])
+    assert close(res["g_LS"], ref["g_LS"])
+    assert close(res["g_Z"], ref["g_Z"], 1e-6)
+    assert close(res["g_ls"], ref["g_ls"], 1e-6)
+    assert close(res["g_sf2"], torch.tensor([ref["g_sf2"]]), 1e-6)
+    if lik == "gaussian":
+        assert close(res["g_s2"], torch.tensor([ref["g_s2"]]))
+    # value-only call returns the same bound
+    res2 = engine.svgp_elbo(D(X), D(y), D(Z), ls.tolist(), 1.3, 0.1, D(m), D(LS), N_total, jitter=1e-6, kernel=kern, likelihood=lik)
+    assert float(res2["out"][0]) == float(res["out"][0])
+    mu, v, info = engine.svgp_predict(D(X[:50]), D(Z), ls.tolist(), 1.3, D(m), D(LS), jitter=1e-6, kernel=kern)
+    mu_r, v_r = S.svgp_predict(X[:50], Z, ls, 1.3, m, LS, 1e-6, kid)
+    assert float((mu.cpu() - mu_r).abs().max()) < 1e-8 and float((v.cpu() - v_r).abs().max()) < 1e-8  # cond(Kuu) ~ 1e6 at M = 256
+
+
+@pytest.mark.gpu
+def test_svgp_model_on_device_c4_shape(engine):
+    """BASELINE config C4 shape at reduced N: 2-D classification, M = 256, minibatch 4096, Bernoulli-probit."""
+    g = torch.Generator().manual_seed(4)
+    N, M, Bsz = 20000, 256, 4096
+    X = torch.randn(N, 2, dtype=DT, generator=g)
+    y = torch.sign(torch.sin(2 * X[:, 0]) * torch.cos(X[:, 1]) + 0.1 * torch.randn(N, dtype=DT, generator=g))
+    Z0 = X[torch.randperm(N, generator=g)[:M]].clone()
+    model = ggp_amd.StochasticVariationalGP(X.to(engine.device), y.to(engine.device), ggp_amd.BernoulliLikelihood(), Z0, engine=engine)
+    batches = [(X[i:i + Bsz].to(engine.device), y[i:i + Bsz].to(engine.device)) for i in range(0, N - Bsz + 1, Bsz)]
+    opt = torch.optim.Adam(model.parameters(), lr=0.05)
+    losses = model.train_model(opt, batches, minibatch_size=Bsz, num_epochs=6)
+    ref = reference_trace(X, y, Z0, [(a.cpu(), b.cpu()) for a, b in batches[:2]], 0.05, 1, N)
+    assert np.max(np.abs(np.array(losses[:2]) - np.array(ref))) < 1e-8
+    assert losses[-1] < losses[0]
+    p = model.posterior_predictive(X[:2000].to(engine.device)).cpu()
+    acc = float(((p > 0.5) == (y[:2000] > 0)).double().mean())
+    assert acc > 0.8, acc
