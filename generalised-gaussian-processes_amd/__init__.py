@@ -9,7 +9,8 @@ from .gp_shim import (BernoulliLikelihood, ExactMarginalLogLikelihood, GaussianL
                       MultivariateNormal, RBFKernel, ScaleKernel, ZeroMean, settings)
 from .hmc import NUTS, Trace, sample_nuts  # noqa: F401
 from .metrics import nlpd, nlpd_marginal, nlpd_mixture, rmse  # noqa: F401
-from .models import BayesianSparseGPR_HMC, SparseGPR, StochasticVariationalGP, mixture_posterior_predictive  # noqa: F401
+from .models import (BayesianSparseGPR_HMC, BayesianStochasticVariationalGP, SparseGPR, StochasticVariationalGP,  # noqa: F401
+                     VariationalHyperDist, mixture_posterior_predictive)
 
 
 def __getattr__(name):  # lazy: importing the package must work without a GPU (build / symbol checks)

@@ -11,6 +11,7 @@ accepts ``num_steps`` as an alias of ``max_steps`` (R5); the bound subtracts the
 """
 from __future__ import annotations
 
+import math
 import time
 from typing import Optional
 
@@ -242,19 +243,22 @@ class _SVGPBoundFn(torch.autograd.Function):
         if info != 0:
             raise NotPositiveDefiniteError(info)
         ctx.res = res if need else None
-        ctx.ls_shape = ls.shape
+        ctx.meta = [(t.shape, t.device) for t in (ls, sf2, s2, Z, m, LS)]
         return res["out"][0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         r = ctx.res
         n = ctx.needs_input_grad
-        return (r["g_ls"].reshape(ctx.ls_shape) * gout if n[0] else None,
-                (r["g_sf2"][0] * gout) if n[1] else None,
-                (r["g_s2"] * gout) if n[2] else None,
-                r["g_Z"] * gout if n[3] else None,
-                r["g_m"] * gout if n[4] else None,
-                r["g_LS"] * gout if n[5] else None, None, None, None)
+        keys = ("g_ls", "g_sf2", "g_s2", "g_Z", "g_m", "g_LS")
+        outs = []
+        for i, k in enumerate(keys):  # hyper-parameters may live on the host (Bayesian variant), Z / m / LS on the device
+            if not n[i]:
+                outs.append(None)
+                continue
+            shape, dev = ctx.meta[i]
+            outs.append((r[k] * gout).to(dev).reshape(shape))
+        return (*outs, None, None, None)
 
 
 class StochasticVariationalGP(torch.nn.Module):
@@ -342,3 +346,100 @@ class StochasticVariationalGP(torch.nn.Module):
             if getattr(self.likelihood, "name", "gaussian") == "bernoulli":
                 return self.likelihood(MultivariateNormal(mean, None, variance=var))
             return MultivariateNormal(mean, None, variance=var + self.likelihood.noise.detach().to(var.device))
+
+
+class VariationalHyperDist(torch.nn.Module):
+    """q(log theta) = N(q_mu, L L^T + 1e-5 I) with the Cholesky factor stored as a vector
+    (reference models/bayesian_svgp.py:30-71).  Host-side: hyper_dim = d + 2."""
+
+    def __init__(self, hyper_dim, prior_var=0.01, n=1, seed=None):
+        super().__init__()
+        self.hyper_dim, self.n, self.prior_var = hyper_dim, n, prior_var
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        self.q_mu = torch.nn.Parameter(torch.randn(hyper_dim, dtype=torch.float64, generator=g) * 1e-3)
+        self.q_sigma_vec = torch.nn.Parameter(torch.randn(hyper_dim * (hyper_dim + 1) // 2, dtype=torch.float64, generator=g) * 1e-3)
+        self._gen = g
+
+    def construct_sigma(self):
+        rows, cols = torch.tril_indices(self.hyper_dim, self.hyper_dim)
+        lower = torch.zeros(self.hyper_dim, self.hyper_dim, dtype=torch.float64)
+        lower = lower.index_put((rows, cols), self.q_sigma_vec)   # the vector also fills the diagonal, as upstream
+        return lower @ lower.T + 1e-5 * torch.eye(self.hyper_dim, dtype=torch.float64)
+
+    def kl_per_point(self):
+        """KL(q(log theta) || N(0, prior_var I)) / n  -- the reference's added loss term (:73-84)."""
+        S = self.construct_sigma()
+        k = self.hyper_dim
+        kl = 0.5 * (torch.trace(S) / self.prior_var + (self.q_mu @ self.q_mu) / self.prior_var - k
+                    + k * math.log(self.prior_var) - torch.logdet(S))
+        return kl / self.n
+
+    def forward(self, num_samples):
+        S = self.construct_sigma()
+        L = torch.linalg.cholesky(S)
+        eps = torch.randn(num_samples, self.hyper_dim, dtype=torch.float64, generator=self._gen)
+        return self.q_mu[None, :] + eps @ L.T
+
+
+class BayesianStochasticVariationalGP(StochasticVariationalGP):
+    """SVGP with a variational distribution over log-hyperparameters, 5 reparametrised theta samples per
+    minibatch (reference models/bayesian_svgp.py:87-181): theta = exp(log theta), outputscale = theta_0,
+    lengthscale = theta_1..d, noise = theta_{d+1}^2.  The five bounds are five sgp_svgp_elbo launches.
+    Deliberate deviations: the reparametrisation gradient reaches q(log theta) (upstream
+    assigns theta through GPyTorch setters, which detaches it), and prediction uses exp() like training."""
+
+    def __init__(self, train_x, train_y, likelihood, Z_init, engine=None, jitter: float = 1e-6, seed=None, num_hyper_samples=5):
+        super().__init__(train_x, train_y, likelihood, Z_init, engine=engine, jitter=jitter)
+        self.n = self.num_data
+        self.input_dim = self.train_x.shape[1]
+        self.num_hyper_samples = num_hyper_samples
+        self.log_theta = VariationalHyperDist(self.input_dim + 2, prior_var=0.01, n=self.n, seed=seed)
+        self.log_theta.to("cpu")
+
+    def sample_variational_log_hyper(self, num_samples):
+        return self.log_theta(num_samples)
+
+    def _elbo_at(self, x_batch, y_batch, log_theta):
+        theta = torch.exp(log_theta)
+        if x_batch.dim() == 1:
+            x_batch = x_batch[:, None]
+        return _SVGPBoundFn.apply(theta[1:-1], theta[0], theta[-1] ** 2, self.inducing_inputs, self.variational_mean,
+                                  self.chol_variational_covar, self, self._dev(x_batch), self._dev(y_batch).reshape(-1))
+
+    def train_model(self, optimizer, train_loader, minibatch_size=100, num_epochs=25, combine_terms=True):
+        """Returns (epoch_losses, batch_losses) like the reference (:144-181)."""
+        self.train()
+        self.likelihood.train()
+        epoch_losses, batch_losses = [], []
+        for i in range(num_epochs):
+            batch_losses = []
+            for x_batch, y_batch in train_loader:
+                optimizer.zero_grad()
+                loss = 0.0
+                kl = self.log_theta.kl_per_point()
+                for _ in range(self.num_hyper_samples):
+                    lt = self.sample_variational_log_hyper(1).flatten()
+                    e = self._elbo_at(x_batch, y_batch, lt)
+                    loss = loss + (-(e.to("cpu")) + kl) / self.num_hyper_samples
+                batch_losses.append(loss.item())
+                loss.backward()
+                optimizer.step()
+            epoch_losses.append(float(np.sum(batch_losses)))
+        return epoch_losses, batch_losses
+
+    def mixture_posterior_predictive(self, test_x, num_samples=100):
+        """One predictive per hyper-sample from q(log theta) (reference :183-207)."""
+        self.eval()
+        self.likelihood.eval()
+        out = []
+        with torch.no_grad():
+            for lt in self.sample_variational_log_hyper(num_samples):
+                th = torch.exp(lt)
+                if test_x.dim() == 1:
+                    test_x = test_x[:, None]
+                mean, var, info = self._engine_obj().svgp_predict(self._dev(test_x), self._dev(self.inducing_inputs), th[1:-1].tolist(),
+                                                                  float(th[0]), self._dev(self.variational_mean),
+                                                                  self._dev(self.chol_variational_covar), jitter=self.jitter)
+                if int(info.to("cpu").item()) == 0:
+                    out.append(MultivariateNormal(mean, None, variance=var + float(th[-1]) ** 2))
+        return out

@@ -142,3 +142,24 @@ def test_svgp_model_on_device_c4_shape(engine):
     p = model.posterior_predictive(X[:2000].to(engine.device)).cpu()
     acc = float(((p > 0.5) == (y[:2000] > 0)).double().mean())
     assert acc > 0.8, acc
+
+
+def test_bayesian_svgp_hyper_distribution_and_training():
+    """reference models/bayesian_svgp.py: q(log theta) KL term, 5 reparametrised samples per minibatch."""
+    X, y, Z0, _, _, _ = problem(N=200, M=8)
+    model = ggp_amd.BayesianStochasticVariationalGP(X, y, ggp_amd.GaussianLikelihood(), Z0, engine=OracleEngine(), seed=3)
+    hd = model.log_theta
+    assert hd.hyper_dim == 4 and hd.q_sigma_vec.numel() == 10
+    q = torch.distributions.MultivariateNormal(hd.q_mu, hd.construct_sigma())
+    p = torch.distributions.MultivariateNormal(torch.zeros(4, dtype=DT), 0.01 * torch.eye(4, dtype=DT))
+    assert abs(float(hd.kl_per_point()) - float(torch.distributions.kl_divergence(q, p)) / 200) < 1e-10
+    s = model.sample_variational_log_hyper(7)
+    assert s.shape == (7, 4)
+    batches = [(X[i:i + 100], y[i:i + 100]) for i in (0, 100)]
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    epoch_losses, batch_losses = model.train_model(opt, batches, num_epochs=3)
+    assert len(epoch_losses) == 3 and len(batch_losses) == 2 and all(math.isfinite(v) for v in epoch_losses)
+    assert hd.q_mu.grad is not None and float(hd.q_mu.grad.abs().max()) > 0     # the reparametrisation gradient arrives
+    assert model.variational_mean.grad is not None and model.inducing_inputs.grad is not None
+    preds = model.mixture_posterior_predictive(X[:9], num_samples=6)
+    assert len(preds) == 6 and preds[0].loc.shape == (9,) and torch.all(preds[0].variance > 0)
