@@ -68,8 +68,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_TOTAL)
-    ap.add_argument("--m", type=int, default=M_IND)
+    ap.add_argument("--rows", dest="n", type=int, default=N_TOTAL)
+    ap.add_argument("--inducing", dest="m", type=int, default=M_IND)
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="rows of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -77,10 +77,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # functional check of the multi-rank path on a 1-GPU box: SGP_BENCH_BACKEND=gloo SGP_BENCH_SHARE_GPU=1 lets
+    # several ranks share cuda:0 (RCCL refuses duplicate devices); numbers from such a run mean nothing
+    backend = os.environ.get("SGP_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGP_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sparse-GP core has no CPU path")
     dev = torch.device("cuda", local_rank)
