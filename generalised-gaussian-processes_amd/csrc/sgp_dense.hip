@@ -6,7 +6,7 @@
 //
 // Design: everything O(M^3) is phrased as 64 x 64-tiled GEMMs on v_mfma_f64_16x16x4_f64 so the only
 // latency-bound pieces are the 64 x 64 diagonal blocks, which one workgroup factors and inverts in LDS.
-//   potrf  : right-looking, per 64-column block  { diag factor+invert | panel = A21 Linv_kk^T | A22 -= P P^T }
+//   potrf  : right-looking, per 64-column block  { fused: diag factor (every WG) + panel forward substitution | A22 -= P P^T }
 //   trtri  : recursive doubling on the inverted diagonal blocks, Inv21 = -Inv22 (L21 Inv11), batched GEMMs
 // Triangular structure is exploited by clipping each output tile's k-range (GemmDesc::klo/khi masks).
 #include "sgp_dense.hpp"
@@ -191,69 +191,6 @@ __device__ __forceinline__ void block_inverse64(double (*S)[DLD], double (*Inv)[
   inv_combine(S, Inv, T, 32, 1);
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Linv, int64_t ld, int k0, int* info, int info_base) {
-  __shared__ double S[DB][DLD];
-  __shared__ double Inv[DB][DLD];
-  __shared__ double T[DB][DLD];
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  for (int e = tid; e < DB * DB; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    S[i][j] = (j <= i) ? A[(int64_t)(k0 + i) * ld + k0 + j] : 0.0;
-    Inv[i][j] = 0.0;
-  }
-  __syncthreads();
-  // Register-resident right-looking factorization: thread (i = tid & 63, g = tid >> 6) keeps the 16
-  // elements S[i][g + 4k] of its row; per column j the owning group publishes the raw column through a
-  // double-buffered LDS vector, everybody reads pivot / own-row / partner entries from it and updates
-  // its registers:  a[i][p] -= col[i] col[p] / col[j].   One barrier per column, fully unrolled so every
-  // register index is static.
-  const int i = tid & 63;
-  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double a[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = S[i][g + 4 * k];
-  double* col = &T[0][0];   // 2 x 64 doubles of scratch inside T
-  double* piv = &T[2][0];   // the 64 pivots d_j = S[j][j] at elimination time
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < DB; ++j) {
-    const int jg = j & 3, jk = j >> 2;
-    double* cb = col + (j & 1) * 64;
-    if (g == jg) cb[i] = a[jk];   // raw column j (the owner keeps it raw: scaled by 1/sqrt(d_j) after the loop)
-    __syncthreads();
-    double d = cb[j];
-    if (!(d > 0.0)) {  // non-positive or NaN pivot: report LAPACK-style, keep going on a unit pivot
-      if (tid == 0 && bad == 0) bad = j + 1;
-      d = 1.0;
-    }
-    if (tid == 0) piv[j] = d;
-    const double t = cb[i] / d;
-    // columns p = g + 4k > j of this row; sqrt and the scaling of column j stay off this critical path
-    if (g > jg) a[jk] = fma(-t, cb[g + 4 * jk], a[jk]);
-#pragma unroll
-    for (int k = jk + 1; k < 16; ++k) a[k] = fma(-t, cb[g + 4 * k], a[k]);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int p = g + 4 * k;
-    const double l = sqrt(piv[p]);
-    S[i][p] = (p < i) ? a[k] / l : (p == i ? l : 0.0);
-  }
-  __syncthreads();
-
-  block_inverse64(S, Inv, T);
-
-  for (int e = tid; e < DB * DB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    A[(int64_t)(k0 + r) * ld + k0 + c] = S[r][c];
-    Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
-  }
-  if (tid == 0 && bad != 0 && *info == 0) *info = info_base + bad;
-}
-
 // inverses of the 64 x 64 diagonal blocks of an already-factored L (one workgroup per block)
 __global__ __launch_bounds__(256) void tri_diag_inv_kernel(const double* L, double* Linv, int64_t ld) {
   __shared__ double S[DB][DLD];
@@ -287,22 +224,121 @@ __global__ void zero_upper_blocks_kernel(double* A, int64_t ld, int Mp) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One block-column step of the factorization in ONE launch:
+//   every workgroup factors the 64 x 64 diagonal block itself (redundantly -- it is latency, not work):
+//     thread (i = tid & 63, g = tid >> 6) keeps A_kk[i][16g .. 16g+15]; the wave that owns a 16-column
+//     panel factors it entirely in registers, rows talk through v_readlane (no LDS, no barrier), then
+//     publishes the panel to LDS and the waves to its right apply the rank-16 update: 4 barriers per block;
+//   workgroup 0 writes L_kk (zeros above the diagonal);
+//   workgroup b >= 1 solves its 256 rows of the panel  P = A_ik L_kk^-T  by forward substitution, one row
+//   per thread with the row in registers and L_kk broadcast from LDS.
+// The inverses of the diagonal blocks (needed by tri_inverse) are computed afterwards, off this chain.
+// ---------------------------------------------------------------------------------------------
+constexpr int PLD = 18;  // LDS row stride of a 64 x 16 panel (16-byte aligned rows)
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* A, int64_t ld, int k0, int Mp, int* info, int info_base) {
+  __shared__ double Sp[4][DB][PLD];  // the four 16-column panels of L_kk
+  __shared__ double rd[DB];          // 1 / L_kk[j][j]
+  __shared__ int bad;
+  const int tid = threadIdx.x, i = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) bad = 0;
+  double a[16];
+  {
+    const double* src = A + (int64_t)(k0 + i) * ld + k0 + 16 * g;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
+      a[2 * k] = v[0];
+      a[2 * k + 1] = v[1];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    if (g == pb) {
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = 16 * pb + jj;
+        double d = readlane_f64(a[jj], j);
+        if (!(d > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
+          if (i == 0 && bad == 0) bad = j + 1;
+          d = 1.0;
+        }
+        const double rs = 1.0 / sqrt(d);
+        const double l = a[jj] * rs;  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
+        a[jj] = l;
+        if (i == 0) rd[j] = rs;
+#pragma unroll
+        for (int q = jj + 1; q < 16; ++q) a[q] = fma(-l, readlane_f64(l, 16 * pb + q), a[q]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) Sp[pb][i][jj] = (i >= 16 * pb + jj) ? a[jj] : 0.0;
+    }
+    __syncthreads();
+    if (g > pb) {  // rank-16 update of this wave's 16 columns p = 16 g + k:  a[i][p] -= sum_j L[i][j] L[p][j]
+      double li[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) li[jj] = Sp[pb][i][jj];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const double* lp = &Sp[pb][16 * g + k][0];  // wave-uniform row: broadcast reads
+        double s = a[k];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) s = fma(-li[jj], lp[jj], s);
+        a[k] = s;
+      }
+    }
+  }
+  __syncthreads();
+
+  if (blockIdx.x == 0) {
+    double* dst = A + (int64_t)(k0 + i) * ld + k0 + 16 * g;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dst[k] = (16 * g + k <= i) ? a[k] : 0.0;
+    if (tid == 0 && bad != 0 && *info == 0) *info = info_base + bad;
+    return;
+  }
+
+  // panel rows of this workgroup: forward substitution  x_j = (a_j - sum_{p<j} x_p L[j][p]) / L[j][j]
+  const int row = k0 + DB + (blockIdx.x - 1) * 256 + tid;
+  if (row >= Mp) return;
+  double* prow = A + (int64_t)row * ld + k0;
+  double x[DB];
+#pragma unroll
+  for (int k = 0; k < DB / 2; ++k) {
+    const d2 v = *reinterpret_cast<const d2*>(prow + 2 * k);
+    x[2 * k] = v[0];
+    x[2 * k + 1] = v[1];
+  }
+#pragma unroll
+  for (int j = 0; j < DB; ++j) {
+    double s = x[j];
+#pragma unroll
+    for (int p = 0; p < j; ++p) s = fma(-x[p], Sp[p >> 4][j][p & 15], s);
+    x[j] = s * rd[j];
+  }
+#pragma unroll
+  for (int k = 0; k < DB / 2; ++k) *reinterpret_cast<d2*>(prow + 2 * k) = d2{x[2 * k], x[2 * k + 1]};
+}
+
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, hipStream_t st) {
   const int nb = Mp / DB;
   fill_zero(Linv, (size_t)Mp * ld, st);
   for (int kb = 0; kb < nb; ++kb) {
     const int k0 = kb * DB;
-    potrf_diag_kernel<<<1, 256, 0, st>>>(A, Linv, ld, k0, info, info_base + k0);
     const int rem = Mp - (kb + 1) * DB;
+    potrf_step_kernel<<<1 + (rem + 255) / 256, 256, 0, st>>>(A, ld, k0, Mp, info, info_base + k0);
     if (rem > 0) {
       double* panel = A + (int64_t)(k0 + DB) * ld + k0;
-      GemmDesc g;
-      g.A = panel; g.lda = ld;
-      g.B = Linv + (int64_t)k0 * (ld + 1); g.ldb = ld; g.tb = true;
-      g.C = panel; g.ldc = ld;
-      g.m = rem; g.n = DB; g.k = DB;
-      g.khi_mask = 0;
-      gemm(g, st);
       GemmDesc u;
       u.A = panel; u.lda = ld;
       u.B = panel; u.ldb = ld; u.tb = true;
@@ -313,6 +349,7 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
     }
   }
   if (nb > 1) zero_upper_blocks_kernel<<<dim3(nb, nb), 256, 0, st>>>(A, ld, Mp);
+  tri_diag_inv_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);  // level 0 of tri_inverse(), all blocks at once
 }
 
 void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {
