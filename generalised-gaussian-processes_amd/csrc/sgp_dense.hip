@@ -209,6 +209,26 @@ __global__ __launch_bounds__(256) void tri_diag_inv_kernel(const double* L, doub
     Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
   }
 }
+// after the last step: Linv's diagonal blocks hold the staged L_kk; move them into A and replace them by their inverses
+__global__ __launch_bounds__(256) void potrf_finish_kernel(double* A, double* Linv, int64_t ld) {
+  __shared__ double S[DB][DLD];
+  __shared__ double Inv[DB][DLD];
+  __shared__ double T[DB][DLD];
+  const int tid = threadIdx.x, k0 = blockIdx.x * DB;
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    const double v = (j <= i) ? Linv[(int64_t)(k0 + i) * ld + k0 + j] : 0.0;
+    S[i][j] = v;
+    Inv[i][j] = 0.0;
+    A[(int64_t)(k0 + i) * ld + k0 + j] = v;
+  }
+  __syncthreads();
+  block_inverse64(S, Inv, T);
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
+  }
+}
 void tri_diag_inverse(const double* L, double* Linv, int64_t ld, int Mp, hipStream_t st) {
   tri_diag_inv_kernel<<<Mp / DB, 256, 0, st>>>(L, Linv, ld);
 }
@@ -230,7 +250,8 @@ __global__ void zero_upper_blocks_kernel(double* A, int64_t ld, int Mp) {
 //     thread (i = tid & 63, g = tid >> 6) keeps A_kk[i][16g .. 16g+15]; the wave that owns a 16-column
 //     panel factors it entirely in registers, rows talk through v_readlane (no LDS, no barrier), then
 //     publishes the panel to LDS and the waves to its right apply the rank-16 update: 4 barriers per block;
-//   workgroup 0 writes L_kk (zeros above the diagonal);
+//   workgroup 0 writes L_kk (zeros above the diagonal) to a staging matrix -- never into A_kk, which the other
+//   workgroups of the same launch are reading; `potrf_finish_kernel` moves it into place at the end;
 //   workgroup b >= 1 solves its 256 rows of the panel  P = A_ik L_kk^-T  by forward substitution, one row
 //   per thread with the row in registers and L_kk broadcast from LDS.
 // The inverses of the diagonal blocks (needed by tri_inverse) are computed afterwards, off this chain.
@@ -244,7 +265,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void potrf_step_kernel(double* A, int64_t ld, int k0, int Mp, int* info, int info_base) {
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lstage, int64_t ld, int k0, int Mp, int* info,
+                                                          int info_base) {
   __shared__ double Sp[4][DB][PLD];  // the four 16-column panels of L_kk
   __shared__ double rd[DB];          // 1 / L_kk[j][j]
   __shared__ int bad;
@@ -301,7 +323,8 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* A, int64_t ld, 
   __syncthreads();
 
   if (blockIdx.x == 0) {
-    double* dst = A + (int64_t)(k0 + i) * ld + k0 + 16 * g;
+    // L_kk goes to the staging matrix, NOT into A: the other workgroups of this launch are still reading A_kk
+    double* dst = Lstage + (int64_t)(k0 + i) * ld + k0 + 16 * g;
 #pragma unroll
     for (int k = 0; k < 16; ++k) dst[k] = (16 * g + k <= i) ? a[k] : 0.0;
     if (tid == 0 && bad != 0 && *info == 0) *info = info_base + bad;
@@ -336,7 +359,7 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   for (int kb = 0; kb < nb; ++kb) {
     const int k0 = kb * DB;
     const int rem = Mp - (kb + 1) * DB;
-    potrf_step_kernel<<<1 + (rem + 255) / 256, 256, 0, st>>>(A, ld, k0, Mp, info, info_base + k0);
+    potrf_step_kernel<<<1 + (rem + 255) / 256, 256, 0, st>>>(A, Linv, ld, k0, Mp, info, info_base + k0);
     if (rem > 0) {
       double* panel = A + (int64_t)(k0 + DB) * ld + k0;
       GemmDesc u;
@@ -349,7 +372,8 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
     }
   }
   if (nb > 1) zero_upper_blocks_kernel<<<dim3(nb, nb), 256, 0, st>>>(A, ld, Mp);
-  tri_diag_inv_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);  // level 0 of tri_inverse(), all blocks at once
+  // staged L_kk -> A_kk, and their inverses -> diagonal blocks of Linv (level 0 of tri_inverse()), all blocks at once
+  potrf_finish_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);
 }
 
 void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {
