@@ -102,10 +102,10 @@ class HipEngine:
         _lib.check("sgp_suffstats_fwd", st)
         return out
 
-    def kuu(self, Z, ls, sf2, jitter, kernel="rbf") -> torch.Tensor:
+    def kuu(self, Z, ls, sf2, jitter, kernel="rbf", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         M, d = Z.shape
         self._chk(Z, "Z")
-        K = self.empty(M, M)
+        K = out if out is not None else self.empty(M, M)
         st = self.lib.sgp_kuu(self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(jitter), M, d, _kernel_id(kernel),
                               self._ptr(K), self._stream())
         _lib.check("sgp_kuu", st)
@@ -121,6 +121,40 @@ class HipEngine:
         st = self.lib.sgp_kuu_factor(self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_kuu_factor", st)
         return Linv, info
+
+    def kuu_factor_graph(self, M: int):
+        """The ~50 launches of ``kuu_factor`` captured once per M in a hipGraph over static buffers: replaying it costs
+        the host one launch instead of ~1 ms of enqueueing, so the factorization really runs underneath the start of
+        pass 1.  Returns dict(graph, Kuu, Linv, info) or None when capture is unavailable (callers fall back)."""
+        ent = self._graphs.get(M, False) if hasattr(self, "_graphs") else False
+        if ent is not False:
+            return ent
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        try:
+            Kst = torch.eye(M, dtype=torch.float64, device=self.device)
+            Linv = self.empty(self.lib.sgp_kuu_factor_len(M))
+            info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            ws = torch.empty(self.lib.sgp_kuu_factor_workspace_bytes(M), dtype=torch.uint8, device=self.device)
+
+            def run():
+                st = self.lib.sgp_kuu_factor(self._ptr(Kst), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+                _lib.check("sgp_kuu_factor", st)
+
+            warm = torch.cuda.Stream(device=self.device)
+            warm.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(warm):
+                run()
+            torch.cuda.current_stream(self.device).wait_stream(warm)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws}
+        except Exception:  # capture not supported in this environment: plain launches still work
+            ent = None
+        self._graphs[M] = ent
+        return ent
 
     def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None):
         """Runs the O(M^3) tail on (already all-reduced) packed statistics.

@@ -306,12 +306,13 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=float(G["jitter"]), engine=engine)
     Z = dev(G["Z"], engine)
     outs = []
-    for ov in (True, False, True):
-        cb.overlap_tail = ov
+    for ov, gr in ((True, True), (False, False), (True, False), (True, True)):
+        cb.overlap_tail, cb.use_graph = ov, gr
         F, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
         outs.append((F, g["ls"].clone(), g["Z"].clone()))
-    assert outs[0][0] == outs[1][0] == outs[2][0]
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert outs[0][0] == outs[1][0] == outs[2][0] == outs[3][0]
+    assert all(torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2]) for o in outs[1:])
+    assert engine.kuu_factor_graph(Z.shape[0]) is not None, "hipGraph capture of the Kuu factorization failed"
     # a singular Kuu is still reported through the merged info flag
     Zbad = torch.zeros(6, 18, dtype=torch.float64, device=engine.device)
     cb0 = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=0.0, engine=engine)
