@@ -132,17 +132,22 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
 // ---------------------------------------------------------------------------------------------
 // 2. contraction: slab[split][tile] (+)= sum over this split's chunks of K'_I^T K'_J
 // ---------------------------------------------------------------------------------------------
-template <bool DIAG>
+// NW = waves per workgroup: 4 (each wave a 64 x 64 block, 2 workgroups = 2 waves per SIMD) or
+//                           8 (each wave a 64 x 32 block, 2 workgroups = 4 waves per SIMD, <= 128 VGPRs)
+template <bool DIAG, int NW>
 __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* __restrict__ Kfu, int Mp, int64_t c0,
                                           int64_t c1, int I0, int J0, int accumulate, int skip_upper,
                                           double* __restrict__ out) {
+  constexpr int NT = NW * 64;
+  constexpr int VB = NW == 4 ? 4 : 2;     // 16-column MFMA tiles per wave (rows: always 4 = 64 rows)
+  constexpr int WCOLS = VB * 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave >> 1, wj = wave & 1;
+  const int wi = NW == 4 ? wave >> 1 : wave >> 2, wj = NW == 4 ? (wave & 1) : (wave & 3);
   const int l15 = lane & 15, l4 = lane >> 4;
   constexpr int boff = DIAG ? 0 : TILE;   // where the B-operand columns live in the LDS tile
-  constexpr int NQ = DIAG ? 4 : 8;        // 16-byte quads this thread moves per chunk
+  constexpr int NQ = (DIAG ? 1024 : 2048) / NT;  // 16-byte quads this thread moves per chunk
 
   // staging role: quad q = tid + 256 i -> LDS row n = q / 128 (off-diagonal) or q / 64 (diagonal),
   // 64 consecutive threads cover one contiguous 1 KB row segment of K'_fu.
@@ -150,7 +155,7 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   int64_t goff[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int q = tid + 256 * i;
+    const int q = tid + NT * i;
     if (DIAG) {
       srow[i] = q >> 6;
       scol[i] = (q & 63) * 2;
@@ -175,27 +180,28 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
     for (int i = 0; i < NQ; ++i) *reinterpret_cast<d2*>(&Ks[buf][srow[i]][scol[i]]) = st[i];
   };
 
-  d4 acc[4][4];
+  d4 acc[4][VB];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int v = 0; v < VB; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
-  const bool idle = DIAG && skip_upper && wi == 0 && wj == 1;  // tuning knob: strictly-upper block of a diagonal tile
+  // strictly-upper blocks of a diagonal tile (tuning knob): columns wj*WCOLS.. entirely right of rows wi*64..+63
+  const bool idle = DIAG && skip_upper && (wj * WCOLS >= wi * 64 + 64);
   auto mfma_chunk = [&](int buf) {
     if (idle) return;
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
       const double* kr = &Ks[buf][ks * 4 + l4][0];
-      double a[4], bq[4];
+      double a[4], bq[VB];
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = kr[wi * 64 + u * 16 + l15];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) bq[v] = kr[boff + wj * 64 + v * 16 + l15];
+      for (int v = 0; v < VB; ++v) bq[v] = kr[boff + wj * WCOLS + v * 16 + l15];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
+        for (int v = 0; v < VB; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
     }
   };
 
@@ -227,20 +233,21 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int v = 0; v < VB; ++v)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wi * 64 + u * 16 + l4 + 4 * r;
-          const int col = wj * 64 + v * 16 + l15;
+          const int col = wj * WCOLS + v * 16 + l15;
           double* dst = out + row * TILE + col;
           *dst = accumulate ? *dst + acc[u][v][r] : acc[u][v][r];
         }
   }
 }
 
-__global__ __launch_bounds__(256, 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks, int cps,
-                                                           int ntiles, int accumulate, int skip_upper,
-                                                           double* __restrict__ slab) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks,
+                                                                    int cps, int ntiles, int accumulate, int skip_upper,
+                                                                    double* __restrict__ slab) {
   __shared__ double Ks[2][NB][KROW];
   // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch
   const int id = blockIdx.x;
@@ -257,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void syrk_tile_kernel(const double* __restr
   if (c1 > nchunks) c1 = nchunks;
   double* out = slab + ((size_t)split * ntiles + t) * (TILE * TILE);
   if (ti == tj)
-    syrk_tile<true>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
+    syrk_tile<true, NW>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
   else
-    syrk_tile<false>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
+    syrk_tile<false, NW>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,7 +448,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   const int grid = p.ntiles * p.nsplit;
   if (p.Npad == 0) {
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
-    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, 1, p.ntiles, 0, 0, w.slab);
+    syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, 1, p.ntiles, 0, 0, w.slab);
   }
   for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
     const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
@@ -452,7 +459,11 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
     timing_begin(TIMING_SYRK, st);
     static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // A/B on MI355X: 17.17 vs 17.29 ms
-    syrk_tile_kernel<<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+    static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
+    if (nwaves == 8)
+      syrk_tile_kernel<8><<<grid, 512, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+    else
+      syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
     timing_end(TIMING_SYRK, st);
   }
   const int nb32 = p.Mp / 32;
