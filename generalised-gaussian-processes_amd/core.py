@@ -15,6 +15,7 @@ replicated.  One evaluation =
 from __future__ import annotations
 
 import math
+from concurrent.futures import ThreadPoolExecutor
 from typing import Optional
 
 import torch
@@ -85,6 +86,7 @@ class CollapsedBound:
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
         self.use_graph = True      # ... replayed from a hipGraph (falls back to plain launches if capture fails)
         self._side = None
+        self._pool = None
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -121,30 +123,37 @@ class CollapsedBound:
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
         overlap = self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
         if overlap:
-            # chol(Kuu) and its inverse depend on (Z, theta) only: they run on a side stream underneath the start of
-            # pass 1 (kernel assembly leaves LDS / wave slots free; once the SYRK saturates the chip a chain of ~50
-            # dependent small kernels would crawl).  Replayed from a hipGraph so the host spends one launch on it
-            # instead of ~1 ms of enqueueing in front of pass 1.
+            # chol(Kuu) and its inverse depend on (Z, theta) only: they run on a side stream beside the prologue /
+            # kernel assembly of pass 1 (once the SYRK saturates the chip a chain of ~50 dependent small kernels
+            # would crawl).  Enqueueing that chain costs the host 0.6-1 ms (graph replay or plain launches alike), so
+            # a helper thread does it -- the ctypes call / graph replay drop the GIL -- while this thread enqueues
+            # pass 1: neither stream waits for the host.
             main = torch.cuda.current_stream(e.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=e.device)
+                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sgp-side")
             gr = e.kuu_factor_graph(Z.shape[0]) if self.use_graph and hasattr(e, "kuu_factor_graph") else None
-            # side work first: replaying the graph costs the host two launches, and the chain then runs beside the
-            # prologue / kernel assembly rather than beside the SYRK (A/B on MI355X: 21.3 vs 22.0 ms per evaluation)
-            self._side.wait_stream(main)  # Z is materialised on the main stream
-            with torch.cuda.stream(self._side):
-                if gr is not None:
-                    Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel, out=gr["Kuu"])
-                    gr["graph"].replay()
-                    linv, kinfo = gr["Linv"], gr["info"]
-                else:
-                    Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
-                    linv, kinfo = e.kuu_factor(Kuu)
-            for t in (Kuu, linv, kinfo):
-                t.record_stream(main)
+            z_ready = main.record_event()  # Z is materialised on the main stream
+            side, jitter, kernel = self._side, self.jitter, self.kernel
+
+            def side_chain():
+                torch.cuda.set_device(e.device)  # the current device is per host thread
+                with torch.cuda.stream(side):
+                    side.wait_event(z_ready)
+                    if gr is not None:
+                        K = e.kuu(Z, ls, sf2, jitter, kernel, out=gr["Kuu"])
+                        gr["graph"].replay()
+                        return K, gr["Linv"], gr["info"]
+                    K = e.kuu(Z, ls, sf2, jitter, kernel)
+                    return (K,) + tuple(e.kuu_factor(K))
+
+            pending = self._pool.submit(side_chain)
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu)
         self._allreduce(packed)
         if overlap:
+            Kuu, linv, kinfo = pending.result()
+            for t in (Kuu, linv, kinfo):
+                t.record_stream(main)
             main.wait_stream(self._side)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv)
             res["info"] = torch.where(kinfo != 0, kinfo, res["info"])

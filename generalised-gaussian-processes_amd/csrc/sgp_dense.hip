@@ -265,6 +265,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(d) off the serial pivot chain: hardware seed (v_rsq_f64, ~2^-26 relative) + two Newton steps
+// y <- y + y (1/2 - d y^2 / 2); seven dependent VALU ops instead of the sqrt + divide expansions (~40).
+__device__ __forceinline__ double rsqrt_newton(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  return y;
+}
+
 __global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lstage, int64_t ld, int k0, int Mp, int* info,
                                                           int info_base) {
   __shared__ double Sp[4][DB][PLD];  // the four 16-column panels of L_kk
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lsta
           if (i == 0 && bad == 0) bad = j + 1;
           d = 1.0;
         }
-        const double rs = 1.0 / sqrt(d);
+        const double rs = rsqrt_newton(d);
         const double l = a[jj] * rs;  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
         a[jj] = l;
         if (i == 0) rd[j] = rs;

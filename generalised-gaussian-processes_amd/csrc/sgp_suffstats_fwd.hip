@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void reduce_phi_kernel(const double* __restric
     double s = 0.0;
     if (gi >= gj) {  // computed part of the slab (lower triangle incl. diagonal)
       const size_t off = (size_t)(gi - Ti * TILE) * TILE + (gj - Tj * TILE);
-      for (int sp = 0; sp < nsplit; ++sp) s += base[sp * sstride + off];
+#pragma unroll 8
+      for (int sp = 0; sp < nsplit; ++sp) s += base[sp * sstride + off];  // fixed order; 8 loads in flight
     }
     tile[lr][tx] = s * scale;
   }
