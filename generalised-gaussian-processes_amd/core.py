@@ -130,7 +130,7 @@ class CollapsedBound:
             # pass 1: neither stream waits for the host.
             main = torch.cuda.current_stream(e.device)
             if self._side is None:
-                self._side = torch.cuda.Stream(device=e.device)
+                self._side = torch.cuda.Stream(device=e.device, priority=-1)  # its small kernels go ahead of queued pass-1 workgroups
                 self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sgp-side")
             gr = e.kuu_factor_graph(Z.shape[0]) if self.use_graph and hasattr(e, "kuu_factor_graph") else None
             z_ready = main.record_event()  # Z is materialised on the main stream

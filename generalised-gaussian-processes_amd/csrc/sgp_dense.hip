@@ -275,25 +275,11 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
   return y;
 }
 
-__global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lstage, int64_t ld, int k0, int Mp, int* info,
-                                                          int info_base) {
-  __shared__ double Sp[4][DB][PLD];  // the four 16-column panels of L_kk
-  __shared__ double rd[DB];          // 1 / L_kk[j][j]
-  __shared__ int bad;
-  const int tid = threadIdx.x, i = tid & 63;
-  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) bad = 0;
-  double a[16];
-  {
-    const double* src = A + (int64_t)(k0 + i) * ld + k0 + 16 * g;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
-      a[2 * k] = v[0];
-      a[2 * k + 1] = v[1];
-    }
-  }
-  __syncthreads();
+// Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k]:
+// the wave that owns a 16-column panel factors it entirely in registers, rows talk through v_readlane (no LDS, no
+// barrier), then publishes the panel to LDS and the waves to its right apply the rank-16 update: 4 barriers per block.
+// On return a[] holds L (garbage above the diagonal), Sp the four panels (zero above the diagonal), rd[j] = 1 / L[j][j].
+__device__ __forceinline__ void diag_factor64(double (&a)[16], double (*Sp)[DB][PLD], double* rd, int* bad, int i, int g) {
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
     if (g == pb) {
@@ -302,7 +288,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lsta
         const int j = 16 * pb + jj;
         double d = readlane_f64(a[jj], j);
         if (!(d > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
-          if (i == 0 && bad == 0) bad = j + 1;
+          if (i == 0 && *bad == 0) *bad = j + 1;
           d = 1.0;
         }
         const double rs = rsqrt_newton(d);
@@ -331,6 +317,106 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lsta
     }
   }
   __syncthreads();
+}
+
+// 16 consecutive doubles from LDS (16-byte aligned; wave-uniform or per-lane address)
+__device__ __forceinline__ void lds_row16(double (&v)[16], const double* p) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const d2 t = *reinterpret_cast<const d2*>(p + 2 * e);
+    v[2 * e] = t[0];
+    v[2 * e + 1] = t[1];
+  }
+}
+// a[k] -= sum_q w[q] * R[k][q]  (k, q = 0..15; R rows at base + k * stride, e.g. 16 rows of a published panel).
+// Row k+1 is fetched while row k is consumed and the fetches are pinned ahead of the arithmetic: left to itself
+// the compiler (256 live VGPRs around here) waits for each 16-byte read before the two FMAs that use it, 85 cycles
+// a piece.  NTRI: only q <= k contributes (lower-triangular R).
+template <bool NTRI>
+__device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[16], const double* base, int stride) {
+  double cur[16], nxt[16];
+  lds_row16(cur, base);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < 15) lds_row16(nxt, base + (k + 1) * stride);
+    __builtin_amdgcn_sched_barrier(0);
+    double s0 = a[k], s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      if (!NTRI || q <= k) s0 = fma(-w[q], cur[q], s0);
+      if (!NTRI || q + 1 <= k) s1 = fma(-w[q + 1], cur[q + 1], s1);
+    }
+    a[k] = s0 + s1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+  }
+}
+
+// Same contract as diag_factor64, restructured for the latency of the pivot chain (it IS the critical path of the
+// dataflow factorization): inside a 16-column panel
+//   * the next pivot  d' = A[j+1][j+1] - L[j+1][j]^2  is formed by lane j+1 from its own registers and fetched with one
+//     v_readlane before the column update, so the rsqrt chain of pivot j+1 starts while column j is still being applied;
+//   * the column l = L[:, j] is broadcast through LDS (one ds_write_b64 + uniform ds_read_b128s) instead of 15
+//     v_readlane pairs whose SGPR results stall the dependent v_fma_f64.
+__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double* rd, double (*Lcol)[DB],
+                                                   int* bad, int i, int g) {
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    if (g == pb) {
+      double d = readlane_f64(a[0], 16 * pb);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = 16 * pb + jj;
+        if (!(d > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
+          if (i == 0 && *bad == 0) *bad = j + 1;
+          d = 1.0;
+        }
+        const double rs = rsqrt_newton(d);
+        const double l = a[jj] * rs;  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
+        a[jj] = l;
+        if (i == 0) rd[j] = rs;
+        if (jj < 15) {
+          d = readlane_f64(fma(-l, l, a[jj + 1]), j + 1);  // next pivot, ahead of the column update
+          double* col = Lcol[jj & 1];
+          col[i] = l;
+#pragma unroll
+          for (int q = jj + 1; q < 16; ++q) a[q] = fma(-l, col[16 * pb + q], a[q]);  // uniform address: broadcast
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) Sp[pb][i][jj] = (i >= 16 * pb + jj) ? a[jj] : 0.0;
+    }
+    __syncthreads();
+    if (g > pb) {  // rank-16 update of this wave's 16 columns p = 16 g + k:  a[i][p] -= sum_j L[i][j] L[p][j]
+      double li[16];
+      lds_row16(li, &Sp[pb][i][0]);
+      rows16_apply<false>(a, li, &Sp[pb][16 * g][0], PLD);  // wave-uniform rows: broadcast reads
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lstage, int64_t ld, int k0, int Mp, int* info,
+                                                          int info_base) {
+  __shared__ double Sp[4][DB][PLD];  // the four 16-column panels of L_kk
+  __shared__ double rd[DB];          // 1 / L_kk[j][j]
+  __shared__ int bad;
+  const int tid = threadIdx.x, i = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) bad = 0;
+  double a[16];
+  {
+    const double* src = A + (int64_t)(k0 + i) * ld + k0 + 16 * g;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
+      a[2 * k] = v[0];
+      a[2 * k + 1] = v[1];
+    }
+  }
+  __syncthreads();
+  diag_factor64(a, Sp, rd, &bad, i, g);
 
   if (blockIdx.x == 0) {
     // L_kk goes to the staging matrix, NOT into A: the other workgroups of this launch are still reading A_kk
@@ -363,9 +449,263 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lsta
   for (int k = 0; k < DB / 2; ++k) *reinterpret_cast<d2*>(prow + 2 * k) = d2{x[2 * k], x[2 * k + 1]};
 }
 
-void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, hipStream_t st) {
+
+// ---------------------------------------------------------------------------------------------
+// Whole factorization in ONE launch: tile dataflow.
+//   The lower triangle is cut into 64 x 64 tiles, numbered column by column; workgroup w owns tiles w, w + G, ...
+//   and handles them in that order.  Tile (i, j):
+//       acc = sum_{p<j} L(i,p) L(j,p)^T          each term as soon as its two operand tiles are published (MFMA)
+//       T   = A(i,j) - acc
+//       i == j :  L(j,j) = chol(T)                (diag_factor64, in registers)
+//       i  > j :  L(i,j) = T L(j,j)^-T            once L(j,j) is published; 4 threads per row, 16-column panels
+//       publish: store, release fence, ready[tile] = 1
+//   Every dependency of a tile has a smaller number, so with all G <= 256 workgroups resident (one per CU; if
+//   another kernel holds CUs they trickle in as it retires -- nothing they wait for depends on them) the
+//   smallest unfinished tile can always run: no deadlock.  Look-ahead is implicit: off the critical path
+//   (potrf -> trsm of the next row block -> its last rank-64 update -> potrf) everything is done early.
+//   Flags are agent-scope atomics bracketed by release / acquire fences (L2 is per XCD on gfx950).  A spin that
+//   exceeds SPIN_LIMIT (seconds) raises the abort flag and reports info = POTRF_TIMEOUT instead of hanging.
+// ---------------------------------------------------------------------------------------------
+constexpr int DF_MAX_WG = 256;
+constexpr int DF_SPIN_LIMIT = 1 << 24;
+constexpr int POTRF_TIMEOUT = -7777;
+constexpr int TLD = DB + 2;  // LDS stride of the T / X tile (16-byte aligned rows)
+
+struct DfShared {
+  union {
+    struct { double As[GK][GLD]; double Bs[GK][GLD]; } mac;  // operand chunks of the rank-64 updates
+    double Sp[4][DB][PLD];                                    // panels of L(j,j) (factor / solve phase)
+  };
+  double Ts[DB][TLD];
+  double Dinv[4][16][16];  // inverses of the four 16 x 16 diagonal blocks of L(j,j)
+  double Lcol[2][DB];
+  double rd[DB];
+  int bad;
+};
+
+__device__ __forceinline__ int df_flag_load(const int* f) {
+  return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Visibility of a published tile (L2 is per XCD on gfx950, write-back, not coherent across XCDs for ordinary lines):
+//   producer: ordinary stores, then an agent-scope RELEASE fence (L2 write-back) before the flag is raised;
+//   consumer: the flag is an agent-scope atomic; the tile is then read with ordinary loads.  No acquire-side cache
+//   invalidate is needed: every L2 starts the launch clean, a line of tile X enters the L2 of another XCD only
+//   through a consumer's first read, which happens after X was published (written back), and X never changes again.
+// every thread polls (no barrier); returns false when the launch has been aborted
+__device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag) {
+  int spins = 0;
+  while (df_flag_load(flag) == 0) {
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if ((spins & 255) == 0 && df_flag_load(abort_flag) != 0) return false;
+    if (spins > DF_SPIN_LIMIT) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+  return true;
+}
+
+// acc += P(64 x 64) Q(64 x 64)^T, both row-major with the contraction index contiguous (tiles of L)
+__device__ __forceinline__ void df_mac(const double* P, const double* Q, int64_t ld, DfShared& sh, d4 (&acc)[2][2]) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  const int row = t >> 2, kq = (t & 3) * 4;
+  double va[4][4], vb[4][4];  // the whole of both tiles: one round trip to L2, then four LDS chunks
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double* sa = P + (int64_t)row * ld + c * GK + kq;
+    const double* sb = Q + (int64_t)row * ld + c * GK + kq;
+    const d2 a0 = *reinterpret_cast<const d2*>(sa), a1 = *reinterpret_cast<const d2*>(sa + 2);
+    const d2 b0 = *reinterpret_cast<const d2*>(sb), b1 = *reinterpret_cast<const d2*>(sb + 2);
+    va[c][0] = a0[0]; va[c][1] = a0[1]; va[c][2] = a1[0]; va[c][3] = a1[1];
+    vb[c][0] = b0[0]; vb[c][1] = b0[1]; vb[c][2] = b1[0]; vb[c][3] = b1[1];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sh.mac.As[kq + e][row] = va[c][e];
+      sh.mac.Bs[kq + e][row] = vb[c][e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+      const int kr = ks * 4 + l4;
+      const double a0 = sh.mac.As[kr][wi * 32 + l15], a1 = sh.mac.As[kr][wi * 32 + 16 + l15];
+      const double b0 = sh.mac.Bs[kr][wj * 32 + l15], b1 = sh.mac.Bs[kr][wj * 32 + 16 + l15];
+      acc[0][0] = mfma16(a0, b0, acc[0][0]);
+      acc[0][1] = mfma16(a0, b1, acc[0][1]);
+      acc[1][0] = mfma16(a1, b0, acc[1][0]);
+      acc[1][1] = mfma16(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t ld, int nb, int* ready, int* info,
+                                                              int info_base) {
+  __shared__ DfShared sh;
+  const int tid = threadIdx.x, r = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  const int ntile = nb * (nb + 1) / 2;
+  int* abort_flag = ready + ntile;
+  int j = 0, start = 0;  // column of the current tile and number of the first tile of that column
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    while (t >= start + (nb - j)) { start += nb - j; ++j; }
+    const int i = j + (t - start);
+    double* Aij = A + (int64_t)i * DB * ld + (int64_t)j * DB;
+    auto tile_no = [&](int ti, int tj) { return tj * nb - (tj * (tj - 1)) / 2 + (ti - tj); };
+
+    if (i != j) {  // the mirrored tile is the strictly-upper part of the result: zero
+      double* U = A + (int64_t)j * DB * ld + (int64_t)i * DB;
+      for (int e = tid; e < DB * DB / 2; e += 256) {
+        const int rr = e >> 5, cc = (e & 31) * 2;
+        *reinterpret_cast<d2*>(U + (int64_t)rr * ld + cc) = d2{0.0, 0.0};
+      }
+    }
+
+    d4 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < j; ++p) {
+      if (!df_wait(ready + tile_no(i, p), abort_flag)) return;
+      if (i != j && !df_wait(ready + tile_no(j, p), abort_flag)) return;
+      df_mac(A + (int64_t)i * DB * ld + (int64_t)p * DB, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, sh, acc);
+    }
+    // acc (MFMA layout) -> LDS, then every thread picks up  T[r][16 g ..] = A(i,j) - acc  in the row layout
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sh.Ts[wi * 32 + u * 16 + l4 + 4 * q][wj * 32 + v * 16 + l15] = acc[u][v][q];
+    if (tid == 0) sh.bad = 0;
+    __syncthreads();
+    double x[16];
+    {
+      const double* src = Aij + (int64_t)r * ld + 16 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
+        x[2 * k] = v[0] - sh.Ts[r][16 * g + 2 * k];
+        x[2 * k + 1] = v[1] - sh.Ts[r][16 * g + 2 * k + 1];
+      }
+    }
+    __syncthreads();  // Ts is reused as the X staging tile below; the mac buffers become Sp
+
+    if (i == j) {
+      diag_factor64_fast(x, sh.Sp, sh.rd, sh.Lcol, &sh.bad, r, g);
+      double* dst = Aij + (int64_t)r * ld + 16 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<d2*>(dst + 2 * k) = d2{(16 * g + 2 * k <= r) ? x[2 * k] : 0.0, (16 * g + 2 * k + 1 <= r) ? x[2 * k + 1] : 0.0};
+      if (tid == 0 && sh.bad != 0 && *info == 0) *info = info_base + j * DB + sh.bad;
+    } else {
+      if (!df_wait(ready + tile_no(j, j), abort_flag)) return;
+      {  // L(j,j) -> Sp panels, rd = 1 / diag
+        const double* src = A + (int64_t)j * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const d2 t2 = *reinterpret_cast<const d2*>(src + 2 * k);
+          v[2 * k] = t2[0];
+          v[2 * k + 1] = t2[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          sh.Sp[g][r][k] = v[k];
+          if (16 * g + k == r) sh.rd[r] = 1.0 / v[k];
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {  // Dinv[blk] = inverse of the 16 x 16 diagonal block blk: thread <-> one column, forward substitution
+        const int blk = tid >> 4, c = tid & 15;
+        double y[16], lrow[16], lnext[16];
+        lds_row16(lrow, &sh.Sp[blk][16 * blk][0]);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          if (rr < 15) lds_row16(lnext, &sh.Sp[blk][16 * blk + rr + 1][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          double sacc = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+          for (int q = 0; q < rr; ++q) sacc = fma(-lrow[q], y[q], sacc);
+          y[rr] = sacc * sh.rd[16 * blk + rr];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) lrow[q] = lnext[q];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sh.Dinv[blk][rr][c] = y[rr];
+      }
+      __syncthreads();
+      // X = T L^-T by 16-column panels: wave pb turns its panel into X with the inverted diagonal block
+      // (X[r][k] = sum_{q<=k} t[q] Dinv[k][q], no serial chain), the waves to its right subtract X_pb L[.,pb]^T
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        if (g == pb) {
+          double xn[16], nx[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            xn[k] = 0.0;
+            nx[k] = -x[k];
+          }
+          rows16_apply<true>(xn, nx, &sh.Dinv[pb][0][0], 16);  // wave-uniform: broadcast reads
+#pragma unroll
+          for (int k = 0; k < 16; ++k) x[k] = xn[k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(&sh.Ts[r][16 * pb + 2 * k]) = d2{x[2 * k], x[2 * k + 1]};
+        }
+        __syncthreads();
+        if (g > pb) {
+          double xr[16];
+          lds_row16(xr, &sh.Ts[r][16 * pb]);
+          rows16_apply<false>(x, xr, &sh.Sp[pb][16 * g][0], PLD);
+        }
+      }
+      double* dst = Aij + (int64_t)r * ld + 16 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(dst + 2 * k) = d2{x[2 * k], x[2 * k + 1]};
+    }
+    // publish: stores written back (release) -> barrier -> flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ready + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Flags / status words are cleared by a plain kernel, never hipMemsetAsync: with the Kuu chain replayed from a hipGraph
+// by a helper host thread while the main thread enqueues its own memsets, the runtime's memset nodes were seen to
+// leave stale words behind on ROCm 7.2 (a spurious abort flag, info = 0x0c0c0c0c).
+__global__ void zero_ints_kernel(int* p, int n) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) p[e] = 0;
+}
+void zero_ints(int* p, int n, hipStream_t st) { zero_ints_kernel<<<1, 256, 0, st>>>(p, n); }
+__global__ void potrf_timeout_kernel(const int* abort_flag, int* info) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *abort_flag != 0) *info = POTRF_TIMEOUT;
+}
+
+size_t potrf_scratch_ints(int Mp) {
+  const size_t nb = Mp / DB;
+  return nb * (nb + 1) / 2 + 16;
+}
+
+void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st) {
+  static const int use_steps = getenv("SGP_POTRF_STEPS") ? atoi(getenv("SGP_POTRF_STEPS")) : 0;  // A/B knob: old per-block launches
   const int nb = Mp / DB;
   fill_zero(Linv, (size_t)Mp * ld, st);
+  if (!use_steps) {
+    const int ntile = nb * (nb + 1) / 2;
+    zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
+    potrf_dataflow_kernel<<<ntile < DF_MAX_WG ? ntile : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base);
+    potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile, info);
+    tri_diag_inv_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);
+    return;
+  }
   for (int kb = 0; kb < nb; ++kb) {
     const int k0 = kb * DB;
     const int rem = Mp - (kb + 1) * DB;
@@ -519,6 +859,7 @@ extern "C" size_t sgp_chol_workspace_bytes(int M) {
   Carver c(nullptr);
   c.take<double>(Mp * Mp);
   c.take<double>(Mp * Mp);
+  c.take<int>(potrf_scratch_ints((int)Mp));
   return c.used();
 }
 
@@ -531,9 +872,10 @@ extern "C" int sgp_chol_lower(double* A, int64_t lda, int M, int* info, void* ws
   Carver c(ws);
   double* Ap = c.take<double>((size_t)Mp * Mp);
   double* Li = c.take<double>((size_t)Mp * Mp);
-  hipMemsetAsync(info, 0, sizeof(int), st);
+  int* flags = c.take<int>(potrf_scratch_ints(Mp));
+  zero_ints(info, 1, st);
   pad_copy(A, lda, M, M, Ap, Mp, Mp, Mp, 1.0, st);
-  potrf_lower(Ap, Li, Mp, Mp, info, 0, st);
+  potrf_lower(Ap, Li, Mp, Mp, info, 0, flags, st);
   crop_copy(Ap, Mp, A, lda, M, M, st);
   return check_launch();
 }

@@ -27,8 +27,11 @@ void gemm(const GemmDesc& g, hipStream_t st);
 // In-place lower Cholesky of the Mp x Mp matrix A (Mp multiple of 64); strictly-upper part of the
 // result is zeroed.  Linv (Mp x Mp, same ld) receives the inverses of the 64 x 64 diagonal blocks of
 // L (and is zero elsewhere) -- level 0 of tri_inverse().  info_base offsets the reported pivot index
-// (info is only written when still 0, so two factorizations can share one flag).
-void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, hipStream_t st);
+// (info is only written when still 0, so two factorizations can share one flag).  scratch: potrf_scratch_ints(Mp)
+// ints (tile-ready flags of the single-launch dataflow factorization; cleared here, reusable right after on the
+// same stream).  info = -7777 reports a dataflow time-out (never expected; instead of a hang).
+size_t potrf_scratch_ints(int Mp);
+void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st);
 
 // Completes Linv (diagonal 64-blocks already inverted by potrf_lower) to the full inverse of L.
 // tmp: Mp x Mp scratch with the same ld.
@@ -44,6 +47,8 @@ void pad_copy(const double* src, int64_t lds, int rs, int cs, double* dst, int64
 // dst (rs x cs, ld ldd) <- top-left corner of src (ld lds)
 void crop_copy(const double* src, int64_t lds, double* dst, int64_t ldd, int rs, int cs, hipStream_t st);
 void fill_zero(double* p, size_t n, hipStream_t st);
+// n ints <- 0 by a kernel launch (graph-replay safe; see sgp_dense.hip)
+void zero_ints(int* p, int n, hipStream_t st);
 // upper triangle <- transpose of lower triangle
 void mirror_lower(double* A, int64_t ld, int Mp, hipStream_t st);
 

@@ -318,6 +318,7 @@ struct SvgpWs {
   double *Kuu, *Kp, *Linv, *tmp, *LSp, *Kub, *A, *T, *U, *Abar, *Av, *S1, *Q, *P, *Kuubar;
   double *mp, *mu, *v, *dmu, *dv, *part, *kl, *kpart, *gzraw;
   void* kuu_ws;
+  int* flags;
   size_t kuu_ws_bytes, bytes;
 };
 static SvgpWs carve_svgp(void* ws, int Mp, int Bp, int M, int d) {
@@ -350,6 +351,7 @@ static SvgpWs carve_svgp(void* ws, int Mp, int Bp, int M, int d) {
   w.gzraw = c.take<double>((size_t)M * d);
   w.kuu_ws_bytes = sgp_kuu_bwd_workspace_bytes(M, d);
   w.kuu_ws = c.take<char>(w.kuu_ws_bytes);
+  w.flags = c.take<int>(potrf_scratch_ints(Mp));
   w.bytes = c.used();
   return w;
 }
@@ -367,10 +369,10 @@ static void svgp_forward(const SvgpWs& w, const double* Xb, int64_t ldx, int64_t
                          const double* inv_ls, double sf2, double jitter, const double* m, const double* LS, int M, int d,
                          int kernel_id, int Mp, int Bp, int* info, hipStream_t st) {
   const KernArgs ka = make_ka_s(inv_ls, sf2, d);
-  hipMemsetAsync(info, 0, sizeof(int), st);
+  zero_ints(info, 1, st);
   sgp_kuu(Z, ldz, inv_ls, sf2, jitter, M, d, kernel_id, w.Kuu, st);
   pad_copy(w.Kuu, M, M, M, w.Kp, Mp, Mp, Mp, 1.0, st);
-  potrf_lower(w.Kp, w.Linv, Mp, Mp, info, 0, st);
+  potrf_lower(w.Kp, w.Linv, Mp, Mp, info, 0, w.flags, st);
   tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st);
   pad_copy(LS, M, M, M, w.LSp, Mp, Mp, Mp, 1.0, st);
   svgp_tril_kernel<<<grid_for_s((int64_t)Mp * Mp), 256, 0, st>>>(w.LSp, Mp, 1.0, 0);

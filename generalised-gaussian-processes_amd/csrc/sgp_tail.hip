@@ -294,6 +294,7 @@ static int grid_for(int64_t total, int cap = 2048) {
 struct BoundWs {
   double *M0, *M1, *M2, *M3, *M4, *M5, *M6, *M7, *M8;
   double *bp, *u, *q, *alpha, *t1, *sc, *partial;
+  int* flags;  // potrf tile-ready flags
   size_t bytes;
 };
 static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
@@ -316,6 +317,7 @@ static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
   w.t1 = c.take<double>(Mp);
   w.sc = c.take<double>(SC_N);
   w.partial = c.take<double>(256);
+  w.flags = c.take<int>(potrf_scratch_ints(Mp));
   w.bytes = c.used();
   return w;
 }
@@ -400,6 +402,7 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
   Carver c(nullptr);
   c.take<double>(Mp * Mp);
   c.take<double>(Mp * Mp);
+  c.take<int>(potrf_scratch_ints((int)Mp));
   return c.used();
 }
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
@@ -414,9 +417,10 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   Carver c(ws);
   double* L = c.take<double>((size_t)Mp * Mp);
   double* tmp = c.take<double>((size_t)Mp * Mp);
-  hipMemsetAsync(info, 0, sizeof(int), st);
+  int* flags = c.take<int>(potrf_scratch_ints(Mp));
+  zero_ints(info, 1, st);
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
-  potrf_lower(L, Linv_out, Mp, Mp, info, 0, st);
+  potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   return check_launch();
 }
@@ -437,7 +441,7 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
   const size_t mm = (size_t)Mp * Mp;
   const bool need_G = with_adjoints || factors;
 
-  hipMemsetAsync(info, 0, sizeof(int), st);
+  zero_ints(info, 1, st);
   fill_zero(w.sc, SC_N, st);
 
   // L = chol(Kuu) in M0, L^-1 in M1 -- or L^-1 handed over by sgp_kuu_factor (read-only from here on)
@@ -445,7 +449,7 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
     w.M1 = const_cast<double*>(kuu_linv);
   } else {
     pad_copy(Kuu, M, M, M, w.M0, ld, Mp, Mp, 1.0, st);
-    potrf_lower(w.M0, w.M1, ld, Mp, info, 0, st);
+    potrf_lower(w.M0, w.M1, ld, Mp, info, 0, w.flags, st);
     tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
   }
 
@@ -465,7 +469,7 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
 
   // B = I + W/s2 in M6 -> LB ; LB^-1 in M7
   make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6);
-  potrf_lower(w.M6, w.M7, ld, Mp, info, M, st);
+  potrf_lower(w.M6, w.M7, ld, Mp, info, M, w.flags, st);
   diag_sum_kernel<<<1, 256, 0, st>>>(w.M6, Mp, 1, 2.0, w.sc + SC_LOGDET);
   tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
 

@@ -83,9 +83,10 @@ def test_bound_and_grads_golden(engine, name):
     cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), kernel=kern, jitter=float(G["jitter"]), engine=engine)
     Z = dev(G["Z"], engine)
     F, parts = cb.value(Z, G["ls"], float(G["sf2"]), float(G["s2"]))
-    tolF = 1e-9 * max(1.0, abs(float(G["F"])))
+    ill = float(G["grad_rtol"]) > 1e-6  # duplicate-Z fixture: cond(Kuu) ~ 2e6, rounding shows at eps * cond ~ 1e-9
+    tolF = (1e-8 if ill else 1e-9) * max(1.0, abs(float(G["F"])))  # north_star: 1e-8
     assert abs(F - float(G["F"])) < tolF, (F, float(G["F"]))
-    ptol = tolF * (1000.0 if float(G["grad_rtol"]) > 1e-6 else 1.0)  # parts cancel to F; ill-conditioned fixture
+    ptol = tolF * (100.0 if ill else 1.0)  # parts cancel to F; ill-conditioned fixture
     assert abs(parts["logmarg"] - float(G["logmarg"])) < ptol
     assert abs(parts["trace_term"] - float(G["trace_term"])) < ptol
     F2, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
@@ -318,6 +319,30 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     cb0 = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=0.0, engine=engine)
     F, parts = cb0.value(Zbad, G["ls"], 1.0, 0.1, raise_on_fail=False)
     assert math.isnan(F) and 1 <= parts["info"] <= 6
+
+
+def test_repeated_evaluations_all_modes_stay_clean(engine):
+    """Regression: many evaluations over several M, fresh CollapsedBound objects (new side streams / helper threads),
+    graph replay / plain launches / single stream.  The single-launch dataflow Cholesky must never report its
+    time-out code and every mode must give the same bits (a stale flag word once showed up as info = -7777)."""
+    import ggp_amd
+    g = torch.Generator().manual_seed(3)
+    for rep in range(3):
+        for (N, d, M) in [(400, 1, 8), (2000, 18, 128), (64, 3, 30), (500, 2, 6), (1000, 5, 129)]:
+            X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+            y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+            Z = X[:M].clone()
+            cb = ggp_amd.CollapsedBound(X, y, jitter=1e-6, engine=engine)
+            vals = []
+            for mode in ((True, True), (True, False), (False, False)):
+                cb.overlap_tail, cb.use_graph = mode
+                for _ in range(4):
+                    F, parts = cb.value(Z, [1.0] * d, 1.0, 0.1, raise_on_fail=False)
+                    assert parts["info"] == 0, (rep, N, d, M, mode, parts)
+                    F2, gr = cb.value_and_grad(Z, [1.0] * d, 1.0, 0.1, raise_on_fail=False)
+                    assert gr["info"] == 0 and F2 == F
+                    vals.append(F)
+            assert all(v == vals[0] for v in vals)
 
 
 # ---------------------------------------------------------------------------------------------
