@@ -6,7 +6,8 @@
 //
 // Design: everything O(M^3) is phrased as 64 x 64-tiled GEMMs on v_mfma_f64_16x16x4_f64 so the only
 // latency-bound pieces are the 64 x 64 diagonal blocks, which one workgroup factors and inverts in LDS.
-//   potrf  : right-looking, per 64-column block  { fused: diag factor (every WG) + panel forward substitution | A22 -= P P^T }
+//   potrf  : ONE launch, 64 x 64 tile dataflow (tile owners wait on ready flags; diagonal tiles factored in registers,
+//            off-diagonal tiles = MFMA rank-64 updates + a 16-column-panel triangular solve); optional L^-1 rhs row
 //   trtri  : recursive doubling on the inverted diagonal blocks, Inv21 = -Inv22 (L21 Inv11), batched GEMMs
 // Triangular structure is exploited by clipping each output tile's k-range (GemmDesc::klo/khi masks).
 #include "sgp_dense.hpp"
@@ -209,53 +210,10 @@ __global__ __launch_bounds__(256) void tri_diag_inv_kernel(const double* L, doub
     Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
   }
 }
-// after the last step: Linv's diagonal blocks hold the staged L_kk; move them into A and replace them by their inverses
-__global__ __launch_bounds__(256) void potrf_finish_kernel(double* A, double* Linv, int64_t ld) {
-  __shared__ double S[DB][DLD];
-  __shared__ double Inv[DB][DLD];
-  __shared__ double T[DB][DLD];
-  const int tid = threadIdx.x, k0 = blockIdx.x * DB;
-  for (int e = tid; e < DB * DB; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    const double v = (j <= i) ? Linv[(int64_t)(k0 + i) * ld + k0 + j] : 0.0;
-    S[i][j] = v;
-    Inv[i][j] = 0.0;
-    A[(int64_t)(k0 + i) * ld + k0 + j] = v;
-  }
-  __syncthreads();
-  block_inverse64(S, Inv, T);
-  for (int e = tid; e < DB * DB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
-  }
-}
 void tri_diag_inverse(const double* L, double* Linv, int64_t ld, int Mp, hipStream_t st) {
   tri_diag_inv_kernel<<<Mp / DB, 256, 0, st>>>(L, Linv, ld);
 }
 
-// zero the strictly-upper 64-blocks of row block kb (the diagonal block is handled by the diag kernel)
-__global__ void zero_upper_blocks_kernel(double* A, int64_t ld, int Mp) {
-  const int rb = blockIdx.y;              // row block
-  const int cb = blockIdx.x;              // column block
-  if (cb <= rb) return;
-  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
-    const int r = e >> 6, c = e & 63;
-    A[(int64_t)(rb * 64 + r) * ld + cb * 64 + c] = 0.0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One block-column step of the factorization in ONE launch:
-//   every workgroup factors the 64 x 64 diagonal block itself (redundantly -- it is latency, not work):
-//     thread (i = tid & 63, g = tid >> 6) keeps A_kk[i][16g .. 16g+15]; the wave that owns a 16-column
-//     panel factors it entirely in registers, rows talk through v_readlane (no LDS, no barrier), then
-//     publishes the panel to LDS and the waves to its right apply the rank-16 update: 4 barriers per block;
-//   workgroup 0 writes L_kk (zeros above the diagonal) to a staging matrix -- never into A_kk, which the other
-//   workgroups of the same launch are reading; `potrf_finish_kernel` moves it into place at the end;
-//   workgroup b >= 1 solves its 256 rows of the panel  P = A_ik L_kk^-T  by forward substitution, one row
-//   per thread with the row in registers and L_kk broadcast from LDS.
-// The inverses of the diagonal blocks (needed by tri_inverse) are computed afterwards, off this chain.
-// ---------------------------------------------------------------------------------------------
 constexpr int PLD = 18;  // LDS row stride of a 64 x 16 panel (16-byte aligned rows)
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -273,50 +231,6 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
   y = fma(y, fma(-h * y, y, 0.5), y);
   y = fma(y, fma(-h * y, y, 0.5), y);
   return y;
-}
-
-// Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k]:
-// the wave that owns a 16-column panel factors it entirely in registers, rows talk through v_readlane (no LDS, no
-// barrier), then publishes the panel to LDS and the waves to its right apply the rank-16 update: 4 barriers per block.
-// On return a[] holds L (garbage above the diagonal), Sp the four panels (zero above the diagonal), rd[j] = 1 / L[j][j].
-__device__ __forceinline__ void diag_factor64(double (&a)[16], double (*Sp)[DB][PLD], double* rd, int* bad, int i, int g) {
-#pragma unroll
-  for (int pb = 0; pb < 4; ++pb) {
-    if (g == pb) {
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * pb + jj;
-        double d = readlane_f64(a[jj], j);
-        if (!(d > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
-          if (i == 0 && *bad == 0) *bad = j + 1;
-          d = 1.0;
-        }
-        const double rs = rsqrt_newton(d);
-        const double l = a[jj] * rs;  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
-        a[jj] = l;
-        if (i == 0) rd[j] = rs;
-#pragma unroll
-        for (int q = jj + 1; q < 16; ++q) a[q] = fma(-l, readlane_f64(l, 16 * pb + q), a[q]);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) Sp[pb][i][jj] = (i >= 16 * pb + jj) ? a[jj] : 0.0;
-    }
-    __syncthreads();
-    if (g > pb) {  // rank-16 update of this wave's 16 columns p = 16 g + k:  a[i][p] -= sum_j L[i][j] L[p][j]
-      double li[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) li[jj] = Sp[pb][i][jj];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double* lp = &Sp[pb][16 * g + k][0];  // wave-uniform row: broadcast reads
-        double s = a[k];
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) s = fma(-li[jj], lp[jj], s);
-        a[k] = s;
-      }
-    }
-  }
-  __syncthreads();
 }
 
 // 16 consecutive doubles from LDS (16-byte aligned; wave-uniform or per-lane address)
@@ -353,8 +267,10 @@ __device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[
   }
 }
 
-// Same contract as diag_factor64, restructured for the latency of the pivot chain (it IS the critical path of the
-// dataflow factorization): inside a 16-column panel
+// Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k]:  the wave that
+// owns a 16-column panel factors it in registers, publishes it to LDS (Sp, zero above the diagonal) and the waves to
+// its right apply the rank-16 update; 4 barriers per block.  On return a[] holds L (garbage above the diagonal) and
+// rd[j] = 1 / L[j][j].  The pivot chain IS the critical path of the factorization, so inside a panel
 //   * the next pivot  d' = A[j+1][j+1] - L[j+1][j]^2  is formed by lane j+1 from its own registers and fetched with one
 //     v_readlane before the column update, so the rsqrt chain of pivot j+1 starts while column j is still being applied;
 //   * the column l = L[:, j] is broadcast through LDS (one ds_write_b64 + uniform ds_read_b128s) instead of 15
@@ -395,58 +311,6 @@ __device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)
     }
   }
   __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void potrf_step_kernel(double* A, double* Lstage, int64_t ld, int k0, int Mp, int* info,
-                                                          int info_base) {
-  __shared__ double Sp[4][DB][PLD];  // the four 16-column panels of L_kk
-  __shared__ double rd[DB];          // 1 / L_kk[j][j]
-  __shared__ int bad;
-  const int tid = threadIdx.x, i = tid & 63;
-  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) bad = 0;
-  double a[16];
-  {
-    const double* src = A + (int64_t)(k0 + i) * ld + k0 + 16 * g;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
-      a[2 * k] = v[0];
-      a[2 * k + 1] = v[1];
-    }
-  }
-  __syncthreads();
-  diag_factor64(a, Sp, rd, &bad, i, g);
-
-  if (blockIdx.x == 0) {
-    // L_kk goes to the staging matrix, NOT into A: the other workgroups of this launch are still reading A_kk
-    double* dst = Lstage + (int64_t)(k0 + i) * ld + k0 + 16 * g;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) dst[k] = (16 * g + k <= i) ? a[k] : 0.0;
-    if (tid == 0 && bad != 0 && *info == 0) *info = info_base + bad;
-    return;
-  }
-
-  // panel rows of this workgroup: forward substitution  x_j = (a_j - sum_{p<j} x_p L[j][p]) / L[j][j]
-  const int row = k0 + DB + (blockIdx.x - 1) * 256 + tid;
-  if (row >= Mp) return;
-  double* prow = A + (int64_t)row * ld + k0;
-  double x[DB];
-#pragma unroll
-  for (int k = 0; k < DB / 2; ++k) {
-    const d2 v = *reinterpret_cast<const d2*>(prow + 2 * k);
-    x[2 * k] = v[0];
-    x[2 * k + 1] = v[1];
-  }
-#pragma unroll
-  for (int j = 0; j < DB; ++j) {
-    double s = x[j];
-#pragma unroll
-    for (int p = 0; p < j; ++p) s = fma(-x[p], Sp[p >> 4][j][p & 15], s);
-    x[j] = s * rd[j];
-  }
-#pragma unroll
-  for (int k = 0; k < DB / 2; ++k) *reinterpret_cast<d2*>(prow + 2 * k) = d2{x[2 * k], x[2 * k + 1]};
 }
 
 
@@ -543,8 +407,64 @@ __device__ __forceinline__ void df_mac(const double* P, const double* Q, int64_t
   }
 }
 
+// Forward substitution of one right-hand side, carried along by the factorization (work item `ntile`, so every tile
+// it waits for has a smaller number): block jb of sol needs the published row jb of L,
+//     r = rhs_jb - sum_{p<jb} L(jb,p) sol_p        thread (row, 16-column slice) partial dot products, summed through LDS
+//     sol_jb = L(jb,jb)^-1 r                       one wave, lane <-> row, 64 steps of readlane + fma
+// All but the last block are done while later block columns are still being factored.
+__device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb, const int* ready, int* abort_flag,
+                                             const double* rhs, double* sol, DfShared& sh) {
+  const int tid = threadIdx.x, row = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* qs = &sh.Ts[0][0];          // the solution so far (<= 4096 doubles fit the T tile)
+  double* red = &sh.Dinv[0][0][0];    // 4 x 64 partial sums
+  auto tile_no = [&](int ti, int tj) { return tj * nb - (tj * (tj - 1)) / 2 + (ti - tj); };
+  for (int jb = 0; jb < nb; ++jb) {
+    double part = 0.0;
+    for (int p = 0; p < jb; ++p) {
+      if (!df_wait(ready + tile_no(jb, p), abort_flag)) return;
+      const double* src = A + ((int64_t)jb * DB + row) * ld + (int64_t)p * DB + 16 * g;
+      double lv[16], qv[16];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const d2 t2 = *reinterpret_cast<const d2*>(src + 2 * k);
+        lv[2 * k] = t2[0];
+        lv[2 * k + 1] = t2[1];
+      }
+      lds_row16(qv, qs + p * DB + 16 * g);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) part = fma(lv[k], qv[k], part);
+    }
+    red[g * DB + row] = part;
+    if (!df_wait(ready + tile_no(jb, jb), abort_flag)) return;
+    __syncthreads();
+    if (g == 0) {
+      double rr = rhs[jb * DB + row] - (red[row] + red[DB + row] + red[2 * DB + row] + red[3 * DB + row]);
+      const double* lsrc = A + ((int64_t)jb * DB + row) * ld + (int64_t)jb * DB;
+      double lrow[DB];
+#pragma unroll
+      for (int k = 0; k < DB / 2; ++k) {
+        const d2 t2 = *reinterpret_cast<const d2*>(lsrc + 2 * k);
+        lrow[2 * k] = t2[0];
+        lrow[2 * k + 1] = t2[1];
+      }
+      const double dinv = 1.0 / lsrc[row];  // own diagonal entry
+      double mine = 0.0;
+#pragma unroll
+      for (int c = 0; c < DB; ++c) {
+        const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
+        if (row == c) mine = xc;
+        rr = fma(-lrow[c], xc, rr);  // rows <= c go stale, never read again
+      }
+      qs[jb * DB + row] = mine;
+      sol[jb * DB + row] = mine;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t ld, int nb, int* ready, int* info,
-                                                              int info_base) {
+                                                              int info_base, const double* rhs, double* sol) {
   __shared__ DfShared sh;
   const int tid = threadIdx.x, r = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -552,8 +472,13 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const int ntile = nb * (nb + 1) / 2;
   int* abort_flag = ready + ntile;
+  const int nitem = ntile + (rhs ? 1 : 0);
   int j = 0, start = 0;  // column of the current tile and number of the first tile of that column
-  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+  for (int t = blockIdx.x; t < nitem; t += gridDim.x) {
+    if (t == ntile) {  // the last work item: sol = L^-1 rhs, 64 entries at a time, trailing the factorization
+      df_solve_rhs(A, ld, nb, ready, abort_flag, rhs, sol, sh);
+      break;
+    }
     while (t >= start + (nb - j)) { start += nb - j; ++j; }
     const int i = j + (t - start);
     double* Aij = A + (int64_t)i * DB * ld + (int64_t)j * DB;
@@ -694,36 +619,18 @@ size_t potrf_scratch_ints(int Mp) {
   return nb * (nb + 1) / 2 + 16;
 }
 
-void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st) {
-  static const int use_steps = getenv("SGP_POTRF_STEPS") ? atoi(getenv("SGP_POTRF_STEPS")) : 0;  // A/B knob: old per-block launches
+void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
+                 const double* rhs, double* sol) {
   const int nb = Mp / DB;
-  fill_zero(Linv, (size_t)Mp * ld, st);
-  if (!use_steps) {
-    const int ntile = nb * (nb + 1) / 2;
-    zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
-    potrf_dataflow_kernel<<<ntile < DF_MAX_WG ? ntile : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base);
-    potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile, info);
+  const int ntile = nb * (nb + 1) / 2;
+  const int nitem = ntile + (rhs ? 1 : 0);
+  zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
+  potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol);
+  potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile, info);
+  if (Linv) {  // level 0 of tri_inverse(): inverses of the 64 x 64 diagonal blocks, zero elsewhere
+    fill_zero(Linv, (size_t)Mp * ld, st);
     tri_diag_inv_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);
-    return;
   }
-  for (int kb = 0; kb < nb; ++kb) {
-    const int k0 = kb * DB;
-    const int rem = Mp - (kb + 1) * DB;
-    potrf_step_kernel<<<1 + (rem + 255) / 256, 256, 0, st>>>(A, Linv, ld, k0, Mp, info, info_base + k0);
-    if (rem > 0) {
-      double* panel = A + (int64_t)(k0 + DB) * ld + k0;
-      GemmDesc u;
-      u.A = panel; u.lda = ld;
-      u.B = panel; u.ldb = ld; u.tb = true;
-      u.C = A + (int64_t)(k0 + DB) * (ld + 1); u.ldc = ld;
-      u.m = rem; u.n = rem; u.k = DB;
-      u.alpha = -1.0; u.beta = 1.0; u.lower_only = true;
-      gemm(u, st);
-    }
-  }
-  if (nb > 1) zero_upper_blocks_kernel<<<dim3(nb, nb), 256, 0, st>>>(A, ld, Mp);
-  // staged L_kk -> A_kk, and their inverses -> diagonal blocks of Linv (level 0 of tri_inverse()), all blocks at once
-  potrf_finish_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);
 }
 
 void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {

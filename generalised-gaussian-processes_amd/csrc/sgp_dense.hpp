@@ -31,7 +31,10 @@ void gemm(const GemmDesc& g, hipStream_t st);
 // ints (tile-ready flags of the single-launch dataflow factorization; cleared here, reusable right after on the
 // same stream).  info = -7777 reports a dataflow time-out (never expected; instead of a hang).
 size_t potrf_scratch_ints(int Mp);
-void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st);
+// rhs / sol (optional, Mp doubles each): sol = L^-1 rhs, computed inside the same launch.  Linv may be null when
+// the caller needs neither tri_inverse() nor the block inverses.
+void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
+                 const double* rhs = nullptr, double* sol = nullptr);
 
 // Completes Linv (diagonal 64-blocks already inverted by potrf_lower) to the full inverse of L.
 // tmp: Mp x Mp scratch with the same ld.

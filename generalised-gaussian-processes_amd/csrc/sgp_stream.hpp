@@ -1,5 +1,6 @@
 // Shared geometry of the two streaming passes (sgp_suffstats_fwd.hip / sgp_suffstats_bwd.hip).
 #pragma once
+#include <cstdlib>
 #include "sgp_common.hpp"
 
 namespace sgp {
@@ -39,7 +40,8 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   if (cap < ASM_ROWS) cap = ASM_ROWS;
   p.sc_rows = p.Npad < cap ? p.Npad : cap;
   const int64_t nchunks = p.sc_rows / NB;
-  int64_t k = (TARGET_WGS + 8 * p.ntiles - 1) / (8 * p.ntiles);
+  static const int target_wgs = getenv("SGP_TARGET_WGS") ? atoi(getenv("SGP_TARGET_WGS")) : TARGET_WGS;  // tuning knob
+  int64_t k = (target_wgs + 8 * p.ntiles - 1) / (8 * p.ntiles);
   int64_t ns = 8 * k;
   const int64_t lim = round_up64(nchunks > 0 ? nchunks : 1, 8);
   if (ns > lim) ns = lim;

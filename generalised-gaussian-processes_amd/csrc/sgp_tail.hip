@@ -467,16 +467,15 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
   }
   diag_sum_kernel<<<1, 256, 0, st>>>(w.M5, Mp, 0, 1.0, w.sc + SC_TRW);
 
-  // B = I + W/s2 in M6 -> LB ; LB^-1 in M7
-  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6);
-  potrf_lower(w.M6, w.M7, ld, Mp, info, M, w.flags, st);
-  diag_sum_kernel<<<1, 256, 0, st>>>(w.M6, Mp, 1, 2.0, w.sc + SC_LOGDET);
-  tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
-
-  // q = LB^-1 L^-1 b
+  // u = L^-1 b
   pad_copy(b, 1, M, 1, w.bp, 1, Mp, 1, 0.0, st);
   gemv(w.M1, ld, Mp, false, w.bp, w.u, st);
-  gemv(w.M7, ld, Mp, false, w.u, w.q, st);
+
+  // B = I + W/s2 in M6 -> LB ; q = LB^-1 u rides along with the factorization; LB^-1 (M7) only when G is wanted
+  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6);
+  potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flags, st, w.u, w.q);
+  diag_sum_kernel<<<1, 256, 0, st>>>(w.M6, Mp, 1, 2.0, w.sc + SC_LOGDET);
+  if (need_G) tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
   dot_kernel<<<1, 256, 0, st>>>(w.q, w.q, Mp, w.sc + SC_QQ);
 
   if (need_G) {
