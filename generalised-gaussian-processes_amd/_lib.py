@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(HERE, "csrc", "libsgp_hip.so")
 SGP_ABI_VERSION = 1
 SGP_MAX_DIM = 32
 SGP_MAX_INDUCING = 4096
-KERNEL_IDS = {"rbf": 0, "matern32": 1, "matern52": 2}
+KERNEL_IDS = {"rbf": 0, "matern32": 1, "matern52": 2, "composite": 3}
+COMP_LEN = 33  # SGP_COMP_LEN: doubles in a composite-kernel parameter block (include/sgp.h)
 OUT_F, OUT_LOGMARG, OUT_TRACE, OUT_LOGDETB, OUT_QUAD, OUT_TRW, OUT_S2BAR, OUT_KAPPABAR, OUT_LEN = range(9)
 
 

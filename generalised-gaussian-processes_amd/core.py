@@ -197,9 +197,10 @@ class CollapsedBound:
                             self.kernel, want_gz=want_gz, kfu=res["kfu"])
         self._allreduce(g)
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
-        gh = g[: d + 1].detach().to("cpu")
-        grads = {"ls": gh[:d].clone(), "sf2": float(gh[d]), "s2": float(o[OUT_S2BAR]),
-                 "Z": g[d + 1:].reshape(M, d) if want_gz else None, "info": 0,
+        nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
+        gh = g[: nh + 1].detach().to("cpu")
+        grads = {"ls": gh[:nh].clone(), "sf2": float(gh[nh]), "s2": float(o[OUT_S2BAR]),
+                 "Z": g[nh + 1:].reshape(M, d) if want_gz else None, "info": 0,
                  "logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE])}
         return float(o[OUT_F]), grads
 

@@ -1,0 +1,249 @@
+// Materialised path for SGP_KERNEL_COMPOSITE (see sgp_composite.hpp).  Same outputs as the streaming kernels of
+// sgp_suffstats_fwd.hip / sgp_suffstats_bwd.hip -- [Phi | b | yy | kappa] and the gradient of F through K_uf and
+// K_uu -- for covariances that are sums of products of isotropic factors.  Row chunks bound the scratch; every
+// cross-workgroup sum goes through partial arrays reduced in a fixed order (no fp64 atomics), like the fast path.
+#include "sgp_composite.hpp"
+#include "sgp_dense.hpp"
+
+namespace sgp {
+
+constexpr int64_t COMP_CHUNK_ROWS = 65536;  // rows of K_fu materialised at a time
+constexpr int COMP_BLK_ROWS = 1024;         // rows one workgroup of the gradient kernel contracts
+
+// out[i][j] = k(a_i, b_j) for i < na, j < nb (+ jitter on i == j), zero in the padding; rows_p x cols_p, ld cols_p
+__global__ __launch_bounds__(256) void comp_k_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                                                     int64_t ldb, CompSpec cs, int d, int64_t na, int nb, int64_t rows_p,
+                                                     int cols_p, double jitter, double* __restrict__ out) {
+  const int64_t total = rows_p * cols_p;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / cols_p;
+    const int j = (int)(e - i * cols_p);
+    double v = 0.0;
+    if (i < na && j < nb) {
+      v = comp_value(cs, A + i * lda, B + (int64_t)j * ldb, d);
+      if (i == j) v += jitter;
+    }
+    out[e] = v;
+  }
+}
+
+// bp[m] (+)= sum_i K[i][m] y[i]   (thread <-> column, rows in order: deterministic)
+__global__ __launch_bounds__(256) void comp_colsum_kernel(const double* __restrict__ K, int64_t ldk, const double* __restrict__ y,
+                                                          int64_t rows, int Mp, int accumulate, double* __restrict__ bp) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mp) return;
+  double s = accumulate ? bp[m] : 0.0;
+  for (int64_t i = 0; i < rows; ++i) s = fma(K[i * ldk + m], y[i], s);
+  bp[m] = s;
+}
+
+__global__ __launch_bounds__(256) void comp_scalars_kernel(const double* __restrict__ y, int64_t N, double kdiag,
+                                                           double* __restrict__ yy, double* __restrict__ kappa) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < N; i += 256) s = fma(y[i], y[i], s);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) {
+    *yy = s;
+    *kappa = (double)N * kdiag;
+  }
+}
+
+static int grid_for_c(int64_t total, int cap = 4096) {
+  int64_t g = (total + 255) / 256;
+  if (g < 1) g = 1;
+  return (int)(g < cap ? g : cap);
+}
+
+void comp_kmatrix(const double* A, int64_t lda, int64_t na, const double* B, int64_t ldb, int nb, const CompSpec& cs, int d,
+                  int64_t rows_p, int cols_p, double jitter, double* out, hipStream_t st) {
+  comp_k_kernel<<<grid_for_c(rows_p * cols_p), 256, 0, st>>>(A, lda, B, ldb, cs, d, na, nb, rows_p, cols_p, jitter, out);
+}
+
+static int64_t chunk_rows(int64_t N) {
+  const int64_t np = round_up64(N > 0 ? N : 1, 64);
+  return np < COMP_CHUNK_ROWS ? np : COMP_CHUNK_ROWS;
+}
+
+size_t comp_fwd_workspace_bytes(int64_t N, int M) {
+  const size_t Mp = padded_m(M);
+  Carver c(nullptr);
+  c.take<double>((size_t)chunk_rows(N) * Mp);
+  c.take<double>(Mp * Mp);
+  c.take<double>(Mp);
+  return c.used();
+}
+
+int comp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
+                       int64_t N, int M, int d, double* Phi, double* b, double* yy, double* kappa, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
+  if (!ws || ws_bytes < comp_fwd_workspace_bytes(N, M)) return SGP_ERR_WORKSPACE;
+  const int Mp = padded_m(M);
+  const int64_t Rc = chunk_rows(N);
+  Carver c(ws);
+  double* Kc = c.take<double>((size_t)Rc * Mp);
+  double* Php = c.take<double>((size_t)Mp * Mp);
+  double* bp = c.take<double>(Mp);
+  fill_zero(Php, (size_t)Mp * Mp, st);
+  fill_zero(bp, Mp, st);
+  for (int64_t r0 = 0; r0 < N; r0 += Rc) {
+    const int64_t rn = (N - r0) < Rc ? (N - r0) : Rc;
+    const int64_t rp = round_up64(rn, 64);
+    comp_k_kernel<<<grid_for_c(rp * Mp), 256, 0, st>>>(X + r0 * ldx, ldx, Z, ldz, cs, d, rn, M, rp, Mp, 0.0, Kc);
+    GemmDesc g;  // Phi += Kc^T Kc
+    g.A = Kc; g.lda = Mp; g.ta = true; g.B = Kc; g.ldb = Mp; g.C = Php; g.ldc = Mp;
+    g.m = Mp; g.n = Mp; g.k = (int)rp; g.beta = 1.0;
+    gemm(g, st);
+    comp_colsum_kernel<<<(Mp + 255) / 256, 256, 0, st>>>(Kc, Mp, y + r0, rn, Mp, 1, bp);
+  }
+  crop_copy(Php, Mp, Phi, M, M, M, st);
+  crop_copy(bp, 1, b, 1, M, 1, st);
+  comp_scalars_kernel<<<1, 256, 0, st>>>(y, N, cs.kdiag, yy, kappa);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient contraction:  sum_{i, m} Kbar[i][m] d k(a_i, b_m) / d(.)   with  Kbar = C (+ y_i bb_m)
+//   workgroup <-> COMP_BLK_ROWS rows, thread <-> columns m = tid, tid + 256, ...
+//   gppart[blk][SGP_COMP_LEN]  parameter-block partials ; gzpart[blk][M][d]  partials of the derivative in b_m
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void comp_grad_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ yv,
+                                                        const double* __restrict__ B, int64_t ldb, CompSpec cs,
+                                                        const double* __restrict__ C, int64_t ldc, const double* __restrict__ bb,
+                                                        int64_t nrows, int M, int d, int64_t blk0,
+                                                        double* __restrict__ gppart, double* __restrict__ gzpart) {
+  __shared__ double red[4];
+  const int64_t r0 = (int64_t)blockIdx.x * COMP_BLK_ROWS;
+  const int64_t r1 = (r0 + COMP_BLK_ROWS) < nrows ? (r0 + COMP_BLK_ROWS) : nrows;
+  const int64_t blk = blk0 + blockIdx.x;
+  double acc[SGP_COMP_LEN];
+#pragma unroll
+  for (int p = 0; p < SGP_COMP_LEN; ++p) acc[p] = 0.0;
+  for (int m = threadIdx.x; m < M; m += 256) {
+    double bv[COMP_MAX_DIM], gz[COMP_MAX_DIM];
+    for (int j = 0; j < d; ++j) {
+      bv[j] = B[(int64_t)m * ldb + j];
+      gz[j] = 0.0;
+    }
+    const double bbm = bb ? bb[m] : 0.0;
+    for (int64_t i = r0; i < r1; ++i) {
+      double gpar[SGP_COMP_LEN], dkdb[COMP_MAX_DIM];
+#pragma unroll
+      for (int p = 0; p < SGP_COMP_LEN; ++p) gpar[p] = 0.0;
+      comp_grad(cs, A + i * lda, bv, d, gpar, dkdb);
+      const double kb = C[i * ldc + m] + (yv ? yv[i] * bbm : 0.0);
+#pragma unroll
+      for (int p = 0; p < SGP_COMP_LEN; ++p) acc[p] = fma(kb, gpar[p], acc[p]);
+      for (int j = 0; j < d; ++j) gz[j] = fma(kb, dkdb[j], gz[j]);
+    }
+    if (gzpart)
+      for (int j = 0; j < d; ++j) gzpart[(blk * M + m) * d + j] = gz[j];
+  }
+  for (int p = 0; p < SGP_COMP_LEN; ++p) {
+    const double s = block_sum256(acc[p], red);
+    if (threadIdx.x == 0) gppart[blk * SGP_COMP_LEN + p] = s;
+  }
+}
+
+// g_blk[p] (+)= scale_p * sum_blk gppart[blk][p] (+ amp_extra on the amplitude slots) ; g_Z[m][j] (+)= scale_z * sum_blk gzpart
+__global__ __launch_bounds__(256) void comp_grad_reduce_kernel(const double* __restrict__ gppart, const double* __restrict__ gzpart,
+                                                               int64_t nblk, int M, int d, CompSpec cs, double amp_extra,
+                                                               double scale_z, int accumulate, double* __restrict__ g_blk,
+                                                               double* __restrict__ g_Z) {
+  if (blockIdx.x == 0 && threadIdx.x < SGP_COMP_LEN) {
+    const int p = threadIdx.x;
+    double s = 0.0;
+    for (int64_t k = 0; k < nblk; ++k) s += gppart[k * SGP_COMP_LEN + p];
+    bool is_amp = false;
+    for (int t = 0; t < cs.nterms; ++t) is_amp = is_amp || (p == 1 + 8 * t);
+    if (is_amp) s += amp_extra;
+    g_blk[p] = accumulate ? g_blk[p] + s : s;
+  }
+  if (g_Z) {
+    const int64_t total = (int64_t)M * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+      double s = 0.0;
+      for (int64_t k = 0; k < nblk; ++k) s += gzpart[k * total + e];
+      s *= scale_z;
+      g_Z[e] = accumulate ? g_Z[e] + s : s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void comp_pad2_kernel(const double* __restrict__ src, int M, int Mp, double scale,
+                                                        double* __restrict__ dst) {
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / Mp), j = (int)(e - (int64_t)i * Mp);
+    dst[e] = (i < M && j < M) ? scale * src[(int64_t)i * M + j] : 0.0;
+  }
+}
+
+size_t comp_bwd_workspace_bytes(int64_t N, int M, int d) {
+  const size_t Mp = padded_m(M);
+  const size_t nblk = (size_t)((N + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS) + 1;
+  Carver c(nullptr);
+  c.take<double>((size_t)chunk_rows(N) * Mp);
+  c.take<double>((size_t)chunk_rows(N) * Mp);
+  c.take<double>(Mp * Mp);
+  c.take<double>(nblk * SGP_COMP_LEN);
+  c.take<double>(nblk * (size_t)M * d);
+  return c.used();
+}
+
+int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
+                       const double* Phibar, const double* bbar, double kappabar, int64_t N, int M, int d, double* g_blk,
+                       double* g_Z, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!ws || ws_bytes < comp_bwd_workspace_bytes(N, M, d)) return SGP_ERR_WORKSPACE;
+  const int Mp = padded_m(M);
+  const int64_t Rc = chunk_rows(N);
+  const int64_t nblk_total = (N + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS;
+  Carver c(ws);
+  double* Kc = c.take<double>((size_t)Rc * Mp);
+  double* Cc = c.take<double>((size_t)Rc * Mp);
+  double* P2 = c.take<double>((size_t)Mp * Mp);
+  double* gpp = c.take<double>((size_t)(nblk_total + 1) * SGP_COMP_LEN);
+  double* gzp = c.take<double>((size_t)(nblk_total + 1) * M * d);
+  comp_pad2_kernel<<<grid_for_c((int64_t)Mp * Mp), 256, 0, st>>>(Phibar, M, Mp, 2.0, P2);
+  int64_t blk0 = 0;
+  for (int64_t r0 = 0; r0 < N; r0 += Rc) {  // Rc is a multiple of COMP_BLK_ROWS or covers all of N
+    const int64_t rn = (N - r0) < Rc ? (N - r0) : Rc;
+    const int64_t rp = round_up64(rn, 64);
+    comp_k_kernel<<<grid_for_c(rp * Mp), 256, 0, st>>>(X + r0 * ldx, ldx, Z, ldz, cs, d, rn, M, rp, Mp, 0.0, Kc);
+    GemmDesc g;  // Cc = Kc (2 Phibar)
+    g.A = Kc; g.lda = Mp; g.B = P2; g.ldb = Mp; g.C = Cc; g.ldc = Mp;
+    g.m = (int)rp; g.n = Mp; g.k = Mp;
+    gemm(g, st);
+    const int nb = (int)((rn + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS);
+    comp_grad_kernel<<<nb, 256, 0, st>>>(X + r0 * ldx, ldx, y + r0, Z, ldz, cs, Cc, Mp, bbar, rn, M, d, blk0, gpp,
+                                         g_Z ? gzp : nullptr);
+    blk0 += nb;
+  }
+  comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, blk0, M, d, cs,
+                                                                            kappabar * (double)N, 1.0, 0, g_blk, g_Z);
+  return check_launch();
+}
+
+size_t comp_kuu_bwd_workspace_bytes(int M, int d) {
+  const size_t nblk = (size_t)((M + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS);
+  Carver c(nullptr);
+  c.take<double>(nblk * SGP_COMP_LEN);
+  c.take<double>(nblk * (size_t)M * d);
+  return c.used();
+}
+
+int comp_kuu_bwd(const double* Z, int64_t ldz, const CompSpec& cs, const double* Kuubar, int M, int d, double* g_blk,
+                 double* g_Z, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!ws || ws_bytes < comp_kuu_bwd_workspace_bytes(M, d)) return SGP_ERR_WORKSPACE;
+  const int nb = (M + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS;
+  Carver c(ws);
+  double* gpp = c.take<double>((size_t)nb * SGP_COMP_LEN);
+  double* gzp = c.take<double>((size_t)nb * M * d);
+  comp_grad_kernel<<<nb, 256, 0, st>>>(Z, ldz, nullptr, Z, ldz, cs, Kuubar, M, nullptr, M, M, d, 0, gpp, g_Z ? gzp : nullptr);
+  // k(z_i, z_m) depends on z_m through both arguments; with a symmetric Kuubar the two halves are equal
+  comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, nb, M, d, cs, 0.0, 2.0, 1,
+                                                                            g_blk, g_Z);
+  return check_launch();
+}
+
+}  // namespace sgp

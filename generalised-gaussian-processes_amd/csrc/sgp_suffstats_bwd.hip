@@ -22,6 +22,8 @@
 //     its L2 then serves the re-reads of every K'_fu row block (speed only, never correctness).
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
+#include "sgp_composite.hpp"
+#include "sgp_dense.hpp"
 
 namespace sgp {
 
@@ -358,7 +360,9 @@ using namespace sgp;
 extern "C" size_t sgp_suffstats_bwd_workspace_bytes(int64_t N, int M, int d) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);
-  return carve_bwd(nullptr, p, true).bytes;
+  const size_t fast = carve_bwd(nullptr, p, true).bytes;
+  const size_t comp = d <= COMP_MAX_DIM ? comp_bwd_workspace_bytes(N, M, d) : 0;  // one size for every kernel_id
+  return fast > comp ? fast : comp;
 }
 
 extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
@@ -368,8 +372,14 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
                                  sgp_stream_t stream) {
   if (!Z || !inv_ls || !Phibar || !bbar || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
-  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {  // g_ls receives the SGP_COMP_LEN-double gradient block, g_sf2 = 0
+    CompSpec cs;
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    fill_zero(g_sf2, 1, (hipStream_t)stream);
+    return comp_suffstats_bwd(X, ldx, y, Z, ldz, cs, Phibar, bbar, kappabar, N, M, d, g_ls, g_Z, ws, ws_bytes, (hipStream_t)stream);
+  }
   StreamPlan p = make_stream_plan(N, M, d);
   // with a caller-owned K'_fu the whole row range is one super-chunk; the split count stays what the
   // workspace query sized (it only shrinks when the caller's range has fewer 128-row blocks)

@@ -27,6 +27,7 @@
 //      lower triangle -- no fp64 atomics anywhere, results are bit-reproducible.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
+#include "sgp_composite.hpp"
 #include <cstdlib>
 
 namespace sgp {
@@ -422,7 +423,8 @@ extern "C" size_t sgp_kfu_len(int64_t N, int M) {
 extern "C" size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);
-  return carve_fwd(nullptr, p, true).bytes;
+  const size_t fast = carve_fwd(nullptr, p, true).bytes, comp = comp_fwd_workspace_bytes(N, M);  // one size for every kernel_id
+  return fast > comp ? fast : comp;
 }
 
 extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
@@ -431,8 +433,13 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
                                  size_t ws_bytes, sgp_stream_t stream) {
   if (!Z || !inv_ls || !Phi || !b || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
-  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {  // inv_ls carries the parameter block; materialised path, Kfu_out unused
+    CompSpec cs;
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    return comp_suffstats_fwd(X, ldx, y, Z, ldz, cs, N, M, d, Phi, b, yy, kappa, ws, ws_bytes, (hipStream_t)stream);
+  }
   StreamPlan p = make_stream_plan(N, M, d);
   if (Kfu_out) p.sc_rows = p.Npad;  // caller keeps the whole K'_fu: one super-chunk
   FwdWs w = carve_fwd(ws, p, Kfu_out == nullptr);

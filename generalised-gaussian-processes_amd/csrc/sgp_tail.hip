@@ -10,6 +10,7 @@
 // padding rows are identity for Kuu / zero for Phi so factors stay exact) through the MFMA GEMM,
 // blocked Cholesky and recursive triangular inverse of sgp_dense.hip; no host round trip.
 #include "sgp_dense.hpp"
+#include "sgp_composite.hpp"
 
 namespace sgp {
 
@@ -278,6 +279,19 @@ __global__ __launch_bounds__(256) void pred_cov_kernel(const double* __restrict_
   }
 }
 
+// cov (already holding K**) += -AtA + CtC (symmetrised) (+ s2 on the diagonal)
+__global__ __launch_bounds__(256) void pred_cov_add_kernel(const double* __restrict__ AtA, const double* __restrict__ CtC, int Tp,
+                                                           int T, double s2, int pred_noise, double* __restrict__ cov) {
+  const int64_t total = (int64_t)T * T;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int a = (int)(e / T), b = (int)(e - (int64_t)a * T);
+    const int64_t p = (int64_t)a * Tp + b, pt = (int64_t)b * Tp + a;
+    double v = cov[e] - 0.5 * (AtA[p] + AtA[pt]) + 0.5 * (CtC[p] + CtC[pt]);
+    if (a == b && pred_noise) v += s2;
+    cov[e] = v;
+  }
+}
+
 static KernArgs make_ka(const double* inv_ls, double sf2, int d) {
   KernArgs ka;
   for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
@@ -342,9 +356,15 @@ extern "C" const char* sgp_status_string(int status) {
 extern "C" int sgp_kuu(const double* Z, int64_t ldz, const double* inv_ls, double sf2, double jitter, int M, int d,
                        int kernel_id, double* Kuu, sgp_stream_t stream) {
   if (!Z || !inv_ls || !Kuu || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
-  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   hipStream_t st = (hipStream_t)stream;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {
+    CompSpec cs;
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    comp_kmatrix(Z, ldz, M, Z, ldz, M, cs, d, M, M, jitter, Kuu, st);
+    return check_launch();
+  }
   const KernArgs ka = make_ka(inv_ls, sf2, d);
   const int g = grid_for((int64_t)M * M);
   switch (kernel_id) {
@@ -367,10 +387,15 @@ extern "C" int sgp_kuu_bwd(const double* Z, int64_t ldz, const double* inv_ls, d
                            int d, int kernel_id, double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
                            sgp_stream_t stream) {
   if (!Z || !inv_ls || !Kuubar || !g_ls || !g_sf2 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
-  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   if (!ws || ws_bytes < sgp_kuu_bwd_workspace_bytes(M, d)) return SGP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {  // ADDS into the SGP_COMP_LEN-double block in g_ls (and g_Z)
+    CompSpec cs;
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    return comp_kuu_bwd(Z, ldz, cs, Kuubar, M, d, g_ls, g_Z, ws, ws_bytes, st);
+  }
   Carver c(ws);
   double* part = c.take<double>((size_t)M * (d + 1));
   double* gzraw = c.take<double>((size_t)M * d);
@@ -545,7 +570,12 @@ extern "C" int sgp_predict(const double* Xs, int64_t ldxs, int64_t T, const doub
                            double sf2, double s2, const double* factors, int M, int d, int kernel_id, int pred_noise,
                            double* mean, double* var, double* cov, void* ws, size_t ws_bytes, sgp_stream_t stream) {
   if (!Xs || !Z || !inv_ls || !factors || !mean || T <= 0 || M <= 0 || d <= 0 || ldxs < d || ldz < d) return SGP_ERR_ARG;
-  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
+  CompSpec cs{};
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    sf2 = cs.kdiag;  // prior variance k(x, x)
+  }
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   const int want_cov = cov != nullptr;
   if (want_cov && T > 32768) return SGP_ERR_DIM;
@@ -578,6 +608,7 @@ extern "C" int sgp_predict(const double* Xs, int64_t ldxs, int64_t T, const doub
     switch (kernel_id) {
       case SGP_KERNEL_RBF: kus_kernel<SGP_KERNEL_RBF><<<g, 256, 0, st>>>(Z, ldz, xs, ldxs, ka, M, Mp, Tn, Tp, Ks); break;
       case SGP_KERNEL_MATERN32: kus_kernel<SGP_KERNEL_MATERN32><<<g, 256, 0, st>>>(Z, ldz, xs, ldxs, ka, M, Mp, Tn, Tp, Ks); break;
+      case SGP_KERNEL_COMPOSITE: comp_kmatrix(Z, ldz, M, xs, ldxs, Tn, cs, d, Mp, Tp, 0.0, Ks, st); break;
       default: kus_kernel<SGP_KERNEL_MATERN52><<<g, 256, 0, st>>>(Z, ldz, xs, ldxs, ka, M, Mp, Tn, Tp, Ks); break;
     }
     GemmDesc a;
@@ -600,6 +631,10 @@ extern "C" int sgp_predict(const double* Xs, int64_t ldxs, int64_t T, const doub
       gemm(y, st);
       const int gc = grid_for((int64_t)Tn * Tn);
       switch (kernel_id) {
+        case SGP_KERNEL_COMPOSITE:
+          comp_kmatrix(xs, ldxs, Tn, xs, ldxs, Tn, cs, d, Tn, Tn, 0.0, cov, st);
+          pred_cov_add_kernel<<<gc, 256, 0, st>>>(AtA, CtC, Tp, Tn, s2, pred_noise, cov);
+          break;
         case SGP_KERNEL_RBF: pred_cov_kernel<SGP_KERNEL_RBF><<<gc, 256, 0, st>>>(xs, ldxs, ka, AtA, CtC, Tp, Tn, s2, pred_noise, cov); break;
         case SGP_KERNEL_MATERN32: pred_cov_kernel<SGP_KERNEL_MATERN32><<<gc, 256, 0, st>>>(xs, ldxs, ka, AtA, CtC, Tp, Tn, s2, pred_noise, cov); break;
         default: pred_cov_kernel<SGP_KERNEL_MATERN52><<<gc, 256, 0, st>>>(xs, ldxs, ka, AtA, CtC, Tp, Tn, s2, pred_noise, cov); break;

@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import KERNEL_IDS, OUT_LEN
+from ._lib import COMP_LEN, KERNEL_IDS, OUT_LEN
 
 
 def _kernel_id(kernel) -> int:
@@ -58,8 +58,17 @@ class HipEngine:
         return t
 
     @staticmethod
-    def _inv_ls(ls: Sequence[float], d: int):
+    def hyper_len(kernel, d: int) -> int:
+        """Entries of the hyper-parameter gradient: d lengthscales, or the composite kernel's parameter block."""
+        return COMP_LEN if _kernel_id(kernel) == KERNEL_IDS["composite"] else d
+
+    @staticmethod
+    def _inv_ls(ls: Sequence[float], d: int, kernel="rbf"):
         vals = [float(v) for v in (ls.tolist() if hasattr(ls, "tolist") else ls)]
+        if _kernel_id(kernel) == KERNEL_IDS["composite"]:  # the parameter block travels in place of 1 / lengthscale
+            if len(vals) != COMP_LEN:
+                raise ValueError("a composite kernel takes a %d-entry parameter block (got %d)" % (COMP_LEN, len(vals)))
+            return (C.c_double * COMP_LEN)(*vals)
         if len(vals) == 1 and d > 1:
             vals = vals * d
         if len(vals) != d:
@@ -96,7 +105,7 @@ class HipEngine:
         ws = self._workspace("fwd", nbytes)
         base = out.data_ptr()
         st = self.lib.sgp_suffstats_fwd(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), N, M, d, _kernel_id(kernel),
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_fwd", st)
@@ -106,7 +115,7 @@ class HipEngine:
         M, d = Z.shape
         self._chk(Z, "Z")
         K = out if out is not None else self.empty(M, M)
-        st = self.lib.sgp_kuu(self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(jitter), M, d, _kernel_id(kernel),
+        st = self.lib.sgp_kuu(self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), float(jitter), M, d, _kernel_id(kernel),
                               self._ptr(K), self._stream())
         _lib.check("sgp_kuu", st)
         return K
@@ -188,19 +197,20 @@ class HipEngine:
     # ------------------------------------------------------------------ pass 2
     def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False,
                       out: Optional[torch.Tensor] = None, kfu: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Packed local gradients [g_ls (d) | g_sf2 | g_Z (M*d, only when want_gz)]."""
+        """Packed local gradients [g_hyper (d lengthscales, or the composite block) | g_sf2 | g_Z (M*d, only when want_gz)]."""
         N, d = X.shape
         M = Z.shape[0]
+        nh = self.hyper_len(kernel, d)
         if out is None:
-            out = self.empty(d + 1 + (M * d if want_gz else 0))
+            out = self.empty(nh + 1 + (M * d if want_gz else 0))
         nbytes = self.lib.sgp_suffstats_bwd_workspace_bytes(N, M, d)
         ws = self._workspace("bwd", nbytes)
         base = out.data_ptr()
         st = self.lib.sgp_suffstats_bwd(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), self._ptr(Phibar),
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(Phibar),
             self._ptr(bbar), float(kappabar), self._ptr(kfu), N, M, d, _kernel_id(kernel), C.c_void_p(base),
-            C.c_void_p(base + 8 * d),
-            C.c_void_p(base + 8 * (d + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
+            C.c_void_p(base + 8 * nh),
+            C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_bwd", st)
         return out
 
@@ -210,9 +220,10 @@ class HipEngine:
         nbytes = self.lib.sgp_kuu_bwd_workspace_bytes(M, d)
         ws = self._workspace("kuu_bwd", nbytes)
         base = grads.data_ptr()
+        nh = self.hyper_len(kernel, d)
         st = self.lib.sgp_kuu_bwd(
-            self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), self._ptr(Kuubar), M, d, _kernel_id(kernel),
-            C.c_void_p(base), C.c_void_p(base + 8 * d), C.c_void_p(base + 8 * (d + 1)) if want_gz else C.c_void_p(0),
+            self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(Kuubar), M, d, _kernel_id(kernel),
+            C.c_void_p(base), C.c_void_p(base + 8 * nh), C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0),
             self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_kuu_bwd", st)
         return grads
@@ -227,7 +238,7 @@ class HipEngine:
         nbytes = self.lib.sgp_predict_workspace_bytes(T, M, d, 1 if full_cov else 0)
         ws = self._workspace("predict", nbytes)
         st = self.lib.sgp_predict(
-            self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(s2), self._ptr(factors), M, d,
+            self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), float(s2), self._ptr(factors), M, d,
             _kernel_id(kernel), 1 if pred_noise else 0, self._ptr(mean), self._ptr(var), self._ptr(cov),
             self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_predict", st)

@@ -49,6 +49,25 @@ typedef void* sgp_stream_t; /* hipStream_t */
 #define SGP_KERNEL_RBF 0
 #define SGP_KERNEL_MATERN32 1
 #define SGP_KERNEL_MATERN52 2
+/* Sum of products of isotropic factors (the reference's CO2 covariance,
+ * experiments/co2_bayesian_sgpr_hmc.py:74-83,107-149: n_per^2 Periodic*ExpQuad + n_med^2 RatQuad + n_trend^2 ExpQuad
+ * + n_noise^2 Matern32, PyMC3 pm.gp.cov definitions).  With this kernel_id every `inv_ls` argument points to a HOST
+ * parameter block of SGP_COMP_LEN doubles instead of d reciprocal lengthscales, sf2 is ignored, d <= 8, and
+ * the gradient entry points write dF/d(block) into g_ls (SGP_COMP_LEN doubles, zero in the slots that carry no
+ * parameter) and 0 into g_sf2.  Block layout:
+ *   [0] nterms (1..SGP_COMP_MAX_TERMS) ; term t at base = 1 + 8 t:  [base] amp2 (> 0)  [base+1] nfac (1..2)
+ *   factor f at fb = base + 2 + 3 f:  [fb] SGP_FAC_*  [fb+1] lengthscale (> 0)  [fb+2] aux (RATQUAD: alpha, PERIODIC: period)
+ * The composite path materialises K_fu in row chunks (it is meant for workloads of the CO2 size), shares the
+ * O(M^3) tail with the other kernels and is not available to the SVGP entry points.                          */
+#define SGP_KERNEL_COMPOSITE 3
+#define SGP_COMP_MAX_TERMS 4
+#define SGP_COMP_MAX_FACTORS 2
+#define SGP_COMP_LEN 33
+#define SGP_FAC_EXPQUAD 0   /* exp(-r2 / (2 l^2)) */
+#define SGP_FAC_MATERN32 1  /* (1 + sqrt3 r / l) exp(-sqrt3 r / l) */
+#define SGP_FAC_MATERN52 2  /* (1 + sqrt5 r / l + 5 r2 / (3 l^2)) exp(-sqrt5 r / l) */
+#define SGP_FAC_RATQUAD 3   /* (1 + r2 / (2 alpha l^2))^-alpha */
+#define SGP_FAC_PERIODIC 4  /* exp(-sum_j sin^2(pi (x_j - z_j) / T) / (2 l^2)) */
 
 #define SGP_OK 0
 #define SGP_ERR_ARG (-1)        /* null pointer / non-positive size / bad kernel_id */

@@ -1,0 +1,225 @@
+"""Sum-of-products covariances: oracle self-consistency, golden fixtures, the host-side kernel
+description / NUTS target, the dataset readers (CPU); HIP parity through the C ABI (``-m gpu``)."""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, dev
+from oracle import composite_oracle as CO
+from oracle import vfe_oracle as O
+
+COMP_DIR = os.path.join(GOLDEN_DIR, "composite")
+
+
+def comp_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(COMP_DIR, "*.npz")))
+
+
+def load_comp(name):
+    z = np.load(os.path.join(COMP_DIR, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _problem(N=120, M=9, d=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(N, d, dtype=torch.float64, generator=g) * 8.0
+    y = torch.sin(X.sum(1)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    return X, y, X[:M].clone()
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_single_factor_composites_equal_the_plain_kernels():
+    X, y, Z = _problem(d=2)
+    for ty, kid in ((CO.EXPQUAD, O.KERNEL_RBF), (CO.MATERN32, O.KERNEL_MATERN32), (CO.MATERN52, O.KERNEL_MATERN52)):
+        blk = CO.make_block([(1.7, [(ty, 0.9)])])
+        Fc = float(CO.vfe_composite(X, y, Z, blk, 0.05, 1e-6))
+        Fp = float(O.vfe_pymc3_order(X, y, Z, [0.9, 0.9], math.sqrt(1.7), math.sqrt(0.05), 1e-6, kid))
+        assert abs(Fc - Fp) < 1e-9 * max(1.0, abs(Fp))
+
+
+def test_oracle_gradients_match_finite_differences():
+    X, y, Z = _problem()
+    blk = CO.co2_block(n_per=0.8, l_psmooth=1.3, l_pdecay=3.0, n_med=0.5, l_med=1.1, alpha=0.7, n_trend=1.5, l_trend=2.0,
+                       n_noise=0.3, l_noise=0.4)
+    F, g = CO.vfe_composite_and_grads(X, y, Z, blk, 0.04)
+    for i in CO.grad_slots(blk):
+        e = np.zeros(CO.COMP_LEN)
+        e[i] = 1e-6 * max(1.0, abs(blk[i]))
+        fd = (float(CO.vfe_composite(X, y, Z, blk + e, 0.04)) - float(CO.vfe_composite(X, y, Z, blk - e, 0.04))) / (2 * e[i])
+        assert abs(fd - float(g["block"][i])) < 1e-5 * max(1.0, abs(fd)), (i, fd, float(g["block"][i]))
+
+
+@pytest.mark.parametrize("name", comp_names())
+def test_oracle_reproduces_composite_golden(name):
+    G = load_comp(name)
+    F, g = CO.vfe_composite_and_grads(G["X"], G["y"], G["Z"], G["block"], float(G["s2"]), float(G["jitter"]))
+    assert abs(F - float(G["F"])) < 1e-9 * max(1.0, abs(float(G["F"])))
+    assert np.allclose(g["block"].numpy(), G["g_block"], rtol=1e-7, atol=1e-9)
+    mu, cov = CO.predict_composite(G["Xs"], G["X"], G["y"], G["Z"], G["block"], float(G["s2"]), float(G["jitter"]))
+    assert np.allclose(mu.numpy(), G["pred_mean"], atol=1e-9) and np.allclose(cov.numpy(), G["pred_cov"], atol=1e-9)
+
+
+def test_composite_kernel_block_layout_and_round_trip():
+    import ggp_amd
+    k = ggp_amd.co2_kernel(n_per=0.8, l_psmooth=1.3, l_pdecay=3.0, n_med=0.5, l_med=1.1, alpha=0.7, n_trend=1.5, l_trend=2.0,
+                           n_noise=0.3, l_noise=0.4)
+    ref = CO.co2_block(n_per=0.8, l_psmooth=1.3, l_pdecay=3.0, n_med=0.5, l_med=1.1, alpha=0.7, n_trend=1.5, l_trend=2.0,
+                       n_noise=0.3, l_noise=0.4)
+    assert np.allclose(k.block(), ref)
+    names = [n for n, _, _ in k.free_parameters()]
+    assert names == ["amp_0", "ls_0_0", "ls_0_1", "amp_1", "ls_1_0", "aux_1_0", "amp_2", "ls_2_0", "amp_3", "ls_3_0"]  # period pinned
+    assert set(names) == set(ggp_amd.CO2_LOG_PRIOR_SD)
+    assert np.allclose(k.with_values(k.values()).block(), ref)
+    with pytest.raises(ValueError):
+        ggp_amd.CompositeKernel([(1.0, [ggp_amd.Factor("rbf", 1.0)] * 3)])
+
+
+class _OracleCompositeBound:
+    """Duck-typed stand-in for CollapsedBound(kernel='composite') on the CPU (test double, lives under tests/)."""
+    kernel = "composite"
+
+    def __init__(self, X, y):
+        self.X, self.y = X, y
+
+    def _prep_Z(self, Z):
+        return torch.as_tensor(Z, dtype=torch.float64)
+
+    def value_and_grad(self, Z, block, sf2, s2, want_gz=False, raise_on_fail=True):
+        F, g = CO.vfe_composite_and_grads(self.X, self.y, Z, np.asarray(block), s2, 1e-6)
+        return F, {"ls": g["block"], "sf2": 0.0, "s2": g["s2"], "Z": None, "info": 0}
+
+
+def test_composite_hmc_target_priors_and_chain_rule():
+    import ggp_amd
+    X, y, Z = _problem(N=80, M=7)
+    kern = ggp_amd.co2_kernel()
+    tgt = ggp_amd.CompositeHmcTarget(_OracleCompositeBound(X, y), Z, kern, ggp_amd.CO2_LOG_PRIOR_SD)
+    g = torch.Generator().manual_seed(1)
+    th = (0.3 * torch.randn(tgt.ndim, dtype=torch.float64, generator=g)).tolist()
+    lp, grad = tgt.logp_and_grad(th)
+    # value: bound + Normal log-densities of the log-parameters + HalfNormal(1) on sigma with its log-Jacobian
+    vals = [math.exp(v) for v in th[:-1]]
+    sigma = math.exp(th[-1])
+    F = float(CO.vfe_composite(X, y, Z, np.asarray(kern.with_values(vals).block()), sigma ** 2, 1e-6))
+    prior = sum(-0.5 * (t / sd) ** 2 - math.log(sd) - 0.5 * math.log(2 * math.pi) for t, sd in zip(th[:-1], tgt.sd))
+    prior += 0.5 * math.log(2 / math.pi) - 0.5 * sigma ** 2 + th[-1]
+    assert abs(lp - (F + prior)) < 1e-9 * max(1.0, abs(lp))
+    for i in range(tgt.ndim):  # gradient by central differences of logp
+        e = [0.0] * tgt.ndim
+        e[i] = 1e-6
+        fd = (tgt.logp([a + b for a, b in zip(th, e)]) - tgt.logp([a - b for a, b in zip(th, e)])) / 2e-6
+        assert abs(fd - grad[i]) < 1e-5 * max(1.0, abs(fd)), (i, fd, grad[i])
+    assert tgt.logp([1000.0] * tgt.ndim) == -math.inf
+    c = tgt.constrain(tgt.start())
+    assert c["sig_n"] == 1.0 and len(c["ls"]) == tgt.ndim - 1
+
+
+def test_dataset_readers(tmp_path):
+    import ggp_amd
+    from scipy.io import savemat
+    rng = np.random.RandomState(0)
+    yrs = 1958.0 + np.arange(700) / 12.0
+    co2 = 315.0 + 1.5 * (yrs - 1958.0) + 3.0 * np.sin(2 * np.pi * yrs)
+    co2[[5, 77]] = -99.99
+    p = tmp_path / "mauna.txt"
+    p.write_text("".join("%.4f   %.2f\n" % (a, b) for a, b in zip(yrs, co2)))
+    y_tr, t_tr, y_te, t_te, std = ggp_amd.datasets.load_co2_dataset(str(p), 2010)
+    assert t_tr.shape == (634, 1) and y_te.shape == (60,) and t_tr[0, 0] == 0.0 and y_tr[0] == 0.0
+    keep = np.array([float("%.2f" % v) for v in np.delete(co2, [5, 77])])
+    assert abs(std - np.std(keep)) < 1e-12 and abs(y_tr[10] - (keep[10] - keep[0]) / std) < 1e-12
+    data = rng.randn(200, 19)
+    savemat(str(tmp_path / "elevators.mat"), {"data": data})
+    X, Y = ggp_amd.datasets.read_elevators_mat(str(tmp_path / "elevators.mat"))
+    assert X.shape == (200, 18) and Y.shape == (200, 1) and np.allclose(Y[:, 0], data[:, -1])
+    Xtr, ytr, Xte, yte = ggp_amd.datasets.split_dataset(X, Y, split=3)
+    assert Xtr.shape == (180, 18) and yte.shape == (20,)
+    ind = np.arange(200)
+    np.random.RandomState(3).shuffle(ind)
+    assert np.allclose(Xtr[0], ((X - X.mean(0)) / (1e-6 + X.std(0)))[ind[0]])
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", comp_names())
+def test_composite_bound_grads_predict_golden(engine, name):
+    import ggp_amd
+    G = load_comp(name)
+    blk = G["block"].tolist()
+    cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), kernel="composite", jitter=float(G["jitter"]), engine=engine)
+    Z = dev(G["Z"], engine)
+    F, _ = cb.value(Z, blk, 1.0, float(G["s2"]))
+    tolF = 1e-8 * max(1.0, abs(float(G["F"])))  # north_star tolerance; the CO2 fixture's cond(Kuu) is ~1e5
+    assert abs(F - float(G["F"])) < tolF, (F, float(G["F"]))
+    F2, g = cb.value_and_grad(Z, blk, 1.0, float(G["s2"]), want_gz=True)
+    assert F2 == F and g["sf2"] == 0.0
+    sl = CO.grad_slots(G["block"])
+    gb = g["ls"].numpy()
+    assert np.abs(gb[sl] - G["g_block"][sl]).max() < 1e-6 * max(1.0, np.abs(G["g_block"][sl]).max())
+    assert np.all(gb[[i for i in range(CO.COMP_LEN) if i not in sl and i not in (1, 9, 17, 25)]] == 0.0)
+    assert abs(g["s2"] - float(G["g_s2"])) < 1e-6 * max(1.0, abs(float(G["g_s2"])))
+    assert (g["Z"].cpu().numpy() - G["g_Z"]).__abs__().max() < 1e-5 * max(1.0, np.abs(G["g_Z"]).max())
+    mean, var, cov = cb.predict(dev(G["Xs"], engine), Z, blk, 1.0, float(G["s2"]), full_cov=True)
+    assert np.abs(mean.cpu().numpy() - G["pred_mean"]).max() < 1e-7
+    assert np.abs(cov.cpu().numpy() - G["pred_cov"]).max() < 1e-7
+    assert np.abs(var.cpu().numpy() - np.diag(G["pred_cov"])).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_composite_rejects_bad_blocks_and_large_d(engine):
+    import ggp_amd
+    X, y, Z = _problem(d=2)
+    cb = ggp_amd.CollapsedBound(X.to(engine.device), y.to(engine.device), kernel="composite", jitter=1e-6, engine=engine)
+    bad = CO.make_block([(1.0, [(CO.EXPQUAD, 1.0)])])
+    bad[1] = -1.0  # negative amplitude
+    with pytest.raises(ggp_amd.SgpStatusError):
+        cb.value(Z.to(engine.device), bad.tolist(), 1.0, 0.1)
+    with pytest.raises(ValueError):
+        cb.value(Z.to(engine.device), [1.0, 1.0], 1.0, 0.1)  # not a parameter block
+    X9 = torch.randn(50, 9, dtype=torch.float64).to(engine.device)
+    cb9 = ggp_amd.CollapsedBound(X9, y[:50].to(engine.device), kernel="composite", jitter=1e-6, engine=engine)
+    with pytest.raises(ggp_amd.SgpStatusError):
+        cb9.value(X9[:5].clone(), CO.make_block([(1.0, [(CO.EXPQUAD, 1.0)])]).tolist(), 1.0, 0.1)
+
+
+@pytest.mark.gpu
+def test_composite_chunked_rows_match_oracle(engine):
+    """More rows than one materialised chunk (65536) and more than one gradient block per chunk."""
+    import ggp_amd
+    g = torch.Generator().manual_seed(5)
+    N, M = 70_000, 40
+    X = torch.rand(N, 1, dtype=torch.float64, generator=g) * 30.0
+    y = torch.sin(X[:, 0]) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[torch.randperm(N, generator=g)[:M]].clone()
+    blk = CO.make_block([(1.1, [(CO.PERIODIC, 1.2, 6.3), (CO.EXPQUAD, 20.0)]), (0.3, [(CO.MATERN32, 0.8)])])
+    F0, g0 = CO.vfe_composite_and_grads(X, y, Z, blk, 0.02, 1e-6)
+    cb = ggp_amd.CollapsedBound(X.to(engine.device), y.to(engine.device), kernel="composite", jitter=1e-6, engine=engine)
+    F1, g1 = cb.value_and_grad(Z.to(engine.device), blk.tolist(), 1.0, 0.02, want_gz=True)
+    assert abs(F1 - F0) < 1e-8 * abs(F0)
+    sl = CO.grad_slots(blk)
+    assert (g1["ls"][sl] - g0["block"][sl]).abs().max() < 1e-6 * g0["block"][sl].abs().max()
+    assert (g1["Z"].cpu() - g0["Z"]).abs().max() < 1e-5 * g0["Z"].abs().max()
+
+
+@pytest.mark.gpu
+def test_co2_nuts_on_device(engine):
+    """The reference's CO2 NUTS stage (co2_bayesian_sgpr_hmc.py:99-158) on a synthetic Keeling-like series."""
+    import ggp_amd
+    g = torch.Generator().manual_seed(11)
+    t = torch.linspace(0.0, 20.0, 240, dtype=torch.float64)[:, None]
+    y = 0.15 * t[:, 0] + 0.3 * torch.sin(2 * math.pi * t[:, 0]) + 0.05 * torch.randn(240, dtype=torch.float64, generator=g)
+    y = (y - y[0]) / y.std()
+    Z = t[::12].clone()
+    cb = ggp_amd.CollapsedBound(t.to(engine.device), y.to(engine.device), kernel="composite", jitter=1e-6, engine=engine)
+    tgt = ggp_amd.CompositeHmcTarget(cb, Z.to(engine.device), ggp_amd.co2_kernel(), ggp_amd.CO2_LOG_PRIOR_SD)
+    lp, grad = tgt.logp_and_grad(tgt.start())
+    F, gg = CO.vfe_composite_and_grads(t, y, Z, np.asarray(ggp_amd.co2_kernel().block()), 1.0, 1e-6)
+    prior = sum(-math.log(sd) - 0.5 * math.log(2 * math.pi) for sd in tgt.sd) + 0.5 * math.log(2 / math.pi) - 0.5
+    assert abs(lp - (F + prior)) < 1e-8 * max(1.0, abs(lp))
+    trace = ggp_amd.sample_nuts(tgt, n_samples=12, tune=30, seed=3, start=tgt.start())
+    assert len(trace) == 12 and np.all(np.isfinite(trace.get_sampler_stats("logp")))
+    assert np.all(trace["ls"] > 0) and trace["ls"].shape == (12, tgt.ndim - 1)
+    assert trace.get_sampler_stats("logp").mean() > lp  # the sampler moved off the (poor) test point
