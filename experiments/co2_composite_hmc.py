@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--mauna", default=None, help="path to mauna.txt (year co2, -99.99 = missing)")
     ap.add_argument("--num_inducing", type=int, default=64)
     ap.add_argument("--num_samples", type=int, default=200)
-    ap.add_argument("--tune", type=int, default=300)
+    ap.add_argument("--tune", type=int, default=150)
+    ap.add_argument("--max_treedepth", type=int, default=6, help="PyMC3 default is 10; the demo caps the work per draw")
     ap.add_argument("--seed", type=int, default=47)
     ap.add_argument("--jitter", type=float, default=1e-4,
                     help="added to diag(Kuu).  PyMC3's stabilize() uses 1e-6; with this covariance (a years-long RatQuad / trend\n"
@@ -64,7 +65,8 @@ def main():
     bound = ggp_amd.CollapsedBound(X, y, kernel="composite", jitter=args.jitter, engine=eng)
     target = ggp_amd.CompositeHmcTarget(bound, Z, ggp_amd.co2_kernel(), ggp_amd.CO2_LOG_PRIOR_SD)
     t0 = time.time()
-    trace = ggp_amd.sample_nuts(target, n_samples=args.num_samples, tune=args.tune, seed=args.seed, start=target.start())
+    trace = ggp_amd.sample_nuts(target, n_samples=args.num_samples, tune=args.tune, seed=args.seed, start=target.start(),
+                                max_treedepth=args.max_treedepth)
     wall = time.time() - t0
 
     # mixture predictive over the draws (models/bayesian_sgpr_hmc.py:198-231): per-draw mean / variance on the test months
@@ -82,7 +84,7 @@ def main():
     names = [n for n, _, _ in target.params] + ["sigma"]
     post = np.concatenate([trace["ls"], trace["sig_n"][:, None]], 1)
     out = {"config": "C2 CO2, composite covariance, NUTS", "data": data, "N_train": int(X.shape[0]), "num_inducing": M, "jitter": args.jitter,
-           "num_samples": len(trace), "tune": args.tune, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
+           "num_samples": len(trace), "tune": args.tune, "max_treedepth": args.max_treedepth, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
            "leapfrogs_per_s": trace.n_leapfrog / wall, "mean_step_size": float(trace.get_sampler_stats("step_size").mean()),
            "diverging": int(trace.get_sampler_stats("diverging").sum()),
            "posterior_mean": {n: float(v) for n, v in zip(names, post.mean(0))},

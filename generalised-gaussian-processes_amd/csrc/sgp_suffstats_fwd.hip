@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
 // ---------------------------------------------------------------------------------------------
 // NW = waves per workgroup: 4 (each wave a 64 x 64 block, 2 workgroups = 2 waves per SIMD) or
 //                           8 (each wave a 64 x 32 block, 2 workgroups = 4 waves per SIMD, <= 128 VGPRs)
-template <bool DIAG, int NW>
+// GLDS: the chunks travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction = one contiguous
+//       1 KB row segment, no VGPR staging, no ds_write) instead of through two register stages.
+template <bool DIAG, int NW, bool GLDS>
 __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* __restrict__ Kfu, int Mp, int64_t c0,
                                           int64_t c1, int I0, int J0, int accumulate, int skip_upper,
                                           double* __restrict__ out) {
@@ -206,29 +208,55 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
     }
   };
 
-  // Diagonal tiles compute their strictly-upper 64 x 64 block too (3 % extra flops): every workgroup of a
-  // split then takes the same time per chunk, the tiles of a split stay in step and re-reads of a K' row
-  // block by its 8-9 consumers hit the XCD's L2 instead of drifting apart.
-  if (c0 < c1) {
-    fetch(c0, stA);
-    stash(0, stA);
-    if (c0 + 1 < c1) fetch(c0 + 1, stB);
-    __syncthreads();
-    // invariant at the top of iteration c: LDS buffer (c-c0)&1 holds chunk c; chunk c+1 is in flight / in
-    // stage B (even trips) or stage A (odd trips)
-    int64_t c = c0;
-    for (; c + 1 < c1; c += 2) {
-      if (c + 2 < c1) fetch(c + 2, stA);
-      mfma_chunk(0);
-      stash(1, stB);  // chunk c+1
-      __syncthreads();
-      if (c + 3 < c1) fetch(c + 3, stB);
-      mfma_chunk(1);
-      if (c + 2 < c1) stash(0, stA);  // chunk c+2
-      __syncthreads();
+  if constexpr (GLDS) {
+    // wave-uniform LDS bases of this thread's NQ row segments (lane l lands at base + 16 l bytes)
+    auto dma = [&](int64_t c, int buf) {
+      const double* base = Kfu + c * NB * Mp;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int qb = wave * 64 + NT * i;  // first quad of this wave's segment
+        const int row = DIAG ? (qb >> 6) : (qb >> 7);
+        const int col0 = DIAG ? 0 : (((qb & 127) < 64) ? 0 : TILE);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
+                                         (__attribute__((address_space(3))) void*)&Ks[buf][row][col0], 16, 0, 0);
+      }
+    };
+    if (c0 < c1) {
+      dma(c0, 0);
+      __syncthreads();  // (emits vmcnt(0)): chunk c0 has landed for every wave
+      for (int64_t c = c0; c < c1; ++c) {
+        const int buf = (int)((c - c0) & 1);
+        if (c + 1 < c1) dma(c + 1, buf ^ 1);  // that buffer was last read before the barrier that ended iteration c-1
+        mfma_chunk(buf);
+        __syncthreads();  // my DMA of chunk c+1 has landed (vmcnt(0)) and everybody is done reading `buf`
+      }
     }
-    if (c < c1) mfma_chunk(0);  // odd chunk count: the last chunk sits in buffer 0
-  }
+  } else {
+  // Diagonal tiles compute their strictly-upper 64 x 64 block too (3 % extra flops): every workgroup of a
+    // split then takes the same time per chunk, the tiles of a split stay in step and re-reads of a K' row
+    // block by its 8-9 consumers hit the XCD's L2 instead of drifting apart.
+    if (c0 < c1) {
+      fetch(c0, stA);
+      stash(0, stA);
+      if (c0 + 1 < c1) fetch(c0 + 1, stB);
+      __syncthreads();
+      // invariant at the top of iteration c: LDS buffer (c-c0)&1 holds chunk c; chunk c+1 is in flight / in
+      // stage B (even trips) or stage A (odd trips)
+      int64_t c = c0;
+      for (; c + 1 < c1; c += 2) {
+        if (c + 2 < c1) fetch(c + 2, stA);
+        mfma_chunk(0);
+        stash(1, stB);  // chunk c+1
+        __syncthreads();
+        if (c + 3 < c1) fetch(c + 3, stB);
+        mfma_chunk(1);
+        if (c + 2 < c1) stash(0, stA);  // chunk c+2
+        __syncthreads();
+      }
+      if (c < c1) mfma_chunk(0);  // odd chunk count: the last chunk sits in buffer 0
+    }
+  
+}
 
   {
 #pragma unroll
@@ -245,7 +273,7 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   }
 }
 
-template <int NW>
+template <int NW, bool GLDS = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks,
                                                                     int cps, int ntiles, int accumulate, int skip_upper,
                                                                     double* __restrict__ slab) {
@@ -265,9 +293,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double
   if (c1 > nchunks) c1 = nchunks;
   double* out = slab + ((size_t)split * ntiles + t) * (TILE * TILE);
   if (ti == tj)
-    syrk_tile<true, NW>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
+    syrk_tile<true, NW, GLDS>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
   else
-    syrk_tile<false, NW>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
+    syrk_tile<false, NW, GLDS>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,7 +496,10 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     timing_begin(TIMING_SYRK, st);
     static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // A/B on MI355X: 17.17 vs 17.29 ms
     static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
-    if (nwaves == 8)
+    static const int glds = getenv("SGP_SYRK_GLDS") ? atoi(getenv("SGP_SYRK_GLDS")) : 0;
+    if (glds)
+      syrk_tile_kernel<4, true><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+    else if (nwaves == 8)
       syrk_tile_kernel<8><<<grid, 512, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
     else
       syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
