@@ -145,7 +145,9 @@ constexpr int DB = 64;
 constexpr int DLD = DB + 1;
 
 // Inv[o+s .. o+2s)[o .. o+s) = -Inv22 * (S21 * Inv11) for `npairs` pairs at o = 0, 2s, ...
-__device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD], double (*T)[DLD], int s, int npairs) {
+// The intermediate T = S21 Inv11 is parked, transposed, in the strictly-upper block of S that a lower-triangular
+// matrix leaves unused (T[i][j] at S[o + j][o + s + i]): two LDS tiles instead of three.
+__device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD], int s, int npairs) {
   const int tid = threadIdx.x;
   const int per = s * s;
   for (int e = tid; e < npairs * per; e += 256) {
@@ -155,7 +157,7 @@ __device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD]
     double acc = 0.0;
 #pragma unroll 8
     for (int q = j; q < s; ++q) acc = fma(S[o + s + i][o + q], Inv[o + q][o + j], acc);  // Inv11 lower: q >= j
-    T[o + s + i][o + j] = acc;
+    S[o + j][o + s + i] = acc;
   }
   __syncthreads();
   for (int e = tid; e < npairs * per; e += 256) {
@@ -164,15 +166,15 @@ __device__ __forceinline__ void inv_combine(double (*S)[DLD], double (*Inv)[DLD]
     const int o = pr * 2 * s;
     double acc = 0.0;
 #pragma unroll 8
-    for (int q = 0; q <= i; ++q) acc = fma(Inv[o + s + i][o + s + q], T[o + s + q][o + j], acc);  // Inv22 lower: q <= i
+    for (int q = 0; q <= i; ++q) acc = fma(Inv[o + s + i][o + s + q], S[o + j][o + s + q], acc);  // Inv22 lower: q <= i
     Inv[o + s + i][o + j] = -acc;
   }
   __syncthreads();
 }
 
-// Inv = S^-1 for a 64 x 64 lower-triangular S in LDS (Inv must be zero on entry):
-// four 16 x 16 diagonal blocks by forward substitution, then two doubling steps 16 -> 32 -> 64.
-__device__ __forceinline__ void block_inverse64(double (*S)[DLD], double (*Inv)[DLD], double (*T)[DLD]) {
+// Inv = S^-1 for a 64 x 64 lower-triangular S in LDS (Inv must be zero on entry; the strictly-upper part of S is
+// scratch): four 16 x 16 diagonal blocks by forward substitution, then two doubling steps 16 -> 32 -> 64.
+__device__ __forceinline__ void block_inverse64(double (*S)[DLD], double (*Inv)[DLD]) {
   const int tid = threadIdx.x;
   if (tid < 64) {
     const int b16 = (tid >> 4) * 16, c = tid & 15;
@@ -188,15 +190,14 @@ __device__ __forceinline__ void block_inverse64(double (*S)[DLD], double (*Inv)[
     for (int r = 0; r < 16; ++r) Inv[b16 + r][b16 + c] = x[r];
   }
   __syncthreads();
-  inv_combine(S, Inv, T, 16, 2);
-  inv_combine(S, Inv, T, 32, 1);
+  inv_combine(S, Inv, 16, 2);
+  inv_combine(S, Inv, 32, 1);
 }
 
 // inverses of the 64 x 64 diagonal blocks of an already-factored L (one workgroup per block)
 __global__ __launch_bounds__(256) void tri_diag_inv_kernel(const double* L, double* Linv, int64_t ld) {
   __shared__ double S[DB][DLD];
   __shared__ double Inv[DB][DLD];
-  __shared__ double T[DB][DLD];
   const int tid = threadIdx.x, k0 = blockIdx.x * DB;
   for (int e = tid; e < DB * DB; e += 256) {
     const int i = e >> 6, j = e & 63;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void tri_diag_inv_kernel(const double* L, doub
     Inv[i][j] = 0.0;
   }
   __syncthreads();
-  block_inverse64(S, Inv, T);
+  block_inverse64(S, Inv);
   for (int e = tid; e < DB * DB; e += 256) {
     const int r = e >> 6, c = e & 63;
     Linv[(int64_t)(k0 + r) * ld + k0 + c] = Inv[r][c];
@@ -464,7 +465,7 @@ __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb
 }
 
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t ld, int nb, int* ready, int* info,
-                                                              int info_base, const double* rhs, double* sol) {
+                                                              int info_base, const double* rhs, double* sol, double* Linv) {
   __shared__ DfShared sh;
   const int tid = threadIdx.x, r = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -600,6 +601,24 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ready + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == j && Linv) {
+      // off the critical path (the tile is already published): inverse of this diagonal block -> Linv, level 0 of
+      // tri_inverse().  The T tile holds S, the panel / operand region holds the inverse.
+      static_assert(sizeof(sh.Ts) >= sizeof(double) * DB * DLD && sizeof(sh.Sp) >= sizeof(double) * DB * DLD, "LDS reuse");
+      double (*S)[DLD] = reinterpret_cast<double (*)[DLD]>(&sh.Ts[0][0]);
+      double (*Inv)[DLD] = reinterpret_cast<double (*)[DLD]>(&sh.Sp[0][0][0]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        S[r][16 * g + k] = (16 * g + k <= r) ? x[k] : 0.0;
+        Inv[r][16 * g + k] = 0.0;
+      }
+      __syncthreads();
+      block_inverse64(S, Inv);
+      double* dst = Linv + ((int64_t)j * DB + r) * ld + (int64_t)j * DB + 16 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(dst + 2 * k) = d2{Inv[r][16 * g + 2 * k], Inv[r][16 * g + 2 * k + 1]};
+      __syncthreads();
+    }
   }
 }
 
@@ -625,12 +644,10 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   const int ntile = nb * (nb + 1) / 2;
   const int nitem = ntile + (rhs ? 1 : 0);
   zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
-  potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol);
+  if (Linv) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
+                                                   // diagonal tile owners inside the launch), zero elsewhere
+  potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
   potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile, info);
-  if (Linv) {  // level 0 of tri_inverse(): inverses of the 64 x 64 diagonal blocks, zero elsewhere
-    fill_zero(Linv, (size_t)Mp * ld, st);
-    tri_diag_inv_kernel<<<nb, 256, 0, st>>>(A, Linv, ld);
-  }
 }
 
 void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {
