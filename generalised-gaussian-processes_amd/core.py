@@ -129,9 +129,11 @@ class CollapsedBound:
             # a helper thread does it -- the ctypes call / graph replay drop the GIL -- while this thread enqueues
             # pass 1: neither stream waits for the host.
             main = torch.cuda.current_stream(e.device)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=e.device, priority=-1)  # its small kernels go ahead of queued pass-1 workgroups
-                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sgp-side")
+            if self._side is None:  # one side stream + one helper thread per engine, shared by every bound built on it
+                if getattr(e, "_side_stream", None) is None:
+                    e._side_stream = torch.cuda.Stream(device=e.device, priority=-1)  # ahead of queued pass-1 workgroups
+                    e._side_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sgp-side")
+                self._side, self._pool = e._side_stream, e._side_pool
             gr = e.kuu_factor_graph(Z.shape[0]) if self.use_graph and hasattr(e, "kuu_factor_graph") else None
             z_ready = main.record_event()  # Z is materialised on the main stream
             side, jitter, kernel = self._side, self.jitter, self.kernel

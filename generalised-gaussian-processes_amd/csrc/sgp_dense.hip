@@ -333,7 +333,7 @@ __device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)
 // ---------------------------------------------------------------------------------------------
 constexpr int DF_MAX_WG = 256;
 constexpr int DF_SPIN_LIMIT = 1 << 24;
-constexpr int POTRF_TIMEOUT = -7777;
+constexpr int POTRF_TIMEOUT = SGP_INFO_TIMEOUT;
 constexpr int TLD = DB + 2;  // LDS stride of the T / X tile (16-byte aligned rows)
 
 struct DfShared {

@@ -24,7 +24,9 @@
  *   - return value: 0 = launched; <0 = rejected before any launch (SGP_ERR_*).  Numerical failure
  *     (non-positive Cholesky pivot) is reported LAPACK-style through the device int `*info`:
  *     0 = ok, k>0 = leading minor of order k is not positive definite (1..M refer to Kuu,
- *     M+1..2M to B = I + L^-1 Phi L^-T / s2).  No exceptions cross the boundary.
+ *     M+1..2M to B = I + L^-1 Phi L^-T / s2).  No exceptions cross the boundary.  SGP_INFO_TIMEOUT (< 0)
+ *     means the single-launch Cholesky gave up waiting for a tile (seconds of spinning: never expected;
+ *     reported instead of hanging the device) -- treat the outputs as invalid.
  *   - kernel_id selects k(x,z): SGP_KERNEL_RBF     sf2 * exp(-r2/2)
  *                               SGP_KERNEL_MATERN32 sf2 * (1+sqrt3 r) exp(-sqrt3 r)
  *                               SGP_KERNEL_MATERN52 sf2 * (1+sqrt5 r+5r2/3) exp(-sqrt5 r)
@@ -45,6 +47,8 @@ typedef void* sgp_stream_t; /* hipStream_t */
 #define SGP_ABI_VERSION 1
 #define SGP_MAX_DIM 32          /* largest input dimension d the streaming kernels accept */
 #define SGP_MAX_INDUCING 4096   /* largest M */
+
+#define SGP_INFO_TIMEOUT (-7777) /* value of *info, not a return code */
 
 #define SGP_KERNEL_RBF 0
 #define SGP_KERNEL_MATERN32 1
