@@ -6,10 +6,13 @@ tolerance each fixture was validated at (1e-6 relative, looser for the ill-condi
 case) ; predictive mean/variance -> 1e-8 absolute.
 """
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from conftest import dev, golden_names, load_golden
 
@@ -319,6 +322,28 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     cb0 = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=0.0, engine=engine)
     F, parts = cb0.value(Zbad, G["ls"], 1.0, 0.1, raise_on_fail=False)
     assert math.isnan(F) and 1 <= parts["info"] <= 6
+
+
+@pytest.mark.parametrize("knob", ["SGP_SYRK_GLDS=1", "SGP_SYRK_WAVES=8", "SGP_SYRK_SKIP_UPPER=0", "SGP_TARGET_WGS=512"])
+def test_tuning_knobs_do_not_change_results(engine, knob):
+    """The A/B knobs of the pass-1 contraction (LDS-DMA staging, 8-wave workgroups, full diagonal tiles, fewer splits) are
+    read once per process, so each runs in a child process; all must reproduce the golden sufficient statistics."""
+    import subprocess
+    import sys as _sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import ggp_amd; from conftest import load_golden, dev\n"
+        "eng = ggp_amd.HipEngine(); G = load_golden('rbf_d18_mid')\n"
+        "full = eng.suffstats(dev(G['X'], eng), dev(G['y'], eng), dev(G['Z'], eng), G['ls'], float(G['sf2'])).cpu().numpy()\n"
+        "M = G['Z'].shape[0]; Phi = full[:M*M].reshape(M, M)\n"
+        "assert np.abs(Phi - G['Phi']).max() < 1e-12 * np.abs(G['Phi']).max(), np.abs(Phi - G['Phi']).max()\n"
+        "assert np.abs(full[M*M:M*M+M] - G['b']).max() < 1e-12 * np.abs(G['b']).max()\n"
+        "print('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ)
+    k, v = knob.split("=")
+    env[k] = v
+    r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (knob, r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_repeated_evaluations_all_modes_stay_clean(engine):
