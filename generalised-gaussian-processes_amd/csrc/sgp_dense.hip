@@ -342,7 +342,7 @@ struct DfShared {
     double Sp[4][DB][PLD];                                    // panels of L(j,j) (factor / solve phase)
   };
   double Ts[DB][TLD];
-  double Dinv[4][16][16];  // inverses of the four 16 x 16 diagonal blocks of L(j,j)
+  double Dinv[4][16][17];  // inverses of the four 16 x 16 diagonal blocks of L(j,j) (odd stride: MFMA operand reads)
   double Lcol[2][DB];
   double rd[DB];
   int bad;
@@ -512,8 +512,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         for (int q = 0; q < 4; ++q) sh.Ts[wi * 32 + u * 16 + l4 + 4 * q][wj * 32 + v * 16 + l15] = acc[u][v][q];
     if (tid == 0) sh.bad = 0;
     __syncthreads();
-    double x[16];
-    {
+
+    double x[16];  // diagonal tiles: row r, columns 16 g .. of the factor (kept for the block inverse below)
+    if (i == j) {
       const double* src = Aij + (int64_t)r * ld + 16 * g;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -521,10 +522,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         x[2 * k] = v[0] - sh.Ts[r][16 * g + 2 * k];
         x[2 * k + 1] = v[1] - sh.Ts[r][16 * g + 2 * k + 1];
       }
-    }
-    __syncthreads();  // Ts is reused as the X staging tile below; the mac buffers become Sp
-
-    if (i == j) {
+      __syncthreads();  // the mac buffers become Sp
       diag_factor64_fast(x, sh.Sp, sh.rd, sh.Lcol, &sh.bad, r, g);
       double* dst = Aij + (int64_t)r * ld + 16 * g;
 #pragma unroll
@@ -532,6 +530,20 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         *reinterpret_cast<d2*>(dst + 2 * k) = d2{(16 * g + 2 * k <= r) ? x[2 * k] : 0.0, (16 * g + 2 * k + 1 <= r) ? x[2 * k + 1] : 0.0};
       if (tid == 0 && sh.bad != 0 && *info == 0) *info = info_base + j * DB + sh.bad;
     } else {
+      // X = T L(j,j)^-T on the matrix cores, one wave per 16 rows of T and no barrier between the panels.
+      // Y = T[rows]^T is kept as four 16 x 16 blocks in the MFMA accumulator layout (component s of block pb, lane l:
+      // T[16 g + (l & 15)][16 pb + 4 s + (l >> 4)]), which is exactly the B operand of k-step s, so
+      //     X_pb^T = Dinv_pb Y_pb                  (Dinv_pb: inverse of the 16 x 16 diagonal block pb of L(j,j))
+      //     Y_q   -= L[q][pb] X_pb^T   for q > pb
+      // chain from block to block in registers; only the A operands (Dinv, L) come from LDS.
+      d4 yb[4];
+      {
+        const double* src = Aij + (int64_t)(16 * g + l15) * ld + l4;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = src[16 * pb + 4 * sq] - sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4];
+      }
       if (!df_wait(ready + tile_no(j, j), abort_flag)) return;
       {  // L(j,j) -> Sp panels, rd = 1 / diag
         const double* src = A + (int64_t)j * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
@@ -569,33 +581,25 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         for (int rr = 0; rr < 16; ++rr) sh.Dinv[blk][rr][c] = y[rr];
       }
       __syncthreads();
-      // X = T L^-T by 16-column panels: wave pb turns its panel into X with the inverted diagonal block
-      // (X[r][k] = sum_{q<=k} t[q] Dinv[k][q], no serial chain), the waves to its right subtract X_pb L[.,pb]^T
+      d4 xb[4];
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb) {
-        if (g == pb) {
-          double xn[16], nx[16];
+        d4 xa = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            xn[k] = 0.0;
-            nx[k] = -x[k];
-          }
-          rows16_apply<true>(xn, nx, &sh.Dinv[pb][0][0], 16);  // wave-uniform: broadcast reads
+        for (int sq = 0; sq < 4; ++sq) xa = mfma16(sh.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
+        xb[pb] = xa;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) x[k] = xn[k];
+        for (int q = pb + 1; q < 4; ++q)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(&sh.Ts[r][16 * pb + 2 * k]) = d2{x[2 * k], x[2 * k + 1]};
-        }
-        __syncthreads();
-        if (g > pb) {
-          double xr[16];
-          lds_row16(xr, &sh.Ts[r][16 * pb]);
-          rows16_apply<false>(x, xr, &sh.Sp[pb][16 * g][0], PLD);
-        }
+          for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-sh.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
       }
-      double* dst = Aij + (int64_t)r * ld + 16 * g;
+      {
+        double* dst = Aij + (int64_t)(16 * g + l15) * ld + l4;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(dst + 2 * k) = d2{x[2 * k], x[2 * k + 1]};
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int sq = 0; sq < 4; ++sq) dst[16 * pb + 4 * sq] = xb[pb][sq];
+      }
     }
     // publish: stores written back (release) -> barrier -> flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
