@@ -134,7 +134,10 @@ class CollapsedBound:
                     e._side_stream = torch.cuda.Stream(device=e.device, priority=-1)  # ahead of queued pass-1 workgroups
                     e._side_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sgp-side")
                 self._side, self._pool = e._side_stream, e._side_pool
-            gr = e.kuu_factor_graph(Z.shape[0]) if self.use_graph and hasattr(e, "kuu_factor_graph") else None
+            # graph replay only single-process: with a process group the helper thread enqueues plain launches (same speed),
+            # which keeps hipGraph capture away from the collective library's own threads
+            use_graph = self.use_graph and self.world == 1 and hasattr(e, "kuu_factor_graph")
+            gr = e.kuu_factor_graph(Z.shape[0]) if use_graph else None
             z_ready = main.record_event()  # Z is materialised on the main stream
             side, jitter, kernel = self._side, self.jitter, self.kernel
 

@@ -157,7 +157,9 @@ class HipEngine:
             torch.cuda.current_stream(self.device).wait_stream(warm)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: another host thread's runtime calls (a collective library's watchdog, the side-chain helper of
+            # another bound) must neither fail nor invalidate this capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 run()
             ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws}
         except Exception:  # capture not supported in this environment: plain launches still work
