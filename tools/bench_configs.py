@@ -39,6 +39,35 @@ def main():
             torch.cuda.synchronize()
             res[label] = k / (time.perf_counter() - t0)
         print(json.dumps(res))
+    # C4: BayesianSVGP-shaped minibatch step (N = 100k, d = 2, M = 256, B = 4096): one bound + full gradient per call
+    N, d, M, B = 100_000, 2, 256, 4096
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    f = torch.sin(2.0 * X[:, 0]) * torch.cos(X[:, 1])
+    Z = X[torch.randperm(N, generator=g)[:M]].clone().to(eng.device)
+    m = (0.1 * torch.randn(M, dtype=torch.float64, generator=g)).to(eng.device)
+    LS = (torch.eye(M, dtype=torch.float64) + 0.01 * torch.tril(torch.randn(M, M, dtype=torch.float64, generator=g))).to(eng.device)
+    for lik, yv in (("gaussian", f + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)), ("bernoulli", torch.sign(f))):
+        Xd, yd = X.to(eng.device), yv.to(eng.device)
+        batches = [torch.randperm(N, generator=g)[:B].to(eng.device) for _ in range(8)]
+        Xb = [Xd[b].contiguous() for b in batches]
+        yb = [yd[b].contiguous() for b in batches]
+
+        def step(i):
+            r = eng.svgp_elbo(Xb[i % 8], yb[i % 8], Z, [1.0, 1.0], 1.0, 0.05, m, LS, N, jitter=1e-6, likelihood=lik, with_grads=True)
+            return r["out"]
+
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 30
+        for i in range(k):
+            o = step(i)
+        float(o[0])
+        torch.cuda.synchronize()
+        print(json.dumps({"config": "C4 SVGP minibatch step (%s)" % lik, "N": N, "d": d, "M": M, "batch": B,
+                          "bound_and_grad_per_s": k / (time.perf_counter() - t0)}))
 
 
 if __name__ == "__main__":
