@@ -324,6 +324,27 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     assert math.isnan(F) and 1 <= parts["info"] <= 6
 
 
+def test_largest_supported_inducing_set(engine):
+    """M = SGP_MAX_INDUCING = 4096: 2080 tiles over 256 persistent workgroups in the dataflow Cholesky, the widest
+    kernel-matrix rows, and one past the limit is refused."""
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    g = torch.Generator().manual_seed(9)
+    N, M, d = 6000, 4096, 4
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X.sum(1)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g) * 1.5
+    ls, sf, sn = [0.7] * d, 1.1, 0.3
+    F_ref = float(O.vfe_pymc3_order(X, y, Z, ls, sf, sn, 1e-6))
+    cb = ggp_amd.CollapsedBound(X.to(engine.device), y.to(engine.device), jitter=1e-6, engine=engine)
+    F, parts = cb.value(Z.to(engine.device), ls, sf * sf, sn * sn)
+    assert abs(F - F_ref) < 1e-8 * abs(F_ref), (F, F_ref)
+    F2, gr = cb.value_and_grad(Z.to(engine.device), ls, sf * sf, sn * sn)
+    assert F2 == F and gr["info"] == 0 and np.all(np.isfinite(gr["ls"].numpy()))
+    with pytest.raises((ggp_amd.SgpStatusError, ValueError)):
+        cb.value(torch.randn(M + 1, d, dtype=torch.float64).to(engine.device), ls, sf * sf, sn * sn)
+
+
 def test_integration_md_ctypes_stub_runs(engine):
     """The binding shown to a reference maintainer in INTEGRATION.md (section B) is executed verbatim."""
     import re
