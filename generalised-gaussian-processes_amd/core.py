@@ -96,10 +96,9 @@ class CollapsedBound:
 
     @staticmethod
     def _fetch(out, info):
-        """One host round trip for the scalars of an evaluation."""
-        o = out.detach().to("cpu")
-        i = int(info.detach().to("cpu").item())
-        return o, i
+        """One host round trip for the scalars of an evaluation (the status word rides along as a double)."""
+        both = torch.cat([out.detach(), info.detach().to(torch.float64)]).to("cpu")
+        return both[:-1], int(both[-1].item())
 
     def _prep_Z(self, Z):
         if Z.dim() == 1:
