@@ -85,6 +85,7 @@ class CollapsedBound:
         self.kfu_budget_bytes = 64 << 30
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
         self.use_graph = True      # ... replayed from a hipGraph (falls back to plain launches if capture fails)
+        self.overlap_min_work = 1 << 21  # local rows x inducing points below which everything stays on one stream
         self._side = None
         self._pool = None
 
@@ -120,7 +121,10 @@ class CollapsedBound:
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False):
         e = self.engine
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
-        overlap = self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
+        # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
+        # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)
+        overlap = (self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
+                   and int(self.X.shape[0]) * int(Z.shape[0]) >= self.overlap_min_work)
         if overlap:
             # chol(Kuu) and its inverse depend on (Z, theta) only: they run on a side stream beside the prologue /
             # kernel assembly of pass 1 (once the SYRK saturates the chip a chain of ~50 dependent small kernels

@@ -311,7 +311,7 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     Z = dev(G["Z"], engine)
     outs = []
     for ov, gr in ((True, True), (False, False), (True, False), (True, True)):
-        cb.overlap_tail, cb.use_graph = ov, gr
+        cb.overlap_tail, cb.use_graph, cb.overlap_min_work = ov, gr, 0  # force the two-stream path at this small size
         F, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
         outs.append((F, g["ls"].clone(), g["Z"].clone()))
     assert outs[0][0] == outs[1][0] == outs[2][0] == outs[3][0]
@@ -397,7 +397,7 @@ def test_repeated_evaluations_all_modes_stay_clean(engine):
             cb = ggp_amd.CollapsedBound(X, y, jitter=1e-6, engine=engine)
             vals = []
             for mode in ((True, True), (True, False), (False, False)):
-                cb.overlap_tail, cb.use_graph = mode
+                cb.overlap_tail, cb.use_graph, cb.overlap_min_work = mode[0], mode[1], 0  # two-stream path even when tiny
                 for _ in range(4):
                     F, parts = cb.value(Z, [1.0] * d, 1.0, 0.1, raise_on_fail=False)
                     assert parts["info"] == 0, (rep, N, d, M, mode, parts)
