@@ -270,14 +270,14 @@ __device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[
 
 // Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k]:  the wave that
 // owns a 16-column panel factors it in registers, publishes it to LDS (Sp, zero above the diagonal) and the waves to
-// its right apply the rank-16 update; 4 barriers per block.  On return a[] holds L (garbage above the diagonal) and
-// rd[j] = 1 / L[j][j].  The pivot chain IS the critical path of the factorization, so inside a panel
+// its right apply the rank-16 update; 4 barriers per block.  On return a[] holds L (garbage above the diagonal).
+// The pivot chain IS the critical path of the factorization, so inside a panel
 //   * the next pivot  d' = A[j+1][j+1] - L[j+1][j]^2  is formed by lane j+1 from its own registers and fetched with one
 //     v_readlane before the column update, so the rsqrt chain of pivot j+1 starts while column j is still being applied;
 //   * the column l = L[:, j] is broadcast through LDS (one ds_write_b64 + uniform ds_read_b128s) instead of 15
 //     v_readlane pairs whose SGPR results stall the dependent v_fma_f64.
-__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double* rd, double (*Lcol)[DB],
-                                                   int* bad, int i, int g) {
+__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double (*Lcol)[DB], int* bad, int i,
+                                                   int g) {
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
     if (g == pb) {
@@ -292,7 +292,6 @@ __device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)
         const double rs = rsqrt_newton(d);
         const double l = a[jj] * rs;  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
         a[jj] = l;
-        if (i == 0) rd[j] = rs;
         if (jj < 15) {
           d = readlane_f64(fma(-l, l, a[jj + 1]), j + 1);  // next pivot, ahead of the column update
           double* col = Lcol[jj & 1];
@@ -346,6 +345,7 @@ struct DfShared {
   double Lcol[2][DB];
   double rd[DB];
   int bad;
+  int dead;
 };
 
 __device__ __forceinline__ int df_flag_load(const int* f) {
@@ -356,19 +356,26 @@ __device__ __forceinline__ int df_flag_load(const int* f) {
 //   consumer: the flag is an agent-scope atomic; the tile is then read with ordinary loads.  No acquire-side cache
 //   invalidate is needed: every L2 starts the launch clean, a line of tile X enters the L2 of another XCD only
 //   through a consumer's first read, which happens after X was published (written back), and X never changes again.
-// every thread polls (no barrier); returns false when the launch has been aborted
-__device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag) {
-  int spins = 0;
-  while (df_flag_load(flag) == 0) {
-    __builtin_amdgcn_s_sleep(1);
-    ++spins;
-    if ((spins & 255) == 0 && df_flag_load(abort_flag) != 0) return false;
-    if (spins > DF_SPIN_LIMIT) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
+// One lane per workgroup polls (540 waves hammering a handful of cache lines delayed the very store they were waiting
+// for: occasional 10x slower launches); the others wait at the barrier.  Flags sit DF_FLAG_STRIDE ints apart, one cache
+// line each, so the polls spread over the L2 channels.  Returns false when the launch has been aborted.
+constexpr int DF_FLAG_STRIDE = 32;
+__device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag, int* dead) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (df_flag_load(flag) == 0) {
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 255) == 0 && df_flag_load(abort_flag) != 0) { *dead = 1; break; }
+      if (spins > DF_SPIN_LIMIT) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *dead = 1;
+        break;
+      }
     }
   }
-  return true;
+  __syncthreads();
+  return *dead == 0;
 }
 
 // acc += P(64 x 64) Q(64 x 64)^T, both row-major with the contraction index contiguous (tiles of L)
@@ -423,7 +430,7 @@ __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb
   for (int jb = 0; jb < nb; ++jb) {
     double part = 0.0;
     for (int p = 0; p < jb; ++p) {
-      if (!df_wait(ready + tile_no(jb, p), abort_flag)) return;
+      if (!df_wait(ready + tile_no(jb, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
       const double* src = A + ((int64_t)jb * DB + row) * ld + (int64_t)p * DB + 16 * g;
       double lv[16], qv[16];
 #pragma unroll
@@ -437,7 +444,7 @@ __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb
       for (int k = 0; k < 16; ++k) part = fma(lv[k], qv[k], part);
     }
     red[g * DB + row] = part;
-    if (!df_wait(ready + tile_no(jb, jb), abort_flag)) return;
+    if (!df_wait(ready + tile_no(jb, jb) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
     __syncthreads();
     if (g == 0) {
       double rr = rhs[jb * DB + row] - (red[row] + red[DB + row] + red[2 * DB + row] + red[3 * DB + row]);
@@ -472,7 +479,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const int ntile = nb * (nb + 1) / 2;
-  int* abort_flag = ready + ntile;
+  int* abort_flag = ready + ntile * DF_FLAG_STRIDE;
+  if (tid == 0) sh.dead = 0;
+  __syncthreads();
   const int nitem = ntile + (rhs ? 1 : 0);
   int j = 0, start = 0;  // column of the current tile and number of the first tile of that column
   for (int t = blockIdx.x; t < nitem; t += gridDim.x) {
@@ -499,8 +508,8 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
 #pragma unroll
       for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
     for (int p = 0; p < j; ++p) {
-      if (!df_wait(ready + tile_no(i, p), abort_flag)) return;
-      if (i != j && !df_wait(ready + tile_no(j, p), abort_flag)) return;
+      if (!df_wait(ready + tile_no(i, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      if (i != j && !df_wait(ready + tile_no(j, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
       df_mac(A + (int64_t)i * DB * ld + (int64_t)p * DB, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, sh, acc);
     }
     // acc (MFMA layout) -> LDS, then every thread picks up  T[r][16 g ..] = A(i,j) - acc  in the row layout
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         x[2 * k + 1] = v[1] - sh.Ts[r][16 * g + 2 * k + 1];
       }
       __syncthreads();  // the mac buffers become Sp
-      diag_factor64_fast(x, sh.Sp, sh.rd, sh.Lcol, &sh.bad, r, g);
+      diag_factor64_fast(x, sh.Sp, sh.Lcol, &sh.bad, r, g);
       double* dst = Aij + (int64_t)r * ld + 16 * g;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
 #pragma unroll
           for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = src[16 * pb + 4 * sq] - sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4];
       }
-      if (!df_wait(ready + tile_no(j, j), abort_flag)) return;
+      if (!df_wait(ready + tile_no(j, j) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
       {  // L(j,j) -> Sp panels, rd = 1 / diag
         const double* src = A + (int64_t)j * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
         double v[16];
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
     // publish: stores written back (release) -> barrier -> flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ready + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(ready + t * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i == j && Linv) {
       // off the critical path (the tile is already published): inverse of this diagonal block -> Linv, level 0 of
       // tri_inverse().  The T tile holds S, the panel / operand region holds the inverse.
@@ -632,14 +641,17 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
 __global__ void zero_ints_kernel(int* p, int n) {
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) p[e] = 0;
 }
-void zero_ints(int* p, int n, hipStream_t st) { zero_ints_kernel<<<1, 256, 0, st>>>(p, n); }
+void zero_ints(int* p, int n, hipStream_t st) {
+  const int blocks = (n + 255) / 256;
+  zero_ints_kernel<<<blocks < 64 ? blocks : 64, 256, 0, st>>>(p, n);
+}
 __global__ void potrf_timeout_kernel(const int* abort_flag, int* info) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && *abort_flag != 0) *info = POTRF_TIMEOUT;
 }
 
 size_t potrf_scratch_ints(int Mp) {
   const size_t nb = Mp / DB;
-  return nb * (nb + 1) / 2 + 16;
+  return (nb * (nb + 1) / 2 + 1) * DF_FLAG_STRIDE;  // one cache line per tile flag + the abort flag
 }
 
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
@@ -651,7 +663,7 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   if (Linv) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
   potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
-  potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile, info);
+  potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
 }
 
 void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {
