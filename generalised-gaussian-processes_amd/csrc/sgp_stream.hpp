@@ -9,7 +9,8 @@ constexpr int TILE = 128;            // tile edge (inducing columns) of both pas
 constexpr int NB = 16;               // data rows per SYRK chunk
 constexpr int KROW = 2 * TILE + 16;  // LDS row stride of a SYRK chunk in doubles (272: +128 B bank shift per row)
 constexpr int ASM_ROWS = 256;        // data rows per assembly workgroup; K'_fu is padded to a multiple of this
-constexpr int TARGET_WGS = 2048;     // ~4 waves of the 512 resident workgroups (2 per CU)
+constexpr int TARGET_WGS = 2048;     // ~4 waves of the 512 resident workgroups (2 per CU): small problems
+constexpr int RESIDENT_WGS = 512;    // 256 CUs x 2 workgroups of the SYRK / K-bar kernels
 constexpr size_t KFU_BUDGET_DEFAULT = size_t(16) << 30;  // K'_fu bytes kept in flight when the library owns the buffer
 size_t stream_kfu_budget();  // current budget (sgp_set_kfu_budget_bytes); defined in sgp_suffstats_fwd.hip
 
@@ -43,12 +44,34 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   static const int target_wgs = getenv("SGP_TARGET_WGS") ? atoi(getenv("SGP_TARGET_WGS")) : TARGET_WGS;  // tuning knob
   int64_t k = (target_wgs + 8 * p.ntiles - 1) / (8 * p.ntiles);
   int64_t ns = 8 * k;
+  // Wave quantisation: workgroups take 3.3-4.7 ms each at C5 and 512 run at a time, so a launch whose last round is
+  // half empty idles a tenth of the chip (per-workgroup stamps: 14.9 ms of work in a 16.5 ms launch at 3.94 rounds).
+  // With enough rows, take the split count (multiple of 8, 6-11 rounds of workgroups that still get >= 64 chunks
+  // each) whose last round is fullest: 128 splits = exactly 9 rounds at M = 1024 (17.6 vs 18.5 ms on one box).
+  if (nchunks >= 64 * 8 && !getenv("SGP_TARGET_WGS")) {
+    double best_waste = 2.0;
+    for (int64_t kk = (3072 + 8 * p.ntiles - 1) / (8 * p.ntiles); 8 * kk * p.ntiles <= 5632; ++kk) {
+      const int64_t cand = 8 * kk;
+      if (kk < 1 || nchunks / cand < 64) break;
+      const double r = (double)p.ntiles * (double)cand / (double)RESIDENT_WGS;
+      const double rounds = (double)(int64_t)(r + 0.999999);
+      const double waste = (rounds - r) / rounds;
+      if (waste < best_waste - 1e-9) {
+        best_waste = waste;
+        ns = cand;
+      }
+    }
+  }
+  static const int ns_override = getenv("SGP_SYRK_NSPLIT") ? atoi(getenv("SGP_SYRK_NSPLIT")) : 0;  // tuning knob
+  if (ns_override > 0) ns = 8 * ((ns_override + 7) / 8);
   const int64_t lim = round_up64(nchunks > 0 ? nchunks : 1, 8);
   if (ns > lim) ns = lim;
   p.nsplit = (int)ns;
   p.nmb = p.Mp / TILE;
   const int64_t nblocks = p.sc_rows / TILE;
   int64_t nsb = 8 * ((TARGET_WGS + 8 * p.nmb - 1) / (8 * p.nmb));  // multiple of 8: one XCD per residue
+  static const int nsb_override = getenv("SGP_KBAR_NSPLIT") ? atoi(getenv("SGP_KBAR_NSPLIT")) : 0;  // tuning knob
+  if (nsb_override > 0) nsb = 8 * ((nsb_override + 7) / 8);
   const int64_t limb = round_up64(nblocks > 0 ? nblocks : 1, 8);
   if (nsb > limb) nsb = limb;
   p.nsplit_b = (int)nsb;
