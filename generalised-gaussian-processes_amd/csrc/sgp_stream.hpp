@@ -26,9 +26,43 @@ struct StreamPlan {
   int64_t Npad;     // N rounded up to ASM_ROWS
   int64_t sc_rows;  // rows of K'_fu materialised at a time (multiple of ASM_ROWS)
   int nsplit;       // pass 1: row-range splits per tile (multiple of 8: one XCD per residue)
+  int taper[4];     // pass 1: groups of 8 splits at relative sizes 8, 4, 2, 1 (all 0: equal splits), see split_range()
   int nmb;          // pass 2: 128-column blocks of Phibar
   int nsplit_b;     // pass 2: row-range splits per column block
 };
+
+// chunk range [c0, c1) of split `split` (8 splits per group; group sizes taper 8 : 4 : 2 : 1 when taper[] is set)
+struct SplitMap {
+  int g[4];
+  int cps;
+};
+__host__ __device__ inline void split_range(const SplitMap& m, int split, int64_t nchunks, int64_t& c0, int64_t& c1) {
+  const int64_t groups = (int64_t)m.g[0] + m.g[1] + m.g[2] + m.g[3];
+  if (groups == 0) {
+    c0 = (int64_t)split * m.cps;
+    c1 = c0 + m.cps;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > nchunks) c0 = nchunks;
+    return;
+  }
+  const int64_t total = 8 * (8 * (int64_t)m.g[0] + 4 * (int64_t)m.g[1] + 2 * (int64_t)m.g[2] + (int64_t)m.g[3]);
+  int64_t gg = split >> 3, before = 0;
+  int w = 8;
+  for (int l = 0; l < 4; ++l) {
+    if (gg >= m.g[l]) {
+      before += (int64_t)m.g[l] * 8 * w;
+      gg -= m.g[l];
+      w >>= 1;
+    } else {
+      before += gg * 8 * w;
+      break;
+    }
+  }
+  if (w == 0) w = 1;
+  const int64_t cum0 = before + (int64_t)(split & 7) * w;
+  c0 = cum0 * nchunks / total;
+  c1 = (cum0 + w) * nchunks / total;
+}
 
 static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   StreamPlan p;
@@ -67,6 +101,15 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   const int64_t lim = round_up64(nchunks > 0 ? nchunks : 1, 8);
   if (ns > lim) ns = lim;
   p.nsplit = (int)ns;
+  p.taper[0] = p.taper[1] = p.taper[2] = p.taper[3] = 0;
+  static const int taper_on = getenv("SGP_SYRK_TAPER") ? atoi(getenv("SGP_SYRK_TAPER")) : 1;  // A/B knob (20.55 vs 20.76 ms)
+  if (taper_on && ns_override == 0 && !getenv("SGP_TARGET_WGS") && ns % 32 == 0 && nchunks / ns >= 64) {
+    // big splits first, then halves, quarters and eighths: the last round of workgroups is short, so the ragged end of
+    // the launch (workgroup durations differ by +-15 %) shrinks with it
+    const int B = (int)(ns / 8);
+    p.taper[0] = 3 * B / 4; p.taper[1] = B / 4; p.taper[2] = B / 4; p.taper[3] = B / 2;
+    p.nsplit = 8 * (p.taper[0] + p.taper[1] + p.taper[2] + p.taper[3]);
+  }
   p.nmb = p.Mp / TILE;
   const int64_t nblocks = p.sc_rows / TILE;
   int64_t nsb = 8 * ((TARGET_WGS + 8 * p.nmb - 1) / (8 * p.nmb));  // multiple of 8: one XCD per residue

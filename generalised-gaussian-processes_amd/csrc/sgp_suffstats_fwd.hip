@@ -275,7 +275,7 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 
 template <int NW, bool GLDS = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks,
-                                                                    int cps, int ntiles, int accumulate, int skip_upper,
+                                                                    SplitMap smap, int ntiles, int accumulate, int skip_upper,
                                                                     double* __restrict__ slab) {
   __shared__ double Ks[2][NB][KROW];
   // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch
@@ -288,9 +288,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while (ti * (ti + 1) / 2 > t) --ti;
   const int tj = t - ti * (ti + 1) / 2;
-  const int64_t c0 = (int64_t)split * cps;
-  int64_t c1 = c0 + cps;
-  if (c1 > nchunks) c1 = nchunks;
+  int64_t c0, c1;
+  split_range(smap, split, nchunks, c0, c1);
   double* out = slab + ((size_t)split * ntiles + t) * (TILE * TILE);
   if (ti == tj)
     syrk_tile<true, NW, GLDS>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
@@ -484,7 +483,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   const int grid = p.ntiles * p.nsplit;
   if (p.Npad == 0) {
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
-    syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, 1, p.ntiles, 0, 0, w.slab);
+    syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, 0, w.slab);
   }
   for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
     const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
@@ -493,16 +492,17 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     timing_end(TIMING_ASSEMBLE, st);
     const int64_t nchunks = rows / NB;
     const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
+    const SplitMap smap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, cps < 1 ? 1 : cps};
     timing_begin(TIMING_SYRK, st);
     static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // A/B on MI355X: 17.17 vs 17.29 ms
     static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
     static const int glds = getenv("SGP_SYRK_GLDS") ? atoi(getenv("SGP_SYRK_GLDS")) : 0;
     if (glds)
-      syrk_tile_kernel<4, true><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+      syrk_tile_kernel<4, true><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
     else if (nwaves == 8)
-      syrk_tile_kernel<8><<<grid, 512, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+      syrk_tile_kernel<8><<<grid, 512, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
     else
-      syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, cps < 1 ? 1 : cps, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+      syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
     timing_end(TIMING_SYRK, st);
   }
   const int nb32 = p.Mp / 32;

@@ -361,7 +361,8 @@ def test_integration_md_ctypes_stub_runs(engine):
     assert abs(F - float(G["F"])) < 1e-9 * max(1.0, abs(float(G["F"])))
 
 
-@pytest.mark.parametrize("knob", ["SGP_SYRK_GLDS=1", "SGP_SYRK_WAVES=8", "SGP_SYRK_SKIP_UPPER=0", "SGP_TARGET_WGS=512"])
+@pytest.mark.parametrize("knob", ["SGP_SYRK_GLDS=1", "SGP_SYRK_WAVES=8", "SGP_SYRK_SKIP_UPPER=0", "SGP_TARGET_WGS=512", "SGP_SYRK_TAPER=0",
+                                  "SGP_SYRK_NSPLIT=24", "SGP_KBAR_NSPLIT=40"])
 def test_tuning_knobs_do_not_change_results(engine, knob):
     """The A/B knobs of the pass-1 contraction (LDS-DMA staging, 8-wave workgroups, full diagonal tiles, fewer splits) are
     read once per process, so each runs in a child process; all must reproduce the golden sufficient statistics."""
