@@ -29,6 +29,7 @@ struct StreamPlan {
   int taper[4];     // pass 1: groups of 8 splits at relative sizes 8, 4, 2, 1 (all 0: equal splits), see split_range()
   int nmb;          // pass 2: 128-column blocks of Phibar
   int nsplit_b;     // pass 2: row-range splits per column block
+  int taper_b[4];   // pass 2: tapered split sizes (as taper[])
 };
 
 // chunk range [c0, c1) of split `split` (8 splits per group; group sizes taper 8 : 4 : 2 : 1 when taper[] is set)
@@ -118,6 +119,13 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   const int64_t limb = round_up64(nblocks > 0 ? nblocks : 1, 8);
   if (nsb > limb) nsb = limb;
   p.nsplit_b = (int)nsb;
+  p.taper_b[0] = p.taper_b[1] = p.taper_b[2] = p.taper_b[3] = 0;
+  static const int taper_b_on = getenv("SGP_KBAR_TAPER") ? atoi(getenv("SGP_KBAR_TAPER")) : 1;  // A/B knob (55.4 vs 56.2 ms)
+  if (taper_b_on && nsb_override == 0 && nsb % 32 == 0 && nblocks / nsb >= 8) {
+    const int B = (int)(nsb / 8);
+    p.taper_b[0] = 3 * B / 4; p.taper_b[1] = B / 4; p.taper_b[2] = B / 4; p.taper_b[3] = B / 2;
+    p.nsplit_b = 8 * (p.taper_b[0] + p.taper_b[1] + p.taper_b[2] + p.taper_b[3]);
+  }
   return p;
 }
 

@@ -70,7 +70,7 @@ template <int DP, int KID>
 __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     const double* __restrict__ Kfu, const double* __restrict__ Xs, const double* __restrict__ ys,
     const double* __restrict__ Zs, const double* __restrict__ Pb, const double* __restrict__ bb, double sf2,
-    int64_t row0, int64_t nblocks, int bps, int64_t N, int M, int Mp, int nmb, int want_gz, int accumulate,
+    int64_t row0, int64_t nblocks, SplitMap bmap, int64_t N, int M, int Mp, int nmb, int want_gz, int accumulate,
     double* __restrict__ gacc, double* __restrict__ gzpart, double* __restrict__ glpart) {
   __shared__ double smem[BSM];
   double (*At)[TILE][ALD] = reinterpret_cast<double (*)[TILE][ALD]>(smem);               // [2][128][18]
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
   const int jj = blockIdx.x >> 3;
   const int mb = jj % nmb;
   const int split = (jj / nmb) * 8 + xcd;
-  const int64_t nb0 = (int64_t)split * bps;
-  const int64_t nb1 = (nb0 + bps < nblocks) ? nb0 + bps : nblocks;
+  int64_t nb0, nb1;
+  split_range(bmap, split, nblocks, nb0, nb1);
   const int m0 = mb * TILE;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -344,7 +344,8 @@ static BwdWs carve_bwd(void* ws, const StreamPlan& p, bool need_kfu) {
 template <int DP>
 static void launch_bwd(int kid, int grid, hipStream_t st, const double* Kfu, const BwdWs& w, double sf2, int64_t row0,
                        int64_t nblocks, int bps, int64_t N, int M, const StreamPlan& p, int want_gz, int accumulate) {
-#define SGP_BWD_ARGS Kfu, w.Xs, w.ys, w.Zs, w.Pb, w.bb, sf2, row0, nblocks, bps, N, M, p.Mp, p.nmb, want_gz, accumulate, w.gacc, w.gzpart, w.glpart
+  const SplitMap bmap{{p.taper_b[0], p.taper_b[1], p.taper_b[2], p.taper_b[3]}, bps};
+#define SGP_BWD_ARGS Kfu, w.Xs, w.ys, w.Zs, w.Pb, w.bb, sf2, row0, nblocks, bmap, N, M, p.Mp, p.nmb, want_gz, accumulate, w.gacc, w.gzpart, w.glpart
   switch (kid) {
     case SGP_KERNEL_RBF: kbar_contract_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;
     case SGP_KERNEL_MATERN32: kbar_contract_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;

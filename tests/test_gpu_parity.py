@@ -362,7 +362,7 @@ def test_integration_md_ctypes_stub_runs(engine):
 
 
 @pytest.mark.parametrize("knob", ["SGP_SYRK_GLDS=1", "SGP_SYRK_WAVES=8", "SGP_SYRK_SKIP_UPPER=0", "SGP_TARGET_WGS=512", "SGP_SYRK_TAPER=0",
-                                  "SGP_SYRK_NSPLIT=24", "SGP_KBAR_NSPLIT=40"])
+                                  "SGP_SYRK_NSPLIT=24", "SGP_KBAR_NSPLIT=40", "SGP_KBAR_TAPER=0"])
 def test_tuning_knobs_do_not_change_results(engine, knob):
     """The A/B knobs of the pass-1 contraction (LDS-DMA staging, 8-wave workgroups, full diagonal tiles, fewer splits) are
     read once per process, so each runs in a child process; all must reproduce the golden sufficient statistics."""
@@ -382,6 +382,39 @@ def test_tuning_knobs_do_not_change_results(engine, knob):
     env[k] = v
     r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (knob, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_tapered_splits_match_equal_splits(engine):
+    """At sizes where the split counts taper (default), F and the gradients must agree with equal splits to rounding
+    (only the order of the fixed-order partial sums changes).  One child process per setting: the knobs are static."""
+    import json
+    import subprocess
+    import sys as _sys
+    code = (
+        "import sys, json, math, torch; sys.path.insert(0, %r)\n"
+        "import ggp_amd\n"
+        "eng = ggp_amd.HipEngine(); g = torch.Generator().manual_seed(4)\n"
+        "N, M, d = 300000, 1024, 8\n"
+        "X = torch.randn(N, d, dtype=torch.float64, generator=g); w = torch.randn(d, dtype=torch.float64, generator=g) / math.sqrt(d)\n"
+        "y = torch.sin(X @ w) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)\n"
+        "Z = X[torch.randperm(N, generator=g)[:M]].clone().to(eng.device)\n"
+        "cb = ggp_amd.CollapsedBound(X.to(eng.device), y.to(eng.device), jitter=1e-6, engine=eng)\n"
+        "F, gr = cb.value_and_grad(Z, [2.0] * d, 1.0, 0.09, want_gz=True)\n"
+        "print(json.dumps({'F': F, 'ls': gr['ls'].tolist(), 'sf2': gr['sf2'], 's2': gr['s2'], 'gz': gr['Z'].cpu().flatten()[:64].tolist(),\n"
+        "                  'gzn': float(gr['Z'].norm())}))\n" % ROOT)
+    outs = []
+    for taper in ("1", "0"):
+        env = dict(os.environ, SGP_SYRK_TAPER=taper, SGP_KBAR_TAPER=taper)
+        r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    # rounding of Phi (1e-16 per entry) is amplified by cond(Kuu) ~ 1e6 at jitter 1e-6: 3e-10 relative in F was observed
+    assert abs(a["F"] - b["F"]) < 1e-8 * abs(b["F"])
+    for k in ("ls", "gz"):
+        assert np.abs(np.array(a[k]) - np.array(b[k])).max() < 1e-6 * max(1.0, np.abs(np.array(b[k])).max())
+    assert abs(a["sf2"] - b["sf2"]) < 1e-6 * abs(b["sf2"]) and abs(a["s2"] - b["s2"]) < 1e-6 * abs(b["s2"])
+    assert abs(a["gzn"] - b["gzn"]) < 1e-6 * b["gzn"]
 
 
 def test_repeated_evaluations_all_modes_stay_clean(engine):
