@@ -104,7 +104,7 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.nsplit = (int)ns;
   p.taper[0] = p.taper[1] = p.taper[2] = p.taper[3] = 0;
   static const int taper_on = getenv("SGP_SYRK_TAPER") ? atoi(getenv("SGP_SYRK_TAPER")) : 1;  // A/B knob (20.55 vs 20.76 ms)
-  if (taper_on && ns_override == 0 && !getenv("SGP_TARGET_WGS") && ns % 32 == 0 && nchunks / ns >= 64) {
+  if (taper_on && !getenv("SGP_TARGET_WGS") && ns % 32 == 0 && nchunks / ns >= 64) {
     // big splits first, then halves, quarters and eighths: the last round of workgroups is short, so the ragged end of
     // the launch (workgroup durations differ by +-15 %) shrinks with it
     const int B = (int)(ns / 8);
@@ -121,7 +121,7 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.nsplit_b = (int)nsb;
   p.taper_b[0] = p.taper_b[1] = p.taper_b[2] = p.taper_b[3] = 0;
   static const int taper_b_on = getenv("SGP_KBAR_TAPER") ? atoi(getenv("SGP_KBAR_TAPER")) : 1;  // A/B knob (55.4 vs 56.2 ms)
-  if (taper_b_on && nsb_override == 0 && nsb % 32 == 0 && nblocks / nsb >= 8) {
+  if (taper_b_on && nsb % 32 == 0 && nblocks / nsb >= 8) {
     const int B = (int)(nsb / 8);
     p.taper_b[0] = 3 * B / 4; p.taper_b[1] = B / 4; p.taper_b[2] = B / 4; p.taper_b[3] = B / 2;
     p.nsplit_b = 8 * (p.taper_b[0] + p.taper_b[1] + p.taper_b[2] + p.taper_b[3]);
