@@ -133,14 +133,48 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
 // ---------------------------------------------------------------------------------------------
 // 2. contraction: slab[split][tile] (+)= sum over this split's chunks of K'_I^T K'_J
 // ---------------------------------------------------------------------------------------------
+// Diagonal 128 x 128 tiles: only the 36 MFMA tiles (16 x 16) on or below the diagonal are needed.  A 64 x 64 block
+// per wave would leave one wave idle and the other three at full work -- and an idle wave's SIMD share is not
+// recovered (the co-resident workgroup's wave there just waits at its own barrier), so a diagonal tile cost as much as
+// a full one.  Instead the 36 tiles are dealt 9 to a wave (row-major walk of the triangle): 1.31 ms instead of 1.72 ms
+// per full-size diagonal workgroup, 16.3 vs 17.3 ms for the launch (per-workgroup stamps, same box).
+// Tile t of wave w is (DT_R[w][t], DT_C[w][t]) in units of 16; its operands are v[r], v[c] with v[b] = K'[k][16 b + ..]
+// (both operands come from the same 128 columns); wave w needs v[0 .. DT_NV[w] - 1].
+__device__ constexpr int DT_R[4][9] = {{0, 1, 1, 2, 2, 2, 3, 3, 3}, {3, 4, 4, 4, 4, 4, 5, 5, 5}, {5, 5, 5, 6, 6, 6, 6, 6, 6}, {6, 7, 7, 7, 7, 7, 7, 7, 7}};
+__device__ constexpr int DT_C[4][9] = {{0, 0, 1, 0, 1, 2, 0, 1, 2}, {3, 0, 1, 2, 3, 4, 0, 1, 2}, {3, 4, 5, 0, 1, 2, 3, 4, 5}, {6, 0, 1, 2, 3, 4, 5, 6, 7}};
+__device__ constexpr int DT_NV[4] = {4, 6, 7, 8};
+
+template <int W>
+__device__ __forceinline__ void diag_chunk(const double (*K)[KROW], d4 (&acc)[4][4], int l15, int l4) {
+#pragma unroll
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const double* kr = &K[ks * 4 + l4][0];
+    double v[8];
+#pragma unroll
+    for (int b = 0; b < DT_NV[W]; ++b) v[b] = kr[16 * b + l15];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t >> 2][t & 3] = mfma16(v[DT_R[W][t]], v[DT_C[W][t]], acc[t >> 2][t & 3]);
+  }
+}
+template <int W>
+__device__ __forceinline__ void diag_store(const d4 (&acc)[4][4], double* __restrict__ out, int accumulate, int l15, int l4) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* dst = out + (16 * DT_R[W][t] + l4 + 4 * r) * TILE + 16 * DT_C[W][t] + l15;
+      *dst = accumulate ? *dst + acc[t >> 2][t & 3][r] : acc[t >> 2][t & 3][r];
+    }
+}
+
 // NW = waves per workgroup: 4 (each wave a 64 x 64 block, 2 workgroups = 2 waves per SIMD) or
 //                           8 (each wave a 64 x 32 block, 2 workgroups = 4 waves per SIMD, <= 128 VGPRs)
 // GLDS: the chunks travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction = one contiguous
 //       1 KB row segment, no VGPR staging, no ds_write) instead of through two register stages.
-template <bool DIAG, int NW, bool GLDS>
+template <bool DIAG, int NW, bool GLDS, bool SKIP>
 __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* __restrict__ Kfu, int Mp, int64_t c0,
-                                          int64_t c1, int I0, int J0, int accumulate, int skip_upper,
-                                          double* __restrict__ out) {
+                                          int64_t c1, int I0, int J0, int accumulate, double* __restrict__ out) {
+  constexpr int skip_upper = SKIP ? 1 : 0;
   constexpr int NT = NW * 64;
   constexpr int VB = NW == 4 ? 4 : 2;     // 16-column MFMA tiles per wave (rows: always 4 = 64 rows)
   constexpr int WCOLS = VB * 16;
@@ -189,9 +223,20 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 #pragma unroll
     for (int v = 0; v < VB; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
-  // strictly-upper blocks of a diagonal tile (tuning knob): columns wj*WCOLS.. entirely right of rows wi*64..+63
-  const bool idle = DIAG && skip_upper && (wj * WCOLS >= wi * 64 + 64);
+  // diagonal tiles, SKIP (default): the balanced 9-tiles-per-wave walk above (4-wave workgroups) or idle waves for the
+  // strictly-upper blocks (8-wave workgroups); !SKIP computes the full tile (A/B knob SGP_SYRK_SKIP_UPPER=0)
+  constexpr bool BALANCED = DIAG && NW == 4 && SKIP;
+  const bool idle = DIAG && !BALANCED && skip_upper && (wj * WCOLS >= wi * 64 + 64);
   auto mfma_chunk = [&](int buf) {
+    if constexpr (BALANCED) {
+      switch (wave) {
+        case 0: diag_chunk<0>(Ks[buf], acc, l15, l4); break;
+        case 1: diag_chunk<1>(Ks[buf], acc, l15, l4); break;
+        case 2: diag_chunk<2>(Ks[buf], acc, l15, l4); break;
+        default: diag_chunk<3>(Ks[buf], acc, l15, l4); break;
+      }
+      return;
+    }
     if (idle) return;
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
@@ -258,6 +303,15 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   
 }
 
+  if constexpr (BALANCED) {
+    switch (wave) {
+      case 0: diag_store<0>(acc, out, accumulate, l15, l4); break;
+      case 1: diag_store<1>(acc, out, accumulate, l15, l4); break;
+      case 2: diag_store<2>(acc, out, accumulate, l15, l4); break;
+      default: diag_store<3>(acc, out, accumulate, l15, l4); break;
+    }
+    return;
+  }
   {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -273,9 +327,9 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   }
 }
 
-template <int NW, bool GLDS = false>
+template <int NW, bool GLDS, bool SKIP>
 __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks,
-                                                                    SplitMap smap, int ntiles, int accumulate, int skip_upper,
+                                                                    SplitMap smap, int ntiles, int accumulate,
                                                                     double* __restrict__ slab) {
   __shared__ double Ks[2][NB][KROW];
   // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch
@@ -292,9 +346,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double
   split_range(smap, split, nchunks, c0, c1);
   double* out = slab + ((size_t)split * ntiles + t) * (TILE * TILE);
   if (ti == tj)
-    syrk_tile<true, NW, GLDS>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
+    syrk_tile<true, NW, GLDS, SKIP>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, out);
   else
-    syrk_tile<false, NW, GLDS>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, skip_upper, out);
+    syrk_tile<false, NW, GLDS, SKIP>(Ks, Kfu, Mp, c0, c1, ti * TILE, tj * TILE, accumulate, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,7 +537,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   const int grid = p.ntiles * p.nsplit;
   if (p.Npad == 0) {
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
-    syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, 0, w.slab);
+    syrk_tile_kernel<4, false, false><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.slab);
   }
   for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
     const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
@@ -494,15 +548,20 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
     const SplitMap smap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, cps < 1 ? 1 : cps};
     timing_begin(TIMING_SYRK, st);
-    static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // A/B on MI355X: 17.17 vs 17.29 ms
+    static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // 0 = full diagonal tiles (A/B knob)
     static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
     static const int glds = getenv("SGP_SYRK_GLDS") ? atoi(getenv("SGP_SYRK_GLDS")) : 0;
-    if (glds)
-      syrk_tile_kernel<4, true><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
-    else if (nwaves == 8)
-      syrk_tile_kernel<8><<<grid, 512, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
-    else
-      syrk_tile_kernel<4><<<grid, 256, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, r0 > 0 ? 1 : 0, skip_upper, w.slab);
+    const int accum = r0 > 0 ? 1 : 0;
+#define SGP_SYRK_LAUNCH(NWV, GL, SK) \
+  syrk_tile_kernel<NWV, GL, SK><<<grid, NWV * 64, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, accum, w.slab)
+    if (glds) {
+      if (skip_upper) SGP_SYRK_LAUNCH(4, true, true); else SGP_SYRK_LAUNCH(4, true, false);
+    } else if (nwaves == 8) {
+      if (skip_upper) SGP_SYRK_LAUNCH(8, false, true); else SGP_SYRK_LAUNCH(8, false, false);
+    } else {
+      if (skip_upper) SGP_SYRK_LAUNCH(4, false, true); else SGP_SYRK_LAUNCH(4, false, false);
+    }
+#undef SGP_SYRK_LAUNCH
     timing_end(TIMING_SYRK, st);
   }
   const int nb32 = p.Mp / 32;
