@@ -30,7 +30,7 @@ LS, SF, SN, JITTER = 2.0, 1.0, 0.3, 1e-6
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= 256 CU x 2.4 GHz x 128 flop/clk/CU); see DESIGN.md
 # HBM bytes one syrk_tile_kernel launch moved at the default config (N=1M, M=1024, 1 GPU), from the PMC passes
 # committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); None for other configs.
-SYRK_TRAFFIC_BYTES_PMC = 5.15e10
+SYRK_TRAFFIC_BYTES_PMC = 5.38e10
 
 
 def synth(n_total, m, d):
@@ -177,7 +177,7 @@ def main():
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": SYRK_TRAFFIC_BYTES_PMC if (args.n, args.m, world) == (N_TOTAL, M_IND, 1) else None, "ms": pass1_ms,
                      "algorithmic_flops": algorithmic_flops_fwd(n_local, args.m, DIM),
                      "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
-                                     "profiles/r01_v10_pmc_hbm_traffic.csv (tools/profile_round.sh); collected in separate passes, not in this run"},
+                                     "profiles/r01_v11_pmc_hbm_traffic.csv (tools/profile_round.sh); collected in separate passes, not in this run"},
         "assembly": {"bound": "hbm", "kernel": "sgp::kfu_assemble_kernel<8,0>", "ms": assemble_ms,
                      "achieved": kfu_bytes / (assemble_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": kfu_bytes / (assemble_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": kfu_bytes},
