@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
     }
     const double msk = n < N ? zmask : 0.0;
     const double kv = kprofile<KID>(r2) * msk;
-    Kfu[(rbase + i) * Mp + m] = kv;
+    __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);  // streamed once (1.80 vs 1.90 ms with plain stores)
     bacc = fma(kv, ysh[i], bacc);
   }
   bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bacc;
