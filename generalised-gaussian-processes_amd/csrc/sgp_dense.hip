@@ -243,11 +243,10 @@ __device__ __forceinline__ void lds_row16(double (&v)[16], const double* p) {
     v[2 * e + 1] = t[1];
   }
 }
-// a[k] -= sum_q w[q] * R[k][q]  (k, q = 0..15; R rows at base + k * stride, e.g. 16 rows of a published panel).
+// a[k] -= sum_q w[q] * R[k][q]  (k, q = 0..15; R rows at base + k * stride: 16 rows of a published panel).
 // Row k+1 is fetched while row k is consumed and the fetches are pinned ahead of the arithmetic: left to itself
 // the compiler (256 live VGPRs around here) waits for each 16-byte read before the two FMAs that use it, 85 cycles
-// a piece.  NTRI: only q <= k contributes (lower-triangular R).
-template <bool NTRI>
+// a piece.
 __device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[16], const double* base, int stride) {
   double cur[16], nxt[16];
   lds_row16(cur, base);
@@ -258,8 +257,8 @@ __device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[
     double s0 = a[k], s1 = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; q += 2) {
-      if (!NTRI || q <= k) s0 = fma(-w[q], cur[q], s0);
-      if (!NTRI || q + 1 <= k) s1 = fma(-w[q + 1], cur[q + 1], s1);
+      s0 = fma(-w[q], cur[q], s0);
+      s1 = fma(-w[q + 1], cur[q + 1], s1);
     }
     a[k] = s0 + s1;
     __builtin_amdgcn_sched_barrier(0);
@@ -307,7 +306,7 @@ __device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)
     if (g > pb) {  // rank-16 update of this wave's 16 columns p = 16 g + k:  a[i][p] -= sum_j L[i][j] L[p][j]
       double li[16];
       lds_row16(li, &Sp[pb][i][0]);
-      rows16_apply<false>(a, li, &Sp[pb][16 * g][0], PLD);  // wave-uniform rows: broadcast reads
+      rows16_apply(a, li, &Sp[pb][16 * g][0], PLD);  // wave-uniform rows: broadcast reads
     }
   }
   __syncthreads();
