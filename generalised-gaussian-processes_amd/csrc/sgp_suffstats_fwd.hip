@@ -277,9 +277,8 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
       }
     }
   } else {
-  // Diagonal tiles compute their strictly-upper 64 x 64 block too (3 % extra flops): every workgroup of a
-    // split then takes the same time per chunk, the tiles of a split stay in step and re-reads of a K' row
-    // block by its 8-9 consumers hit the XCD's L2 instead of drifting apart.
+    // (A/B: writing chunk c+1 to LDS at the top of iteration c -- one register stage, ds_writes hidden under the
+    // MFMAs -- is 4.7 % slower: the loads then have one MFMA phase instead of two to land.)
     if (c0 < c1) {
       fetch(c0, stA);
       stash(0, stA);
