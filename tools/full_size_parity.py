@@ -27,10 +27,23 @@ def main():
     t0 = time.time()
     F_cpu = O.vfe_pymc3_order_chunked(X, y, Z, [bench.LS] * d, bench.SF, bench.SN, bench.JITTER)
     secs = time.time() - t0
-    print(json.dumps({"workload": "C5 N=%d d=%d M=%d, all rows" % (N, d, M), "F_hip": F_hip, "F_cpu_oracle": F_cpu,
-                      "abs_diff": abs(F_hip - F_cpu), "rel_diff": abs(F_hip - F_cpu) / abs(F_cpu),
-                      "diff_per_datum": abs(F_hip - F_cpu) / N, "tolerance_north_star_rel": 1e-8,
-                      "cpu_oracle_seconds": secs, "cpu_threads": os.cpu_count()}))
+    out = {"workload": "C5 N=%d d=%d M=%d, all rows" % (N, d, M), "F_hip": F_hip, "F_cpu_oracle": F_cpu,
+           "abs_diff": abs(F_hip - F_cpu), "rel_diff": abs(F_hip - F_cpu) / abs(F_cpu),
+           "diff_per_datum": abs(F_hip - F_cpu) / N, "tolerance_north_star_rel": 1e-8,
+           "cpu_oracle_seconds": secs, "cpu_threads": os.cpu_count()}
+    # gradients (the leapfrog path) against torch autograd on the PyMC3-order graph, on the first GR rows
+    GR = 100_000
+    Xg, yg = X[:GR], y[:GR]
+    cbg = ggp_amd.CollapsedBound(Xg.to(eng.device), yg.to(eng.device), jitter=bench.JITTER, engine=eng)
+    Fg, g = cbg.value_and_grad(Z.to(eng.device), [bench.LS] * d, bench.SF ** 2, bench.SN ** 2, want_gz=True)
+    t0 = time.time()
+    ref = O.grads_autograd(Xg, yg, Z, [bench.LS] * d, bench.SF ** 2, bench.SN ** 2, bench.JITTER)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    out["gradients"] = {"rows": GR, "rel_err_ls": rel(g["ls"], ref["g_ls"]), "rel_err_Z": rel(g["Z"].cpu(), ref["g_Z"]),
+                        "rel_err_sf2": abs(g["sf2"] - ref["g_sf2"]) / abs(ref["g_sf2"]),
+                        "rel_err_s2": abs(g["s2"] - ref["g_s2"]) / abs(ref["g_s2"]),
+                        "rel_err_F": abs(Fg - ref["F"]) / abs(ref["F"]), "autograd_seconds": time.time() - t0}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
