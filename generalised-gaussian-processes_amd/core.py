@@ -25,7 +25,7 @@ try:  # torch.distributed is plumbing; single-process use never touches it
 except Exception:  # pragma: no cover
     dist = None
 
-from ._lib import OUT_F, OUT_KAPPABAR, OUT_LOGMARG, OUT_S2BAR, OUT_TRACE
+from ._lib import OUT_F, OUT_LOGMARG, OUT_S2BAR, OUT_TRACE
 
 
 class NotPositiveDefiniteError(RuntimeError):
@@ -86,6 +86,7 @@ class CollapsedBound:
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
         self.use_graph = True      # ... replayed from a hipGraph (falls back to plain launches if capture fails)
         self.overlap_min_work = 1 << 21  # local rows x inducing points below which everything stays on one stream
+        self.early_check_min_work = 1 << 28  # ... from which value_and_grad reads the status before enqueueing pass 2
         self._side = None
         self._pool = None
 
@@ -95,11 +96,13 @@ class CollapsedBound:
             dist.all_reduce(buf, group=self.group)
         return buf
 
-    @staticmethod
-    def _fetch(out, info):
-        """One host round trip for the scalars of an evaluation (the status word rides along as a double)."""
-        both = torch.cat([out.detach(), info.detach().to(torch.float64)]).to("cpu")
-        return both[:-1], int(both[-1].item())
+    def _fetch(self, res, upto=None):
+        """The one host round trip of an evaluation: a single device-to-host copy of the result buffer ([out | status
+        word | whatever the caller appended], see ``HipEngine.result_buffer``) -- no cast / concatenate launches."""
+        buf = res["buf"] if upto is None else res["buf"][:upto]
+        host = buf.detach().to("cpu")
+        o, info = self.engine.read_result(host)
+        return o, info, host
 
     def _prep_Z(self, Z):
         if Z.dim() == 1:
@@ -118,8 +121,9 @@ class CollapsedBound:
             self._kfu = e.kfu_buffer(n_local, M)
         return self._kfu
 
-    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False):
+    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0):
         e = self.engine
+        result = e.result_buffer(extra)  # (buf, out, info): everything the host reads back, one allocation
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
         # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
         # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)
@@ -151,23 +155,25 @@ class CollapsedBound:
                     if gr is not None:
                         K = e.kuu(Z, ls, sf2, jitter, kernel, out=gr["Kuu"])
                         gr["graph"].replay()
-                        return K, gr["Linv"], gr["info"]
+                        result[2].copy_(gr["info"])  # the evaluation's status word starts as the Kuu status
+                        return K, gr["Linv"]
                     K = e.kuu(Z, ls, sf2, jitter, kernel)
-                    return (K,) + tuple(e.kuu_factor(K))
+                    return K, e.kuu_factor(K, info=result[2])[0]
 
+            result[0].record_stream(side)
             pending = self._pool.submit(side_chain)
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu)
         self._allreduce(packed)
         if overlap:
-            Kuu, linv, kinfo = pending.result()
-            for t in (Kuu, linv, kinfo):
+            Kuu, linv = pending.result()
+            for t in (Kuu, linv):
                 t.record_stream(main)
             main.wait_stream(self._side)
-            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv)
-            res["info"] = torch.where(kinfo != 0, kinfo, res["info"])
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
+                          result=result)
         else:
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
-            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors)
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, result=result)
         res["packed"] = packed
         res["kfu"] = kfu
         return res
@@ -177,7 +183,7 @@ class CollapsedBound:
         """F (not divided by N).  Returns (F, parts) with parts = dict(logmarg, trace_term, info)."""
         Z = self._prep_Z(Z)
         res = self._forward(Z, ls, sf2, s2, with_adjoints=False)
-        o, info = self._fetch(res["out"], res["info"])
+        o, info, _ = self._fetch(res)
         self.n_evals += 1
         if info != 0:
             if raise_on_fail:
@@ -193,20 +199,35 @@ class CollapsedBound:
         e = self.engine
         Z = self._prep_Z(Z)
         M, d = Z.shape
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=True)
-        o, info = self._fetch(res["out"], res["info"])
+        nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0))
+        head = res["out"].numel() + 1  # [out | status word], then the packed gradient
+        # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the
+        # status and the gradient -- a failed factorization then costs a wasted pass 2 (its NaNs are discarded), which
+        # is cheaper than idling the GPU for a host round trip on every leapfrog.  Big shards check the status first.
+        early = int(self.X.shape[0]) * M >= self.early_check_min_work
+        if early:
+            o, info, _ = self._fetch(res, upto=head)
+            if info != 0:
+                self.n_evals += 1
+                self.n_grads += 1
+                if raise_on_fail:
+                    raise NotPositiveDefiniteError(info)
+                return float("nan"), {"info": info}
+        g = res["buf"][head:]
+        # kappabar = dF/dkappa = -1 / (2 s2) needs nothing from the device (same value the tail writes to out)
+        e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
+                        self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
+        self._allreduce(g)
+        e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
+        o, info, host = self._fetch(res, upto=head + nh + 1)
         self.n_evals += 1
         self.n_grads += 1
         if info != 0:
             if raise_on_fail:
                 raise NotPositiveDefiniteError(info)
             return float("nan"), {"info": info}
-        g = e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], float(o[OUT_KAPPABAR]),
-                            self.kernel, want_gz=want_gz, kfu=res["kfu"])
-        self._allreduce(g)
-        e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
-        nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
-        gh = g[: nh + 1].detach().to("cpu")
+        gh = host[head:]
         grads = {"ls": gh[:nh].clone(), "sf2": float(gh[nh]), "s2": float(o[OUT_S2BAR]),
                  "Z": g[nh + 1:].reshape(M, d) if want_gz else None, "info": 0,
                  "logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE])}
@@ -216,7 +237,7 @@ class CollapsedBound:
         """Device tensor [Linv | G | q] for ``predict`` (computed from the current statistics)."""
         Z = self._prep_Z(Z)
         res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True)
-        _, info = self._fetch(res["out"], res["info"])
+        _, info, _ = self._fetch(res)
         if info != 0:
             raise NotPositiveDefiniteError(info)
         return res["factors"]

@@ -28,43 +28,58 @@ struct GemmP {
   int klo_mask, khi_mask, lower_only;
 };
 
-// op(A) tile -> As[k][row]; "K-contiguous" source (A not transposed / B transposed) or
-// "MN-contiguous" source (A transposed / B not transposed).
+// Operand tiles in LDS: S[k][col'] with 64-double rows and col' = (col + rot(k)) & 63, rot(k) = 4 (k >> 2) + 16 (k & 1).
+//  * MFMA operand reads (ds_read_b64, 32-lane groups, 64 banks): a group reads 16 columns of k-rows kr and kr + 1; the
+//    16-double shift between odd and even rows puts them on the two halves of the bank row -> conflict-free.
+//  * stores (32 banks, 16- / 8-lane groups): the four k-quads a group writes are shifted by 4 doubles each ->
+//    conflict-free (an unswizzled [16][80] image made every ds_write_b64 4-way: the stores of one k-chunk then
+//    occupied the LDS for half as long as its MFMAs run).
+__device__ __forceinline__ int tile_rot(int k) { return 4 * (k >> 2) + 16 * (k & 1); }
+
+// op(A) tile -> S; "K-contiguous" source (A not transposed / B transposed): thread = (row, k-quad), 32 B along k;
+// "MN-contiguous" source (A transposed / B not transposed): thread = (k, column pair), 2 x 16 B along the row.
+// t = thread index inside its 256-thread group.
 template <bool KCONTIG>
-__device__ __forceinline__ void tile_fetch(const double* P, int64_t ld, int r0, int k0, double (&v)[4]) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void tile_fetch(const double* P, int64_t ld, int r0, int k0, int t, d2 (&v)[2]) {
   if constexpr (KCONTIG) {
     const int row = t >> 2, kq = (t & 3) * 4;
     const double* s = P + (int64_t)(r0 + row) * ld + k0 + kq;
-    const d2 x0 = *reinterpret_cast<const d2*>(s);
-    const d2 x1 = *reinterpret_cast<const d2*>(s + 2);
-    v[0] = x0[0]; v[1] = x0[1]; v[2] = x1[0]; v[3] = x1[1];
+    v[0] = *reinterpret_cast<const d2*>(s);
+    v[1] = *reinterpret_cast<const d2*>(s + 2);
   } else {
-    const int kk = t >> 4, mq = (t & 15) * 4;
-    const double* s = P + (int64_t)(k0 + kk) * ld + r0 + mq;
-    const d2 x0 = *reinterpret_cast<const d2*>(s);
-    const d2 x1 = *reinterpret_cast<const d2*>(s + 2);
-    v[0] = x0[0]; v[1] = x0[1]; v[2] = x1[0]; v[3] = x1[1];
+    const int kk = t >> 4, c2 = (t & 15) * 2;
+    const double* s = P + (int64_t)(k0 + kk) * ld + r0 + c2;
+    v[0] = *reinterpret_cast<const d2*>(s);
+    v[1] = *reinterpret_cast<const d2*>(s + 32);
   }
 }
 template <bool KCONTIG>
-__device__ __forceinline__ void tile_stash(double (*S)[GLD], const double (&v)[4]) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void tile_stash(double (*S)[GT], int t, const d2 (&v)[2]) {
   if constexpr (KCONTIG) {
     const int row = t >> 2, kq = (t & 3) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) S[kq + e][row] = v[e];
+    for (int e = 0; e < 4; ++e) S[kq + e][(row + tile_rot(kq + e)) & 63] = v[e >> 1][e & 1];
   } else {
-    const int kk = t >> 4, mq = (t & 15) * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) S[kk][mq + e] = v[e];
+    const int kk = t >> 4, c2 = (t & 15) * 2, rot = tile_rot(kk);
+    *reinterpret_cast<d2*>(&S[kk][(c2 + rot) & 63]) = v[0];
+    *reinterpret_cast<d2*>(&S[kk][(c2 + 32 + rot) & 63]) = v[1];
   }
 }
 
+// One 64 x 64 output tile per workgroup of 8 waves.  The two 4-wave groups take alternate 16-deep k-chunks, so every
+// SIMD holds two waves; each group double-buffers its operand tiles in LDS (the stores of chunk j + 1 are issued
+// before the MFMAs of chunk j, one barrier per chunk) and keeps two chunks of global loads in flight in registers.
+// The groups' partial tiles are added in a fixed order (group 0 + group 1) through LDS: results do not depend on
+// timing.  History on one box, 1024^3: one group, single buffer 64 us; two groups 52 us; this version see DESIGN.md.
+struct GemmShared {
+  double As[2][2][GK][GT];  // [group][stage]
+  double Bs[2][2][GK][GT];
+};
+static_assert(sizeof(GemmShared) >= sizeof(double) * GT * GT, "partial tile is exchanged through the operand tiles");
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
-  __shared__ double As[GK][GLD];
-  __shared__ double Bs[GK][GLD];
+__global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
+  __shared__ GemmShared sh;
   const int bj = blockIdx.x, bi = blockIdx.y;
   if (p.lower_only && bj > bi) return;
   const int64_t bz = blockIdx.z;
@@ -78,9 +93,12 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
   if (p.khi_mask & 1) khi = min(khi, (bi + 1) * GT);
   if (p.khi_mask & 2) khi = min(khi, (bj + 1) * GT);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const int r0 = bi * GT, c0 = bj * GT;
+  // column of this lane's operands in k-row ks * 4 + l4, before the 4 ks part of the rotation
+  const int ca = wi * 32 + l15 + 16 * (l4 & 1), cb = wj * 32 + l15 + 16 * (l4 & 1);
 
   d4 acc[2][2];
 #pragma unroll
@@ -89,30 +107,84 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
     for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
   if (klo < khi) {
-    double va[4], vb[4];
-    tile_fetch<!TA>(A, p.lda, r0, klo, va);
-    tile_fetch<TB>(B, p.ldb, c0, klo, vb);
-    for (int k0 = klo; k0 < khi; k0 += GK) {
-      tile_stash<!TA>(As, va);
-      tile_stash<TB>(Bs, vb);
-      __syncthreads();
-      if (k0 + GK < khi) {
-        tile_fetch<!TA>(A, p.lda, r0, k0 + GK, va);
-        tile_fetch<TB>(B, p.ldb, c0, k0 + GK, vb);
+    // chunk j of this group starts at klo + (2 j + grp) GK; both groups run the same number of barriers
+    const int nchunk = (khi - klo + GK - 1) / GK, niter = (nchunk + 1) / 2;
+    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+    auto fetch = [&](int j, d2 (&ra)[2], d2 (&rb)[2]) {
+      const int c = 2 * j + grp;
+      if (c < nchunk) {
+        tile_fetch<!TA>(A, p.lda, r0, klo + c * GK, tid, ra);
+        tile_fetch<TB>(B, p.ldb, c0, klo + c * GK, tid, rb);
       }
+    };
+    auto stash = [&](int j, int stage, const d2 (&ra)[2], const d2 (&rb)[2]) {
+      if (2 * j + grp < nchunk) {
+        tile_stash<!TA>(sh.As[grp][stage], tid, ra);
+        tile_stash<TB>(sh.Bs[grp][stage], tid, rb);
+      }
+    };
+    // r holds chunk j + 1 on entry and chunk j + 3 on exit
+    auto body = [&](int j, int stage, d2 (&ra)[2], d2 (&rb)[2]) {
+      const bool live = 2 * j + grp < nchunk;
+      double a0[GK / 4], a1[GK / 4], b0[GK / 4], b1[GK / 4];
+      if (live) {  // operands of the whole chunk first: the MFMAs start as soon as the barrier falls
+        const double (*As)[GT] = sh.As[grp][stage];
+        const double (*Bs)[GT] = sh.Bs[grp][stage];
 #pragma unroll
-      for (int ks = 0; ks < GK / 4; ++ks) {
-        const int kr = ks * 4 + l4;
-        const double a0 = As[kr][wi * 32 + l15], a1 = As[kr][wi * 32 + 16 + l15];
-        const double b0 = Bs[kr][wj * 32 + l15], b1 = Bs[kr][wj * 32 + 16 + l15];
-        acc[0][0] = mfma16(a0, b0, acc[0][0]);
-        acc[0][1] = mfma16(a0, b1, acc[0][1]);
-        acc[1][0] = mfma16(a1, b0, acc[1][0]);
-        acc[1][1] = mfma16(a1, b1, acc[1][1]);
+        for (int ks = 0; ks < GK / 4; ++ks) {
+          const int kr = ks * 4 + l4;
+          a0[ks] = As[kr][(ca + 4 * ks) & 63];
+          a1[ks] = As[kr][(ca + 16 + 4 * ks) & 63];
+          b0[ks] = Bs[kr][(cb + 4 * ks) & 63];
+          b1[ks] = Bs[kr][(cb + 16 + 4 * ks) & 63];
+        }
+      }
+      auto mac = [&](int ks) {
+        acc[0][0] = mfma16(a0[ks], b0[ks], acc[0][0]);
+        acc[0][1] = mfma16(a0[ks], b1[ks], acc[0][1]);
+        acc[1][0] = mfma16(a1[ks], b0[ks], acc[1][0]);
+        acc[1][1] = mfma16(a1[ks], b1[ks], acc[1][1]);
+      };
+      if (live) mac(0);
+      stash(j + 1, stage ^ 1, ra, rb);  // LDS stores and global loads of later chunks issue under the MFMAs
+      if (live) mac(1);
+      fetch(j + 3, ra, rb);
+      if (live) {
+        mac(2);
+        mac(3);
       }
       __syncthreads();
+    };
+    fetch(0, ra0, rb0);
+    fetch(1, ra1, rb1);
+    stash(0, 0, ra0, rb0);
+    fetch(2, ra0, rb0);
+    __syncthreads();
+    for (int j = 0; j < niter; j += 2) {
+      body(j, 0, ra1, rb1);
+      if (j + 1 < niter) body(j + 1, 1, ra0, rb0);
+    }
+    // group 1's partial tile -> LDS -> added by group 0
+    double* red = &sh.As[0][0][0][0];
+    if (grp == 1) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((u * 2 + v) * 4 + r) * 256 + tid] = acc[u][v][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][v][r] += red[((u * 2 + v) * 4 + r) * 256 + tid];
     }
   }
+  if (grp != 0) return;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -132,10 +204,10 @@ void gemm(const GemmDesc& g, hipStream_t st) {
   GemmP p{g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.sA, g.sB, g.sC, g.m, g.n, g.k,
           g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? 1 : 0};
   dim3 grid(g.n / GT, g.m / GT, g.batch);
-  if (!g.ta && !g.tb) gemm64_kernel<false, false><<<grid, 256, 0, st>>>(p);
-  else if (!g.ta && g.tb) gemm64_kernel<false, true><<<grid, 256, 0, st>>>(p);
-  else if (g.ta && !g.tb) gemm64_kernel<true, false><<<grid, 256, 0, st>>>(p);
-  else gemm64_kernel<true, true><<<grid, 256, 0, st>>>(p);
+  if (!g.ta && !g.tb) gemm64_kernel<false, false><<<grid, 512, 0, st>>>(p);
+  else if (!g.ta && g.tb) gemm64_kernel<false, true><<<grid, 512, 0, st>>>(p);
+  else if (g.ta && !g.tb) gemm64_kernel<true, false><<<grid, 512, 0, st>>>(p);
+  else gemm64_kernel<true, true><<<grid, 512, 0, st>>>(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -653,16 +725,21 @@ size_t potrf_scratch_ints(int Mp) {
   return (nb * (nb + 1) / 2 + 1) * DF_FLAG_STRIDE;  // one cache line per tile flag + the abort flag
 }
 
+const int* potrf_abort_flag(const int* scratch, int Mp) {
+  const int nb = Mp / DB;
+  return scratch + (size_t)(nb * (nb + 1) / 2) * DF_FLAG_STRIDE;
+}
+
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
-                 const double* rhs, double* sol) {
+                 const double* rhs, double* sol, bool caller_managed) {
   const int nb = Mp / DB;
   const int ntile = nb * (nb + 1) / 2;
   const int nitem = ntile + (rhs ? 1 : 0);
-  zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
+  if (!caller_managed) zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
   if (Linv) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
   potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
-  potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
+  if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
 }
 
 void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {

@@ -33,8 +33,12 @@ void gemm(const GemmDesc& g, hipStream_t st);
 size_t potrf_scratch_ints(int Mp);
 // rhs / sol (optional, Mp doubles each): sol = L^-1 rhs, computed inside the same launch.  Linv may be null when
 // the caller needs neither tri_inverse() nor the block inverses.
+// caller_managed: the caller has already zeroed `scratch` on this stream and reads the abort flag
+// (potrf_abort_flag) itself after the launch -- saves two tiny launches on the latency-critical tail.
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
-                 const double* rhs = nullptr, double* sol = nullptr);
+                 const double* rhs = nullptr, double* sol = nullptr, bool caller_managed = false);
+// the word of `scratch` the dataflow launch raises when it gave up waiting (then info must become SGP_INFO_TIMEOUT)
+const int* potrf_abort_flag(const int* scratch, int Mp);
 
 // Completes Linv (diagonal 64-blocks already inverted by potrf_lower) to the full inverse of L.
 // tmp: Mp x Mp scratch with the same ld.

@@ -121,13 +121,53 @@ __global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __res
 // Bm = I + W / s2 (full matrix) ; sc[SC_TRW] = tr W
 enum { SC_TRW = 0, SC_LOGDET = 1, SC_QQ = 2, SC_TRSP = 3, SC_BA = 4, SC_APA = 5, SC_N = 8 };
 
-__global__ __launch_bounds__(256) void make_B_kernel(const double* __restrict__ W, int Mp, double inv_s2, double* __restrict__ Bm) {
+__global__ __launch_bounds__(256) void make_B_kernel(const double* __restrict__ W, int Mp, double inv_s2, double* __restrict__ Bm,
+                                                     double* __restrict__ trW) {
   const int64_t total = (int64_t)Mp * Mp;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
     // symmetrise: the two triangles of L^-1 Phi L^-T differ by rounding only
     const double w = 0.5 * (W[e] + W[(int64_t)c * Mp + r]);
     Bm[e] = (r == c ? 1.0 : 0.0) + w * inv_s2;
+  }
+  if (blockIdx.x == gridDim.x - 1) {  // tr W rides along (was a launch of its own)
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < Mp; i += 256) s += W[(int64_t)i * Mp + i];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) *trW = s;
+  }
+}
+// One launch ahead of the latency-critical chain: scalars <- 0, status word <- 0 (unless it already carries the
+// status of sgp_kuu_factor), tile flags of the second factorization <- 0, bp <- b zero-padded.
+__global__ __launch_bounds__(256) void tail_prep_kernel(int* info, double* __restrict__ sc, int* __restrict__ flags, int nflags,
+                                                        const double* __restrict__ b, int M, int Mp, double* __restrict__ bp) {
+  const int e0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  if (e0 == 0 && info) *info = 0;
+  if (e0 < SC_N) sc[e0] = 0.0;
+  for (int e = e0; e < nflags; e += stride) flags[e] = 0;
+  for (int e = e0; e < Mp; e += stride) bp[e] = e < M ? b[e] : 0.0;
+}
+// After chol(B): sum log diag(LB)^2, q.q and the dataflow launch's time-out word, in one block.
+__device__ __forceinline__ void potrf_scalars(const double* __restrict__ LB, const double* __restrict__ q, int Mp,
+                                              const int* abort_flag, int* info, double* red, double& logdet, double& qq) {
+  double s = 0.0, t = 0.0;
+  for (int i = threadIdx.x; i < Mp; i += 256) {
+    s += log(LB[(int64_t)i * Mp + i]);
+    t = fma(q[i], q[i], t);
+  }
+  logdet = 2.0 * block_sum256(s, red);
+  qq = block_sum256(t, red);
+  if (threadIdx.x == 0 && *abort_flag != 0) *info = SGP_INFO_TIMEOUT;
+}
+__global__ __launch_bounds__(256) void post_potrf_kernel(const double* __restrict__ LB, const double* __restrict__ q, int Mp,
+                                                         const int* abort_flag, int* info, double* __restrict__ sc) {
+  __shared__ double red[4];
+  double logdet, qq;
+  potrf_scalars(LB, q, Mp, abort_flag, info, red, logdet, qq);
+  if (threadIdx.x == 0) {
+    sc[SC_LOGDET] = logdet;
+    sc[SC_QQ] = qq;
   }
 }
 __global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict__ A, int Mp, int take_log, double scale, double* out) {
@@ -162,11 +202,22 @@ __global__ __launch_bounds__(256) void sum256_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) *out = s;
 }
 
-__global__ void finalize_bound_kernel(const double* __restrict__ sc, const double* __restrict__ yy, const double* __restrict__ kappa,
-                                      double s2, double Nd, int with_adj, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// LB != null (value-only evaluations): the chol(B) scalars are computed here instead of by post_potrf_kernel.
+__global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __restrict__ sc, const double* __restrict__ yy,
+                                                             const double* __restrict__ kappa, double s2, double Nd, int with_adj,
+                                                             const double* __restrict__ LB, const double* __restrict__ q, int Mp,
+                                                             const int* abort_flag, int* info, double* __restrict__ out) {
+  __shared__ double red[4];
+  double logdetB = 0.0, qq = 0.0;
+  if (LB) {
+    potrf_scalars(LB, q, Mp, abort_flag, info, red, logdetB, qq);
+  } else {
+    logdetB = sc[SC_LOGDET];
+    qq = sc[SC_QQ];
+  }
+  if (threadIdx.x != 0) return;
   const double LOG2PI = 1.8378770664093453;
-  const double trW = sc[SC_TRW], logdetB = sc[SC_LOGDET], qq = sc[SC_QQ];
+  const double trW = sc[SC_TRW];
   const double quad = *yy / s2 - qq / (s2 * s2);
   const double logmarg = -(0.5 * Nd * LOG2PI + 0.5 * Nd * log(s2) + 0.5 * logdetB + 0.5 * quad);
   const double trace_term = (*kappa - trW) / (2.0 * s2);
@@ -308,7 +359,7 @@ static int grid_for(int64_t total, int cap = 2048) {
 struct BoundWs {
   double *M0, *M1, *M2, *M3, *M4, *M5, *M6, *M7, *M8;
   double *bp, *u, *q, *alpha, *t1, *sc, *partial;
-  int* flags;  // potrf tile-ready flags
+  int *flags, *flagsB;  // potrf tile-ready flags: chol(Kuu) (cleared by potrf_lower), chol(B) (cleared by tail_prep_kernel)
   size_t bytes;
 };
 static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
@@ -332,6 +383,7 @@ static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
   w.sc = c.take<double>(SC_N);
   w.partial = c.take<double>(256);
   w.flags = c.take<int>(potrf_scratch_ints(Mp));
+  w.flagsB = c.take<int>(potrf_scratch_ints(Mp));
   w.bytes = c.used();
   return w;
 }
@@ -466,8 +518,10 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
   const size_t mm = (size_t)Mp * Mp;
   const bool need_G = with_adjoints || factors;
 
-  zero_ints(info, 1, st);
-  fill_zero(w.sc, SC_N, st);
+  // status word: zeroed here, except when L^-1 comes from sgp_kuu_factor -- then *info already holds that call's
+  // status and (like every factorization here) chol(B) only reports into it while it is still 0
+  const int nflags = (int)potrf_scratch_ints(Mp);
+  tail_prep_kernel<<<(nflags + 255) / 256, 256, 0, st>>>(kuu_linv ? nullptr : info, w.sc, w.flagsB, nflags, b, M, Mp, w.bp);
 
   // L = chol(Kuu) in M0, L^-1 in M1 -- or L^-1 handed over by sgp_kuu_factor (read-only from here on)
   if (kuu_linv) {
@@ -478,8 +532,9 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
     tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
   }
 
-  // W = L^-1 Phi L^-T in M5 (V in M4)
-  pad_copy(Phi, M, M, M, w.M3, ld, Mp, Mp, 0.0, st);
+  // W = L^-1 Phi L^-T in M5 (V in M4); Phi is used in place when it needs no padding
+  if (M == Mp) w.M3 = const_cast<double*>(Phi);
+  else pad_copy(Phi, M, M, M, w.M3, ld, Mp, Mp, 0.0, st);
   {
     GemmDesc g;
     g.A = w.M1; g.lda = ld; g.B = w.M3; g.ldb = ld; g.C = w.M4; g.ldc = ld;
@@ -490,18 +545,18 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
     h.m = Mp; h.n = Mp; h.k = Mp; h.khi_mask = 2;
     gemm(h, st);
   }
-  diag_sum_kernel<<<1, 256, 0, st>>>(w.M5, Mp, 0, 1.0, w.sc + SC_TRW);
 
   // u = L^-1 b
-  pad_copy(b, 1, M, 1, w.bp, 1, Mp, 1, 0.0, st);
   gemv(w.M1, ld, Mp, false, w.bp, w.u, st);
 
   // B = I + W/s2 in M6 -> LB ; q = LB^-1 u rides along with the factorization; LB^-1 (M7) only when G is wanted
-  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6);
-  potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flags, st, w.u, w.q);
-  diag_sum_kernel<<<1, 256, 0, st>>>(w.M6, Mp, 1, 2.0, w.sc + SC_LOGDET);
-  if (need_G) tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
-  dot_kernel<<<1, 256, 0, st>>>(w.q, w.q, Mp, w.sc + SC_QQ);
+  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW);
+  potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flagsB, st, w.u, w.q, /*caller_managed=*/true);
+  const int* abort_flag = potrf_abort_flag(w.flagsB, Mp);
+  if (need_G) {
+    post_potrf_kernel<<<1, 256, 0, st>>>(w.M6, w.q, Mp, abort_flag, info, w.sc);
+    tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
+  }
 
   if (need_G) {
     // G = LB^-1 L^-1 in M4 (both lower triangular)
@@ -544,7 +599,8 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
     dot_kernel<<<1, 256, 0, st>>>(w.t1, w.alpha, Mp, w.sc + SC_APA);
     adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(w.M0, w.M2, w.M8, w.alpha, Mp, M, s2, Phibar, Kuubar, bbar);
   }
-  finalize_bound_kernel<<<1, 64, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, out);
+  finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, need_G ? nullptr : w.M6, w.q, Mp,
+                                           abort_flag, info, out);
   return check_launch();
 }
 

@@ -121,11 +121,24 @@ class HipEngine:
         return K
 
     # ------------------------------------------------------------------ tail
-    def kuu_factor(self, Kuu):
+    def result_buffer(self, extra: int = 0):
+        """One allocation for everything the host reads back after an evaluation: (buf, out, info) with
+        buf = [out (OUT_LEN doubles) | status word (int32, in the low half of one double) | extra doubles], so a single
+        device-to-host copy of ``buf`` -- and no cast / concatenate launches -- ends the evaluation."""
+        buf = self.empty(OUT_LEN + 1 + extra)
+        return buf, buf[:OUT_LEN], buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[:1]
+
+    @staticmethod
+    def read_result(host_buf):
+        """(out, info) from a host copy of a ``result_buffer``."""
+        return host_buf[:OUT_LEN], int(host_buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[0])
+
+    def kuu_factor(self, Kuu, info: Optional[torch.Tensor] = None):
         """Padded L^-1 of chol(Kuu) and its info flag; independent of the streamed statistics (side-stream work)."""
         M = Kuu.shape[0]
         Linv = self.empty(self.lib.sgp_kuu_factor_len(M))
-        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if info is None:
+            info = torch.empty(1, dtype=torch.int32, device=self.device)  # cleared by the call itself
         ws = self._workspace("kuu_factor", self.lib.sgp_kuu_factor_workspace_bytes(M))
         st = self.lib.sgp_kuu_factor(self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_kuu_factor", st)
@@ -167,17 +180,23 @@ class HipEngine:
         self._graphs[M] = ent
         return ent
 
-    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None):
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None, kuu_info=None, result=None):
         """Runs the O(M^3) tail on (already all-reduced) packed statistics.
 
-        Returns dict(out=[8] device tensor, info=int32 device tensor, and when asked Phibar, bbar,
-        Kuubar, factors).  Nothing is synchronised.
+        Returns dict(out=[8] device tensor, info=int32 device tensor, buf=the ``result_buffer`` both live in, and
+        when asked Phibar, bbar, Kuubar, factors).  Nothing is synchronised.  With ``kuu_linv`` (from ``kuu_factor``)
+        the status word must already hold that call's status: pass ``result`` whose info word ``kuu_factor`` wrote,
+        or ``kuu_info`` (copied in with one tiny launch).
         """
         M = Kuu.shape[0]
         self._chk(Kuu, "Kuu"), self._chk(packed, "packed")
-        out = self.empty(OUT_LEN)
-        info = torch.zeros(1, dtype=torch.int32, device=self.device)
-        res = {"out": out, "info": info}
+        buf, out, info = result if result is not None else self.result_buffer()
+        if kuu_linv is not None:
+            if kuu_info is not None:
+                info.copy_(kuu_info)
+            elif result is None:
+                raise ValueError("bound(kuu_linv=...) needs the status of kuu_factor: kuu_info= or result=")
+        res = {"out": out, "info": info, "buf": buf}
         Phibar = bbar = Kuubar = factors = None
         if with_adjoints:
             Phibar, bbar, Kuubar = self.empty(M, M), self.empty(M), self.empty(M, M)

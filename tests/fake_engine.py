@@ -27,6 +27,14 @@ class OracleEngine:
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float64)
 
+    def result_buffer(self, extra=0):
+        buf = torch.zeros(OUT_LEN + 1 + extra, dtype=torch.float64)
+        return buf, buf[:OUT_LEN], buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[:1]
+
+    @staticmethod
+    def read_result(host_buf):
+        return host_buf[:OUT_LEN], int(host_buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[0])
+
     def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out=None, kfu=None):
         self.calls["suffstats"] += 1
         M, d = Z.shape
@@ -43,14 +51,15 @@ class OracleEngine:
     def kuu(self, Z, ls, sf2, jitter, kernel="rbf"):
         return O.kuu(Z, self._ls(ls, Z.shape[1]), float(sf2), float(jitter), KID[kernel])
 
-    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False):
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, result=None):
         self.calls["bound"] += 1
         M = Kuu.shape[0]
         st = O.SuffStats(packed[: M * M].reshape(M, M), packed[M * M: M * M + M], float(packed[M * M + M]),
                          float(packed[M * M + M + 1]), int(N))
-        out = torch.zeros(OUT_LEN, dtype=torch.float64)
-        info = torch.zeros(1, dtype=torch.int32)
-        res = {"out": out, "info": info}
+        buf, out, info = result if result is not None else self.result_buffer()
+        out.zero_()
+        info.zero_()
+        res = {"out": out, "info": info, "buf": buf}
         try:
             r = O.bound_from_stats(Kuu, st, float(s2), with_adjoints=with_adjoints)
         except Exception:  # torch.linalg.cholesky failure -> LAPACK-style info like the HIP path
