@@ -781,21 +781,34 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
   s = wave_sum(s);
   if (lane == 0) y[row] = s;
 }
-__global__ __launch_bounds__(256) void gemv_cols_kernel(const double* __restrict__ A, int64_t ld, int Mp,
-                                                        const double* __restrict__ x, double* __restrict__ y) {
-  // y[i] = sum_j A[j][i] x[j]; a block owns 64 columns, its 4 waves split the rows
-  __shared__ double part[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+__global__ __launch_bounds__(1024) void gemv_cols_kernel(const double* __restrict__ A, int64_t ld, int Mp,
+                                                         const double* __restrict__ x, double* __restrict__ y) {
+  // y[i] = sum_j A[j][i] x[j]; a block owns 64 columns, its 16 waves split the rows (4 waves took 80 us at
+  // Mp = 1024: 256 dependent steps per wave on 16 CUs); partial sums are added in wave order
+  __shared__ double part[16][64];
+  const int lane = threadIdx.x & 63, col = blockIdx.x * 64 + lane;
   const int w = threadIdx.x >> 6;
-  double s = 0.0;
-  for (int j = w; j < Mp; j += 4) s = fma(A[(int64_t)j * ld + col], x[j], s);
-  part[w][threadIdx.x & 63] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int j = w;
+  for (; j + 48 < Mp; j += 64) {
+    s0 = fma(A[(int64_t)j * ld + col], x[j], s0);
+    s1 = fma(A[(int64_t)(j + 16) * ld + col], x[j + 16], s1);
+    s2 = fma(A[(int64_t)(j + 32) * ld + col], x[j + 32], s2);
+    s3 = fma(A[(int64_t)(j + 48) * ld + col], x[j + 48], s3);
+  }
+  for (; j < Mp; j += 16) s0 = fma(A[(int64_t)j * ld + col], x[j], s0);
+  part[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (w == 0) y[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (w == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][lane];
+    y[col] = t;
+  }
 }
 void gemv(const double* A, int64_t ld, int Mp, bool trans, const double* x, double* y, hipStream_t st) {
   if (!trans) gemv_rows_kernel<<<Mp / 4, 256, 0, st>>>(A, ld, Mp, x, y);
-  else gemv_cols_kernel<<<Mp / 64, 256, 0, st>>>(A, ld, Mp, x, y);
+  else gemv_cols_kernel<<<Mp / 64, 1024, 0, st>>>(A, ld, Mp, x, y);
 }
 
 __global__ void pad_copy_kernel(const double* __restrict__ src, int64_t lds, int rs, int cs, double* __restrict__ dst,

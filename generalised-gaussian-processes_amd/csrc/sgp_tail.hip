@@ -471,7 +471,7 @@ extern "C" size_t sgp_bound_factors_len(int M) { return M > 0 ? (size_t)2 * M * 
 extern "C" size_t sgp_kuu_factor_len(int M) {
   if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
   const size_t Mp = padded_m(M);
-  return Mp * Mp;
+  return 2 * Mp * Mp;  // [ L^-1 | Kuu^-1 = L^-T L^-1 ], both padded
 }
 extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
   if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
@@ -499,6 +499,12 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
+  {  // Kuu^-1 (only the adjoints read it) depends on (Z, theta) alone as well: off the critical path with the rest
+    GemmDesc k;
+    k.A = Linv_out; k.lda = Mp; k.ta = true; k.B = Linv_out; k.ldb = Mp; k.C = Linv_out + (size_t)Mp * Mp; k.ldc = Mp;
+    k.m = Mp; k.n = Mp; k.k = Mp; k.klo_mask = 3;
+    gemm(k, st);
+  }
   return check_launch();
 }
 
@@ -578,10 +584,14 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
     s.A = w.M4; s.lda = ld; s.ta = true; s.B = w.M4; s.ldb = ld; s.C = w.M2; s.ldc = ld;
     s.m = Mp; s.n = Mp; s.k = Mp; s.klo_mask = 3;
     gemm(s, st);
-    GemmDesc k;
-    k.A = w.M1; k.lda = ld; k.ta = true; k.B = w.M1; k.ldb = ld; k.C = w.M0; k.ldc = ld;
-    k.m = Mp; k.n = Mp; k.k = Mp; k.klo_mask = 3;
-    gemm(k, st);
+    if (kuu_linv) {
+      w.M0 = const_cast<double*>(kuu_linv) + mm;  // computed by sgp_kuu_factor
+    } else {
+      GemmDesc k;
+      k.A = w.M1; k.lda = ld; k.ta = true; k.B = w.M1; k.ldb = ld; k.C = w.M0; k.ldc = ld;
+      k.m = Mp; k.n = Mp; k.k = Mp; k.klo_mask = 3;
+      gemm(k, st);
+    }
     // KPK = Kinv Phi Kinv = L^-T W L^-1 : T1 = W L^-1 in M6, KPK = L^-T T1 in M8
     GemmDesc t1;
     t1.A = w.M5; t1.lda = ld; t1.B = w.M1; t1.ldb = ld; t1.C = w.M6; t1.ldc = ld;

@@ -147,7 +147,7 @@ int sgp_logdiag_sum(const double* L, int64_t ldl, int M, double* out, sgp_stream
 size_t sgp_bound_workspace_bytes(int M, int with_adjoints);
 size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
 /* Optional split of the tail: chol(Kuu) and its inverse depend on (Z, theta) only, not on the streamed
- * statistics.  sgp_kuu_factor writes the padded L^-1 (sgp_kuu_factor_len(M) doubles) and its own `info`
+ * statistics.  sgp_kuu_factor writes the padded L^-1 and Kuu^-1 (sgp_kuu_factor_len(M) doubles, opaque) and its own `info`
  * (1..M); issued on a second stream it runs underneath pass 1.  Passing the result as `kuu_linv` makes
  * sgp_bound_from_stats skip that part (Kuu may then be NULL).  In that case `info` is NOT cleared on entry:
  * pass the word sgp_kuu_factor wrote (the first failure stays; chol(B) reports M+1..2M only into a word
