@@ -342,43 +342,94 @@ __device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[
 // Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k]:  the wave that
 // owns a 16-column panel factors it in registers, publishes it to LDS (Sp, zero above the diagonal) and the waves to
 // its right apply the rank-16 update; 4 barriers per block.  On return a[] holds L (garbage above the diagonal).
-// The pivot chain IS the critical path of the factorization, so inside a panel
-//   * the next pivot  d' = A[j+1][j+1] - L[j+1][j]^2  is formed by lane j+1 from its own registers and fetched with one
-//     v_readlane before the column update, so the rsqrt chain of pivot j+1 starts while column j is still being applied;
-//   * the column l = L[:, j] is broadcast through LDS (one ds_write_b64 + uniform ds_read_b128s) instead of 15
-//     v_readlane pairs whose SGPR results stall the dependent v_fma_f64.
-__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double (*Lcol)[DB], int* bad, int i,
+// The pivot chain is the critical path of the factorization.  Inside a panel the columns are formed left-looking:
+//     t  = L[j][j-1]                     one v_readlane pair from lane j (the column finished a moment ago)
+//     d  = p_j - t^2 ;  rs = 1/sqrt(d)   p_j = A[j][j] - sum_{k<jj-1} L[j][k]^2, fetched by a readlane
+//     l  = (p_i - l_prev t) rs           every lane: its entry of column j
+// and p for the NEXT pivot -- this lane's finished entries dotted with row j + 1 of the panel (LDS at a wave-uniform
+// address for the entries stored two or more pivots ago, one more readlane for the newest) -- has no dependence on
+// the current rsqrt.  Measured with wall-clock stamps (M = 1024, 26 us per block step): a 16-pivot panel takes
+// 1.6-2.4 us = 250-350 cycles per pivot although the dependent chain is ~90: the lone wave is ISSUE-bound (~45
+// instructions per pivot at 5-7 cycles each; a wave-uniform ds_read_b128 alone costs it ~17 cycles), and the
+// rank-16 update of the next panel (256 FMAs + 136 uniform reads) another 1.2 us.  Forcing chain-first order with
+// sched_barriers or a right-looking panel (column broadcast through LDS) gave the same time within 4 %.
+__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double (*Dinv)[16][17], int* bad, int i,
                                                    int g) {
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
+    double rsv[16];  // 1 / L[j][j] of this panel's pivots (wave-uniform; only wave pb's copy is used)
     if (g == pb) {
-      double d = readlane_f64(a[0], 16 * pb);
+      const int base = 16 * pb;
+      double p = a[0], lprev = 0.0;
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * pb + jj;
+        const int j = base + jj;
+        // p for pivot jj + 1 without its k = jj term: independent of this pivot's chain (row j + 1 of the panel was
+        // completed up to column jj - 1 by the previous iterations' stores, same wave: LDS keeps program order)
+        double pnext = 0.0;
+        if (jj < 15) {
+          double s0 = a[jj + 1], s1 = 0.0;
+          const double* row = &Sp[pb][j + 1][0];
+          const int nl = jj > 0 ? jj - 1 : 0;  // k < jj - 1 from LDS (stored at least two pivots ago) ...
+#pragma unroll
+          for (int k = 0; k + 1 < nl; k += 2) {
+            const d2 r2 = *reinterpret_cast<const d2*>(row + k);
+            s0 = fma(-a[k], r2[0], s0);
+            s1 = fma(-a[k + 1], r2[1], s1);
+          }
+          if (nl & 1) s0 = fma(-a[nl - 1], row[nl - 1], s0);
+          if (jj > 0) s1 = fma(-a[jj - 1], readlane_f64(lprev, j + 1), s1);  // ... k = jj - 1 straight from lane j + 1
+          pnext = s0 + s1;
+        }
+        double d, afull;
+        if (jj == 0) {
+          d = readlane_f64(p, j);
+          afull = p;
+        } else {
+          const double t = readlane_f64(lprev, j);
+          const double pj = readlane_f64(p, j);
+          d = fma(-t, t, pj);
+          afull = fma(-lprev, t, p);
+        }
         if (!(d > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
           if (i == 0 && *bad == 0) *bad = j + 1;
           d = 1.0;
         }
-        const double rs = rsqrt_newton(d);
-        const double l = a[jj] * rs;  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
+        rsv[jj] = rsqrt_newton(d);
+        const double l = afull * rsv[jj];  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
         a[jj] = l;
-        if (jj < 15) {
-          d = readlane_f64(fma(-l, l, a[jj + 1]), j + 1);  // next pivot, ahead of the column update
-          double* col = Lcol[jj & 1];
-          col[i] = l;
-#pragma unroll
-          for (int q = jj + 1; q < 16; ++q) a[q] = fma(-l, col[16 * pb + q], a[q]);  // uniform address: broadcast
-        }
+        Sp[pb][i][jj] = (i >= j) ? l : 0.0;
+        lprev = l;
+        p = pnext;
       }
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) Sp[pb][i][jj] = (i >= 16 * pb + jj) ? a[jj] : 0.0;
     }
     __syncthreads();
     if (g > pb) {  // rank-16 update of this wave's 16 columns p = 16 g + k:  a[i][p] -= sum_j L[i][j] L[p][j]
       double li[16];
       lds_row16(li, &Sp[pb][i][0]);
       rows16_apply(a, li, &Sp[pb][16 * g][0], PLD);  // wave-uniform rows: broadcast reads
+    } else if (g == pb) {
+      // Inverse of the 16 x 16 diagonal block just factored (what the triangular solves of the tiles below this one
+      // start from), by the wave that would otherwise idle until the block is finished: lane c < 16 <-> column c,
+      // forward substitution with the reciprocal pivots kept from the chain.
+      if (i < 16) {
+        double y[16], lrow[16], lnext[16];
+        lds_row16(lrow, &Sp[pb][16 * pb][0]);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          if (rr < 15) lds_row16(lnext, &Sp[pb][16 * pb + rr + 1][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          double sacc = (rr == i) ? 1.0 : 0.0;
+#pragma unroll
+          for (int q = 0; q < rr; ++q) sacc = fma(-lrow[q], y[q], sacc);
+          y[rr] = sacc * rsv[rr];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) lrow[q] = lnext[q];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) Dinv[pb][rr][i] = y[rr];
+      }
     }
   }
   __syncthreads();
@@ -413,8 +464,6 @@ struct DfShared {
   };
   double Ts[DB][TLD];
   double Dinv[4][16][17];  // inverses of the four 16 x 16 diagonal blocks of L(j,j) (odd stride: MFMA operand reads)
-  double Lcol[2][DB];
-  double rd[DB];
   int bad;
   int dead;
 };
@@ -542,7 +591,28 @@ __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb
   }
 }
 
-__global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t ld, int nb, int* ready, int* info,
+// acc += X X^T for the 64 x 64 tile X held in LDS as Xs[row][col] (the sub-diagonal tile its owner has just solved):
+// the last rank-64 update of the next diagonal tile without a round trip through global memory.
+__device__ __forceinline__ void df_mac_lds(const double (*Xs)[TLD], d4 (&acc)[2][2], int wi, int wj, int l15, int l4) {
+#pragma unroll
+  for (int ks = 0; ks < DB / 4; ++ks) {
+    const int k = 4 * ks + l4;
+    const double a0 = Xs[wi * 32 + l15][k], a1 = Xs[wi * 32 + 16 + l15][k];
+    const double b0 = Xs[wj * 32 + l15][k], b1 = Xs[wj * 32 + 16 + l15][k];
+    acc[0][0] = mfma16(a0, b0, acc[0][0]);
+    acc[0][1] = mfma16(a0, b1, acc[0][1]);
+    acc[1][0] = mfma16(a1, b0, acc[1][0]);
+    acc[1][1] = mfma16(a1, b1, acc[1][1]);
+  }
+}
+
+// Work items = tiles in column-major order, with one fusion on the critical path: the item of the sub-diagonal tile
+// (j+1, j) also owns the diagonal tile (j+1, j+1) (whose own item is skipped).  That workgroup solves
+// X = T L(j,j)^-T, publishes X and -- still holding X in LDS -- applies X X^T to the diagonal tile it has already
+// updated with every earlier column, factors it and publishes it: the hand-over (publish, poll, reload from L2) between
+// the two critical tiles of a step is gone.  dinv_g: nb x 4 x 16 x 16 doubles of scratch, the inverses of the 16 x 16
+// diagonal blocks of every L(j,j), written by the diagonal tile's owner before it raises the tile's flag.
+__global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t ld, int nb, int* ready, double* dinv_g, int* info,
                                                               int info_base, const double* rhs, double* sol, double* Linv) {
   __shared__ DfShared sh;
   const int tid = threadIdx.x, r = tid & 63;
@@ -554,140 +624,50 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
   if (tid == 0) sh.dead = 0;
   __syncthreads();
   const int nitem = ntile + (rhs ? 1 : 0);
-  int j = 0, start = 0;  // column of the current tile and number of the first tile of that column
-  for (int t = blockIdx.x; t < nitem; t += gridDim.x) {
-    if (t == ntile) {  // the last work item: sol = L^-1 rhs, 64 entries at a time, trailing the factorization
-      df_solve_rhs(A, ld, nb, ready, abort_flag, rhs, sol, sh);
-      break;
-    }
-    while (t >= start + (nb - j)) { start += nb - j; ++j; }
-    const int i = j + (t - start);
-    double* Aij = A + (int64_t)i * DB * ld + (int64_t)j * DB;
-    auto tile_no = [&](int ti, int tj) { return tj * nb - (tj * (tj - 1)) / 2 + (ti - tj); };
-
-    if (i != j) {  // the mirrored tile is the strictly-upper part of the result: zero
-      double* U = A + (int64_t)j * DB * ld + (int64_t)i * DB;
-      for (int e = tid; e < DB * DB / 2; e += 256) {
-        const int rr = e >> 5, cc = (e & 31) * 2;
-        *reinterpret_cast<d2*>(U + (int64_t)rr * ld + cc) = d2{0.0, 0.0};
-      }
-    }
-
-    d4 acc[2][2];
+  auto tile_no = [&](int ti, int tj) { return tj * nb - (tj * (tj - 1)) / 2 + (ti - tj); };
+  auto zero_acc = [&](d4 (&acc)[2][2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int p = 0; p < j; ++p) {
-      if (!df_wait(ready + tile_no(i, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
-      if (i != j && !df_wait(ready + tile_no(j, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
-      df_mac(A + (int64_t)i * DB * ld + (int64_t)p * DB, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, sh, acc);
-    }
-    // acc (MFMA layout) -> LDS, then every thread picks up  T[r][16 g ..] = A(i,j) - acc  in the row layout
+  };
+  // acc (MFMA layout) -> sh.Ts[row][col]
+  auto acc_to_ts = [&](const d4 (&acc)[2][2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int v = 0; v < 2; ++v)
 #pragma unroll
         for (int q = 0; q < 4; ++q) sh.Ts[wi * 32 + u * 16 + l4 + 4 * q][wj * 32 + v * 16 + l15] = acc[u][v][q];
-    if (tid == 0) sh.bad = 0;
-    __syncthreads();
-
-    double x[16];  // diagonal tiles: row r, columns 16 g .. of the factor (kept for the block inverse below)
-    if (i == j) {
-      const double* src = Aij + (int64_t)r * ld + 16 * g;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
-        x[2 * k] = v[0] - sh.Ts[r][16 * g + 2 * k];
-        x[2 * k + 1] = v[1] - sh.Ts[r][16 * g + 2 * k + 1];
-      }
-      __syncthreads();  // the mac buffers become Sp
-      diag_factor64_fast(x, sh.Sp, sh.Lcol, &sh.bad, r, g);
-      double* dst = Aij + (int64_t)r * ld + 16 * g;
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        *reinterpret_cast<d2*>(dst + 2 * k) = d2{(16 * g + 2 * k <= r) ? x[2 * k] : 0.0, (16 * g + 2 * k + 1 <= r) ? x[2 * k + 1] : 0.0};
-      if (tid == 0 && sh.bad != 0 && *info == 0) *info = info_base + j * DB + sh.bad;
-    } else {
-      // X = T L(j,j)^-T on the matrix cores, one wave per 16 rows of T and no barrier between the panels.
-      // Y = T[rows]^T is kept as four 16 x 16 blocks in the MFMA accumulator layout (component s of block pb, lane l:
-      // T[16 g + (l & 15)][16 pb + 4 s + (l >> 4)]), which is exactly the B operand of k-step s, so
-      //     X_pb^T = Dinv_pb Y_pb                  (Dinv_pb: inverse of the 16 x 16 diagonal block pb of L(j,j))
-      //     Y_q   -= L[q][pb] X_pb^T   for q > pb
-      // chain from block to block in registers; only the A operands (Dinv, L) come from LDS.
-      d4 yb[4];
-      {
-        const double* src = Aij + (int64_t)(16 * g + l15) * ld + l4;
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-          for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = src[16 * pb + 4 * sq] - sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4];
-      }
-      if (!df_wait(ready + tile_no(j, j) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
-      {  // L(j,j) -> Sp panels, rd = 1 / diag
-        const double* src = A + (int64_t)j * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const d2 t2 = *reinterpret_cast<const d2*>(src + 2 * k);
-          v[2 * k] = t2[0];
-          v[2 * k + 1] = t2[1];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          sh.Sp[g][r][k] = v[k];
-          if (16 * g + k == r) sh.rd[r] = 1.0 / v[k];
-        }
-      }
-      __syncthreads();
-      if (tid < 64) {  // Dinv[blk] = inverse of the 16 x 16 diagonal block blk: thread <-> one column, forward substitution
-        const int blk = tid >> 4, c = tid & 15;
-        double y[16], lrow[16], lnext[16];
-        lds_row16(lrow, &sh.Sp[blk][16 * blk][0]);
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          if (rr < 15) lds_row16(lnext, &sh.Sp[blk][16 * blk + rr + 1][0]);
-          __builtin_amdgcn_sched_barrier(0);
-          double sacc = (rr == c) ? 1.0 : 0.0;
-#pragma unroll
-          for (int q = 0; q < rr; ++q) sacc = fma(-lrow[q], y[q], sacc);
-          y[rr] = sacc * sh.rd[16 * blk + rr];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 16; ++q) lrow[q] = lnext[q];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) sh.Dinv[blk][rr][c] = y[rr];
-      }
-      __syncthreads();
-      d4 xb[4];
-#pragma unroll
-      for (int pb = 0; pb < 4; ++pb) {
-        d4 xa = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int sq = 0; sq < 4; ++sq) xa = mfma16(sh.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
-        xb[pb] = xa;
-#pragma unroll
-        for (int q = pb + 1; q < 4; ++q)
-#pragma unroll
-          for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-sh.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
-      }
-      {
-        double* dst = Aij + (int64_t)(16 * g + l15) * ld + l4;
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-          for (int sq = 0; sq < 4; ++sq) dst[16 * pb + 4 * sq] = xb[pb][sq];
-      }
-    }
-    // publish: stores written back (release) -> barrier -> flag
+  };
+  // publish tile number tn: stores written back (release) -> barrier -> flag
+  auto publish = [&](int tn) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ready + t * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i == j && Linv) {
-      // off the critical path (the tile is already published): inverse of this diagonal block -> Linv, level 0 of
-      // tri_inverse().  The T tile holds S, the panel / operand region holds the inverse.
+    if (tid == 0) __hip_atomic_store(ready + tn * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // Diagonal tile jd: x[] = T (row r, columns 16 g ..) -> factor, store, report, 16 x 16 block inverses -> dinv_g,
+  // publish, then (off the critical path) the 64 x 64 block inverse -> Linv.  sh.Ts / sh.Sp are free on entry.
+  auto diag_finish = [&](int jd, double (&x)[16]) {
+    double* Ajj = A + (int64_t)jd * DB * (ld + 1);
+    diag_factor64_fast(x, sh.Sp, sh.Dinv, &sh.bad, r, g);
+    double* dst = Ajj + (int64_t)r * ld + 16 * g;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      *reinterpret_cast<d2*>(dst + 2 * k) = d2{(16 * g + 2 * k <= r) ? x[2 * k] : 0.0, (16 * g + 2 * k + 1 <= r) ? x[2 * k + 1] : 0.0};
+    {
+      double* dg = dinv_g + (size_t)jd * 1024;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = tid + 256 * e;  // (blk, row, col) = (idx >> 8, (idx >> 4) & 15, idx & 15)
+        dg[idx] = sh.Dinv[idx >> 8][(idx >> 4) & 15][idx & 15];
+      }
+    }
+    if (tid == 0 && sh.bad != 0 && *info == 0) *info = info_base + jd * DB + sh.bad;
+    publish(tile_no(jd, jd));
+    if (Linv) {
+      // inverse of this diagonal block -> Linv, level 0 of tri_inverse().  The T tile holds S, the panel / operand
+      // region holds the inverse.
       static_assert(sizeof(sh.Ts) >= sizeof(double) * DB * DLD && sizeof(sh.Sp) >= sizeof(double) * DB * DLD, "LDS reuse");
       double (*S)[DLD] = reinterpret_cast<double (*)[DLD]>(&sh.Ts[0][0]);
       double (*Inv)[DLD] = reinterpret_cast<double (*)[DLD]>(&sh.Sp[0][0][0]);
@@ -698,10 +678,145 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
       }
       __syncthreads();
       block_inverse64(S, Inv);
-      double* dst = Linv + ((int64_t)j * DB + r) * ld + (int64_t)j * DB + 16 * g;
+      double* ldst = Linv + ((int64_t)jd * DB + r) * ld + (int64_t)jd * DB + 16 * g;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(dst + 2 * k) = d2{Inv[r][16 * g + 2 * k], Inv[r][16 * g + 2 * k + 1]};
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(ldst + 2 * k) = d2{Inv[r][16 * g + 2 * k], Inv[r][16 * g + 2 * k + 1]};
       __syncthreads();
+    }
+  };
+
+  int j = 0, start = 0;  // column of the current tile and number of the first tile of that column
+  for (int t = blockIdx.x; t < nitem; t += gridDim.x) {
+    if (t == ntile) {  // the last work item: sol = L^-1 rhs, 64 entries at a time, trailing the factorization
+      df_solve_rhs(A, ld, nb, ready, abort_flag, rhs, sol, sh);
+      break;
+    }
+    while (t >= start + (nb - j)) { start += nb - j; ++j; }
+    const int i = j + (t - start);
+    if (i == j && j > 0) continue;  // done by the owner of tile (j, j - 1)
+    double* Aij = A + (int64_t)i * DB * ld + (int64_t)j * DB;
+
+    if (i == j) {  // tile (0, 0): nothing to wait for
+      double x[16];
+      const double* src = Aij + (int64_t)r * ld + 16 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
+        x[2 * k] = v[0];
+        x[2 * k + 1] = v[1];
+      }
+      if (tid == 0) sh.bad = 0;
+      __syncthreads();
+      diag_finish(0, x);
+      continue;
+    }
+
+    {  // the mirrored tile is the strictly-upper part of the result: zero
+      double* U = A + (int64_t)j * DB * ld + (int64_t)i * DB;
+      for (int e = tid; e < DB * DB / 2; e += 256) {
+        const int rr = e >> 5, cc = (e & 31) * 2;
+        *reinterpret_cast<d2*>(U + (int64_t)rr * ld + cc) = d2{0.0, 0.0};
+      }
+    }
+    const bool head = (i == j + 1);  // this item continues with the diagonal tile (i, i)
+
+    d4 acc[2][2], accd[2][2];
+    zero_acc(acc);
+    zero_acc(accd);
+    for (int p = 0; p < j; ++p) {
+      if (!df_wait(ready + tile_no(i, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      if (!df_wait(ready + tile_no(j, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      const double* Lip = A + (int64_t)i * DB * ld + (int64_t)p * DB;
+      df_mac(Lip, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, sh, acc);
+      if (head) df_mac(Lip, Lip, ld, sh, accd);  // the diagonal tile's updates by the columns before j
+    }
+    acc_to_ts(acc);
+    if (tid == 0) sh.bad = 0;
+    __syncthreads();
+
+    // X = T L(j,j)^-T on the matrix cores, one wave per 16 rows of T and no barrier between the panels.
+    // Y = T[rows]^T is kept as four 16 x 16 blocks in the MFMA accumulator layout (component s of block pb, lane l:
+    // T[16 g + (l & 15)][16 pb + 4 s + (l >> 4)]), which is exactly the B operand of k-step s, so
+    //     X_pb^T = Dinv_pb Y_pb                  (Dinv_pb: inverse of the 16 x 16 diagonal block pb of L(j,j))
+    //     Y_q   -= L[q][pb] X_pb^T   for q > pb
+    // chain from block to block in registers; only the A operands (Dinv, L) come from LDS.
+    d4 yb[4];
+    {
+      const double* src = Aij + (int64_t)(16 * g + l15) * ld + l4;
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = src[16 * pb + 4 * sq] - sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4];
+    }
+    double xd[16];  // head: row r, columns 16 g .. of A(i,i), fetched before the wait
+    if (head) {
+      const double* src = A + (int64_t)i * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
+        xd[2 * k] = v[0];
+        xd[2 * k + 1] = v[1];
+      }
+    }
+    if (!df_wait(ready + tile_no(j, j) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+    {  // L(j,j) -> Sp panels, block inverses -> Dinv
+      const double* src = A + (int64_t)j * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
+      const double* dg = dinv_g + (size_t)j * 1024;
+      double v[16], dv[4];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const d2 t2 = *reinterpret_cast<const d2*>(src + 2 * k);
+        v[2 * k] = t2[0];
+        v[2 * k + 1] = t2[1];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dv[e] = dg[tid + 256 * e];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sh.Sp[g][r][k] = v[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = tid + 256 * e;
+        sh.Dinv[idx >> 8][(idx >> 4) & 15][idx & 15] = dv[e];
+      }
+    }
+    __syncthreads();
+    d4 xb[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      d4 xa = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) xa = mfma16(sh.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
+      xb[pb] = xa;
+#pragma unroll
+      for (int q = pb + 1; q < 4; ++q)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-sh.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
+    }
+    {
+      double* dst = Aij + (int64_t)(16 * g + l15) * ld + l4;
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+          dst[16 * pb + 4 * sq] = xb[pb][sq];
+          if (head) sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4] = xb[pb][sq];  // X stays on chip for the update below
+        }
+    }
+    if (!head) {
+      publish(t);
+    } else {
+      // X is published only after the update below: its stores drain while the MFMAs run (raising the flag first
+      // meant waiting 1.2-1.9 us for the write-back on the critical path; the other tiles of column i need X much later)
+      __syncthreads();
+      df_mac_lds(sh.Ts, accd, wi, wj, l15, l4);
+      publish(t);  // (barrier: everybody is done reading X)
+      acc_to_ts(accd);
+      if (tid == 0) sh.bad = 0;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) xd[k] -= sh.Ts[r][16 * g + k];
+      __syncthreads();  // Ts / the operand region become scratch of the factorization
+      diag_finish(i, xd);
     }
   }
 }
@@ -720,9 +835,13 @@ __global__ void potrf_timeout_kernel(const int* abort_flag, int* info) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && *abort_flag != 0) *info = POTRF_TIMEOUT;
 }
 
-size_t potrf_scratch_ints(int Mp) {
+size_t potrf_flag_ints(int Mp) {
   const size_t nb = Mp / DB;
   return (nb * (nb + 1) / 2 + 1) * DF_FLAG_STRIDE;  // one cache line per tile flag + the abort flag
+}
+size_t potrf_scratch_ints(int Mp) {
+  const size_t nb = Mp / DB;
+  return potrf_flag_ints(Mp) + nb * 1024 * 2;  // + the 16 x 16 block inverses of every diagonal tile (doubles)
 }
 
 const int* potrf_abort_flag(const int* scratch, int Mp) {
@@ -735,10 +854,11 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   const int nb = Mp / DB;
   const int ntile = nb * (nb + 1) / 2;
   const int nitem = ntile + (rhs ? 1 : 0);
-  if (!caller_managed) zero_ints(scratch, (int)potrf_scratch_ints(Mp), st);
+  if (!caller_managed) zero_ints(scratch, (int)potrf_flag_ints(Mp), st);
   if (Linv) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
-  potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
+  potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(
+      A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv);
   if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
 }
 

@@ -31,6 +31,7 @@ void gemm(const GemmDesc& g, hipStream_t st);
 // ints (tile-ready flags of the single-launch dataflow factorization; cleared here, reusable right after on the
 // same stream).  info = -7777 reports a dataflow time-out (never expected; instead of a hang).
 size_t potrf_scratch_ints(int Mp);
+size_t potrf_flag_ints(int Mp);  // the leading part of the scratch that must be zero when the launch starts
 // rhs / sol (optional, Mp doubles each): sol = L^-1 rhs, computed inside the same launch.  Linv may be null when
 // the caller needs neither tri_inverse() nor the block inverses.
 // caller_managed: the caller has already zeroed `scratch` on this stream and reads the abort flag

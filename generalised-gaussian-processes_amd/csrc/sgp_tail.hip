@@ -526,7 +526,7 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
 
   // status word: zeroed here, except when L^-1 comes from sgp_kuu_factor -- then *info already holds that call's
   // status and (like every factorization here) chol(B) only reports into it while it is still 0
-  const int nflags = (int)potrf_scratch_ints(Mp);
+  const int nflags = (int)potrf_flag_ints(Mp);
   tail_prep_kernel<<<(nflags + 255) / 256, 256, 0, st>>>(kuu_linv ? nullptr : info, w.sc, w.flagsB, nflags, b, M, Mp, w.bp);
 
   // L = chol(Kuu) in M0, L^-1 in M1 -- or L^-1 handed over by sgp_kuu_factor (read-only from here on)
