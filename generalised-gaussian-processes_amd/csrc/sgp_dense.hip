@@ -339,27 +339,47 @@ __device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[
   }
 }
 
-// Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k]:  the wave that
-// owns a 16-column panel factors it in registers, publishes it to LDS (Sp, zero above the diagonal) and the waves to
-// its right apply the rank-16 update; 4 barriers per block.  On return a[] holds L (garbage above the diagonal).
-// The pivot chain is the critical path of the factorization.  Inside a panel the columns are formed left-looking:
+// Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k].  Wave pb factors
+// the 16-column panel pb in registers; on return a[] holds L (garbage above the diagonal), Sp the panels and Dinv the
+// inverses of the four 16 x 16 diagonal blocks.  prog[0..3] must be 0 on entry (the caller's barrier covers it).
+//
+// The pivot chain is the critical path.  Inside a panel the columns are formed left-looking:
 //     t  = L[j][j-1]                     one v_readlane pair from lane j (the column finished a moment ago)
 //     d  = p_j - t^2 ;  rs = 1/sqrt(d)   p_j = A[j][j] - sum_{k<jj-1} L[j][k]^2, fetched by a readlane
 //     l  = (p_i - l_prev t) rs           every lane: its entry of column j
 // and p for the NEXT pivot -- this lane's finished entries dotted with row j + 1 of the panel (LDS at a wave-uniform
 // address for the entries stored two or more pivots ago, one more readlane for the newest) -- has no dependence on
-// the current rsqrt.  Measured with wall-clock stamps (M = 1024, 26 us per block step): a 16-pivot panel takes
-// 1.6-2.4 us = 250-350 cycles per pivot although the dependent chain is ~90: the lone wave is ISSUE-bound (~45
-// instructions per pivot at 5-7 cycles each; a wave-uniform ds_read_b128 alone costs it ~17 cycles), and the
-// rank-16 update of the next panel (256 FMAs + 136 uniform reads) another 1.2 us.  Forcing chain-first order with
-// sched_barriers or a right-looking panel (column broadcast through LDS) gave the same time within 4 %.
-__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double (*Dinv)[16][17], int* bad, int i,
-                                                   int g) {
+// the current rsqrt.  Wall-clock stamps: a 16-pivot panel takes 1.6-2.4 us = 250-350 cycles per pivot although the
+// dependent chain is ~90: the lone wave is ISSUE-bound (~45 instructions per pivot at 5-7 cycles each).
+//
+// Between panels there is no barrier and no rank-16 update (that cost the next panel's wave 1.2 us before it could
+// start): the waves to the right of the chain wave follow it column by column.  The chain wave stores every finished
+// column also transposed (Lt[pb][jj][row]) and then bumps prog[pb]; a follower polls prog[pb], reads its own entry of
+// the column and the 16 entries of its panel's rows (one contiguous, wave-uniform segment of Lt) and applies the
+// rank-1 update to its 16 columns.  When the chain wave finishes column 15 the next panel's wave is one rank-1 update
+// away from starting its own chain.  LDS executes one wave's operations in order, so column-then-counter stores and
+// counter-then-column loads need only compiler barriers.  The last panel's block inverse is computed by wave 0
+// (idle by then), row by row behind the chain.
+__device__ __forceinline__ int prog_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Dinv[blk] row rr for column c = lane (lanes < 16), given the finished row 16 blk + rr of the panel in `row`
+__device__ __forceinline__ void dinv_row(double (&y)[16], const double (&row)[16], int rr, int c, double rdiag) {
+  double s0 = (rr == c) ? 1.0 : 0.0, s1 = 0.0;  // two accumulators: half the dependent-FMA latency
+#pragma unroll
+  for (int q = 0; q < 16; q += 2) {
+    if (q < rr) s0 = fma(-row[q], y[q], s0);
+    if (q + 1 < rr) s1 = fma(-row[q + 1], y[q + 1], s1);
+  }
+  y[rr] = (s0 + s1) * rdiag;
+}
+
+__device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)[DB][PLD], double (*Lt)[16][DB], int* prog,
+                                                   double* rdiag3, double (*Dinv)[16][17], int* bad, int i, int g) {
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
-    double rsv[16];  // 1 / L[j][j] of this panel's pivots (wave-uniform; only wave pb's copy is used)
     if (g == pb) {
       const int base = 16 * pb;
+      double rsv[16];  // 1 / L[j][j] of this panel's pivots (wave-uniform)
       double p = a[0], lprev = 0.0;
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
@@ -399,36 +419,70 @@ __device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)
         const double l = afull * rsv[jj];  // L[i][j] (row j itself: d / sqrt(d) = sqrt(d))
         a[jj] = l;
         Sp[pb][i][jj] = (i >= j) ? l : 0.0;
+        Lt[pb][jj][i] = l;
+        if (pb == 3) rdiag3[jj] = rsv[jj];
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&prog[pb], jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lprev = l;
         p = pnext;
       }
-    }
-    __syncthreads();
-    if (g > pb) {  // rank-16 update of this wave's 16 columns p = 16 g + k:  a[i][p] -= sum_j L[i][j] L[p][j]
-      double li[16];
-      lds_row16(li, &Sp[pb][i][0]);
-      rows16_apply(a, li, &Sp[pb][16 * g][0], PLD);  // wave-uniform rows: broadcast reads
-    } else if (g == pb) {
       // Inverse of the 16 x 16 diagonal block just factored (what the triangular solves of the tiles below this one
-      // start from), by the wave that would otherwise idle until the block is finished: lane c < 16 <-> column c,
-      // forward substitution with the reciprocal pivots kept from the chain.
-      if (i < 16) {
+      // start from), while the next panel's wave runs its chain: lane c < 16 <-> column c, forward substitution with
+      // the reciprocal pivots kept from the chain.  (Panel 3: wave 0 does it, see below.)
+      if (pb < 3 && i < 16) {
         double y[16], lrow[16], lnext[16];
         lds_row16(lrow, &Sp[pb][16 * pb][0]);
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
           if (rr < 15) lds_row16(lnext, &Sp[pb][16 * pb + rr + 1][0]);
           __builtin_amdgcn_sched_barrier(0);
-          double sacc = (rr == i) ? 1.0 : 0.0;
-#pragma unroll
-          for (int q = 0; q < rr; ++q) sacc = fma(-lrow[q], y[q], sacc);
-          y[rr] = sacc * rsv[rr];
+          dinv_row(y, lrow, rr, i, rsv[rr]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < 16; ++q) lrow[q] = lnext[q];
         }
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) Dinv[pb][rr][i] = y[rr];
+      }
+    } else if (g > pb) {
+      // follow the chain wave: rank-1 update of this wave's 16 columns c = 16 g + k by every column as it appears:
+      //   a[i][c] -= L[i][j] L[c][j]
+#pragma unroll 1
+      for (int jj = 0; jj < 16; ++jj) {
+        while (prog_load(&prog[pb]) <= jj) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const double own = Lt[pb][jj][i];
+        double lc[16];
+        lds_row16(lc, &Lt[pb][jj][16 * g]);  // wave-uniform segment: broadcast reads
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = fma(-own, lc[k], a[k]);
+      }
+    } else if (pb == 3 && g == 0) {
+      // block inverse of the last panel, one row behind wave 3's chain
+      if (i < 16) {
+        double y[16], lrow[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          // counter and row prefix are read back to back (LDS keeps the order: a row read after a counter value > rr is
+          // complete); only when the chain is not there yet is the pair repeated
+          double rd;
+          for (;;) {
+            const int done = prog_load(&prog[3]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; 2 * e < rr; ++e) {
+              const d2 t2 = *reinterpret_cast<const d2*>(&Sp[3][48 + rr][2 * e]);
+              lrow[2 * e] = t2[0];
+              lrow[2 * e + 1] = t2[1];
+            }
+            rd = rdiag3[rr];
+            asm volatile("" ::: "memory");
+            if (done > rr) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          dinv_row(y, lrow, rr, i, rd);
+          Dinv[3][rr][i] = y[rr];  // stored at once: keeps the arithmetic inside the loop (it was being sunk below it)
+        }
       }
     }
   }
@@ -464,6 +518,9 @@ struct DfShared {
   };
   double Ts[DB][TLD];
   double Dinv[4][16][17];  // inverses of the four 16 x 16 diagonal blocks of L(j,j) (odd stride: MFMA operand reads)
+  double Lt[4][16][DB];    // diagonal tiles: finished columns, transposed, for the waves following the pivot chain
+  int prog[4];             // ... and how many columns of each panel are finished
+  double rdiag3[16];       // reciprocal pivots of the last panel (for wave 0's block inverse behind the chain)
   int bad;
   int dead;
 };
@@ -625,14 +682,14 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
   __syncthreads();
   const int nitem = ntile + (rhs ? 1 : 0);
   auto tile_no = [&](int ti, int tj) { return tj * nb - (tj * (tj - 1)) / 2 + (ti - tj); };
-  auto zero_acc = [&](d4 (&acc)[2][2]) {
+  auto zero_acc = [&](d4 (&acc)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
   };
   // acc (MFMA layout) -> sh.Ts[row][col]
-  auto acc_to_ts = [&](const d4 (&acc)[2][2]) {
+  auto acc_to_ts = [&](const d4 (&acc)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -641,16 +698,16 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         for (int q = 0; q < 4; ++q) sh.Ts[wi * 32 + u * 16 + l4 + 4 * q][wj * 32 + v * 16 + l15] = acc[u][v][q];
   };
   // publish tile number tn: stores written back (release) -> barrier -> flag
-  auto publish = [&](int tn) {
+  auto publish = [&](int tn) __attribute__((always_inline)) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ready + tn * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // Diagonal tile jd: x[] = T (row r, columns 16 g ..) -> factor, store, report, 16 x 16 block inverses -> dinv_g,
   // publish, then (off the critical path) the 64 x 64 block inverse -> Linv.  sh.Ts / sh.Sp are free on entry.
-  auto diag_finish = [&](int jd, double (&x)[16]) {
+  auto diag_finish = [&](int jd, double (&x)[16]) __attribute__((always_inline)) {
     double* Ajj = A + (int64_t)jd * DB * (ld + 1);
-    diag_factor64_fast(x, sh.Sp, sh.Dinv, &sh.bad, r, g);
+    diag_factor64_fast(x, sh.Sp, sh.Lt, sh.prog, sh.rdiag3, sh.Dinv, &sh.bad, r, g);
     double* dst = Ajj + (int64_t)r * ld + 16 * g;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -705,6 +762,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
         x[2 * k] = v[0];
         x[2 * k + 1] = v[1];
       }
+      if (tid < 4) sh.prog[tid] = 0;
       if (tid == 0) sh.bad = 0;
       __syncthreads();
       diag_finish(0, x);
@@ -731,6 +789,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
       if (head) df_mac(Lip, Lip, ld, sh, accd);  // the diagonal tile's updates by the columns before j
     }
     acc_to_ts(acc);
+    if (tid < 4) sh.prog[tid] = 0;
     if (tid == 0) sh.bad = 0;
     __syncthreads();
 
@@ -811,6 +870,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
       df_mac_lds(sh.Ts, accd, wi, wj, l15, l4);
       publish(t);  // (barrier: everybody is done reading X)
       acc_to_ts(accd);
+      if (tid < 4) sh.prog[tid] = 0;
       if (tid == 0) sh.bad = 0;
       __syncthreads();
 #pragma unroll
