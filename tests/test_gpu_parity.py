@@ -54,6 +54,54 @@ def test_chol_trsm_logdiag(engine, M):
     assert abs(ld - torch.log(torch.diagonal(L_ref)).sum().item()) < 1e-10 * max(1, M)
 
 
+@pytest.mark.parametrize("M,pivot", [(256, 0), (256, 15), (256, 16), (256, 63), (256, 64), (256, 130), (1024, 1023), (1152, 700)])
+def test_chol_reports_first_bad_pivot_of_any_tile_and_panel(engine, M, pivot):
+    """LAPACK-style info = index of the first non-positive pivot, whichever work item / wave of the single-launch
+    factorization meets it (tile (0,0), a fused sub-diagonal + diagonal item, any of the four 16-column panels)."""
+    g = torch.Generator().manual_seed(M + pivot)
+    R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
+    A = R @ R.T / M + torch.eye(M, dtype=torch.float64)
+    L_ref = torch.linalg.cholesky(A)
+    # make the Schur complement at `pivot` negative: lower A[p][p] below the sum of squares of row p of the factor
+    A[pivot, pivot] = float((L_ref[pivot, :pivot] ** 2).sum()) - 0.5
+    _, info = engine.chol_lower(A.to(engine.device))
+    assert int(info.item()) == pivot + 1
+
+
+def test_bound_keeps_the_kuu_status_when_the_inverse_is_handed_over(engine):
+    """sgp_bound_from_stats(kuu_linv=...) must not clear the status word sgp_kuu_factor wrote (include/sgp.h): one
+    word, one host read, covers both factorizations; the first failure wins."""
+    M, N, d = 96, 400, 2
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = X[:M].clone()
+    packed = engine.suffstats(X, y, Z, [1.0] * d, 1.0, "rbf")
+    K = engine.kuu(Z, [1.0] * d, 1.0, 1e-6, "rbf")
+    # healthy: result buffer shared by kuu_factor and bound, status 0, same F as the one-call path
+    res = engine.result_buffer()
+    linv, _ = engine.kuu_factor(K, info=res[2])
+    out = engine.bound(K, packed, 0.1, N, kuu_linv=linv, result=res)
+    o, info = engine.read_result(out["buf"].cpu())
+    ref = engine.bound(K, packed, 0.1, N)
+    o_ref, info_ref = engine.read_result(ref["buf"].cpu())
+    assert info == 0 and info_ref == 0 and abs(float(o[0]) - float(o_ref[0])) < 1e-9 * abs(float(o_ref[0]))
+    # broken Kuu: the status of kuu_factor (pivot 41) survives the second factorization
+    Kbad = K.clone()
+    Kbad[40, 40] = -1.0
+    res = engine.result_buffer()
+    linv, _ = engine.kuu_factor(Kbad, info=res[2])
+    out = engine.bound(Kbad, packed, 0.1, N, kuu_linv=linv, result=res)
+    _, info = engine.read_result(out["buf"].cpu())
+    assert info == 41
+    # ... also when it arrives as a separate tensor
+    linv, kinfo = engine.kuu_factor(Kbad)
+    out = engine.bound(Kbad, packed, 0.1, N, kuu_linv=linv, kuu_info=kinfo)
+    assert engine.read_result(out["buf"].cpu())[1] == 41
+    with pytest.raises(ValueError):
+        engine.bound(K, packed, 0.1, N, kuu_linv=linv)
+
+
 def test_chol_reports_non_pd_pivot(engine):
     A = torch.eye(200, dtype=torch.float64)
     A[150, 150] = -1.0
