@@ -492,19 +492,21 @@ __device__ __forceinline__ void diag_factor64_fast(double (&a)[16], double (*Sp)
 
 // ---------------------------------------------------------------------------------------------
 // Whole factorization in ONE launch: tile dataflow.
-//   The lower triangle is cut into 64 x 64 tiles, numbered column by column; workgroup w owns tiles w, w + G, ...
-//   and handles them in that order.  Tile (i, j):
+//   The lower triangle is cut into 64 x 64 tiles, numbered column by column; workgroup w owns items w, w + G, ...
+//   and handles them in that order.  Tile (i, j), i > j:
 //       acc = sum_{p<j} L(i,p) L(j,p)^T          each term as soon as its two operand tiles are published (MFMA)
 //       T   = A(i,j) - acc
-//       i == j :  L(j,j) = chol(T)                (diag_factor64, in registers)
-//       i  > j :  L(i,j) = T L(j,j)^-T            once L(j,j) is published; 4 threads per row, 16-column panels
+//       L(i,j) = T L(j,j)^-T                     once L(j,j) is published; matrix cores, 16-column panels
 //       publish: store, release fence, ready[tile] = 1
-//   Every dependency of a tile has a smaller number, so with all G <= 256 workgroups resident (one per CU; if
+//   The item of tile (j+1, j) carries on with the diagonal tile (j+1, j+1) (see the kernel): update by X X^T from
+//   LDS, chol() in registers (diag_factor64_fast), publish.  Tile (0, 0) is an item of its own; the items of the
+//   other diagonal tiles are empty.
+//   Every dependency of an item has a smaller number, so with all G <= 256 workgroups resident (one per CU; if
 //   another kernel holds CUs they trickle in as it retires -- nothing they wait for depends on them) the
-//   smallest unfinished tile can always run: no deadlock.  Look-ahead is implicit: off the critical path
-//   (potrf -> trsm of the next row block -> its last rank-64 update -> potrf) everything is done early.
-//   Flags are agent-scope atomics bracketed by release / acquire fences (L2 is per XCD on gfx950).  A spin that
-//   exceeds SPIN_LIMIT (seconds) raises the abort flag and reports info = POTRF_TIMEOUT instead of hanging.
+//   smallest unfinished item can always run: no deadlock.  Look-ahead is implicit: off the critical path
+//   (chol -> solve of the next row block -> its X X^T -> chol) everything is done early.
+//   Flags are agent-scope atomics behind release fences (L2 is per XCD on gfx950).  A spin that exceeds
+//   DF_SPIN_LIMIT polls raises the abort flag and reports info = POTRF_TIMEOUT instead of hanging.
 // ---------------------------------------------------------------------------------------------
 constexpr int DF_MAX_WG = 256;
 constexpr int DF_SPIN_LIMIT = 1 << 24;
