@@ -201,7 +201,7 @@ class CollapsedBound:
         M, d = Z.shape
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
         res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0))
-        head = res["out"].numel() + 1  # [out | status word], then the packed gradient
+        head = res["out"].numel() + 2  # [out | status word | pad], then the packed gradient (16-byte aligned)
         # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the
         # status and the gradient -- a failed factorization then costs a wasted pass 2 (its NaNs are discarded), which
         # is cheaper than idling the GPU for a host round trip on every leapfrog.  Big shards check the status first.

@@ -18,6 +18,8 @@ import torch
 from . import _lib
 from ._lib import COMP_LEN, KERNEL_IDS, OUT_LEN
 
+RESULT_HEAD = OUT_LEN + 2  # doubles ahead of the caller's extras in a result buffer: out, status word, pad
+
 
 def _kernel_id(kernel) -> int:
     if isinstance(kernel, int):
@@ -123,9 +125,10 @@ class HipEngine:
     # ------------------------------------------------------------------ tail
     def result_buffer(self, extra: int = 0):
         """One allocation for everything the host reads back after an evaluation: (buf, out, info) with
-        buf = [out (OUT_LEN doubles) | status word (int32, in the low half of one double) | extra doubles], so a single
+        buf = [out (OUT_LEN doubles) | status word (int32, in the low half of one double) | pad | extra doubles]
+        (RESULT_HEAD doubles ahead of the extras: they start 16-byte aligned, collectives run on that slice), so a single
         device-to-host copy of ``buf`` -- and no cast / concatenate launches -- ends the evaluation."""
-        buf = self.empty(OUT_LEN + 1 + extra)
+        buf = self.empty(RESULT_HEAD + extra)
         return buf, buf[:OUT_LEN], buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[:1]
 
     @staticmethod

@@ -28,7 +28,7 @@ class OracleEngine:
         return torch.empty(*shape, dtype=torch.float64)
 
     def result_buffer(self, extra=0):
-        buf = torch.zeros(OUT_LEN + 1 + extra, dtype=torch.float64)
+        buf = torch.zeros(OUT_LEN + 2 + extra, dtype=torch.float64)
         return buf, buf[:OUT_LEN], buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[:1]
 
     @staticmethod
