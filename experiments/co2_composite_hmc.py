@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--tune", type=int, default=150)
     ap.add_argument("--max_treedepth", type=int, default=6, help="PyMC3 default is 10; the demo caps the work per draw")
     ap.add_argument("--seed", type=int, default=47)
+    ap.add_argument("--map_steps", type=int, default=400, help="Adam steps on the log posterior before sampling (0 = start at the prior mean)")
+    ap.add_argument("--map_lr", type=float, default=0.05)
     ap.add_argument("--jitter", type=float, default=1e-4,
                     help="added to diag(Kuu).  PyMC3's stabilize() uses 1e-6; with this covariance (a years-long RatQuad / trend\n"
                          "lengthscale over monthly inducing inputs) cond(Kuu) then exceeds 1e10 and the rounding noise of logp\n"
@@ -64,8 +66,26 @@ def main():
 
     bound = ggp_amd.CollapsedBound(X, y, kernel="composite", jitter=args.jitter, engine=eng)
     target = ggp_amd.CompositeHmcTarget(bound, Z, ggp_amd.co2_kernel(), ggp_amd.CO2_LOG_PRIOR_SD)
+    # Warm start, as the reference does before it begins to sample (hmc_scheduler, co2_bayesian_sgpr_hmc.py:205): a
+    # few hundred Adam steps on the log posterior from PyMC3's test point; NUTS then starts near the mode instead of
+    # adapting its step size in the far tails of an 11-dimensional, badly scaled density.
+    theta = list(target.start())
+    t_map = time.time()
+    m1 = [0.0] * len(theta)
+    m2 = [0.0] * len(theta)
+    lp_map = float("-inf")
+    for it in range(1, args.map_steps + 1):
+        lp, gth = target.logp_and_grad(theta)
+        if not math.isfinite(lp):
+            break
+        lp_map = lp
+        for k in range(len(theta)):
+            m1[k] = 0.9 * m1[k] + 0.1 * gth[k]
+            m2[k] = 0.999 * m2[k] + 0.001 * gth[k] * gth[k]
+            theta[k] += args.map_lr * (m1[k] / (1 - 0.9 ** it)) / (math.sqrt(m2[k] / (1 - 0.999 ** it)) + 1e-8)
+    map_secs = time.time() - t_map
     t0 = time.time()
-    trace = ggp_amd.sample_nuts(target, n_samples=args.num_samples, tune=args.tune, seed=args.seed, start=target.start(),
+    trace = ggp_amd.sample_nuts(target, n_samples=args.num_samples, tune=args.tune, seed=args.seed, start=theta,
                                 max_treedepth=args.max_treedepth)
     wall = time.time() - t0
 
@@ -84,7 +104,7 @@ def main():
     names = [n for n, _, _ in target.params] + ["sigma"]
     post = np.concatenate([trace["ls"], trace["sig_n"][:, None]], 1)
     out = {"config": "C2 CO2, composite covariance, NUTS", "data": data, "N_train": int(X.shape[0]), "num_inducing": M, "jitter": args.jitter,
-           "num_samples": len(trace), "tune": args.tune, "max_treedepth": args.max_treedepth, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
+           "map_steps": args.map_steps, "map_secs": map_secs, "logp_after_map": lp_map, "num_samples": len(trace), "tune": args.tune, "max_treedepth": args.max_treedepth, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
            "leapfrogs_per_s": trace.n_leapfrog / wall, "mean_step_size": float(trace.get_sampler_stats("step_size").mean()),
            "diverging": int(trace.get_sampler_stats("diverging").sum()),
            "posterior_mean": {n: float(v) for n, v in zip(names, post.mean(0))},

@@ -27,14 +27,22 @@ __global__ __launch_bounds__(256) void comp_k_kernel(const double* __restrict__ 
   }
 }
 
-// bp[m] (+)= sum_i K[i][m] y[i]   (thread <-> column, rows in order: deterministic)
-__global__ __launch_bounds__(256) void comp_colsum_kernel(const double* __restrict__ K, int64_t ldk, const double* __restrict__ y,
-                                                          int64_t rows, int Mp, int accumulate, double* __restrict__ bp) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= Mp) return;
-  double s = accumulate ? bp[m] : 0.0;
-  for (int64_t i = 0; i < rows; ++i) s = fma(K[i * ldk + m], y[i], s);
-  bp[m] = s;
+// bp[m] (+)= sum_i K[i][m] y[i]   (block <-> 64 columns, its 16 waves split the rows, partials added in wave order)
+__global__ __launch_bounds__(1024) void comp_colsum_kernel(const double* __restrict__ K, int64_t ldk, const double* __restrict__ y,
+                                                           int64_t rows, int Mp, int accumulate, double* __restrict__ bp) {
+  __shared__ double part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  for (int64_t i = w; i < rows; i += 16) s = fma(K[i * ldk + m], y[i], s);
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0) {
+    double t = accumulate ? bp[m] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][lane];
+    bp[m] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void comp_scalars_kernel(const double* __restrict__ y, int64_t N, double kdiag,
@@ -94,7 +102,7 @@ int comp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const doub
     g.A = Kc; g.lda = Mp; g.ta = true; g.B = Kc; g.ldb = Mp; g.C = Php; g.ldc = Mp;
     g.m = Mp; g.n = Mp; g.k = (int)rp; g.beta = 1.0;
     gemm(g, st);
-    comp_colsum_kernel<<<(Mp + 255) / 256, 256, 0, st>>>(Kc, Mp, y + r0, rn, Mp, 1, bp);
+    comp_colsum_kernel<<<Mp / 64, 1024, 0, st>>>(Kc, Mp, y + r0, rn, Mp, 1, bp);
   }
   crop_copy(Php, Mp, Phi, M, M, M, st);
   crop_copy(bp, 1, b, 1, M, 1, st);
@@ -104,29 +112,48 @@ int comp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const doub
 
 // ---------------------------------------------------------------------------------------------
 // gradient contraction:  sum_{i, m} Kbar[i][m] d k(a_i, b_m) / d(.)   with  Kbar = C (+ y_i bb_m)
-//   workgroup <-> COMP_BLK_ROWS rows, thread <-> columns m = tid, tid + 256, ...
-//   gppart[blk][SGP_COMP_LEN]  parameter-block partials ; gzpart[blk][M][d]  partials of the derivative in b_m
+//   workgroup <-> blk_rows rows; thread <-> (row lane rl, column lane cl): RL x MC = 256, MC = 64 / 128 / 256 columns
+//   per pass so that small inducing sets still fill the block (with one workgroup per 1024 rows and a thread per
+//   column, the CO2 workload -- N = 634, M = 64 -- ran 634 evaluations of the derivative in sequence on 64 lanes).
+//   gppart[blk][SGP_COMP_LEN]  parameter-block partials ; gzpart[blk * RL + rl][M][d]  partials of the derivative
+//   in b_m (one slice per row lane: the reduce kernel adds the slices in order, no atomics).
 // ---------------------------------------------------------------------------------------------
+struct GradGeom {
+  int MC, RL, blk_rows;
+};
+static GradGeom grad_geom(int64_t rows, int M) {
+  GradGeom g;
+  g.MC = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+  g.RL = 256 / g.MC;
+  int64_t br = (rows + 1023) / 1024;  // ~1024 workgroups at most
+  if (br < 2 * g.RL) br = 2 * g.RL;
+  br = (br + g.RL - 1) / g.RL * g.RL;
+  if (br > COMP_BLK_ROWS) br = COMP_BLK_ROWS;
+  g.blk_rows = (int)br;
+  return g;
+}
+
 __global__ __launch_bounds__(256) void comp_grad_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ yv,
                                                         const double* __restrict__ B, int64_t ldb, CompSpec cs,
                                                         const double* __restrict__ C, int64_t ldc, const double* __restrict__ bb,
-                                                        int64_t nrows, int M, int d, int64_t blk0,
+                                                        int64_t nrows, int M, int d, int64_t blk0, int MC, int RL, int blk_rows,
                                                         double* __restrict__ gppart, double* __restrict__ gzpart) {
   __shared__ double red[4];
-  const int64_t r0 = (int64_t)blockIdx.x * COMP_BLK_ROWS;
-  const int64_t r1 = (r0 + COMP_BLK_ROWS) < nrows ? (r0 + COMP_BLK_ROWS) : nrows;
+  const int64_t r0 = (int64_t)blockIdx.x * blk_rows;
+  const int64_t r1 = (r0 + blk_rows) < nrows ? (r0 + blk_rows) : nrows;
   const int64_t blk = blk0 + blockIdx.x;
+  const int cl = threadIdx.x % MC, rl = threadIdx.x / MC;
   double acc[SGP_COMP_LEN];
 #pragma unroll
   for (int p = 0; p < SGP_COMP_LEN; ++p) acc[p] = 0.0;
-  for (int m = threadIdx.x; m < M; m += 256) {
+  for (int m = cl; m < M; m += MC) {
     double bv[COMP_MAX_DIM], gz[COMP_MAX_DIM];
     for (int j = 0; j < d; ++j) {
       bv[j] = B[(int64_t)m * ldb + j];
       gz[j] = 0.0;
     }
     const double bbm = bb ? bb[m] : 0.0;
-    for (int64_t i = r0; i < r1; ++i) {
+    for (int64_t i = r0 + rl; i < r1; i += RL) {
       double gpar[SGP_COMP_LEN], dkdb[COMP_MAX_DIM];
 #pragma unroll
       for (int p = 0; p < SGP_COMP_LEN; ++p) gpar[p] = 0.0;
@@ -137,7 +164,7 @@ __global__ __launch_bounds__(256) void comp_grad_kernel(const double* __restrict
       for (int j = 0; j < d; ++j) gz[j] = fma(kb, dkdb[j], gz[j]);
     }
     if (gzpart)
-      for (int j = 0; j < d; ++j) gzpart[(blk * M + m) * d + j] = gz[j];
+      for (int j = 0; j < d; ++j) gzpart[((blk * RL + rl) * M + m) * d + j] = gz[j];
   }
   for (int p = 0; p < SGP_COMP_LEN; ++p) {
     const double s = block_sum256(acc[p], red);
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(256) void comp_grad_kernel(const double* __restrict
 
 // g_blk[p] (+)= scale_p * sum_blk gppart[blk][p] (+ amp_extra on the amplitude slots) ; g_Z[m][j] (+)= scale_z * sum_blk gzpart
 __global__ __launch_bounds__(256) void comp_grad_reduce_kernel(const double* __restrict__ gppart, const double* __restrict__ gzpart,
-                                                               int64_t nblk, int M, int d, CompSpec cs, double amp_extra,
+                                                               int64_t nblk, int64_t nzslice, int M, int d, CompSpec cs, double amp_extra,
                                                                double scale_z, int accumulate, double* __restrict__ g_blk,
                                                                double* __restrict__ g_Z) {
   if (blockIdx.x == 0 && threadIdx.x < SGP_COMP_LEN) {
@@ -163,7 +190,7 @@ __global__ __launch_bounds__(256) void comp_grad_reduce_kernel(const double* __r
     const int64_t total = (int64_t)M * d;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
       double s = 0.0;
-      for (int64_t k = 0; k < nblk; ++k) s += gzpart[k * total + e];
+      for (int64_t k = 0; k < nzslice; ++k) s += gzpart[k * total + e];
       s *= scale_z;
       g_Z[e] = accumulate ? g_Z[e] + s : s;
     }
@@ -179,15 +206,21 @@ __global__ __launch_bounds__(256) void comp_pad2_kernel(const double* __restrict
   }
 }
 
+static size_t grad_blocks_max(int64_t N, const GradGeom& gg) {  // blocks never straddle row chunks: one extra per chunk
+  const int64_t Rc = chunk_rows(N);
+  return (size_t)((N + gg.blk_rows - 1) / gg.blk_rows + (N + Rc - 1) / Rc + 1);
+}
+
 size_t comp_bwd_workspace_bytes(int64_t N, int M, int d) {
   const size_t Mp = padded_m(M);
-  const size_t nblk = (size_t)((N + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS) + 1;
+  const GradGeom gg = grad_geom(N, M);
+  const size_t nblk = grad_blocks_max(N, gg);
   Carver c(nullptr);
   c.take<double>((size_t)chunk_rows(N) * Mp);
   c.take<double>((size_t)chunk_rows(N) * Mp);
   c.take<double>(Mp * Mp);
   c.take<double>(nblk * SGP_COMP_LEN);
-  c.take<double>(nblk * (size_t)M * d);
+  c.take<double>(nblk * gg.RL * (size_t)M * d);
   return c.used();
 }
 
@@ -197,16 +230,17 @@ int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const doub
   if (!ws || ws_bytes < comp_bwd_workspace_bytes(N, M, d)) return SGP_ERR_WORKSPACE;
   const int Mp = padded_m(M);
   const int64_t Rc = chunk_rows(N);
-  const int64_t nblk_total = (N + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS;
+  const GradGeom gg = grad_geom(N, M);
+  const size_t nblk_max = grad_blocks_max(N, gg);
   Carver c(ws);
   double* Kc = c.take<double>((size_t)Rc * Mp);
   double* Cc = c.take<double>((size_t)Rc * Mp);
   double* P2 = c.take<double>((size_t)Mp * Mp);
-  double* gpp = c.take<double>((size_t)(nblk_total + 1) * SGP_COMP_LEN);
-  double* gzp = c.take<double>((size_t)(nblk_total + 1) * M * d);
+  double* gpp = c.take<double>(nblk_max * SGP_COMP_LEN);
+  double* gzp = c.take<double>(nblk_max * gg.RL * (size_t)M * d);
   comp_pad2_kernel<<<grid_for_c((int64_t)Mp * Mp), 256, 0, st>>>(Phibar, M, Mp, 2.0, P2);
   int64_t blk0 = 0;
-  for (int64_t r0 = 0; r0 < N; r0 += Rc) {  // Rc is a multiple of COMP_BLK_ROWS or covers all of N
+  for (int64_t r0 = 0; r0 < N; r0 += Rc) {
     const int64_t rn = (N - r0) < Rc ? (N - r0) : Rc;
     const int64_t rp = round_up64(rn, 64);
     comp_k_kernel<<<grid_for_c(rp * Mp), 256, 0, st>>>(X + r0 * ldx, ldx, Z, ldz, cs, d, rn, M, rp, Mp, 0.0, Kc);
@@ -214,35 +248,38 @@ int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const doub
     g.A = Kc; g.lda = Mp; g.B = P2; g.ldb = Mp; g.C = Cc; g.ldc = Mp;
     g.m = (int)rp; g.n = Mp; g.k = Mp;
     gemm(g, st);
-    const int nb = (int)((rn + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS);
-    comp_grad_kernel<<<nb, 256, 0, st>>>(X + r0 * ldx, ldx, y + r0, Z, ldz, cs, Cc, Mp, bbar, rn, M, d, blk0, gpp,
-                                         g_Z ? gzp : nullptr);
+    const int nb = (int)((rn + gg.blk_rows - 1) / gg.blk_rows);
+    comp_grad_kernel<<<nb, 256, 0, st>>>(X + r0 * ldx, ldx, y + r0, Z, ldz, cs, Cc, Mp, bbar, rn, M, d, blk0, gg.MC, gg.RL,
+                                         gg.blk_rows, gpp, g_Z ? gzp : nullptr);
     blk0 += nb;
   }
-  comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, blk0, M, d, cs,
+  comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, blk0, blk0 * gg.RL, M, d, cs,
                                                                             kappabar * (double)N, 1.0, 0, g_blk, g_Z);
   return check_launch();
 }
 
 size_t comp_kuu_bwd_workspace_bytes(int M, int d) {
-  const size_t nblk = (size_t)((M + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS);
+  const GradGeom gg = grad_geom(M, M);
+  const size_t nblk = (size_t)((M + gg.blk_rows - 1) / gg.blk_rows);
   Carver c(nullptr);
   c.take<double>(nblk * SGP_COMP_LEN);
-  c.take<double>(nblk * (size_t)M * d);
+  c.take<double>(nblk * gg.RL * (size_t)M * d);
   return c.used();
 }
 
 int comp_kuu_bwd(const double* Z, int64_t ldz, const CompSpec& cs, const double* Kuubar, int M, int d, double* g_blk,
                  double* g_Z, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!ws || ws_bytes < comp_kuu_bwd_workspace_bytes(M, d)) return SGP_ERR_WORKSPACE;
-  const int nb = (M + COMP_BLK_ROWS - 1) / COMP_BLK_ROWS;
+  const GradGeom gg = grad_geom(M, M);
+  const int nb = (M + gg.blk_rows - 1) / gg.blk_rows;
   Carver c(ws);
   double* gpp = c.take<double>((size_t)nb * SGP_COMP_LEN);
-  double* gzp = c.take<double>((size_t)nb * M * d);
-  comp_grad_kernel<<<nb, 256, 0, st>>>(Z, ldz, nullptr, Z, ldz, cs, Kuubar, M, nullptr, M, M, d, 0, gpp, g_Z ? gzp : nullptr);
+  double* gzp = c.take<double>((size_t)nb * gg.RL * M * d);
+  comp_grad_kernel<<<nb, 256, 0, st>>>(Z, ldz, nullptr, Z, ldz, cs, Kuubar, M, nullptr, M, M, d, 0, gg.MC, gg.RL, gg.blk_rows, gpp,
+                                       g_Z ? gzp : nullptr);
   // k(z_i, z_m) depends on z_m through both arguments; with a symmetric Kuubar the two halves are equal
-  comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, nb, M, d, cs, 0.0, 2.0, 1,
-                                                                            g_blk, g_Z);
+  comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, nb, (int64_t)nb * gg.RL, M, d,
+                                                                            cs, 0.0, 2.0, 1, g_blk, g_Z);
   return check_launch();
 }
 

@@ -432,7 +432,8 @@ extern "C" size_t sgp_kuu_bwd_workspace_bytes(int M, int d) {
   Carver c(nullptr);
   c.take<double>((size_t)M * (d + 1));
   c.take<double>((size_t)M * d);
-  return c.used();
+  const size_t comp = d <= COMP_MAX_DIM ? comp_kuu_bwd_workspace_bytes(M, d) : 0;  // one size for every kernel_id
+  return c.used() > comp ? c.used() : comp;
 }
 
 extern "C" int sgp_kuu_bwd(const double* Z, int64_t ldz, const double* inv_ls, double sf2, const double* Kuubar, int M,
