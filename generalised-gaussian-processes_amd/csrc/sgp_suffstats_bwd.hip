@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const int half = wave >> 1;                        // wave-uniform: tid >> 7
-  const int prow = tid >> 4, pcol = (tid & 15) * 8;  // staging role for the Phibar slab (16 x 128)
+  // staging role for the Phibar slab (16 x 128): row tid / 16, four 16-byte pieces 32 doubles apart, so that the 16 lanes
+  // of a row write 256 contiguous bytes per ds_write_b128 (8 contiguous doubles per thread made every such store 4-way
+  // bank-conflicted: SQ_LDS_BANK_CONFLICT was 44 % of the kernel's LDS cycles)
+  const int prow = tid >> 4, pcol = (tid & 15) * 2;
   const int erow = tid & 127;                        // epilogue: inducing column this thread contracts
   const int nchunks = Mp / BK;
 
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     auto fetchP = [&](int ch) {
       const double* pb = Pb + (int64_t)ch * BK * Mp + m0;  // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pv[e] = *reinterpret_cast<const d2*>(pb + poff + 2 * e);
+      for (int e = 0; e < 4; ++e) pv[e] = *reinterpret_cast<const d2*>(pb + poff + 32 * e);
     };
     auto stashA = [&](int buf, const d2 (&av)[4]) {
 #pragma unroll
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     };
     auto stashP = [&](int buf) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) *reinterpret_cast<d2*>(&Bt[buf][prow][pcol + 2 * e]) = pv[e];
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<d2*>(&Bt[buf][prow][pcol + 32 * e]) = pv[e];
     };
 
     d4 acc[4][4];
