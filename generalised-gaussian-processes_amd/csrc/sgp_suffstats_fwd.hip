@@ -228,6 +228,10 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   constexpr bool BALANCED = DIAG && NW == 4 && SKIP;
   const bool idle = DIAG && !BALANCED && skip_upper && (wj * WCOLS >= wi * 64 + 64);
   auto mfma_chunk = [&](int buf) {
+    // While it issues MFMAs a wave outranks the co-resident workgroup's wave on its SIMD (which is then staging or
+    // about to): 16.4-16.5 vs 16.7-16.9 ms for the launch, three alternations on one box.  (The same two lines in
+    // pass 2 cost 0.8 %: there the partner's epilogue VALU work is what gets starved.)
+    __builtin_amdgcn_s_setprio(1);
     if constexpr (BALANCED) {
       switch (wave) {
         case 0: diag_chunk<0>(Ks[buf], acc, l15, l4); break;
@@ -235,9 +239,13 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
         case 2: diag_chunk<2>(Ks[buf], acc, l15, l4); break;
         default: diag_chunk<3>(Ks[buf], acc, l15, l4); break;
       }
+      __builtin_amdgcn_s_setprio(0);
       return;
     }
-    if (idle) return;
+    if (idle) {
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
       const double* kr = &Ks[buf][ks * 4 + l4][0];
@@ -251,6 +259,7 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 #pragma unroll
         for (int v = 0; v < VB; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   if constexpr (GLDS) {
