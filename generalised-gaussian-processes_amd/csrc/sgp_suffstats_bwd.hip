@@ -66,7 +66,9 @@ __device__ __forceinline__ double hprime_from_k(double kp, double r2) {
   }
 }
 
-template <int DP, int KID>
+// GZ: the derivative with respect to the inducing inputs is wanted (Adam steps); HMC leapfrogs keep Z fixed and skip
+// its 2 DP accumulate operations per element (GZ == (want_gz != 0))
+template <int DP, int KID, bool GZ>
 __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     const double* __restrict__ Kfu, const double* __restrict__ Xs, const double* __restrict__ ys,
     const double* __restrict__ Zs, const double* __restrict__ Pb, const double* __restrict__ bb, double sf2,
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
           const double t = E * df[j];
-          gz[j] += t;
+          if constexpr (GZ) gz[j] += t;
           gl[j] = fma(t, df[j], gl[j]);
         }
       }
@@ -350,10 +352,16 @@ static void launch_bwd(int kid, int grid, hipStream_t st, const double* Kfu, con
   const SplitMap bmap{{p.taper_b[0], p.taper_b[1], p.taper_b[2], p.taper_b[3]}, bps};
 #define SGP_BWD_ARGS Kfu, w.Xs, w.ys, w.Zs, w.Pb, w.bb, sf2, row0, nblocks, bmap, N, M, p.Mp, p.nmb, want_gz, accumulate, w.gacc, w.gzpart, w.glpart
   switch (kid) {
-    case SGP_KERNEL_RBF: kbar_contract_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;
-    case SGP_KERNEL_MATERN32: kbar_contract_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;
-    default: kbar_contract_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); break;
+#define SGP_BWD_LAUNCH(K) \
+  do { \
+    if (want_gz) kbar_contract_kernel<DP, K, true><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); \
+    else kbar_contract_kernel<DP, K, false><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); \
+  } while (0)
+    case SGP_KERNEL_RBF: SGP_BWD_LAUNCH(SGP_KERNEL_RBF); break;
+    case SGP_KERNEL_MATERN32: SGP_BWD_LAUNCH(SGP_KERNEL_MATERN32); break;
+    default: SGP_BWD_LAUNCH(SGP_KERNEL_MATERN52); break;
   }
+#undef SGP_BWD_LAUNCH
 #undef SGP_BWD_ARGS
 }
 
