@@ -177,7 +177,7 @@ def main():
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": SYRK_TRAFFIC_BYTES_PMC if (args.n, args.m, world) == (N_TOTAL, M_IND, 1) else None, "ms": pass1_ms,
                      "algorithmic_flops": algorithmic_flops_fwd(n_local, args.m, DIM),
                      "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
-                                     "profiles/r01_v13_pmc_hbm_traffic.csv (tools/profile_round.sh); collected in separate passes, not in this run"},
+                                     "profiles/r01_v14_pmc_hbm_traffic.csv (tools/profile_round.sh); collected in separate passes, not in this run"},
         "assembly": {"bound": "hbm", "kernel": "sgp::kfu_assemble_kernel<8,0>", "ms": assemble_ms,
                      "achieved": kfu_bytes / (assemble_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": kfu_bytes / (assemble_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": kfu_bytes},
