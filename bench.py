@@ -30,7 +30,7 @@ LS, SF, SN, JITTER = 2.0, 1.0, 0.3, 1e-6
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= 256 CU x 2.4 GHz x 128 flop/clk/CU); see DESIGN.md
 # HBM bytes one syrk_tile_kernel launch moved at the default config (N=1M, M=1024, 1 GPU), from the PMC passes
 # committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); None for other configs.
-SYRK_TRAFFIC_BYTES_PMC = 5.38e10
+SYRK_TRAFFIC_BYTES_PMC = 4.54e10
 
 
 def synth(n_total, m, d):
