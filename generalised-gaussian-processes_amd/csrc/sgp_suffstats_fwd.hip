@@ -38,19 +38,21 @@ size_t stream_kfu_budget() { return g_kfu_budget; }
 static int g_timing = 0;
 static hipEvent_t g_ev[TIMING_SLOTS][2];
 static int g_ev_ready = 0, g_ev_used[TIMING_SLOTS] = {0, 0, 0};
+// (a failed event call only leaves the optional timing slot unused: sgp_timing_last_ms then reports SGP_ERR_ARG)
 void timing_begin(int slot, hipStream_t st) {
   if (!g_timing) return;
   if (!g_ev_ready) {
+    bool ok = true;
     for (int s = 0; s < TIMING_SLOTS; ++s)
-      for (int k = 0; k < 2; ++k) hipEventCreate(&g_ev[s][k]);
+      for (int k = 0; k < 2; ++k) ok = (hipEventCreate(&g_ev[s][k]) == hipSuccess) && ok;
+    if (!ok) return;
     g_ev_ready = 1;
   }
-  hipEventRecord(g_ev[slot][0], st);
+  if (hipEventRecord(g_ev[slot][0], st) != hipSuccess) g_ev_used[slot] = 0;
 }
 void timing_end(int slot, hipStream_t st) {
-  if (!g_timing) return;
-  hipEventRecord(g_ev[slot][1], st);
-  g_ev_used[slot] = 1;
+  if (!g_timing || !g_ev_ready) return;
+  g_ev_used[slot] = hipEventRecord(g_ev[slot][1], st) == hipSuccess ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
