@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch-overhead diagnostic for the small configs: run K leapfrog-shaped evaluations of C2 (N=634, d=1, M=128)
-under `rocprofv3 --kernel-trace` and compare wall time per evaluation with the sum of kernel durations.
+under `rocprofv3 --kernel-trace` and compare wall time per evaluation with the sum of kernel durations
+(SHAPE=N,d,M selects another config, e.g. SHAPE=13279,18,512 for C3).
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/small -- python3 tools/small_trace.py
     python3 tools/small_trace.py --analyse gpurun_out/small/*/*kernel_trace.csv"""
 import csv
@@ -34,18 +35,18 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import ggp_amd
     eng = ggp_amd.HipEngine()
-    N, d, M = 634, 1, 128
+    N, d, M = (int(v) for v in os.environ.get("SHAPE", "634,1,128").split(","))
     g = torch.Generator().manual_seed(0)
     X = torch.randn(N, d, dtype=torch.float64, generator=g)
     y = torch.sin(X.sum(1) / math.sqrt(d)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
     Z = X[torch.randperm(N, generator=g)[:M]].clone().to(eng.device)
     cb = ggp_amd.CollapsedBound(X.to(eng.device), y.to(eng.device), jitter=1e-6, engine=eng)
     for _ in range(5):
-        cb.value_and_grad(Z, [0.7], 1.0, 0.09, want_gz=False)
+        cb.value_and_grad(Z, [0.7 if d == 1 else 2.0] * d, 1.0, 0.09, want_gz=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
-        cb.value_and_grad(Z, [0.7], 1.0, 0.09, want_gz=False)
+        cb.value_and_grad(Z, [0.7 if d == 1 else 2.0] * d, 1.0, 0.09, want_gz=False)
     torch.cuda.synchronize()
     print(json.dumps({"wall_us_per_eval": (time.perf_counter() - t0) / K * 1e6, "evals": K}))
 
