@@ -199,6 +199,42 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
       }
 }
 
+// C = alpha * sum over S k-slices (+ beta C): for products with a few output tiles and a long contraction (the
+// M x M x B products of the SVGP reverse pass: 16 tiles, k = 4096) -- S workgroups per tile write partial tiles, a
+// second launch adds them in slice order.  scratch: S * m * n doubles.  No k-range masks, no batch.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ part, int S, int m, int n, double* __restrict__ C,
+                                                            int64_t ldc, double alpha, double beta) {
+  const int64_t total = (int64_t)m * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / n), c = (int)(e - (int64_t)r * n);
+    double s = 0.0;
+    for (int z = 0; z < S; ++z) s += part[(int64_t)z * total + e];
+    double* dst = C + (int64_t)r * ldc + c;
+    *dst = (beta == 0.0) ? alpha * s : fma(beta, *dst, alpha * s);
+  }
+}
+void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st) {
+  if (g.m <= 0 || g.n <= 0 || S <= 1 || g.k % (S * GK) != 0) {
+    gemm(g, st);
+    return;
+  }
+  const int kc = g.k / S;
+  GemmDesc p = g;
+  p.k = kc;
+  p.batch = S;
+  p.sA = g.ta ? (int64_t)kc * g.lda : kc;  // op(A) is m x k: the k index runs along rows of A when transposed
+  p.sB = g.tb ? kc : (int64_t)kc * g.ldb;
+  p.C = scratch;
+  p.ldc = g.n;
+  p.sC = (int64_t)g.m * g.n;
+  p.alpha = 1.0;
+  p.beta = 0.0;
+  gemm(p, st);
+  const int64_t total = (int64_t)g.m * g.n;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  splitk_reduce_kernel<<<blocks, 256, 0, st>>>(scratch, S, g.m, g.n, g.C, g.ldc, g.alpha, g.beta);
+}
+
 void gemm(const GemmDesc& g, hipStream_t st) {
   if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return;
   GemmP p{g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.sA, g.sB, g.sC, g.m, g.n, g.k,

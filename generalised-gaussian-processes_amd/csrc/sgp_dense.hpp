@@ -23,6 +23,9 @@ struct GemmDesc {
   bool lower_only = false;
 };
 void gemm(const GemmDesc& g, hipStream_t st);
+// the same product with the contraction cut into S slices (S * m * n doubles of scratch; falls back to gemm() when k is
+// not a multiple of 16 S): for few output tiles and a long k
+void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st);
 
 // In-place lower Cholesky of the Mp x Mp matrix A (Mp multiple of 64); strictly-upper part of the
 // result is zeroed.  Linv (Mp x Mp, same ld) receives the inverses of the 64 x 64 diagonal blocks of

@@ -152,20 +152,23 @@ __global__ __launch_bounds__(256) void svgp_ell_kernel(const double* __restrict_
 }
 
 // KL(N(m, LS LS^T) || N(0, I)) and, on request, its gradients into g_m / g_LS (scaled by kl_scale = -1/N)
+// klpart[block] = partial of  sum m^2 - 2 sum log diag(LS) + ||tril(LS)||_F^2  (fixed grid of 64 blocks; one block
+// walking the M^2 entries took 90 us at M = 256)
 __global__ __launch_bounds__(256) void svgp_kl_kernel(const double* __restrict__ m, const double* __restrict__ LS, int M,
-                                                      double* __restrict__ kl_out) {
+                                                      double* __restrict__ klpart) {
   __shared__ double red[4];
   double s = 0.0;
-  for (int i = threadIdx.x; i < M; i += 256) s += m[i] * m[i] - 2.0 * log(LS[(int64_t)i * M + i]);
-  for (int64_t e = threadIdx.x; e < (int64_t)M * M; e += 256) {
+  const int t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+  for (int i = t; i < M; i += nt) s += m[i] * m[i] - 2.0 * log(LS[(int64_t)i * M + i]);
+  for (int64_t e = t; e < (int64_t)M * M; e += nt) {
     const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
     if (c <= r) s = fma(LS[e], LS[e], s);
   }
   s = block_sum256(s, red);
-  if (threadIdx.x == 0) *kl_out = 0.5 * (s - (double)M);
+  if (threadIdx.x == 0) klpart[blockIdx.x] = s;
 }
 
-__global__ void svgp_finalize_kernel(const double* __restrict__ part, int nparts, const double* __restrict__ kl, int B,
+__global__ void svgp_finalize_kernel(const double* __restrict__ part, int nparts, const double* __restrict__ kl, int M, int B,
                                      double N_total, const double* __restrict__ dvbuf, double* __restrict__ out,
                                      double* __restrict__ g_s2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -174,9 +177,12 @@ __global__ void svgp_finalize_kernel(const double* __restrict__ part, int nparts
     se += part[2 * i];
     ss += part[2 * i + 1];
   }
-  out[0] = se / (double)B - *kl / N_total;
+  double klsum = 0.0;
+  for (int i = 0; i < 64; ++i) klsum += kl[i];
+  const double klv = 0.5 * (klsum - (double)M);
+  out[0] = se / (double)B - klv / N_total;
   out[1] = se;
-  out[2] = *kl;
+  out[2] = klv;
   if (g_s2) *g_s2 = ss / (double)B;
 }
 
@@ -314,9 +320,10 @@ static int grid_for_s(int64_t total, int cap = 2048) {
   return (int)(g < cap ? g : cap);
 }
 
+constexpr int SVGP_SPLITK = 16;  // k-slices of the two M x M x B products of the reverse pass
 struct SvgpWs {
   double *Kuu, *Kp, *Linv, *tmp, *LSp, *Kub, *A, *T, *U, *Abar, *Av, *S1, *Q, *P, *Kuubar;
-  double *mp, *mu, *v, *dmu, *dv, *part, *kl, *kpart, *gzraw;
+  double *mp, *mu, *v, *dmu, *dv, *part, *kl, *kpart, *gzraw, *splitk;
   void* kuu_ws;
   int* flags;
   size_t kuu_ws_bytes, bytes;
@@ -346,7 +353,8 @@ static SvgpWs carve_svgp(void* ws, int Mp, int Bp, int M, int d) {
   w.dmu = c.take<double>(Bp);
   w.dv = c.take<double>(Bp);
   w.part = c.take<double>(128);
-  w.kl = c.take<double>(8);
+  w.kl = c.take<double>(64);
+  w.splitk = c.take<double>((size_t)SVGP_SPLITK * mm);
   w.kpart = c.take<double>((size_t)M * (d + 1));
   w.gzraw = c.take<double>((size_t)M * d);
   w.kuu_ws_bytes = sgp_kuu_bwd_workspace_bytes(M, d);
@@ -431,8 +439,8 @@ extern "C" int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, in
 
   svgp_forward(w, Xb, ldx, B, Z, ldz, inv_ls, sf2, jitter, m, LS, M, d, kernel_id, Mp, Bp, info, st);
   svgp_ell_kernel<<<64, 256, 0, st>>>(yb, w.mu, w.v, (int)B, s2, likelihood_id, gh, w.dmu, w.dv, w.part);
-  svgp_kl_kernel<<<1, 256, 0, st>>>(m, LS, M, w.kl);
-  svgp_finalize_kernel<<<1, 64, 0, st>>>(w.part, 64, w.kl, (int)B, (double)N_total, w.dv, out, with_grads ? g_s2 : nullptr);
+  svgp_kl_kernel<<<64, 256, 0, st>>>(m, LS, M, w.kl);
+  svgp_finalize_kernel<<<1, 64, 0, st>>>(w.part, 64, w.kl, M, (int)B, (double)N_total, w.dv, out, with_grads ? g_s2 : nullptr);
   if (!with_grads) return check_launch();
 
   // ---- reverse pass -------------------------------------------------------------------------------
@@ -445,7 +453,7 @@ extern "C" int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, in
   GemmDesc gl;  // G = (A diag(vbar)) T^T  -> g_LS
   gl.A = w.Av; gl.lda = Bp; gl.B = w.T; gl.ldb = Bp; gl.tb = true; gl.C = w.S1; gl.ldc = Mp;
   gl.m = Mp; gl.n = Mp; gl.k = Bp;
-  gemm(gl, st);
+  gemm_splitk(gl, SVGP_SPLITK, w.splitk, st);
   svgp_gls_kernel<<<grid_for_s((int64_t)M * M), 256, 0, st>>>(w.S1, Mp, LS, M, invN, g_LS);
   GemmDesc bb;  // Kubbar = L^-T Abar   (into U, no longer needed)
   bb.A = w.Linv; bb.lda = Mp; bb.ta = true; bb.B = w.Abar; bb.ldb = Bp; bb.C = w.U; bb.ldc = Bp;
@@ -454,7 +462,7 @@ extern "C" int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, in
   GemmDesc s1;  // S1 = Kubbar A^T ; Lbar = -tril(S1)
   s1.A = w.U; s1.lda = Bp; s1.B = w.A; s1.ldb = Bp; s1.tb = true; s1.C = w.S1; s1.ldc = Mp;
   s1.m = Mp; s1.n = Mp; s1.k = Bp;
-  gemm(s1, st);
+  gemm_splitk(s1, SVGP_SPLITK, w.splitk, st);
   svgp_tril_kernel<<<grid_for_s((int64_t)Mp * Mp), 256, 0, st>>>(w.S1, Mp, -1.0, 0);
   GemmDesc q;  // Q = L^T Lbar ; Phi(Q)
   q.A = w.Kp; q.lda = Mp; q.ta = true; q.B = w.S1; q.ldb = Mp; q.C = w.Q; q.ldc = Mp;
