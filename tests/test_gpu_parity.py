@@ -68,6 +68,38 @@ def test_chol_reports_first_bad_pivot_of_any_tile_and_panel(engine, M, pivot):
     assert int(info.item()) == pivot + 1
 
 
+def test_chol_fuzz_against_lapack(engine):
+    """Random sizes 1..1300: well-conditioned and ill-conditioned (cond 1e10) SPD matrices reconstruct to 1e-12, an
+    indefinite matrix reports LAPACK's pivot index, a NaN is reported as a failure (never a hang, never info = 0)."""
+    g = torch.Generator().manual_seed(123)
+    for trial in range(32):
+        M = int(torch.randint(1, 1300, (1,), generator=g))
+        kind = trial % 4
+        R = torch.randn(M, M, dtype=torch.float64, generator=g)
+        A = R @ R.T / M + torch.eye(M, dtype=torch.float64)
+        if kind == 1:
+            Q, _ = torch.linalg.qr(R)
+            A = (Q * torch.logspace(0, -10, M, dtype=torch.float64)) @ Q.T
+            A = 0.5 * (A + A.T)
+        elif kind >= 2:
+            p = int(torch.randint(0, M, (1,), generator=g))
+            A[p, p] = -abs(float(A[p, p])) if kind == 2 else float("nan")
+        L, info = engine.chol_lower(A.to(engine.device))
+        info = int(info.item())
+        _, info_ref = torch.linalg.cholesky_ex(A)
+        info_ref = int(info_ref)
+        if kind <= 1:
+            if info_ref == 0:
+                Lc = torch.tril(L).cpu()
+                assert info == 0 and float((Lc @ Lc.T - A).abs().max() / A.abs().max()) < 1e-12, (M, kind, info)
+            else:
+                assert info != 0, (M, kind)
+        elif kind == 2:
+            assert info == info_ref, (M, info, info_ref)
+        else:
+            assert info > 0, (M, info)
+
+
 def test_bound_keeps_the_kuu_status_when_the_inverse_is_handed_over(engine):
     """sgp_bound_from_stats(kuu_linv=...) must not clear the status word sgp_kuu_factor wrote (include/sgp.h): one
     word, one host read, covers both factorizations; the first failure wins."""
