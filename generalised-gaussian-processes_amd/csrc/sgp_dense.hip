@@ -351,30 +351,6 @@ __device__ __forceinline__ void lds_row16(double (&v)[16], const double* p) {
     v[2 * e + 1] = t[1];
   }
 }
-// a[k] -= sum_q w[q] * R[k][q]  (k, q = 0..15; R rows at base + k * stride: 16 rows of a published panel).
-// Row k+1 is fetched while row k is consumed and the fetches are pinned ahead of the arithmetic: left to itself
-// the compiler (256 live VGPRs around here) waits for each 16-byte read before the two FMAs that use it, 85 cycles
-// a piece.
-__device__ __forceinline__ void rows16_apply(double (&a)[16], const double (&w)[16], const double* base, int stride) {
-  double cur[16], nxt[16];
-  lds_row16(cur, base);
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < 15) lds_row16(nxt, base + (k + 1) * stride);
-    __builtin_amdgcn_sched_barrier(0);
-    double s0 = a[k], s1 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; q += 2) {
-      s0 = fma(-w[q], cur[q], s0);
-      s1 = fma(-w[q + 1], cur[q + 1], s1);
-    }
-    a[k] = s0 + s1;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
-  }
-}
-
 // Cholesky of a 64 x 64 block held as  thread (i = tid & 63, g = tid >> 6) <-> a[k] = A[i][16 g + k].  Wave pb factors
 // the 16-column panel pb in registers; on return a[] holds L (garbage above the diagonal), Sp the panels and Dinv the
 // inverses of the four 16 x 16 diagonal blocks.  prog[0..3] must be 0 on entry (the caller's barrier covers it).
