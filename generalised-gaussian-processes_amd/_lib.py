@@ -43,6 +43,9 @@ PROTOTYPES = {
     "sgp_set_kfu_budget_bytes": (None, [_sz]),
     "sgp_suffstats_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_stats_packed_len": (_sz, [_i32]),
+    "sgp_stats_pack_lower": (_i32, [_vp, _i32, _vp, _vp]),
+    "sgp_stats_unpack_lower": (_i32, [_vp, _i32, _vp, _vp]),
     "sgp_kuu": (_i32, [_vp, _i64, _dp, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp]),
     "sgp_chol_workspace_bytes": (_sz, [_i32]),
     "sgp_chol_lower": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),

@@ -239,26 +239,46 @@ __global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __res
   }
 }
 
-// Phibar = (Kinv - Sinv - a a^T / s2^2) / (2 s2)
-// Kuubar = -1/2 (Sinv + a a^T / s2^2 - Kinv + KPK / s2)        (cropped to M x M, ld M)
-__global__ __launch_bounds__(256) void adjoint_out_kernel(const double* __restrict__ Kinv, const double* __restrict__ Sinv,
-                                                          const double* __restrict__ KPK, const double* __restrict__ alpha,
+// Adjoints in the whitened basis (everything between L^-T ... L^-1 is formed from B, B^-1 and g = B^-1 u, whose
+// entries are O(1) however ill-conditioned Kuu is):
+//     2 s2 Phibar = L^-T C L^-1      C = I - B^-1 - g g^T / s2^2
+//    -2 Kuubar    = L^-T S L^-1      S = B + B^-1 - 2 I + g g^T / s2^2 = W / s2 - I + B^-1 + g g^T / s2^2
+// The textbook form (Kuu^-1 - Sigma^-1 - alpha alpha^T) subtracts matrices of size cond(Kuu) to get an O(1) result:
+// with cond(Kuu) ~ 1e8 (inducing inputs closer than the lengthscale) its gradients were off by 1e-2 relative, this
+// form by 1e-9 (tests/studies/logp_noise.py, profiles/r02_logp_noise.json) -- same number of M^3 products.
+// CS = [C | S], two Mp x Mp matrices back to back (one batched GEMM pair sandwiches both).
+__global__ __launch_bounds__(256) void whitened_cs_kernel(const double* __restrict__ W, const double* __restrict__ Binv,
+                                                          const double* __restrict__ g, int Mp, double s2,
+                                                          double* __restrict__ CS) {
+  const int64_t total = (int64_t)Mp * Mp;
+  const double is2 = 1.0 / s2, is22 = 1.0 / (s2 * s2);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    const int64_t pt = (int64_t)c * Mp + r;
+    const double w = 0.5 * (W[e] + W[pt]);
+    const double bi = 0.5 * (Binv[e] + Binv[pt]);
+    const double gg = g[r] * g[c] * is22;
+    const double id = (r == c) ? 1.0 : 0.0;
+    CS[e] = id - bi - gg;
+    CS[total + e] = w * is2 - id + bi + gg;
+  }
+}
+// Phibar = sym(R0) / (2 s2), Kuubar = -sym(R1) / 2 (cropped to M x M, ld M), bbar = t / s2^2 with t = L^-T g
+__global__ __launch_bounds__(256) void adjoint_out_kernel(const double* __restrict__ R, const double* __restrict__ t,
                                                           int Mp, int M, double s2, double* __restrict__ Phibar,
                                                           double* __restrict__ Kuubar, double* __restrict__ bbar) {
   const int64_t total = (int64_t)M * M;
-  const double is22 = 1.0 / (s2 * s2);
+  const int64_t mm = (int64_t)Mp * Mp;
+  const double h = 0.25 / s2;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
     const int64_t p = (int64_t)r * Mp + c, pt = (int64_t)c * Mp + r;
-    const double ki = 0.5 * (Kinv[p] + Kinv[pt]);
-    const double si = 0.5 * (Sinv[p] + Sinv[pt]);
-    const double kp = 0.5 * (KPK[p] + KPK[pt]);
-    const double aa = alpha[r] * alpha[c] * is22;
-    Phibar[e] = (ki - si - aa) / (2.0 * s2);
-    Kuubar[e] = -0.5 * (si + aa - ki + kp / s2);
+    Phibar[e] = h * (R[p] + R[pt]);
+    Kuubar[e] = -0.25 * (R[mm + p] + R[mm + pt]);
   }
+  const double is22 = 1.0 / (s2 * s2);
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < M; i += 256) bbar[i] = alpha[i] * is22;
+    for (int i = threadIdx.x; i < M; i += 256) bbar[i] = t[i] * is22;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -343,6 +363,34 @@ __global__ __launch_bounds__(256) void pred_cov_add_kernel(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// exchange format of the statistics: Phi is symmetric, only its lower triangle crosses xGMI
+// ---------------------------------------------------------------------------------------------
+// tri = [ Phi[i][j], j <= i, row by row (M (M + 1) / 2) | b (M) | yy | kappa ]
+__global__ __launch_bounds__(256) void stats_pack_kernel(const double* __restrict__ stats, int M, double* __restrict__ tri) {
+  const int64_t mm = (int64_t)M * M, nt = (int64_t)M * (M + 1) / 2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < mm + M + 2; e += (int64_t)gridDim.x * 256) {
+    if (e >= mm) {
+      tri[nt + (e - mm)] = stats[e];
+      continue;
+    }
+    const int i = (int)(e / M), j = (int)(e - (int64_t)i * M);
+    if (j <= i) tri[(int64_t)i * (i + 1) / 2 + j] = stats[e];
+  }
+}
+__global__ __launch_bounds__(256) void stats_unpack_kernel(const double* __restrict__ tri, int M, double* __restrict__ stats) {
+  const int64_t mm = (int64_t)M * M, nt = (int64_t)M * (M + 1) / 2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < mm + M + 2; e += (int64_t)gridDim.x * 256) {
+    if (e >= mm) {
+      stats[e] = tri[nt + (e - mm)];
+      continue;
+    }
+    const int i = (int)(e / M), j = (int)(e - (int64_t)i * M);
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    stats[e] = tri[(int64_t)hi * (hi + 1) / 2 + lo];
+  }
+}
+
 static KernArgs make_ka(const double* inv_ls, double sf2, int d) {
   KernArgs ka;
   for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
@@ -357,7 +405,7 @@ static int grid_for(int64_t total, int cap = 2048) {
 }
 
 struct BoundWs {
-  double *M0, *M1, *M2, *M3, *M4, *M5, *M6, *M7, *M8;
+  double *M0, *M1, *M2, *M3, *M4, *M5, *M6, *M7;  // M0 / M4 are the first halves of the two-matrix buffers CS / TT
   double *bp, *u, *q, *alpha, *t1, *sc, *partial;
   int *flags, *flagsB;  // potrf tile-ready flags: chol(Kuu) (cleared by potrf_lower), chol(B) (cleared by tail_prep_kernel)
   size_t bytes;
@@ -366,15 +414,15 @@ static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
   Carver c(ws);
   BoundWs w;
   const size_t mm = (size_t)Mp * Mp;
-  w.M0 = c.take<double>(mm);
+  (void)with_adj;
+  w.M0 = c.take<double>(2 * mm);
   w.M1 = c.take<double>(mm);
   w.M2 = c.take<double>(mm);
   w.M3 = c.take<double>(mm);
-  w.M4 = c.take<double>(mm);
+  w.M4 = c.take<double>(2 * mm);
   w.M5 = c.take<double>(mm);
   w.M6 = c.take<double>(mm);
   w.M7 = c.take<double>(mm);
-  w.M8 = with_adj ? c.take<double>(mm) : nullptr;
   w.bp = c.take<double>(Mp);
   w.u = c.take<double>(Mp);
   w.q = c.take<double>(Mp);
@@ -403,6 +451,22 @@ extern "C" const char* sgp_status_string(int status) {
     case SGP_ERR_LAUNCH: return "HIP launch failed";
     default: return status > 0 ? "matrix not positive definite (LAPACK-style pivot index)" : "unknown status";
   }
+}
+
+extern "C" size_t sgp_stats_packed_len(int M) {
+  return M > 0 && M <= SGP_MAX_INDUCING ? (size_t)M * (M + 1) / 2 + M + 2 : 0;
+}
+extern "C" int sgp_stats_pack_lower(const double* stats, int M, double* tri, sgp_stream_t stream) {
+  if (!stats || !tri || M <= 0) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  stats_pack_kernel<<<grid_for((int64_t)M * M + M + 2), 256, 0, (hipStream_t)stream>>>(stats, M, tri);
+  return check_launch();
+}
+extern "C" int sgp_stats_unpack_lower(const double* tri, int M, double* stats, sgp_stream_t stream) {
+  if (!stats || !tri || M <= 0) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  stats_unpack_kernel<<<grid_for((int64_t)M * M + M + 2), 256, 0, (hipStream_t)stream>>>(tri, M, stats);
+  return check_launch();
 }
 
 extern "C" int sgp_kuu(const double* Z, int64_t ldz, const double* inv_ls, double sf2, double jitter, int M, int d,
@@ -472,7 +536,7 @@ extern "C" size_t sgp_bound_factors_len(int M) { return M > 0 ? (size_t)2 * M * 
 extern "C" size_t sgp_kuu_factor_len(int M) {
   if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
   const size_t Mp = padded_m(M);
-  return 2 * Mp * Mp;  // [ L^-1 | Kuu^-1 = L^-T L^-1 ], both padded
+  return Mp * Mp;  // L^-1, padded
 }
 extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
   if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
@@ -500,12 +564,6 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
-  {  // Kuu^-1 (only the adjoints read it) depends on (Z, theta) alone as well: off the critical path with the rest
-    GemmDesc k;
-    k.A = Linv_out; k.lda = Mp; k.ta = true; k.B = Linv_out; k.ldb = Mp; k.C = Linv_out + (size_t)Mp * Mp; k.ldc = Mp;
-    k.m = Mp; k.n = Mp; k.k = Mp; k.klo_mask = 3;
-    gemm(k, st);
-  }
   return check_launch();
 }
 
@@ -565,50 +623,43 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
     tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
   }
 
-  if (need_G) {
-    // G = LB^-1 L^-1 in M4 (both lower triangular)
+  if (factors) {
+    // G = LB^-1 L^-1 in M4 (both lower triangular): what sgp_predict needs
     GemmDesc g;
     g.A = w.M7; g.lda = ld; g.B = w.M1; g.ldb = ld; g.C = w.M4; g.ldc = ld;
     g.m = Mp; g.n = Mp; g.k = Mp; g.khi_mask = 1; g.klo_mask = 2;
     gemm(g, st);
-  }
-  if (factors) {
     crop_copy(w.M1, ld, factors, M, M, M, st);
     crop_copy(w.M4, ld, factors + (size_t)M * M, M, M, M, st);
     crop_copy(w.q, 1, factors + (size_t)2 * M * M, 1, M, 1, st);
   }
   if (with_adjoints) {
-    // alpha = Sigma^-1 b = G^T q
-    gemv(w.M4, ld, Mp, true, w.q, w.alpha, st);
-    // Sinv = G^T G in M2 ; Kinv = L^-T L^-1 in M0
+    // B^-1 = LB^-T LB^-1 in M2 ; g = B^-1 u = LB^-T q in alpha
     GemmDesc s;
-    s.A = w.M4; s.lda = ld; s.ta = true; s.B = w.M4; s.ldb = ld; s.C = w.M2; s.ldc = ld;
+    s.A = w.M7; s.lda = ld; s.ta = true; s.B = w.M7; s.ldb = ld; s.C = w.M2; s.ldc = ld;
     s.m = Mp; s.n = Mp; s.k = Mp; s.klo_mask = 3;
     gemm(s, st);
-    if (kuu_linv) {
-      w.M0 = const_cast<double*>(kuu_linv) + mm;  // computed by sgp_kuu_factor
-    } else {
-      GemmDesc k;
-      k.A = w.M1; k.lda = ld; k.ta = true; k.B = w.M1; k.ldb = ld; k.C = w.M0; k.ldc = ld;
-      k.m = Mp; k.n = Mp; k.k = Mp; k.klo_mask = 3;
-      gemm(k, st);
-    }
-    // KPK = Kinv Phi Kinv = L^-T W L^-1 : T1 = W L^-1 in M6, KPK = L^-T T1 in M8
+    gemv(w.M7, ld, Mp, true, w.q, w.alpha, st);
+    // [C | S] in M0.., [C | S] L^-1 in M4.., L^-T [C | S] L^-1 back in M0..: two batched products for both sandwiches
+    double* CS = w.M0;
+    double* TT = w.M4;
+    whitened_cs_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, w.M2, w.alpha, Mp, s2, CS);
     GemmDesc t1;
-    t1.A = w.M5; t1.lda = ld; t1.B = w.M1; t1.ldb = ld; t1.C = w.M6; t1.ldc = ld;
-    t1.m = Mp; t1.n = Mp; t1.k = Mp; t1.klo_mask = 2;
+    t1.A = CS; t1.lda = ld; t1.sA = (int64_t)mm; t1.B = w.M1; t1.ldb = ld; t1.sB = 0; t1.C = TT; t1.ldc = ld; t1.sC = (int64_t)mm;
+    t1.m = Mp; t1.n = Mp; t1.k = Mp; t1.batch = 2; t1.klo_mask = 2;
     gemm(t1, st);
     GemmDesc t2;
-    t2.A = w.M1; t2.lda = ld; t2.ta = true; t2.B = w.M6; t2.ldb = ld; t2.C = w.M8; t2.ldc = ld;
-    t2.m = Mp; t2.n = Mp; t2.k = Mp; t2.klo_mask = 1;
+    t2.A = w.M1; t2.lda = ld; t2.ta = true; t2.sA = 0; t2.B = TT; t2.ldb = ld; t2.sB = (int64_t)mm; t2.C = CS; t2.ldc = ld; t2.sC = (int64_t)mm;
+    t2.m = Mp; t2.n = Mp; t2.k = Mp; t2.batch = 2; t2.klo_mask = 1;
     gemm(t2, st);
-    // scalars for s2bar: tr(Sinv Phi), b.alpha, alpha^T Phi alpha
-    frob_partial_kernel<<<256, 256, 0, st>>>(w.M2, w.M3, (int64_t)mm, w.partial);
+    // scalars for s2bar (slots keep their names): tr(B^-1 W) = tr(Sigma^-1 Phi), u.g = b.alpha, g^T W g = alpha^T Phi alpha
+    frob_partial_kernel<<<256, 256, 0, st>>>(w.M2, w.M5, (int64_t)mm, w.partial);
     sum256_kernel<<<1, 256, 0, st>>>(w.partial, w.sc + SC_TRSP);
-    dot_kernel<<<1, 256, 0, st>>>(w.bp, w.alpha, Mp, w.sc + SC_BA);
-    gemv(w.M3, ld, Mp, false, w.alpha, w.t1, st);
+    dot_kernel<<<1, 256, 0, st>>>(w.u, w.alpha, Mp, w.sc + SC_BA);
+    gemv(w.M5, ld, Mp, false, w.alpha, w.t1, st);
     dot_kernel<<<1, 256, 0, st>>>(w.t1, w.alpha, Mp, w.sc + SC_APA);
-    adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(w.M0, w.M2, w.M8, w.alpha, Mp, M, s2, Phibar, Kuubar, bbar);
+    gemv(w.M1, ld, Mp, true, w.alpha, w.t1, st);  // L^-T g (stream order: after the dot product that read t1)
+    adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(CS, w.t1, Mp, M, s2, Phibar, Kuubar, bbar);
   }
   finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, need_G ? nullptr : w.M6, w.q, Mp,
                                            abort_flag, info, out);

@@ -23,7 +23,7 @@ RESULT_HEAD = OUT_LEN + 2  # doubles ahead of the caller's extras in a result bu
 
 def _kernel_id(kernel) -> int:
     if isinstance(kernel, int):
-        if kernel not in (0, 1, 2):
+        if kernel not in KERNEL_IDS.values():
             raise ValueError("unknown kernel id %r" % (kernel,))
         return kernel
     try:
@@ -113,6 +113,16 @@ class HipEngine:
         _lib.check("sgp_suffstats_fwd", st)
         return out
 
+    def pack_lower(self, stats: torch.Tensor, M: int) -> torch.Tensor:
+        """[lower triangle of Phi | b | yy | kappa]: what crosses xGMI (half the bytes of ``stats``)."""
+        tri = self.empty(self.lib.sgp_stats_packed_len(M))
+        _lib.check("sgp_stats_pack_lower", self.lib.sgp_stats_pack_lower(self._ptr(stats), M, self._ptr(tri), self._stream()))
+        return tri
+
+    def unpack_lower(self, tri: torch.Tensor, M: int, stats: torch.Tensor) -> torch.Tensor:
+        _lib.check("sgp_stats_unpack_lower", self.lib.sgp_stats_unpack_lower(self._ptr(tri), M, self._ptr(stats), self._stream()))
+        return stats
+
     def kuu(self, Z, ls, sf2, jitter, kernel="rbf", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         M, d = Z.shape
         self._chk(Z, "Z")
@@ -178,7 +188,13 @@ class HipEngine:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 run()
             ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws}
-        except Exception:  # capture not supported in this environment: plain launches still work
+        except RuntimeError as exc:  # stream capture unavailable / refused: plain launches still work
+            import warnings
+            warnings.warn("hipGraph capture of the Kuu chain failed (%s); falling back to plain launches" % (exc,))
+            try:  # leave no half-open capture behind
+                torch.cuda.synchronize(self.device)
+            except RuntimeError:
+                pass
             ent = None
         self._graphs[M] = ent
         return ent

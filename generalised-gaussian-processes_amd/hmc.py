@@ -30,7 +30,7 @@ class DualAveraging:
         self.mu = math.log(10.0 * initial_step)
         self.target, self.gamma, self.t0, self.kappa = target, gamma, t0, kappa
         self.log_step = math.log(initial_step)
-        self.log_bar = 0.0
+        self.log_bar = math.log(initial_step)  # tune = 0 samples with the initial step (PyMC3 behaviour), not exp(0)
         self.hbar = 0.0
         self.count = 1
 
@@ -38,7 +38,7 @@ class DualAveraging:
         w = 1.0 / (self.count + self.t0)
         self.hbar = (1.0 - w) * self.hbar + w * (self.target - accept_stat)
         self.log_step = self.mu - self.hbar * math.sqrt(self.count) / self.gamma
-        mk = self.count ** (-self.kappa)
+        mk = self.count ** (-self.kappa)  # count = 1: the average starts from the first adapted step
         self.log_bar = mk * self.log_step + (1.0 - mk) * self.log_bar
         self.count += 1
 
@@ -46,36 +46,38 @@ class DualAveraging:
         return math.exp(self.log_step if tuning else self.log_bar)
 
 
-class _Welford:
-    def __init__(self, n):
-        self.n = 0
-        self.mean = np.zeros(n)
-        self.m2 = np.zeros(n)
+class _WeightedVariance:
+    """Running mean / variance that starts from a prior guess carrying ``weight`` pseudo-observations -- PyMC3's
+    ``_WeightedVariance`` behind ``init='jitter+adapt_diag'`` [UPSTREAM pymc3/step_methods/hmc/quadpotential.py]:
+    the foreground estimator starts at mean = start point, variance = 1, weight = 10, so the first few (possibly
+    identical) draws cannot collapse the metric; the background estimator starts empty."""
+
+    def __init__(self, n, mean=None, var=None, weight=0.0):
+        self.n = float(weight)
+        self.mean = np.zeros(n) if mean is None else np.array(mean, dtype=np.float64)
+        self.m2 = np.zeros(n) if var is None else np.array(var, dtype=np.float64) * float(weight)
 
     def add(self, x):
-        self.n += 1
+        self.n += 1.0
         d = x - self.mean
-        self.mean += d / self.n
-        self.m2 += d * (x - self.mean)
+        self.mean = self.mean + d / self.n
+        self.m2 = self.m2 + d * (x - self.mean)
 
     def var(self):
-        """Regularised like Stan / PyMC3: shrink towards 1e-3 with 5 pseudo-counts."""
-        if self.n < 2:
-            return None
-        v = self.m2 / (self.n - 1)
-        return (self.n / (self.n + 5.0)) * v + 1e-3 * (5.0 / (self.n + 5.0))
+        return self.m2 / self.n if self.n > 0 else None
 
 
 class DiagMassAdapter:
-    """Windowed diagonal mass matrix (inverse metric = posterior variance estimate), foreground/background estimators."""
+    """Windowed diagonal mass matrix (inverse metric = posterior variance estimate), foreground / background estimators
+    switched every ``window`` tuning draws (PyMC3 ``QuadPotentialDiagAdapt``, adaptation_window = 101)."""
 
-    def __init__(self, n, window=101, growth=1.0):
+    def __init__(self, n, window=101, growth=1.0, initial_mean=None, initial_weight=10.0):
         self.n = n
         self.var = np.ones(n)
         self.window = window
         self.growth = growth
-        self.fg = _Welford(n)
-        self.bg = _Welford(n)
+        self.fg = _WeightedVariance(n, np.zeros(n) if initial_mean is None else initial_mean, np.ones(n), initial_weight)
+        self.bg = _WeightedVariance(n)
         self.count = 0
 
     def update(self, sample, tuning):
@@ -84,13 +86,13 @@ class DiagMassAdapter:
         self.fg.add(sample)
         self.bg.add(sample)
         v = self.fg.var()
-        if v is not None:
+        if v is not None and np.all(np.isfinite(v)) and np.all(v > 0.0):
             self.var = v
-        self.count += 1
-        if self.count % self.window == 0:
+        if self.count > 0 and self.count % self.window == 0:
             self.fg = self.bg
-            self.bg = _Welford(self.n)
+            self.bg = _WeightedVariance(self.n)
             self.window = int(self.window * self.growth)
+        self.count += 1
 
 
 # ---------------------------------------------------------------------------------------------
@@ -266,26 +268,53 @@ class Trace:
         return set(self._stats)
 
 
+def shared_seed(seed: Optional[int], group=None) -> Optional[int]:
+    """One seed for every rank of a ``torch.distributed`` job (the tree logic runs redundantly
+    on every rank "from a shared seed").  Each leapfrog issues collectives, so ranks whose random streams differ build
+    different trees, issue different numbers of all-reduces and hang.  Rank 0's seed (fresh entropy when ``seed`` is
+    None) is broadcast; without an initialised process group ``seed`` is returned unchanged."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return seed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return seed
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.item())
+
+
 def sample_nuts(target, n_samples: int, tune: int, seed: Optional[int] = None, start: Optional[Sequence[float]] = None,
-                step_scale=0.25, target_accept=0.8, max_treedepth=10, progress: Optional[Callable[[int, dict], None]] = None) -> Trace:
+                step_scale=0.25, target_accept=0.8, max_treedepth=10, progress: Optional[Callable[[int, dict], None]] = None,
+                group=None) -> Trace:
     """``pm.sample(n_samples, tune=tune, chains=1)`` for an ``HmcTarget``-like object
-    (``ndim``, ``logp_and_grad``, ``constrain``).  Returns the post-tuning draws as a ``Trace``."""
+    (``ndim``, ``logp_and_grad``, ``constrain``).  Returns the post-tuning draws as a ``Trace``.
+    Under ``torch.distributed`` every rank calls this; the seed is made common first (``shared_seed``)."""
     nd = target.ndim
+    seed = shared_seed(seed, group)
     nuts = NUTS(target.logp_and_grad, nd, step_scale=step_scale, target_accept=target_accept, max_treedepth=max_treedepth, seed=seed)
-    if start is None:
+
+    def test_point():
         # PyMC3 test point (Gamma(2,1) -> mean 2 ; HalfCauchy(1) -> 1) in log space, plus U(-1,1) jitter
-        d = nd - 2
-        q = np.array([math.log(2.0)] * d + [0.0, 0.0]) + nuts.rng.uniform(-1.0, 1.0, nd)
-    else:
-        q = np.asarray(start, dtype=np.float64).copy()
+        base = np.asarray(target.start(), dtype=np.float64) if hasattr(target, "start") else np.array([math.log(2.0)] * (nd - 2) + [0.0, 0.0])
+        return base + nuts.rng.uniform(-1.0, 1.0, nd)
+
+    q = test_point() if start is None else np.asarray(start, dtype=np.float64).copy()
     lp, g = nuts._eval(q)
     tries = 0
-    while not math.isfinite(lp) and tries < 20:  # unlucky jitter: redraw
-        q = np.array([math.log(2.0)] * (nd - 2) + [0.0, 0.0]) + nuts.rng.uniform(-1.0, 1.0, nd)
+    while start is None and not math.isfinite(lp) and tries < 20:  # unlucky jitter: redraw (a user-supplied start is never replaced)
+        q = test_point()
         lp, g = nuts._eval(q)
         tries += 1
     if not math.isfinite(lp):
-        raise RuntimeError("could not find a starting point with finite log-density")
+        raise RuntimeError("could not find a starting point with finite log-density" if start is None
+                           else "the log-density is not finite at the supplied start")
+    nuts.mass = DiagMassAdapter(nd, initial_mean=q)  # jitter+adapt_diag: mean = start, variance 1, weight 10
     samples, stat_rows = [], []
     for it in range(tune + n_samples):
         tuning = it < tune

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError
+from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeoutError
 from .gp_shim import (ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, LazyPredictive,
                       MultivariateNormal, RBFKernel, ScaleKernel, TrainPrior, ZeroMean)
 from .hmc import Trace, sample_nuts
@@ -240,6 +240,8 @@ class _SVGPBoundFn(torch.autograd.Function):
                             m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
                             kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
         info = int(res["info"].to("cpu").item())
+        if info < 0:
+            raise SgpTimeoutError()
         if info != 0:
             raise NotPositiveDefiniteError(info)
         ctx.res = res if need else None

@@ -200,9 +200,15 @@ def kuu(Z, ls, sf2, jitter, kernel_id=KERNEL_RBF):
     return kernel_from_r2(sqdist(Z, Z, _t(ls)), sf2, kernel_id) + jitter * torch.eye(Z.shape[0], dtype=DT)
 
 
-def bound_from_stats(Kuu, st: SuffStats, s2, with_adjoints=False):
+def bound_from_stats(Kuu, st: SuffStats, s2, with_adjoints=False, whitened=True):
     """O(M^3) tail.  Returns dict with F, logmarg, trace_term and (optionally) the adjoints of
-    F wrt Phi, b, Kuu, s2, kappa."""
+    F wrt Phi, b, Kuu, s2, kappa.
+
+    ``whitened=True`` (default) evaluates the adjoints between L^-T ... L^-1 from B, B^-1 and g = B^-1 L^-1 b:
+        2 s2 Phibar = L^-T (I - B^-1 - g g^T / s2^2) L^-1 ;  -2 Kuubar = L^-T (B + B^-1 - 2 I + g g^T / s2^2) L^-1
+    ``whitened=False`` is App. A.5 as written (Kuu^-1 - Sigma^-1 - alpha alpha^T ...): identical in exact arithmetic,
+    but it cancels O(cond Kuu) entries -- relative gradient errors of 1e-2 at cond 1e8 against 1e-9 for the whitened
+    form (tests/studies/logp_noise.py).  Kept for that A/B only."""
     Kuu = _t(Kuu)
     Phi, b = _t(st.Phi), _t(st.b)
     M = Kuu.shape[0]
@@ -224,7 +230,26 @@ def bound_from_stats(Kuu, st: SuffStats, s2, with_adjoints=False):
     F = logmarg - trace_term
     out = {"F": float(F), "logmarg": float(logmarg), "trace_term": float(trace_term),
            "L": L, "LB": LB, "q": q}
-    if with_adjoints:
+    if with_adjoints and whitened:
+        Binv = torch.cholesky_inverse(LB)
+        g = Binv @ u                                                         # B^-1 L^-1 b
+        gg = torch.outer(g, g) / (s2 * s2)
+
+        def sandwich(X):                                                     # L^-T X L^-1 by triangular solves
+            Y = torch.linalg.solve_triangular(L.T, X, upper=True)
+            return torch.linalg.solve_triangular(L.T, Y.T, upper=True).T
+
+        Phibar = sandwich(I - Binv - gg) / (2.0 * s2)
+        Kuubar = -0.5 * sandwich(B + Binv - 2.0 * I + gg)
+        Phibar, Kuubar = 0.5 * (Phibar + Phibar.T), 0.5 * (Kuubar + Kuubar.T)
+        alpha = torch.linalg.solve_triangular(L.T, g[:, None], upper=True)[:, 0]   # Sigma^-1 b
+        bbar = alpha / (s2 * s2)
+        kappabar = -1.0 / (2.0 * s2)
+        s2bar = -0.5 * (-(Binv * W).sum() / s2 ** 2 + N / s2 - st.yy / s2 ** 2
+                        + 2.0 * (u @ g) / s2 ** 3 - (g @ W @ g) / s2 ** 4
+                        - st.kappa / s2 ** 2 + trW / s2 ** 2)
+        out.update(Phibar=Phibar, bbar=bbar, Kuubar=Kuubar, s2bar=float(s2bar), kappabar=kappabar, alpha=alpha)
+    elif with_adjoints:
         Linv = torch.linalg.solve_triangular(L, I, upper=False)
         Kinv = Linv.T @ Linv
         G = torch.linalg.solve_triangular(LB, Linv, upper=False)            # LB^-1 L^-1
@@ -266,13 +291,13 @@ def _dk_factors(r2, K, sf2, kernel_id):
     raise ValueError(kernel_id)
 
 
-def grads_analytic(X, y, Z, ls, sf2, s2, jitter=0.0, kernel_id=KERNEL_RBF, chunk=4096):
+def grads_analytic(X, y, Z, ls, sf2, s2, jitter=0.0, kernel_id=KERNEL_RBF, chunk=4096, whitened=True):
     """dF/d(ls_j), dF/d(sf2), dF/d(s2), dF/dZ by the two-pass scheme the HIP path uses."""
     X, y, Z, ls = _t(X), _t(y), _t(Z), _t(ls)
     M, d = Z.shape
     st = suffstats(X, y, Z, ls, sf2, kernel_id)
     Kuu_ = kuu(Z, ls, sf2, jitter, kernel_id)
-    res = bound_from_stats(Kuu_, st, s2, with_adjoints=True)
+    res = bound_from_stats(Kuu_, st, s2, with_adjoints=True, whitened=whitened)
     Phibar, bbar, Kuubar = res["Phibar"], res["bbar"], res["Kuubar"]
     g_ls = torch.zeros(d, dtype=DT)
     g_Z = torch.zeros(M, d, dtype=DT)

@@ -48,6 +48,20 @@ class OracleEngine:
             return out
         return packed
 
+    def pack_lower(self, stats, M):
+        r, c = torch.tril_indices(M, M)
+        return torch.cat([stats[: M * M].reshape(M, M)[r, c], stats[M * M:]])
+
+    def unpack_lower(self, tri, M, stats):
+        r, c = torch.tril_indices(M, M)
+        nt = M * (M + 1) // 2
+        P = torch.zeros(M, M, dtype=torch.float64)
+        P[r, c] = tri[:nt]
+        P = P + P.T - torch.diag(torch.diagonal(P))
+        stats[: M * M] = P.reshape(-1)
+        stats[M * M:] = tri[nt:]
+        return stats
+
     def kuu(self, Z, ls, sf2, jitter, kernel="rbf"):
         return O.kuu(Z, self._ls(ls, Z.shape[1]), float(sf2), float(jitter), KID[kernel])
 

@@ -68,7 +68,7 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert lib.sgp_bound_from_stats(one, one, one, one, one, -1.0, 10, 4, 0, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
     assert lib.sgp_bound_from_stats(one, one, one, one, one, 0.1, 10, 4, 1, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
     assert lib.sgp_bound_from_stats(null, one, one, one, one, 0.1, 10, 4, 0, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
-    assert lib.sgp_kuu_factor(one, 4, one, one, null, 0, null) == -3 and lib.sgp_kuu_factor_len(100) == 2 * 128 * 128
+    assert lib.sgp_kuu_factor(one, 4, one, one, null, 0, null) == -3 and lib.sgp_kuu_factor_len(100) == 128 * 128
     assert lib.sgp_chol_lower(one, 4, 4, one, null, 0, null) == -3
 
 
