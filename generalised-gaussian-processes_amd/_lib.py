@@ -59,6 +59,11 @@ PROTOTYPES = {
     "sgp_kuu_factor": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_whitened_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_suffstats_fwd_whitened": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
+                                          _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -63,9 +63,16 @@ class CollapsedBound:
     engine : object with the ``HipEngine`` interface; defaults to ``HipEngine()`` (the only product engine).
     jitter : added to diag(Kuu): 0.0 = GPyTorch parity, 1e-6 = PyMC3 ``stabilize`` parity.
     group : torch.distributed process group (None = default group when initialised).
+    form : "streaming" -- Phi = K_uf K_fu streamed over the rows, W = L^-1 Phi L^-T in the tail (the N >> M design);
+           "whitened"  -- PyMC3's op order, A = L^-1 K_uf materialised, W = A A^T: B = I + W/s2 is positive definite by
+                          construction and F keeps 1e-10 accuracy at cond(Kuu) ~ 1e8, for twice the N M^2 work;
+           "auto"      -- whitened up to ``WHITENED_MAX_WORK`` row x inducing pairs per rank (the reference's own
+                          workloads: N ~ 250-1300, M ~ 100-480), streaming above.
     """
 
-    def __init__(self, X, y, kernel="rbf", jitter=0.0, engine=None, group=None):
+    WHITENED_MAX_WORK = 1 << 22  # local rows x inducing points up to which form="auto" means "whitened"
+
+    def __init__(self, X, y, kernel="rbf", jitter=0.0, engine=None, group=None, form="auto"):
         if engine is None:
             from .engine import HipEngine
             engine = HipEngine(X.device if X.is_cuda else None)
@@ -79,6 +86,9 @@ class CollapsedBound:
         self.d = int(self.X.shape[1])
         self.kernel = kernel
         self.jitter = float(jitter)
+        if form not in ("auto", "streaming", "whitened"):
+            raise ValueError("form must be 'auto', 'streaming' or 'whitened'")
+        self.form = form
         self.group = group
         self.world = _world(group)
         n_local = int(self.X.shape[0])
@@ -151,9 +161,25 @@ class CollapsedBound:
             self._kfu = e.kfu_buffer(n_local, M)
         return self._kfu
 
+    def _whitened(self, M):
+        if self.form == "auto":
+            return hasattr(self.engine, "suffstats_whitened") and int(self.X.shape[0]) * int(M) <= self.WHITENED_MAX_WORK
+        return self.form == "whitened"
+
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0):
         e = self.engine
         result = e.result_buffer(extra)  # (buf, out, info): everything the host reads back, one allocation
+        if self._whitened(Z.shape[0]):
+            # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
+            Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
+            linv, _ = e.kuu_factor(Kuu, info=result[2])
+            packed = e.suffstats_whitened(self.X, self.y, Z, ls, sf2, linv, self.kernel)
+            self._allreduce_stats(packed, int(Z.shape[0]))
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
+                          result=result, whitened=True)
+            res["packed"] = packed
+            res["kfu"] = None
+            return res
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
         # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
         # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)

@@ -391,9 +391,39 @@ __global__ __launch_bounds__(256) void stats_unpack_kernel(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// whitened pass 1 (PyMC3 op order): A = L^-1 K_uf materialised in row chunks, W = A A^T, u = A y
+// ---------------------------------------------------------------------------------------------
+// up[m] (+)= sum_t As[m][t] y[t]  (one wave per row m; As is Mp x Tp, ld Tp; y has T valid entries)
+__global__ __launch_bounds__(256) void rows_dot_y_kernel(const double* __restrict__ As, int Mp, int Tp, int T,
+                                                         const double* __restrict__ y, int accumulate, double* __restrict__ up) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= Mp) return;
+  double s0 = 0.0, s1 = 0.0;
+  int t = lane;
+  for (; t + 64 < T; t += 128) {
+    s0 = fma(As[(int64_t)m * Tp + t], y[t], s0);
+    s1 = fma(As[(int64_t)m * Tp + t + 64], y[t + 64], s1);
+  }
+  for (; t < T; t += 64) s0 = fma(As[(int64_t)m * Tp + t], y[t], s0);
+  const double s = wave_sum(s0 + s1);
+  if (lane == 0) up[m] = accumulate ? up[m] + s : s;
+}
+__global__ __launch_bounds__(256) void yy_kappa_kernel(const double* __restrict__ y, int64_t N, double kdiag,
+                                                       double* __restrict__ yy, double* __restrict__ kappa) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < N; i += 256) s = fma(y[i], y[i], s);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) {
+    *yy = s;
+    *kappa = (double)N * kdiag;
+  }
+}
+
 static KernArgs make_ka(const double* inv_ls, double sf2, int d) {
   KernArgs ka;
-  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = (inv_ls && j < d) ? inv_ls[j] : 0.0;
   ka.sf2 = sf2;
   ka.d = d;
   return ka;
@@ -567,12 +597,14 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   return check_launch();
 }
 
-extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b, const double* yy,
-                                    const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
-                                    double* Phibar, double* bbar, double* Kuubar, double* factors,
-                                    const double* kuu_linv, int* info, void* ws, size_t ws_bytes,
-                                    sgp_stream_t stream) {
+// whitened: Phi / b already are W = A A^T and u = A y with A = L^-1 K_uf (sgp_suffstats_fwd_whitened); kuu_linv required
+static int bound_impl(const double* Kuu, const double* Phi, const double* b, const double* yy,
+                      const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
+                      double* Phibar, double* bbar, double* Kuubar, double* factors,
+                      const double* kuu_linv, int* info, void* ws, size_t ws_bytes,
+                      sgp_stream_t stream, bool whitened) {
   if ((!Kuu && !kuu_linv) || !Phi || !b || !yy || !kappa || !out || !info || M <= 0 || N < 0 || !(s2 > 0.0)) return SGP_ERR_ARG;
+  if (whitened && !kuu_linv) return SGP_ERR_ARG;
   if (with_adjoints && (!Phibar || !bbar || !Kuubar)) return SGP_ERR_ARG;
   if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   const int Mp = padded_m(M);
@@ -598,6 +630,11 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
   }
 
   // W = L^-1 Phi L^-T in M5 (V in M4); Phi is used in place when it needs no padding
+  if (whitened) {
+    if (M == Mp) w.M5 = const_cast<double*>(Phi);
+    else pad_copy(Phi, M, M, M, w.M5, ld, Mp, Mp, 0.0, st);
+    w.u = w.bp;  // tail_prep_kernel has padded u into bp
+  } else {
   if (M == Mp) w.M3 = const_cast<double*>(Phi);
   else pad_copy(Phi, M, M, M, w.M3, ld, Mp, Mp, 0.0, st);
   {
@@ -613,6 +650,7 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
 
   // u = L^-1 b
   gemv(w.M1, ld, Mp, false, w.bp, w.u, st);
+  }
 
   // B = I + W/s2 in M6 -> LB ; q = LB^-1 u rides along with the factorization; LB^-1 (M7) only when G is wanted
   make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW);
@@ -663,6 +701,94 @@ extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const 
   }
   finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, need_G ? nullptr : w.M6, w.q, Mp,
                                            abort_flag, info, out);
+  return check_launch();
+}
+
+extern "C" int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b, const double* yy,
+                                    const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
+                                    double* Phibar, double* bbar, double* Kuubar, double* factors,
+                                    const double* kuu_linv, int* info, void* ws, size_t ws_bytes,
+                                    sgp_stream_t stream) {
+  return bound_impl(Kuu, Phi, b, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info, ws,
+                    ws_bytes, stream, false);
+}
+extern "C" int sgp_bound_from_whitened_stats(const double* W, const double* u, const double* yy, const double* kappa, double s2,
+                                             int64_t N, int M, int with_adjoints, double* out, double* Phibar, double* bbar,
+                                             double* Kuubar, double* factors, const double* kuu_linv, int* info, void* ws,
+                                             size_t ws_bytes, sgp_stream_t stream) {
+  return bound_impl(nullptr, W, u, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info, ws,
+                    ws_bytes, stream, true);
+}
+
+// ---- whitened pass 1 -------------------------------------------------------------------------------------------
+constexpr int64_t WH_CHUNK = 32768;  // data rows of K_uf / A materialised at a time
+static int64_t wh_chunk(int64_t N) {
+  const int64_t np = round_up64(N > 0 ? N : 1, 64);
+  return np < WH_CHUNK ? np : WH_CHUNK;
+}
+extern "C" size_t sgp_suffstats_whitened_workspace_bytes(int64_t N, int M, int d) {
+  if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = padded_m(M), Tc = (size_t)wh_chunk(N);
+  Carver c(nullptr);
+  c.take<double>(Mp * Tc);
+  c.take<double>(Mp * Tc);
+  c.take<double>(Mp * Mp);
+  c.take<double>(Mp);
+  return c.used();
+}
+extern "C" int sgp_suffstats_fwd_whitened(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                          const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                          const double* kuu_linv, double* W, double* u, double* yy, double* kappa, void* ws,
+                                          size_t ws_bytes, sgp_stream_t stream) {
+  if (!Z || !inv_ls || !kuu_linv || !W || !u || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  CompSpec cs{};
+  double kdiag = sf2;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    kdiag = cs.kdiag;
+  }
+  if (!ws || ws_bytes < sgp_suffstats_whitened_workspace_bytes(N, M, d)) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mp = padded_m(M);
+  const int64_t Tc = wh_chunk(N);
+  Carver c(ws);
+  double* Ks = c.take<double>((size_t)Mp * Tc);
+  double* As = c.take<double>((size_t)Mp * Tc);
+  double* Wp = c.take<double>((size_t)Mp * Mp);
+  double* up = c.take<double>(Mp);
+  const KernArgs ka = make_ka(kernel_id == SGP_KERNEL_COMPOSITE ? nullptr : inv_ls, sf2, d);
+  if (N == 0) {
+    fill_zero(Wp, (size_t)Mp * Mp, st);
+    fill_zero(up, Mp, st);
+  }
+  for (int64_t t0 = 0; t0 < N; t0 += Tc) {
+    const int Tn = (int)((N - t0) < Tc ? (N - t0) : Tc);
+    const int Tp = (int)round_up64(Tn, 64);
+    const double* xs = X + t0 * ldx;
+    const int g = grid_for((int64_t)Mp * Tp);
+    switch (kernel_id) {  // K_uf chunk, M x T layout, zero in the padding
+      case SGP_KERNEL_RBF: kus_kernel<SGP_KERNEL_RBF><<<g, 256, 0, st>>>(Z, ldz, xs, ldx, ka, M, Mp, Tn, Tp, Ks); break;
+      case SGP_KERNEL_MATERN32: kus_kernel<SGP_KERNEL_MATERN32><<<g, 256, 0, st>>>(Z, ldz, xs, ldx, ka, M, Mp, Tn, Tp, Ks); break;
+      case SGP_KERNEL_COMPOSITE: comp_kmatrix(Z, ldz, M, xs, ldx, Tn, cs, d, Mp, Tp, 0.0, Ks, st); break;
+      default: kus_kernel<SGP_KERNEL_MATERN52><<<g, 256, 0, st>>>(Z, ldz, xs, ldx, ka, M, Mp, Tn, Tp, Ks); break;
+    }
+    GemmDesc a;  // A = L^-1 K_uf
+    a.A = kuu_linv; a.lda = Mp; a.B = Ks; a.ldb = Tp; a.C = As; a.ldc = Tp;
+    a.m = Mp; a.n = Tp; a.k = Mp; a.khi_mask = 1;
+    gemm(a, st);
+    GemmDesc w;  // W (+)= A A^T, lower tiles only (mirrored below)
+    w.A = As; w.lda = Tp; w.B = As; w.ldb = Tp; w.tb = true; w.C = Wp; w.ldc = Mp;
+    w.m = Mp; w.n = Mp; w.k = Tp; w.beta = t0 > 0 ? 1.0 : 0.0; w.lower_only = true;
+    gemm(w, st);
+    rows_dot_y_kernel<<<Mp / 4, 256, 0, st>>>(As, Mp, Tp, Tn, y + t0, t0 > 0 ? 1 : 0, up);
+  }
+  mirror_lower(Wp, Mp, Mp, st);
+  crop_copy(Wp, Mp, W, M, M, M, st);
+  crop_copy(up, 1, u, 1, M, 1, st);
+  yy_kappa_kernel<<<1, 256, 0, st>>>(y, N, kdiag, yy, kappa);
   return check_launch();
 }
 

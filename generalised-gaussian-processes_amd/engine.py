@@ -113,6 +113,28 @@ class HipEngine:
         _lib.check("sgp_suffstats_fwd", st)
         return out
 
+    def suffstats_whitened(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Packed local statistics in the whitened basis, [W = A A^T (M*M) | u = A y (M) | yy | kappa] with A = L^-1 K_uf
+        (PyMC3's op order; ``kuu_linv`` from ``kuu_factor``).  Same layout and all-reduce as ``suffstats``."""
+        N, d = X.shape
+        M = Z.shape[0]
+        self._chk(Z, "Z"), self._chk(kuu_linv, "kuu_linv")
+        if N > 0:
+            self._chk(X, "X"), self._chk(y, "y")
+        if out is None:
+            out = self.empty(M * M + M + 2)
+        nbytes = self.lib.sgp_suffstats_whitened_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("unsupported shape N=%d M=%d d=%d" % (N, M, d))
+        ws = self._workspace("fwd_whitened", nbytes)
+        base = out.data_ptr()
+        st = self.lib.sgp_suffstats_fwd_whitened(
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+            self._ptr(kuu_linv), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_suffstats_fwd_whitened", st)
+        return out
+
     def pack_lower(self, stats: torch.Tensor, M: int) -> torch.Tensor:
         """[lower triangle of Phi | b | yy | kappa]: what crosses xGMI (half the bytes of ``stats``)."""
         tri = self.empty(self.lib.sgp_stats_packed_len(M))
@@ -199,7 +221,8 @@ class HipEngine:
         self._graphs[M] = ent
         return ent
 
-    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None, kuu_info=None, result=None):
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None, kuu_info=None, result=None,
+              whitened=False):
         """Runs the O(M^3) tail on (already all-reduced) packed statistics.
 
         Returns dict(out=[8] device tensor, info=int32 device tensor, buf=the ``result_buffer`` both live in, and
@@ -209,6 +232,8 @@ class HipEngine:
         """
         M = Kuu.shape[0]
         self._chk(Kuu, "Kuu"), self._chk(packed, "packed")
+        if whitened and kuu_linv is None:
+            raise ValueError("bound(whitened=True) needs kuu_linv (the factor the statistics were whitened with)")
         buf, out, info = result if result is not None else self.result_buffer()
         if kuu_linv is not None:
             if kuu_info is not None:
@@ -226,12 +251,14 @@ class HipEngine:
         nbytes = self.lib.sgp_bound_workspace_bytes(M, 1 if with_adjoints else 0)
         ws = self._workspace("bound", nbytes)
         base = packed.data_ptr()
-        st = self.lib.sgp_bound_from_stats(
-            self._ptr(Kuu), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
-            C.c_void_p(base + 8 * (M * M + M + 1)), float(s2), int(N), M, 1 if with_adjoints else 0, self._ptr(out),
-            self._ptr(Phibar), self._ptr(bbar), self._ptr(Kuubar), self._ptr(factors), self._ptr(kuu_linv),
-            self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
-        _lib.check("sgp_bound_from_stats", st)
+        stats = (C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+                 C.c_void_p(base + 8 * (M * M + M + 1)))
+        tail = (float(s2), int(N), M, 1 if with_adjoints else 0, self._ptr(out), self._ptr(Phibar), self._ptr(bbar),
+                self._ptr(Kuubar), self._ptr(factors), self._ptr(kuu_linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        if whitened:
+            _lib.check("sgp_bound_from_whitened_stats", self.lib.sgp_bound_from_whitened_stats(*stats, *tail))
+        else:
+            _lib.check("sgp_bound_from_stats", self.lib.sgp_bound_from_stats(self._ptr(Kuu), *stats, *tail))
         return res
 
     # ------------------------------------------------------------------ pass 2

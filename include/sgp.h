@@ -171,6 +171,28 @@ int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b,
                          const double* kuu_linv /* from sgp_kuu_factor, or NULL */,
                          int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 
+/* ---- whitened statistics: the PyMC3 op order for small / ill-conditioned problems ----------------------------
+ * pm.gp.MarginalSparse (models/bayesian_sgpr_hmc.py:66,71; experiments/co2_bayesian_sgpr_hmc.py:150-158) forms
+ * A = L^-1 K_uf (M x N) and B = I + A A^T / s2.  B is then positive definite by construction and F keeps ~1e-10
+ * absolute accuracy at cond(Kuu) ~ 1e8, where W = L^-1 (K_uf K_fu) L^-T formed from the streamed Phi is off by up
+ * to 1 and chol(B) can fail (profiles/r02_logp_noise.json).  The price is a second N M^2 product and the
+ * materialised A (row chunks of 32768), so this path is for N M up to a few million; the callers of this
+ * library choose it below 2^22 row x inducing pairs.  Same kernel_id / inv_ls conventions as sgp_suffstats_fwd.
+ *   W = A A^T (M x M, ld M), u = A y (M), yy, kappa as in sgp_suffstats_fwd; kuu_linv from sgp_kuu_factor.
+ * Ranks all-reduce [W | u | yy | kappa] exactly like [Phi | b | yy | kappa] (L is replicated).
+ * sgp_bound_from_whitened_stats is sgp_bound_from_stats without the L^-1 . L^-T sandwich; Phibar, bbar, Kuubar are
+ * the adjoints with respect to the UNwhitened Phi, b, Kuu, so sgp_suffstats_bwd / sgp_kuu_bwd follow unchanged.  */
+size_t sgp_suffstats_whitened_workspace_bytes(int64_t N, int M, int d);
+int sgp_suffstats_fwd_whitened(const double* X, int64_t ldx, const double* y,
+                               const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                               int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
+                               double* W, double* u, double* yy, double* kappa,
+                               void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_bound_from_whitened_stats(const double* W, const double* u, const double* yy, const double* kappa,
+                                  double s2, int64_t N, int M, int with_adjoints, double* out,
+                                  double* Phibar, double* bbar, double* Kuubar, double* factors,
+                                  const double* kuu_linv, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+
 /* ---- streaming pass 2: gradients through Kuf -------------------------------------------------------
  * Kbar_uf = 2 Phibar Kuf + bbar y^T is formed tile by tile and contracted with dKuf/d(.) on the fly.
  * Writes (overwrites) g_ls[d] = dF/d lengthscale_j, g_sf2[1] = dF/d sf2 (including the kappa term

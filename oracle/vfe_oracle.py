@@ -195,17 +195,33 @@ def suffstats(X, y, Z, ls, sf2, kernel_id=KERNEL_RBF, chunk=8192):
     return SuffStats(Phi, b, float(y @ y), float(sf2) * X.shape[0], int(X.shape[0]))
 
 
+def suffstats_whitened(X, y, Z, ls, sf2, L, kernel_id=KERNEL_RBF, chunk=8192):
+    """W = A A^T, u = A y with A = L^-1 K_uf (App. A.2 op order), accumulated over row chunks."""
+    X, y, Z, ls, L = _t(X), _t(y), _t(Z), _t(ls), _t(L)
+    M = Z.shape[0]
+    N = X.shape[0]
+    W = torch.zeros(M, M, dtype=DT)
+    u = torch.zeros(M, dtype=DT)
+    for s in range(0, N, chunk):
+        A = torch.linalg.solve_triangular(L, kern(Z, X[s:s + chunk], ls, sf2, kernel_id), upper=False)
+        W += A @ A.T
+        u += A @ y[s:s + chunk]
+    return SuffStats(W, u, float(y @ y), float(N * sf2), N)
+
+
 def kuu(Z, ls, sf2, jitter, kernel_id=KERNEL_RBF):
     Z = _t(Z)
     return kernel_from_r2(sqdist(Z, Z, _t(ls)), sf2, kernel_id) + jitter * torch.eye(Z.shape[0], dtype=DT)
 
 
-def bound_from_stats(Kuu, st: SuffStats, s2, with_adjoints=False, whitened=True):
+def bound_from_stats(Kuu, st: SuffStats, s2, with_adjoints=False, whitened=True, stats_whitened=False):
     """O(M^3) tail.  Returns dict with F, logmarg, trace_term and (optionally) the adjoints of
     F wrt Phi, b, Kuu, s2, kappa.
 
     ``whitened=True`` (default) evaluates the adjoints between L^-T ... L^-1 from B, B^-1 and g = B^-1 L^-1 b:
         2 s2 Phibar = L^-T (I - B^-1 - g g^T / s2^2) L^-1 ;  -2 Kuubar = L^-T (B + B^-1 - 2 I + g g^T / s2^2) L^-1
+    ``stats_whitened=True``: ``st.Phi`` / ``st.b`` already are W = A A^T and u = A y with A = L^-1 K_uf (the PyMC3
+    op order of ``vfe_pymc3_order``, App. A.2); the adjoints returned are still those of the unwhitened Phi, b, Kuu.
     ``whitened=False`` is App. A.5 as written (Kuu^-1 - Sigma^-1 - alpha alpha^T ...): identical in exact arithmetic,
     but it cancels O(cond Kuu) entries -- relative gradient errors of 1e-2 at cond 1e8 against 1e-9 for the whitened
     form (tests/studies/logp_noise.py).  Kept for that A/B only."""
@@ -215,12 +231,15 @@ def bound_from_stats(Kuu, st: SuffStats, s2, with_adjoints=False, whitened=True)
     N = st.N
     I = torch.eye(M, dtype=DT)
     L = torch.linalg.cholesky(Kuu)
-    V = torch.linalg.solve_triangular(L, Phi, upper=False)                  # L^-1 Phi
-    W = torch.linalg.solve_triangular(L, V.T, upper=False).T                # L^-1 Phi L^-T
+    if stats_whitened:
+        W, u = Phi, b
+    else:
+        V = torch.linalg.solve_triangular(L, Phi, upper=False)                  # L^-1 Phi
+        W = torch.linalg.solve_triangular(L, V.T, upper=False).T                # L^-1 Phi L^-T
+        u = torch.linalg.solve_triangular(L, b[:, None], upper=False)[:, 0]     # L^-1 b
     W = 0.5 * (W + W.T)
     B = I + W / s2
     LB = torch.linalg.cholesky(B)
-    u = torch.linalg.solve_triangular(L, b[:, None], upper=False)[:, 0]     # L^-1 b
     logdetB = 2.0 * torch.log(torch.diagonal(LB)).sum()
     trW = torch.diagonal(W).sum()
     q = torch.linalg.solve_triangular(LB, u[:, None], upper=False)[:, 0]    # LB^-1 L^-1 b  (= s2 * c of App. A.3)

@@ -17,7 +17,7 @@ OUT_LEN = 8
 class OracleEngine:
     def __init__(self):
         self.device = torch.device("cpu")
-        self.calls = {"suffstats": 0, "bound": 0, "suffstats_bwd": 0, "kuu_bwd": 0, "predict": 0}
+        self.calls = {"suffstats": 0, "suffstats_whitened": 0, "bound": 0, "suffstats_bwd": 0, "kuu_bwd": 0, "predict": 0}
 
     @staticmethod
     def _ls(ls, d):
@@ -65,17 +65,49 @@ class OracleEngine:
     def kuu(self, Z, ls, sf2, jitter, kernel="rbf"):
         return O.kuu(Z, self._ls(ls, Z.shape[1]), float(sf2), float(jitter), KID[kernel])
 
-    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, result=None):
+    def kuu_factor(self, Kuu, info=None):
+        """(L^-1, info); like the HIP engine the status word is written, never raised."""
+        M = Kuu.shape[0]
+        if info is None:
+            info = torch.zeros(1, dtype=torch.int32)
+        info.zero_()
+        try:
+            L = torch.linalg.cholesky(Kuu)
+        except Exception:
+            info[0] = 1
+            return torch.eye(M, dtype=torch.float64), info
+        return torch.linalg.solve_triangular(L, torch.eye(M, dtype=torch.float64), upper=False), info
+
+    def suffstats_whitened(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None):
+        self.calls["suffstats_whitened"] += 1
+        M, d = Z.shape
+        if X.shape[0] == 0:
+            packed = torch.zeros(M * M + M + 2, dtype=torch.float64)
+        else:
+            L = torch.linalg.solve_triangular(kuu_linv, torch.eye(M, dtype=torch.float64), upper=False)
+            st = O.suffstats_whitened(X, y, Z, self._ls(ls, d), float(sf2), L, KID[kernel])
+            packed = torch.cat([st.Phi.reshape(-1), st.b, torch.tensor([st.yy, st.kappa], dtype=torch.float64)])
+        if out is not None:
+            out.copy_(packed)
+            return out
+        return packed
+
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, result=None, kuu_linv=None, whitened=False):
         self.calls["bound"] += 1
         M = Kuu.shape[0]
         st = O.SuffStats(packed[: M * M].reshape(M, M), packed[M * M: M * M + M], float(packed[M * M + M]),
                          float(packed[M * M + M + 1]), int(N))
         buf, out, info = result if result is not None else self.result_buffer()
         out.zero_()
-        info.zero_()
         res = {"out": out, "info": info, "buf": buf}
+        if kuu_linv is not None and int(info[0]) != 0:  # kuu_factor already failed: the status word stays
+            if with_adjoints:
+                res.update(Phibar=torch.zeros(M, M, dtype=torch.float64), bbar=torch.zeros(M, dtype=torch.float64),
+                           Kuubar=torch.zeros(M, M, dtype=torch.float64))
+            return res
+        info.zero_()
         try:
-            r = O.bound_from_stats(Kuu, st, float(s2), with_adjoints=with_adjoints)
+            r = O.bound_from_stats(Kuu, st, float(s2), with_adjoints=with_adjoints, stats_whitened=whitened)
         except Exception:  # torch.linalg.cholesky failure -> LAPACK-style info like the HIP path
             info[0] = 1
             if with_adjoints:

@@ -22,11 +22,13 @@ def T(a):
     return torch.as_tensor(np.asarray(a), dtype=torch.float64)
 
 
+@pytest.mark.parametrize("form", ["streaming", "whitened"])
 @pytest.mark.parametrize("name", golden_names())
-def test_collapsed_bound_value_and_grad(name):
+def test_collapsed_bound_value_and_grad(name, form):
     G = load_golden(name)
     eng = OracleEngine()
-    cb = ggp_amd.CollapsedBound(T(G["X"]), T(G["y"]), kernel=KNAME[int(G["kernel_id"])], jitter=float(G["jitter"]), engine=eng)
+    cb = ggp_amd.CollapsedBound(T(G["X"]), T(G["y"]), kernel=KNAME[int(G["kernel_id"])], jitter=float(G["jitter"]), engine=eng,
+                                form=form)
     F, parts = cb.value(T(G["Z"]), G["ls"], float(G["sf2"]), float(G["s2"]))
     tol = 1e-9 * max(1.0, abs(float(G["F"])))
     rt, rz = float(G["grad_rtol"]), float(G["gz_rtol"])
@@ -38,7 +40,9 @@ def test_collapsed_bound_value_and_grad(name):
     assert abs(g["sf2"] - float(G["g_sf2"])) < rt * max(1.0, abs(float(G["g_sf2"])))
     assert abs(g["s2"] - float(G["g_s2"])) < rt * max(1.0, abs(float(G["g_s2"])))
     assert float((g["Z"] - T(G["g_Z"])).abs().max()) < rz * max(1.0, float(T(G["g_Z"]).abs().max()))
-    assert eng.calls["suffstats"] == 2 and eng.calls["suffstats_bwd"] == 1 and eng.calls["kuu_bwd"] == 1
+    assert eng.calls["suffstats" if form == "streaming" else "suffstats_whitened"] == 2
+    assert eng.calls["suffstats_whitened" if form == "streaming" else "suffstats"] == 0
+    assert eng.calls["suffstats_bwd"] == 1 and eng.calls["kuu_bwd"] == 1
     mean, var, _ = cb.predict(T(G["Xs"]), T(G["Z"]), G["ls"], float(G["sf2"]), float(G["s2"]))
     assert float((mean - T(G["pred_mean"])).abs().max()) < 1e-8 and float((var - T(G["pred_var"])).abs().max()) < 1e-8
 
