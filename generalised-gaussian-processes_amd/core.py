@@ -70,7 +70,7 @@ class CollapsedBound:
                           workloads: N ~ 250-1300, M ~ 100-480), streaming above.
     """
 
-    WHITENED_MAX_WORK = 1 << 22  # local rows x inducing points up to which form="auto" means "whitened"
+    WHITENED_MAX_WORK = 1 << 20  # local rows x inducing points up to which form="auto" means "whitened"
 
     def __init__(self, X, y, kernel="rbf", jitter=0.0, engine=None, group=None, form="auto"):
         if engine is None:

@@ -177,7 +177,7 @@ int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b,
  * absolute accuracy at cond(Kuu) ~ 1e8, where W = L^-1 (K_uf K_fu) L^-T formed from the streamed Phi is off by up
  * to 1 and chol(B) can fail (profiles/r02_logp_noise.json).  The price is a second N M^2 product and the
  * materialised A (row chunks of 32768), so this path is for N M up to a few million; the callers of this
- * library choose it below 2^22 row x inducing pairs.  Same kernel_id / inv_ls conventions as sgp_suffstats_fwd.
+ * library choose it below 2^20 row x inducing pairs.  Same kernel_id / inv_ls conventions as sgp_suffstats_fwd.
  *   W = A A^T (M x M, ld M), u = A y (M), yy, kappa as in sgp_suffstats_fwd; kuu_linv from sgp_kuu_factor.
  * Ranks all-reduce [W | u | yy | kappa] exactly like [Phi | b | yy | kappa] (L is replicated).
  * sgp_bound_from_whitened_stats is sgp_bound_from_stats without the L^-1 . L^-T sandwich; Phibar, bbar, Kuubar are

@@ -156,3 +156,61 @@ def test_two_rank_gloo_matches_single_process(name):
         assert np.abs(mean - G["pred_mean"]).max() < 1e-8 and np.abs(var - G["pred_var"]).max() < 1e-8
     # replicated tail: both ranks hold bit-identical results
     assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][5], outs[1][5])
+
+
+# ---------------------------------------------------------------------------------------------
+# world_size = 2: NUTS with the DEFAULT seed -- every rank must build the same trees (each leapfrog issues
+# collectives: ranks that draw different momenta would issue different numbers of all-reduces and hang)
+# ---------------------------------------------------------------------------------------------
+def _nuts_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ggp_amd as pkg
+    from fake_engine import OracleEngine as Eng
+    from conftest import load_golden as lg
+    G = lg("rbf_d3_small")
+    X, y, Z = T(G["X"]), T(G["y"]), T(G["Z"])
+    lo, hi = pkg.shard_rows(X.shape[0], rank, world)
+    cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=1e-6, engine=Eng())
+    tgt = pkg.HmcTarget(cb, Z)
+    np.random.seed(1234 + rank)  # whatever the ranks' global RNG state is, the chains must coincide
+    tr = pkg.sample_nuts(tgt, n_samples=5, tune=5, seed=None)
+    thetas = np.stack([row["theta_unc"] for row in tr])
+    q.put((rank, thetas, int(tr.n_leapfrog), int(cb.n_collectives), tr.get_sampler_stats("tree_size")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_nuts_default_seed_builds_identical_trees():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nuts_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    outs.sort(key=lambda t: t[0])
+    (_, th0, nl0, nc0, ts0), (_, th1, nl1, nc1, ts1) = outs
+    assert np.array_equal(th0, th1), "ranks drew different chains"
+    assert nl0 == nl1 and np.array_equal(ts0, ts1)
+    assert nc0 == nc1 and nc0 == 2 * nl0  # one statistics + one gradient all-reduce per leapfrog
+    assert th0.shape == (5, 5) and np.all(np.isfinite(th0))
+
+
+def test_lower_triangle_exchange_round_trip():
+    eng = OracleEngine()
+    M = 7
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(M, M, dtype=torch.float64, generator=g)
+    stats = torch.cat([(A + A.T).reshape(-1), torch.randn(M + 2, dtype=torch.float64, generator=g)])
+    tri = eng.pack_lower(stats, M)
+    assert tri.numel() == M * (M + 1) // 2 + M + 2
+    back = eng.unpack_lower(tri, M, torch.zeros_like(stats))
+    assert torch.equal(back, stats)

@@ -31,13 +31,15 @@ def main():
                           ("value_and_grad_Z_per_s", lambda: cb.value_and_grad(Z, ls, 1.0, 0.09, want_gz=True))):
             for _ in range(3):
                 fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            k = 30
-            for _ in range(k):
-                fn()
-            torch.cuda.synchronize()
-            res[label] = k / (time.perf_counter() - t0)
+            k, best = 30, float("inf")
+            for _ in range(3):  # best of three timed loops: these boxes stall a launch for 10-70 ms about once in a hundred
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    fn()
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            res[label] = k / best
         print(json.dumps(res))
     # C4: BayesianSVGP-shaped minibatch step (N = 100k, d = 2, M = 256, B = 4096): one bound + full gradient per call
     N, d, M, B = 100_000, 2, 256, 4096
@@ -59,15 +61,17 @@ def main():
 
         for i in range(3):
             step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        k = 30
-        for i in range(k):
-            o = step(i)
-        float(o[0])
-        torch.cuda.synchronize()
+        k, best = 30, float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                o = step(i)
+            float(o[0])
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
         print(json.dumps({"config": "C4 SVGP minibatch step (%s)" % lik, "N": N, "d": d, "M": M, "batch": B,
-                          "bound_and_grad_per_s": k / (time.perf_counter() - t0)}))
+                          "bound_and_grad_per_s": k / best}))
 
 
 if __name__ == "__main__":
