@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libsgp_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["sgp_suffstats_fwd.hip", "sgp_suffstats_bwd.hip", "sgp_dense.hip", "sgp_tail.hip", "sgp_svgp.hip", "sgp_composite.hip"]
+SOURCES = ["sgp_suffstats_fwd.hip", "sgp_suffstats_bwd.hip", "sgp_dense.hip", "sgp_tail.hip", "sgp_svgp.hip", "sgp_composite.hip", "sgp_small.hip"]
 HEADERS = ["sgp_common.hpp", "sgp_dense.hpp", "sgp_potrf.hpp", "sgp_stream.hpp", "sgp_composite.hpp", os.path.join("..", "..", "include", "sgp.h")]
 ARCH = "gfx950"
 

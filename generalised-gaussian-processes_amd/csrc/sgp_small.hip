@@ -1,0 +1,809 @@
+// Single-launch evaluation of the collapsed bound and its gradient for SMALL problems (M <= 128) -- the size class of
+// every HMC run the reference publishes (models/bayesian_sgpr_hmc.py:58-80,144-157: N ~ 250-1300, M = 100; BASELINE
+// configs C1 / C2).  The multi-launch path needs ~60 dependent kernels per leapfrog there (0.39 ms for microseconds of
+// arithmetic); here ONE cooperative launch does everything, with the hyper-parameters read from DEVICE memory (so a
+// sampler can keep its state on the GPU) and in the PyMC3 op order:
+//
+//     Kuu = k(Z,Z) + J I ; L = chol(Kuu) ; A = L^-1 K_uf ; B = I + A A^T / s2 ; LB = chol(B) ; c0 = LB^-1 (A y)
+//     F = -[ N/2 log 2pi + N/2 log s2 + sum log diag LB + (yy/s2 - c0.c0/s2^2)/2 + (kappa - sum A o A)/(2 s2) ]
+//
+// B is positive definite by construction and nothing of size cond(Kuu) is ever subtracted: every solve is a blocked
+// forward / backward substitution on the matrix cores (16-column panels, 16 x 16 diagonal-block inverses from the
+// factorization), never an explicit L^-1.  Reverse pass, closed form in the same basis (g = B^-1 A y):
+//     Abar  = [ (I - B^-1 - g g^T / s2^2) A + g y^T / s2 ] / s2          column by column:  two solves with LB
+//     Kbar_uf = L^-T Abar                                                  one solve with L^T, contracted with dK_uf on the fly
+//     Kbar_uu = -1/2 L^-T (B + B^-1 - 2 I + g g^T / s2^2) L^-1             the same solves applied to the columns of I
+//
+// Work decomposition (one workgroup = 4 waves; all workgroups co-resident, <= 66 of the 256 CUs):
+//     workgroup 0            the chain: Kuu, chol(Kuu), [wait] chol(B) with c0 riding along, g, F, final reduction
+//     workgroup 1            Kbar_uu ("virtual slabs": the columns of I go through the slab pipeline), tr B^-1
+//     workgroups 2 ..        row slabs of 64 data rows: assemble K_uf straight into the MFMA accumulator layout, solve,
+//                            partial A A^T / A y; later the reverse pass of the same rows
+// A slab lives in REGISTERS during the solves: lane (wave w, l15, l4) holds element (row 16 w + l15, column 16 pb + 4 s
+// + l4) in component s of block pb -- transposed 16 x 16 blocks in the accumulator layout, which is also the B-operand
+// layout of the next MFMA, so X_pb^T = Dinv_pb Y_pb and Y_q -= L[q][pb] X_pb^T chain without leaving the registers.
+// Synchronisation: agent-scope flags / counters behind release fences, acquire fences after every wait (the buffers are
+// rewritten on every evaluation, so stale L2 lines of another XCD must be dropped); spins are bounded (SGP_INFO_TIMEOUT).
+// All cross-workgroup sums go through partial arrays reduced in a fixed order: results are bit-reproducible.
+#include "sgp_potrf.hpp"
+
+namespace sgp {
+
+constexpr int SM_SLAB = 64;
+constexpr int SM_MAXD = 16;
+constexpr int SM_MAX_ROWWG = 64;
+constexpr int SM_SPIN_LIMIT = 1 << 22;
+constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_WORDS = 6 };
+constexpr int SM_GP = SM_MAXD + 4;  // doubles per gradient partial: g_ls[d] at 0.., then g_sf2, tr B^-1
+
+struct SmallArgs {
+  const double* X; int64_t ldx; const double* y; const double* Z; int64_t ldz; const double* theta;
+  int N, M, d, kid, mode, want_grad, want_gz;
+  double jitter;
+  int nslab, grow;
+  double *Lk, *dinvK, *Bm, *Lb, *dinvB, *A, *Ppart, *upart, *spart, *u, *c0, *g, *gpart, *gzpart, *Qm;
+  int *flagsK, *flagsB, *sync, *info;
+  double* out;
+  double* gZ;
+};
+
+struct SmHyp {
+  double inv_ls[SM_MAXD], ls[SM_MAXD];
+  double sf2, s2;
+  int ok;
+};
+
+template <int MP>
+struct SmSlabShared {
+  static constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2, SLD = MP + 2;
+  union {
+    double Lblk[NBL][16][17];  // lower 16 x 16 blocks of the current triangular factor, block (q, p) at q (q + 1) / 2 + p
+    double S[SM_SLAB][SLD];    // a solved slab, [row][column] (SYRK operands, column sums, the E matrix of dF/dZ)
+  };
+  double Dinv[NB16][16][17];   // inverses of its diagonal blocks
+  double zs[MP][SM_MAXD + 1];  // scaled inducing inputs
+  double xs[SM_SLAB][SM_MAXD + 1];
+  double ys[SM_SLAB];
+  double gv[MP];
+  double red[4][MP];
+  double gz[MP * SM_MAXD];
+  double acc[SM_GP];
+};
+
+template <int MP>
+union SmShared {
+  DfShared df;
+  SmSlabShared<MP> sl;
+};
+
+__device__ __forceinline__ int sm_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// every thread of the workgroup calls; false = the launch has been aborted
+__device__ __forceinline__ bool sm_wait_ge(int* word, int target, int* abort_word, int* dead) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (sm_ld(word) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      ++spins;
+      if ((spins & 127) == 0 && sm_ld(abort_word) != 0) { *dead = 1; break; }
+      if (spins > SM_SPIN_LIMIT) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *dead = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return *dead == 0;
+}
+__device__ __forceinline__ void sm_publish_set(int* word, int v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sm_publish_add(int* word) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double sm_kprofile(int kid, double r2) {
+  if (kid == SGP_KERNEL_RBF) return kprofile<SGP_KERNEL_RBF>(r2);
+  if (kid == SGP_KERNEL_MATERN32) return kprofile<SGP_KERNEL_MATERN32>(r2);
+  return kprofile<SGP_KERNEL_MATERN52>(r2);
+}
+__device__ __forceinline__ void sm_kprofile_grad(int kid, double r2, double& k, double& h) {
+  if (kid == SGP_KERNEL_RBF) kprofile_grad<SGP_KERNEL_RBF>(r2, k, h);
+  else if (kid == SGP_KERNEL_MATERN32) kprofile_grad<SGP_KERNEL_MATERN32>(r2, k, h);
+  else kprofile_grad<SGP_KERNEL_MATERN52>(r2, k, h);
+}
+
+// theta -> hyper-parameters (thread 0), the same arithmetic in every workgroup.
+//   mode 0: theta = [ls_1..d | sf2 | s2] ;  mode 1: theta = [log ls_1..d | log sig_f | log sig_n]
+__device__ __forceinline__ void sm_hypers(const SmallArgs& a, SmHyp& h) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    for (int j = 0; j < a.d; ++j) {
+      const double t = a.theta[j];
+      const double l = a.mode ? exp(t) : t;
+      if (!(fabs(t) < 300.0) || !(l > 0.0)) ok = 0;
+      h.ls[j] = l;
+      h.inv_ls[j] = 1.0 / l;
+    }
+    for (int j = a.d; j < SM_MAXD; ++j) { h.ls[j] = 1.0; h.inv_ls[j] = 0.0; }
+    const double tf = a.theta[a.d], tn = a.theta[a.d + 1];
+    h.sf2 = a.mode ? exp(2.0 * tf) : tf;
+    h.s2 = a.mode ? exp(2.0 * tn) : tn;
+    if (!(fabs(tf) < 300.0) || !(fabs(tn) < 300.0) || !(h.sf2 > 0.0) || !(h.s2 > 0.0)) ok = 0;
+    if (a.mode && (fabs(tf) > 150.0 || fabs(tn) > 150.0)) ok = 0;
+    h.ok = ok;
+  }
+  __syncthreads();
+}
+
+// ---- register-resident slab: NB16 transposed 16 x 16 blocks per wave ---------------------------------------------
+template <int NB16>
+struct SlabRegs {
+  d4 b[NB16];
+};
+__device__ __forceinline__ int sm_blk(int q, int p) { return q * (q + 1) / 2 + p; }
+
+// Y <- Y L^-T  (every slab row t solves L a = t)
+template <int NB16>
+__device__ __forceinline__ void sm_trsm_fwd(SlabRegs<NB16>& Y, const double (*Lb)[16][17], const double (*Di)[16][17], int l15, int l4) {
+#pragma unroll
+  for (int pb = 0; pb < NB16; ++pb) {
+    d4 xa = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) xa = mfma16(Di[pb][l15][4 * sq + l4], Y.b[pb][sq], xa);
+    Y.b[pb] = xa;
+#pragma unroll
+    for (int q = pb + 1; q < NB16; ++q)
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) Y.b[q] = mfma16(-Lb[sm_blk(q, pb)][l15][4 * sq + l4], xa[sq], Y.b[q]);
+  }
+}
+// Y <- Y L^-1  (every slab row t solves L^T x = t)
+template <int NB16>
+__device__ __forceinline__ void sm_trsm_bwd(SlabRegs<NB16>& Y, const double (*Lb)[16][17], const double (*Di)[16][17], int l15, int l4) {
+#pragma unroll
+  for (int pb = NB16 - 1; pb >= 0; --pb) {
+    d4 xa = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) xa = mfma16(Di[pb][4 * sq + l4][l15], Y.b[pb][sq], xa);
+    Y.b[pb] = xa;
+#pragma unroll
+    for (int q = 0; q < pb; ++q)
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) Y.b[q] = mfma16(-Lb[sm_blk(pb, q)][4 * sq + l4][l15], xa[sq], Y.b[q]);
+  }
+}
+
+// global lower-triangular factor (ld MP) + its 16 x 16 diagonal-block inverses (potrf's dinv_g layout) -> LDS blocks
+template <int MP>
+__device__ __forceinline__ void sm_stage_factor(SmSlabShared<MP>& sl, const double* __restrict__ L, const double* __restrict__ dinv) {
+  constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2;
+  const int t = threadIdx.x, r = t >> 4, c = t & 15;
+  int q = 0, p = 0;
+  for (int b = 0; b < NBL; ++b) {
+    sl.Lblk[b][r][c] = L[(size_t)(16 * q + r) * MP + 16 * p + c];
+    if (++p > q) { p = 0; ++q; }
+  }
+  for (int b = 0; b < NB16; ++b) sl.Dinv[b][r][c] = dinv[(size_t)(b >> 2) * 1024 + (b & 3) * 256 + t];
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------
+template <int MP>
+__global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
+  constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2, NBW = (NBL + 3) / 4, NB64 = MP / 64;
+  __shared__ SmShared<MP> sh;
+  __shared__ SmHyp hyp;
+  __shared__ int dead;
+  __shared__ double redw[4];
+  SmSlabShared<MP>& sl = sh.sl;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int wg = blockIdx.x;
+  const int d = a.d, M = a.M, N = a.N;
+  int* sy = a.sync;
+  int* abortw = sy + SY_ABORT * SM_SYNC_STRIDE;
+  if (tid == 0) dead = 0;
+  sm_hypers(a, hyp);
+  const double sf2 = hyp.sf2, s2 = hyp.s2;
+  const int role = wg == 0 ? 0 : (wg == 1 ? 1 : 2);
+  const int ngrad = a.grow + 1;  // workgroups that contribute gradient partials
+
+  if (!hyp.ok) {  // theta outside the representable range: density zero, never an exception (PyMC3: non-finite logp)
+    if (wg == 0 && tid <= d + 2) a.out[tid] = tid == 0 ? -INFINITY : 0.0;
+    if (wg == 0 && tid == 0) *a.info = 0;
+    return;
+  }
+
+  // scaled inducing inputs (rows >= M zero)
+  auto stage_z = [&]() {
+    for (int e = tid; e < MP * (SM_MAXD + 1); e += 256) {
+      const int m = e / (SM_MAXD + 1), j = e - m * (SM_MAXD + 1);
+      sl.zs[m][j] = (m < M && j < d) ? a.Z[(size_t)m * a.ldz + j] * hyp.inv_ls[j] : 0.0;
+    }
+  };
+  // r2 of this lane's element (pb, s) against slab row nl:  acc over j outside
+  auto block_sum = [&](double v) -> double {  // sum over the 256 threads, valid everywhere
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) redw[w] = v;
+    __syncthreads();
+    return (redw[0] + redw[1]) + (redw[2] + redw[3]);
+  };
+
+  // =================================================================================================================
+  if (role == 0) {
+    // ---- Kuu -> Lk, factor --------------------------------------------------------------------------------------
+    const int nflag = (NB64 * (NB64 + 1) / 2 + 1) * DF_FLAG_STRIDE;
+    for (int e = tid; e < nflag; e += 256) { a.flagsK[e] = 0; a.flagsB[e] = 0; }
+    if (tid == 0) *a.info = 0;
+    for (int e = tid; e < MP * MP; e += 256) {
+      const int i = e / MP, j = e - i * MP;
+      double v = i == j ? 1.0 : 0.0;
+      if (i < M && j < M) {
+        double r2 = 0.0;
+        for (int q = 0; q < d; ++q) {
+          const double df = (a.Z[(size_t)i * a.ldz + q] - a.Z[(size_t)j * a.ldz + q]) * hyp.inv_ls[q];
+          r2 = fma(df, df, r2);
+        }
+        v = sf2 * sm_kprofile(a.kid, r2) + (i == j ? a.jitter : 0.0);
+      }
+      a.Lk[e] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) sh.df.dead = 0;
+    __syncthreads();
+    potrf_dataflow_body(a.Lk, MP, NB64, a.flagsK, a.dinvK, a.info, 0, nullptr, nullptr, nullptr, sh.df, 0, 1);
+    sm_publish_set(sy + SY_L * SM_SYNC_STRIDE, 1);
+
+    // ---- B complete -> LB, c0 = LB^-1 u --------------------------------------------------------------------------
+    if (!sm_wait_ge(sy + SY_SLICE * SM_SYNC_STRIDE, a.grow, abortw, &dead)) {
+      if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
+      return;
+    }
+    for (int e = tid; e < MP * MP; e += 256) a.Lb[e] = a.Bm[e];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) sh.df.dead = 0;
+    __syncthreads();
+    potrf_dataflow_body(a.Lb, MP, NB64, a.flagsB, a.dinvB, a.info, M, a.u, a.c0, nullptr, sh.df, 0, 1);
+    __threadfence();
+    __syncthreads();
+    // g = LB^-T c0 : backward substitution, 64 x 64 tiles from the last to the first (wave 0; lane <-> row)
+    if (w == 0) {
+      for (int jb = NB64 - 1; jb >= 0; --jb) {
+        double rr = a.c0[jb * 64 + lane];
+        for (int p = jb + 1; p < NB64; ++p) {  // - sum_p LB(p, jb)^T g_p
+          double s = 0.0;
+          for (int k = 0; k < 64; ++k) s = fma(a.Lb[(size_t)(p * 64 + k) * MP + jb * 64 + lane], a.g[p * 64 + k], s);
+          rr -= s;
+        }
+        const double dinv = 1.0 / a.Lb[(size_t)(jb * 64 + lane) * (MP + 1)];
+        double mine = 0.0;
+        for (int c = 63; c >= 0; --c) {
+          const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
+          if (lane == c) mine = xc;
+          rr = fma(-a.Lb[(size_t)(jb * 64 + c) * MP + jb * 64 + lane], xc, rr);  // column `lane` of row c: LB^T[lane][c]
+        }
+        a.g[jb * 64 + lane] = mine;
+        __threadfence();
+      }
+    }
+    __syncthreads();
+    // scalars
+    double ld = 0.0, cc = 0.0, ug = 0.0, gg = 0.0;
+    for (int i = tid; i < MP; i += 256) {
+      ld += log(a.Lb[(size_t)i * (MP + 1)]);
+      cc = fma(a.c0[i], a.c0[i], cc);
+      ug = fma(a.u[i], a.g[i], ug);
+      gg = fma(a.g[i], a.g[i], gg);
+    }
+    ld = block_sum(ld);
+    cc = block_sum(cc);
+    ug = block_sum(ug);
+    gg = block_sum(gg);
+    const double sumA2 = a.spart[0], yy = a.spart[1];  // reduced by the slice stage
+    const double Nd = (double)N, kappa = Nd * sf2;
+    const double LOG2PI = 1.8378770664093453;
+    const double quad = yy / s2 - cc / (s2 * s2);
+    const double logmarg = -(0.5 * Nd * LOG2PI + 0.5 * Nd * log(s2) + ld + 0.5 * quad);
+    const double trace_term = (kappa - sumA2) / (2.0 * s2);
+    const double F = logmarg - trace_term;
+    if (sm_ld(abortw) != 0 && tid == 0) *a.info = SGP_INFO_TIMEOUT;
+    if (!a.want_grad) {
+      if (tid == 0) {
+        a.out[0] = F;
+        a.out[d + 3] = logmarg;
+        a.out[d + 4] = trace_term;
+      }
+      __syncthreads();
+      for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;  // ready for the next launch
+      return;
+    }
+    sm_publish_set(sy + SY_LB * SM_SYNC_STRIDE, 1);
+
+    // ---- gradients --------------------------------------------------------------------------------------------------
+    if (!sm_wait_ge(sy + SY_GRAD * SM_SYNC_STRIDE, ngrad, abortw, &dead)) {
+      if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
+      return;
+    }
+    if (tid < SM_GP) {
+      double s = 0.0;
+      for (int g = 0; g < ngrad; ++g) s += a.gpart[(size_t)g * SM_GP + tid];
+      sl.acc[tid] = s;
+    }
+    if (a.want_gz && a.gZ) {
+      for (int e = tid; e < M * d; e += 256) {
+        double s = 0.0;
+        for (int g = 0; g < ngrad; ++g) s += a.gzpart[(size_t)g * MP * SM_MAXD + e];
+        a.gZ[e] = s;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double trBinv = sl.acc[SM_MAXD + 1];
+      const double g_sf2 = sl.acc[SM_MAXD] - Nd / (2.0 * s2);  // + kappabar dkappa/dsf2
+      const double s22 = s2 * s2;
+      const double g_s2 = -0.5 * (-((double)MP - trBinv) / s2 + Nd / s2 - yy / s22 + 2.0 * ug / (s22 * s2) - (ug - gg) / (s22 * s2)
+                                  - kappa / s22 + sumA2 / s22);
+      if (a.mode == 0) {
+        a.out[0] = F;
+        for (int j = 0; j < d; ++j) a.out[1 + j] = sl.acc[j];
+        a.out[1 + d] = g_sf2;
+        a.out[2 + d] = g_s2;
+      } else {
+        // NUTS target of models/bayesian_sgpr_hmc.py:60-71: ls ~ Gamma(2, 1), sig_f, sig_n ~ HalfCauchy(1), log transforms
+        double lp = F, sumth = 0.0;
+        const double c = log(2.0) - log(3.141592653589793);
+        for (int j = 0; j < d; ++j) {
+          const double l = hyp.ls[j];
+          lp += log(l) - l;
+          sumth += a.theta[j];
+          a.out[1 + j] = l * (sl.acc[j] + 1.0 / l - 1.0) + 1.0;
+        }
+        const double sf = exp(a.theta[d]), sn = exp(a.theta[d + 1]);
+        lp += (c - log1p(sf * sf)) + (c - log1p(sn * sn));
+        sumth += a.theta[d] + a.theta[d + 1];
+        a.out[1 + d] = sf * (2.0 * sf * g_sf2 - 2.0 * sf / (1.0 + sf * sf)) + 1.0;
+        a.out[2 + d] = sn * (2.0 * sn * g_s2 - 2.0 * sn / (1.0 + sn * sn)) + 1.0;
+        a.out[0] = lp + sumth;
+      }
+      a.out[d + 3] = logmarg;
+      a.out[d + 4] = trace_term;
+    }
+    __syncthreads();
+    for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;
+    return;
+  }
+
+  // =================================================================================================================
+  // slab pipeline shared by the row workgroups (role 2) and the Kuu-adjoint workgroup (role 1)
+  // contraction of kbar (in Y, dF/dK_uf of this slab) with dK/d(ls, sf2, Z); data rows in sl.xs (scaled), validity masks
+  auto contract = [&](const SlabRegs<NB16>& Y, int nvalid, double zscale) {
+    // nvalid: slab rows that are real ; zscale: 1 for K_uf, 2 for the symmetric K_uu (both arguments are inducing inputs)
+    const int nl = 16 * w + l15;
+    double E[NB16][4];
+    double ksum = 0.0;
+    {
+      double r2[NB16][4];
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r2[pb][s] = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double xj = sl.xs[nl][j];
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double df = xj - sl.zs[16 * pb + 4 * s + l4][j];
+            r2[pb][s] = fma(df, df, r2[pb][s]);
+          }
+      }
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          double kp, hp;
+          sm_kprofile_grad(a.kid, r2[pb][s], kp, hp);
+          const bool live = nl < nvalid && (16 * pb + 4 * s + l4) < M;
+          const double kb = live ? Y.b[pb][s] : 0.0;
+          ksum = fma(kb, kp, ksum);
+          E[pb][s] = kb * sf2 * hp;
+        }
+    }
+    ksum = wave_sum(ksum);
+    if (lane == 0) sl.red[w][SM_MAXD] = ksum;
+    for (int j = 0; j < d; ++j) {
+      const double xj = sl.xs[nl][j];
+      double sj = 0.0;
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double df = xj - sl.zs[16 * pb + 4 * s + l4][j];
+          sj = fma(E[pb][s] * df, df, sj);
+        }
+      sj = wave_sum(sj);
+      if (lane == 0) sl.red[w][j] = -2.0 * hyp.inv_ls[j] * sj;  // d r2 / d ls_j = -2 df_j^2 / ls_j
+    }
+    __syncthreads();
+    if (tid <= SM_MAXD && (tid < d || tid == SM_MAXD)) sl.acc[tid] += (sl.red[0][tid] + sl.red[1][tid]) + (sl.red[2][tid] + sl.red[3][tid]);
+    if (a.want_gz) {
+      // E -> LDS (over the factor blocks: the solves of this slab are done), then thread <-> (m, j)
+      __syncthreads();
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sl.S[nl][16 * pb + 4 * s + l4] = E[pb][s];
+      __syncthreads();
+      for (int e = tid; e < M * d; e += 256) {
+        const int m = e / d, j = e - m * d;
+        const double zj = sl.zs[m][j];
+        double s = 0.0;
+        for (int r = 0; r < SM_SLAB; ++r) s = fma(sl.S[r][m], sl.xs[r][j] - zj, s);
+        sl.gz[e] += -2.0 * zscale * hyp.inv_ls[j] * s;  // d r2 / d z_mj = -2 (x~ - z~) / ls_j
+      }
+    }
+    __syncthreads();
+  };
+
+  stage_z();
+  if (tid < SM_GP) sl.acc[tid] = 0.0;
+  if (a.want_gz)
+    for (int e = tid; e < MP * SM_MAXD; e += 256) sl.gz[e] = 0.0;
+  __syncthreads();
+
+  if (role == 2) {
+    const int rw = wg - 2;
+    // ---- forward: A = L^-1 K_uf for this workgroup's slabs, partial A A^T, A y, sum A o A, yy -----------------------
+    if (!sm_wait_ge(sy + SY_L * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+    d4 pacc[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) pacc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double uacc = 0.0, a2acc = 0.0, yyacc = 0.0;  // thread m < MP: column sums over this workgroup's slabs
+    for (int sb = rw; sb < a.nslab; sb += a.grow) {
+      const int n0 = sb * SM_SLAB;
+      __syncthreads();
+      sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
+      for (int e = tid; e < SM_SLAB * (SM_MAXD + 1); e += 256) {
+        const int r = e / (SM_MAXD + 1), j = e - r * (SM_MAXD + 1);
+        sl.xs[r][j] = (n0 + r < N && j < d) ? a.X[(size_t)(n0 + r) * a.ldx + j] * hyp.inv_ls[j] : 0.0;
+      }
+      if (tid < SM_SLAB) sl.ys[tid] = n0 + tid < N ? a.y[n0 + tid] : 0.0;
+      __syncthreads();
+      SlabRegs<NB16> Y;
+      {  // K_uf of this slab straight into the register layout
+        const int nl = 16 * w + l15;
+        double r2[NB16][4];
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) r2[pb][s] = 0.0;
+        for (int j = 0; j < d; ++j) {
+          const double xj = sl.xs[nl][j];
+#pragma unroll
+          for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const double df = xj - sl.zs[16 * pb + 4 * s + l4][j];
+              r2[pb][s] = fma(df, df, r2[pb][s]);
+            }
+        }
+        const bool rowlive = n0 + nl < N;
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            Y.b[pb][s] = (rowlive && (16 * pb + 4 * s + l4) < M) ? sf2 * sm_kprofile(a.kid, r2[pb][s]) : 0.0;
+      }
+      sm_trsm_fwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+      __syncthreads();  // everybody is done with the factor blocks: the slab takes their place
+      {
+        const int nl = 16 * w + l15;
+        double* arow = a.A + (size_t)(n0 + nl) * MP;
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sl.S[nl][16 * pb + 4 * s + l4] = Y.b[pb][s];
+            arow[16 * pb + 4 * s + l4] = Y.b[pb][s];
+          }
+      }
+      __syncthreads();
+      if (tid < MP) {
+        double su = 0.0, sa = 0.0;
+        for (int r = 0; r < SM_SLAB; ++r) {
+          const double v = sl.S[r][tid];
+          su = fma(v, sl.ys[r], su);
+          sa = fma(v, v, sa);
+        }
+        uacc += su;
+        a2acc += sa;
+      } else if (tid < MP + SM_SLAB && tid - MP < SM_SLAB) {
+        // (only reached when MP < 256 - 64) y^2 of this slab, one row per thread
+        const double v = sl.ys[tid - MP];
+        yyacc = fma(v, v, yyacc);
+      }
+      // partial A^T A: lower 16 x 16 blocks dealt round-robin to the waves
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        const int b = 4 * i + w;
+        if (b < NBL) {
+          int bi = 0;
+          while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+          const int bj = b - bi * (bi + 1) / 2;
+#pragma unroll
+          for (int ks = 0; ks < SM_SLAB / 4; ++ks)
+            pacc[i] = mfma16(sl.S[4 * ks + l4][16 * bi + l15], sl.S[4 * ks + l4][16 * bj + l15], pacc[i]);
+        }
+      }
+    }
+    __syncthreads();
+    {  // partials of this workgroup -> global
+      double* P = a.Ppart + (size_t)rw * MP * MP;
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        const int b = 4 * i + w;
+        if (b < NBL) {
+          int bi = 0;
+          while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+          const int bj = b - bi * (bi + 1) / 2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[(size_t)(16 * bi + l4 + 4 * r) * MP + 16 * bj + l15] = pacc[i][r];
+        }
+      }
+      if (tid < MP) a.upart[(size_t)rw * MP + tid] = uacc;
+      const double sa = block_sum(tid < MP ? a2acc : 0.0);
+      const double sy2 = block_sum(tid >= MP ? yyacc : 0.0);
+      if (tid == 0) {
+        a.spart[2 + 2 * rw] = sa;
+        a.spart[3 + 2 * rw] = sy2;
+      }
+    }
+    sm_publish_add(sy + SY_PART * SM_SYNC_STRIDE);
+    if (!sm_wait_ge(sy + SY_PART * SM_SYNC_STRIDE, a.grow, abortw, &dead)) return;
+    // ---- slices: B = I + sum_g P_g / s2 (mirrored), u, scalars -- fixed order over g ---------------------------------
+    {
+      const double is2 = 1.0 / s2;
+      for (int e = rw * 256 + tid; e < NBL * 256; e += a.grow * 256) {
+        const int b = e >> 8, i = (e >> 4) & 15, j = e & 15;
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2;
+        const int gi = 16 * bi + i, gj = 16 * bj + j;
+        if (gi < gj) continue;  // upper half of a diagonal block
+        double s = 0.0;
+        for (int g = 0; g < a.grow; ++g) s += a.Ppart[(size_t)g * MP * MP + (size_t)gi * MP + gj];
+        const double v = (gi == gj ? 1.0 : 0.0) + s * is2;
+        a.Bm[(size_t)gi * MP + gj] = v;
+        a.Bm[(size_t)gj * MP + gi] = v;
+      }
+      if (rw == 0) {
+        if (tid < MP) {
+          double s = 0.0;
+          for (int g = 0; g < a.grow; ++g) s += a.upart[(size_t)g * MP + tid];
+          a.u[tid] = s;
+        }
+        if (tid == 0) {
+          double sa = 0.0, sy2 = 0.0;
+          for (int g = 0; g < a.grow; ++g) {
+            sa += a.spart[2 + 2 * g];
+            sy2 += a.spart[3 + 2 * g];
+          }
+          a.spart[0] = sa;
+          a.spart[1] = sy2;
+        }
+      }
+    }
+    sm_publish_add(sy + SY_SLICE * SM_SYNC_STRIDE);
+    if (!a.want_grad) return;
+
+    // ---- reverse: Abar per slab (two solves with LB), Kbar_uf = Abar L^-1 (one solve with L^T), contraction ----------
+    if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+    if (tid < MP) sl.gv[tid] = a.g[tid];
+    const double is2 = 1.0 / s2, is22 = is2 * is2;
+    for (int sb = rw; sb < a.nslab; sb += a.grow) {
+      const int n0 = sb * SM_SLAB, nl = 16 * w + l15;
+      __syncthreads();
+      sm_stage_factor<MP>(sl, a.Lb, a.dinvB);
+      for (int e = tid; e < SM_SLAB * (SM_MAXD + 1); e += 256) {
+        const int r = e / (SM_MAXD + 1), j = e - r * (SM_MAXD + 1);
+        sl.xs[r][j] = (n0 + r < N && j < d) ? a.X[(size_t)(n0 + r) * a.ldx + j] * hyp.inv_ls[j] : 0.0;
+      }
+      if (tid < SM_SLAB) sl.ys[tid] = n0 + tid < N ? a.y[n0 + tid] : 0.0;
+      __syncthreads();
+      SlabRegs<NB16> Ya, Y;
+      {
+        const double* arow = a.A + (size_t)(n0 + nl) * MP;
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) Ya.b[pb][s] = arow[16 * pb + 4 * s + l4];
+      }
+      Y = Ya;
+      sm_trsm_fwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+      sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);  // V = B^-1 a_n
+      double tn = 0.0;
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) tn = fma(sl.gv[16 * pb + 4 * s + l4], Ya.b[pb][s], tn);
+      tn += __shfl_xor(tn, 16, 64);
+      tn += __shfl_xor(tn, 32, 64);  // g . a_n, in the four lanes that share the row
+      const double yn = sl.ys[nl];
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double gm = sl.gv[16 * pb + 4 * s + l4];
+          Y.b[pb][s] = (Ya.b[pb][s] - Y.b[pb][s] + gm * (yn * is2 - tn * is22)) * is2;
+        }
+      __syncthreads();
+      sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
+      __syncthreads();
+      sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);  // Kbar_uf rows of this slab
+      __syncthreads();
+      contract(Y, N - n0 < SM_SLAB ? N - n0 : SM_SLAB, 1.0);
+    }
+    if (tid < SM_GP) a.gpart[(size_t)(rw + 1) * SM_GP + tid] = sl.acc[tid];
+    if (a.want_gz)
+      for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)(rw + 1) * MP * SM_MAXD + e] = sl.gz[e];
+    sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
+    return;
+  }
+
+  // =================================================================================================================
+  // role 1: Kbar_uu = -1/2 L^-T S L^-1, S = B + B^-1 - 2 I + g g^T / s2^2 ; its contraction with dK_uu ; tr B^-1
+  if (!a.want_grad) return;
+  if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+  if (tid < MP) sl.gv[tid] = a.g[tid];
+  const double is22 = 1.0 / (s2 * s2);
+  double trb = 0.0;
+  for (int v = 0; v < NB64; ++v) {  // Q[:, cols] = L^-T S[:, cols]
+    const int col = 64 * v + 16 * w + l15;
+    __syncthreads();
+    sm_stage_factor<MP>(sl, a.Lb, a.dinvB);
+    __syncthreads();
+    SlabRegs<NB16> Y;
+#pragma unroll
+    for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Y.b[pb][s] = (16 * pb + 4 * s + l4) == col ? 1.0 : 0.0;
+    sm_trsm_fwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+    sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);  // columns of B^-1
+    const double gc = sl.gv[col] * is22;
+#pragma unroll
+    for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int m = 16 * pb + 4 * s + l4;
+        if (m == col) trb += Y.b[pb][s];
+        Y.b[pb][s] += a.Bm[(size_t)m * MP + col] - (m == col ? 2.0 : 0.0) + sl.gv[m] * gc;
+      }
+    __syncthreads();
+    sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
+    __syncthreads();
+    sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+#pragma unroll
+    for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a.Qm[(size_t)(16 * pb + 4 * s + l4) * MP + col] = Y.b[pb][s];
+  }
+  __threadfence();
+  __syncthreads();
+  trb = block_sum(trb);
+  if (tid == 0) sl.acc[SM_MAXD + 1] = trb;
+  // the factor of L stays staged: R[:, j] = L^-T (row j of Q)^T
+  for (int v = 0; v < NB64; ++v) {
+    const int col = 64 * v + 16 * w + l15;
+    SlabRegs<NB16> Y;
+    {
+      const double* qrow = a.Qm + (size_t)col * MP;
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Y.b[pb][s] = qrow[16 * pb + 4 * s + l4];
+    }
+    if (v > 0) {
+      __syncthreads();
+      sm_stage_factor<MP>(sl, a.Lk, a.dinvK);  // the contraction of the previous slab may have overwritten the blocks
+      __syncthreads();
+    }
+    sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+#pragma unroll
+    for (int pb = 0; pb < NB16; ++pb) Y.b[pb] = Y.b[pb] * -0.5;  // Kbar_uu[m][col]
+    // "data rows" of this slab are the inducing inputs col: scaled copies into xs
+    __syncthreads();
+    for (int e = tid; e < SM_SLAB * (SM_MAXD + 1); e += 256) {
+      const int r = e / (SM_MAXD + 1), j = e - r * (SM_MAXD + 1);
+      sl.xs[r][j] = sl.zs[64 * v + r][j];
+    }
+    __syncthreads();
+    contract(Y, M - 64 * v < SM_SLAB ? (M - 64 * v > 0 ? M - 64 * v : 0) : SM_SLAB, 2.0);
+  }
+  if (tid < SM_GP) a.gpart[tid] = sl.acc[tid];
+  if (a.want_gz)
+    for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[e] = sl.gz[e];
+  sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
+}
+
+struct SmallWs {
+  SmallArgs a;
+  size_t bytes;
+};
+static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
+  (void)d;
+  const int MP = M <= 64 ? 64 : 128, NB64 = MP / 64;
+  const int nslab = (int)((N + SM_SLAB - 1) / SM_SLAB) > 0 ? (int)((N + SM_SLAB - 1) / SM_SLAB) : 1;
+  const int grow = nslab < SM_MAX_ROWWG ? nslab : SM_MAX_ROWWG;
+  const size_t mm = (size_t)MP * MP;
+  const size_t nflag = (size_t)(NB64 * (NB64 + 1) / 2 + 1) * DF_FLAG_STRIDE;
+  Carver c(ws);
+  SmallWs w{};
+  w.a.sync = c.take<int>(SY_WORDS * SM_SYNC_STRIDE);  // first: the caller zeroes the head of the workspace once
+  w.a.flagsK = c.take<int>(nflag);
+  w.a.flagsB = c.take<int>(nflag);
+  w.a.Lk = c.take<double>(mm);
+  w.a.dinvK = c.take<double>((size_t)NB64 * 1024);
+  w.a.Bm = c.take<double>(mm);
+  w.a.Lb = c.take<double>(mm);
+  w.a.dinvB = c.take<double>((size_t)NB64 * 1024);
+  w.a.A = c.take<double>((size_t)nslab * SM_SLAB * MP);
+  w.a.Ppart = c.take<double>((size_t)grow * mm);
+  w.a.upart = c.take<double>((size_t)grow * MP);
+  w.a.spart = c.take<double>(2 + 2 * (size_t)grow);
+  w.a.u = c.take<double>(MP);
+  w.a.c0 = c.take<double>(MP);
+  w.a.g = c.take<double>(MP);
+  w.a.gpart = c.take<double>((size_t)(grow + 1) * SM_GP);
+  w.a.gzpart = c.take<double>((size_t)(grow + 1) * MP * SM_MAXD);
+  w.a.Qm = c.take<double>(mm);
+  w.a.nslab = nslab;
+  w.a.grow = grow;
+  w.bytes = c.used();
+  return w;
+}
+
+}  // namespace sgp
+
+using namespace sgp;
+
+extern "C" int sgp_small_supported(int64_t N, int M, int d, int kernel_id) {
+  return N >= 1 && N <= (int64_t)1 << 22 && M >= 1 && M <= 128 && d >= 1 && d <= SM_MAXD && kernel_id >= SGP_KERNEL_RBF &&
+         kernel_id <= SGP_KERNEL_MATERN52;
+}
+extern "C" size_t sgp_small_workspace_bytes(int64_t N, int M, int d) {
+  if (!sgp_small_supported(N, M, d, SGP_KERNEL_RBF)) return 0;
+  return carve_small(nullptr, N, M, d).bytes;
+}
+extern "C" size_t sgp_small_sync_bytes(void) { return (size_t)SY_WORDS * SM_SYNC_STRIDE * sizeof(int); }
+
+extern "C" int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                              const double* theta, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
+                              int want_grad, double* out, double* g_Z, int* info, void* ws, size_t ws_bytes,
+                              sgp_stream_t stream) {
+  if (!X || !y || !Z || !theta || !out || !info || ldx < d || ldz < d || (mode != 0 && mode != 1)) return SGP_ERR_ARG;
+  if (!sgp_small_supported(N, M, d, kernel_id)) return SGP_ERR_DIM;
+  SmallWs w = carve_small(ws, N, M, d);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  SmallArgs& a = w.a;
+  a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta;
+  a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = mode; a.want_grad = want_grad ? 1 : 0;
+  a.want_gz = (want_grad && g_Z) ? 1 : 0;
+  a.jitter = jitter;
+  a.info = info; a.out = out; a.gZ = g_Z;
+  const int grid = 2 + a.grow;
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 64) small_eval_kernel<64><<<grid, 256, 0, st>>>(a);
+  else small_eval_kernel<128><<<grid, 256, 0, st>>>(a);
+  return check_launch();
+}

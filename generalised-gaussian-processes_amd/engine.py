@@ -261,6 +261,51 @@ class HipEngine:
             _lib.check("sgp_bound_from_stats", self.lib.sgp_bound_from_stats(self._ptr(Kuu), *stats, *tail))
         return res
 
+    # ------------------------------------------------------------------ single-launch path for small problems
+    def small_supported(self, N: int, M: int, d: int, kernel="rbf") -> bool:
+        return bool(self.lib.sgp_small_supported(int(N), int(M), int(d), _kernel_id(kernel)))
+
+    def small_eval(self, X, y, Z, theta: torch.Tensor, jitter, kernel="rbf", mode=0, want_grad=True, want_gz=False,
+                   out: Optional[torch.Tensor] = None):
+        """ONE kernel launch: the bound (mode 0) or the NUTS target (mode 1) and its gradient, hyper-parameters read from
+        the device tensor ``theta``.  Returns (out[d + 5] device tensor, gZ or None, info int32 device tensor); nothing is
+        synchronised.  ``out`` may be a caller-owned d + 5 (+1 for the status word, see ``small_result``) buffer."""
+        N, d = X.shape
+        M = Z.shape[0]
+        for t, n in ((X, "X"), (y, "y"), (Z, "Z"), (theta, "theta")):
+            self._chk(t, n)
+        if theta.numel() != d + 2:
+            raise ValueError("theta has %d entries, expected d + 2 = %d" % (theta.numel(), d + 2))
+        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
+        key = "small"
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)  # zeroed once: the sync words
+            self._ws[key] = ws
+        if out is None:
+            out, info = self.small_result(d)
+        else:
+            info = out[d + 5:d + 6].view(torch.int32)[:1]
+        gz = self.empty(M, d) if (want_grad and want_gz) else None
+        st = self.lib.sgp_small_eval(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), N, M, d, _kernel_id(kernel),
+                                     float(jitter), int(mode), 1 if want_grad else 0, self._ptr(out), self._ptr(gz),
+                                     C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_small_eval", st)
+        return out, gz, info
+
+    def small_result(self, d: int):
+        """[out (d + 5) | status word] in one buffer, so one device-to-host copy ends an evaluation."""
+        buf = self.empty(d + 6)
+        return buf, buf[d + 5:d + 6].view(torch.int32)[:1]
+
+    def small_reset(self):
+        """Zero the sync words again (only needed after a SGP_INFO_TIMEOUT)."""
+        ws = self._ws.get("small")
+        if ws is not None:
+            ws[: self.lib.sgp_small_sync_bytes()].zero_()
+
     # ------------------------------------------------------------------ pass 2
     def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False,
                       out: Optional[torch.Tensor] = None, kfu: Optional[torch.Tensor] = None) -> torch.Tensor:

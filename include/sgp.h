@@ -193,6 +193,28 @@ int sgp_bound_from_whitened_stats(const double* W, const double* u, const double
                                   double* Phibar, double* bbar, double* Kuubar, double* factors,
                                   const double* kuu_linv, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 
+/* ---- single-launch evaluation for small problems (M <= 128, d <= 16, stationary kernels) -------------------------
+ * The size class of the reference's own HMC runs (models/bayesian_sgpr_hmc.py:58-80,144-157: N ~ 250-1300, M = 100).
+ * ONE cooperative kernel launch evaluates the bound and its gradient in the PyMC3 op order (A = L^-1 K_uf by blocked
+ * substitution on the matrix cores; B = I + A A^T / s2), reading the hyper-parameters from DEVICE memory:
+ *   mode SGP_SMALL_NATURAL : theta = [ls_1..d | sf2 | s2]                    out = [F | dF/dls_1..d | dF/dsf2 | dF/ds2 | logmarg | trace]
+ *   mode SGP_SMALL_HMC     : theta = [log ls_1..d | log sig_f | log sig_n]   out = [logp | dlogp/dtheta (d + 2) | logmarg | trace]
+ *                            logp = F + log Gamma(ls; 2, 1) + log HalfCauchy(sig_f; 1) + log HalfCauchy(sig_n; 1) + log-Jacobians,
+ *                            the NUTS target of models/bayesian_sgpr_hmc.py:60-71; theta outside exp()'s range gives logp = -inf
+ * out (d + 5 doubles), g_Z (M*d, ld d, optional: NULL skips dF/dZ) and info are DEVICE pointers; nothing is synchronised.
+ * want_grad = 0 writes out[0] (and the two parts) only.  The first sgp_small_sync_bytes() bytes of `ws` must be zero
+ * before the FIRST launch on a workspace (the kernel leaves them zero; after info = SGP_INFO_TIMEOUT zero them again).
+ * All workgroups (2 + min(ceil(N/64), 64)) must be co-resident: do not run it beside a kernel that fills the device.   */
+#define SGP_SMALL_NATURAL 0
+#define SGP_SMALL_HMC 1
+int sgp_small_supported(int64_t N, int M, int d, int kernel_id);
+size_t sgp_small_workspace_bytes(int64_t N, int M, int d);
+size_t sgp_small_sync_bytes(void);
+int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                   const double* theta, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
+                   int want_grad, double* out, double* g_Z, int* info,
+                   void* ws, size_t ws_bytes, sgp_stream_t stream);
+
 /* ---- streaming pass 2: gradients through Kuf -------------------------------------------------------
  * Kbar_uf = 2 Phibar Kuf + bbar y^T is formed tile by tile and contracted with dKuf/d(.) on the fly.
  * Writes (overwrites) g_ls[d] = dF/d lengthscale_j, g_sf2[1] = dF/d sf2 (including the kappa term

@@ -1,0 +1,108 @@
+"""Single-launch path for small problems (sgp_small_eval): parity with the fixtures and the oracle, through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import dev, golden_names, load_golden
+
+KNAME = {0: "rbf", 1: "matern32", 2: "matern52"}
+SMALL = [n for n in golden_names() if load_golden(n)["X"].shape[1] <= 16]
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def _theta(G, engine):
+    return dev(np.concatenate([G["ls"], [float(G["sf2"]), float(G["s2"])]]), engine)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL)
+def test_small_value_and_grad_golden(engine, name):
+    """PyMC3 op order with substitution solves: 1e-9 on F and 1e-6 on every gradient, duplicate-Z fixture included."""
+    G = load_golden(name)
+    d = G["X"].shape[1]
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    kern = KNAME[int(G["kernel_id"])]
+    assert engine.small_supported(X.shape[0], Z.shape[0], d, kern)
+    out, gz, info = engine.small_eval(X, y, Z, _theta(G, engine), float(G["jitter"]), kern, mode=0, want_grad=True, want_gz=True)
+    o = out.cpu().numpy()
+    assert int(info.item()) == 0
+    F = float(G["F"])
+    assert abs(o[0] - F) < 1e-9 * max(1.0, abs(F)), (o[0], F)
+    assert abs(o[d + 3] - float(G["logmarg"])) < 1e-8 * max(1.0, abs(F)) and abs(o[d + 4] - float(G["trace_term"])) < 1e-8 * max(1.0, abs(F))
+    ill = float(G["grad_rtol"]) > 1e-6
+    assert relerr(o[1:1 + d], G["g_ls"]) < 1e-6, (o[1:1 + d], G["g_ls"])
+    assert abs(o[1 + d] - float(G["g_sf2"])) < 1e-6 * max(1.0, abs(float(G["g_sf2"])))
+    assert abs(o[2 + d] - float(G["g_s2"])) < 1e-6 * max(1.0, abs(float(G["g_s2"])))
+    assert relerr(gz.cpu().numpy(), G["g_Z"]) < (1e-4 if ill else 1e-6)
+    # value-only launch: same F, bit for bit
+    out2, _, info2 = engine.small_eval(X, y, Z, _theta(G, engine), float(G["jitter"]), kern, mode=0, want_grad=False)
+    assert int(info2.item()) == 0 and float(out2[0]) == o[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in SMALL if n.startswith("rbf")])
+def test_small_hmc_target_golden(engine, name):
+    G = load_golden(name)
+    d = G["X"].shape[1]
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    for th, lp_ref, g_ref in zip(G["hmc_theta"], G["hmc_logp"], G["hmc_grad"]):
+        out, _, info = engine.small_eval(X, y, Z, dev(th, engine), 1e-6, "rbf", mode=1, want_grad=True)
+        o = out.cpu().numpy()
+        assert int(info.item()) == 0
+        assert abs(o[0] - lp_ref) < 1e-9 * max(1.0, abs(lp_ref))
+        assert np.max(np.abs(o[1:d + 3] - g_ref)) < 1e-6 * max(1.0, np.max(np.abs(g_ref)))
+    # outside exp()'s range: zero density, not an exception
+    bad = np.array(list(G["hmc_theta"][0]))
+    bad[0] = 400.0
+    out, _, info = engine.small_eval(X, y, Z, dev(bad, engine), 1e-6, "rbf", mode=1, want_grad=True)
+    assert float(out[0]) == -math.inf and int(info.item()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,d,kern", [(1, 1, 1, "rbf"), (63, 7, 2, "rbf"), (64, 64, 3, "matern32"), (65, 65, 1, "rbf"),
+                                         (634, 128, 1, "rbf"), (500, 50, 1, "matern52"), (1300, 100, 13, "rbf"),
+                                         (5000, 100, 8, "rbf")])
+def test_small_shapes_vs_oracle(engine, N, M, d, kern):
+    """Edge shapes: one row, slab boundaries, both padded sizes, several slabs per workgroup (N = 5000 -> 79 slabs on 64
+    workgroups), d up to 13 (the reference's UCI sets)."""
+    from oracle import vfe_oracle as O
+    kid = {"rbf": 0, "matern32": 1, "matern52": 2}[kern]
+    g = torch.Generator().manual_seed(N + M)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X.sum(1) / math.sqrt(d)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = (X[torch.randperm(N, generator=g)[:M]] if M <= N else torch.randn(M, d, dtype=torch.float64, generator=g)).clone()
+    ls = torch.rand(d, dtype=torch.float64, generator=g) * 0.8 + (0.6 if d == 1 else 1.5)
+    sf2, s2, jit = 1.3, 0.07, 1e-6
+    # reference gradients: autograd through the PyMC3-order graph where it exists (RBF), the closed form otherwise
+    ref = O.grads_autograd(X, y, Z, ls, sf2, s2, jit) if kid == 0 else O.grads_analytic(X, y, Z, ls, sf2, s2, jit, kid)
+    Fr = float(O.vfe_pymc3_order(X, y, Z, ls, math.sqrt(sf2), math.sqrt(s2), jit, kid))
+    th = torch.cat([ls, torch.tensor([sf2, s2], dtype=torch.float64)]).to(engine.device)
+    out, gz, info = engine.small_eval(X.to(engine.device), y.to(engine.device), Z.to(engine.device), th, jit, kern, mode=0,
+                                      want_grad=True, want_gz=True)
+    o = out.cpu().numpy()
+    assert int(info.item()) == 0
+    assert abs(o[0] - Fr) < 1e-9 * max(1.0, abs(Fr)), (o[0], Fr)
+    assert relerr(o[1:1 + d], ref["g_ls"].numpy()) < 1e-6
+    assert abs(o[1 + d] - ref["g_sf2"]) < 1e-6 * max(1.0, abs(ref["g_sf2"])) and abs(o[2 + d] - ref["g_s2"]) < 1e-6 * max(1.0, abs(ref["g_s2"]))
+    assert relerr(gz.cpu().numpy(), ref["g_Z"].numpy()) < 1e-6
+    # bit-reproducible
+    out2, gz2, _ = engine.small_eval(X.to(engine.device), y.to(engine.device), Z.to(engine.device), th, jit, kern, mode=0,
+                                     want_grad=True, want_gz=True)
+    assert torch.equal(out2[:d + 5], out[:d + 5]) and torch.equal(gz2, gz)
+
+
+@pytest.mark.gpu
+def test_small_reports_non_pd(engine):
+    X = torch.randn(40, 2, dtype=torch.float64)
+    y = torch.randn(40, dtype=torch.float64)
+    Z = torch.zeros(6, 2, dtype=torch.float64)  # identical inducing rows, no jitter
+    th = torch.tensor([1.0, 1.0, 1.0, 0.1], dtype=torch.float64).to(engine.device)
+    out, _, info = engine.small_eval(X.to(engine.device), y.to(engine.device), Z.to(engine.device), th, 0.0, "rbf", mode=0, want_grad=True)
+    assert 1 <= int(info.item()) <= 6
