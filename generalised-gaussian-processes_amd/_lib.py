@@ -65,6 +65,7 @@ PROTOTYPES = {
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_small_supported": (_i32, [_i64, _i32, _i32, _i32]),
+    "sgp_small_debug_stamps": (None, [_vp]),
     "sgp_small_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_small_sync_bytes": (_sz, []),
     "sgp_small_eval": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _vp, _vp, _vp,

@@ -16,8 +16,8 @@
 //
 // Work decomposition (one workgroup = 4 waves; all workgroups co-resident, <= 66 of the 256 CUs):
 //     workgroup 0            the chain: Kuu, chol(Kuu), [wait] chol(B) with c0 riding along, g, F, final reduction
-//     workgroup 1            Kbar_uu ("virtual slabs": the columns of I go through the slab pipeline), tr B^-1
-//     workgroups 2 ..        row slabs of 64 data rows: assemble K_uf straight into the MFMA accumulator layout, solve,
+//     workgroups 1 .. MP/64  Kbar_uu ("virtual slabs": 64 columns of I each go through the slab pipeline), tr B^-1
+//     the others             row slabs of 64 data rows: assemble K_uf straight into the MFMA accumulator layout, solve,
 //                            partial A A^T / A y; later the reverse pass of the same rows
 // A slab lives in REGISTERS during the solves: lane (wave w, l15, l4) holds element (row 16 w + l15, column 16 pb + 4 s
 // + l4) in component s of block pb -- transposed 16 x 16 blocks in the accumulator layout, which is also the B-operand
@@ -34,7 +34,7 @@ constexpr int SM_MAXD = 16;
 constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
-enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_WORDS = 6 };
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_WORDS = 7 };
 constexpr int SM_GP = SM_MAXD + 4;  // doubles per gradient partial: g_ls[d] at 0.., then g_sf2, tr B^-1
 
 struct SmallArgs {
@@ -43,9 +43,10 @@ struct SmallArgs {
   double jitter;
   int nslab, grow;
   double *Lk, *dinvK, *Bm, *Lb, *dinvB, *A, *Ppart, *upart, *spart, *u, *c0, *g, *gpart, *gzpart, *Qm;
-  int *flagsK, *flagsB, *sync, *info;
+  int *sync, *info;
   double* out;
   double* gZ;
+  unsigned long long* stamps;  // optional (tools/small_eval_phases.py): [workgroup][16] s_memrealtime ticks (100 MHz)
 };
 
 struct SmHyp {
@@ -71,11 +72,144 @@ struct SmSlabShared {
   double acc[SM_GP];
 };
 
+// the chain workgroup's view: the whole MP x MP matrix stays in LDS through assembly, factorization and the two
+// vector solves; only the finished factor (and the block inverses the slab solves start from) go to global memory
+template <int MP>
+struct SmChainShared {
+  static constexpr int LDA = MP + 1;
+  double Am[MP][LDA];
+  union {
+    double Dinv[MP / 16][16][17];
+    double zs[MP][SM_MAXD + 1];  // scaled inducing inputs, only while Kuu is assembled (same size)
+  };
+  double xv[MP];  // solution vector of the block substitutions
+  double rs[MP];  // reciprocal pivots
+  int bad;
+};
+
 template <int MP>
 union SmShared {
-  DfShared df;
+  SmChainShared<MP> ch;
   SmSlabShared<MP> sl;
 };
+
+// In-place lower Cholesky of cs.Am (MP x MP, in LDS) by one workgroup of 4 waves, left-looking over 16-column panels:
+//   (U) panel -= L(:, earlier) L(p, earlier)^T     MFMA, row blocks dealt to the waves
+//   (D) 16 x 16 diagonal block                      wave 0: lane <-> row, pivots broadcast by v_readlane, rsqrt + 2 Newton steps;
+//       its inverse Dinv[p]                          same wave, forward substitution on the rows still in registers
+//   (T) L(q, p) = A(q, p) Dinv[p]^T                 MFMA
+// cs.bad = first non-positive pivot (1-based; the factorization continues on a unit pivot), cs.rs = 1 / diag(L).
+// Written for a matrix that is factored ONCE per launch: compact loops (the tile-dataflow factorization of
+// sgp_potrf.hpp, built for M = 1024, is 19k instructions of straight-line code -- cold, it took 38 us for M = 128).
+template <int MP>
+__device__ __forceinline__ void sm_chol_lds(SmChainShared<MP>& cs) {
+  constexpr int NB16 = MP / 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  if (tid == 0) cs.bad = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int p = 0; p < NB16; ++p) {
+    if (p > 0) {
+      for (int q = p + w; q < NB16; q += 4) {
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int t = 0; t < p; ++t) {
+#pragma unroll
+          for (int sq = 0; sq < 4; ++sq)
+            acc = mfma16(cs.Am[16 * q + l15][16 * t + 4 * sq + l4], cs.Am[16 * p + l15][16 * t + 4 * sq + l4], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs.Am[16 * q + l4 + 4 * r][16 * p + l15] -= acc[r];
+      }
+      __syncthreads();
+    }
+    if (w == 0) {
+      const int row = 16 * p + l15;
+      double a[16], rsv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = cs.Am[row][16 * p + k];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double dj = readlane_f64(a[j], j);
+        if (!(dj > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
+          if (lane == 0 && cs.bad == 0) cs.bad = 16 * p + j + 1;
+          dj = 1.0;
+        }
+        rsv[j] = rsqrt_newton(dj);
+        const double lj = a[j] * rsv[j];
+        a[j] = lj;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-lj, readlane_f64(lj, k), a[k]);
+      }
+      // inverse of the block: lane c <-> column c, y[r] = (delta_rc - sum_{q<r} L[r][q] y[q]) / L[r][r]
+      double y[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double s0 = (r == l15) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < r; ++q) {
+          const double lrq = readlane_f64(a[q], r);
+          if (q & 1) s1 = fma(-lrq, y[q], s1);
+          else s0 = fma(-lrq, y[q], s0);
+        }
+        y[r] = (s0 + s1) * rsv[r];
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          cs.Am[row][16 * p + k] = (k <= l15) ? a[k] : 0.0;
+          cs.Dinv[p][k][l15] = y[k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (lane == j) cs.rs[16 * p + j] = rsv[j];
+    }
+    __syncthreads();
+    for (int q = p + 1 + w; q < NB16; q += 4) {
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) acc = mfma16(cs.Am[16 * q + l15][16 * p + 4 * sq + l4], cs.Dinv[p][l15][4 * sq + l4], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs.Am[16 * q + l4 + 4 * r][16 * p + l15] = acc[r];
+    }
+    __syncthreads();
+  }
+}
+
+// x <- L^-1 x (trans = false) or L^-T x (trans = true) for the factor in cs.Am / cs.Dinv; x = cs.xv; wave 0 works
+template <int MP>
+__device__ __forceinline__ void sm_vec_solve(SmChainShared<MP>& cs, bool trans) {
+  constexpr int NB16 = MP / 16;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  if (tid < 64) {
+#pragma unroll 1
+    for (int pp = 0; pp < NB16; ++pp) {
+      const int p = trans ? NB16 - 1 - pp : pp;
+      double part = 0.0;
+      if (!trans) {
+        for (int k = l4; k < 16 * p; k += 4) part = fma(cs.Am[16 * p + l15][k], cs.xv[k], part);
+      } else {
+        for (int k = 16 * p + 16 + l4; k < MP; k += 4) part = fma(cs.Am[k][16 * p + l15], cs.xv[k], part);
+      }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      const double r = cs.xv[16 * p + l15] - part;  // every lane: entry l15 of the block's right-hand side
+      double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const double rk = __shfl(r, k, 64);
+        x = fma(trans ? cs.Dinv[p][k][l15] : cs.Dinv[p][l15][k], rk, x);
+      }
+      if (lane < 16) cs.xv[16 * p + l15] = x;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ int sm_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -181,17 +315,49 @@ __device__ __forceinline__ void sm_trsm_bwd(SlabRegs<NB16>& Y, const double (*Lb
   }
 }
 
-// global lower-triangular factor (ld MP) + its 16 x 16 diagonal-block inverses (potrf's dinv_g layout) -> LDS blocks
+// global lower-triangular factor (ld MP) + the inverses of its 16 x 16 diagonal blocks ([block][16][16]) -> LDS blocks.
+// Every load is issued before the first LDS store: one round trip to a line another XCD has just written.
 template <int MP>
 __device__ __forceinline__ void sm_stage_factor(SmSlabShared<MP>& sl, const double* __restrict__ L, const double* __restrict__ dinv) {
-  constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2;
-  const int t = threadIdx.x, r = t >> 4, c = t & 15;
-  int q = 0, p = 0;
-  for (int b = 0; b < NBL; ++b) {
-    sl.Lblk[b][r][c] = L[(size_t)(16 * q + r) * MP + 16 * p + c];
-    if (++p > q) { p = 0; ++q; }
+  constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2, NP = (NBL + 3) / 4;
+  const int t = threadIdx.x, grp = t >> 6, tb = t & 63, r = tb >> 2, c4 = (tb & 3) * 4;
+  d2 v[NP][2], dv[NB16 / 4][2];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int b = 4 * i + grp;
+    if (b < NBL) {
+      int q = 0;
+      while ((q + 1) * (q + 2) / 2 <= b) ++q;
+      const int p = b - q * (q + 1) / 2;
+      const double* src = L + (size_t)(16 * q + r) * MP + 16 * p + c4;
+      v[i][0] = *reinterpret_cast<const d2*>(src);
+      v[i][1] = *reinterpret_cast<const d2*>(src + 2);
+    }
   }
-  for (int b = 0; b < NB16; ++b) sl.Dinv[b][r][c] = dinv[(size_t)(b >> 2) * 1024 + (b & 3) * 256 + t];
+#pragma unroll
+  for (int i = 0; i < NB16 / 4; ++i) {
+    const double* src = dinv + (size_t)(4 * i + grp) * 256 + r * 16 + c4;
+    dv[i][0] = *reinterpret_cast<const d2*>(src);
+    dv[i][1] = *reinterpret_cast<const d2*>(src + 2);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int b = 4 * i + grp;
+    if (b < NBL) {
+      sl.Lblk[b][r][c4] = v[i][0][0];
+      sl.Lblk[b][r][c4 + 1] = v[i][0][1];
+      sl.Lblk[b][r][c4 + 2] = v[i][1][0];
+      sl.Lblk[b][r][c4 + 3] = v[i][1][1];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB16 / 4; ++i) {
+    const int b = 4 * i + grp;
+    sl.Dinv[b][r][c4] = dv[i][0][0];
+    sl.Dinv[b][r][c4 + 1] = dv[i][0][1];
+    sl.Dinv[b][r][c4 + 2] = dv[i][1][0];
+    sl.Dinv[b][r][c4 + 3] = dv[i][1][1];
+  }
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------
@@ -202,6 +368,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   __shared__ SmHyp hyp;
   __shared__ int dead;
   __shared__ double redw[4];
+  __shared__ double gsum[SM_GP];
   SmSlabShared<MP>& sl = sh.sl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,10 +378,14 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   int* sy = a.sync;
   int* abortw = sy + SY_ABORT * SM_SYNC_STRIDE;
   if (tid == 0) dead = 0;
+  auto stamp = [&](int k) {
+    if (a.stamps && tid == 0) a.stamps[(size_t)wg * 16 + k] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   sm_hypers(a, hyp);
   const double sf2 = hyp.sf2, s2 = hyp.s2;
-  const int role = wg == 0 ? 0 : (wg == 1 ? 1 : 2);
-  const int ngrad = a.grow + 1;  // workgroups that contribute gradient partials
+  const int role = wg == 0 ? 0 : (wg <= NB64 ? 1 : 2);
+  const int ngrad = a.grow + NB64;  // workgroups that contribute gradient partials
 
   if (!hyp.ok) {  // theta outside the representable range: density zero, never an exception (PyMC3: non-finite logp)
     if (wg == 0 && tid <= d + 2) a.out[tid] = tid == 0 ? -INFINITY : 0.0;
@@ -240,71 +411,104 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
 
   // =================================================================================================================
   if (role == 0) {
-    // ---- Kuu -> Lk, factor --------------------------------------------------------------------------------------
-    const int nflag = (NB64 * (NB64 + 1) / 2 + 1) * DF_FLAG_STRIDE;
-    for (int e = tid; e < nflag; e += 256) { a.flagsK[e] = 0; a.flagsB[e] = 0; }
+    SmChainShared<MP>& cs = sh.ch;
+    // ---- Kuu assembled in LDS (lower triangle, four independent exp() chains per thread), factored in place ----------
     if (tid == 0) *a.info = 0;
-    for (int e = tid; e < MP * MP; e += 256) {
-      const int i = e / MP, j = e - i * MP;
-      double v = i == j ? 1.0 : 0.0;
-      if (i < M && j < M) {
-        double r2 = 0.0;
-        for (int q = 0; q < d; ++q) {
-          const double df = (a.Z[(size_t)i * a.ldz + q] - a.Z[(size_t)j * a.ldz + q]) * hyp.inv_ls[q];
-          r2 = fma(df, df, r2);
-        }
-        v = sf2 * sm_kprofile(a.kid, r2) + (i == j ? a.jitter : 0.0);
-      }
-      a.Lk[e] = v;
+    for (int e = tid; e < MP * (SM_MAXD + 1); e += 256) {
+      const int m = e / (SM_MAXD + 1), j = e - m * (SM_MAXD + 1);
+      cs.zs[m][j] = (m < M && j < d) ? a.Z[(size_t)m * a.ldz + j] * hyp.inv_ls[j] : 0.0;
     }
-    __threadfence();
     __syncthreads();
-    if (tid == 0) sh.df.dead = 0;
-    __syncthreads();
-    potrf_dataflow_body(a.Lk, MP, NB64, a.flagsK, a.dinvK, a.info, 0, nullptr, nullptr, nullptr, sh.df, 0, 1);
+    {
+      constexpr int NLOW = MP * (MP + 1) / 2;
+      for (int e0 = tid; e0 < NLOW; e0 += 1024) {
+        double r2[4];
+        int ii[4], jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + 256 * u;
+          int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+          while ((i + 1) * (i + 2) / 2 <= e) ++i;
+          while (i * (i + 1) / 2 > e) --i;
+          ii[u] = e < NLOW ? i : 0;
+          jj[u] = e < NLOW ? e - i * (i + 1) / 2 : 0;
+          r2[u] = 0.0;
+        }
+        for (int q = 0; q < d; ++q) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double df = cs.zs[ii[u]][q] - cs.zs[jj[u]][q];
+            r2[u] = fma(df, df, r2[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (e0 + 256 * u < NLOW) {
+            const int i = ii[u], j = jj[u];
+            double v = i == j ? 1.0 : 0.0;
+            if (i < M && j < M) v = sf2 * sm_kprofile(a.kid, r2[u]) + (i == j ? a.jitter : 0.0);
+            cs.Am[i][j] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();  // (zs is dead from here: Dinv takes its place)
+    stamp(1);
+    sm_chol_lds<MP>(cs);
+    auto write_factor = [&](double* Lg, double* dg) {
+      for (int e = tid; e < MP * MP; e += 256) {
+        const int i = e / MP, j = e - i * MP;
+        Lg[e] = j <= i ? cs.Am[i][j] : 0.0;
+      }
+      for (int e = tid; e < NB16 * 256; e += 256) dg[e] = cs.Dinv[e >> 8][(e >> 4) & 15][e & 15];
+    };
+    write_factor(a.Lk, a.dinvK);
+    if (tid == 0 && cs.bad != 0) *a.info = cs.bad;
     sm_publish_set(sy + SY_L * SM_SYNC_STRIDE, 1);
+    stamp(2);
 
-    // ---- B complete -> LB, c0 = LB^-1 u --------------------------------------------------------------------------
+    // ---- B complete -> LB, c0 = LB^-1 u, g = LB^-T c0 ---------------------------------------------------------------
     if (!sm_wait_ge(sy + SY_SLICE * SM_SYNC_STRIDE, a.grow, abortw, &dead)) {
       if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
       return;
     }
-    for (int e = tid; e < MP * MP; e += 256) a.Lb[e] = a.Bm[e];
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) sh.df.dead = 0;
-    __syncthreads();
-    potrf_dataflow_body(a.Lb, MP, NB64, a.flagsB, a.dinvB, a.info, M, a.u, a.c0, nullptr, sh.df, 0, 1);
-    __threadfence();
-    __syncthreads();
-    // g = LB^-T c0 : backward substitution, 64 x 64 tiles from the last to the first (wave 0; lane <-> row)
-    if (w == 0) {
-      for (int jb = NB64 - 1; jb >= 0; --jb) {
-        double rr = a.c0[jb * 64 + lane];
-        for (int p = jb + 1; p < NB64; ++p) {  // - sum_p LB(p, jb)^T g_p
-          double s = 0.0;
-          for (int k = 0; k < 64; ++k) s = fma(a.Lb[(size_t)(p * 64 + k) * MP + jb * 64 + lane], a.g[p * 64 + k], s);
-          rr -= s;
+    stamp(3);
+    {
+      constexpr int NV = MP * MP / 256 / 8;
+      for (int it = 0; it < NV; ++it) {  // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a.Bm[(size_t)(it * 8 + k) * 256 + tid];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int e = (it * 8 + k) * 256 + tid;
+          cs.Am[e / MP][e % MP] = v[k];
         }
-        const double dinv = 1.0 / a.Lb[(size_t)(jb * 64 + lane) * (MP + 1)];
-        double mine = 0.0;
-        for (int c = 63; c >= 0; --c) {
-          const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
-          if (lane == c) mine = xc;
-          rr = fma(-a.Lb[(size_t)(jb * 64 + c) * MP + jb * 64 + lane], xc, rr);  // column `lane` of row c: LB^T[lane][c]
-        }
-        a.g[jb * 64 + lane] = mine;
-        __threadfence();
       }
+      if (tid < MP) cs.xv[tid] = a.u[tid];
     }
     __syncthreads();
-    // scalars
-    double ld = 0.0, cc = 0.0, ug = 0.0, gg = 0.0;
+    stamp(4);
+    sm_chol_lds<MP>(cs);
+    if (tid == 0 && cs.bad != 0 && *a.info == 0) *a.info = M + cs.bad;
+    write_factor(a.Lb, a.dinvB);
+    sm_vec_solve<MP>(cs, false);
+    if (tid < MP) a.c0[tid] = cs.xv[tid];
+    double cc = 0.0, ld = 0.0;
     for (int i = tid; i < MP; i += 256) {
-      ld += log(a.Lb[(size_t)i * (MP + 1)]);
-      cc = fma(a.c0[i], a.c0[i], cc);
-      ug = fma(a.u[i], a.g[i], ug);
-      gg = fma(a.g[i], a.g[i], gg);
+      cc = fma(cs.xv[i], cs.xv[i], cc);
+      ld -= log(cs.rs[i]);
+    }
+    stamp(5);
+    sm_vec_solve<MP>(cs, true);
+    if (tid < MP) a.g[tid] = cs.xv[tid];
+    __syncthreads();
+    stamp(6);
+    // scalars
+    double ug = 0.0, gg = 0.0;
+    for (int i = tid; i < MP; i += 256) {
+      ug = fma(a.u[i], cs.xv[i], ug);
+      gg = fma(cs.xv[i], cs.xv[i], gg);
     }
     ld = block_sum(ld);
     cc = block_sum(cc);
@@ -329,16 +533,18 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       return;
     }
     sm_publish_set(sy + SY_LB * SM_SYNC_STRIDE, 1);
+    stamp(7);
 
     // ---- gradients --------------------------------------------------------------------------------------------------
     if (!sm_wait_ge(sy + SY_GRAD * SM_SYNC_STRIDE, ngrad, abortw, &dead)) {
       if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
       return;
     }
+    stamp(8);
     if (tid < SM_GP) {
       double s = 0.0;
       for (int g = 0; g < ngrad; ++g) s += a.gpart[(size_t)g * SM_GP + tid];
-      sl.acc[tid] = s;
+      gsum[tid] = s;
     }
     if (a.want_gz && a.gZ) {
       for (int e = tid; e < M * d; e += 256) {
@@ -349,14 +555,14 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-      const double trBinv = sl.acc[SM_MAXD + 1];
-      const double g_sf2 = sl.acc[SM_MAXD] - Nd / (2.0 * s2);  // + kappabar dkappa/dsf2
+      const double trBinv = gsum[SM_MAXD + 1];
+      const double g_sf2 = gsum[SM_MAXD] - Nd / (2.0 * s2);  // + kappabar dkappa/dsf2
       const double s22 = s2 * s2;
       const double g_s2 = -0.5 * (-((double)MP - trBinv) / s2 + Nd / s2 - yy / s22 + 2.0 * ug / (s22 * s2) - (ug - gg) / (s22 * s2)
                                   - kappa / s22 + sumA2 / s22);
       if (a.mode == 0) {
         a.out[0] = F;
-        for (int j = 0; j < d; ++j) a.out[1 + j] = sl.acc[j];
+        for (int j = 0; j < d; ++j) a.out[1 + j] = gsum[j];
         a.out[1 + d] = g_sf2;
         a.out[2 + d] = g_s2;
       } else {
@@ -367,7 +573,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
           const double l = hyp.ls[j];
           lp += log(l) - l;
           sumth += a.theta[j];
-          a.out[1 + j] = l * (sl.acc[j] + 1.0 / l - 1.0) + 1.0;
+          a.out[1 + j] = l * (gsum[j] + 1.0 / l - 1.0) + 1.0;
         }
         const double sf = exp(a.theta[d]), sn = exp(a.theta[d + 1]);
         lp += (c - log1p(sf * sf)) + (c - log1p(sn * sn));
@@ -381,6 +587,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     }
     __syncthreads();
     for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;
+    stamp(9);
     return;
   }
 
@@ -463,50 +670,61 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   __syncthreads();
 
   if (role == 2) {
-    const int rw = wg - 2;
+    const int rw = wg - 1 - NB64;
     // ---- forward: A = L^-1 K_uf for this workgroup's slabs, partial A A^T, A y, sum A o A, yy -----------------------
-    if (!sm_wait_ge(sy + SY_L * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
-    d4 pacc[NBW];
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) pacc[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double uacc = 0.0, a2acc = 0.0, yyacc = 0.0;  // thread m < MP: column sums over this workgroup's slabs
-    for (int sb = rw; sb < a.nslab; sb += a.grow) {
-      const int n0 = sb * SM_SLAB;
+    // K_uf of a slab straight into the register layout (needs theta only: the first slab is assembled while the chain
+    // workgroup is still factoring Kuu)
+    auto assemble = [&](int n0, SlabRegs<NB16>& Y) {
       __syncthreads();
-      sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
       for (int e = tid; e < SM_SLAB * (SM_MAXD + 1); e += 256) {
         const int r = e / (SM_MAXD + 1), j = e - r * (SM_MAXD + 1);
         sl.xs[r][j] = (n0 + r < N && j < d) ? a.X[(size_t)(n0 + r) * a.ldx + j] * hyp.inv_ls[j] : 0.0;
       }
       if (tid < SM_SLAB) sl.ys[tid] = n0 + tid < N ? a.y[n0 + tid] : 0.0;
       __syncthreads();
-      SlabRegs<NB16> Y;
-      {  // K_uf of this slab straight into the register layout
-        const int nl = 16 * w + l15;
-        double r2[NB16][4];
+      const int nl = 16 * w + l15;
+      double r2[NB16][4];
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r2[pb][s] = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double xj = sl.xs[nl][j];
 #pragma unroll
         for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) r2[pb][s] = 0.0;
-        for (int j = 0; j < d; ++j) {
-          const double xj = sl.xs[nl][j];
-#pragma unroll
-          for (int pb = 0; pb < NB16; ++pb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const double df = xj - sl.zs[16 * pb + 4 * s + l4][j];
-              r2[pb][s] = fma(df, df, r2[pb][s]);
-            }
-        }
-        const bool rowlive = n0 + nl < N;
-#pragma unroll
-        for (int pb = 0; pb < NB16; ++pb)
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            Y.b[pb][s] = (rowlive && (16 * pb + 4 * s + l4) < M) ? sf2 * sm_kprofile(a.kid, r2[pb][s]) : 0.0;
+          for (int s = 0; s < 4; ++s) {
+            const double df = xj - sl.zs[16 * pb + 4 * s + l4][j];
+            r2[pb][s] = fma(df, df, r2[pb][s]);
+          }
       }
+      const bool rowlive = n0 + nl < N;
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          Y.b[pb][s] = (rowlive && (16 * pb + 4 * s + l4) < M) ? sf2 * sm_kprofile(a.kid, r2[pb][s]) : 0.0;
+    };
+    SlabRegs<NB16> Y;
+    assemble(rw * SM_SLAB, Y);
+    stamp(1);
+    if (!sm_wait_ge(sy + SY_L * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+    stamp(2);
+    d4 pacc[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) pacc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double uacc = 0.0, a2acc = 0.0, yyacc = 0.0;  // thread m < MP: column sums over this workgroup's slabs
+    for (int sb = rw; sb < a.nslab; sb += a.grow) {
+      const int n0 = sb * SM_SLAB;
+      if (sb != rw) assemble(n0, Y);
+      __syncthreads();
+      sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
+      __syncthreads();
+      if (sb == rw) stamp(8);
+      if (sb == rw) stamp(9);
       sm_trsm_fwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
       __syncthreads();  // everybody is done with the factor blocks: the slab takes their place
+      if (sb == rw) stamp(10);
       {
         const int nl = 16 * w + l15;
         double* arow = a.A + (size_t)(n0 + nl) * MP;
@@ -533,6 +751,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
         const double v = sl.ys[tid - MP];
         yyacc = fma(v, v, yyacc);
       }
+      if (sb == rw) stamp(11);
       // partial A^T A: lower 16 x 16 blocks dealt round-robin to the waves
 #pragma unroll
       for (int i = 0; i < NBW; ++i) {
@@ -548,6 +767,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       }
     }
     __syncthreads();
+    stamp(12);
     {  // partials of this workgroup -> global
       double* P = a.Ppart + (size_t)rw * MP * MP;
 #pragma unroll
@@ -569,8 +789,10 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
         a.spart[3 + 2 * rw] = sy2;
       }
     }
+    stamp(3);
     sm_publish_add(sy + SY_PART * SM_SYNC_STRIDE);
     if (!sm_wait_ge(sy + SY_PART * SM_SYNC_STRIDE, a.grow, abortw, &dead)) return;
+    stamp(4);
     // ---- slices: B = I + sum_g P_g / s2 (mirrored), u, scalars -- fixed order over g ---------------------------------
     {
       const double is2 = 1.0 / s2;
@@ -582,10 +804,21 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
         const int gi = 16 * bi + i, gj = 16 * bj + j;
         if (gi < gj) continue;  // upper half of a diagonal block
         double s = 0.0;
-        for (int g = 0; g < a.grow; ++g) s += a.Ppart[(size_t)g * MP * MP + (size_t)gi * MP + gj];
+        const double* pp = a.Ppart + (size_t)gi * MP + gj;
+        int g = 0;
+        for (; g + 8 <= a.grow; g += 8) {  // eight loads in flight; the additions keep the fixed order
+          double t[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = pp[(size_t)(g + k) * MP * MP];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s += t[k];
+        }
+        for (; g < a.grow; ++g) s += pp[(size_t)g * MP * MP];
         const double v = (gi == gj ? 1.0 : 0.0) + s * is2;
         a.Bm[(size_t)gi * MP + gj] = v;
         a.Bm[(size_t)gj * MP + gi] = v;
+        a.Lb[(size_t)gi * MP + gj] = v;  // factored in place by the chain (only the lower triangle is read)
+        a.Lb[(size_t)gj * MP + gi] = v;
       }
       if (rw == 0) {
         if (tid < MP) {
@@ -605,10 +838,12 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       }
     }
     sm_publish_add(sy + SY_SLICE * SM_SYNC_STRIDE);
+    stamp(5);
     if (!a.want_grad) return;
 
     // ---- reverse: Abar per slab (two solves with LB), Kbar_uf = Abar L^-1 (one solve with L^T), contraction ----------
     if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+    stamp(6);
     if (tid < MP) sl.gv[tid] = a.g[tid];
     const double is2 = 1.0 / s2, is22 = is2 * is2;
     for (int sb = rw; sb < a.nslab; sb += a.grow) {
@@ -654,9 +889,10 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       __syncthreads();
       contract(Y, N - n0 < SM_SLAB ? N - n0 : SM_SLAB, 1.0);
     }
-    if (tid < SM_GP) a.gpart[(size_t)(rw + 1) * SM_GP + tid] = sl.acc[tid];
+    stamp(7);
+    if (tid < SM_GP) a.gpart[(size_t)(rw + NB64) * SM_GP + tid] = sl.acc[tid];
     if (a.want_gz)
-      for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)(rw + 1) * MP * SM_MAXD + e] = sl.gz[e];
+      for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)(rw + NB64) * MP * SM_MAXD + e] = sl.gz[e];
     sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
     return;
   }
@@ -665,10 +901,12 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   // role 1: Kbar_uu = -1/2 L^-T S L^-1, S = B + B^-1 - 2 I + g g^T / s2^2 ; its contraction with dK_uu ; tr B^-1
   if (!a.want_grad) return;
   if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+  stamp(1);
   if (tid < MP) sl.gv[tid] = a.g[tid];
   const double is22 = 1.0 / (s2 * s2);
   double trb = 0.0;
-  for (int v = 0; v < NB64; ++v) {  // Q[:, cols] = L^-T S[:, cols]
+  const int v = wg - 1;  // this workgroup's 64 columns of I
+  {  // Q[:, cols] = L^-T S[:, cols]
     const int col = 64 * v + 16 * w + l15;
     __syncthreads();
     sm_stage_factor<MP>(sl, a.Lb, a.dinvB);
@@ -698,12 +936,17 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) a.Qm[(size_t)(16 * pb + 4 * s + l4) * MP + col] = Y.b[pb][s];
   }
-  __threadfence();
-  __syncthreads();
   trb = block_sum(trb);
   if (tid == 0) sl.acc[SM_MAXD + 1] = trb;
-  // the factor of L stays staged: R[:, j] = L^-T (row j of Q)^T
-  for (int v = 0; v < NB64; ++v) {
+  stamp(2);
+  if (NB64 > 1) {  // the other workgroups' columns of Q
+    sm_publish_add(sy + SY_Q * SM_SYNC_STRIDE);
+    if (!sm_wait_ge(sy + SY_Q * SM_SYNC_STRIDE, NB64, abortw, &dead)) return;
+  } else {
+    __threadfence();
+    __syncthreads();
+  }
+  {  // the factor of L stays staged: R[:, j] = L^-T (row j of Q)^T
     const int col = 64 * v + 16 * w + l15;
     SlabRegs<NB16> Y;
     {
@@ -712,11 +955,6 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) Y.b[pb][s] = qrow[16 * pb + 4 * s + l4];
-    }
-    if (v > 0) {
-      __syncthreads();
-      sm_stage_factor<MP>(sl, a.Lk, a.dinvK);  // the contraction of the previous slab may have overwritten the blocks
-      __syncthreads();
     }
     sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
 #pragma unroll
@@ -730,9 +968,10 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     __syncthreads();
     contract(Y, M - 64 * v < SM_SLAB ? (M - 64 * v > 0 ? M - 64 * v : 0) : SM_SLAB, 2.0);
   }
-  if (tid < SM_GP) a.gpart[tid] = sl.acc[tid];
+  stamp(3);
+  if (tid < SM_GP) a.gpart[(size_t)v * SM_GP + tid] = sl.acc[tid];
   if (a.want_gz)
-    for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[e] = sl.gz[e];
+    for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)v * MP * SM_MAXD + e] = sl.gz[e];
   sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
 }
 
@@ -746,17 +985,14 @@ static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
   const int nslab = (int)((N + SM_SLAB - 1) / SM_SLAB) > 0 ? (int)((N + SM_SLAB - 1) / SM_SLAB) : 1;
   const int grow = nslab < SM_MAX_ROWWG ? nslab : SM_MAX_ROWWG;
   const size_t mm = (size_t)MP * MP;
-  const size_t nflag = (size_t)(NB64 * (NB64 + 1) / 2 + 1) * DF_FLAG_STRIDE;
   Carver c(ws);
   SmallWs w{};
   w.a.sync = c.take<int>(SY_WORDS * SM_SYNC_STRIDE);  // first: the caller zeroes the head of the workspace once
-  w.a.flagsK = c.take<int>(nflag);
-  w.a.flagsB = c.take<int>(nflag);
   w.a.Lk = c.take<double>(mm);
-  w.a.dinvK = c.take<double>((size_t)NB64 * 1024);
+  w.a.dinvK = c.take<double>((size_t)(MP / 16) * 256);
   w.a.Bm = c.take<double>(mm);
   w.a.Lb = c.take<double>(mm);
-  w.a.dinvB = c.take<double>((size_t)NB64 * 1024);
+  w.a.dinvB = c.take<double>((size_t)(MP / 16) * 256);
   w.a.A = c.take<double>((size_t)nslab * SM_SLAB * MP);
   w.a.Ppart = c.take<double>((size_t)grow * mm);
   w.a.upart = c.take<double>((size_t)grow * MP);
@@ -764,8 +1000,8 @@ static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
   w.a.u = c.take<double>(MP);
   w.a.c0 = c.take<double>(MP);
   w.a.g = c.take<double>(MP);
-  w.a.gpart = c.take<double>((size_t)(grow + 1) * SM_GP);
-  w.a.gzpart = c.take<double>((size_t)(grow + 1) * MP * SM_MAXD);
+  w.a.gpart = c.take<double>((size_t)(grow + NB64) * SM_GP);
+  w.a.gzpart = c.take<double>((size_t)(grow + NB64) * MP * SM_MAXD);
   w.a.Qm = c.take<double>(mm);
   w.a.nslab = nslab;
   w.a.grow = grow;
@@ -776,6 +1012,11 @@ static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
 }  // namespace sgp
 
 using namespace sgp;
+
+static unsigned long long* g_small_stamps = nullptr;
+// measurement aid (tools/small_eval_phases.py): a device buffer of (2 + 64) x 16 uint64 that the next launches fill with
+// s_memrealtime stamps at their phase boundaries; NULL switches it off
+extern "C" void sgp_small_debug_stamps(void* dev_buffer) { g_small_stamps = static_cast<unsigned long long*>(dev_buffer); }
 
 extern "C" int sgp_small_supported(int64_t N, int M, int d, int kernel_id) {
   return N >= 1 && N <= (int64_t)1 << 22 && M >= 1 && M <= 128 && d >= 1 && d <= SM_MAXD && kernel_id >= SGP_KERNEL_RBF &&
@@ -801,7 +1042,8 @@ extern "C" int sgp_small_eval(const double* X, int64_t ldx, const double* y, con
   a.want_gz = (want_grad && g_Z) ? 1 : 0;
   a.jitter = jitter;
   a.info = info; a.out = out; a.gZ = g_Z;
-  const int grid = 2 + a.grow;
+  a.stamps = g_small_stamps;
+  const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
   hipStream_t st = (hipStream_t)stream;
   if (M <= 64) small_eval_kernel<64><<<grid, 256, 0, st>>>(a);
   else small_eval_kernel<128><<<grid, 256, 0, st>>>(a);

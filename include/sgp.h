@@ -204,10 +204,13 @@ int sgp_bound_from_whitened_stats(const double* W, const double* u, const double
  * out (d + 5 doubles), g_Z (M*d, ld d, optional: NULL skips dF/dZ) and info are DEVICE pointers; nothing is synchronised.
  * want_grad = 0 writes out[0] (and the two parts) only.  The first sgp_small_sync_bytes() bytes of `ws` must be zero
  * before the FIRST launch on a workspace (the kernel leaves them zero; after info = SGP_INFO_TIMEOUT zero them again).
- * All workgroups (2 + min(ceil(N/64), 64)) must be co-resident: do not run it beside a kernel that fills the device.   */
+ * All workgroups (1 + ceil(M/64) + min(ceil(N/64), 64)) must be co-resident: do not run it beside a kernel that fills the device.   */
 #define SGP_SMALL_NATURAL 0
 #define SGP_SMALL_HMC 1
 int sgp_small_supported(int64_t N, int M, int d, int kernel_id);
+/* measurement aid: device buffer of (3 + 64) * 16 uint64 filled with s_memrealtime ticks (100 MHz) at the phase
+ * boundaries of every workgroup by the following launches; NULL (default) switches it off */
+void sgp_small_debug_stamps(void* dev_buffer);
 size_t sgp_small_workspace_bytes(int64_t N, int M, int d);
 size_t sgp_small_sync_bytes(void);
 int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
