@@ -106,6 +106,8 @@ class CollapsedBound:
         # 16 GiB super-chunks and pass 2 re-assembles.
         self._kfu = None
         self.kfu_budget_bytes = 64 << 30
+        self.fused = True          # single-launch path for small problems (M <= 128, one rank): sgp_small_eval
+        self._small = None         # (pinned host theta, device theta, result buffer) of the single-launch path
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
         self.use_graph = True      # ... replayed from a hipGraph (falls back to plain launches if capture fails)
         self.overlap_min_work = 1 << 21  # local rows x inducing points below which everything stays on one stream
@@ -160,6 +162,37 @@ class CollapsedBound:
         if self._kfu is None or self._kfu.numel() < need:
             self._kfu = e.kfu_buffer(n_local, M)
         return self._kfu
+
+    # ------------------------------------------------------------------ single-launch path (small problems)
+    def _small_ok(self, M):
+        """One cooperative launch instead of ~60: M <= 128, stationary kernel, d <= 16, this rank holds all rows, and the
+        caller did not insist on the streaming order (the launch evaluates the whitened / PyMC3 order)."""
+        e = self.engine
+        return (self.fused and self.world == 1 and self.form != "streaming" and hasattr(e, "small_eval")
+                and e.small_supported(int(self.X.shape[0]), int(M), self.d, self.kernel))
+
+    def _small_eval(self, Z, theta_host, mode, want_grad, want_gz):
+        """theta_host: d + 2 floats.  Returns (host out[d + 5], info, gZ device tensor or None): one launch, one small
+        host-to-device copy before it and one device-to-host copy after it."""
+        e = self.engine
+        d = self.d
+        if self._small is None:
+            pin = e.device.type == "cuda"
+            host = torch.empty(d + 2, dtype=torch.float64, pin_memory=pin)
+            self._small = (host, torch.empty(d + 2, dtype=torch.float64, device=e.device), e.small_result(d)[0])
+        host, dev_theta, buf = self._small
+        for i, v in enumerate(theta_host):
+            host[i] = float(v)
+        dev_theta.copy_(host, non_blocking=True)
+        out, gz, _ = e.small_eval(self.X, self.y, Z, dev_theta, self.jitter, self.kernel, mode=mode, want_grad=want_grad,
+                                  want_gz=want_gz, out=buf)
+        h = out.detach().to("cpu")
+        info = int(h[d + 5:d + 6].view(torch.int32)[0])
+        if info < 0:
+            if hasattr(e, "small_reset"):
+                e.small_reset()
+            raise SgpTimeoutError()
+        return h, info, gz
 
     def _whitened(self, M):
         if self.form == "auto":
@@ -238,6 +271,15 @@ class CollapsedBound:
     def value(self, Z, ls, sf2, s2, raise_on_fail=True):
         """F (not divided by N).  Returns (F, parts) with parts = dict(logmarg, trace_term, info)."""
         Z = self._prep_Z(Z)
+        if self._small_ok(Z.shape[0]):
+            d = self.d
+            h, info, _ = self._small_eval(Z, self._natural_theta(ls, sf2, s2), 0, False, False)
+            self.n_evals += 1
+            if info != 0:
+                if raise_on_fail:
+                    raise NotPositiveDefiniteError(info)
+                return float("nan"), {"info": info}
+            return float(h[0]), {"logmarg": float(h[d + 3]), "trace_term": float(h[d + 4]), "info": 0}
         res = self._forward(Z, ls, sf2, s2, with_adjoints=False)
         o, info, _ = self._fetch(res)
         self.n_evals += 1
@@ -247,6 +289,14 @@ class CollapsedBound:
             return float("nan"), {"info": info}
         return float(o[OUT_F]), {"logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE]), "info": 0}
 
+    def _natural_theta(self, ls, sf2, s2):
+        vals = [float(v) for v in (ls.tolist() if hasattr(ls, "tolist") else ls)]
+        if len(vals) == 1 and self.d > 1:
+            vals = vals * self.d
+        if len(vals) != self.d:
+            raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), self.d))
+        return vals + [float(sf2), float(s2)]
+
     def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True):
         """F and dF/d{lengthscale_j, sf2, s2[, Z]} (natural parameters, not their raw transforms).
 
@@ -255,6 +305,16 @@ class CollapsedBound:
         e = self.engine
         Z = self._prep_Z(Z)
         M, d = Z.shape
+        if self._small_ok(M):
+            h, info, gz = self._small_eval(Z, self._natural_theta(ls, sf2, s2), 0, True, want_gz)
+            self.n_evals += 1
+            self.n_grads += 1
+            if info != 0:
+                if raise_on_fail:
+                    raise NotPositiveDefiniteError(info)
+                return float("nan"), {"info": info}
+            return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
+                                 "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
         res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0))
         head = res["out"].numel() + 2  # [out | status word | pad], then the packed gradient (16-byte aligned)
@@ -360,6 +420,8 @@ class HmcTarget:
     def logp(self, theta):
         if not self._in_range(theta):
             return -math.inf
+        if self.bound._small_ok(self.Z.shape[0]):
+            return self.logp_and_grad(theta)[0]
         p = self.constrain(theta)
         F, parts = self.bound.value(self.Z, p["ls"], p["sig_f"] ** 2, p["sig_n"] ** 2, raise_on_fail=False)
         if parts.get("info", 0) != 0 or not math.isfinite(F):
@@ -371,6 +433,16 @@ class HmcTarget:
         """Returns (logp, grad list[d+2]).  One call = one HMC leapfrog's worth of device work."""
         if not self._in_range(theta):
             return -math.inf, [0.0] * self.ndim
+        b = self.bound
+        if b._small_ok(self.Z.shape[0]):
+            # ONE launch: transforms, priors and Jacobians are applied on the device (mode SGP_SMALL_HMC)
+            h, info, _ = b._small_eval(self.Z, [float(v) for v in theta], 1, True, False)
+            b.n_evals += 1
+            b.n_grads += 1
+            lp = float(h[0])
+            if info != 0 or not math.isfinite(lp):
+                return -math.inf, [0.0] * self.ndim
+            return lp, [float(v) for v in h[1:1 + self.ndim]]
         p = self.constrain(theta)
         ls, sf, sn = p["ls"], p["sig_f"], p["sig_n"]
         F, g = self.bound.value_and_grad(self.Z, ls, sf * sf, sn * sn, want_gz=False, raise_on_fail=False)

@@ -106,3 +106,30 @@ def test_small_reports_non_pd(engine):
     th = torch.tensor([1.0, 1.0, 1.0, 0.1], dtype=torch.float64).to(engine.device)
     out, _, info = engine.small_eval(X.to(engine.device), y.to(engine.device), Z.to(engine.device), th, 0.0, "rbf", mode=0, want_grad=True)
     assert 1 <= int(info.item()) <= 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL)
+def test_fused_launch_agrees_with_the_multi_launch_whitened_path(engine, name):
+    """CollapsedBound routes M <= 128 through the single launch; ``fused = False`` keeps the multi-launch whitened path
+    (sgp_kuu_factor -> sgp_suffstats_fwd_whitened -> sgp_bound_from_whitened_stats -> pass 2).  Same mathematics, different
+    association order (substitution solves vs explicit L^-1, per-slab partial sums vs GEMM tiles), so the two agree to
+    rounding, not bit for bit: 1e-10 relative on F, 1e-7 on the gradients (1e-5 on the duplicate-Z fixture)."""
+    import ggp_amd
+    G = load_golden(name)
+    kern = KNAME[int(G["kernel_id"])]
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    a = ggp_amd.CollapsedBound(X, y, kernel=kern, jitter=float(G["jitter"]), engine=engine)
+    b = ggp_amd.CollapsedBound(X, y, kernel=kern, jitter=float(G["jitter"]), engine=engine, form="whitened")
+    b.fused = False
+    assert a._small_ok(Z.shape[0]) and not b._small_ok(Z.shape[0])
+    Fa, ga = a.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+    Fb, gb = b.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+    ill = float(G["grad_rtol"]) > 1e-6
+    assert abs(Fa - Fb) < 1e-10 * max(1.0, abs(Fb))
+    rt = 1e-5 if ill else 1e-7
+    assert relerr(ga["ls"].numpy(), gb["ls"].numpy()) < rt and abs(ga["sf2"] - gb["sf2"]) < rt * max(1.0, abs(gb["sf2"]))
+    assert abs(ga["s2"] - gb["s2"]) < rt * max(1.0, abs(gb["s2"]))
+    assert relerr(ga["Z"].cpu().numpy(), gb["Z"].cpu().numpy()) < (1e-3 if ill else 1e-6)
+    Fv, parts = a.value(Z, G["ls"], float(G["sf2"]), float(G["s2"]))
+    assert Fv == Fa and abs(parts["trace_term"] - gb["trace_term"]) < 1e-8 * max(1.0, abs(Fb))
