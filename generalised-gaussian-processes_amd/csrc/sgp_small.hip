@@ -72,19 +72,11 @@ struct SmSlabShared {
   double acc[SM_GP];
 };
 
-// the chain workgroup's view: the whole MP x MP matrix stays in LDS through assembly, factorization and the two
-// vector solves; only the finished factor (and the block inverses the slab solves start from) go to global memory
+// the chain workgroup's view: the scratch of the 64 x 64 tile factorization (sgp_potrf.hpp) + the scaled inducing inputs
 template <int MP>
 struct SmChainShared {
-  static constexpr int LDA = MP + 1;
-  double Am[MP][LDA];
-  union {
-    double Dinv[MP / 16][16][17];
-    double zs[MP][SM_MAXD + 1];  // scaled inducing inputs, only while Kuu is assembled (same size)
-  };
-  double xv[MP];  // solution vector of the block substitutions
-  double rs[MP];  // reciprocal pivots
-  int bad;
+  DfShared df;
+  double zs[MP][SM_MAXD + 1];
 };
 
 template <int MP>
@@ -92,124 +84,6 @@ union SmShared {
   SmChainShared<MP> ch;
   SmSlabShared<MP> sl;
 };
-
-// In-place lower Cholesky of cs.Am (MP x MP, in LDS) by one workgroup of 4 waves, left-looking over 16-column panels:
-//   (U) panel -= L(:, earlier) L(p, earlier)^T     MFMA, row blocks dealt to the waves
-//   (D) 16 x 16 diagonal block                      wave 0: lane <-> row, pivots broadcast by v_readlane, rsqrt + 2 Newton steps;
-//       its inverse Dinv[p]                          same wave, forward substitution on the rows still in registers
-//   (T) L(q, p) = A(q, p) Dinv[p]^T                 MFMA
-// cs.bad = first non-positive pivot (1-based; the factorization continues on a unit pivot), cs.rs = 1 / diag(L).
-// Written for a matrix that is factored ONCE per launch: compact loops (the tile-dataflow factorization of
-// sgp_potrf.hpp, built for M = 1024, is 19k instructions of straight-line code -- cold, it took 38 us for M = 128).
-template <int MP>
-__device__ __forceinline__ void sm_chol_lds(SmChainShared<MP>& cs) {
-  constexpr int NB16 = MP / 16;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  if (tid == 0) cs.bad = 0;
-  __syncthreads();
-#pragma unroll 1
-  for (int p = 0; p < NB16; ++p) {
-    if (p > 0) {
-      for (int q = p + w; q < NB16; q += 4) {
-        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int t = 0; t < p; ++t) {
-#pragma unroll
-          for (int sq = 0; sq < 4; ++sq)
-            acc = mfma16(cs.Am[16 * q + l15][16 * t + 4 * sq + l4], cs.Am[16 * p + l15][16 * t + 4 * sq + l4], acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cs.Am[16 * q + l4 + 4 * r][16 * p + l15] -= acc[r];
-      }
-      __syncthreads();
-    }
-    if (w == 0) {
-      const int row = 16 * p + l15;
-      double a[16], rsv[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = cs.Am[row][16 * p + k];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double dj = readlane_f64(a[j], j);
-        if (!(dj > 0.0)) {  // non-positive or NaN pivot: LAPACK-style report, continue on a unit pivot
-          if (lane == 0 && cs.bad == 0) cs.bad = 16 * p + j + 1;
-          dj = 1.0;
-        }
-        rsv[j] = rsqrt_newton(dj);
-        const double lj = a[j] * rsv[j];
-        a[j] = lj;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] = fma(-lj, readlane_f64(lj, k), a[k]);
-      }
-      // inverse of the block: lane c <-> column c, y[r] = (delta_rc - sum_{q<r} L[r][q] y[q]) / L[r][r]
-      double y[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double s0 = (r == l15) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < r; ++q) {
-          const double lrq = readlane_f64(a[q], r);
-          if (q & 1) s1 = fma(-lrq, y[q], s1);
-          else s0 = fma(-lrq, y[q], s0);
-        }
-        y[r] = (s0 + s1) * rsv[r];
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          cs.Am[row][16 * p + k] = (k <= l15) ? a[k] : 0.0;
-          cs.Dinv[p][k][l15] = y[k];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (lane == j) cs.rs[16 * p + j] = rsv[j];
-    }
-    __syncthreads();
-    for (int q = p + 1 + w; q < NB16; q += 4) {
-      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) acc = mfma16(cs.Am[16 * q + l15][16 * p + 4 * sq + l4], cs.Dinv[p][l15][4 * sq + l4], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cs.Am[16 * q + l4 + 4 * r][16 * p + l15] = acc[r];
-    }
-    __syncthreads();
-  }
-}
-
-// x <- L^-1 x (trans = false) or L^-T x (trans = true) for the factor in cs.Am / cs.Dinv; x = cs.xv; wave 0 works
-template <int MP>
-__device__ __forceinline__ void sm_vec_solve(SmChainShared<MP>& cs, bool trans) {
-  constexpr int NB16 = MP / 16;
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-  if (tid < 64) {
-#pragma unroll 1
-    for (int pp = 0; pp < NB16; ++pp) {
-      const int p = trans ? NB16 - 1 - pp : pp;
-      double part = 0.0;
-      if (!trans) {
-        for (int k = l4; k < 16 * p; k += 4) part = fma(cs.Am[16 * p + l15][k], cs.xv[k], part);
-      } else {
-        for (int k = 16 * p + 16 + l4; k < MP; k += 4) part = fma(cs.Am[k][16 * p + l15], cs.xv[k], part);
-      }
-      part += __shfl_xor(part, 16, 64);
-      part += __shfl_xor(part, 32, 64);
-      const double r = cs.xv[16 * p + l15] - part;  // every lane: entry l15 of the block's right-hand side
-      double x = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double rk = __shfl(r, k, 64);
-        x = fma(trans ? cs.Dinv[p][k][l15] : cs.Dinv[p][l15][k], rk, x);
-      }
-      if (lane < 16) cs.xv[16 * p + l15] = x;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-}
 
 __device__ __forceinline__ int sm_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -252,6 +126,46 @@ __device__ __forceinline__ void sm_kprofile_grad(int kid, double r2, double& k, 
   if (kid == SGP_KERNEL_RBF) kprofile_grad<SGP_KERNEL_RBF>(r2, k, h);
   else if (kid == SGP_KERNEL_MATERN32) kprofile_grad<SGP_KERNEL_MATERN32>(r2, k, h);
   else kprofile_grad<SGP_KERNEL_MATERN52>(r2, k, h);
+}
+
+// v[i] <- scale * k'(v[i]) for NE independent entries: ONE switch on the kernel id, then straight-line code, so the NE
+// exp() chains interleave (a lone wave per SIMD pays the full latency of every dependent fp64 instruction otherwise:
+// 0.4 us per serial exp(), measured)
+template <int NE>
+__device__ __forceinline__ void sm_profile_vec(int kid, double (&v)[NE], double scale) {
+  if (kid == SGP_KERNEL_RBF) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) v[i] = scale * kprofile<SGP_KERNEL_RBF>(v[i]);
+  } else if (kid == SGP_KERNEL_MATERN32) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) v[i] = scale * kprofile<SGP_KERNEL_MATERN32>(v[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) v[i] = scale * kprofile<SGP_KERNEL_MATERN52>(v[i]);
+  }
+}
+// r2[i] -> (k'[i] in r2[i], h[i] = dk'/dr2)
+template <int NE>
+__device__ __forceinline__ void sm_profile_grad_vec(int kid, double (&r2)[NE], double (&h)[NE]) {
+  if (kid == SGP_KERNEL_RBF) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const double t = r2[i];
+      kprofile_grad<SGP_KERNEL_RBF>(t, r2[i], h[i]);
+    }
+  } else if (kid == SGP_KERNEL_MATERN32) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const double t = r2[i];
+      kprofile_grad<SGP_KERNEL_MATERN32>(t, r2[i], h[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const double t = r2[i];
+      kprofile_grad<SGP_KERNEL_MATERN52>(t, r2[i], h[i]);
+    }
+  }
 }
 
 // theta -> hyper-parameters (thread 0), the same arithmetic in every workgroup.
@@ -360,6 +274,47 @@ __device__ __forceinline__ void sm_stage_factor(SmSlabShared<MP>& sl, const doub
   }
 }
 
+// x <- L^-1 x (trans = false) or L^-T x (trans = true) for the factor staged in sl.Lblk / sl.Dinv; x (MP doubles) in LDS.
+// Wave 0 works, every thread calls.  ~1.3 us at MP = 128: each workgroup derives c0 = LB^-1 u and g = LB^-T c0 itself
+// instead of waiting for the chain workgroup to do it.
+template <int MP>
+__device__ __forceinline__ void sm_vec_solve_blocks(SmSlabShared<MP>& sl, double* xv, bool trans) {
+  constexpr int NB16 = MP / 16;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  __syncthreads();
+  if (tid < 64) {
+#pragma unroll 1
+    for (int pp = 0; pp < NB16; ++pp) {
+      const int p = trans ? NB16 - 1 - pp : pp;
+      double part = 0.0;
+      if (!trans) {
+        for (int t = l4; t < p; t += 4) {
+          const double (*B)[17] = sl.Lblk[sm_blk(p, t)];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) part = fma(B[l15][k], xv[16 * t + k], part);
+        }
+      } else {
+        for (int t = p + 1 + l4; t < NB16; t += 4) {
+          const double (*B)[17] = sl.Lblk[sm_blk(t, p)];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) part = fma(B[k][l15], xv[16 * t + k], part);
+        }
+      }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      const double r = xv[16 * p + l15] - part;
+      double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x = fma(trans ? sl.Dinv[p][k][l15] : sl.Dinv[p][l15][k], __shfl(r, k, 64), x);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 16) xv[16 * p + l15] = x;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------------
 template <int MP>
 __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
@@ -411,109 +366,205 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
 
   // =================================================================================================================
   if (role == 0) {
-    SmChainShared<MP>& cs = sh.ch;
-    // ---- Kuu assembled in LDS (lower triangle, four independent exp() chains per thread), factored in place ----------
+    DfShared& df = sh.ch.df;
+    double (*zs)[SM_MAXD + 1] = sh.ch.zs;
+    const int r = tid & 63, g = w;                       // thread <-> (row r, columns 16 g ..) of a diagonal tile
+    const int wi = w >> 1, wj = w & 1;
     if (tid == 0) *a.info = 0;
     for (int e = tid; e < MP * (SM_MAXD + 1); e += 256) {
       const int m = e / (SM_MAXD + 1), j = e - m * (SM_MAXD + 1);
-      cs.zs[m][j] = (m < M && j < d) ? a.Z[(size_t)m * a.ldz + j] * hyp.inv_ls[j] : 0.0;
+      zs[m][j] = (m < M && j < d) ? a.Z[(size_t)m * a.ldz + j] * hyp.inv_ls[j] : 0.0;
     }
     __syncthreads();
-    {
-      constexpr int NLOW = MP * (MP + 1) / 2;
-      for (int e0 = tid; e0 < NLOW; e0 += 1024) {
-        double r2[4];
-        int ii[4], jj[4];
+    // 16 entries of the padded Kuu: row i, columns j0 + cstride * k (k = 0..15)
+    auto kuu16 = [&](int i, int j0, int cstride, double (&v)[16]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + 256 * u;
-          int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-          while ((i + 1) * (i + 2) / 2 <= e) ++i;
-          while (i * (i + 1) / 2 > e) --i;
-          ii[u] = e < NLOW ? i : 0;
-          jj[u] = e < NLOW ? e - i * (i + 1) / 2 : 0;
-          r2[u] = 0.0;
-        }
-        for (int q = 0; q < d; ++q) {
+      for (int k = 0; k < 16; ++k) v[k] = 0.0;
+      for (int q = 0; q < d; ++q) {
+        const double zi = zs[i][q];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double df = cs.zs[ii[u]][q] - cs.zs[jj[u]][q];
-            r2[u] = fma(df, df, r2[u]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (e0 + 256 * u < NLOW) {
-            const int i = ii[u], j = jj[u];
-            double v = i == j ? 1.0 : 0.0;
-            if (i < M && j < M) v = sf2 * sm_kprofile(a.kid, r2[u]) + (i == j ? a.jitter : 0.0);
-            cs.Am[i][j] = v;
-          }
+        for (int k = 0; k < 16; ++k) {
+          const double dz = zi - zs[j0 + cstride * k][q];
+          v[k] = fma(dz, dz, v[k]);
         }
       }
-    }
-    __syncthreads();  // (zs is dead from here: Dinv takes its place)
-    stamp(1);
-    sm_chol_lds<MP>(cs);
-    auto write_factor = [&](double* Lg, double* dg) {
-      for (int e = tid; e < MP * MP; e += 256) {
-        const int i = e / MP, j = e - i * MP;
-        Lg[e] = j <= i ? cs.Am[i][j] : 0.0;
+      sm_profile_vec<16>(a.kid, v, sf2);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int j = j0 + cstride * k;
+        if (i >= M || j >= M) v[k] = i == j ? 1.0 : 0.0;
+        else if (i == j) v[k] += a.jitter;
       }
-      for (int e = tid; e < NB16 * 256; e += 256) dg[e] = cs.Dinv[e >> 8][(e >> 4) & 15][e & 15];
     };
-    write_factor(a.Lk, a.dinvK);
-    if (tid == 0 && cs.bad != 0) *a.info = cs.bad;
-    sm_publish_set(sy + SY_L * SM_SYNC_STRIDE, 1);
-    stamp(2);
-
-    // ---- B complete -> LB, c0 = LB^-1 u, g = LB^-T c0 ---------------------------------------------------------------
-    if (!sm_wait_ge(sy + SY_SLICE * SM_SYNC_STRIDE, a.grow, abortw, &dead)) {
-      if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
-      return;
-    }
-    stamp(3);
-    {
-      constexpr int NV = MP * MP / 256 / 8;
-      for (int it = 0; it < NV; ++it) {  // eight loads in flight per thread
-        double v[8];
+    double ldsum[2] = {0.0, 0.0};
+    // Two factorizations through ONE copy of the tile code (pass 0: Kuu, its entries evaluated straight into the
+    // registers the factorization works in; pass 1: B from the slices).  64 x 64 tiles, one workgroup, no flags:
+    //   diagonal tile  -> diag_factor64_fast (sgp_potrf.hpp: pivot chain pipelined over the four waves)
+    //   tile (1, 0)    -> X = T L00^-T on the matrix cores from the panels / block inverses the factorization left in LDS
+    //   tile (1, 1)    -= X X^T from LDS, then factored
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      double* Lg = pass == 0 ? a.Lk : a.Lb;
+      double* dg = pass == 0 ? a.dinvK : a.dinvB;
+      if (pass == 1) {
+        if (!sm_wait_ge(sy + SY_SLICE * SM_SYNC_STRIDE, a.grow, abortw, &dead)) {
+          if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
+          return;
+        }
+        stamp(3);
+      }
+      int bad_first = 0;
+      double ld = 0.0;
+#pragma unroll 1
+      for (int jd = 0; jd < NB64; ++jd) {
+        double x[16];
+        if (pass == 0) {
+          kuu16(64 * jd + r, 64 * jd + 16 * g, 1, x);
+        } else {
+          const double* src = a.Lb + (size_t)(64 * jd + r) * MP + 64 * jd + 16 * g;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = a.Bm[(size_t)(it * 8 + k) * 256 + tid];
+          for (int k = 0; k < 8; ++k) {
+            const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
+            x[2 * k] = v[0];
+            x[2 * k + 1] = v[1];
+          }
+        }
+        if (jd > 0) {  // minus X X^T (X = tile (jd, jd - 1), still in df.Ts)
+          d4 acc[2][2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int e = (it * 8 + k) * 256 + tid;
-          cs.Am[e / MP][e % MP] = v[k];
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+          df_mac_lds(df.Ts, acc, wi, wj, l15, l4);
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) df.Ts[wi * 32 + u * 16 + l4 + 4 * q][wj * 32 + v * 16 + l15] = acc[u][v][q];
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) x[k] -= df.Ts[r][16 * g + k];
+        }
+        if (tid < 4) df.prog[tid] = 0;
+        if (tid == 0) df.bad = 0;
+        __syncthreads();
+        diag_factor64_fast(x, df.Sp, df.Lt, df.prog, df.rdiag3, df.Dinv, &df.bad, r, g);
+        if (df.bad != 0 && bad_first == 0) bad_first = 64 * jd + df.bad;
+        {  // L(jd, jd) rows, the zero tile above it, the 16 x 16 block inverses
+          double* dst = Lg + (size_t)(64 * jd + r) * MP + 64 * jd + 16 * g;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<d2*>(dst + 2 * k) = d2{(16 * g + 2 * k <= r) ? x[2 * k] : 0.0, (16 * g + 2 * k + 1 <= r) ? x[2 * k + 1] : 0.0};
+          if (jd + 1 < NB64) {
+            double* up = Lg + (size_t)(64 * jd + r) * MP + 64 * (jd + 1) + 16 * g;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<d2*>(up + 2 * k) = d2{0.0, 0.0};
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;  // (blk, row, col) = (idx >> 8, (idx >> 4) & 15, idx & 15)
+            dg[(size_t)jd * 1024 + idx] = df.Dinv[idx >> 8][(idx >> 4) & 15][idx & 15];
+          }
+          if ((r >> 4) == g) ld += log(x[r & 15]);
+        }
+        if (jd + 1 < NB64) {
+          // X = T L(jd,jd)^-T : wave g <-> rows 16 g .. of the tile below, transposed blocks in the accumulator layout
+          d4 yb[4];
+          const int trow = 64 * (jd + 1) + 16 * g + l15;
+          if (pass == 0) {
+            double v[16];  // columns 64 jd + l4 + 4 k  <->  (pb, sq) = (k >> 2, k & 3)
+            kuu16(trow, 64 * jd + l4, 4, v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) yb[k >> 2][k & 3] = v[k];
+          } else {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+              for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = a.Lb[(size_t)trow * MP + 64 * jd + 16 * pb + 4 * sq + l4];
+          }
+          d4 xb[4];
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) {
+            d4 xa = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) xa = mfma16(df.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
+            xb[pb] = xa;
+#pragma unroll
+            for (int q = pb + 1; q < 4; ++q)
+#pragma unroll
+              for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-df.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
+          }
+          __syncthreads();  // the panels have been read: Ts may be written
+          double* dst = Lg + (size_t)trow * MP + 64 * jd + l4;
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+              dst[16 * pb + 4 * sq] = xb[pb][sq];
+              df.Ts[16 * g + l15][16 * pb + 4 * sq + l4] = xb[pb][sq];
+            }
+          __syncthreads();
         }
       }
-      if (tid < MP) cs.xv[tid] = a.u[tid];
+      ld = block_sum(ld);
+      ldsum[pass] = ld;
+      if (tid == 0 && bad_first != 0 && *a.info == 0) *a.info = (pass == 0 ? 0 : M) + bad_first;
+      if (pass == 0) {
+        stamp(1);
+        sm_publish_set(sy + SY_L * SM_SYNC_STRIDE, 1);
+        stamp(2);
+      }
     }
-    __syncthreads();
     stamp(4);
-    sm_chol_lds<MP>(cs);
-    if (tid == 0 && cs.bad != 0 && *a.info == 0) *a.info = M + cs.bad;
-    write_factor(a.Lb, a.dinvB);
-    sm_vec_solve<MP>(cs, false);
-    if (tid < MP) a.c0[tid] = cs.xv[tid];
-    double cc = 0.0, ld = 0.0;
-    for (int i = tid; i < MP; i += 256) {
-      cc = fma(cs.xv[i], cs.xv[i], cc);
-      ld -= log(cs.rs[i]);
+    if (a.want_grad) sm_publish_set(sy + SY_LB * SM_SYNC_STRIDE, 1);
+    else {
+      __threadfence();
+      __syncthreads();
     }
     stamp(5);
-    sm_vec_solve<MP>(cs, true);
-    if (tid < MP) a.g[tid] = cs.xv[tid];
-    __syncthreads();
+    // c0 = LB^-1 u for the value (the other workgroups derive c0 and g themselves from the published factor): wave 0,
+    // lane <-> row, 64-step chains per tile with the row of L in registers
+    double cc = 0.0;
+    if (w == 0) {
+      for (int jb = 0; jb < NB64; ++jb) {
+        const double* lsrc = a.Lb + (size_t)(jb * 64 + lane) * MP + (size_t)jb * 64;
+        double lrow[64];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const d2 t2 = *reinterpret_cast<const d2*>(lsrc + 2 * k);
+          lrow[2 * k] = t2[0];
+          lrow[2 * k + 1] = t2[1];
+        }
+        double rr = a.u[jb * 64 + lane];
+        for (int p = 0; p < jb; ++p) {
+          const double* lp = a.Lb + (size_t)(jb * 64 + lane) * MP + (size_t)p * 64;
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+          for (int k = 0; k < 64; k += 2) {
+            s0 = fma(lp[k], a.c0[p * 64 + k], s0);
+            s1 = fma(lp[k + 1], a.c0[p * 64 + k + 1], s1);
+          }
+          rr -= s0 + s1;
+        }
+        const double dinv = 1.0 / a.Lb[(size_t)(jb * 64 + lane) * (MP + 1)];
+        double mine = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+          const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
+          if (lane == c) mine = xc;
+          rr = fma(-lrow[c], xc, rr);
+        }
+        a.c0[jb * 64 + lane] = mine;
+        cc = fma(mine, mine, cc);
+        __threadfence();
+      }
+    }
+    cc = block_sum(cc);
+    const double ld = ldsum[1];
     stamp(6);
     // scalars
-    double ug = 0.0, gg = 0.0;
-    for (int i = tid; i < MP; i += 256) {
-      ug = fma(a.u[i], cs.xv[i], ug);
-      gg = fma(cs.xv[i], cs.xv[i], gg);
-    }
-    ld = block_sum(ld);
-    cc = block_sum(cc);
-    ug = block_sum(ug);
-    gg = block_sum(gg);
     const double sumA2 = a.spart[0], yy = a.spart[1];  // reduced by the slice stage
     const double Nd = (double)N, kappa = Nd * sf2;
     const double LOG2PI = 1.8378770664093453;
@@ -532,7 +583,6 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;  // ready for the next launch
       return;
     }
-    sm_publish_set(sy + SY_LB * SM_SYNC_STRIDE, 1);
     stamp(7);
 
     // ---- gradients --------------------------------------------------------------------------------------------------
@@ -555,7 +605,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-      const double trBinv = gsum[SM_MAXD + 1];
+      const double trBinv = gsum[SM_MAXD + 1], ug = gsum[SM_MAXD + 2], gg = gsum[SM_MAXD + 3];
       const double g_sf2 = gsum[SM_MAXD] - Nd / (2.0 * s2);  // + kappabar dkappa/dsf2
       const double s22 = s2 * s2;
       const double g_s2 = -0.5 * (-((double)MP - trBinv) / s2 + Nd / s2 - yy / s22 + 2.0 * ug / (s22 * s2) - (ug - gg) / (s22 * s2)
@@ -615,16 +665,17 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
             r2[pb][s] = fma(df, df, r2[pb][s]);
           }
       }
+      double (&rv)[NB16 * 4] = reinterpret_cast<double (&)[NB16 * 4]>(r2);
+      double (&hv)[NB16 * 4] = reinterpret_cast<double (&)[NB16 * 4]>(E);
+      sm_profile_grad_vec<NB16 * 4>(a.kid, rv, hv);  // r2 <- k', E <- dk'/dr2
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          double kp, hp;
-          sm_kprofile_grad(a.kid, r2[pb][s], kp, hp);
           const bool live = nl < nvalid && (16 * pb + 4 * s + l4) < M;
           const double kb = live ? Y.b[pb][s] : 0.0;
-          ksum = fma(kb, kp, ksum);
-          E[pb][s] = kb * sf2 * hp;
+          ksum = fma(kb, r2[pb][s], ksum);
+          E[pb][s] = kb * sf2 * E[pb][s];
         }
     }
     ksum = wave_sum(ksum);
@@ -699,11 +750,12 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
           }
       }
       const bool rowlive = n0 + nl < N;
+      double (&rv)[NB16 * 4] = reinterpret_cast<double (&)[NB16 * 4]>(r2);
+      sm_profile_vec<NB16 * 4>(a.kid, rv, sf2);
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          Y.b[pb][s] = (rowlive && (16 * pb + 4 * s + l4) < M) ? sf2 * sm_kprofile(a.kid, r2[pb][s]) : 0.0;
+        for (int s = 0; s < 4; ++s) Y.b[pb][s] = (rowlive && (16 * pb + 4 * s + l4) < M) ? r2[pb][s] : 0.0;
     };
     SlabRegs<NB16> Y;
     assemble(rw * SM_SLAB, Y);
@@ -844,7 +896,6 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     // ---- reverse: Abar per slab (two solves with LB), Kbar_uf = Abar L^-1 (one solve with L^T), contraction ----------
     if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
     stamp(6);
-    if (tid < MP) sl.gv[tid] = a.g[tid];
     const double is2 = 1.0 / s2, is22 = is2 * is2;
     for (int sb = rw; sb < a.nslab; sb += a.grow) {
       const int n0 = sb * SM_SLAB, nl = 16 * w + l15;
@@ -855,6 +906,11 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
         sl.xs[r][j] = (n0 + r < N && j < d) ? a.X[(size_t)(n0 + r) * a.ldx + j] * hyp.inv_ls[j] : 0.0;
       }
       if (tid < SM_SLAB) sl.ys[tid] = n0 + tid < N ? a.y[n0 + tid] : 0.0;
+      if (sb == rw) {  // g = B^-1 u from the factor just staged (every workgroup for itself: nobody waits for a broadcast)
+        if (tid < MP) sl.gv[tid] = a.u[tid];
+        sm_vec_solve_blocks<MP>(sl, sl.gv, false);
+        sm_vec_solve_blocks<MP>(sl, sl.gv, true);
+      }
       __syncthreads();
       SlabRegs<NB16> Ya, Y;
       {
@@ -902,7 +958,6 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   if (!a.want_grad) return;
   if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
   stamp(1);
-  if (tid < MP) sl.gv[tid] = a.g[tid];
   const double is22 = 1.0 / (s2 * s2);
   double trb = 0.0;
   const int v = wg - 1;  // this workgroup's 64 columns of I
@@ -910,6 +965,17 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     const int col = 64 * v + 16 * w + l15;
     __syncthreads();
     sm_stage_factor<MP>(sl, a.Lb, a.dinvB);
+    if (tid < MP) sl.gv[tid] = a.u[tid];
+    sm_vec_solve_blocks<MP>(sl, sl.gv, false);
+    sm_vec_solve_blocks<MP>(sl, sl.gv, true);  // g = B^-1 u
+    if (v == 0) {  // the two scalars of dF/ds2 that involve g
+      const double ug = block_sum(tid < MP ? a.u[tid] * sl.gv[tid] : 0.0);
+      const double gg = block_sum(tid < MP ? sl.gv[tid] * sl.gv[tid] : 0.0);
+      if (tid == 0) {
+        sl.acc[SM_MAXD + 2] = ug;
+        sl.acc[SM_MAXD + 3] = gg;
+      }
+    }
     __syncthreads();
     SlabRegs<NB16> Y;
 #pragma unroll
