@@ -1,0 +1,418 @@
+// NUTS as a resumable state machine -- the sampler the reference gets from pm.NUTS() / pm.sample(n, tune=tune, chains=1)
+// (models/bayesian_sgpr_hmc.py:73-78), written so that ONE thread of a persistent GPU kernel can run it between the
+// cooperative evaluations of the log-density (sgp_small.hip): `nuts_step` consumes the result of the evaluation it asked
+// for last and returns the next position to evaluate (or NUTS_DONE).  The same header compiles for the host (g++): the
+// CPU tests run it against the Python sampler (generalised-gaussian-processes_amd/hmc.py), whose algorithm it follows
+// line by line -- multinomial NUTS with the generalised U-turn criterion on sub-trees, biased progressive sampling at the
+// top level, dual-averaging step size (target_accept 0.8) and PyMC3's jitter+adapt_diag mass adaptation -- with the
+// recursion of `NUTS._build` unrolled into a stack of finished sub-trees (binary-counter merging: after every leaf the two
+// topmost sub-trees of equal depth are combined; a diverging / turning sub-tree is folded into the pending left siblings
+// exactly as the recursion would return it upwards).  Random numbers: splitmix64 -> uniforms / Box-Muller normals, the
+// same generator as `hmc.SplitMix` so host, device and Python draw identical streams.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SGP_HD __host__ __device__
+#else
+#define SGP_HD
+#endif
+
+namespace sgp {
+
+constexpr int NUTS_MAXD = 20;      // dimension of theta (d + 2 for the collapsed bound, d <= 16)
+constexpr int NUTS_MAXDEPTH = 12;  // stack entries (max_treedepth <= 11)
+enum { NUTS_EVAL = 1, NUTS_DONE = 2 };
+enum { NS_INIT = 0, NS_WAIT_INIT, NS_BEGIN_DRAW, NS_WAIT_LEAF, NS_FINISHED };
+// per-draw statistics written to the trace: columns of `stats`
+enum { NST_STEP = 0, NST_TREE, NST_DEPTH, NST_ACCEPT, NST_DIVERGING, NST_ENERGY, NST_LOGP, NST_NLEAP, NST_COLS = 8 };
+
+struct NutsRng {
+  uint64_t s;
+  int have_spare;
+  double spare;
+};
+SGP_HD inline uint64_t rng_u64(NutsRng& r) {
+  uint64_t z = (r.s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+SGP_HD inline double rng_uniform(NutsRng& r) { return (double)(rng_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
+SGP_HD inline double rng_normal(NutsRng& r) {
+  if (r.have_spare) {
+    r.have_spare = 0;
+    return r.spare;
+  }
+  const double u1 = 1.0 - rng_uniform(r), u2 = rng_uniform(r);  // u1 in (0, 1]
+  const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+  r.spare = rad * sin(ang);
+  r.have_spare = 1;
+  return rad * cos(ang);
+}
+
+struct NutsPoint {  // a phase-space point of the trajectory
+  double q[NUTS_MAXD], p[NUTS_MAXD], grad[NUTS_MAXD];
+  double logp, energy;
+};
+struct NutsTree {  // a finished sub-tree (hmc.py: _Tree)
+  double lp[NUTS_MAXD], rp[NUTS_MAXD];  // momenta of its left- / rightmost state (v = var o p is recomputed)
+  double p_sum[NUTS_MAXD];
+  double prop_q[NUTS_MAXD], prop_grad[NUTS_MAXD];
+  double prop_logp, prop_energy;
+  double log_size, accept_sum;
+  int n, depth, diverging, turning;
+};
+struct NutsWeightedVar {  // hmc.py: _WeightedVariance
+  double n;
+  double mean[NUTS_MAXD], m2[NUTS_MAXD];
+};
+
+struct NutsState {
+  // configuration
+  int ndim, n_tune, n_draws, max_treedepth;
+  double target_accept, Emax;
+  // adaptation (hmc.py: DualAveraging, DiagMassAdapter)
+  double da_mu, da_log_step, da_log_bar, da_hbar, da_gamma, da_t0, da_kappa;
+  int da_count;
+  double var[NUTS_MAXD];
+  NutsWeightedVar fg, bg;
+  int mass_count, mass_window;
+  NutsRng rng;
+  // chain
+  int phase, it;       // it = index of the current draw (tuning draws first)
+  long n_leapfrog;
+  NutsPoint cur;       // current state of the chain (q, logp, grad)
+  // the transition in flight
+  double eps, e0;
+  NutsPoint left, right, edge, trial;
+  double p0[NUTS_MAXD];
+  double top_p_sum[NUTS_MAXD], top_prop_q[NUTS_MAXD], top_prop_grad[NUTS_MAXD];
+  double top_prop_logp, top_prop_energy, top_log_size, top_accept_sum;
+  int top_n, depth, direction, diverging, nleaf, nleaf_target, sp;
+  NutsTree stack[NUTS_MAXDEPTH];
+};
+
+SGP_HD inline double nuts_logaddexp(double a, double b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const double m = a > b ? a : b;
+  return m + log1p(exp(-fabs(a - b)));
+}
+SGP_HD inline void wv_reset(NutsWeightedVar& w, int n, const double* mean, double var, double weight) {
+  w.n = weight;
+  for (int i = 0; i < n; ++i) {
+    w.mean[i] = mean ? mean[i] : 0.0;
+    w.m2[i] = var * weight;
+  }
+}
+SGP_HD inline void wv_add(NutsWeightedVar& w, int n, const double* x) {
+  w.n += 1.0;
+  for (int i = 0; i < n; ++i) {
+    const double d = x[i] - w.mean[i];
+    w.mean[i] += d / w.n;
+    w.m2[i] += d * (x[i] - w.mean[i]);
+  }
+}
+
+// q_start: where the chain starts (the caller has already added PyMC3's jitter if it wants it)
+SGP_HD inline void nuts_init(NutsState& s, int ndim, int n_tune, int n_draws, int max_treedepth, double step_scale,
+                             double target_accept, uint64_t seed, const double* q_start) {
+  s.ndim = ndim;
+  s.n_tune = n_tune;
+  s.n_draws = n_draws;
+  s.max_treedepth = max_treedepth;
+  s.target_accept = target_accept;
+  s.Emax = 1000.0;
+  const double step0 = step_scale / pow((double)ndim, 0.25);
+  s.da_mu = log(10.0 * step0);
+  s.da_log_step = log(step0);
+  s.da_log_bar = log(step0);
+  s.da_hbar = 0.0;
+  s.da_gamma = 0.05;
+  s.da_t0 = 10.0;
+  s.da_kappa = 0.75;
+  s.da_count = 1;
+  for (int i = 0; i < ndim; ++i) s.var[i] = 1.0;
+  wv_reset(s.fg, ndim, q_start, 1.0, 10.0);
+  wv_reset(s.bg, ndim, nullptr, 0.0, 0.0);
+  s.mass_count = 0;
+  s.mass_window = 101;
+  s.rng.s = seed;
+  s.rng.have_spare = 0;
+  s.rng.spare = 0.0;
+  s.phase = NS_INIT;
+  s.it = 0;
+  s.n_leapfrog = 0;
+  for (int i = 0; i < ndim; ++i) s.cur.q[i] = q_start[i];
+}
+
+SGP_HD inline double nuts_kinetic(const NutsState& s, const double* p) {
+  double k = 0.0;
+  for (int i = 0; i < s.ndim; ++i) k += p[i] * (s.var[i] * p[i]);
+  return 0.5 * k;
+}
+// hmc.py: NUTS._uturn -- p_sum . v_left <= 0 or p_sum . v_right <= 0 with v = var o p
+SGP_HD inline bool nuts_uturn(const NutsState& s, const double* p_sum, const double* pl, const double* pr) {
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < s.ndim; ++i) {
+    a += p_sum[i] * (s.var[i] * pl[i]);
+    b += p_sum[i] * (s.var[i] * pr[i]);
+  }
+  return a <= 0.0 || b <= 0.0;
+}
+
+// combine the finished sub-trees a (built first) and b into a (hmc.py: the second half of NUTS._build)
+SGP_HD inline void nuts_merge(NutsState& s, NutsTree& a, const NutsTree& b) {
+  const int n = s.ndim, dir = s.direction;
+  double psum[NUTS_MAXD];
+  for (int i = 0; i < n; ++i) psum[i] = a.p_sum[i] + b.p_sum[i];
+  const double log_size = nuts_logaddexp(a.log_size, b.log_size);
+  const bool bad = b.diverging || b.turning;
+  bool take_b = false;
+  if (!bad) take_b = log(rng_uniform(s.rng) + 1e-300) < b.log_size - log_size;
+  int turning = b.turning;
+  if (!bad) {
+    // first / second = the earlier / later half in trajectory order (left to right)
+    const NutsTree& first = dir > 0 ? a : b;
+    const NutsTree& second = dir > 0 ? b : a;
+    double t1[NUTS_MAXD], t2[NUTS_MAXD];
+    for (int i = 0; i < n; ++i) {
+      t1[i] = first.p_sum[i] + second.lp[i];
+      t2[i] = first.rp[i] + second.p_sum[i];
+    }
+    turning = nuts_uturn(s, psum, first.lp, second.rp) || nuts_uturn(s, t1, first.lp, second.lp) ||
+              nuts_uturn(s, t2, first.rp, second.rp);
+  }
+  if (dir > 0) {
+    for (int i = 0; i < n; ++i) a.rp[i] = b.rp[i];
+  } else {
+    for (int i = 0; i < n; ++i) a.lp[i] = b.lp[i];
+  }
+  for (int i = 0; i < n; ++i) a.p_sum[i] = psum[i];
+  if (take_b) {
+    for (int i = 0; i < n; ++i) {
+      a.prop_q[i] = b.prop_q[i];
+      a.prop_grad[i] = b.prop_grad[i];
+    }
+    a.prop_logp = b.prop_logp;
+    a.prop_energy = b.prop_energy;
+  }
+  a.log_size = log_size;
+  a.accept_sum += b.accept_sum;
+  a.n += b.n;
+  a.depth += 1;
+  a.diverging = b.diverging;
+  a.turning = turning;
+}
+
+// begin the leapfrog from s.edge in direction s.direction: fills s.trial.q (the position to evaluate) and the half-step
+// momentum in s.trial.p
+SGP_HD inline void nuts_half_step(NutsState& s) {
+  const double e = s.eps * (double)s.direction;
+  for (int i = 0; i < s.ndim; ++i) {
+    const double ph = s.edge.p[i] + 0.5 * e * s.edge.grad[i];
+    s.trial.p[i] = ph;
+    s.trial.q[i] = s.edge.q[i] + e * (s.var[i] * ph);
+  }
+}
+
+SGP_HD inline void nuts_begin_doubling(NutsState& s) {
+  s.direction = rng_uniform(s.rng) < 0.5 ? 1 : -1;
+  s.edge = s.direction > 0 ? s.right : s.left;
+  s.sp = 0;
+  s.nleaf = 0;
+  s.nleaf_target = 1 << s.depth;
+  nuts_half_step(s);
+}
+
+// One call = everything the sampler can do without a new evaluation.  On entry (except the very first call) `logp` / `grad`
+// are the log-density and gradient at the position returned by the previous call; `samples` (n_draws x ndim) and `stats`
+// (n_draws x NST_COLS) receive the post-tuning draws.  Returns NUTS_EVAL with *q_next set, or NUTS_DONE.
+SGP_HD inline int nuts_step(NutsState& s, double logp, const double* grad, const double** q_next, double* samples, double* stats) {
+  const int n = s.ndim;
+  if (s.phase == NS_INIT) {
+    s.phase = NS_WAIT_INIT;
+    *q_next = s.cur.q;
+    return NUTS_EVAL;
+  }
+  if (s.phase == NS_WAIT_INIT) {
+    s.n_leapfrog += 1;
+    s.cur.logp = logp;
+    for (int i = 0; i < n; ++i) s.cur.grad[i] = grad[i];
+    if (!isfinite(logp)) {  // the caller chose a start with zero density: nothing can be sampled
+      s.phase = NS_FINISHED;
+      return NUTS_DONE;
+    }
+    s.phase = NS_BEGIN_DRAW;
+  }
+  for (;;) {
+    if (s.phase == NS_BEGIN_DRAW) {
+      if (s.it >= s.n_tune + s.n_draws) {
+        s.phase = NS_FINISHED;
+        return NUTS_DONE;
+      }
+      const bool tuning = s.it < s.n_tune;
+      s.eps = exp(tuning ? s.da_log_step : s.da_log_bar);
+      for (int i = 0; i < n; ++i) s.p0[i] = rng_normal(s.rng) / sqrt(s.var[i]);
+      for (int i = 0; i < n; ++i) s.cur.p[i] = s.p0[i];
+      s.cur.energy = isfinite(s.cur.logp) ? -s.cur.logp + nuts_kinetic(s, s.p0) : INFINITY;
+      s.e0 = s.cur.energy;
+      s.left = s.cur;
+      s.right = s.cur;
+      for (int i = 0; i < n; ++i) {
+        s.top_p_sum[i] = s.p0[i];
+        s.top_prop_q[i] = s.cur.q[i];
+        s.top_prop_grad[i] = s.cur.grad[i];
+      }
+      s.top_prop_logp = s.cur.logp;
+      s.top_prop_energy = s.cur.energy;
+      s.top_log_size = 0.0;
+      s.top_accept_sum = 0.0;
+      s.top_n = 0;
+      s.depth = 0;
+      s.diverging = 0;
+      if (s.depth >= s.max_treedepth) goto end_draw;
+      nuts_begin_doubling(s);
+      s.phase = NS_WAIT_LEAF;
+      *q_next = s.trial.q;
+      return NUTS_EVAL;
+    }
+    if (s.phase == NS_WAIT_LEAF) {
+      // ---- finish the leapfrog (hmc.py: NUTS._leapfrog) and make the leaf (NUTS._leaf) --------------------------------
+      s.n_leapfrog += 1;
+      bool finite = isfinite(logp);
+      for (int i = 0; i < n && finite; ++i) finite = isfinite(grad[i]);
+      const double e = s.eps * (double)s.direction;
+      if (finite) {
+        for (int i = 0; i < n; ++i) {
+          s.trial.p[i] += 0.5 * e * grad[i];
+          s.trial.grad[i] = grad[i];
+        }
+        s.trial.logp = logp;
+        s.trial.energy = -logp + nuts_kinetic(s, s.trial.p);
+      } else {
+        for (int i = 0; i < n; ++i) s.trial.grad[i] = 0.0;
+        s.trial.logp = -INFINITY;
+        s.trial.energy = INFINITY;
+      }
+      s.edge = s.trial;
+      NutsTree& t = s.stack[s.sp];
+      double de = s.trial.energy - s.e0;
+      if (!isfinite(de)) de = INFINITY;
+      for (int i = 0; i < n; ++i) {
+        t.lp[i] = t.rp[i] = t.p_sum[i] = s.trial.p[i];
+        t.prop_q[i] = s.trial.q[i];
+        t.prop_grad[i] = s.trial.grad[i];
+      }
+      t.prop_logp = s.trial.logp;
+      t.prop_energy = s.trial.energy;
+      t.diverging = de > s.Emax;
+      t.log_size = isfinite(de) ? -de : -INFINITY;
+      t.accept_sum = (de > -700.0 && isfinite(de)) ? fmin(1.0, exp(-de)) : (de <= -700.0 ? 1.0 : 0.0);
+      t.n = 1;
+      t.depth = 0;
+      t.turning = 0;
+      s.sp += 1;
+      s.nleaf += 1;
+      // ---- binary-counter merging ----------------------------------------------------------------------------------------
+      bool bad = s.stack[s.sp - 1].diverging || s.stack[s.sp - 1].turning;
+      while (!bad && s.sp >= 2 && s.stack[s.sp - 2].depth == s.stack[s.sp - 1].depth) {
+        nuts_merge(s, s.stack[s.sp - 2], s.stack[s.sp - 1]);
+        s.sp -= 1;
+        bad = s.stack[s.sp - 1].diverging || s.stack[s.sp - 1].turning;
+      }
+      if (bad) {  // the recursion returns the bad sub-tree upwards: it joins every pending left sibling
+        while (s.sp >= 2) {
+          nuts_merge(s, s.stack[s.sp - 2], s.stack[s.sp - 1]);
+          s.sp -= 1;
+        }
+      } else if (s.nleaf < s.nleaf_target) {
+        nuts_half_step(s);
+        *q_next = s.trial.q;
+        return NUTS_EVAL;
+      }
+      // ---- the sub-tree is finished: top level of NUTS.draw -------------------------------------------------------------
+      {
+        const NutsTree& sub = s.stack[0];
+        s.top_accept_sum += sub.accept_sum;
+        s.top_n += sub.n;
+        if (sub.diverging) {
+          s.diverging = 1;
+          goto end_draw;
+        }
+        if (sub.turning) goto end_draw;
+        if (log(rng_uniform(s.rng) + 1e-300) < sub.log_size - s.top_log_size) {
+          for (int i = 0; i < n; ++i) {
+            s.top_prop_q[i] = sub.prop_q[i];
+            s.top_prop_grad[i] = sub.prop_grad[i];
+          }
+          s.top_prop_logp = sub.prop_logp;
+          s.top_prop_energy = sub.prop_energy;
+        }
+        s.top_log_size = nuts_logaddexp(s.top_log_size, sub.log_size);
+        if (s.direction > 0) s.right = s.edge;
+        else s.left = s.edge;
+        for (int i = 0; i < n; ++i) s.top_p_sum[i] += sub.p_sum[i];
+        s.depth += 1;
+        if (nuts_uturn(s, s.top_p_sum, s.left.p, s.right.p)) goto end_draw;
+        if (s.depth >= s.max_treedepth) goto end_draw;
+        nuts_begin_doubling(s);
+        *q_next = s.trial.q;
+        return NUTS_EVAL;
+      }
+    }
+  end_draw : {
+    const bool tuning = s.it < s.n_tune;
+    const double accept = s.top_accept_sum / (double)(s.top_n > 1 ? s.top_n : 1);
+    if (!tuning) {
+      const int row = s.it - s.n_tune;
+      for (int i = 0; i < n; ++i) samples[(long)row * n + i] = s.top_prop_q[i];
+      double* st = stats + (long)row * NST_COLS;
+      st[NST_STEP] = s.eps;
+      st[NST_TREE] = (double)s.top_n;
+      st[NST_DEPTH] = (double)s.depth;
+      st[NST_ACCEPT] = accept;
+      st[NST_DIVERGING] = (double)s.diverging;
+      st[NST_ENERGY] = s.top_prop_energy;
+      st[NST_LOGP] = s.top_prop_logp;
+      st[NST_NLEAP] = (double)s.n_leapfrog;
+    } else {
+      // hmc.py: DualAveraging.update
+      const double w = 1.0 / ((double)s.da_count + s.da_t0);
+      s.da_hbar = (1.0 - w) * s.da_hbar + w * (s.target_accept - accept);
+      s.da_log_step = s.da_mu - s.da_hbar * sqrt((double)s.da_count) / s.da_gamma;
+      const double mk = pow((double)s.da_count, -s.da_kappa);
+      s.da_log_bar = mk * s.da_log_step + (1.0 - mk) * s.da_log_bar;
+      s.da_count += 1;
+      // hmc.py: DiagMassAdapter.update
+      wv_add(s.fg, n, s.top_prop_q);
+      wv_add(s.bg, n, s.top_prop_q);
+      if (s.fg.n > 0.0) {
+        bool ok = true;
+        for (int i = 0; i < n; ++i) {
+          const double v = s.fg.m2[i] / s.fg.n;
+          ok = ok && isfinite(v) && v > 0.0;
+        }
+        if (ok)
+          for (int i = 0; i < n; ++i) s.var[i] = s.fg.m2[i] / s.fg.n;
+      }
+      if (s.mass_count > 0 && s.mass_count % s.mass_window == 0) {
+        s.fg = s.bg;
+        wv_reset(s.bg, n, nullptr, 0.0, 0.0);
+      }
+      s.mass_count += 1;
+    }
+    for (int i = 0; i < n; ++i) {
+      s.cur.q[i] = s.top_prop_q[i];
+      s.cur.grad[i] = s.top_prop_grad[i];
+    }
+    s.cur.logp = s.top_prop_logp;
+    s.it += 1;
+    s.phase = NS_BEGIN_DRAW;
+  }
+  }
+}
+
+}  // namespace sgp

@@ -21,6 +21,55 @@ import numpy as np
 
 
 # ---------------------------------------------------------------------------------------------
+# random numbers shared with the device sampler
+# ---------------------------------------------------------------------------------------------
+class SplitMix:
+    """splitmix64 -> uniforms / Box-Muller normals: the generator of the device-resident sampler (csrc/sgp_nuts.hpp),
+    restated so that ``NUTS(..., rng=SplitMix(seed))`` draws the same stream -- the CPU tests compare the two samplers
+    draw for draw.  Implements the three ``numpy.random.Generator`` methods the sampler uses."""
+
+    MASK = (1 << 64) - 1
+
+    def __init__(self, seed: int):
+        self.s = int(seed) & self.MASK
+        self.spare = None
+
+    def _u64(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & self.MASK
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.MASK
+        return z ^ (z >> 31)
+
+    def random(self):
+        return float(self._u64() >> 11) * (1.0 / 9007199254740992.0)
+
+    def _normal(self):
+        if self.spare is not None:
+            v, self.spare = self.spare, None
+            return v
+        u1, u2 = 1.0 - self.random(), self.random()
+        rad, ang = math.sqrt(-2.0 * math.log(u1)), 6.283185307179586 * u2
+        self.spare = rad * math.sin(ang)
+        return rad * math.cos(ang)
+
+    def standard_normal(self, n):
+        return np.array([self._normal() for _ in range(n)], dtype=np.float64)
+
+    def uniform(self, lo, hi, n):
+        return np.array([lo + (hi - lo) * self.random() for _ in range(n)], dtype=np.float64)
+
+
+def _logaddexp(a, b):
+    """log(exp(a) + exp(b)), the formula of csrc/sgp_nuts.hpp (so both samplers round alike)."""
+    if a == -math.inf:
+        return b
+    if b == -math.inf:
+        return a
+    return max(a, b) + math.log1p(math.exp(-abs(a - b)))
+
+
+# ---------------------------------------------------------------------------------------------
 # adaptation
 # ---------------------------------------------------------------------------------------------
 class DualAveraging:
@@ -111,10 +160,10 @@ class _Tree:
 
 class NUTS:
     def __init__(self, logp_and_grad: Callable[[Sequence[float]], tuple], ndim: int, step_scale=0.25, target_accept=0.8,
-                 max_treedepth=10, Emax=1000.0, seed: Optional[int] = None):
+                 max_treedepth=10, Emax=1000.0, seed: Optional[int] = None, rng=None):
         self.f = logp_and_grad
         self.ndim = ndim
-        self.rng = np.random.default_rng(seed)
+        self.rng = rng if rng is not None else np.random.default_rng(seed)
         self.step0 = step_scale / ndim ** 0.25
         self.da = DualAveraging(self.step0, target=target_accept)
         self.mass = DiagMassAdapter(ndim)
@@ -128,9 +177,16 @@ class NUTS:
         self.n_leapfrog += 1
         return float(lp), np.asarray(g, dtype=np.float64)
 
+    @staticmethod
+    def _dot(a, b):
+        s = 0.0
+        for x, y in zip(a.tolist(), b.tolist()):  # left-to-right like csrc/sgp_nuts.hpp (BLAS may reorder)
+            s += x * y
+        return s
+
     def _state(self, q, p, lp, g):
         v = self.mass.var * p
-        energy = -lp + 0.5 * float(p @ v) if math.isfinite(lp) else math.inf
+        energy = -lp + 0.5 * self._dot(p, v) if math.isfinite(lp) else math.inf
         return _State(q, p, v, g, lp, energy)
 
     def _leapfrog(self, s: _State, eps):
@@ -159,7 +215,7 @@ class NUTS:
 
     @staticmethod
     def _uturn(p_sum, left: _State, right: _State):
-        return float(p_sum @ left.v) <= 0.0 or float(p_sum @ right.v) <= 0.0
+        return NUTS._dot(p_sum, left.v) <= 0.0 or NUTS._dot(p_sum, right.v) <= 0.0
 
     def _build(self, edge: _State, direction, depth, eps, e0):
         if depth == 0:
@@ -172,7 +228,7 @@ class NUTS:
         t = _Tree()
         t.left, t.right = (a.left, b.right) if direction > 0 else (b.left, a.right)
         t.p_sum = a.p_sum + b.p_sum
-        t.log_size = np.logaddexp(a.log_size, b.log_size)
+        t.log_size = _logaddexp(a.log_size, b.log_size)
         t.accept_sum = a.accept_sum + b.accept_sum
         t.n = a.n + b.n
         t.diverging = b.diverging
@@ -215,7 +271,7 @@ class NUTS:
             # biased progressive sampling at the top level
             if math.log(self.rng.random() + 1e-300) < sub.log_size - log_size:
                 proposal = sub.proposal
-            log_size = np.logaddexp(log_size, sub.log_size)
+            log_size = _logaddexp(log_size, sub.log_size)
             first_p, first_right = p_sum, right
             if direction > 0:
                 right = sub.right
