@@ -9,7 +9,7 @@ from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeou
 from . import datasets  # noqa: F401
 from .gp_shim import (BernoulliLikelihood, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, MaternKernel,  # noqa: F401
                       MultivariateNormal, RBFKernel, ScaleKernel, ZeroMean, settings)
-from .hmc import NUTS, Trace, sample_nuts  # noqa: F401
+from .hmc import NUTS, SplitMix, Trace, sample_nuts, sample_nuts_device  # noqa: F401
 from .metrics import nlpd, nlpd_marginal, nlpd_mixture, rmse  # noqa: F401
 from .models import (BayesianSparseGPR_HMC, BayesianStochasticVariationalGP, SparseGPR, StochasticVariationalGP,  # noqa: F401
                      VariationalHyperDist, mixture_posterior_predictive)

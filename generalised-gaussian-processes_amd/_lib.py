@@ -70,6 +70,9 @@ PROTOTYPES = {
     "sgp_small_sync_bytes": (_sz, []),
     "sgp_small_eval": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _vp, _vp, _vp,
                               _vp, _sz, _vp]),
+    "sgp_small_nuts_stat_cols": (_sz, []),
+    "sgp_small_nuts": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _i32, _dbl, _dbl,
+                              C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _sz, _vp]),

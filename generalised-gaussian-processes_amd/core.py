@@ -399,6 +399,10 @@ class HmcTarget:
         """PyMC3's test point in the unconstrained space: Gamma(2,1) -> mean 2, HalfCauchy(1) -> 1."""
         return [math.log(2.0)] * self.d + [0.0, 0.0]
 
+    def device_sampler_ok(self):
+        """True when ``hmc.sample_nuts_device`` can run this target: the bound takes the single-launch path."""
+        return hasattr(self.bound.engine, "small_nuts") and self.bound._small_ok(self.Z.shape[0])
+
     @staticmethod
     def _prior(ls, sf, sn):
         lp = sum(math.log(v) - v for v in ls)

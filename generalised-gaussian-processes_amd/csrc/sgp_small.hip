@@ -26,6 +26,7 @@
 // rewritten on every evaluation, so stale L2 lines of another XCD must be dropped); spins are bounded (SGP_INFO_TIMEOUT).
 // All cross-workgroup sums go through partial arrays reduced in a fixed order: results are bit-reproducible.
 #include "sgp_potrf.hpp"
+#include "sgp_nuts.hpp"
 
 namespace sgp {
 
@@ -34,7 +35,7 @@ constexpr int SM_MAXD = 16;
 constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
-enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_WORDS = 7 };
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_WORDS = 9 };
 constexpr int SM_GP = SM_MAXD + 4;  // doubles per gradient partial: g_ls[d] at 0.., then g_sf2, tr B^-1
 
 struct SmallArgs {
@@ -317,13 +318,25 @@ __device__ __forceinline__ void sm_vec_solve_blocks(SmSlabShared<MP>& sl, double
 
 // ---- the kernel -------------------------------------------------------------------------------------------------
 template <int MP>
-__global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
+struct SmKernelShared {
+  SmShared<MP> sh;
+  SmHyp hyp;
+  int dead;
+  double redw[4];
+  double gsum[SM_GP];
+};
+
+// One evaluation, executed by every workgroup of the launch.  `ev` = 1-based count of evaluations this launch has run
+// (flags carry it, counters are cumulative: ev x contributors), so a persistent kernel calls this repeatedly without
+// clearing anything; `persistent` = false additionally leaves the sync words zero for the next launch.
+template <int MP>
+__device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<MP>& ks, int ev, bool persistent) {
   constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2, NBW = (NBL + 3) / 4, NB64 = MP / 64;
-  __shared__ SmShared<MP> sh;
-  __shared__ SmHyp hyp;
-  __shared__ int dead;
-  __shared__ double redw[4];
-  __shared__ double gsum[SM_GP];
+  SmShared<MP>& sh = ks.sh;
+  SmHyp& hyp = ks.hyp;
+  int& dead = ks.dead;
+  double (&redw)[4] = ks.redw;
+  double (&gsum)[SM_GP] = ks.gsum;
   SmSlabShared<MP>& sl = sh.sl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -332,21 +345,13 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   const int d = a.d, M = a.M, N = a.N;
   int* sy = a.sync;
   int* abortw = sy + SY_ABORT * SM_SYNC_STRIDE;
-  if (tid == 0) dead = 0;
   auto stamp = [&](int k) {
     if (a.stamps && tid == 0) a.stamps[(size_t)wg * 16 + k] = __builtin_amdgcn_s_memrealtime();
   };
   stamp(0);
-  sm_hypers(a, hyp);
   const double sf2 = hyp.sf2, s2 = hyp.s2;
   const int role = wg == 0 ? 0 : (wg <= NB64 ? 1 : 2);
   const int ngrad = a.grow + NB64;  // workgroups that contribute gradient partials
-
-  if (!hyp.ok) {  // theta outside the representable range: density zero, never an exception (PyMC3: non-finite logp)
-    if (wg == 0 && tid <= d + 2) a.out[tid] = tid == 0 ? -INFINITY : 0.0;
-    if (wg == 0 && tid == 0) *a.info = 0;
-    return;
-  }
 
   // scaled inducing inputs (rows >= M zero)
   auto stage_z = [&]() {
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       double* Lg = pass == 0 ? a.Lk : a.Lb;
       double* dg = pass == 0 ? a.dinvK : a.dinvB;
       if (pass == 1) {
-        if (!sm_wait_ge(sy + SY_SLICE * SM_SYNC_STRIDE, a.grow, abortw, &dead)) {
+        if (!sm_wait_ge(sy + SY_SLICE * SM_SYNC_STRIDE, ev * a.grow, abortw, &dead)) {
           if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
           return;
         }
@@ -513,12 +518,12 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       if (tid == 0 && bad_first != 0 && *a.info == 0) *a.info = (pass == 0 ? 0 : M) + bad_first;
       if (pass == 0) {
         stamp(1);
-        sm_publish_set(sy + SY_L * SM_SYNC_STRIDE, 1);
+        sm_publish_set(sy + SY_L * SM_SYNC_STRIDE, ev);
         stamp(2);
       }
     }
     stamp(4);
-    if (a.want_grad) sm_publish_set(sy + SY_LB * SM_SYNC_STRIDE, 1);
+    if (a.want_grad) sm_publish_set(sy + SY_LB * SM_SYNC_STRIDE, ev);
     else {
       __threadfence();
       __syncthreads();
@@ -580,13 +585,14 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
         a.out[d + 4] = trace_term;
       }
       __syncthreads();
-      for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;  // ready for the next launch
+      if (!persistent)
+        for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;  // ready for the next launch
       return;
     }
     stamp(7);
 
     // ---- gradients --------------------------------------------------------------------------------------------------
-    if (!sm_wait_ge(sy + SY_GRAD * SM_SYNC_STRIDE, ngrad, abortw, &dead)) {
+    if (!sm_wait_ge(sy + SY_GRAD * SM_SYNC_STRIDE, ev * ngrad, abortw, &dead)) {
       if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
       return;
     }
@@ -636,7 +642,8 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
       a.out[d + 4] = trace_term;
     }
     __syncthreads();
-    for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;
+    if (!persistent)
+      for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256) sy[e] = 0;
     stamp(9);
     return;
   }
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     SlabRegs<NB16> Y;
     assemble(rw * SM_SLAB, Y);
     stamp(1);
-    if (!sm_wait_ge(sy + SY_L * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+    if (!sm_wait_ge(sy + SY_L * SM_SYNC_STRIDE, ev, abortw, &dead)) return;
     stamp(2);
     d4 pacc[NBW];
 #pragma unroll
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     }
     stamp(3);
     sm_publish_add(sy + SY_PART * SM_SYNC_STRIDE);
-    if (!sm_wait_ge(sy + SY_PART * SM_SYNC_STRIDE, a.grow, abortw, &dead)) return;
+    if (!sm_wait_ge(sy + SY_PART * SM_SYNC_STRIDE, ev * a.grow, abortw, &dead)) return;
     stamp(4);
     // ---- slices: B = I + sum_g P_g / s2 (mirrored), u, scalars -- fixed order over g ---------------------------------
     {
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
     if (!a.want_grad) return;
 
     // ---- reverse: Abar per slab (two solves with LB), Kbar_uf = Abar L^-1 (one solve with L^T), contraction ----------
-    if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+    if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, ev, abortw, &dead)) return;
     stamp(6);
     const double is2 = 1.0 / s2, is22 = is2 * is2;
     for (int sb = rw; sb < a.nslab; sb += a.grow) {
@@ -956,7 +963,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   // =================================================================================================================
   // role 1: Kbar_uu = -1/2 L^-T S L^-1, S = B + B^-1 - 2 I + g g^T / s2^2 ; its contraction with dK_uu ; tr B^-1
   if (!a.want_grad) return;
-  if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, 1, abortw, &dead)) return;
+  if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, ev, abortw, &dead)) return;
   stamp(1);
   const double is22 = 1.0 / (s2 * s2);
   double trb = 0.0;
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   stamp(2);
   if (NB64 > 1) {  // the other workgroups' columns of Q
     sm_publish_add(sy + SY_Q * SM_SYNC_STRIDE);
-    if (!sm_wait_ge(sy + SY_Q * SM_SYNC_STRIDE, NB64, abortw, &dead)) return;
+    if (!sm_wait_ge(sy + SY_Q * SM_SYNC_STRIDE, ev * NB64, abortw, &dead)) return;
   } else {
     __threadfence();
     __syncthreads();
@@ -1039,6 +1046,112 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   if (a.want_gz)
     for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)v * MP * SM_MAXD + e] = sl.gz[e];
   sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
+}
+
+template <int MP>
+__global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
+  __shared__ SmKernelShared<MP> ks;
+  if (threadIdx.x == 0) ks.dead = 0;
+  sm_hypers(a, ks.hyp);
+  if (!ks.hyp.ok) {  // theta outside the representable range: density zero, never an exception (PyMC3: non-finite logp)
+    if (blockIdx.x == 0 && threadIdx.x <= a.d + 2) a.out[threadIdx.x] = threadIdx.x == 0 ? -INFINITY : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.info = 0;
+    return;
+  }
+  sm_eval_body<MP>(a, ks, 1, false);
+}
+
+// ---- device-resident NUTS ------------------------------------------------------------------------------------------
+// One PERSISTENT launch runs the whole of pm.sample(n, tune=tune, chains=1) (models/bayesian_sgpr_hmc.py:73-78): thread 0
+// of workgroup 0 advances the sampler's state machine (sgp_nuts.hpp, state in LDS), writes the next position into
+// a.theta and raises the request word; every workgroup then runs one evaluation of the NUTS target (sm_eval_body, mode
+// SGP_SMALL_HMC) and workgroup 0 feeds (logp, gradient) back.  No host round trip, no launch per leapfrog.
+struct NutsArgs {
+  const double* q0;   // start (unconstrained), ndim doubles
+  double* theta_w;    // = a.theta, writable
+  double* samples;    // n_draws x ndim
+  double* stats;      // n_draws x SGP_NUTS_STAT_COLS
+  long long* counters;  // [0] leapfrogs (evaluations), [1] draws finished
+  int n_tune, n_draws, max_treedepth;
+  double step_scale, target_accept;
+  unsigned long long seed;
+};
+constexpr int SM_NUTS_COLS = NST_COLS + 1;  // + seconds per draw (device clock)
+
+template <int MP>
+__global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs na) {
+  __shared__ SmKernelShared<MP> ks;
+  __shared__ NutsState st;
+  __shared__ int cmd;
+  const int tid = threadIdx.x, wg = blockIdx.x, ndim = a.d + 2;
+  int* sy = a.sync;
+  int* abortw = sy + SY_ABORT * SM_SYNC_STRIDE;
+  if (tid == 0) ks.dead = 0;
+  int ev = 0, req = 0;
+  double lp = 0.0;
+  unsigned long long t_draw = 0;
+  if (wg == 0 && tid == 0) {
+    nuts_init(st, ndim, na.n_tune, na.n_draws, na.max_treedepth, na.step_scale, na.target_accept, na.seed, na.q0);
+    t_draw = __builtin_amdgcn_s_memrealtime();
+  }
+  __syncthreads();
+  for (;;) {
+    ++req;
+    if (wg == 0) {
+      if (tid == 0) {
+        const double* qn = nullptr;
+        const int it0 = st.it;
+        const int c = nuts_step(st, lp, a.out + 1, &qn, na.samples, na.stats /* NST_COLS columns, re-packed at the end */);
+        if (st.it != it0) {  // a draw has finished: its device time
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          const int row = it0 - na.n_tune;
+          if (row >= 0) na.stats[(size_t)na.n_draws * NST_COLS + row] = (double)(now - t_draw) * 1e-8;
+          t_draw = now;
+        }
+        if (c == NUTS_EVAL)
+          for (int i = 0; i < ndim; ++i) na.theta_w[i] = qn[i];
+        cmd = c;
+      }
+      __syncthreads();
+      if (cmd != NUTS_EVAL) {
+        if (tid == 0) {
+          na.counters[0] = st.n_leapfrog;
+          na.counters[1] = st.it;
+        }
+        sm_publish_set(sy + SY_DONE * SM_SYNC_STRIDE, 1);
+        sm_publish_set(sy + SY_REQ * SM_SYNC_STRIDE, req);
+        break;
+      }
+      sm_publish_set(sy + SY_REQ * SM_SYNC_STRIDE, req);
+      __syncthreads();
+    } else {
+      if (!sm_wait_ge(sy + SY_REQ * SM_SYNC_STRIDE, req, abortw, &ks.dead)) break;
+      if (sm_ld(sy + SY_DONE * SM_SYNC_STRIDE) != 0) break;
+    }
+    sm_hypers(a, ks.hyp);  // every workgroup from the same theta: the same decision everywhere
+    if (!ks.hyp.ok) {
+      if (wg == 0 && tid == 0) {
+        a.out[0] = -INFINITY;
+        lp = -INFINITY;
+      }
+      continue;
+    }
+    ++ev;
+    sm_eval_body<MP>(a, ks, ev, true);
+    if (ks.dead || sm_ld(abortw) != 0) {
+      if (wg == 0 && tid == 0) *a.info = SGP_INFO_TIMEOUT;
+      break;
+    }
+    if (wg == 0) {
+      __syncthreads();
+      if (tid == 0) lp = (*a.info == 0) ? a.out[0] : -INFINITY;  // a failed factorization is a divergence, not an error
+    }
+  }
+  if (wg == 0) {
+    __syncthreads();
+    for (int e = tid; e < SY_WORDS * SM_SYNC_STRIDE; e += 256)
+      if (e / SM_SYNC_STRIDE != SY_REQ && e / SM_SYNC_STRIDE != SY_DONE) sy[e] = 0;
+  }
 }
 
 struct SmallWs {
@@ -1113,5 +1226,34 @@ extern "C" int sgp_small_eval(const double* X, int64_t ldx, const double* y, con
   hipStream_t st = (hipStream_t)stream;
   if (M <= 64) small_eval_kernel<64><<<grid, 256, 0, st>>>(a);
   else small_eval_kernel<128><<<grid, 256, 0, st>>>(a);
+  return check_launch();
+}
+
+extern "C" size_t sgp_small_nuts_stat_cols(void) { return SM_NUTS_COLS; }
+
+extern "C" int sgp_small_nuts(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* q0,
+                              int64_t N, int M, int d, int kernel_id, double jitter, int n_tune, int n_draws, int max_treedepth,
+                              double step_scale, double target_accept, uint64_t seed, double* theta_scratch, double* samples,
+                              double* stats, long long* counters, double* out, int* info, void* ws, size_t ws_bytes,
+                              sgp_stream_t stream) {
+  if (!X || !y || !Z || !q0 || !theta_scratch || !samples || !stats || !counters || !out || !info || ldx < d || ldz < d)
+    return SGP_ERR_ARG;
+  if (n_tune < 0 || n_draws < 1 || max_treedepth < 1 || max_treedepth >= NUTS_MAXDEPTH || !(step_scale > 0.0)) return SGP_ERR_ARG;
+  if (!sgp_small_supported(N, M, d, kernel_id) || d + 2 > NUTS_MAXD) return SGP_ERR_DIM;
+  SmallWs w = carve_small(ws, N, M, d);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  SmallArgs& a = w.a;
+  a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta_scratch;
+  a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = SGP_SMALL_HMC; a.want_grad = 1; a.want_gz = 0;
+  a.jitter = jitter;
+  a.info = info; a.out = out; a.gZ = nullptr;
+  a.stamps = nullptr;
+  NutsArgs na{q0, theta_scratch, samples, stats, counters, n_tune, n_draws, max_treedepth, step_scale, target_accept, seed};
+  const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
+  hipStream_t st = (hipStream_t)stream;
+  // the request / done words of the previous run (the only sync words a run leaves non-zero)
+  zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
+  if (M <= 64) small_nuts_kernel<64><<<grid, 256, 0, st>>>(a, na);
+  else small_nuts_kernel<128><<<grid, 256, 0, st>>>(a, na);
   return check_launch();
 }

@@ -295,6 +295,45 @@ class HipEngine:
         _lib.check("sgp_small_eval", st)
         return out, gz, info
 
+    def small_nuts(self, X, y, Z, q0, n_tune, n_draws, seed, jitter=1e-6, kernel="rbf", max_treedepth=10, step_scale=0.25,
+                   target_accept=0.8):
+        """The whole NUTS run in one persistent launch (sgp_small_nuts).  Returns dict(samples [n_draws, d + 2] unconstrained,
+        stats [n_draws, 8], seconds [n_draws], evaluations, draws, info) as host tensors / ints (synchronises)."""
+        N, d = X.shape
+        M = Z.shape[0]
+        for t, n in ((X, "X"), (y, "y"), (Z, "Z")):
+            self._chk(t, n)
+        nd = d + 2
+        q0d = torch.as_tensor([float(v) for v in q0], dtype=torch.float64).to(self.device)
+        if q0d.numel() != nd:
+            raise ValueError("q0 has %d entries, expected d + 2 = %d" % (q0d.numel(), nd))
+        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
+        ws = self._ws.get("small")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws["small"] = ws
+        cols = int(self.lib.sgp_small_nuts_stat_cols())
+        samples = self.empty(n_draws, nd)
+        stats = torch.zeros(n_draws * cols, dtype=torch.float64, device=self.device)
+        counters = torch.zeros(2, dtype=torch.int64, device=self.device)
+        theta, out = self.empty(nd), self.empty(d + 5)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        st = self.lib.sgp_small_nuts(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(q0d), N, M, d, _kernel_id(kernel),
+                                     float(jitter), int(n_tune), int(n_draws), int(max_treedepth), float(step_scale),
+                                     float(target_accept), int(seed) & ((1 << 64) - 1), self._ptr(theta), self._ptr(samples),
+                                     self._ptr(stats), C.c_void_p(counters.data_ptr()), self._ptr(out),
+                                     C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_small_nuts", st)
+        h = stats.to("cpu")
+        c = counters.to("cpu")
+        res = {"samples": samples.to("cpu"), "stats": h[: n_draws * (cols - 1)].reshape(n_draws, cols - 1),
+               "seconds": h[n_draws * (cols - 1):], "evaluations": int(c[0]), "draws": int(c[1]), "info": int(info.to("cpu")[0])}
+        if res["info"] < 0:
+            self.small_reset()
+        return res
+
     def small_result(self, d: int):
         """[out (d + 5) | status word] in one buffer, so one device-to-host copy ends an evaluation."""
         buf = self.empty(d + 6)

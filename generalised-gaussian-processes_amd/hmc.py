@@ -345,6 +345,58 @@ def shared_seed(seed: Optional[int], group=None) -> Optional[int]:
     return int(t.item())
 
 
+def sample_nuts_device(target, n_samples: int, tune: int, seed: Optional[int] = None, start: Optional[Sequence[float]] = None,
+                       step_scale=0.25, target_accept=0.8, max_treedepth=10) -> Trace:
+    """``pm.sample(n_samples, tune=tune, chains=1)`` entirely on the GPU: one persistent launch (``sgp_small_nuts``) runs the
+    sampler and every leapfrog's evaluation; theta, the momentum and the sampler state never visit the host (SURVEY section 8
+    f-1).  ``target`` is an ``HmcTarget`` whose bound takes the single-launch path (M <= 128, one rank).  Same algorithm and
+    random stream as ``NUTS(..., rng=SplitMix(seed))``; the trace has the surface the reference reads
+    (``trace['ls']``, ``trace[i]``, ``get_sampler_stats('step_size' | 'perf_counter_diff')``)."""
+    b = target.bound
+    if not target.device_sampler_ok():
+        raise ValueError("the device sampler needs the single-launch path (M <= 128, d <= 16, stationary kernel, one rank)")
+    nd = target.ndim
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
+    rng = SplitMix(seed)
+    if start is None:  # PyMC3's jitter around the test point; redrawn while the density there is zero
+        q = np.asarray(target.start(), dtype=np.float64) + rng.uniform(-1.0, 1.0, nd)
+        tries = 0
+        while not math.isfinite(target.logp(q)) and tries < 20:
+            q = np.asarray(target.start(), dtype=np.float64) + rng.uniform(-1.0, 1.0, nd)
+            tries += 1
+    else:
+        q = np.asarray(start, dtype=np.float64).copy()
+    if not math.isfinite(target.logp(q)):
+        raise RuntimeError("could not find a starting point with finite log-density" if start is None
+                           else "the log-density is not finite at the supplied start")
+    t0 = time.perf_counter()
+    r = b.engine.small_nuts(b.X, b.y, target.Z, q, tune, n_samples, rng.s, jitter=b.jitter, kernel=b.kernel,
+                            max_treedepth=max_treedepth, step_scale=step_scale, target_accept=target_accept)
+    wall = time.perf_counter() - t0
+    if r["info"] < 0:
+        from .core import SgpTimeoutError
+        raise SgpTimeoutError()
+    if r["draws"] != tune + n_samples:
+        raise RuntimeError("the device sampler stopped after %d of %d draws" % (r["draws"], tune + n_samples))
+    b.n_evals += r["evaluations"]
+    b.n_grads += r["evaluations"]
+    th = r["samples"].numpy()
+    samples = []
+    for row in th:
+        c = target.constrain(row)
+        samples.append({"ls": np.asarray(c["ls"], dtype=np.float64), "sig_f": float(c["sig_f"]), "sig_n": float(c["sig_n"]),
+                        "theta_unc": row.copy()})
+    st = r["stats"].numpy()
+    stats = {"step_size": st[:, 0], "tree_size": st[:, 1], "depth": st[:, 2], "mean_tree_accept": st[:, 3],
+             "diverging": st[:, 4] != 0.0, "energy": st[:, 5], "logp": st[:, 6], "perf_counter_diff": r["seconds"].numpy()}
+    tr = Trace(samples, stats)
+    tr.n_leapfrog = r["evaluations"]
+    tr.wall_clock_secs = wall
+    tr.device_resident = True
+    return tr
+
+
 def sample_nuts(target, n_samples: int, tune: int, seed: Optional[int] = None, start: Optional[Sequence[float]] = None,
                 step_scale=0.25, target_accept=0.8, max_treedepth=10, progress: Optional[Callable[[int, dict], None]] = None,
                 group=None) -> Trace:

@@ -218,6 +218,24 @@ int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* 
                    int want_grad, double* out, double* g_Z, int* info,
                    void* ws, size_t ws_bytes, sgp_stream_t stream);
 
+/* ---- device-resident NUTS over the same target ------------------------------------------------
+ * pm.sample(n_draws, tune=n_tune, chains=1) with pm.NUTS() defaults (models/bayesian_sgpr_hmc.py:73-78) in ONE persistent
+ * launch: multinomial NUTS, dual-averaging step size, jitter+adapt_diag mass matrix; the sampler state, theta and the
+ * momentum never leave the GPU, every leapfrog is one cooperative evaluation (SGP_SMALL_HMC) inside the running kernel.
+ *   q0 (device, d + 2): start in the unconstrained space; theta_scratch (device, d + 2) and out (device, d + 5) are work buffers
+ *   samples (device, n_draws x (d + 2)): post-tuning draws, unconstrained;  stats (device, sgp_small_nuts_stat_cols() arrays
+ *   of n_draws... see below);  counters (device, 2 x int64): evaluations (leapfrogs + 1), draws finished;  info as above.
+ *   stats layout: n_draws rows x 8 columns [step_size, tree_size, depth, mean_tree_accept, diverging, energy, logp,
+ *   cumulative evaluations] followed by n_draws doubles: seconds spent on each draw (device clock).
+ * Random numbers: splitmix64 seeded with `seed` (host twin: hmc.SplitMix) -- a run is reproducible bit for bit.
+ * Same workspace, co-residency and zeroed-sync-words rules as sgp_small_eval; max_treedepth <= 11.                       */
+size_t sgp_small_nuts_stat_cols(void);
+int sgp_small_nuts(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* q0,
+                   int64_t N, int M, int d, int kernel_id, double jitter, int n_tune, int n_draws, int max_treedepth,
+                   double step_scale, double target_accept, uint64_t seed, double* theta_scratch, double* samples,
+                   double* stats, long long* counters, double* out, int* info,
+                   void* ws, size_t ws_bytes, sgp_stream_t stream);
+
 /* ---- streaming pass 2: gradients through Kuf -------------------------------------------------------
  * Kbar_uf = 2 Phibar Kuf + bbar y^T is formed tile by tile and contracted with dKuf/d(.) on the fly.
  * Writes (overwrites) g_ls[d] = dF/d lengthscale_j, g_sf2[1] = dF/d sf2 (including the kappa term

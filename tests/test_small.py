@@ -133,3 +133,59 @@ def test_fused_launch_agrees_with_the_multi_launch_whitened_path(engine, name):
     assert relerr(ga["Z"].cpu().numpy(), gb["Z"].cpu().numpy()) < (1e-3 if ill else 1e-6)
     Fv, parts = a.value(Z, G["ls"], float(G["sf2"]), float(G["s2"]))
     assert Fv == Fa and abs(parts["trace_term"] - gb["trace_term"]) < 1e-8 * max(1.0, abs(Fb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rbf_d3_small", "rbf_d1_tiny"])
+def test_device_resident_nuts_matches_the_host_driven_sampler(engine, name):
+    """sgp_small_nuts (one persistent launch) against hmc.NUTS driven from the host with the same splitmix stream and the
+    same evaluations (the single-launch NUTS target): identical trees, draws equal to rounding (the sampler's own exp / log
+    / sin / cos come from the device math library there, from libm here)."""
+    import ggp_amd
+    from ggp_amd.hmc import NUTS, DiagMassAdapter, SplitMix
+    G = load_golden(name)
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    cb = ggp_amd.CollapsedBound(X, y, jitter=1e-6, engine=engine)
+    tgt = ggp_amd.HmcTarget(cb, Z)
+    assert tgt.device_sampler_ok()
+    q0 = np.array(tgt.start()) + 0.05
+    tune, draws, seed = 20, 15, 1234
+    r = engine.small_nuts(X, y, Z, q0, tune, draws, seed, jitter=1e-6, max_treedepth=8)
+    assert r["info"] == 0 and r["draws"] == tune + draws
+    nuts = NUTS(tgt.logp_and_grad, tgt.ndim, max_treedepth=8, rng=SplitMix(seed))
+    q = q0.copy()
+    lp, g = nuts._eval(q)
+    nuts.mass = DiagMassAdapter(tgt.ndim, initial_mean=q)
+    rows, sizes, steps = [], [], []
+    for it in range(tune + draws):
+        q, lp, g, st = nuts.draw(q, lp, g, it < tune)
+        if it >= tune:
+            rows.append(q.copy())
+            sizes.append(st["tree_size"])
+            steps.append(st["step_size"])
+    assert r["evaluations"] == nuts.n_leapfrog
+    assert np.array_equal(r["stats"][:, 1].numpy(), np.array(sizes, dtype=np.float64))
+    assert np.allclose(r["stats"][:, 0].numpy(), steps, rtol=1e-9)
+    assert np.allclose(r["samples"].numpy(), np.array(rows), rtol=1e-7, atol=1e-9)
+    assert np.all(r["seconds"].numpy() > 0.0)
+
+
+@pytest.mark.gpu
+def test_sample_nuts_device_trace_surface_and_posterior(engine):
+    """The Trace the reference reads (models/bayesian_sgpr_hmc.py:144-157, demo_1d_regression.py:199-206) from a device run,
+    and agreement of the posterior means with a host-driven run of the same length (statistical)."""
+    import ggp_amd
+    G = load_golden("rbf_d3_small")
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    tgt = ggp_amd.HmcTarget(ggp_amd.CollapsedBound(X, y, jitter=1e-6, engine=engine), Z)
+    tr = ggp_amd.sample_nuts_device(tgt, 150, 150, seed=3)
+    assert len(tr) == 150 and tr["ls"].shape == (150, 3) and tr[0]["sig_n"] > 0
+    assert tr.get_sampler_stats("step_size").shape == (150,) and float(tr.get_sampler_stats("perf_counter_diff").sum()) > 0
+    assert len(tr[::2]) == 75 and not tr.get_sampler_stats("diverging").any()
+    tr2 = ggp_amd.sample_nuts(tgt, 150, 150, seed=4)
+    m1 = np.log(np.concatenate([tr["ls"], tr["sig_f"][:, None], tr["sig_n"][:, None]], 1)).mean(0)
+    m2 = np.log(np.concatenate([tr2["ls"], tr2["sig_f"][:, None], tr2["sig_n"][:, None]], 1)).mean(0)
+    s2 = np.log(np.concatenate([tr2["ls"], tr2["sig_f"][:, None], tr2["sig_n"][:, None]], 1)).std(0)
+    assert np.all(np.abs(m1 - m2) < 0.6 * s2 + 0.02), (m1, m2, s2)
+    lf_per_s = tr.n_leapfrog / tr.wall_clock_secs
+    print("device NUTS: %d leapfrogs in %.3f s = %.0f / s" % (tr.n_leapfrog, tr.wall_clock_secs, lf_per_s))
