@@ -21,7 +21,7 @@ import torch
 from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeoutError
 from .gp_shim import (ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, LazyPredictive,
                       MultivariateNormal, RBFKernel, ScaleKernel, TrainPrior, ZeroMean)
-from .hmc import Trace, sample_nuts
+from .hmc import Trace, sample_nuts, sample_nuts_device
 
 FULL_COV_MAX_T = 4096  # predictive covariance is T x T; beyond this only mean / variance are formed
 
@@ -123,6 +123,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         self._hmc_cb: Optional[CollapsedBound] = None
         self._seed = seed
         self._n_hmc_calls = 0
+        self.device_sampler = True  # NUTS on the device when the problem takes the single-launch path (M <= 128)
 
     def freeze_kernel_hyperparameters(self):
         for name, parameter in self.named_hyperparameters():
@@ -142,6 +143,9 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         scale = 0.25 if not sampler_params else sampler_params.get('step_scale', 0.25)
         seed = None if self._seed is None else self._seed + self._n_hmc_calls
         self._n_hmc_calls += 1
+        if self.device_sampler and target.device_sampler_ok():
+            # the whole of pm.sample() in one persistent launch: theta, momentum and the tree never leave the GPU
+            return sample_nuts_device(target, n_samples, tune, seed=seed, step_scale=scale)
         return sample_nuts(target, n_samples, tune, seed=seed, step_scale=scale)
 
     def update_model_to_hyper(self, elbo, hyper_sample):
