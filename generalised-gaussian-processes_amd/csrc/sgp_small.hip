@@ -35,7 +35,7 @@ constexpr int SM_MAXD = 16;
 constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
-enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_WORDS = 9 };
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_WORDS = 10 };
 constexpr int SM_GP = SM_MAXD + 4;  // doubles per gradient partial: g_ls[d] at 0.., then g_sf2, tr B^-1
 
 struct SmallArgs {
@@ -43,7 +43,7 @@ struct SmallArgs {
   int N, M, d, kid, mode, want_grad, want_gz;
   double jitter;
   int nslab, grow;
-  double *Lk, *dinvK, *Bm, *Lb, *dinvB, *A, *Ppart, *upart, *spart, *u, *c0, *g, *gpart, *gzpart, *Qm;
+  double *Lk, *dinvK, *Bm, *Lb, *dinvB, *A, *Ppart, *upart, *spart, *u, *c0, *g, *h, *gpart, *gzpart, *Qm;
   int *sync, *info;
   double* out;
   double* gZ;
@@ -67,7 +67,7 @@ struct SmSlabShared {
   double zs[MP][SM_MAXD + 1];  // scaled inducing inputs
   double xs[SM_SLAB][SM_MAXD + 1];
   double ys[SM_SLAB];
-  double gv[MP];
+  double gv[MP], hv[MP];
   double red[4][MP];
   double gz[MP * SM_MAXD];
   double acc[SM_GP];
@@ -78,6 +78,7 @@ template <int MP>
 struct SmChainShared {
   DfShared df;
   double zs[MP][SM_MAXD + 1];
+  double vc0[MP], vg[MP], vh[MP];  // c0, g, h while the chain's vector solves run
 };
 
 template <int MP>
@@ -316,6 +317,67 @@ __device__ __forceinline__ void sm_vec_solve_blocks(SmSlabShared<MP>& sl, double
   __syncthreads();
 }
 
+// out <- L^-1 in (trans = false) or L^-T in (trans = true) for a factor in GLOBAL memory (ld MP), 64 x 64 tiles: wave 0,
+// lane <-> row, 64-step readlane chains with the tile's row / column preloaded into registers.  `in` / `out` live in LDS
+// (an agent-scope fence per tile -- an L2 write-back -- cost more than the chains).  Every thread calls.
+template <int MP>
+__device__ __forceinline__ void sm_vec_solve_tiles(const double* __restrict__ L, const double* in, double* out, bool trans) {
+  constexpr int NB64 = MP / 64;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    for (int jj = 0; jj < NB64; ++jj) {
+      const int jb = trans ? NB64 - 1 - jj : jj;
+      double lv[64];  // trans: lv[c] = L[c][lane] (column of the diagonal tile) ; else lv[c] = L[lane][c] (row)
+      if (trans) {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) lv[c] = L[(size_t)(jb * 64 + c) * MP + jb * 64 + lane];
+      } else {
+        const double* lsrc = L + (size_t)(jb * 64 + lane) * MP + (size_t)jb * 64;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const d2 t2 = *reinterpret_cast<const d2*>(lsrc + 2 * k);
+          lv[2 * k] = t2[0];
+          lv[2 * k + 1] = t2[1];
+        }
+      }
+      double rr = in[jb * 64 + lane];
+      for (int pp = 0; pp < jj; ++pp) {  // the tiles already solved
+        const int p = trans ? NB64 - 1 - pp : pp;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < 64; k += 2) {
+          const double l0 = trans ? L[(size_t)(p * 64 + k) * MP + jb * 64 + lane] : L[(size_t)(jb * 64 + lane) * MP + p * 64 + k];
+          const double l1 = trans ? L[(size_t)(p * 64 + k + 1) * MP + jb * 64 + lane] : L[(size_t)(jb * 64 + lane) * MP + p * 64 + k + 1];
+          s0 = fma(l0, out[p * 64 + k], s0);
+          s1 = fma(l1, out[p * 64 + k + 1], s1);
+        }
+        rr -= s0 + s1;
+      }
+      const double dinv = 1.0 / L[(size_t)(jb * 64 + lane) * (MP + 1)];
+      double mine = 0.0;
+      if (trans) {
+#pragma unroll
+        for (int c = 63; c >= 0; --c) {
+          const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
+          if (lane == c) mine = xc;
+          rr = fma(-lv[c], xc, rr);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+          const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
+          if (lane == c) mine = xc;
+          rr = fma(-lv[c], xc, rr);
+        }
+      }
+      out[jb * 64 + lane] = mine;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------------
 template <int MP>
 struct SmKernelShared {
@@ -529,41 +591,23 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       __syncthreads();
     }
     stamp(5);
-    // c0 = LB^-1 u for the value (the other workgroups derive c0 and g themselves from the published factor): wave 0,
-    // lane <-> row, 64-step chains per tile with the row of L in registers
+    // c0 = LB^-1 u (for the value), g = LB^-T c0 = B^-1 u and h = L^-T g: the vectors the reverse pass needs only in its
+    // last step (the contraction), computed here while the other workgroups run their solves; one flag hands them over
     double cc = 0.0;
-    if (w == 0) {
-      for (int jb = 0; jb < NB64; ++jb) {
-        const double* lsrc = a.Lb + (size_t)(jb * 64 + lane) * MP + (size_t)jb * 64;
-        double lrow[64];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          const d2 t2 = *reinterpret_cast<const d2*>(lsrc + 2 * k);
-          lrow[2 * k] = t2[0];
-          lrow[2 * k + 1] = t2[1];
+    {
+      SmChainShared<MP>& ch = sh.ch;
+      if (tid < MP) ch.vg[tid] = a.u[tid];
+      __syncthreads();
+      sm_vec_solve_tiles<MP>(a.Lb, ch.vg, ch.vc0, false);
+      for (int i = tid; i < MP; i += 256) cc = fma(ch.vc0[i], ch.vc0[i], cc);
+      if (a.want_grad) {
+        sm_vec_solve_tiles<MP>(a.Lb, ch.vc0, ch.vg, true);
+        sm_vec_solve_tiles<MP>(a.Lk, ch.vg, ch.vh, true);
+        if (tid < MP) {
+          a.g[tid] = ch.vg[tid];
+          a.h[tid] = ch.vh[tid];
         }
-        double rr = a.u[jb * 64 + lane];
-        for (int p = 0; p < jb; ++p) {
-          const double* lp = a.Lb + (size_t)(jb * 64 + lane) * MP + (size_t)p * 64;
-          double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-          for (int k = 0; k < 64; k += 2) {
-            s0 = fma(lp[k], a.c0[p * 64 + k], s0);
-            s1 = fma(lp[k + 1], a.c0[p * 64 + k + 1], s1);
-          }
-          rr -= s0 + s1;
-        }
-        const double dinv = 1.0 / a.Lb[(size_t)(jb * 64 + lane) * (MP + 1)];
-        double mine = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) {
-          const double xc = readlane_f64(rr, c) * readlane_f64(dinv, c);
-          if (lane == c) mine = xc;
-          rr = fma(-lrow[c], xc, rr);
-        }
-        a.c0[jb * 64 + lane] = mine;
-        cc = fma(mine, mine, cc);
-        __threadfence();
+        sm_publish_set(sy + SY_G * SM_SYNC_STRIDE, ev);
       }
     }
     cc = block_sum(cc);
@@ -796,19 +840,19 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
           }
       }
       __syncthreads();
-      if (tid < MP) {
+      {  // column sums A^T y, sum A o A: thread <-> (column, part of the rows); y^2 rides on the last threads
+        constexpr int PARTS = 256 / MP, RPP = SM_SLAB / PARTS;
+        const int m = tid % MP, part = tid / MP;
         double su = 0.0, sa = 0.0;
-        for (int r = 0; r < SM_SLAB; ++r) {
-          const double v = sl.S[r][tid];
+#pragma unroll 8
+        for (int r = part * RPP; r < (part + 1) * RPP; ++r) {
+          const double v = sl.S[r][m];
           su = fma(v, sl.ys[r], su);
           sa = fma(v, v, sa);
         }
         uacc += su;
         a2acc += sa;
-      } else if (tid < MP + SM_SLAB && tid - MP < SM_SLAB) {
-        // (only reached when MP < 256 - 64) y^2 of this slab, one row per thread
-        const double v = sl.ys[tid - MP];
-        yyacc = fma(v, v, yyacc);
+        if (tid < SM_SLAB) yyacc = fma(sl.ys[tid], sl.ys[tid], yyacc);
       }
       if (sb == rw) stamp(11);
       // partial A^T A: lower 16 x 16 blocks dealt round-robin to the waves
@@ -840,9 +884,19 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
           for (int r = 0; r < 4; ++r) P[(size_t)(16 * bi + l4 + 4 * r) * MP + 16 * bj + l15] = pacc[i][r];
         }
       }
-      if (tid < MP) a.upart[(size_t)rw * MP + tid] = uacc;
-      const double sa = block_sum(tid < MP ? a2acc : 0.0);
-      const double sy2 = block_sum(tid >= MP ? yyacc : 0.0);
+      {  // the row parts of a column, added in a fixed order
+        __syncthreads();
+        double* ured = &sl.red[0][0];  // 4 x MP doubles >= 256
+        ured[tid] = uacc;
+        __syncthreads();
+        if (tid < MP) {
+          double su = 0.0;
+          for (int part = 0; part < 256 / MP; ++part) su += ured[part * MP + tid];
+          a.upart[(size_t)rw * MP + tid] = su;
+        }
+      }
+      const double sa = block_sum(a2acc);
+      const double sy2 = block_sum(yyacc);
       if (tid == 0) {
         a.spart[2 + 2 * rw] = sa;
         a.spart[3 + 2 * rw] = sy2;
@@ -913,12 +967,8 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         sl.xs[r][j] = (n0 + r < N && j < d) ? a.X[(size_t)(n0 + r) * a.ldx + j] * hyp.inv_ls[j] : 0.0;
       }
       if (tid < SM_SLAB) sl.ys[tid] = n0 + tid < N ? a.y[n0 + tid] : 0.0;
-      if (sb == rw) {  // g = B^-1 u from the factor just staged (every workgroup for itself: nobody waits for a broadcast)
-        if (tid < MP) sl.gv[tid] = a.u[tid];
-        sm_vec_solve_blocks<MP>(sl, sl.gv, false);
-        sm_vec_solve_blocks<MP>(sl, sl.gv, true);
-      }
       __syncthreads();
+      if (sb == rw) stamp(13);
       SlabRegs<NB16> Ya, Y;
       {
         const double* arow = a.A + (size_t)(n0 + nl) * MP;
@@ -930,26 +980,40 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       Y = Ya;
       sm_trsm_fwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
       sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);  // V = B^-1 a_n
-      double tn = 0.0;
+      // Abar = [(a - B^-1 a) + g (y_n / s2 - g.a_n / s2^2)] / s2 ; Kbar = L^-T Abar = L^-T (a - B^-1 a) / s2 + h c_n with
+      // h = L^-T g, c_n = (y_n - g.a_n / s2) / s2^2: the part that needs g joins after the solve
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) tn = fma(sl.gv[16 * pb + 4 * s + l4], Ya.b[pb][s], tn);
-      tn += __shfl_xor(tn, 16, 64);
-      tn += __shfl_xor(tn, 32, 64);  // g . a_n, in the four lanes that share the row
-      const double yn = sl.ys[nl];
-#pragma unroll
-      for (int pb = 0; pb < NB16; ++pb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double gm = sl.gv[16 * pb + 4 * s + l4];
-          Y.b[pb][s] = (Ya.b[pb][s] - Y.b[pb][s] + gm * (yn * is2 - tn * is22)) * is2;
-        }
+        for (int s = 0; s < 4; ++s) Y.b[pb][s] = (Ya.b[pb][s] - Y.b[pb][s]) * is2;
       __syncthreads();
+      if (sb == rw) stamp(15);
       sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
       __syncthreads();
-      sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);  // Kbar_uf rows of this slab
+      sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+      if (sb == rw) {  // g, h from the chain workgroup (normally there long before)
+        if (!sm_wait_ge(sy + SY_G * SM_SYNC_STRIDE, ev, abortw, &dead)) return;
+        if (tid < MP) {
+          sl.gv[tid] = a.g[tid];
+          sl.hv[tid] = a.h[tid];
+        }
+      }
       __syncthreads();
+      {
+        double tn = 0.0;
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) tn = fma(sl.gv[16 * pb + 4 * s + l4], Ya.b[pb][s], tn);
+        tn += __shfl_xor(tn, 16, 64);
+        tn += __shfl_xor(tn, 32, 64);  // g . a_n, in the four lanes that share the row
+        const double cn = (sl.ys[nl] - tn * is2) * is22;
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) Y.b[pb][s] = fma(sl.hv[16 * pb + 4 * s + l4], cn, Y.b[pb][s]);  // Kbar_uf rows of this slab
+      }
+      if (sb == rw) stamp(10);
       contract(Y, N - n0 < SM_SLAB ? N - n0 : SM_SLAB, 1.0);
     }
     stamp(7);
@@ -972,17 +1036,6 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     const int col = 64 * v + 16 * w + l15;
     __syncthreads();
     sm_stage_factor<MP>(sl, a.Lb, a.dinvB);
-    if (tid < MP) sl.gv[tid] = a.u[tid];
-    sm_vec_solve_blocks<MP>(sl, sl.gv, false);
-    sm_vec_solve_blocks<MP>(sl, sl.gv, true);  // g = B^-1 u
-    if (v == 0) {  // the two scalars of dF/ds2 that involve g
-      const double ug = block_sum(tid < MP ? a.u[tid] * sl.gv[tid] : 0.0);
-      const double gg = block_sum(tid < MP ? sl.gv[tid] * sl.gv[tid] : 0.0);
-      if (tid == 0) {
-        sl.acc[SM_MAXD + 2] = ug;
-        sl.acc[SM_MAXD + 3] = gg;
-      }
-    }
     __syncthreads();
     SlabRegs<NB16> Y;
 #pragma unroll
@@ -991,23 +1044,39 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       for (int s = 0; s < 4; ++s) Y.b[pb][s] = (16 * pb + 4 * s + l4) == col ? 1.0 : 0.0;
     sm_trsm_fwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
     sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);  // columns of B^-1
-    const double gc = sl.gv[col] * is22;
 #pragma unroll
     for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int m = 16 * pb + 4 * s + l4;
         if (m == col) trb += Y.b[pb][s];
-        Y.b[pb][s] += a.Bm[(size_t)m * MP + col] - (m == col ? 2.0 : 0.0) + sl.gv[m] * gc;
+        Y.b[pb][s] += a.Bm[(size_t)m * MP + col] - (m == col ? 2.0 : 0.0);  // columns of B + B^-1 - 2 I
       }
     __syncthreads();
     sm_stage_factor<MP>(sl, a.Lk, a.dinvK);
     __syncthreads();
     sm_trsm_bwd<NB16>(Y, sl.Lblk, sl.Dinv, l15, l4);
+    // the rank-one part of S joins after the solve: L^-T (g g^T / s2^2) = h g^T / s2^2 (g, h from the chain workgroup, which
+    // computes them while these solves run)
+    if (!sm_wait_ge(sy + SY_G * SM_SYNC_STRIDE, ev, abortw, &dead)) return;
+    if (tid < MP) {
+      sl.gv[tid] = a.g[tid];
+      sl.hv[tid] = a.h[tid];
+    }
+    __syncthreads();
+    if (v == 0) {  // the two scalars of dF/ds2 that involve g
+      const double ug = block_sum(tid < MP ? a.u[tid] * sl.gv[tid] : 0.0);
+      const double gg = block_sum(tid < MP ? sl.gv[tid] * sl.gv[tid] : 0.0);
+      if (tid == 0) {
+        sl.acc[SM_MAXD + 2] = ug;
+        sl.acc[SM_MAXD + 3] = gg;
+      }
+    }
+    const double gc = sl.gv[col] * is22;
 #pragma unroll
     for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) a.Qm[(size_t)(16 * pb + 4 * s + l4) * MP + col] = Y.b[pb][s];
+      for (int s = 0; s < 4; ++s) a.Qm[(size_t)(16 * pb + 4 * s + l4) * MP + col] = fma(sl.hv[16 * pb + 4 * s + l4], gc, Y.b[pb][s]);
   }
   trb = block_sum(trb);
   if (tid == 0) sl.acc[SM_MAXD + 1] = trb;
@@ -1179,6 +1248,7 @@ static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
   w.a.u = c.take<double>(MP);
   w.a.c0 = c.take<double>(MP);
   w.a.g = c.take<double>(MP);
+  w.a.h = c.take<double>(MP);
   w.a.gpart = c.take<double>((size_t)(grow + NB64) * SM_GP);
   w.a.gzpart = c.take<double>((size_t)(grow + NB64) * MP * SM_MAXD);
   w.a.Qm = c.take<double>(mm);

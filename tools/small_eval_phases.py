@@ -55,6 +55,10 @@ def main():
     print("row workgroup 0, first forward slab")
     for k, nm in zip(range(8, 13), names):
         print("   %-42s %8.1f us" % (nm, (int(r[k]) - t0) / 100.0))
+    print("row workgroup 0, first reverse slab (LB seen at %.1f us)" % ((int(r[6]) - t0) / 100.0))
+    for k, nm in ((13, "LB blocks staged"), (14, "c0, g solved"), (15, "B^-1 a (two solves), Abar formed"), (10, "L blocks staged, Kbar solved"),
+                  (7, "contraction done")):
+        print("   %-42s %8.1f us" % (nm, (int(r[k]) - t0) / 100.0))
 
 
 if __name__ == "__main__":
