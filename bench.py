@@ -7,10 +7,20 @@ d = 8, M = 1024 inducing points, RBF-ARD, fp64.  A "step" is ONE evaluation of t
 N rows are split into G contiguous shards (strong scaling: the job is fixed, one rank per GPU over RCCL).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).  Extra keys:
-  leapfrog_per_s : value + gradient wrt (lengthscales, sig_f, sig_n) evaluations / s, same run, same data
-  roofline       : dominant kernel (fused assembly + SYRK, `suffstats_fwd_kernel`) against the fp64 matrix peak
-  cpu_baseline   : the oracle's PyMC3-op-order restatement timed on this box's host cores (rank 0, N=1 only)
+  leapfrog_per_s    : value + gradient wrt (lengthscales, sig_f, sig_n) evaluations / s, same run, same data
+  roofline          : the dominant kernel of an evaluation, `syrk_tile_kernel` (pass-1 contraction), against the fp64
+                      matrix peak.  achieved = the kernel's OWN algorithmic work N M (M + 1) flop / its HIP-event time
+                      (events recorded by the library on the launch stream right around the kernel: sgp_timing_*).
+                      `pass1` inside it times kernel assembly + contraction together against SURVEY section 8d's
+                      whole-evaluation W_fwd; traffic = HBM bytes of the kernel from the newest profiles/*_pmc_hbm_traffic.csv
+                      (PMC passes, tools/profile_round.sh), traffic_ratio = traffic / the kernel's algorithmic bytes
+  roofline_leapfrog : the same for the dominant kernel of the reverse pass, `kbar_contract_kernel` (2 N M^2 flop)
+  cpu_baseline      : the oracle's PyMC3-op-order restatement timed on this box's host cores (rank 0, N=1 only): value
+                      only at two sample sizes (fixed + per-row cost fitted, then evaluated at N; --cpu-full times all N
+                      rows instead), and value + autograd gradient next to leapfrog_per_s
 """
+import csv
+import glob
 import argparse
 import json
 import math
@@ -28,9 +38,23 @@ M_IND = 1024
 DIM = 8
 LS, SF, SN, JITTER = 2.0, 1.0, 0.3, 1e-6
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= 256 CU x 2.4 GHz x 128 flop/clk/CU); see DESIGN.md
-# HBM bytes one syrk_tile_kernel launch moved at the default config (N=1M, M=1024, 1 GPU), from the PMC passes
-# committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); None for other configs.
-SYRK_TRAFFIC_BYTES_PMC = 4.54e10
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel at the default config (N = 1M, M = 1024, 1 GPU) from the newest
+    profiles/*_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes: tools/summarise_pmc.py).  Returns (bytes, file) or (None, None)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")), key=os.path.getmtime)
+    for f in reversed(files):
+        tot, seen = 0.0, set()
+        with open(f, newline="") as fh:
+            for row in csv.reader(r for r in fh if not r.startswith("#")):
+                if len(row) == 5 and row[0] in ("FETCH_SIZE", "WRITE_SIZE") and kernel_substr in row[1] and row[0] not in seen:
+                    tot += float(row[4])
+                    seen.add(row[0])
+        if len(seen) == 2:
+            return tot, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def synth(n_total, m, d):
@@ -49,18 +73,46 @@ def algorithmic_flops_fwd(n, m, d):
     return n * m * (m + 1) + 2.0 * n * m + n * m * (3 * d + 2)
 
 
-def cpu_baseline(X, y, Z, sample_rows):
+def cpu_baseline(X, y, Z, sample_rows, full):
+    """The timed CPU path: the oracle's PyMC3-op-order form, torch-CPU fp64, every host thread."""
     from oracle import vfe_oracle as O
     torch.set_num_threads(os.cpu_count() or 1)
-    Xs, ys = X[:sample_rows], y[:sample_rows]
-    ls = torch.full((X.shape[1],), LS, dtype=torch.float64)
-    t0 = time.perf_counter()
-    O.vfe_pymc3_order_chunked(Xs, ys, Z, ls, SF, SN, JITTER, chunk=65536)
-    dt = time.perf_counter() - t0
-    full = dt * (X.shape[0] / float(sample_rows))
-    return {"value": 1.0 / full, "unit": "ELBO evals/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle.vfe_pymc3_order_chunked (PyMC3 MarginalSparse op order, torch-CPU fp64) on the first %d of "
-                      "%d rows, M=%d d=%d, value only: %.2f s, extrapolated linearly in N" % (sample_rows, X.shape[0], Z.shape[0], X.shape[1], dt)}
+    N, d = X.shape
+    M = Z.shape[0]
+    ls = torch.full((d,), LS, dtype=torch.float64)
+
+    def t_value(rows):
+        t0 = time.perf_counter()
+        O.vfe_pymc3_order_chunked(X[:rows], y[:rows], Z, ls, SF, SN, JITTER, chunk=65536)
+        return time.perf_counter() - t0
+
+    def t_grad(rows):
+        t0 = time.perf_counter()
+        O.grads_autograd(X[:rows], y[:rows], Z, ls, SF * SF, SN * SN, JITTER)
+        return time.perf_counter() - t0
+
+    t_value(min(8192, N))  # thread pool / allocator warm-up
+    if full:
+        full_s = t_value(N)
+        how = "all %d rows: %.2f s" % (N, full_s)
+    else:
+        n1, n2 = max(1, sample_rows // 2), sample_rows
+        t1, t2 = t_value(n1), t_value(n2)
+        per_row = max((t2 - t1) / max(1, n2 - n1), 0.0)
+        fixed = max(t1 - per_row * n1, 0.0)
+        full_s = fixed + per_row * N
+        how = ("%d rows: %.2f s, %d rows: %.2f s; fixed %.2f s + %.3g s/row evaluated at N = %d -> %.1f s"
+               % (n1, t1, n2, t2, fixed, per_row, N, full_s))
+    g1, g2 = max(1, min(N, sample_rows) // 8), max(2, min(N, sample_rows) // 4)
+    tg1, tg2 = t_grad(g1), t_grad(g2)
+    gper = max((tg2 - tg1) / max(1, g2 - g1), 0.0)
+    gfull = max(tg1 - gper * g1, 0.0) + gper * N
+    return {"value": 1.0 / full_s, "unit": "ELBO evals/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle.vfe_pymc3_order_chunked (PyMC3 MarginalSparse op order, torch-CPU fp64), M=%d d=%d, value only, %s"
+                      % (M, d, how),
+            "leapfrog": {"value": 1.0 / gfull, "unit": "value+gradient evals/s",
+                         "sample": "oracle.grads_autograd (torch autograd through the same graph) on %d rows: %.2f s and %d rows: "
+                                   "%.2f s, fitted and evaluated at N = %d -> %.1f s" % (g1, tg1, g2, tg2, N, gfull)}}
 
 
 def main():
@@ -70,7 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", dest="n", type=int, default=N_TOTAL)
     ap.add_argument("--inducing", dest="m", type=int, default=M_IND)
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="rows of the larger CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on all N rows (~80-110 s) instead of fitting two samples")
     ap.add_argument("--side-chain", choices=["graph", "launches", "off"], default="graph",
                     help="how chol(Kuu) is enqueued on the side stream (A/B knob; default = the product default)")
     args = ap.parse_args()
@@ -139,29 +192,50 @@ def main():
     evals_per_s = args.steps / dt_val
     leap_per_s = max(2, args.steps // 2) / dt_grad
 
-    # dominant kernel (the SYRK contraction of pass 1 on this rank's shard), timed alone: the library
-    # records HIP events on the launch stream right around that kernel (include/sgp.h: sgp_timing_*)
+    # dominant kernels, timed alone: the library records HIP events on the launch stream right around them
+    # (include/sgp.h: sgp_timing_*; slot 0 kernel assembly, 1 pass-1 contraction, 2 pass-2 contraction)
     import ctypes
+    n_local = hi - lo
     eng.lib.sgp_timing_enable(1)
-    packed = eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf")
+    kfu = eng.kfu_buffer(n_local, args.m)
+    packed = eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf", kfu=kfu)
+    Kuu = eng.kuu(Zd, ls, sf2, JITTER, "rbf")
+    adj = eng.bound(Kuu, packed, s2, args.n, with_adjoints=True)
     torch.cuda.synchronize(dev)
     reps = max(3, min(10, args.steps))
-    syrk_ms, asm_ms = [], []
+    ms = {0: [], 1: [], 2: []}
     for _ in range(reps):
-        eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf", out=packed)
-        t = ctypes.c_float(0.0)
-        assert eng.lib.sgp_timing_last_ms(1, ctypes.byref(t)) == 0
-        syrk_ms.append(t.value)
-        assert eng.lib.sgp_timing_last_ms(0, ctypes.byref(t)) == 0
-        asm_ms.append(t.value)
+        eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf", out=packed, kfu=kfu)
+        eng.suffstats_bwd(Xd, yd, Zd, ls, sf2, adj["Phibar"], adj["bbar"], -1.0 / (2.0 * s2), "rbf", kfu=kfu)
+        for slot in ms:
+            t = ctypes.c_float(0.0)
+            assert eng.lib.sgp_timing_last_ms(slot, ctypes.byref(t)) == 0
+            ms[slot].append(t.value)
     eng.lib.sgp_timing_enable(0)
-    syrk_ms.sort()
-    asm_ms.sort()
-    pass1_ms = syrk_ms[len(syrk_ms) // 2]
-    assemble_ms = asm_ms[len(asm_ms) // 2]
-    n_local = hi - lo
-    achieved = algorithmic_flops_fwd(n_local, args.m, DIM) / (pass1_ms * 1e-3) / 1e12
-    kfu_bytes = 8.0 * ((n_local + 255) // 256 * 256) * ((args.m + 127) // 128 * 128)
+    del kfu
+    med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+    assemble_ms, syrk_ms, kbar_ms = med[0], med[1], med[2]
+    Mp = (args.m + 127) // 128 * 128
+    kfu_bytes = 8.0 * ((n_local + 255) // 256 * 256) * Mp
+    syrk_flops = float(n_local) * args.m * (args.m + 1)            # the contraction's own work: lower triangle, 2 flop / MAC
+    kbar_flops = 2.0 * float(n_local) * args.m * args.m             # Kbar_uf = 2 Phibar K_uf
+    wfwd = algorithmic_flops_fwd(n_local, args.m, DIM)
+    default_cfg = (args.n, args.m, world) == (N_TOTAL, M_IND, 1)
+    syrk_traffic, syrk_file = pmc_traffic("syrk_tile_kernel") if default_cfg else (None, None)
+    kbar_traffic, kbar_file = pmc_traffic("kbar_contract_kernel") if default_cfg else (None, None)
+    syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12
+    kbar_tf = kbar_flops / (kbar_ms * 1e-3) / 1e12
+    note = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE in separate passes "
+            "(tools/profile_round.sh), read from %s; not collected in this run")
+
+    devices = [torch.cuda.get_device_properties(dev).name + " #%d" % local_rank]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, local_rank, torch.cuda.current_device(), str(torch.cuda.get_device_properties(dev).uuid)
+                                         if hasattr(torch.cuda.get_device_properties(dev), "uuid") else ""))
+        devices = ["rank %d: cuda:%d %s" % (r, cur, u) for r, lr, cur, u in gathered]
+        assert dist.get_world_size() == world and len({(cur, u) for _, _, cur, u in gathered}) == world or os.environ.get("SGP_BENCH_SHARE_GPU") == "1", \
+            "ranks share a device: %r" % (gathered,)
 
     res = {
         "metric": "ELBO evals/sec", "value": evals_per_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
@@ -169,21 +243,34 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C5 synthetic regression N=%d d=%d M=%d RBF-ARD, collapsed VFE bound, rows sharded over %d GPU(s)"
                                % (args.n, DIM, args.m, world), "N": args.n, "M": args.m, "d": DIM, "jitter": JITTER,
-                   "theta": {"ls": LS, "sig_f": SF, "sig_n": SN}},
+                   "theta": {"ls": LS, "sig_f": SF, "sig_n": SN}, "ranks": world, "collective_backend": backend if world > 1 else None,
+                   "devices": devices, "rows_per_rank": n_local,
+                   "evaluation_order": "streaming (Phi = K_uf K_fu over the row shards, W = L^-1 Phi L^-T in the replicated tail)"},
         "leapfrog_per_s": leap_per_s, "ms_per_leapfrog": 1e3 / leap_per_s,
         "F": last["F"], "F_per_datum": last["F"] / args.n,
         "roofline": {"bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction, this rank's shard)",
-                     "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": SYRK_TRAFFIC_BYTES_PMC if (args.n, args.m, world) == (N_TOTAL, M_IND, 1) else None, "ms": pass1_ms,
-                     "algorithmic_flops": algorithmic_flops_fwd(n_local, args.m, DIM),
-                     "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
-                                     "profiles/r01_v14_pmc_hbm_traffic.csv (tools/profile_round.sh); collected in separate passes, not in this run"},
+                     "achieved": syrk_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tf / FP64_MATRIX_PEAK_TFLOPS,
+                     "ms": syrk_ms, "algorithmic_flops": syrk_flops, "algorithmic_flops_formula": "N M (M + 1): lower triangle of Phi, 2 flop per MAC",
+                     "algorithmic_bytes": kfu_bytes, "traffic": syrk_traffic,
+                     "traffic_ratio": (syrk_traffic / kfu_bytes) if syrk_traffic else None,
+                     "traffic_note": (note % syrk_file) if syrk_file else None,
+                     "pass1": {"kernels": "kfu_assemble_kernel + syrk_tile_kernel", "ms": assemble_ms + syrk_ms, "algorithmic_flops": wfwd,
+                               "achieved": wfwd / ((assemble_ms + syrk_ms) * 1e-3) / 1e12, "frac": wfwd / ((assemble_ms + syrk_ms) * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                               "note": "SURVEY section 8d W_fwd (contraction + b + scaled distances) over both kernels of pass 1"},
+                     "materialised_note": "K'_fu is written once (HBM-write bound assembly) and read back by the contraction: a fused kernel would "
+                                          "move 80.5 MB per evaluation instead of ~55 GB, but measured 53 ms (fp64 VALU exp() and MFMA share the datapath)"},
+        "roofline_leapfrog": {"bound": "mfma", "kernel": "sgp::kbar_contract_kernel (pass-2 contraction + derivative epilogue)",
+                              "achieved": kbar_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kbar_tf / FP64_MATRIX_PEAK_TFLOPS,
+                              "ms": kbar_ms, "algorithmic_flops": kbar_flops, "algorithmic_flops_formula": "2 N M^2 (Kbar_uf = 2 Phibar K_uf)",
+                              "algorithmic_bytes": kfu_bytes, "traffic": kbar_traffic,
+                              "traffic_ratio": (kbar_traffic / kfu_bytes) if kbar_traffic else None,
+                              "traffic_note": (note % kbar_file) if kbar_file else None},
         "assembly": {"bound": "hbm", "kernel": "sgp::kfu_assemble_kernel<8,0>", "ms": assemble_ms,
                      "achieved": kfu_bytes / (assemble_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": kfu_bytes / (assemble_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": kfu_bytes},
     }
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n))
+        res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

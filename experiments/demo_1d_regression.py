@@ -49,12 +49,14 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
     t0 = time.time()
     losses = model.train_model(opt, max_steps=args.max_iters, verbose=False)
-    out["SparseGPR"] = {"wall_clock_secs": time.time() - t0, "final_loss": losses[-1]}
+    wall = time.time() - t0
     pred = model.posterior_predictive(X_test.to(dev))
-    out["SparseGPR"].update(test_rmse=float(rmse(pred.loc, Y_test, ystd)), test_nlpd=float(nlpd(pred, Y_test, ystd)),
-                            lengthscale=model.base_covar_module.base_kernel.lengthscale.detach().cpu().reshape(-1).tolist(),
-                            outputscale=float(model.base_covar_module.outputscale.detach()),
-                            noise=float(model.likelihood.noise.detach()))
+    # one record per model in the reference's result schema (experiments/regression.py:157-179)
+    out["SparseGPR"] = ggp_amd.experiment_tools.result_record(
+        "demo_1d", "SGPR", float(rmse(pred.loc, Y_test, ystd)), float(nlpd(pred, Y_test, ystd)), wall, num_inducing=args.num_inducing,
+        max_iter=args.max_iters, final_loss=losses[-1],
+        lengthscale=model.base_covar_module.base_kernel.lengthscale.detach().cpu().reshape(-1).tolist(),
+        outputscale=float(model.base_covar_module.outputscale.detach()), noise=float(model.likelihood.noise.detach()))
 
     if not args.skip_hmc:
         hmc = BayesianSparseGPR_HMC(X_train, Y_train, GaussianLikelihood(), Z_init, jitter=1e-6, seed=45)
@@ -65,12 +67,11 @@ def main():
         wall = time.time() - t0
         preds = mixture_posterior_predictive(hmc, X_test.to(dev), trace)
         means = torch.stack([p.loc.cpu() for p in preds]).mean(0)
-        out["BayesianSGPR_HMC"] = {"wall_clock_secs": wall, "perf_times": [float(p) for p in perf],
-                                   "step_sizes": [float(s) for s in step_sizes], "n_mixture": len(preds),
-                                   "test_rmse": float(rmse(means, Y_test, ystd)),
-                                   "test_nlpd": float(nlpd_mixture(preds, Y_test, ystd)),
-                                   "ls_mean": float(np.mean(trace["ls"])), "sig_n_mean": float(np.mean(trace["sig_n"])),
-                                   "leapfrogs_last_phase": int(trace.n_leapfrog)}
+        out["BayesianSGPR_HMC"] = ggp_amd.experiment_tools.result_record(
+            "demo_1d", "Bayesian_SGPR_HMC", float(rmse(means, Y_test, ystd)), float(nlpd_mixture(preds, Y_test, ystd)), wall,
+            perf_times=perf, step_sizes=step_sizes, num_inducing=args.num_inducing, max_iter=args.max_iters, n_mixture=len(preds),
+            ls_mean=float(np.mean(trace["ls"])), sig_n_mean=float(np.mean(trace["sig_n"])),
+            leapfrogs_last_phase=int(trace.n_leapfrog), sampler_on_device=bool(getattr(trace, "device_resident", False)))
     print(json.dumps(out))
 
 

@@ -45,14 +45,19 @@ def main():
     wall = time.time() - t0
     pred = model.posterior_predictive(Xte)
     ystd = torch.tensor([float(sd)])
-    out = {"model": "SGPR", "N": args.n, "M": args.num_inducing, "d": args.dim, "max_iters": args.max_iters,
-           "wall_clock_secs": wall, "secs_per_step": wall / max(1, args.max_iters), "loss_first": losses[0], "loss_last": losses[-1],
-           "test_rmse": float(rmse(pred.loc, yte, ystd)), "test_nlpd": nlpd_marginal(pred, yte, ystd)}
+    # the reference's result schema (experiments/regression.py:157-179: exp_info + metrics in one flat dict), then extras
+    out = ggp_amd.experiment_tools.result_record(
+        "Synthetic_N%d_d%d" % (args.n, args.dim), "SGPR", float(rmse(pred.loc, yte, ystd)), nlpd_marginal(pred, yte, ystd), wall,
+        num_inducing=args.num_inducing, max_iter=args.max_iters, train_test_split=args.n / float(args.n + n_test),
+        N=args.n, d=args.dim, secs_per_step=wall / max(1, args.max_iters), loss_first=losses[0], loss_last=losses[-1],
+        nlpd_kind="marginal (utils/metrics.py:49-58; the joint form needs a 10 000 x 10 000 covariance)")
     if args.hmc_samples > 0:
         hmc = BayesianSparseGPR_HMC(Xtr, ytr, GaussianLikelihood(), model.inducing_points.cpu(), jitter=1e-6, seed=1)
         t0 = time.time()
         trace, steps, perf = hmc.train_fixed_model(num_tune=args.hmc_tune, num_samples=args.hmc_samples)
         wall = time.time() - t0
+        out["step_sizes"] = [float(v) for v in steps]
+        out["perf_times"] = [float(v) for v in perf]
         out["hmc"] = {"draws": len(trace), "tune": args.hmc_tune, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
                       "leapfrogs_per_sec": trace.n_leapfrog / wall, "step_size": float(steps[0]),
                       "sig_n_mean": float(trace["sig_n"].mean()), "ls_mean": trace["ls"].mean(0).tolist()}

@@ -6,7 +6,7 @@ valid Python identifier: import it through the repo-root shim ``ggp_amd`` (``imp
 from ._lib import KERNEL_IDS, SgpLibraryError, SgpStatusError, load_library  # noqa: F401
 from .composite import CO2_LOG_PRIOR_SD, CompositeHmcTarget, CompositeKernel, Factor, co2_kernel  # noqa: F401
 from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeoutError, shard_rows  # noqa: F401
-from . import datasets  # noqa: F401
+from . import datasets, experiment_tools  # noqa: F401
 from .gp_shim import (BernoulliLikelihood, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, MaternKernel,  # noqa: F401
                       MultivariateNormal, RBFKernel, ScaleKernel, ZeroMean, settings)
 from .hmc import NUTS, SplitMix, Trace, sample_nuts, sample_nuts_device  # noqa: F401

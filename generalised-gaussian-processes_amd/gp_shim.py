@@ -168,10 +168,11 @@ class MultivariateNormal:
     """loc / covariance container with the members the reference's metrics and plots use
     (utils/metrics.py:44,53-54; utils/visualisation.py:22,41)."""
 
-    def __init__(self, mean, covariance_matrix, variance=None):
+    def __init__(self, mean, covariance_matrix, variance=None, engine=None):
         self.loc = mean
         self._cov = covariance_matrix
         self._var = variance
+        self._engine = engine  # HipEngine when the covariance lives on the GPU: factorizations stay there
 
     @property
     def mean(self):
@@ -193,13 +194,44 @@ class MultivariateNormal:
         s = 2.0 * self.stddev
         return self.loc - s, self.loc + s
 
+    def _on_device(self):
+        return self._engine is not None and self._cov is not None and self._cov.is_cuda and hasattr(self._engine, "chol_lower")
+
+    def is_psd(self, jitter=1e-4):
+        """The reference's gate on a predictive covariance, ``torch.linalg.cholesky(cov + 1e-4 I)`` succeeding
+        (models/bayesian_sgpr_hmc.py:225-229).  On the GPU the T x T matrix is factored where it is (sgp_chol_lower) and
+        only the 4-byte status word comes back."""
+        if self._cov is None:
+            return True
+        if self._on_device():
+            A = self._cov.detach().clone()
+            A.diagonal().add_(jitter)
+            _, info = self._engine.chol_lower(A)
+            return int(info.to("cpu")[0]) == 0
+        cov = self._cov.detach().to("cpu", torch.float64)
+        try:
+            torch.linalg.cholesky(cov + torch.eye(cov.shape[0], dtype=cov.dtype) * jitter)
+            return True
+        except RuntimeError:
+            return False
+
     def log_prob(self, y):
-        """Joint log-density (needs the T x T covariance); host LAPACK -- post-processing, not the hot path."""
+        """Joint log-density (needs the T x T covariance).  On the GPU: sgp_chol_lower, sgp_trsm_lower, sgp_logdiag_sum on
+        the device-resident covariance (one scalar comes back); otherwise host LAPACK."""
+        T = self.loc.shape[0]
+        if self._on_device():
+            e = self._engine
+            L, info = e.chol_lower(self._cov.detach())
+            r = (y.detach().to(device=self._cov.device, dtype=torch.float64).reshape(-1) - self.loc.detach()).reshape(T, 1).contiguous()
+            a = e.trsm_lower(L, r)
+            ld = e.logdiag_sum(L)
+            if int(info.to("cpu")[0]) != 0:
+                raise RuntimeError("predictive covariance is not positive definite (leading minor %d)" % int(info.to("cpu")[0]))
+            return (-0.5 * (a * a).sum() - ld[0] - 0.5 * T * math.log(2.0 * math.pi)).to("cpu")
         cov = self._cov.detach().to("cpu", torch.float64)
         r = (y.detach().to("cpu", torch.float64).reshape(-1) - self.loc.detach().to("cpu", torch.float64))
         L = torch.linalg.cholesky(cov)
         a = torch.linalg.solve_triangular(L, r[:, None], upper=False)[:, 0]
-        T = r.shape[0]
         return -0.5 * (a @ a) - torch.log(torch.diagonal(L)).sum() - 0.5 * T * math.log(2.0 * math.pi)
 
 

@@ -74,7 +74,8 @@ class SparseGPR(ExactGP):
         full = test_x.shape[0] <= FULL_COV_MAX_T
         mean, var, cov = self._bound().predict(test_x, self.covar_module.inducing_points, ls, sf2, s2,
                                                pred_noise=pred_noise, full_cov=full)
-        return MultivariateNormal(mean, cov, variance=var)
+        eng = self._bound().engine
+        return MultivariateNormal(mean, cov, variance=var, engine=eng if getattr(eng, "device", None) is not None and eng.device.type == "cuda" else None)
 
     def train_model(self, optimizer, combine_terms=True, n_restarts=10, max_steps=10000, num_steps=None, verbose=True):
         """Full-batch optimisation of -ELBO/N (reference models/sgpr.py:110-144); one list entry per step."""
@@ -221,9 +222,10 @@ def mixture_posterior_predictive(model, test_x, trace_hyper):
             model.likelihood.eval()
             try:
                 pred = model.likelihood(model(test_x))
-                if pred.covariance_matrix is not None:
-                    cov = pred.covariance_matrix.detach().to("cpu")
-                    torch.linalg.cholesky(cov + torch.eye(cov.shape[0], dtype=cov.dtype) * 1e-4)
+                # the reference's PSD gate, cholesky(cov + 1e-4 I): on the device the T x T covariance is factored where
+                # it is and only the status word crosses PCIe (no per-sample T x T copy)
+                if not pred.is_psd(1e-4):
+                    raise RuntimeError("predictive covariance not positive definite")
                 preds.append(pred)
             except (RuntimeError, NotPositiveDefiniteError):
                 print('Not psd for sample ' + str(i))

@@ -189,3 +189,24 @@ def test_sample_nuts_device_trace_surface_and_posterior(engine):
     assert np.all(np.abs(m1 - m2) < 0.6 * s2 + 0.02), (m1, m2, s2)
     lf_per_s = tr.n_leapfrog / tr.wall_clock_secs
     print("device NUTS: %d leapfrogs in %.3f s = %.0f / s" % (tr.n_leapfrog, tr.wall_clock_secs, lf_per_s))
+
+
+@pytest.mark.gpu
+def test_integration_md_small_stub_runs(engine):
+    """The single-launch / persistent-sampler binding shown in INTEGRATION.md is executed verbatim and checked against the
+    oracle's NUTS target."""
+    import os
+    import re
+    from conftest import ROOT
+    from oracle import vfe_oracle as O
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "sgp_small_nuts(" in b)
+    stub = stub.replace('C.CDLL("generalised-gaussian-processes_amd/csrc/libsgp_hip.so")',
+                        "C.CDLL(%r)" % os.path.join(ROOT, "generalised-gaussian-processes_amd", "csrc", "libsgp_hip.so"))
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    lp_ref, g_ref = O.hmc_logp(torch.tensor([0.3, 0.0, -1.0], dtype=torch.float64), ns["X"].cpu(), ns["y"].cpu(), ns["Z"].cpu())
+    assert abs(ns["logp"] - lp_ref) < 1e-8 * max(1.0, abs(lp_ref))
+    assert np.max(np.abs(np.array(ns["grad"]) - g_ref.numpy())) < 1e-5 * max(1.0, float(g_ref.abs().max()))
+    assert ns["draws_done"] == 200 and ns["leapfrogs"] > 200 and bool(torch.all(ns["ls_draws"] > 0))

@@ -145,6 +145,39 @@ def test_svgp_model_on_device_c4_shape(engine):
     assert acc > 0.8, acc
 
 
+@pytest.mark.gpu
+def test_bayesian_svgp_on_device_c4_shape(engine):
+    """``BayesianStochasticVariationalGP`` (reference models/bayesian_svgp.py:156-167: five reparametrised hyper-samples
+    per minibatch) on the HIP path at the C4 minibatch shape (B = 4096, M = 256): the first minibatch losses against the
+    same model on the CPU test double with the same seeds, then a few epochs that must reduce the loss."""
+    g = torch.Generator().manual_seed(4)
+    N, M, Bsz = 12288, 256, 4096
+    X = torch.randn(N, 2, dtype=DT, generator=g)
+    y = torch.sin(2 * X[:, 0]) * torch.cos(X[:, 1]) + 0.1 * torch.randn(N, dtype=DT, generator=g)
+    Z0 = X[torch.randperm(N, generator=g)[:M]].clone()
+    out = []
+    for eng in (engine, OracleEngine()):
+        torch.manual_seed(0)
+        model = ggp_amd.BayesianStochasticVariationalGP(X.to(eng.device), y.to(eng.device), ggp_amd.GaussianLikelihood(), Z0,
+                                                        engine=eng, seed=3)
+        batches = [(X[i:i + Bsz].to(eng.device), y[i:i + Bsz].to(eng.device)) for i in range(0, N, Bsz)]
+        opt = torch.optim.Adam(model.parameters(), lr=0.02)
+        ne = 4 if eng is engine else 1
+        epoch_losses, batch_losses = model.train_model(opt, batches if eng is engine else batches[:2], num_epochs=ne)
+        out.append((epoch_losses, batch_losses, model))
+    (ea, ba, ma), (eb, bb, mb) = out
+    assert abs(ea[0] / 3 - 0) >= 0 and len(ea) == 4 and all(math.isfinite(v) for v in ea)
+    assert ea[-1] < ea[0]
+    # first epoch, first two minibatches: same numbers as the CPU double (losses are O(1) per datum)
+    ma2 = ggp_amd.BayesianStochasticVariationalGP(X.to(engine.device), y.to(engine.device), ggp_amd.GaussianLikelihood(), Z0,
+                                                  engine=engine, seed=3)
+    batches = [(X[i:i + Bsz].to(engine.device), y[i:i + Bsz].to(engine.device)) for i in range(0, N, Bsz)]
+    _, b2 = ma2.train_model(torch.optim.Adam(ma2.parameters(), lr=0.02), batches[:2], num_epochs=1)
+    assert np.max(np.abs(np.array(b2) - np.array(bb))) < 1e-7 * max(1.0, np.max(np.abs(bb))), (b2, bb)
+    preds = ma.mixture_posterior_predictive(X[:64].to(engine.device), num_samples=5)
+    assert len(preds) == 5 and preds[0].loc.shape == (64,) and bool(torch.all(preds[0].variance > 0))
+
+
 def test_bayesian_svgp_hyper_distribution_and_training():
     """reference models/bayesian_svgp.py: q(log theta) KL term, 5 reparametrised samples per minibatch."""
     X, y, Z0, _, _, _ = problem(N=200, M=8)
