@@ -39,6 +39,8 @@ PROTOTYPES = {
     "sgp_timing_enable": (None, [_i32]),
     "sgp_timing_last_ms": (_i32, [_i32, C.POINTER(C.c_float)]),
     "sgp_suffstats_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_suffstats_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
+    "sgp_suffstats_bwd_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_kfu_len": (_sz, [_i64, _i32]),
     "sgp_set_kfu_budget_bytes": (None, [_sz]),
     "sgp_suffstats_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,

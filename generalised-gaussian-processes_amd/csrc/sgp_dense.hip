@@ -300,15 +300,30 @@ const int* potrf_abort_flag(const int* scratch, int Mp) {
   return scratch + (size_t)(nb * (nb + 1) / 2) * DF_FLAG_STRIDE;
 }
 
+// Workgroups of the dataflow launch: one per CU at most (112 KB of LDS each), so that every workgroup of the launch is
+// resident and the smallest unfinished item always has an owner that can run (forward progress, see sgp_potrf.hpp).  The CU
+// count is the device's, not a constant: on a partitioned (CPX / DPX) device a launch of 256 could not be co-resident.
+static int df_max_workgroups() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = DF_MAX_WG;
+    n = cus < DF_MAX_WG ? cus : DF_MAX_WG;
+  }
+  return n;
+}
+
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
                  const double* rhs, double* sol, bool caller_managed) {
   const int nb = Mp / DB;
   const int ntile = nb * (nb + 1) / 2;
   const int nitem = ntile + (rhs ? 1 : 0);
+  const int max_wg = df_max_workgroups();
   if (!caller_managed) zero_ints(scratch, (int)potrf_flag_ints(Mp), st);
   if (Linv) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
-  potrf_dataflow_kernel<<<nitem < DF_MAX_WG ? nitem : DF_MAX_WG, 256, 0, st>>>(
+  potrf_dataflow_kernel<<<nitem < max_wg ? nitem : max_wg, 256, 0, st>>>(
       A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv);
   if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
 }

@@ -369,12 +369,16 @@ static void launch_bwd(int kid, int grid, hipStream_t st, const double* Kfu, con
 
 using namespace sgp;
 
-extern "C" size_t sgp_suffstats_bwd_workspace_bytes(int64_t N, int M, int d) {
+static size_t bwd_workspace_bytes(int64_t N, int M, int d, bool library_kfu) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);
-  const size_t fast = carve_bwd(nullptr, p, true).bytes;
+  const size_t fast = carve_bwd(nullptr, p, library_kfu).bytes;
   const size_t comp = d <= COMP_MAX_DIM ? comp_bwd_workspace_bytes(N, M, d) : 0;  // one size for every kernel_id
   return fast > comp ? fast : comp;
+}
+extern "C" size_t sgp_suffstats_bwd_workspace_bytes(int64_t N, int M, int d) { return bwd_workspace_bytes(N, M, d, true); }
+extern "C" size_t sgp_suffstats_bwd_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns_kfu) {
+  return bwd_workspace_bytes(N, M, d, caller_owns_kfu == 0);
 }
 
 extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,

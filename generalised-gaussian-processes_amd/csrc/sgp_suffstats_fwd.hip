@@ -515,11 +515,15 @@ extern "C" size_t sgp_kfu_len(int64_t N, int M) {
   return (size_t)round_up64(N > 0 ? N : 1, ASM_ROWS) * padded_m(M);
 }
 
-extern "C" size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d) {
+static size_t fwd_workspace_bytes(int64_t N, int M, int d, bool library_kfu) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);
-  const size_t fast = carve_fwd(nullptr, p, true).bytes, comp = comp_fwd_workspace_bytes(N, M);  // one size for every kernel_id
+  const size_t fast = carve_fwd(nullptr, p, library_kfu).bytes, comp = comp_fwd_workspace_bytes(N, M);  // one size for every kernel_id
   return fast > comp ? fast : comp;
+}
+extern "C" size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d) { return fwd_workspace_bytes(N, M, d, true); }
+extern "C" size_t sgp_suffstats_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns_kfu) {
+  return fwd_workspace_bytes(N, M, d, caller_owns_kfu == 0);
 }
 
 extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,

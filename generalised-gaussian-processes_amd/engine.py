@@ -101,10 +101,11 @@ class HipEngine:
             self._chk(X, "X"), self._chk(y, "y")
         if out is None:
             out = self.empty(M * M + M + 2)
-        nbytes = self.lib.sgp_suffstats_workspace_bytes(N, M, d)
+        # with a caller-owned K'_fu the library's own super-chunk (up to 16 GiB) is not part of the workspace
+        nbytes = self.lib.sgp_suffstats_workspace_bytes_ex(N, M, d, 1 if kfu is not None else 0)
         if nbytes == 0:
             raise ValueError("unsupported shape N=%d M=%d d=%d (d <= %d, M <= %d)" % (N, M, d, _lib.SGP_MAX_DIM, _lib.SGP_MAX_INDUCING))
-        ws = self._workspace("fwd", nbytes)
+        ws = self._workspace("fwd_kfu" if kfu is not None else "fwd", nbytes)
         base = out.data_ptr()
         st = self.lib.sgp_suffstats_fwd(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
@@ -354,8 +355,8 @@ class HipEngine:
         nh = self.hyper_len(kernel, d)
         if out is None:
             out = self.empty(nh + 1 + (M * d if want_gz else 0))
-        nbytes = self.lib.sgp_suffstats_bwd_workspace_bytes(N, M, d)
-        ws = self._workspace("bwd", nbytes)
+        nbytes = self.lib.sgp_suffstats_bwd_workspace_bytes_ex(N, M, d, 1 if kfu is not None else 0)
+        ws = self._workspace("bwd_kfu" if kfu is not None else "bwd", nbytes)
         base = out.data_ptr()
         st = self.lib.sgp_suffstats_bwd(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(Phibar),

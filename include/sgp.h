@@ -26,7 +26,10 @@
  *     0 = ok, k>0 = leading minor of order k is not positive definite (1..M refer to Kuu,
  *     M+1..2M to B = I + L^-1 Phi L^-T / s2).  No exceptions cross the boundary.  SGP_INFO_TIMEOUT (< 0)
  *     means the single-launch Cholesky gave up waiting for a tile (seconds of spinning: never expected;
- *     reported instead of hanging the device) -- treat the outputs as invalid.
+ *     reported instead of hanging the device) -- treat the outputs as invalid.  The single-launch kernels (the dataflow
+ *     Cholesky, sgp_small_eval, sgp_small_nuts) synchronise workgroups through device memory: they launch at most one
+ *     workgroup per CU of the device and assume that all of them become resident (they do once kernels that hold CUs
+ *     retire; forward progress never depends on a workgroup that is not yet resident being scheduled FIRST).
  *   - kernel_id selects k(x,z): SGP_KERNEL_RBF     sf2 * exp(-r2/2)
  *                               SGP_KERNEL_MATERN32 sf2 * (1+sqrt3 r) exp(-sqrt3 r)
  *                               SGP_KERNEL_MATERN52 sf2 * (1+sqrt5 r+5r2/3) exp(-sqrt5 r)
@@ -108,6 +111,9 @@ int sgp_timing_last_ms(int slot, float* ms);
  * fp64 matrix cores reading it back).  On several GPUs every rank calls this on its own rows and the
  * caller all-reduces [Phi | b | yy | kappa].  N == 0 is allowed (all outputs zero).             */
 size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d);
+/* the same query for a caller that passes its own Kfu_out (caller_owns_kfu != 0): without the library's K'_fu super-chunk
+ * (up to 16 GiB) the workspace is a few MB + the split slabs */
+size_t sgp_suffstats_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns_kfu);
 /* doubles in the materialised K'_fu block of an N-row shard: roundup(N,256) x roundup(M,128), row-major.
  * K'_fu[n][m] = k(x_n, z_m) / sf2 (zero in the padding) -- the reference's K_fu (N x M) without the
  * output scale.  Optional: a caller that passes such a buffer as Kfu_out keeps the assembled block and
@@ -241,6 +247,7 @@ int sgp_small_nuts(const double* X, int64_t ldx, const double* y, const double* 
  * Writes (overwrites) g_ls[d] = dF/d lengthscale_j, g_sf2[1] = dF/d sf2 (including the kappa term
  * kappabar * N), g_Z[M*d] (ld d; skipped when g_Z == NULL).  Local shard only; caller all-reduces.  */
 size_t sgp_suffstats_bwd_workspace_bytes(int64_t N, int M, int d);
+size_t sgp_suffstats_bwd_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns_kfu); /* with Kfu_in from pass 1 */
 int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y,
                       const double* Z, int64_t ldz, const double* inv_ls, double sf2,
                       const double* Phibar, const double* bbar, double kappabar,

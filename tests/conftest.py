@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _few_host_threads():
+    """The CPU double / oracle work on matrices of a few hundred rows: with the 256 host threads of a GPU box every small
+    torch op costs milliseconds of thread hand-over (a 9-step schedule test took 370 s instead of 5).  Eight threads for
+    everything; the one full-size oracle evaluation raises the count itself."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    yield
+    torch.set_num_threads(n)
+
+
 def golden_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 

@@ -699,3 +699,18 @@ def test_mixture_predictive_stays_on_the_device(engine, monkeypatch):
         mu, cov = O.predict(Xt, X, y, Z0, torch.as_tensor(r["ls"]), r["sig_f"] ** 2, r["sig_n"] ** 2, 1e-6, full_cov=True)
         ref.append(O.nlpd_joint(mu, cov, yt, 1.0))
     assert abs(val - float(np.mean(ref))) < 1e-7 * max(1.0, abs(float(np.mean(ref)))), (val, float(np.mean(ref)))
+
+
+def test_kernel_exp_accuracy(engine):
+    """The hand-rolled exp() of the kernel profiles (csrc/sgp_common.hpp: sgp_exp) against libm over its whole range: the first
+    row of a 1-D RBF Kuu with unit lengthscale is exp(-z_i^2 / 2).  <= 2.5e-16 relative (1-2 ulp), exact 1 at 0, clean underflow."""
+    t = np.concatenate([np.linspace(0.0, 40.0, 2000), np.linspace(40.0, 744.0, 2000), [745.2, 760.0, 1.0e4]])
+    z = np.concatenate([[0.0], np.sqrt(2.0 * t)])
+    M = z.size
+    K = engine.kuu(dev(z[:, None], engine), [1.0], 1.0, 0.0, "rbf").cpu().numpy()
+    ref = np.exp(-0.5 * (z * z))
+    got = K[0]
+    assert got[0] == 1.0 and got[1] == 1.0
+    big = ref > 1e-300
+    assert np.max(np.abs(got[big] - ref[big]) / ref[big]) < 2.5e-16, np.max(np.abs(got[big] - ref[big]) / ref[big])
+    assert np.all(np.abs(got[~big] - ref[~big]) <= 1e-300) and np.all(np.isfinite(got)) and np.all(got >= 0.0)
