@@ -49,6 +49,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd += os.environ.get("SGP_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds (tools/ab_build.sh); empty for the product
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

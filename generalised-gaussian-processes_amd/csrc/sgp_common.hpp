@@ -37,6 +37,9 @@ struct KernArgs {
 // 1.4), and in the epilogue of pass 2 every VALU instruction is taken from the MFMA datapath.  <= 1.5 ulp against the
 // library exp over [-745, 0] (tests/test_gpu_parity.py::test_kernel_exp_accuracy).
 __device__ __forceinline__ double sgp_exp(double x) {
+#if defined(SGP_AB_LIBRARY_EXP)  // A/B knob of tools/ab_build.sh only: the device library's routine
+  return exp(x);
+#endif
   x = fmax(x, -800.0);
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
