@@ -32,10 +32,11 @@ struct KernArgs {
 
 // exp(x) for the kernel profiles (x <= 0 there; correct for any finite x, saturating to 0 below -745): range reduction
 // x = k ln2 + r with the two-part ln2 of fdlibm, Taylor polynomial of degree 13 on |r| <= ln2 / 2 (remainder 4e-18
-// relative), v_ldexp_f64.  19 fp64 VALU instructions against ~28 for the library routine: kernel assembly is
-// VALU-bound (50 -> 41 instructions per element at d = 8; the 8.2 GB it writes would take 1.0-1.3 ms, the arithmetic took
-// 1.4), and in the epilogue of pass 2 every VALU instruction is taken from the MFMA datapath.  <= 1.5 ulp against the
-// library exp over [-745, 0] (tests/test_gpu_parity.py::test_kernel_exp_accuracy).
+// relative), v_ldexp_f64.  19 fp64 VALU instructions against ~28 for the library routine; <= 2 ulp against libm over
+// [-745, 0] (tests/test_gpu_parity.py::test_kernel_exp_accuracy).  Same-box A/B (tools/ab_build.sh, three alternations):
+// kernel assembly 1.62 vs 1.66 ms -- it sits at the HBM write ceiling (5.05 TB/s), not at the VALU -- so this routine is
+// used where values are generated (kprofile); in the epilogue of pass 2 its 13-deep dependent FMA chain is SLOWER than the
+// library's shorter chains (34.8 vs 33.5 ms for the launch), so kprofile_grad keeps exp().
 __device__ __forceinline__ double sgp_exp(double x) {
 #if defined(SGP_AB_LIBRARY_EXP)  // A/B knob of tools/ab_build.sh only: the device library's routine
   return exp(x);
@@ -79,16 +80,16 @@ __device__ __forceinline__ double kprofile(double r2) {
 template <int KID>
 __device__ __forceinline__ void kprofile_grad(double r2, double& k, double& h) {
   if constexpr (KID == SGP_KERNEL_RBF) {
-    k = sgp_exp(-0.5 * r2);
+    k = exp(-0.5 * r2);
     h = -0.5 * k;
   } else if constexpr (KID == SGP_KERNEL_MATERN32) {
     const double a = 1.7320508075688772 * sqrt(r2);
-    const double e = sgp_exp(-a);
+    const double e = exp(-a);
     k = (1.0 + a) * e;
     h = -1.5 * e;
   } else {
     const double a = 2.23606797749979 * sqrt(r2);
-    const double e = sgp_exp(-a);
+    const double e = exp(-a);
     k = (1.0 + a + a * a * (1.0 / 3.0)) * e;
     h = -(5.0 / 6.0) * (1.0 + a) * e;
   }
