@@ -44,7 +44,10 @@ def pmc_traffic(kernel_substr):
     """HBM bytes per launch of a kernel at the default config (N = 1M, M = 1024, 1 GPU) from the newest
     profiles/*_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
     MI355X_MICROARCH.md prescribes: tools/summarise_pmc.py).  Returns (bytes, file) or (None, None)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")), key=os.path.getmtime)
+    import re
+    # newest = highest (round, version) in the file name r<round>_v<version>_...: a checkout gives every file the same mtime
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])
     for f in reversed(files):
         tot, seen = 0.0, set()
         with open(f, newline="") as fh:
