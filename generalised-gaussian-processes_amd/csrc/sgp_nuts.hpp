@@ -92,6 +92,7 @@ struct NutsState {
   double top_prop_logp, top_prop_energy, top_log_size, top_accept_sum;
   int top_n, depth, direction, diverging, nleaf, nleaf_target, sp;
   NutsTree stack[NUTS_MAXDEPTH];
+  double tmp[3][NUTS_MAXD];  // work vectors of nuts_merge (kept in the state: on the GPU the state lives in LDS, locals in scratch)
 };
 
 SGP_HD inline double nuts_logaddexp(double a, double b) {
@@ -166,7 +167,7 @@ SGP_HD inline bool nuts_uturn(const NutsState& s, const double* p_sum, const dou
 // combine the finished sub-trees a (built first) and b into a (hmc.py: the second half of NUTS._build)
 SGP_HD inline void nuts_merge(NutsState& s, NutsTree& a, const NutsTree& b) {
   const int n = s.ndim, dir = s.direction;
-  double psum[NUTS_MAXD];
+  double* psum = s.tmp[0];
   for (int i = 0; i < n; ++i) psum[i] = a.p_sum[i] + b.p_sum[i];
   const double log_size = nuts_logaddexp(a.log_size, b.log_size);
   const bool bad = b.diverging || b.turning;
@@ -177,7 +178,8 @@ SGP_HD inline void nuts_merge(NutsState& s, NutsTree& a, const NutsTree& b) {
     // first / second = the earlier / later half in trajectory order (left to right)
     const NutsTree& first = dir > 0 ? a : b;
     const NutsTree& second = dir > 0 ? b : a;
-    double t1[NUTS_MAXD], t2[NUTS_MAXD];
+    double* t1 = s.tmp[1];
+    double* t2 = s.tmp[2];
     for (int i = 0; i < n; ++i) {
       t1[i] = first.p_sum[i] + second.lp[i];
       t2[i] = first.rp[i] + second.p_sum[i];

@@ -35,7 +35,7 @@ constexpr int SM_MAXD = 16;
 constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
-enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_WORDS = 10 };
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_WORDS = 11 };
 constexpr int SM_GP = SM_MAXD + 4;  // doubles per gradient partial: g_ls[d] at 0.., then g_sf2, tr B^-1
 
 struct SmallArgs {
@@ -482,19 +482,36 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       }
       int bad_first = 0;
       double ld = 0.0;
+      double xn[16], yv[16];  // tile (1, 1) rows / tile (1, 0) in the solve layout, fetched ahead of the factorization of (0, 0)
+      auto fetch_lower_tiles = [&]() {
+        const double* s11 = Lg + (size_t)(64 + r) * MP + 64 + 16 * g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const d2 v = *reinterpret_cast<const d2*>(s11 + 2 * k);
+          xn[2 * k] = v[0];
+          xn[2 * k + 1] = v[1];
+        }
+        const double* s10 = Lg + (size_t)(64 + 16 * g + l15) * MP + l4;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) yv[k] = s10[16 * (k >> 2) + 4 * (k & 3)];
+      };
 #pragma unroll 1
       for (int jd = 0; jd < NB64; ++jd) {
         double x[16];
-        if (pass == 0) {
-          kuu16(64 * jd + r, 64 * jd + 16 * g, 1, x);
+        if (jd > 0) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) x[k] = xn[k];
+        } else if (pass == 0) {
+          kuu16(r, 16 * g, 1, x);  // tile (0, 0) of Kuu evaluated straight into the factorization's registers
         } else {
-          const double* src = a.Lb + (size_t)(64 * jd + r) * MP + 64 * jd + 16 * g;
+          const double* src = a.Lb + (size_t)r * MP + 16 * g;
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const d2 v = *reinterpret_cast<const d2*>(src + 2 * k);
             x[2 * k] = v[0];
             x[2 * k + 1] = v[1];
           }
+          if (NB64 > 1) fetch_lower_tiles();  // B is complete: the loads land while tile (0, 0) is factored
         }
         if (jd > 0) {  // minus X X^T (X = tile (jd, jd - 1), still in df.Ts)
           d4 acc[2][2];
@@ -541,16 +558,16 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
           d4 yb[4];
           const int trow = 64 * (jd + 1) + 16 * g + l15;
           if (pass == 0) {
-            double v[16];  // columns 64 jd + l4 + 4 k  <->  (pb, sq) = (k >> 2, k & 3)
-            kuu16(trow, 64 * jd + l4, 4, v);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) yb[k >> 2][k & 3] = v[k];
-          } else {
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-              for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = a.Lb[(size_t)trow * MP + 64 * jd + 16 * pb + 4 * sq + l4];
+            // tiles (1, 0) and (1, 1) of Kuu were evaluated by the first Kbar_uu workgroup (idle until LB exists) while
+            // this workgroup factored tile (0, 0)
+            if (!sm_wait_ge(sy + SY_KUU * SM_SYNC_STRIDE, ev, abortw, &dead)) {
+              if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
+              return;
+            }
+            fetch_lower_tiles();
           }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) yb[k >> 2][k & 3] = yv[k];
           d4 xb[4];
 #pragma unroll
           for (int pb = 0; pb < 4; ++pb) {
@@ -919,14 +936,20 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         double s = 0.0;
         const double* pp = a.Ppart + (size_t)gi * MP + gj;
         int g = 0;
-        for (; g + 8 <= a.grow; g += 8) {  // eight loads in flight; the additions keep the fixed order
-          double t[8];
+        for (; g + 16 <= a.grow; g += 16) {  // sixteen loads in flight; the additions keep the fixed order
+          double t[16];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) t[k] = pp[(size_t)(g + k) * MP * MP];
+          for (int k = 0; k < 16; ++k) t[k] = pp[(size_t)(g + k) * MP * MP];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) s += t[k];
+          for (int k = 0; k < 16; ++k) s += t[k];
         }
-        for (; g < a.grow; ++g) s += pp[(size_t)g * MP * MP];
+        {
+          double t[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) t[k] = g + k < a.grow ? pp[(size_t)(g + k) * MP * MP] : 0.0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) s += t[k];
+        }
         const double v = (gi == gj ? 1.0 : 0.0) + s * is2;
         a.Bm[(size_t)gi * MP + gj] = v;
         a.Bm[(size_t)gj * MP + gi] = v;
@@ -1026,6 +1049,34 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
 
   // =================================================================================================================
   // role 1: Kbar_uu = -1/2 L^-T S L^-1, S = B + B^-1 - 2 I + g g^T / s2^2 ; its contraction with dK_uu ; tr B^-1
+  if (NB64 > 1 && wg == 1) {
+    // first, while the chain workgroup factors tile (0, 0): rows 64.. of the padded Kuu (tiles (1, 0) and (1, 1)) -> a.Lk
+    for (int e0 = tid; e0 < 64 * 8; e0 += 256) {  // (row, group of 16 columns)
+      const int i = 64 + (e0 >> 3), j0 = 16 * (e0 & 7);
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = 0.0;
+      for (int q = 0; q < d; ++q) {
+        const double zi = sl.zs[i][q];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const double dz = zi - sl.zs[j0 + k][q];
+          v[k] = fma(dz, dz, v[k]);
+        }
+      }
+      sm_profile_vec<16>(a.kid, v, sf2);
+      double* dst = a.Lk + (size_t)i * MP + j0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int j = j0 + k;
+        double val = v[k];
+        if (i >= M || j >= M) val = i == j ? 1.0 : 0.0;
+        else if (i == j) val += a.jitter;
+        dst[k] = val;
+      }
+    }
+    sm_publish_set(sy + SY_KUU * SM_SYNC_STRIDE, ev);
+  }
   if (!a.want_grad) return;
   if (!sm_wait_ge(sy + SY_LB * SM_SYNC_STRIDE, ev, abortw, &dead)) return;
   stamp(1);
@@ -1130,6 +1181,14 @@ __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   sm_eval_body<MP>(a, ks, 1, false);
 }
 
+// The evaluation as an out-of-line call for the persistent kernel: inlined into its request loop the compiler kept the
+// loop's state live across the whole evaluation (455 spilled VGPRs at MP = 128 against 13 in the single-evaluation kernel,
+// +45 us per leapfrog).
+template <int MP>
+__device__ __attribute__((noinline)) void sm_eval_call(const SmallArgs* a, SmKernelShared<MP>* ks, int ev) {
+  sm_eval_body<MP>(*a, *ks, ev, true);
+}
+
 // ---- device-resident NUTS ------------------------------------------------------------------------------------------
 // One PERSISTENT launch runs the whole of pm.sample(n, tune=tune, chains=1) (models/bayesian_sgpr_hmc.py:73-78): thread 0
 // of workgroup 0 advances the sampler's state machine (sgp_nuts.hpp, state in LDS), writes the next position into
@@ -1206,7 +1265,7 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
       continue;
     }
     ++ev;
-    sm_eval_body<MP>(a, ks, ev, true);
+    sm_eval_call<MP>(&a, &ks, ev);
     if (ks.dead || sm_ld(abortw) != 0) {
       if (wg == 0 && tid == 0) *a.info = SGP_INFO_TIMEOUT;
       break;

@@ -11,8 +11,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ggp_amd  # noqa: E402
 
-CHAIN = ["start", "Kuu assembled", "chol(Kuu) published", "B complete (waited)", "B copied", "chol(B) done", "g solved", "F, LB published",
-         "gradient partials in (waited)", "done"]
+CHAIN = ["start", "Kuu evaluated + factored", "L published", "B complete (waited)", "chol(B) done", "LB published", "c0, g, h solved",
+         "g, h published", "gradient partials in (waited)", "done"]
 ROW = ["start", "z staged", "L seen", "forward slabs done", "all partials in", "slices done", "LB seen", "reverse slabs done"]
 KUU = ["start", "LB seen", "Q columns done", "R + contraction done"]
 
