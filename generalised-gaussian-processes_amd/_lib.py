@@ -72,6 +72,8 @@ PROTOTYPES = {
     "sgp_small_sync_bytes": (_sz, []),
     "sgp_small_eval": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _vp, _vp, _vp,
                               _vp, _sz, _vp]),
+    "sgp_small_eval_batch": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _vp,
+                                    _vp, _sz, _vp]),
     "sgp_small_nuts_stat_cols": (_sz, []),
     "sgp_small_nuts": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _i32, _dbl, _dbl,
                               C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1203,6 +1203,12 @@ struct NutsArgs {
   int n_tune, n_draws, max_treedepth;
   double step_scale, target_accept;
   unsigned long long seed;
+  // batch mode (S > 0): no sampler -- evaluate S given hyper-parameter sets one after the other in the same launch
+  int S;
+  const double* batch_theta;  // S x (d + 2)
+  double* batch_out;          // S x (d + 5)
+  double* batch_gz;           // S x M x d, or null
+  int* batch_info;            // S
 };
 constexpr int SM_NUTS_COLS = NST_COLS + 1;  // + seconds per draw (device clock)
 
@@ -1218,31 +1224,45 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
   int ev = 0, req = 0;
   double lp = 0.0;
   unsigned long long t_draw = 0;
-  if (wg == 0 && tid == 0) {
+  const bool batch = na.S > 0;
+  if (wg == 0 && tid == 0 && !batch) {
     nuts_init(st, ndim, na.n_tune, na.n_draws, na.max_treedepth, na.step_scale, na.target_accept, na.seed, na.q0);
     t_draw = __builtin_amdgcn_s_memrealtime();
   }
   __syncthreads();
+  SmallArgs al = a;  // batch mode: the outputs of evaluation s go to slot s
   for (;;) {
     ++req;
+    if (batch) {
+      const int sidx = req - 1 < na.S ? req - 1 : na.S - 1;
+      al.out = na.batch_out + (size_t)sidx * (a.d + 5);
+      al.gZ = na.batch_gz ? na.batch_gz + (size_t)sidx * a.M * a.d : nullptr;
+      al.info = na.batch_info + sidx;
+    }
     if (wg == 0) {
       if (tid == 0) {
-        const double* qn = nullptr;
-        const int it0 = st.it;
-        const int c = nuts_step(st, lp, a.out + 1, &qn, na.samples, na.stats /* NST_COLS columns, re-packed at the end */);
-        if (st.it != it0) {  // a draw has finished: its device time
-          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-          const int row = it0 - na.n_tune;
-          if (row >= 0) na.stats[(size_t)na.n_draws * NST_COLS + row] = (double)(now - t_draw) * 1e-8;
-          t_draw = now;
+        if (batch) {
+          cmd = req <= na.S ? NUTS_EVAL : NUTS_DONE;
+          if (req <= na.S)
+            for (int i = 0; i < ndim; ++i) na.theta_w[i] = na.batch_theta[(size_t)(req - 1) * ndim + i];
+        } else {
+          const double* qn = nullptr;
+          const int it0 = st.it;
+          const int c = nuts_step(st, lp, a.out + 1, &qn, na.samples, na.stats /* NST_COLS columns, re-packed at the end */);
+          if (st.it != it0) {  // a draw has finished: its device time
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            const int row = it0 - na.n_tune;
+            if (row >= 0) na.stats[(size_t)na.n_draws * NST_COLS + row] = (double)(now - t_draw) * 1e-8;
+            t_draw = now;
+          }
+          if (c == NUTS_EVAL)
+            for (int i = 0; i < ndim; ++i) na.theta_w[i] = qn[i];
+          cmd = c;
         }
-        if (c == NUTS_EVAL)
-          for (int i = 0; i < ndim; ++i) na.theta_w[i] = qn[i];
-        cmd = c;
       }
       __syncthreads();
       if (cmd != NUTS_EVAL) {
-        if (tid == 0) {
+        if (tid == 0 && !batch) {
           na.counters[0] = st.n_leapfrog;
           na.counters[1] = st.it;
         }
@@ -1256,23 +1276,24 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
       if (!sm_wait_ge(sy + SY_REQ * SM_SYNC_STRIDE, req, abortw, &ks.dead)) break;
       if (sm_ld(sy + SY_DONE * SM_SYNC_STRIDE) != 0) break;
     }
-    sm_hypers(a, ks.hyp);  // every workgroup from the same theta: the same decision everywhere
+    sm_hypers(al, ks.hyp);  // every workgroup from the same theta: the same decision everywhere
     if (!ks.hyp.ok) {
       if (wg == 0 && tid == 0) {
-        a.out[0] = -INFINITY;
+        al.out[0] = -INFINITY;
+        *al.info = 0;
         lp = -INFINITY;
       }
       continue;
     }
     ++ev;
-    sm_eval_call<MP>(&a, &ks, ev);
+    sm_eval_call<MP>(&al, &ks, ev);
     if (ks.dead || sm_ld(abortw) != 0) {
-      if (wg == 0 && tid == 0) *a.info = SGP_INFO_TIMEOUT;
+      if (wg == 0 && tid == 0) *al.info = SGP_INFO_TIMEOUT;
       break;
     }
     if (wg == 0) {
       __syncthreads();
-      if (tid == 0) lp = (*a.info == 0) ? a.out[0] : -INFINITY;  // a failed factorization is a divergence, not an error
+      if (tid == 0) lp = (*al.info == 0) ? al.out[0] : -INFINITY;  // a failed factorization is a divergence, not an error
     }
   }
   if (wg == 0) {
@@ -1377,10 +1398,40 @@ extern "C" int sgp_small_nuts(const double* X, int64_t ldx, const double* y, con
   a.jitter = jitter;
   a.info = info; a.out = out; a.gZ = nullptr;
   a.stamps = nullptr;
-  NutsArgs na{q0, theta_scratch, samples, stats, counters, n_tune, n_draws, max_treedepth, step_scale, target_accept, seed};
+  NutsArgs na{q0, theta_scratch, samples, stats, counters, n_tune, n_draws, max_treedepth, step_scale, target_accept, seed,
+              0, nullptr, nullptr, nullptr, nullptr};
   const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
   hipStream_t st = (hipStream_t)stream;
   // the request / done words of the previous run (the only sync words a run leaves non-zero)
+  zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
+  if (M <= 64) small_nuts_kernel<64><<<grid, 256, 0, st>>>(a, na);
+  else small_nuts_kernel<128><<<grid, 256, 0, st>>>(a, na);
+  return check_launch();
+}
+
+// S evaluations (S hyper-parameter sets, the same X, y, Z) in ONE launch: the theta-averaged loss of the reference's
+// alternating schedule (models/bayesian_sgpr_hmc.py:121-134: for every sample of the current trace, set the hypers,
+// evaluate the bound, average, back-propagate to Z only).  thetas (S x (d + 2)), outs (S x (d + 5)), g_Z (S x M x d, may be
+// NULL) and infos (S) are device arrays laid out per sample as in sgp_small_eval.
+extern "C" int sgp_small_eval_batch(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                    const double* thetas, int S, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
+                                    int want_grad, double* theta_scratch, double* outs, double* g_Z, int* infos, void* ws,
+                                    size_t ws_bytes, sgp_stream_t stream) {
+  if (!X || !y || !Z || !thetas || !theta_scratch || !outs || !infos || S < 1 || ldx < d || ldz < d || (mode != 0 && mode != 1))
+    return SGP_ERR_ARG;
+  if (!sgp_small_supported(N, M, d, kernel_id)) return SGP_ERR_DIM;
+  SmallWs w = carve_small(ws, N, M, d);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  SmallArgs& a = w.a;
+  a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta_scratch;
+  a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = mode; a.want_grad = want_grad ? 1 : 0;
+  a.want_gz = (want_grad && g_Z) ? 1 : 0;
+  a.jitter = jitter;
+  a.info = infos; a.out = outs; a.gZ = g_Z;
+  a.stamps = nullptr;
+  NutsArgs na{thetas, theta_scratch, nullptr, nullptr, nullptr, 0, 0, 1, 0.25, 0.8, 0, S, thetas, outs, g_Z, infos};
+  const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
+  hipStream_t st = (hipStream_t)stream;
   zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
   if (M <= 64) small_nuts_kernel<64><<<grid, 256, 0, st>>>(a, na);
   else small_nuts_kernel<128><<<grid, 256, 0, st>>>(a, na);

@@ -296,6 +296,34 @@ class HipEngine:
         _lib.check("sgp_small_eval", st)
         return out, gz, info
 
+    def small_eval_batch(self, X, y, Z, thetas: torch.Tensor, jitter, kernel="rbf", mode=0, want_grad=True, want_gz=False):
+        """S evaluations (``thetas``: S x (d + 2) on the device) in one launch.  Returns (outs [S, d + 5], gZ [S, M, d] or None,
+        infos [S] int32), device tensors; nothing is synchronised."""
+        N, d = X.shape
+        M = Z.shape[0]
+        for t, n in ((X, "X"), (y, "y"), (Z, "Z"), (thetas, "thetas")):
+            self._chk(t, n)
+        S = thetas.shape[0]
+        if thetas.shape[1] != d + 2:
+            raise ValueError("thetas must be S x (d + 2)")
+        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
+        ws = self._ws.get("small")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws["small"] = ws
+        outs = self.empty(S, d + 5)
+        gz = self.empty(S, M, d) if (want_grad and want_gz) else None
+        infos = torch.zeros(S, dtype=torch.int32, device=self.device)
+        scratch = self.empty(d + 2)
+        st = self.lib.sgp_small_eval_batch(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(thetas), S, N, M, d,
+                                           _kernel_id(kernel), float(jitter), int(mode), 1 if want_grad else 0, self._ptr(scratch),
+                                           self._ptr(outs), self._ptr(gz), C.c_void_p(infos.data_ptr()), self._ptr(ws), ws.numel(),
+                                           self._stream())
+        _lib.check("sgp_small_eval_batch", st)
+        return outs, gz, infos
+
     def small_nuts(self, X, y, Z, q0, n_tune, n_draws, seed, jitter=1e-6, kernel="rbf", max_treedepth=10, step_scale=0.25,
                    target_accept=0.8):
         """The whole NUTS run in one persistent launch (sgp_small_nuts).  Returns dict(samples [n_draws, d + 2] unconstrained,

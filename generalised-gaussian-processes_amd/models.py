@@ -114,6 +114,35 @@ class SparseGPR(ExactGP):
         return y_star
 
 
+class _ThetaAveragedLossFn(torch.autograd.Function):
+    """mean_s( -F(theta_s, Z) / N ) over the samples of a trace, differentiable in Z only -- the loss of the reference's
+    alternating schedule once the kernel hyper-parameters are frozen (models/bayesian_sgpr_hmc.py:117-134).  All S bounds
+    and their dF/dZ come from ONE launch (sgp_small_eval_batch)."""
+
+    @staticmethod
+    def forward(ctx, Z, model, thetas):
+        cb = model._bound()
+        e = cb.engine
+        Zd = cb._prep_Z(Z)
+        outs, gz, infos = e.small_eval_batch(cb.X, cb.y, Zd, thetas, cb.jitter, cb.kernel, mode=0, want_grad=True, want_gz=True)
+        info = infos.to("cpu")
+        if int(info.min()) < 0:
+            e.small_reset()
+            raise SgpTimeoutError()
+        if int(info.max()) != 0:
+            raise NotPositiveDefiniteError(int(info[info != 0][0]))
+        n = float(cb.N)
+        ctx.gz = -(gz.mean(0)) / n
+        ctx.zshape, ctx.zdev = Z.shape, Z.device
+        cb.n_evals += thetas.shape[0]
+        cb.n_grads += thetas.shape[0]
+        return (-(outs[:, 0].mean()) / n).to(Z.device)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (ctx.gz.to(ctx.zdev) * gout).reshape(ctx.zshape), None, None
+
+
 class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
     """Doubly collapsed SGPR: q(u) implicit, theta sampled with NUTS at scheduled iterations
     (reference models/bayesian_sgpr_hmc.py:26)."""
@@ -125,6 +154,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         self._seed = seed
         self._n_hmc_calls = 0
         self.device_sampler = True  # NUTS on the device when the problem takes the single-launch path (M <= 128)
+        self.batched_theta_loss = True  # ... and the theta-averaged loss of the alternating schedule in one launch
 
     def freeze_kernel_hyperparameters(self):
         for name, parameter in self.named_hyperparameters():
@@ -163,6 +193,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         self.likelihood.train()
         elbo = ExactMarginalLogLikelihood(self.likelihood, self)
         losses, trace_hyper, trace_step_size, trace_perf_time = [], None, [], []
+        thetas_dev = None  # the current trace's hyper-parameters on the device (rebuilt after every NUTS phase)
         for n_iter in range(max_steps):
             optimizer.zero_grad()
             if n_iter < hmc_scheduler[0]:  # warm start: plain SGPR optimisation
@@ -174,11 +205,22 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
             else:
                 self.freeze_kernel_hyperparameters()
                 if trace_hyper is not None:  # stochastic ELBO: average over the current theta samples
-                    loss = 0.0
-                    for i in range(len(trace_hyper)):
-                        self.update_model_to_hyper(elbo, trace_hyper[i])
-                        output = self(self.train_x)
-                        loss = loss + (-elbo(output, self.train_y).sum() / len(trace_hyper))
+                    Zp = self.covar_module.inducing_points
+                    if self.batched_theta_loss and self._bound()._small_ok(Zp.shape[0]):
+                        # all samples in ONE launch; the model is left at the last sample's hypers like the loop below
+                        cb = self._bound()
+                        if thetas_dev is None:
+                            rows = [list(np.asarray(h['ls'], dtype=np.float64).reshape(-1)) + [float(h['sig_f']) ** 2, float(h['sig_n']) ** 2]
+                                    for h in trace_hyper]
+                            thetas_dev = torch.tensor(rows, dtype=torch.float64).to(cb.engine.device)
+                        loss = _ThetaAveragedLossFn.apply(Zp, self, thetas_dev)
+                        self.update_model_to_hyper(elbo, trace_hyper[len(trace_hyper) - 1])
+                    else:
+                        loss = 0.0
+                        for i in range(len(trace_hyper)):
+                            self.update_model_to_hyper(elbo, trace_hyper[i])
+                            output = self(self.train_x)
+                            loss = loss + (-elbo(output, self.train_y).sum() / len(trace_hyper))
                     if verbose:
                         print('Iter %d/%d - Loss: %.3f ' % (n_iter, max_steps, loss.item()))
                     losses.append(loss.item())
@@ -192,6 +234,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
                         num_tune, num_samples = num_tune_short, num_samples_short
                     trace_hyper = self.sample_optimal_variational_hyper_dist(num_samples, self.data_dim, Z_opt, num_tune,
                                                                              sampler_params=None)
+                    thetas_dev = None
                     trace_step_size.append(trace_hyper.get_sampler_stats('step_size')[0])
                     trace_perf_time.append(trace_hyper.get_sampler_stats('perf_counter_diff').sum())
         return losses, trace_hyper, trace_step_size, trace_perf_time

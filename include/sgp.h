@@ -224,6 +224,14 @@ int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* 
                    int want_grad, double* out, double* g_Z, int* info,
                    void* ws, size_t ws_bytes, sgp_stream_t stream);
 
+/* S evaluations in one launch (the same X, y, Z; S hyper-parameter sets): the theta-averaged loss of the reference's
+ * alternating schedule (models/bayesian_sgpr_hmc.py:121-134).  thetas (S x (d + 2)), outs (S x (d + 5)), g_Z (S x M x d or
+ * NULL), infos (S) are device arrays with sgp_small_eval's per-sample layout; theta_scratch: d + 2 doubles.          */
+int sgp_small_eval_batch(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                         const double* thetas, int S, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
+                         int want_grad, double* theta_scratch, double* outs, double* g_Z, int* infos,
+                         void* ws, size_t ws_bytes, sgp_stream_t stream);
+
 /* ---- device-resident NUTS over the same target ------------------------------------------------
  * pm.sample(n_draws, tune=n_tune, chains=1) with pm.NUTS() defaults (models/bayesian_sgpr_hmc.py:73-78) in ONE persistent
  * launch: multinomial NUTS, dual-averaging step size, jitter+adapt_diag mass matrix; the sampler state, theta and the

@@ -210,3 +210,24 @@ def test_integration_md_small_stub_runs(engine):
     assert abs(ns["logp"] - lp_ref) < 1e-8 * max(1.0, abs(lp_ref))
     assert np.max(np.abs(np.array(ns["grad"]) - g_ref.numpy())) < 1e-5 * max(1.0, float(g_ref.abs().max()))
     assert ns["draws_done"] == 200 and ns["leapfrogs"] > 200 and bool(torch.all(ns["ls_draws"] > 0))
+
+
+@pytest.mark.gpu
+def test_small_eval_batch_equals_single_evaluations(engine):
+    """S hyper-parameter sets in one launch (sgp_small_eval_batch, the theta-averaged loss of row a7): every slot equals
+    the stand-alone evaluation of the same theta bit for bit, a non-representable theta gives -inf in its slot only."""
+    G = load_golden("rbf_d3_small")
+    d = 3
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    base = np.concatenate([G["ls"], [float(G["sf2"]), float(G["s2"])]])
+    rows = np.stack([base * (1.0 + 0.1 * k) for k in range(5)])
+    outs, gz, infos = engine.small_eval_batch(X, y, Z, dev(rows, engine), 1e-6, "rbf", mode=0, want_grad=True, want_gz=True)
+    assert infos.cpu().tolist() == [0] * 5
+    for k in range(5):
+        o, g, info = engine.small_eval(X, y, Z, dev(rows[k], engine), 1e-6, "rbf", mode=0, want_grad=True, want_gz=True)
+        assert torch.equal(outs[k], o[:d + 5]) and torch.equal(gz[k], g) and int(info.item()) == 0
+    th = np.stack([G["hmc_theta"][0], [500.0, 0.0, 0.0, 0.0, 0.0], G["hmc_theta"][1]])
+    outs, _, infos = engine.small_eval_batch(X, y, Z, dev(th, engine), 1e-6, "rbf", mode=1, want_grad=True)
+    o = outs.cpu().numpy()
+    assert abs(o[0, 0] - G["hmc_logp"][0]) < 1e-9 * abs(G["hmc_logp"][0]) and abs(o[2, 0] - G["hmc_logp"][1]) < 1e-9 * abs(G["hmc_logp"][1])
+    assert o[1, 0] == -np.inf and infos.cpu().tolist() == [0, 0, 0]
