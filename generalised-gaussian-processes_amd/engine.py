@@ -184,6 +184,8 @@ class HipEngine:
         """The ~50 launches of ``kuu_factor`` captured once per M in a hipGraph over static buffers: replaying it costs
         the host one launch instead of ~1 ms of enqueueing, so the factorization really runs underneath the start of
         pass 1.  Returns dict(graph, Kuu, Linv, info) or None when capture is unavailable (callers fall back)."""
+        if not 0 < M <= _lib.SGP_MAX_INDUCING:
+            raise ValueError("M = %d inducing points is outside 1 .. %d" % (M, _lib.SGP_MAX_INDUCING))
         ent = self._graphs.get(M, False) if hasattr(self, "_graphs") else False
         if ent is not False:
             return ent

@@ -278,6 +278,13 @@ def mixture_posterior_predictive(model, test_x, trace_hyper):
 # ---------------------------------------------------------------------------------------------
 # SVGP
 # ---------------------------------------------------------------------------------------------
+def _raise_on_info(info: int):
+    if info < 0:
+        raise SgpTimeoutError()
+    if info != 0:
+        raise NotPositiveDefiniteError(info)
+
+
 class _SVGPBoundFn(torch.autograd.Function):
     """ELBO per datum of one minibatch; forward and the whole reverse pass run in sgp_svgp_elbo."""
 
@@ -288,11 +295,11 @@ class _SVGPBoundFn(torch.autograd.Function):
         res = eng.svgp_elbo(xb, yb, Z.detach().contiguous(), ls.detach().reshape(-1).tolist(), float(sf2), float(s2),
                             m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
                             kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
-        info = int(res["info"].to("cpu").item())
-        if info < 0:
-            raise SgpTimeoutError()
-        if info != 0:
-            raise NotPositiveDefiniteError(info)
+        pending = getattr(model, "_pending_infos", None)
+        if pending is not None:  # the caller checks the status words of several bounds with ONE host round trip
+            pending.append(res["info"])
+        else:
+            _raise_on_info(int(res["info"].to("cpu").item()))
         ctx.res = res if need else None
         ctx.meta = [(t.shape, t.device) for t in (ls, sf2, s2, Z, m, LS)]
         return res["out"][0].clone()
@@ -468,10 +475,22 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
                 optimizer.zero_grad()
                 loss = 0.0
                 kl = self.log_theta.kl_per_point()
-                for _ in range(self.num_hyper_samples):
-                    lt = self.sample_variational_log_hyper(1).flatten()
-                    e = self._elbo_at(x_batch, y_batch, lt)
-                    loss = loss + (-(e.to("cpu")) + kl) / self.num_hyper_samples
+                # the five bounds are enqueued back to back: no host round trip between them (their status words are read
+                # together, with the loss)
+                self._pending_infos = []
+                es = []
+                try:
+                    for _ in range(self.num_hyper_samples):
+                        lt = self.sample_variational_log_hyper(1).flatten()
+                        es.append(self._elbo_at(x_batch, y_batch, lt))
+                    infos = torch.cat(self._pending_infos).to("cpu") if self._pending_infos else torch.zeros(1, dtype=torch.int32)
+                finally:
+                    self._pending_infos = None
+                for v in infos.tolist():
+                    _raise_on_info(int(v))
+                host = torch.stack(es).to("cpu")  # one copy; differentiable
+                for k in range(self.num_hyper_samples):
+                    loss = loss + (-host[k] + kl) / self.num_hyper_samples
                 batch_losses.append(loss.item())
                 loss.backward()
                 optimizer.step()
