@@ -31,6 +31,7 @@ class SgpStatusError(RuntimeError):
 
 _vp, _i64, _i32, _dbl, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
 _dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
 
 # name -> (restype, argtypes) ; mirrors include/sgp.h line by line
 PROTOTYPES = {
@@ -72,6 +73,10 @@ PROTOTYPES = {
     "sgp_small_sync_bytes": (_sz, []),
     "sgp_small_eval": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _vp, _vp, _vp,
                               _vp, _sz, _vp]),
+    "sgp_small_eval_composite": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _dp, _i32, _ip, _ip, _dp, _i64, _i32, _i32, _dbl, _i32, _i32,
+                                        _vp, _vp, _vp, _sz, _vp]),
+    "sgp_small_nuts_composite": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _dp, _i32, _ip, _ip, _dp, _i64, _i32, _i32, _dbl, _i32, _i32,
+                                        _i32, _dbl, _dbl, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_small_eval_batch": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _vp,
                                     _vp, _sz, _vp]),
     "sgp_small_nuts_stat_cols": (_sz, []),

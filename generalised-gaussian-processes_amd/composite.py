@@ -149,10 +149,38 @@ class CompositeHmcTarget:
         """PyMC3's test point: the prior mean of every Normal log-parameter (0) and sigma = 1."""
         return [0.0] * self.ndim
 
+    _ROLE_ID = {"amp": 0, "ls": 1, "aux": 2}
+
+    def device_description(self):
+        """The ``composite=`` argument of ``engine.small_eval`` / ``small_nuts``: the structure (term / factor types, fixed
+        periods) and the table (block slot, role, prior sd) of the sampled parameters."""
+        return {"structure": self.kernel.block(),
+                "free": [(slot, self._ROLE_ID[role], sd) for (_, slot, role), sd in zip(self.params, self.sd)]}
+
+    def device_sampler_ok(self):
+        """True when ``hmc.sample_nuts_device`` can run this target (single-launch path, at most 17 sampled parameters)."""
+        b = self.bound
+        return (hasattr(b, "_small_ok") and hasattr(b.engine, "small_nuts") and b._small_ok(self.Z.shape[0]) and self.ndim <= 18)
+
+    def device_sampler_args(self):
+        return {"composite": self.device_description()}
+
     def logp_and_grad(self, theta):
         th = [float(v) for v in theta]
         if not all(math.isfinite(v) and abs(v) < 300.0 for v in th):
             return -math.inf, [0.0] * self.ndim
+        b = self.bound
+        if hasattr(b, "_small_ok") and b._small_ok(self.Z.shape[0]):
+            # ONE launch: exp transforms, priors and the chain rule run on the device (sgp_small_eval_composite, SGP_SMALL_HMC)
+            if not all(abs(v) < 150.0 for v in th):
+                return -math.inf, [0.0] * self.ndim
+            h, info, _ = b._small_eval(self.Z, th, 1, True, False, self.device_description())
+            b.n_evals += 1
+            b.n_grads += 1
+            lp = float(h[0])
+            if info != 0 or not math.isfinite(lp):
+                return -math.inf, [0.0] * self.ndim
+            return lp, [float(v) for v in h[1:1 + self.ndim]]
         vals = [math.exp(v) for v in th[:-1]]
         sigma = math.exp(th[-1])
         kern = self.kernel.with_values(vals)

@@ -25,7 +25,7 @@ try:  # torch.distributed is plumbing; single-process use never touches it
 except Exception:  # pragma: no cover
     dist = None
 
-from ._lib import OUT_F, OUT_LOGMARG, OUT_S2BAR, OUT_TRACE
+from ._lib import COMP_LEN, OUT_F, OUT_LOGMARG, OUT_S2BAR, OUT_TRACE
 
 
 class NotPositiveDefiniteError(RuntimeError):
@@ -164,30 +164,35 @@ class CollapsedBound:
         return self._kfu
 
     # ------------------------------------------------------------------ single-launch path (small problems)
-    def _small_ok(self, M):
-        """One cooperative launch instead of ~60: M <= 128, stationary kernel, d <= 16, this rank holds all rows, and the
-        caller did not insist on the streaming order (the launch evaluates the whitened / PyMC3 order)."""
+    def _small_ok(self, M, want_gz=False, sf2=1.0):
+        """One cooperative launch instead of ~60: M <= 128, this rank holds all rows, and the caller did not insist on the
+        streaming order (the launch evaluates the whitened / PyMC3 order).  Stationary kernels d <= 16; composite kernels
+        d <= 8, without dF/dZ (that goes through the materialised path) and with the block's own amplitudes (sf2 = 1)."""
         e = self.engine
+        if self.kernel == "composite" and (want_gz or float(sf2) != 1.0):
+            return False
         return (self.fused and self.world == 1 and self.form != "streaming" and hasattr(e, "small_eval")
                 and e.small_supported(int(self.X.shape[0]), int(M), self.d, self.kernel))
 
-    def _small_eval(self, Z, theta_host, mode, want_grad, want_gz):
-        """theta_host: d + 2 floats.  Returns (host out[d + 5], info, gZ device tensor or None): one launch, one small
-        host-to-device copy before it and one device-to-host copy after it."""
+    def _small_eval(self, Z, theta_host, mode, want_grad, want_gz, composite=None):
+        """theta_host: the launch's hyper-parameter vector (d + 2 floats; composite kernels: block + [s2], or the log free
+        parameters + [log sigma]).  Returns (host out, info, gZ device tensor or None): one launch, one small host-to-device
+        copy before it and one device-to-host copy after it; out = [value | gradients (len(theta_host)) | logmarg | trace]."""
         e = self.engine
-        d = self.d
-        if self._small is None:
+        nt = len(theta_host)
+        if self._small is None or self._small[0].numel() != nt:
             pin = e.device.type == "cuda"
-            host = torch.empty(d + 2, dtype=torch.float64, pin_memory=pin)
-            self._small = (host, torch.empty(d + 2, dtype=torch.float64, device=e.device), e.small_result(d)[0])
+            host = torch.empty(nt, dtype=torch.float64, pin_memory=pin)
+            self._small = (host, torch.empty(nt, dtype=torch.float64, device=e.device), e.small_result(nt - 2)[0])
         host, dev_theta, buf = self._small
         for i, v in enumerate(theta_host):
             host[i] = float(v)
         dev_theta.copy_(host, non_blocking=True)
+        kw = {"composite": composite} if composite is not None else {}
         out, gz, _ = e.small_eval(self.X, self.y, Z, dev_theta, self.jitter, self.kernel, mode=mode, want_grad=want_grad,
-                                  want_gz=want_gz, out=buf)
+                                  want_gz=want_gz, out=buf, **kw)
         h = out.detach().to("cpu")
-        info = int(h[d + 5:d + 6].view(torch.int32)[0])
+        info = int(h[nt + 3:nt + 4].view(torch.int32)[0])
         if info < 0:
             if hasattr(e, "small_reset"):
                 e.small_reset()
@@ -271,15 +276,16 @@ class CollapsedBound:
     def value(self, Z, ls, sf2, s2, raise_on_fail=True):
         """F (not divided by N).  Returns (F, parts) with parts = dict(logmarg, trace_term, info)."""
         Z = self._prep_Z(Z)
-        if self._small_ok(Z.shape[0]):
-            d = self.d
-            h, info, _ = self._small_eval(Z, self._natural_theta(ls, sf2, s2), 0, False, False)
+        if self._small_ok(Z.shape[0], sf2=sf2):
+            th, comp = self._natural_theta(ls, sf2, s2)
+            nh = len(th) - 1
+            h, info, _ = self._small_eval(Z, th, 0, False, False, comp)
             self.n_evals += 1
             if info != 0:
                 if raise_on_fail:
                     raise NotPositiveDefiniteError(info)
                 return float("nan"), {"info": info}
-            return float(h[0]), {"logmarg": float(h[d + 3]), "trace_term": float(h[d + 4]), "info": 0}
+            return float(h[0]), {"logmarg": float(h[nh + 2]), "trace_term": float(h[nh + 3]), "info": 0}
         res = self._forward(Z, ls, sf2, s2, with_adjoints=False)
         o, info, _ = self._fetch(res)
         self.n_evals += 1
@@ -290,12 +296,17 @@ class CollapsedBound:
         return float(o[OUT_F]), {"logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE]), "info": 0}
 
     def _natural_theta(self, ls, sf2, s2):
+        """(theta of the single launch in natural parameters, composite description or None)."""
         vals = [float(v) for v in (ls.tolist() if hasattr(ls, "tolist") else ls)]
+        if self.kernel == "composite":
+            if len(vals) != COMP_LEN:
+                raise ValueError("composite kernels take the %d-entry parameter block as `ls`" % COMP_LEN)
+            return vals + [float(s2)], {"structure": vals}
         if len(vals) == 1 and self.d > 1:
             vals = vals * self.d
         if len(vals) != self.d:
             raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), self.d))
-        return vals + [float(sf2), float(s2)]
+        return vals + [float(sf2), float(s2)], None
 
     def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True):
         """F and dF/d{lengthscale_j, sf2, s2[, Z]} (natural parameters, not their raw transforms).
@@ -305,14 +316,19 @@ class CollapsedBound:
         e = self.engine
         Z = self._prep_Z(Z)
         M, d = Z.shape
-        if self._small_ok(M):
-            h, info, gz = self._small_eval(Z, self._natural_theta(ls, sf2, s2), 0, True, want_gz)
+        if self._small_ok(M, want_gz, sf2):
+            th, comp = self._natural_theta(ls, sf2, s2)
+            h, info, gz = self._small_eval(Z, th, 0, True, want_gz, comp)
             self.n_evals += 1
             self.n_grads += 1
             if info != 0:
                 if raise_on_fail:
                     raise NotPositiveDefiniteError(info)
                 return float("nan"), {"info": info}
+            nh = len(th) - 1  # kernel hyper-parameter entries: d lengthscales + sf2, or the composite block
+            if comp is not None:
+                return float(h[0]), {"ls": h[1:1 + nh].clone(), "sf2": 0.0, "s2": float(h[1 + nh]), "Z": None, "info": 0,
+                                     "logmarg": float(h[nh + 2]), "trace_term": float(h[nh + 3])}
             return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
                                  "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block

@@ -27,6 +27,7 @@
 // All cross-workgroup sums go through partial arrays reduced in a fixed order: results are bit-reproducible.
 #include "sgp_potrf.hpp"
 #include "sgp_nuts.hpp"
+#include "sgp_composite.hpp"
 
 namespace sgp {
 
@@ -36,12 +37,23 @@ constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
 enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_WORDS = 11 };
-constexpr int SM_GP = SM_MAXD + 4;  // doubles per gradient partial: g_ls[d] at 0.., then g_sf2, tr B^-1
+constexpr int SM_GP = 40;  // doubles per gradient partial.  Stationary: g_ls[d] at 0.., g_sf2 at 16; composite: dF/d(block) at its
+                          // 33 slots.  Both: tr B^-1, u.g, g.g at SM_XTRA + 0, 1, 2
+constexpr int SM_XTRA = 34;
+constexpr int SM_MAXCP = 20;  // free parameters of a composite kernel (4 terms x (amplitude + 2 x (lengthscale, aux)))
 
 struct SmallArgs {
   const double* X; int64_t ldx; const double* y; const double* Z; int64_t ldz; const double* theta;
   int N, M, d, kid, mode, want_grad, want_gz;
+  int nh;     // kernel hyper-parameter outputs: out = [value | nh | noise | logmarg | trace]  (d + 1, 33, or ncp)
+  int ndim;   // entries of theta (d + 2 ; 34 for a composite block + s2 ; ncp + 1 for the composite NUTS target)
   double jitter;
+  // SGP_KERNEL_COMPOSITE: the structure (term / factor types, fixed aux values) and, for the NUTS target, which block slot
+  // each sampled log-parameter fills (role 0 amplitude sd -> amp2 = v^2, 1 lengthscale, 2 aux) with its Normal prior sd
+  CompSpec cs;
+  int ncp;
+  int cp_slot[SM_MAXCP], cp_role[SM_MAXCP];
+  double cp_sd[SM_MAXCP];
   int nslab, grow;
   double *Lk, *dinvK, *Bm, *Lb, *dinvB, *A, *Ppart, *upart, *spart, *u, *c0, *g, *h, *gpart, *gzpart, *Qm;
   int *sync, *info;
@@ -53,7 +65,9 @@ struct SmallArgs {
 struct SmHyp {
   double inv_ls[SM_MAXD], ls[SM_MAXD];
   double sf2, s2;
+  double kdiag;  // k(x, x): sf2, or the sum of a composite kernel's amplitudes
   int ok;
+  CompSpec cs;   // composite kernels: the structure with this evaluation's parameter values
 };
 
 template <int MP>
@@ -170,11 +184,57 @@ __device__ __forceinline__ void sm_profile_grad_vec(int kid, double (&r2)[NE], d
   }
 }
 
+// one parameter slot of the block (amplitude / lengthscale / aux) <- v
+__device__ __forceinline__ void sm_set_slot(CompSpec& cs, int slot, double v) {
+  const int t = (slot - 1) >> 3, rem = (slot - 1) & 7;
+  if (rem == 0) cs.amp2[t] = v;
+  else if ((rem - 2) % 3 == 1) cs.ls[t][(rem - 2) / 3] = v;
+  else cs.aux[t][(rem - 2) / 3] = v;
+}
 // theta -> hyper-parameters (thread 0), the same arithmetic in every workgroup.
 //   mode 0: theta = [ls_1..d | sf2 | s2] ;  mode 1: theta = [log ls_1..d | log sig_f | log sig_n]
+template <bool COMP>
 __device__ __forceinline__ void sm_hypers(const SmallArgs& a, SmHyp& h) {
   if (threadIdx.x == 0) {
     int ok = 1;
+    if constexpr (COMP) {
+      // mode 0: theta = [parameter block (SGP_COMP_LEN) | s2] ; SGP_SMALL_HMC: theta = [log of every free parameter | log sigma]
+      CompSpec cs = a.cs;
+      double tn;
+      if (a.mode == 0) {
+        for (int t = 0; t < cs.nterms; ++t) {
+          const int base = 1 + 8 * t;
+          cs.amp2[t] = a.theta[base];
+          ok = ok && (cs.amp2[t] > 0.0);
+          for (int f = 0; f < cs.nfac[t]; ++f) {
+            cs.ls[t][f] = a.theta[base + 2 + 3 * f + 1];
+            cs.aux[t][f] = a.theta[base + 2 + 3 * f + 2];
+            ok = ok && (cs.ls[t][f] > 0.0);
+            if (cs.type[t][f] == SGP_FAC_RATQUAD || cs.type[t][f] == SGP_FAC_PERIODIC) ok = ok && (cs.aux[t][f] > 0.0);
+          }
+        }
+        tn = a.theta[SGP_COMP_LEN];
+        h.s2 = tn;
+      } else {
+        for (int k = 0; k < a.ncp; ++k) {
+          const double t = a.theta[k], v = exp(t);
+          if (!(fabs(t) < 150.0)) ok = 0;
+          sm_set_slot(cs, a.cp_slot[k], a.cp_role[k] == 0 ? v * v : v);
+        }
+        tn = a.theta[a.ncp];
+        if (!(fabs(tn) < 150.0)) ok = 0;
+        h.s2 = exp(2.0 * tn);
+      }
+      double kd = 0.0;
+      for (int t = 0; t < cs.nterms; ++t) kd += cs.amp2[t];
+      cs.kdiag = kd;
+      h.cs = cs;
+      h.kdiag = kd;
+      h.sf2 = 1.0;
+      for (int j = 0; j < SM_MAXD; ++j) { h.ls[j] = 1.0; h.inv_ls[j] = j < a.d ? 1.0 : 0.0; }
+      if (!(h.s2 > 0.0) || !(kd > 0.0)) ok = 0;
+      h.ok = ok;
+    } else {
     for (int j = 0; j < a.d; ++j) {
       const double t = a.theta[j];
       const double l = a.mode ? exp(t) : t;
@@ -186,11 +246,47 @@ __device__ __forceinline__ void sm_hypers(const SmallArgs& a, SmHyp& h) {
     const double tf = a.theta[a.d], tn = a.theta[a.d + 1];
     h.sf2 = a.mode ? exp(2.0 * tf) : tf;
     h.s2 = a.mode ? exp(2.0 * tn) : tn;
+    h.kdiag = h.sf2;
     if (!(fabs(tf) < 300.0) || !(fabs(tn) < 300.0) || !(h.sf2 > 0.0) || !(h.s2 > 0.0)) ok = 0;
     if (a.mode && (fabs(tf) > 150.0 || fabs(tn) > 150.0)) ok = 0;
     h.ok = ok;
+    }
   }
   __syncthreads();
+}
+
+// k(a, b) k-bar accumulated into the per-lane sums of a composite kernel's parameter derivatives (static indexing: terms and
+// factors unrolled, guarded by the runtime structure)
+__device__ __forceinline__ void sm_comp_accum(const CompSpec& cs, const double* a, const double* b, int d, double kb,
+                                              double (&acc_amp)[SGP_COMP_MAX_TERMS], double (&acc_ls)[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS],
+                                              double (&acc_aux)[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS]) {
+  double delta[COMP_MAX_DIM];
+  double r2 = 0.0;
+  for (int j = 0; j < d; ++j) {
+    delta[j] = a[j] - b[j];
+    r2 = fma(delta[j], delta[j], r2);
+  }
+#pragma unroll
+  for (int t = 0; t < SGP_COMP_MAX_TERMS; ++t) {
+    if (t < cs.nterms) {
+      FacOut fo[SGP_COMP_MAX_FACTORS];
+      double prod = 1.0;
+#pragma unroll
+      for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f)
+        if (f < cs.nfac[t]) {
+          fo[f] = comp_factor(cs.type[t][f], cs.ls[t][f], cs.aux[t][f], r2, delta, d);
+          prod *= fo[f].F;
+        }
+      acc_amp[t] = fma(kb, prod, acc_amp[t]);
+#pragma unroll
+      for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f)
+        if (f < cs.nfac[t]) {
+          const double other = kb * cs.amp2[t] * (cs.nfac[t] == 2 ? fo[1 - f].F : 1.0);
+          acc_ls[t][f] = fma(other, fo[f].dls, acc_ls[t][f]);
+          acc_aux[t][f] = fma(other, fo[f].daux, acc_aux[t][f]);
+        }
+    }
+  }
 }
 
 // ---- register-resident slab: NB16 transposed 16 x 16 blocks per wave ---------------------------------------------
@@ -391,7 +487,7 @@ struct SmKernelShared {
 // One evaluation, executed by every workgroup of the launch.  `ev` = 1-based count of evaluations this launch has run
 // (flags carry it, counters are cumulative: ev x contributors), so a persistent kernel calls this repeatedly without
 // clearing anything; `persistent` = false additionally leaves the sync words zero for the next launch.
-template <int MP>
+template <int MP, bool COMP>
 __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<MP>& ks, int ev, bool persistent) {
   constexpr int NB16 = MP / 16, NBL = NB16 * (NB16 + 1) / 2, NBW = (NBL + 3) / 4, NB64 = MP / 64;
   SmShared<MP>& sh = ks.sh;
@@ -412,6 +508,8 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
   };
   stamp(0);
   const double sf2 = hyp.sf2, s2 = hyp.s2;
+  constexpr bool comp = COMP;  // SGP_KERNEL_COMPOSITE (sums of products of isotropic factors, values through comp_value()):
+                               // its own instantiation, so the stationary kernels carry none of its code or registers
   const int role = wg == 0 ? 0 : (wg <= NB64 ? 1 : 2);
   const int ngrad = a.grow + NB64;  // workgroups that contribute gradient partials
 
@@ -445,6 +543,10 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     __syncthreads();
     // 16 entries of the padded Kuu: row i, columns j0 + cstride * k (k = 0..15)
     auto kuu16 = [&](int i, int j0, int cstride, double (&v)[16]) {
+      if (comp) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = comp_value(hyp.cs, zs[i], zs[j0 + cstride * k], d);
+      } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
       for (int q = 0; q < d; ++q) {
@@ -456,6 +558,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         }
       }
       sm_profile_vec<16>(a.kid, v, sf2);
+      }
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int j = j0 + cstride * k;
@@ -632,7 +735,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     stamp(6);
     // scalars
     const double sumA2 = a.spart[0], yy = a.spart[1];  // reduced by the slice stage
-    const double Nd = (double)N, kappa = Nd * sf2;
+    const double Nd = (double)N, kappa = Nd * hyp.kdiag;
     const double LOG2PI = 1.8378770664093453;
     const double quad = yy / s2 - cc / (s2 * s2);
     const double logmarg = -(0.5 * Nd * LOG2PI + 0.5 * Nd * log(s2) + ld + 0.5 * quad);
@@ -642,8 +745,8 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     if (!a.want_grad) {
       if (tid == 0) {
         a.out[0] = F;
-        a.out[d + 3] = logmarg;
-        a.out[d + 4] = trace_term;
+        a.out[a.nh + 2] = logmarg;
+        a.out[a.nh + 3] = trace_term;
       }
       __syncthreads();
       if (!persistent)
@@ -672,12 +775,34 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     }
     __syncthreads();
     if (tid == 0) {
-      const double trBinv = gsum[SM_MAXD + 1], ug = gsum[SM_MAXD + 2], gg = gsum[SM_MAXD + 3];
+      const double trBinv = gsum[SM_XTRA], ug = gsum[SM_XTRA + 1], gg = gsum[SM_XTRA + 2];
       const double g_sf2 = gsum[SM_MAXD] - Nd / (2.0 * s2);  // + kappabar dkappa/dsf2
       const double s22 = s2 * s2;
       const double g_s2 = -0.5 * (-((double)MP - trBinv) / s2 + Nd / s2 - yy / s22 + 2.0 * ug / (s22 * s2) - (ug - gg) / (s22 * s2)
                                   - kappa / s22 + sumA2 / s22);
-      if (a.mode == 0) {
+      if (comp) {
+        // dF/d(block): the contraction sums at the parameter slots, + kappabar dkappa/d(amp2_t) = -N / (2 s2) on the amplitudes
+        for (int t = 0; t < hyp.cs.nterms; ++t) gsum[1 + 8 * t] -= Nd / (2.0 * s2);
+        if (a.mode == 0) {
+          a.out[0] = F;
+          for (int p = 0; p < SGP_COMP_LEN; ++p) a.out[1 + p] = gsum[p];
+          a.out[1 + SGP_COMP_LEN] = g_s2;
+        } else {
+          // the NUTS target of experiments/co2_bayesian_sgpr_hmc.py:99-158: log-parameters ~ Normal(0, sd) (sampled in log
+          // space, no Jacobian), sigma ~ HalfNormal(1) log-transformed
+          double lp = F;
+          for (int k = 0; k < a.ncp; ++k) {
+            const double t = a.theta[k], v = exp(t), sd = a.cp_sd[k];
+            const double dF = gsum[a.cp_slot[k]];
+            lp += -0.5 * (t / sd) * (t / sd) - log(sd) - 0.9189385332046727;
+            a.out[1 + k] = (a.cp_role[k] == 0 ? 2.0 * v * v * dF : v * dF) - t / (sd * sd);
+          }
+          const double tn = a.theta[a.ncp], sig2 = exp(2.0 * tn);
+          lp += -0.22579135264472741 - 0.5 * sig2 + tn;  // 0.5 log(2 / pi)
+          a.out[1 + a.ncp] = 2.0 * sig2 * g_s2 - sig2 + 1.0;
+          a.out[0] = lp;
+        }
+      } else if (a.mode == 0) {
         a.out[0] = F;
         for (int j = 0; j < d; ++j) a.out[1 + j] = gsum[j];
         a.out[1 + d] = g_sf2;
@@ -699,8 +824,8 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         a.out[2 + d] = sn * (2.0 * sn * g_s2 - 2.0 * sn / (1.0 + sn * sn)) + 1.0;
         a.out[0] = lp + sumth;
       }
-      a.out[d + 3] = logmarg;
-      a.out[d + 4] = trace_term;
+      a.out[a.nh + 2] = logmarg;
+      a.out[a.nh + 3] = trace_term;
     }
     __syncthreads();
     if (!persistent)
@@ -715,6 +840,42 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
   auto contract = [&](const SlabRegs<NB16>& Y, int nvalid, double zscale) {
     // nvalid: slab rows that are real ; zscale: 1 for K_uf, 2 for the symmetric K_uu (both arguments are inducing inputs)
     const int nl = 16 * w + l15;
+    if (comp) {
+      // composite kernels: per-pair factor derivatives, summed per lane into (term, factor) slots, then over the workgroup
+      double am[SGP_COMP_MAX_TERMS], al[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS], ax[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS];
+#pragma unroll
+      for (int t = 0; t < SGP_COMP_MAX_TERMS; ++t) {
+        am[t] = 0.0;
+#pragma unroll
+        for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f) al[t][f] = ax[t][f] = 0.0;
+      }
+#pragma unroll
+      for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+          const int m = 16 * pb + 4 * sq + l4;
+          const double kb = (nl < nvalid && m < M) ? Y.b[pb][sq] : 0.0;
+          sm_comp_accum(hyp.cs, sl.xs[nl], sl.zs[m], d, kb, am, al, ax);
+        }
+#pragma unroll
+      for (int t = 0; t < SGP_COMP_MAX_TERMS; ++t) {
+        const double v = wave_sum(am[t]);
+        if (lane == 0) sl.red[w][1 + 8 * t] = v;
+#pragma unroll
+        for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f) {
+          const double vl = wave_sum(al[t][f]), vx = wave_sum(ax[t][f]);
+          if (lane == 0) {
+            sl.red[w][1 + 8 * t + 2 + 3 * f + 1] = vl;
+            sl.red[w][1 + 8 * t + 2 + 3 * f + 2] = vx;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid >= 1 && tid < SGP_COMP_LEN && ((tid - 1) & 7) != 1 && ((tid - 1) & 7) != 2 && ((tid - 1) & 7) != 5)
+        sl.acc[tid] += (sl.red[0][tid] + sl.red[1][tid]) + (sl.red[2][tid] + sl.red[3][tid]);
+      __syncthreads();
+      return;
+    }
     double E[NB16][4];
     double ksum = 0.0;
     {
@@ -802,7 +963,14 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       if (tid < SM_SLAB) sl.ys[tid] = n0 + tid < N ? a.y[n0 + tid] : 0.0;
       __syncthreads();
       const int nl = 16 * w + l15;
+      const bool rowlive = n0 + nl < N;
       double r2[NB16][4];
+      if (comp) {
+#pragma unroll
+        for (int pb = 0; pb < NB16; ++pb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) r2[pb][s] = comp_value(hyp.cs, sl.xs[nl], sl.zs[16 * pb + 4 * s + l4], d);
+      } else {
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
@@ -817,9 +985,9 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
             r2[pb][s] = fma(df, df, r2[pb][s]);
           }
       }
-      const bool rowlive = n0 + nl < N;
       double (&rv)[NB16 * 4] = reinterpret_cast<double (&)[NB16 * 4]>(r2);
       sm_profile_vec<NB16 * 4>(a.kid, rv, sf2);
+      }
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
@@ -1054,6 +1222,10 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     for (int e0 = tid; e0 < 64 * 8; e0 += 256) {  // (row, group of 16 columns)
       const int i = 64 + (e0 >> 3), j0 = 16 * (e0 & 7);
       double v[16];
+      if (comp) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = comp_value(hyp.cs, sl.zs[i], sl.zs[j0 + k], d);
+      } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
       for (int q = 0; q < d; ++q) {
@@ -1065,6 +1237,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         }
       }
       sm_profile_vec<16>(a.kid, v, sf2);
+      }
       double* dst = a.Lk + (size_t)i * MP + j0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -1119,8 +1292,8 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       const double ug = block_sum(tid < MP ? a.u[tid] * sl.gv[tid] : 0.0);
       const double gg = block_sum(tid < MP ? sl.gv[tid] * sl.gv[tid] : 0.0);
       if (tid == 0) {
-        sl.acc[SM_MAXD + 2] = ug;
-        sl.acc[SM_MAXD + 3] = gg;
+        sl.acc[SM_XTRA + 1] = ug;
+        sl.acc[SM_XTRA + 2] = gg;
       }
     }
     const double gc = sl.gv[col] * is22;
@@ -1130,7 +1303,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       for (int s = 0; s < 4; ++s) a.Qm[(size_t)(16 * pb + 4 * s + l4) * MP + col] = fma(sl.hv[16 * pb + 4 * s + l4], gc, Y.b[pb][s]);
   }
   trb = block_sum(trb);
-  if (tid == 0) sl.acc[SM_MAXD + 1] = trb;
+  if (tid == 0) sl.acc[SM_XTRA] = trb;
   stamp(2);
   if (NB64 > 1) {  // the other workgroups' columns of Q
     sm_publish_add(sy + SY_Q * SM_SYNC_STRIDE);
@@ -1168,25 +1341,25 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
   sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
 }
 
-template <int MP>
+template <int MP, bool COMP>
 __global__ __launch_bounds__(256) void small_eval_kernel(SmallArgs a) {
   __shared__ SmKernelShared<MP> ks;
   if (threadIdx.x == 0) ks.dead = 0;
-  sm_hypers(a, ks.hyp);
+  sm_hypers<COMP>(a, ks.hyp);
   if (!ks.hyp.ok) {  // theta outside the representable range: density zero, never an exception (PyMC3: non-finite logp)
-    if (blockIdx.x == 0 && threadIdx.x <= a.d + 2) a.out[threadIdx.x] = threadIdx.x == 0 ? -INFINITY : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x <= a.nh + 1) a.out[threadIdx.x] = threadIdx.x == 0 ? -INFINITY : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.info = 0;
     return;
   }
-  sm_eval_body<MP>(a, ks, 1, false);
+  sm_eval_body<MP, COMP>(a, ks, 1, false);
 }
 
 // The evaluation as an out-of-line call for the persistent kernel: inlined into its request loop the compiler kept the
 // loop's state live across the whole evaluation (455 spilled VGPRs at MP = 128 against 13 in the single-evaluation kernel,
 // +45 us per leapfrog).
-template <int MP>
+template <int MP, bool COMP>
 __device__ __attribute__((noinline)) void sm_eval_call(const SmallArgs* a, SmKernelShared<MP>* ks, int ev) {
-  sm_eval_body<MP>(*a, *ks, ev, true);
+  sm_eval_body<MP, COMP>(*a, *ks, ev, true);
 }
 
 // ---- device-resident NUTS ------------------------------------------------------------------------------------------
@@ -1212,12 +1385,12 @@ struct NutsArgs {
 };
 constexpr int SM_NUTS_COLS = NST_COLS + 1;  // + seconds per draw (device clock)
 
-template <int MP>
+template <int MP, bool COMP>
 __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs na) {
   __shared__ SmKernelShared<MP> ks;
   __shared__ NutsState st;
   __shared__ int cmd;
-  const int tid = threadIdx.x, wg = blockIdx.x, ndim = a.d + 2;
+  const int tid = threadIdx.x, wg = blockIdx.x, ndim = a.ndim;
   int* sy = a.sync;
   int* abortw = sy + SY_ABORT * SM_SYNC_STRIDE;
   if (tid == 0) ks.dead = 0;
@@ -1235,7 +1408,7 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
     ++req;
     if (batch) {
       const int sidx = req - 1 < na.S ? req - 1 : na.S - 1;
-      al.out = na.batch_out + (size_t)sidx * (a.d + 5);
+      al.out = na.batch_out + (size_t)sidx * (a.nh + 4);
       al.gZ = na.batch_gz ? na.batch_gz + (size_t)sidx * a.M * a.d : nullptr;
       al.info = na.batch_info + sidx;
     }
@@ -1276,7 +1449,7 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
       if (!sm_wait_ge(sy + SY_REQ * SM_SYNC_STRIDE, req, abortw, &ks.dead)) break;
       if (sm_ld(sy + SY_DONE * SM_SYNC_STRIDE) != 0) break;
     }
-    sm_hypers(al, ks.hyp);  // every workgroup from the same theta: the same decision everywhere
+    sm_hypers<COMP>(al, ks.hyp);  // every workgroup from the same theta: the same decision everywhere
     if (!ks.hyp.ok) {
       if (wg == 0 && tid == 0) {
         al.out[0] = -INFINITY;
@@ -1286,7 +1459,7 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
       continue;
     }
     ++ev;
-    sm_eval_call<MP>(&al, &ks, ev);
+    sm_eval_call<MP, COMP>(&al, &ks, ev);
     if (ks.dead || sm_ld(abortw) != 0) {
       if (wg == 0 && tid == 0) *al.info = SGP_INFO_TIMEOUT;
       break;
@@ -1348,8 +1521,9 @@ static unsigned long long* g_small_stamps = nullptr;
 extern "C" void sgp_small_debug_stamps(void* dev_buffer) { g_small_stamps = static_cast<unsigned long long*>(dev_buffer); }
 
 extern "C" int sgp_small_supported(int64_t N, int M, int d, int kernel_id) {
-  return N >= 1 && N <= (int64_t)1 << 22 && M >= 1 && M <= 128 && d >= 1 && d <= SM_MAXD && kernel_id >= SGP_KERNEL_RBF &&
-         kernel_id <= SGP_KERNEL_MATERN52;
+  if (!(N >= 1 && N <= (int64_t)1 << 22 && M >= 1 && M <= 128 && d >= 1)) return 0;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) return d <= COMP_MAX_DIM;
+  return d <= SM_MAXD && kernel_id >= SGP_KERNEL_RBF && kernel_id <= SGP_KERNEL_MATERN52;
 }
 extern "C" size_t sgp_small_workspace_bytes(int64_t N, int M, int d) {
   if (!sgp_small_supported(N, M, d, SGP_KERNEL_RBF)) return 0;
@@ -1357,15 +1531,61 @@ extern "C" size_t sgp_small_workspace_bytes(int64_t N, int M, int d) {
 }
 extern "C" size_t sgp_small_sync_bytes(void) { return (size_t)SY_WORDS * SM_SYNC_STRIDE * sizeof(int); }
 
-extern "C" int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
-                              const double* theta, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
-                              int want_grad, double* out, double* g_Z, int* info, void* ws, size_t ws_bytes,
-                              sgp_stream_t stream) {
+// the composite description an entry point hands over (host memory): the parameter block as the structure (term / factor
+// types and the values of parameters that are not sampled) and, for the NUTS target, the free-parameter table
+struct CompHost {
+  const double* structure;
+  int ncp;
+  const int* slot;
+  const int* role;
+  const double* sd;
+};
+// fills the kernel-specific fields of `a` (nh, ndim, cs, cp_*) ; SGP_OK or an error code
+static int small_kernel_fields(SmallArgs& a, int d, int kernel_id, int mode, const CompHost* ch) {
+  a.ncp = 0;
+  if (kernel_id != SGP_KERNEL_COMPOSITE) {
+    if (ch) return SGP_ERR_ARG;
+    a.nh = d + 1;
+    a.ndim = d + 2;
+    return SGP_OK;
+  }
+  if (!ch || !ch->structure) return SGP_ERR_ARG;
+  if (comp_parse(ch->structure, d, &a.cs) != SGP_OK) return SGP_ERR_ARG;
+  if (mode == 0) {
+    a.nh = SGP_COMP_LEN;
+    a.ndim = SGP_COMP_LEN + 1;
+    return SGP_OK;
+  }
+  if (ch->ncp < 1 || ch->ncp > SM_MAXCP || !ch->slot || !ch->role || !ch->sd) return SGP_ERR_ARG;
+  for (int k = 0; k < ch->ncp; ++k) {
+    const int slot = ch->slot[k], role = ch->role[k];
+    if (slot < 1 || slot >= SGP_COMP_LEN || role < 0 || role > 2 || !(ch->sd[k] > 0.0)) return SGP_ERR_ARG;
+    const int t = (slot - 1) >> 3, rem = (slot - 1) & 7;
+    if (t >= a.cs.nterms) return SGP_ERR_ARG;
+    // the slot must be of the stated role and belong to a factor the structure has
+    const bool is_amp = rem == 0, is_ls = rem == 3 || rem == 6, is_aux = rem == 4 || rem == 7;
+    if ((role == 0) != is_amp || (role == 1) != is_ls || (role == 2) != is_aux) return SGP_ERR_ARG;
+    if (!is_amp && (rem - 2) / 3 >= a.cs.nfac[t]) return SGP_ERR_ARG;
+    a.cp_slot[k] = slot;
+    a.cp_role[k] = role;
+    a.cp_sd[k] = ch->sd[k];
+  }
+  a.ncp = ch->ncp;
+  a.nh = ch->ncp;
+  a.ndim = ch->ncp + 1;
+  return SGP_OK;
+}
+
+static int small_eval_impl(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* theta,
+                           int64_t N, int M, int d, int kernel_id, const CompHost* ch, double jitter, int mode, int want_grad,
+                           double* out, double* g_Z, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
   if (!X || !y || !Z || !theta || !out || !info || ldx < d || ldz < d || (mode != 0 && mode != 1)) return SGP_ERR_ARG;
   if (!sgp_small_supported(N, M, d, kernel_id)) return SGP_ERR_DIM;
+  if (kernel_id == SGP_KERNEL_COMPOSITE && g_Z) return SGP_ERR_ARG;  // dF/dZ of a composite kernel: the materialised path
   SmallWs w = carve_small(ws, N, M, d);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
   SmallArgs& a = w.a;
+  if (int rc = small_kernel_fields(a, d, kernel_id, mode, ch)) return rc;
   a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta;
   a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = mode; a.want_grad = want_grad ? 1 : 0;
   a.want_gz = (want_grad && g_Z) ? 1 : 0;
@@ -1374,25 +1594,52 @@ extern "C" int sgp_small_eval(const double* X, int64_t ldx, const double* y, con
   a.stamps = g_small_stamps;
   const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
   hipStream_t st = (hipStream_t)stream;
-  if (M <= 64) small_eval_kernel<64><<<grid, 256, 0, st>>>(a);
-  else small_eval_kernel<128><<<grid, 256, 0, st>>>(a);
+  const bool comp = kernel_id == SGP_KERNEL_COMPOSITE;
+  if (M <= 64) {
+    if (comp) small_eval_kernel<64, true><<<grid, 256, 0, st>>>(a);
+    else small_eval_kernel<64, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (comp) small_eval_kernel<128, true><<<grid, 256, 0, st>>>(a);
+    else small_eval_kernel<128, false><<<grid, 256, 0, st>>>(a);
+  }
   return check_launch();
+}
+
+extern "C" int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                              const double* theta, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
+                              int want_grad, double* out, double* g_Z, int* info, void* ws, size_t ws_bytes,
+                              sgp_stream_t stream) {
+  if (kernel_id == SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;  // sgp_small_eval_composite carries the structure
+  return small_eval_impl(X, ldx, y, Z, ldz, theta, N, M, d, kernel_id, nullptr, jitter, mode, want_grad, out, g_Z, info, ws,
+                         ws_bytes, stream);
+}
+
+extern "C" int sgp_small_eval_composite(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                        const double* theta, const double* structure, int n_free, const int* free_slot,
+                                        const int* free_role, const double* free_prior_sd, int64_t N, int M, int d,
+                                        double jitter, int mode, int want_grad, double* out, int* info, void* ws,
+                                        size_t ws_bytes, sgp_stream_t stream) {
+  const CompHost ch{structure, n_free, free_slot, free_role, free_prior_sd};
+  return small_eval_impl(X, ldx, y, Z, ldz, theta, N, M, d, SGP_KERNEL_COMPOSITE, &ch, jitter, mode, want_grad, out, nullptr,
+                         info, ws, ws_bytes, stream);
 }
 
 extern "C" size_t sgp_small_nuts_stat_cols(void) { return SM_NUTS_COLS; }
 
-extern "C" int sgp_small_nuts(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* q0,
-                              int64_t N, int M, int d, int kernel_id, double jitter, int n_tune, int n_draws, int max_treedepth,
-                              double step_scale, double target_accept, uint64_t seed, double* theta_scratch, double* samples,
-                              double* stats, long long* counters, double* out, int* info, void* ws, size_t ws_bytes,
-                              sgp_stream_t stream) {
+static int small_nuts_impl(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* q0,
+                           int64_t N, int M, int d, int kernel_id, const CompHost* ch, double jitter, int n_tune, int n_draws,
+                           int max_treedepth, double step_scale, double target_accept, uint64_t seed, double* theta_scratch,
+                           double* samples, double* stats, long long* counters, double* out, int* info, void* ws,
+                           size_t ws_bytes, sgp_stream_t stream) {
   if (!X || !y || !Z || !q0 || !theta_scratch || !samples || !stats || !counters || !out || !info || ldx < d || ldz < d)
     return SGP_ERR_ARG;
   if (n_tune < 0 || n_draws < 1 || max_treedepth < 1 || max_treedepth >= NUTS_MAXDEPTH || !(step_scale > 0.0)) return SGP_ERR_ARG;
-  if (!sgp_small_supported(N, M, d, kernel_id) || d + 2 > NUTS_MAXD) return SGP_ERR_DIM;
+  if (!sgp_small_supported(N, M, d, kernel_id)) return SGP_ERR_DIM;
   SmallWs w = carve_small(ws, N, M, d);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
   SmallArgs& a = w.a;
+  if (int rc = small_kernel_fields(a, d, kernel_id, SGP_SMALL_HMC, ch)) return rc;
+  if (a.ndim > NUTS_MAXD) return SGP_ERR_DIM;
   a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta_scratch;
   a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = SGP_SMALL_HMC; a.want_grad = 1; a.want_gz = 0;
   a.jitter = jitter;
@@ -1404,9 +1651,37 @@ extern "C" int sgp_small_nuts(const double* X, int64_t ldx, const double* y, con
   hipStream_t st = (hipStream_t)stream;
   // the request / done words of the previous run (the only sync words a run leaves non-zero)
   zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
-  if (M <= 64) small_nuts_kernel<64><<<grid, 256, 0, st>>>(a, na);
-  else small_nuts_kernel<128><<<grid, 256, 0, st>>>(a, na);
+  const bool comp = kernel_id == SGP_KERNEL_COMPOSITE;
+  if (M <= 64) {
+    if (comp) small_nuts_kernel<64, true><<<grid, 256, 0, st>>>(a, na);
+    else small_nuts_kernel<64, false><<<grid, 256, 0, st>>>(a, na);
+  } else {
+    if (comp) small_nuts_kernel<128, true><<<grid, 256, 0, st>>>(a, na);
+    else small_nuts_kernel<128, false><<<grid, 256, 0, st>>>(a, na);
+  }
   return check_launch();
+}
+
+extern "C" int sgp_small_nuts(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* q0,
+                              int64_t N, int M, int d, int kernel_id, double jitter, int n_tune, int n_draws, int max_treedepth,
+                              double step_scale, double target_accept, uint64_t seed, double* theta_scratch, double* samples,
+                              double* stats, long long* counters, double* out, int* info, void* ws, size_t ws_bytes,
+                              sgp_stream_t stream) {
+  if (kernel_id == SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;  // sgp_small_nuts_composite carries the structure
+  return small_nuts_impl(X, ldx, y, Z, ldz, q0, N, M, d, kernel_id, nullptr, jitter, n_tune, n_draws, max_treedepth, step_scale,
+                         target_accept, seed, theta_scratch, samples, stats, counters, out, info, ws, ws_bytes, stream);
+}
+
+extern "C" int sgp_small_nuts_composite(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                        const double* q0, const double* structure, int n_free, const int* free_slot,
+                                        const int* free_role, const double* free_prior_sd, int64_t N, int M, int d,
+                                        double jitter, int n_tune, int n_draws, int max_treedepth, double step_scale,
+                                        double target_accept, uint64_t seed, double* theta_scratch, double* samples,
+                                        double* stats, long long* counters, double* out, int* info, void* ws, size_t ws_bytes,
+                                        sgp_stream_t stream) {
+  const CompHost ch{structure, n_free, free_slot, free_role, free_prior_sd};
+  return small_nuts_impl(X, ldx, y, Z, ldz, q0, N, M, d, SGP_KERNEL_COMPOSITE, &ch, jitter, n_tune, n_draws, max_treedepth,
+                         step_scale, target_accept, seed, theta_scratch, samples, stats, counters, out, info, ws, ws_bytes, stream);
 }
 
 // S evaluations (S hyper-parameter sets, the same X, y, Z) in ONE launch: the theta-averaged loss of the reference's
@@ -1419,10 +1694,12 @@ extern "C" int sgp_small_eval_batch(const double* X, int64_t ldx, const double* 
                                     size_t ws_bytes, sgp_stream_t stream) {
   if (!X || !y || !Z || !thetas || !theta_scratch || !outs || !infos || S < 1 || ldx < d || ldz < d || (mode != 0 && mode != 1))
     return SGP_ERR_ARG;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
   if (!sgp_small_supported(N, M, d, kernel_id)) return SGP_ERR_DIM;
   SmallWs w = carve_small(ws, N, M, d);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
   SmallArgs& a = w.a;
+  if (int rc = small_kernel_fields(a, d, kernel_id, mode, nullptr)) return rc;
   a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta_scratch;
   a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = mode; a.want_grad = want_grad ? 1 : 0;
   a.want_gz = (want_grad && g_Z) ? 1 : 0;
@@ -1433,7 +1710,7 @@ extern "C" int sgp_small_eval_batch(const double* X, int64_t ldx, const double* 
   const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
   hipStream_t st = (hipStream_t)stream;
   zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
-  if (M <= 64) small_nuts_kernel<64><<<grid, 256, 0, st>>>(a, na);
-  else small_nuts_kernel<128><<<grid, 256, 0, st>>>(a, na);
+  if (M <= 64) small_nuts_kernel<64, false><<<grid, 256, 0, st>>>(a, na);
+  else small_nuts_kernel<128, false><<<grid, 256, 0, st>>>(a, na);
   return check_launch();
 }

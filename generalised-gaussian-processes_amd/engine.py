@@ -268,29 +268,66 @@ class HipEngine:
     def small_supported(self, N: int, M: int, d: int, kernel="rbf") -> bool:
         return bool(self.lib.sgp_small_supported(int(N), int(M), int(d), _kernel_id(kernel)))
 
+    def _small_ws(self, N, M, d):
+        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
+        ws = self._ws.get("small")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)  # zeroed once: the sync words
+            self._ws["small"] = ws
+        return ws
+
+    @staticmethod
+    def _composite_args(composite, hmc: bool):
+        """(structure, n_free, slots, roles, sds) ctypes arguments of the *_composite entry points (host arrays).
+        ``composite`` = {"structure": the SGP_COMP_LEN parameter block, "free": [(slot, role 0 amp / 1 ls / 2 aux, prior sd)]}."""
+        blk = [float(v) for v in composite["structure"]]
+        if len(blk) != _lib.COMP_LEN:
+            raise ValueError("composite structure must have %d entries" % _lib.COMP_LEN)
+        free = list(composite.get("free") or []) if hmc else []
+        n = len(free)
+        return ((C.c_double * len(blk))(*blk), n, (C.c_int * max(n, 1))(*[int(f[0]) for f in free]),
+                (C.c_int * max(n, 1))(*[int(f[1]) for f in free]), (C.c_double * max(n, 1))(*[float(f[2]) for f in free]))
+
+    @staticmethod
+    def small_out_len(d: int, mode: int = 0, composite=None) -> int:
+        """Entries of the result of one evaluation: [value | kernel hyper-parameter gradients | noise | logmarg | trace]."""
+        if composite is None:
+            return d + 5
+        return (len(composite["free"]) if mode else _lib.COMP_LEN) + 4
+
     def small_eval(self, X, y, Z, theta: torch.Tensor, jitter, kernel="rbf", mode=0, want_grad=True, want_gz=False,
-                   out: Optional[torch.Tensor] = None):
+                   out: Optional[torch.Tensor] = None, composite=None):
         """ONE kernel launch: the bound (mode 0) or the NUTS target (mode 1) and its gradient, hyper-parameters read from
-        the device tensor ``theta``.  Returns (out[d + 5] device tensor, gZ or None, info int32 device tensor); nothing is
-        synchronised.  ``out`` may be a caller-owned d + 5 (+1 for the status word, see ``small_result``) buffer."""
+        the device tensor ``theta``.  Returns (out device tensor, gZ or None, info int32 device tensor); nothing is
+        synchronised.  ``out`` may be a caller-owned buffer of ``small_out_len`` (+1 for the status word, see
+        ``small_result``) entries.  ``kernel="composite"``: ``composite`` carries the structure (see ``_composite_args``);
+        theta = [parameter block | s2] (mode 0) or [log free parameters | log sigma] (mode 1); no dF/dZ."""
         N, d = X.shape
         M = Z.shape[0]
         for t, n in ((X, "X"), (y, "y"), (Z, "Z"), (theta, "theta")):
             self._chk(t, n)
-        if theta.numel() != d + 2:
-            raise ValueError("theta has %d entries, expected d + 2 = %d" % (theta.numel(), d + 2))
-        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
-        if nbytes == 0:
-            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
-        key = "small"
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)  # zeroed once: the sync words
-            self._ws[key] = ws
+        is_comp = _kernel_id(kernel) == _kernel_id("composite")
+        if is_comp != (composite is not None):
+            raise ValueError("composite= goes with kernel='composite'")
+        nout = self.small_out_len(d, mode, composite)
+        if theta.numel() != nout - 3:
+            raise ValueError("theta has %d entries, expected %d" % (theta.numel(), nout - 3))
+        ws = self._small_ws(N, M, d)
         if out is None:
-            out, info = self.small_result(d)
+            out, info = self.small_result(nout - 5)
         else:
-            info = out[d + 5:d + 6].view(torch.int32)[:1]
+            info = out[nout:nout + 1].view(torch.int32)[:1]
+        if is_comp:
+            if want_gz:
+                raise ValueError("the single-launch path has no dF/dZ for composite kernels")
+            cargs = self._composite_args(composite, bool(mode))
+            st = self.lib.sgp_small_eval_composite(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), *cargs, N, M, d,
+                                                   float(jitter), int(mode), 1 if want_grad else 0, self._ptr(out),
+                                                   C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
+            _lib.check("sgp_small_eval_composite", st)
+            return out, None, info
         gz = self.empty(M, d) if (want_grad and want_gz) else None
         st = self.lib.sgp_small_eval(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), N, M, d, _kernel_id(kernel),
                                      float(jitter), int(mode), 1 if want_grad else 0, self._ptr(out), self._ptr(gz),
@@ -308,13 +345,7 @@ class HipEngine:
         S = thetas.shape[0]
         if thetas.shape[1] != d + 2:
             raise ValueError("thetas must be S x (d + 2)")
-        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
-        if nbytes == 0:
-            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
-        ws = self._ws.get("small")
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
-            self._ws["small"] = ws
+        ws = self._small_ws(N, M, d)
         outs = self.empty(S, d + 5)
         gz = self.empty(S, M, d) if (want_grad and want_gz) else None
         infos = torch.zeros(S, dtype=torch.int32, device=self.device)
@@ -327,36 +358,39 @@ class HipEngine:
         return outs, gz, infos
 
     def small_nuts(self, X, y, Z, q0, n_tune, n_draws, seed, jitter=1e-6, kernel="rbf", max_treedepth=10, step_scale=0.25,
-                   target_accept=0.8):
-        """The whole NUTS run in one persistent launch (sgp_small_nuts).  Returns dict(samples [n_draws, d + 2] unconstrained,
-        stats [n_draws, 8], seconds [n_draws], evaluations, draws, info) as host tensors / ints (synchronises)."""
+                   target_accept=0.8, composite=None):
+        """The whole NUTS run in one persistent launch (sgp_small_nuts / sgp_small_nuts_composite).  Returns dict(samples
+        [n_draws, ndim] unconstrained, stats [n_draws, 8], seconds [n_draws], evaluations, draws, info) as host tensors /
+        ints (synchronises).  ndim = d + 2, or the composite kernel's free parameters + 1."""
         N, d = X.shape
         M = Z.shape[0]
         for t, n in ((X, "X"), (y, "y"), (Z, "Z")):
             self._chk(t, n)
-        nd = d + 2
+        is_comp = _kernel_id(kernel) == _kernel_id("composite")
+        if is_comp != (composite is not None):
+            raise ValueError("composite= goes with kernel='composite'")
+        nout = self.small_out_len(d, 1, composite)
+        nd = nout - 3
         q0d = torch.as_tensor([float(v) for v in q0], dtype=torch.float64).to(self.device)
         if q0d.numel() != nd:
-            raise ValueError("q0 has %d entries, expected d + 2 = %d" % (q0d.numel(), nd))
-        nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
-        if nbytes == 0:
-            raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
-        ws = self._ws.get("small")
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
-            self._ws["small"] = ws
+            raise ValueError("q0 has %d entries, expected %d" % (q0d.numel(), nd))
+        ws = self._small_ws(N, M, d)
         cols = int(self.lib.sgp_small_nuts_stat_cols())
         samples = self.empty(n_draws, nd)
         stats = torch.zeros(n_draws * cols, dtype=torch.float64, device=self.device)
         counters = torch.zeros(2, dtype=torch.int64, device=self.device)
-        theta, out = self.empty(nd), self.empty(d + 5)
+        theta, out = self.empty(nd), self.empty(nout)
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
-        st = self.lib.sgp_small_nuts(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(q0d), N, M, d, _kernel_id(kernel),
-                                     float(jitter), int(n_tune), int(n_draws), int(max_treedepth), float(step_scale),
-                                     float(target_accept), int(seed) & ((1 << 64) - 1), self._ptr(theta), self._ptr(samples),
-                                     self._ptr(stats), C.c_void_p(counters.data_ptr()), self._ptr(out),
-                                     C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
-        _lib.check("sgp_small_nuts", st)
+        head = (self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(q0d))
+        tail = (float(jitter), int(n_tune), int(n_draws), int(max_treedepth), float(step_scale), float(target_accept),
+                int(seed) & ((1 << 64) - 1), self._ptr(theta), self._ptr(samples), self._ptr(stats),
+                C.c_void_p(counters.data_ptr()), self._ptr(out), C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(),
+                self._stream())
+        if is_comp:
+            cargs = self._composite_args(composite, True)
+            _lib.check("sgp_small_nuts_composite", self.lib.sgp_small_nuts_composite(*head, *cargs, N, M, d, *tail))
+        else:
+            _lib.check("sgp_small_nuts", self.lib.sgp_small_nuts(*head, N, M, d, _kernel_id(kernel), *tail))
         h = stats.to("cpu")
         c = counters.to("cpu")
         res = {"samples": samples.to("cpu"), "stats": h[: n_draws * (cols - 1)].reshape(n_draws, cols - 1),

@@ -349,12 +349,13 @@ def sample_nuts_device(target, n_samples: int, tune: int, seed: Optional[int] = 
                        step_scale=0.25, target_accept=0.8, max_treedepth=10) -> Trace:
     """``pm.sample(n_samples, tune=tune, chains=1)`` entirely on the GPU: one persistent launch (``sgp_small_nuts``) runs the
     sampler and every leapfrog's evaluation; theta, the momentum and the sampler state never visit the host (SURVEY section 8
-    f-1).  ``target`` is an ``HmcTarget`` whose bound takes the single-launch path (M <= 128, one rank).  Same algorithm and
+    f-1).  ``target`` is an ``HmcTarget`` or ``CompositeHmcTarget`` whose bound takes the single-launch path (M <= 128, one rank).  Same algorithm and
     random stream as ``NUTS(..., rng=SplitMix(seed))``; the trace has the surface the reference reads
     (``trace['ls']``, ``trace[i]``, ``get_sampler_stats('step_size' | 'perf_counter_diff')``)."""
     b = target.bound
     if not target.device_sampler_ok():
-        raise ValueError("the device sampler needs the single-launch path (M <= 128, d <= 16, stationary kernel, one rank)")
+        raise ValueError("the device sampler needs the single-launch path (M <= 128, one rank; stationary kernels d <= 16, "
+                         "composite kernels d <= 8)")
     nd = target.ndim
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
@@ -371,8 +372,9 @@ def sample_nuts_device(target, n_samples: int, tune: int, seed: Optional[int] = 
         raise RuntimeError("could not find a starting point with finite log-density" if start is None
                            else "the log-density is not finite at the supplied start")
     t0 = time.perf_counter()
+    extra = target.device_sampler_args() if hasattr(target, "device_sampler_args") else {}  # composite kernels: the structure
     r = b.engine.small_nuts(b.X, b.y, target.Z, q, tune, n_samples, rng.s, jitter=b.jitter, kernel=b.kernel,
-                            max_treedepth=max_treedepth, step_scale=step_scale, target_accept=target_accept)
+                            max_treedepth=max_treedepth, step_scale=step_scale, target_accept=target_accept, **extra)
     wall = time.perf_counter() - t0
     if r["info"] < 0:
         from .core import SgpTimeoutError

@@ -199,7 +199,7 @@ int sgp_bound_from_whitened_stats(const double* W, const double* u, const double
                                   double* Phibar, double* bbar, double* Kuubar, double* factors,
                                   const double* kuu_linv, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 
-/* ---- single-launch evaluation for small problems (M <= 128, d <= 16, stationary kernels) -------------------------
+/* ---- single-launch evaluation for small problems (M <= 128; stationary kernels d <= 16, composite d <= 8) -------------------------
  * The size class of the reference's own HMC runs (models/bayesian_sgpr_hmc.py:58-80,144-157: N ~ 250-1300, M = 100).
  * ONE cooperative kernel launch evaluates the bound and its gradient in the PyMC3 op order (A = L^-1 K_uf by blocked
  * substitution on the matrix cores; B = I + A A^T / s2), reading the hyper-parameters from DEVICE memory:
@@ -223,6 +223,23 @@ int sgp_small_eval(const double* X, int64_t ldx, const double* y, const double* 
                    const double* theta, int64_t N, int M, int d, int kernel_id, double jitter, int mode,
                    int want_grad, double* out, double* g_Z, int* info,
                    void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* The same launch for SGP_KERNEL_COMPOSITE (the reference's CO2 covariance, experiments/co2_bayesian_sgpr_hmc.py:107-149;
+ * d <= 8, no dF/dZ).  `structure` (HOST, SGP_COMP_LEN doubles) is a valid parameter block: it fixes the term / factor types
+ * and the value of every parameter the caller does not pass in theta.
+ *   mode SGP_SMALL_NATURAL : theta (device) = [parameter block (SGP_COMP_LEN) | s2]   out = [F | dF/d block (SGP_COMP_LEN, zero
+ *                            at the structural slots) | dF/ds2 | logmarg | trace]; the free_* arguments are ignored
+ *   mode SGP_SMALL_HMC     : theta (device) = [log of the n_free free parameters | log sigma]   out = [logp | dlogp/dtheta
+ *                            (n_free + 1) | logmarg | trace].  Free parameter k fills block slot free_slot[k] (HOST arrays;
+ *                            free_role[k] = 0: an amplitude slot, the parameter is the amplitude's standard deviation and the
+ *                            slot gets its square; 1: a lengthscale slot; 2: an aux slot) and carries the prior log-parameter ~
+ *                            Normal(0, free_prior_sd[k]); sigma ~ HalfNormal(1), log-transformed: the PyMC3 model of
+ *                            co2_bayesian_sgpr_hmc.py:99-158.  n_free <= 20.                                              */
+int sgp_small_eval_composite(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                             const double* theta, const double* structure, int n_free, const int* free_slot,
+                             const int* free_role, const double* free_prior_sd, int64_t N, int M, int d,
+                             double jitter, int mode, int want_grad, double* out, int* info,
+                             void* ws, size_t ws_bytes, sgp_stream_t stream);
 
 /* S evaluations in one launch (the same X, y, Z; S hyper-parameter sets): the theta-averaged loss of the reference's
  * alternating schedule (models/bayesian_sgpr_hmc.py:121-134).  thetas (S x (d + 2)), outs (S x (d + 5)), g_Z (S x M x d or
@@ -249,6 +266,16 @@ int sgp_small_nuts(const double* X, int64_t ldx, const double* y, const double* 
                    double step_scale, double target_accept, uint64_t seed, double* theta_scratch, double* samples,
                    double* stats, long long* counters, double* out, int* info,
                    void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* device-resident NUTS over the composite target of sgp_small_eval_composite (mode SGP_SMALL_HMC): q0, theta_scratch and the
+ * rows of `samples` have n_free + 1 entries (<= 18), `out` n_free + 4.                                                    */
+int sgp_small_nuts_composite(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                             const double* q0, const double* structure, int n_free, const int* free_slot,
+                             const int* free_role, const double* free_prior_sd, int64_t N, int M, int d,
+                             double jitter, int n_tune, int n_draws, int max_treedepth, double step_scale,
+                             double target_accept, uint64_t seed, double* theta_scratch, double* samples,
+                             double* stats, long long* counters, double* out, int* info,
+                             void* ws, size_t ws_bytes, sgp_stream_t stream);
 
 /* ---- streaming pass 2: gradients through Kuf -------------------------------------------------------
  * Kbar_uf = 2 Phibar Kuf + bbar y^T is formed tile by tile and contracted with dKuf/d(.) on the fly.
