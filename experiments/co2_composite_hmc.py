@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--tune", type=int, default=150)
     ap.add_argument("--max_treedepth", type=int, default=6, help="PyMC3 default is 10; the demo caps the work per draw")
     ap.add_argument("--seed", type=int, default=47)
+    ap.add_argument("--sampler", choices=("auto", "device", "host"), default="auto",
+                    help="device: the whole NUTS run in one persistent launch (sgp_small_nuts_composite; M <= 128); host: the tree "
+                         "logic in Python, one launch per leapfrog; auto: device when the target supports it")
     ap.add_argument("--map_steps", type=int, default=400, help="Adam steps on the log posterior before sampling (0 = start at the prior mean)")
     ap.add_argument("--map_lr", type=float, default=0.05)
     ap.add_argument("--jitter", type=float, default=1e-6,
@@ -83,8 +86,9 @@ def main():
             theta[k] += args.map_lr * (m1[k] / (1 - 0.9 ** it)) / (math.sqrt(m2[k] / (1 - 0.999 ** it)) + 1e-8)
     map_secs = time.time() - t_map
     t0 = time.time()
-    trace = ggp_amd.sample_nuts(target, n_samples=args.num_samples, tune=args.tune, seed=args.seed, start=theta,
-                                max_treedepth=args.max_treedepth)
+    on_device = args.sampler == "device" or (args.sampler == "auto" and target.device_sampler_ok())
+    sample = ggp_amd.sample_nuts_device if on_device else ggp_amd.sample_nuts
+    trace = sample(target, n_samples=args.num_samples, tune=args.tune, seed=args.seed, start=theta, max_treedepth=args.max_treedepth)
     wall = time.time() - t0
 
     # mixture predictive over the draws (models/bayesian_sgpr_hmc.py:198-231): per-draw mean / variance on the test months
@@ -102,7 +106,8 @@ def main():
     names = [n for n, _, _ in target.params] + ["sigma"]
     post = np.concatenate([trace["ls"], trace["sig_n"][:, None]], 1)
     out = {"config": "C2 CO2, composite covariance, NUTS", "data": data, "N_train": int(X.shape[0]), "num_inducing": M, "jitter": args.jitter,
-           "map_steps": args.map_steps, "map_secs": map_secs, "logp_after_map": lp_map, "num_samples": len(trace), "tune": args.tune, "max_treedepth": args.max_treedepth, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
+           "map_steps": args.map_steps, "map_secs": map_secs, "logp_after_map": lp_map, "sampler": "device-resident (one persistent launch)" if on_device else "host-driven (one launch per leapfrog)",
+           "single_launch_evaluations": bool(bound._small_ok(M)), "num_samples": len(trace), "tune": args.tune, "max_treedepth": args.max_treedepth, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
            "leapfrogs_per_s": trace.n_leapfrog / wall, "mean_step_size": float(trace.get_sampler_stats("step_size").mean()),
            "diverging": int(trace.get_sampler_stats("diverging").sum()),
            "posterior_mean": {n: float(v) for n, v in zip(names, post.mean(0))},

@@ -255,37 +255,146 @@ __device__ __forceinline__ void sm_hypers(const SmallArgs& a, SmHyp& h) {
   __syncthreads();
 }
 
-// k(a, b) k-bar accumulated into the per-lane sums of a composite kernel's parameter derivatives (static indexing: terms and
-// factors unrolled, guarded by the runtime structure)
-__device__ __forceinline__ void sm_comp_accum(const CompSpec& cs, const double* a, const double* b, int d, double kb,
-                                              double (&acc_amp)[SGP_COMP_MAX_TERMS], double (&acc_ls)[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS],
-                                              double (&acc_aux)[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS]) {
-  double delta[COMP_MAX_DIM];
-  double r2 = 0.0;
-  for (int j = 0; j < d; ++j) {
-    delta[j] = a[j] - b[j];
-    r2 = fma(delta[j], delta[j], r2);
-  }
+// ---- composite kernels, NE pairs (a, b_k) at a time -------------------------------------------------------------------
+// One switch per factor, then straight-line code over the NE pairs, so the exp / log / sin chains of different pairs
+// interleave: a lone wave per SIMD otherwise waits out every dependent fp64 instruction (pair-at-a-time comp_value() cost
+// 3.6 us per entry and thread, measured: 58 us for a 64 x 64 K_uu).  bco(k, j) = coordinate j of b_k.
+// F = factor value; with GRAD also dF/d ls and dF/d aux (formulas: comp_factor, sgp_composite.hpp).
+template <int NE, bool GRAD, class BF>
+__device__ __forceinline__ void sm_factor_vec(int ty, double ls, double aux, const double (&r2)[NE], const double* a, BF bco, int d,
+                                              double (&F)[NE], double (&DL)[NE], double (&DA)[NE]) {
+  const double il2 = 1.0 / (ls * ls), il = 1.0 / ls;
+  if (ty == SGP_FAC_EXPQUAD) {
 #pragma unroll
-  for (int t = 0; t < SGP_COMP_MAX_TERMS; ++t) {
-    if (t < cs.nterms) {
-      FacOut fo[SGP_COMP_MAX_FACTORS];
-      double prod = 1.0;
-#pragma unroll
-      for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f)
-        if (f < cs.nfac[t]) {
-          fo[f] = comp_factor(cs.type[t][f], cs.ls[t][f], cs.aux[t][f], r2, delta, d);
-          prod *= fo[f].F;
-        }
-      acc_amp[t] = fma(kb, prod, acc_amp[t]);
-#pragma unroll
-      for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f)
-        if (f < cs.nfac[t]) {
-          const double other = kb * cs.amp2[t] * (cs.nfac[t] == 2 ? fo[1 - f].F : 1.0);
-          acc_ls[t][f] = fma(other, fo[f].dls, acc_ls[t][f]);
-          acc_aux[t][f] = fma(other, fo[f].daux, acc_aux[t][f]);
-        }
+    for (int k = 0; k < NE; ++k) {
+      F[k] = exp(-0.5 * r2[k] * il2);
+      if (GRAD) { DL[k] = F[k] * r2[k] * il2 * il; DA[k] = 0.0; }
     }
+  } else if (ty == SGP_FAC_MATERN32) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double t = 1.7320508075688772 * sqrt(r2[k]) * il, e = exp(-t);
+      F[k] = (1.0 + t) * e;
+      if (GRAD) { DL[k] = t * t * e * il; DA[k] = 0.0; }
+    }
+  } else if (ty == SGP_FAC_MATERN52) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double t = 2.23606797749979 * sqrt(r2[k]) * il, e = exp(-t);
+      F[k] = (1.0 + t + t * t * (1.0 / 3.0)) * e;
+      if (GRAD) { DL[k] = t * t * (1.0 + t) * e * il * (1.0 / 3.0); DA[k] = 0.0; }
+    }
+  } else if (ty == SGP_FAC_RATQUAD) {
+    const double c = 0.5 * il2 / aux;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double w = fma(c, r2[k], 1.0), lw = log(w);
+      F[k] = exp(-aux * lw);
+      if (GRAD) {
+        const double iw = 1.0 / w;
+        DL[k] = F[k] * iw * r2[k] * il2 * il;
+        DA[k] = F[k] * ((w - 1.0) * iw - lw);
+      }
+    }
+  } else {  // SGP_FAC_PERIODIC
+    const double w = 3.141592653589793 / aux;
+    double S[NE], T[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) S[k] = T[k] = 0.0;
+    for (int j = 0; j < d; ++j) {
+      const double aj = a[j];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const double dl = aj - bco(k, j);
+        double sn, cs;
+        sincos(w * dl, &sn, &cs);
+        S[k] = fma(sn, sn, S[k]);
+        if (GRAD) T[k] = fma(2.0 * sn * cs, dl, T[k]);  // sin(2 w delta) delta
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      F[k] = exp(-0.5 * S[k] * il2);
+      if (GRAD) { DL[k] = F[k] * S[k] * il2 * il; DA[k] = 0.5 * F[k] * il2 * T[k] * w / aux; }
+    }
+  }
+}
+
+template <int NE, class BF>
+__device__ __forceinline__ void sm_comp_r2(const double* a, BF bco, int d, double (&r2)[NE]) {
+#pragma unroll
+  for (int k = 0; k < NE; ++k) r2[k] = 0.0;
+  for (int j = 0; j < d; ++j) {
+    const double aj = a[j];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double df = aj - bco(k, j);
+      r2[k] = fma(df, df, r2[k]);
+    }
+  }
+}
+
+// v[k] = k(a, b_k)
+template <int NE, class BF>
+__device__ __forceinline__ void sm_comp_value_vec(const CompSpec& cs, const double* a, BF bco, int d, double (&v)[NE]) {
+  double r2[NE], F[NE], term[NE];
+  sm_comp_r2<NE>(a, bco, d, r2);
+#pragma unroll
+  for (int k = 0; k < NE; ++k) v[k] = 0.0;
+#pragma unroll 1
+  for (int t = 0; t < cs.nterms; ++t) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) term[k] = cs.amp2[t];
+#pragma unroll 1
+    for (int f = 0; f < cs.nfac[t]; ++f) {
+      sm_factor_vec<NE, false>(cs.type[t][f], cs.ls[t][f], cs.aux[t][f], r2, a, bco, d, F, F, F);
+#pragma unroll
+      for (int k = 0; k < NE; ++k) term[k] *= F[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) v[k] += term[k];
+  }
+}
+
+// sum_k kb[k] dk(a, b_k)/d(parameter), handed per parameter slot of the block to emit(slot, this lane's sum): the loop
+// over terms stays a loop (one copy of the factor code), so the sums cannot live in statically indexed registers
+template <int NE, class BF, class EM>
+__device__ __forceinline__ void sm_comp_accum_vec(const CompSpec& cs, const double* a, BF bco, int d, const double (&kb)[NE], EM emit) {
+  double r2[NE];
+  sm_comp_r2<NE>(a, bco, d, r2);
+#pragma unroll 1
+  for (int t = 0; t < cs.nterms; ++t) {
+    const int base = 1 + 8 * t;
+    double F0[NE], L0[NE], A0[NE];
+    sm_factor_vec<NE, true>(cs.type[t][0], cs.ls[t][0], cs.aux[t][0], r2, a, bco, d, F0, L0, A0);
+    const double amp = cs.amp2[t];
+    double s_amp = 0.0, s_l0 = 0.0, s_a0 = 0.0;
+    if (cs.nfac[t] == 2) {
+      double F1[NE], L1[NE], A1[NE];
+      sm_factor_vec<NE, true>(cs.type[t][1], cs.ls[t][1], cs.aux[t][1], r2, a, bco, d, F1, L1, A1);
+      double s_l1 = 0.0, s_a1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const double k0 = kb[k] * F0[k], k1 = kb[k] * F1[k];
+        s_amp = fma(k0, F1[k], s_amp);
+        s_l0 = fma(k1, L0[k], s_l0);
+        s_a0 = fma(k1, A0[k], s_a0);
+        s_l1 = fma(k0, L1[k], s_l1);
+        s_a1 = fma(k0, A1[k], s_a1);
+      }
+      emit(base + 6, amp * s_l1);
+      emit(base + 7, amp * s_a1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        s_amp = fma(kb[k], F0[k], s_amp);
+        s_l0 = fma(kb[k], L0[k], s_l0);
+        s_a0 = fma(kb[k], A0[k], s_a0);
+      }
+    }
+    emit(base, s_amp);
+    emit(base + 3, amp * s_l0);
+    emit(base + 4, amp * s_a0);
   }
 }
 
@@ -544,8 +653,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     // 16 entries of the padded Kuu: row i, columns j0 + cstride * k (k = 0..15)
     auto kuu16 = [&](int i, int j0, int cstride, double (&v)[16]) {
       if (comp) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = comp_value(hyp.cs, zs[i], zs[j0 + cstride * k], d);
+        sm_comp_value_vec<16>(hyp.cs, zs[i], [&](int k, int q) { return zs[j0 + cstride * k][q]; }, d, v);
       } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
@@ -837,38 +945,34 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
   // =================================================================================================================
   // slab pipeline shared by the row workgroups (role 2) and the Kuu-adjoint workgroup (role 1)
   // contraction of kbar (in Y, dF/dK_uf of this slab) with dK/d(ls, sf2, Z); data rows in sl.xs (scaled), validity masks
-  auto contract = [&](const SlabRegs<NB16>& Y, int nvalid, double zscale) {
+  auto contract = [&](const SlabRegs<NB16>& Y, int nvalid, double zscale) __attribute__((always_inline)) {
     // nvalid: slab rows that are real ; zscale: 1 for K_uf, 2 for the symmetric K_uu (both arguments are inducing inputs)
     const int nl = 16 * w + l15;
     if (comp) {
-      // composite kernels: per-pair factor derivatives, summed per lane into (term, factor) slots, then over the workgroup
-      double am[SGP_COMP_MAX_TERMS], al[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS], ax[SGP_COMP_MAX_TERMS][SGP_COMP_MAX_FACTORS];
-#pragma unroll
-      for (int t = 0; t < SGP_COMP_MAX_TERMS; ++t) {
-        am[t] = 0.0;
-#pragma unroll
-        for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f) al[t][f] = ax[t][f] = 0.0;
-      }
-#pragma unroll
-      for (int pb = 0; pb < NB16; ++pb)
-#pragma unroll
-        for (int sq = 0; sq < 4; ++sq) {
-          const int m = 16 * pb + 4 * sq + l4;
-          const double kb = (nl < nvalid && m < M) ? Y.b[pb][sq] : 0.0;
-          sm_comp_accum(hyp.cs, sl.xs[nl], sl.zs[m], d, kb, am, al, ax);
+      // composite kernels: factor derivatives of 8 pairs at a time, summed over the wave per parameter slot
+      if (lane < SGP_COMP_LEN) sl.red[w][lane] = 0.0;
+      auto emit = [&](int slot, double v) {
+        v = wave_sum(v);
+        if (lane == 0) sl.red[w][slot] += v;
+      };
+      auto ysel = [&](int c, int h, int sq) -> double {  // Y.b[2 c + h][sq] for a run-time (wave-uniform) c: selects, no
+        double v = Y.b[h][sq];                             // dynamically indexed registers
+        if (c == 1) v = Y.b[2 + h][sq];
+        if constexpr (NB16 > 4) {
+          if (c == 2) v = Y.b[4 + h][sq];
+          if (c == 3) v = Y.b[6 + h][sq];
         }
+        return v;
+      };
+#pragma unroll 1
+      for (int c = 0; c < NB16 / 2; ++c) {  // column blocks 2 c, 2 c + 1 ; a loop: one copy of the factor code
+        double kb[8];
 #pragma unroll
-      for (int t = 0; t < SGP_COMP_MAX_TERMS; ++t) {
-        const double v = wave_sum(am[t]);
-        if (lane == 0) sl.red[w][1 + 8 * t] = v;
-#pragma unroll
-        for (int f = 0; f < SGP_COMP_MAX_FACTORS; ++f) {
-          const double vl = wave_sum(al[t][f]), vx = wave_sum(ax[t][f]);
-          if (lane == 0) {
-            sl.red[w][1 + 8 * t + 2 + 3 * f + 1] = vl;
-            sl.red[w][1 + 8 * t + 2 + 3 * f + 2] = vx;
-          }
+        for (int k = 0; k < 8; ++k) {
+          const int m = 32 * c + 4 * k + l4;
+          kb[k] = (nl < nvalid && m < M) ? ysel(c, k >> 2, k & 3) : 0.0;
         }
+        sm_comp_accum_vec<8>(hyp.cs, sl.xs[nl], [&](int k, int q) { return sl.zs[32 * c + 4 * k + l4][q]; }, d, kb, emit);
       }
       __syncthreads();
       if (tid >= 1 && tid < SGP_COMP_LEN && ((tid - 1) & 7) != 1 && ((tid - 1) & 7) != 2 && ((tid - 1) & 7) != 5)
@@ -954,7 +1058,9 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     // ---- forward: A = L^-1 K_uf for this workgroup's slabs, partial A A^T, A y, sum A o A, yy -----------------------
     // K_uf of a slab straight into the register layout (needs theta only: the first slab is assembled while the chain
     // workgroup is still factoring Kuu)
-    auto assemble = [&](int n0, SlabRegs<NB16>& Y) {
+    // always_inline: an out-of-line copy receives the register slab through memory -- and the one the compiler made for
+    // MP = 128 / composite faulted when reached from the persistent kernel's out-of-line evaluation call (cause not established)
+    auto assemble = [&](int n0, SlabRegs<NB16>& Y) __attribute__((always_inline)) {
       __syncthreads();
       for (int e = tid; e < SM_SLAB * (SM_MAXD + 1); e += 256) {
         const int r = e / (SM_MAXD + 1), j = e - r * (SM_MAXD + 1);
@@ -967,9 +1073,10 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       double r2[NB16][4];
       if (comp) {
 #pragma unroll
-        for (int pb = 0; pb < NB16; ++pb)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) r2[pb][s] = comp_value(hyp.cs, sl.xs[nl], sl.zs[16 * pb + 4 * s + l4], d);
+        for (int c = 0; c < NB16 / 4; ++c) {  // 16 pairs at a time: column blocks 4 c .. 4 c + 3
+          double (&v16)[16] = reinterpret_cast<double (&)[16]>(r2[4 * c]);
+          sm_comp_value_vec<16>(hyp.cs, sl.xs[nl], [&](int k, int q) { return sl.zs[64 * c + 4 * k + l4][q]; }, d, v16);
+        }
       } else {
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
@@ -1223,8 +1330,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       const int i = 64 + (e0 >> 3), j0 = 16 * (e0 & 7);
       double v[16];
       if (comp) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = comp_value(hyp.cs, sl.zs[i], sl.zs[j0 + k], d);
+        sm_comp_value_vec<16>(hyp.cs, sl.zs[i], [&](int k, int q) { return sl.zs[j0 + k][q]; }, d, v);
       } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;

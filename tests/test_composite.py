@@ -344,3 +344,38 @@ def test_composite_device_resident_nuts_matches_the_host_driven_sampler(engine):
     tr = ggp_amd.sample_nuts_device(tgt, 20, 30, seed=5, start=tgt.start(), max_treedepth=6)
     assert len(tr) == 20 and tr["ls"].shape == (20, tgt.ndim - 1) and np.all(tr["ls"] > 0)
     assert np.all(np.isfinite(tr.get_sampler_stats("logp")))
+
+
+@pytest.mark.gpu
+def test_composite_single_launch_two_tile_size_class(engine):
+    """64 < M <= 128 (two 64-wide tiles, two Kuu-adjoint workgroups): the launch against the oracle, the NUTS target against
+    the host chain rule over the materialised path, and a short device-resident run (this instantiation once faulted)."""
+    import ggp_amd
+    g = torch.Generator().manual_seed(4)
+    N, M = 634, 100
+    t = torch.linspace(0.0, 30.0, N, dtype=torch.float64)[:, None]
+    y = 0.15 * t[:, 0] + 0.3 * torch.sin(2 * math.pi * t[:, 0]) + 0.05 * torch.randn(N, dtype=torch.float64, generator=g)
+    y = (y - y[0]) / y.std()
+    Z = t[torch.linspace(0, N - 1, M).round().long()].clone()
+    X, yd, Zd = t.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    kern = ggp_amd.co2_kernel(0.5, 1.0, 5.0, 1.0, 3.0, 1.0, 0.5, 2.0, 0.1, 0.5)
+    blk = np.asarray(kern.block())
+    cb = ggp_amd.CollapsedBound(X, yd, kernel="composite", jitter=1e-6, engine=engine)
+    assert cb._small_ok(M)
+    F0, g0 = CO.vfe_composite_and_grads(t, y, Z, blk, 0.05, 1e-6)
+    F1, g1 = cb.value_and_grad(Zd, blk.tolist(), 1.0, 0.05)
+    assert abs(F1 - float(F0)) < 1e-8 * max(1.0, abs(float(F0)))
+    sl = CO.grad_slots(blk)
+    assert (g1["ls"][sl] - g0["block"][sl]).abs().max() < 1e-6 * max(1.0, float(g0["block"][sl].abs().max()))
+    assert abs(g1["s2"] - float(g0["s2"])) < 1e-6 * max(1.0, abs(float(g0["s2"])))
+    tgt = ggp_amd.CompositeHmcTarget(cb, Zd, ggp_amd.co2_kernel(), ggp_amd.CO2_LOG_PRIOR_SD)
+    th = [0.1] * tgt.ndim
+    lp1, gr1 = tgt.logp_and_grad(th)
+    cb.fused = False
+    lp2, gr2 = tgt.logp_and_grad(th)
+    cb.fused = True
+    assert abs(lp1 - lp2) < 1e-8 * max(1.0, abs(lp2))
+    assert np.max(np.abs(np.array(gr1) - np.array(gr2))) < 1e-6 * max(1.0, np.max(np.abs(gr2)))
+    r = engine.small_nuts(X, yd, Zd, np.array(th), 8, 8, 5, jitter=1e-6, kernel="composite", max_treedepth=4,
+                          **tgt.device_sampler_args())
+    assert r["info"] == 0 and r["draws"] == 16 and np.all(np.isfinite(r["samples"].numpy()))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Device time of the single-launch small-problem kernel (sgp_small_eval): K back-to-back launches between two events,
 and the host-visible time of one evaluation including the device-to-host copy of the result.
-    python3 tools/small_eval_bench.py            (SHAPES="500,1,50;634,1,128" to override)"""
+    python3 tools/small_eval_bench.py            (SHAPES="500,1,50;634,1,128" to override; KERNEL=co2: the composite CO2
+    covariance on the d = 1 shapes)"""
 import json
 import math
 import os
@@ -28,29 +29,39 @@ def main():
         X, y = X.to(eng.device), y.to(eng.device)
         th = torch.tensor([0.7 if d == 1 else 2.0] * d + [1.0, 0.09], dtype=torch.float64).to(eng.device)
         res = {"N": N, "d": d, "M": M}
-        for label, kw in (("value_us", dict(want_grad=False)), ("value_grad_us", dict(want_grad=True)),
-                          ("value_grad_Z_us", dict(want_grad=True, want_gz=True))):
-            out, info = eng.small_result(d)
+        cases = (("value_us", dict(want_grad=False)), ("value_grad_us", dict(want_grad=True)),
+                 ("value_grad_Z_us", dict(want_grad=True, want_gz=True)))
+        kern, ckw, nres = "rbf", {}, d
+        if os.environ.get("KERNEL", "rbf") == "co2":
+            if d != 1:
+                continue
+            blk = ggp_amd.co2_kernel(0.5, 1.0, 5.0, 1.0, 3.0, 1.0, 0.5, 2.0, 0.1, 0.5).block()
+            th = torch.tensor(blk + [0.09], dtype=torch.float64).to(eng.device)
+            kern, ckw, nres, cases = "composite", {"composite": {"structure": blk}}, len(blk) - 1, cases[:2]
+            res["kernel"] = "co2 composite"
+        for label, kw in cases:
+            kw = dict(kw, **ckw)
+            out, info = eng.small_result(nres)
             for _ in range(5):
-                eng.small_eval(X, y, Z, th, 1e-6, "rbf", mode=0, out=out, **kw)
+                eng.small_eval(X, y, Z, th, 1e-6, kern, mode=0, out=out, **kw)
             torch.cuda.synchronize()
             best = float("inf")
             for _ in range(3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(K):
-                    eng.small_eval(X, y, Z, th, 1e-6, "rbf", mode=0, out=out, **kw)
+                    eng.small_eval(X, y, Z, th, 1e-6, kern, mode=0, out=out, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) * 1e3 / K)
             res[label] = round(best, 2)
         # host-visible: launch + one D2H copy of [out | status]
-        out, info = eng.small_result(d)
+        out, info = eng.small_result(nres)
         best = float("inf")
         for _ in range(3):
             t0 = time.perf_counter()
             for _ in range(K):
-                eng.small_eval(X, y, Z, th, 1e-6, "rbf", mode=0, want_grad=True, out=out)
+                eng.small_eval(X, y, Z, th, 1e-6, kern, mode=0, want_grad=True, out=out, **ckw)
                 host = out.to("cpu")
             best = min(best, (time.perf_counter() - t0) / K * 1e6)
         res["value_grad_with_readback_us"] = round(best, 2)

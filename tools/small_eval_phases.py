@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the time of one sgp_small_eval launch goes: s_memrealtime stamps (100 MHz) of every workgroup's phases.
-    python3 tools/small_eval_phases.py            (SHAPE=N,d,M)"""
+    python3 tools/small_eval_phases.py            (SHAPE=N,d,M ; KERNEL=co2 for the composite CO2 covariance, d = 1)"""
 import ctypes as C
 import math
 import os
@@ -26,10 +26,15 @@ def main():
     Z = X[torch.randperm(N, generator=g)[:M]].clone().to(eng.device)
     X, y = X.to(eng.device), y.to(eng.device)
     th = torch.tensor([0.7 if d == 1 else 2.0] * d + [1.0, 0.09], dtype=torch.float64).to(eng.device)
+    kern, kw = "rbf", {}
+    if os.environ.get("KERNEL", "rbf") == "co2":
+        blk = ggp_amd.co2_kernel(0.5, 1.0, 5.0, 1.0, 3.0, 1.0, 0.5, 2.0, 0.1, 0.5).block()
+        th = torch.tensor(blk + [0.09], dtype=torch.float64).to(eng.device)
+        kern, kw = "composite", {"composite": {"structure": blk}}
     stamps = torch.zeros(67 * 16, dtype=torch.int64, device=eng.device)
     eng.lib.sgp_small_debug_stamps(C.c_void_p(stamps.data_ptr()))
     for _ in range(20):
-        eng.small_eval(X, y, Z, th, 1e-6, "rbf", mode=0, want_grad=True)
+        eng.small_eval(X, y, Z, th, 1e-6, kern, mode=0, want_grad=True, **kw)
     torch.cuda.synchronize()
     eng.lib.sgp_small_debug_stamps(C.c_void_p(0))
     s = stamps.cpu().reshape(67, 16)
