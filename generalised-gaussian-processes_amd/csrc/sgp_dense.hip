@@ -272,6 +272,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
   potrf_dataflow_body(A, ld, nb, ready, dinv_g, info, info_base, rhs, sol, Linv, sh, blockIdx.x, gridDim.x);
 }
 
+#ifdef SGP_POTRF_STAMPS
+extern "C" int sgp_debug_potrf_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_potrf_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
+
 // Flags / status words are cleared by a plain kernel, never hipMemsetAsync: with the Kuu chain replayed from a hipGraph
 // by a helper host thread while the main thread enqueues its own memsets, the runtime's memset nodes were seen to
 // leave stale words behind on ROCm 7.2 (a spurious abort flag, info = 0x0c0c0c0c).

@@ -266,6 +266,13 @@ constexpr int DF_SPIN_LIMIT = 1 << 24;
 constexpr int POTRF_TIMEOUT = SGP_INFO_TIMEOUT;
 constexpr int TLD = DB + 2;  // LDS stride of the T / X tile (16-byte aligned rows)
 
+#ifdef SGP_POTRF_STAMPS  // measurement build only (tools/potrf_phases.py): s_memrealtime stamps of the critical path
+__device__ unsigned long long g_potrf_stamps[64 * 16];
+#define SGP_PSTAMP(step, k) do { if (threadIdx.x == 0 && (step) < 64) g_potrf_stamps[(step) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SGP_PSTAMP(step, k) do { } while (0)
+#endif
+
 struct DfShared {
   union {
     struct { double As[GK][GLD]; double Bs[GK][GLD]; } mac;  // operand chunks of the rank-64 updates
@@ -465,7 +472,9 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
   // publish, then (off the critical path) the 64 x 64 block inverse -> Linv.  sh.Ts / sh.Sp are free on entry.
   auto diag_finish = [&](int jd, double (&x)[16]) __attribute__((always_inline)) {
     double* Ajj = A + (int64_t)jd * DB * (ld + 1);
+    SGP_PSTAMP(jd, 6);
     diag_factor64_fast(x, sh.Sp, sh.Lt, sh.prog, sh.rdiag3, sh.Dinv, &sh.bad, r, g);
+    SGP_PSTAMP(jd, 7);
     double* dst = Ajj + (int64_t)r * ld + 16 * g;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -480,6 +489,7 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
     }
     if (tid == 0 && sh.bad != 0 && *info == 0) *info = info_base + jd * DB + sh.bad;
     publish(tile_no(jd, jd));
+    SGP_PSTAMP(jd, 8);
     if (Linv) {
       // inverse of this diagonal block -> Linv, level 0 of tri_inverse().  The T tile holds S, the panel / operand
       // region holds the inverse.
@@ -541,10 +551,14 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
     zero_acc(accd);
     for (int p = 0; p < j; ++p) {
       if (!df_wait(ready + tile_no(i, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
-      if (!df_wait(ready + tile_no(j, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
       const double* Lip = A + (int64_t)i * DB * ld + (int64_t)p * DB;
+      // the diagonal tile's update first: it needs row i only, while for p = j - 1 the other operand of `acc`, tile
+      // (j, j - 1), is the X its owner publishes just before it starts to factor (j, j) -- what is still to do after
+      // that flag decides whether this item is ready when that factorization ends (stamps, tools/potrf_phases.py)
+      if (head) df_mac(Lip, Lip, ld, sh, accd);
+      if (!df_wait(ready + tile_no(j, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      if (head && p == j - 1) SGP_PSTAMP(i, 0);
       df_mac(Lip, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, sh, acc);
-      if (head) df_mac(Lip, Lip, ld, sh, accd);  // the diagonal tile's updates by the columns before j
     }
     acc_to_ts(acc);
     if (tid < 4) sh.prog[tid] = 0;
@@ -575,7 +589,9 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
         xd[2 * k + 1] = v[1];
       }
     }
+    if (head) SGP_PSTAMP(i, 1);
     if (!df_wait(ready + tile_no(j, j) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+    if (head) SGP_PSTAMP(i, 2);
     {  // L(j,j) -> Sp panels, block inverses -> Dinv
       const double* src = A + (int64_t)j * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
       const double* dg = dinv_g + (size_t)j * 1024;
@@ -624,9 +640,12 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
     } else {
       // X is published only after the update below: its stores drain while the MFMAs run (raising the flag first
       // meant waiting 1.2-1.9 us for the write-back on the critical path; the other tiles of column i need X much later)
+      SGP_PSTAMP(i, 3);
       __syncthreads();
       df_mac_lds(sh.Ts, accd, wi, wj, l15, l4);
+      SGP_PSTAMP(i, 4);
       publish(t);  // (barrier: everybody is done reading X)
+      SGP_PSTAMP(i, 5);
       acc_to_ts(accd);
       if (tid < 4) sh.prog[tid] = 0;
       if (tid == 0) sh.bad = 0;

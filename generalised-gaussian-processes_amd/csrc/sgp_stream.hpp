@@ -121,9 +121,8 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.nmb = p.Mp / TILE;
   const int64_t nblocks = p.sc_rows / TILE;
   int64_t nsb = 8 * ((TARGET_WGS + 8 * p.nmb - 1) / (8 * p.nmb));  // multiple of 8: one XCD per residue
-  if (nblocks / nsb < 2) {  // mid-size shards: one round of resident workgroups (one per CU when d > 8), 1309 -> 1213 us at C3
-    const int resident = p.DP <= 8 ? RESIDENT_WGS : RESIDENT_WGS / 2;
-    const int64_t one_round = 8 * ((resident + 8 * p.nmb - 1) / (8 * p.nmb));
+  if (nblocks / nsb < 2) {  // mid-size shards: one round of resident workgroups (two per CU), 1309 -> 1213 us at C3
+    const int64_t one_round = 8 * ((RESIDENT_WGS + 8 * p.nmb - 1) / (8 * p.nmb));
     if (one_round < nsb) nsb = one_round;
   }
   static const int nsb_override = getenv("SGP_KBAR_NSPLIT") ? atoi(getenv("SGP_KBAR_NSPLIT")) : 0;  // tuning knob

@@ -68,8 +68,24 @@ __device__ __forceinline__ double hprime_from_k(double kp, double r2) {
 
 // GZ: the derivative with respect to the inducing inputs is wanted (Adam steps); HMC leapfrogs keep Z fixed and skip
 // its 2 DP accumulate operations per element (GZ == (want_gz != 0))
+//
+// d > 8 (C3: d = 18): the one-pass epilogue keeps z~, df and up to 2 DP running sums per thread -- beside the 128
+// accumulator registers that leaves room for ONE workgroup per CU, i.e. one wave per SIMD in the GEMM.  For the RBF
+// profile dk'/dr2 = -k'/2 and k' itself sits in the materialised K'_fu the main loop has just streamed, so the
+// epilogue needs neither r2 nor exp(): pass A turns the C^T image in LDS into dF/dr2 in place (one coalesced load of k'
+// per element), pass B walks the dimensions eight at a time with the DP <= 8 register budget -> two workgroups per CU
+// for every d.  The Matern profiles need r2 and keep the one-pass epilogue (one workgroup per CU when d > 8).
+template <int DP, int KID>
+constexpr bool kbar_two_pass() {
+#ifdef SGP_AB_KBAR_TWO_PASS_ALL  // A/B (tools/ab_build.sh): the two-pass epilogue for every d
+  return KID == SGP_KERNEL_RBF;
+#else
+  return DP > 8 && KID == SGP_KERNEL_RBF;
+#endif
+}
+
 template <int DP, int KID, bool GZ>
-__global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
+__global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID>()) ? 2 : 1)) void kbar_contract_kernel(
     const double* __restrict__ Kfu, const double* __restrict__ Xs, const double* __restrict__ ys,
     const double* __restrict__ Zs, const double* __restrict__ Pb, const double* __restrict__ bb, double sf2,
     int64_t row0, int64_t nblocks, SplitMap bmap, int64_t N, int M, int Mp, int nmb, int want_gz, int accumulate,
@@ -193,8 +209,65 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
     }
 
     // ---- epilogue: two 64-row halves of C^T through LDS, thread <-> inducing column ----------------
-    double zrow[DP], gl[DP], gz[DP], gs;
     const bool first = nb == nb0;
+    if constexpr (kbar_two_pass<DP, KID>()) {
+      double gs = first ? 0.0 : gmine[(size_t)(2 * DP) * 256];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (wi == h) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Ct[u * 16 + l4 + 4 * r][wj * 64 + v * 16 + l15] = acc[u][v][r];
+        }
+        __syncthreads();
+        // pass A: C^T -> dF/dr2 in place (every thread rewrites only the 32 entries it reads); k' is zero in the padding
+        const int64_t nbase = row0 + r0 + h * 64 + half * 32;  // first of this thread's 32 (wave-uniform) data rows
+        const double* __restrict__ kcol = Ablk + (int64_t)(h * 64 + half * 32) * Mp + m0 + erow;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          const double kp = kcol[(int64_t)i * Mp];
+          const double kbar = 2.0 * sf2 * Ct[half * 32 + i][erow] + bbm * ys[nbase + i];  // dF/dK[m][n]
+          gs = fma(kbar, kp, gs);
+          Ct[half * 32 + i][erow] = -0.5 * sf2 * kbar * kp;                                // dF/d r2[m][n]
+        }
+        // pass B: the dimensions eight at a time
+        constexpr int DG = DP < 8 ? DP : 8;
+#pragma unroll 1
+        for (int j0 = 0; j0 < DP; j0 += DG) {
+          double zg[DG], gl[DG], gz[DG];
+          const bool fresh = first && h == 0;
+#pragma unroll
+          for (int k = 0; k < DG; ++k) {
+            zg[k] = Zs[(size_t)(m0 + erow) * DP + j0 + k];
+            gl[k] = fresh ? 0.0 : gmine[(size_t)(j0 + k) * 256];
+            gz[k] = (fresh || !GZ) ? 0.0 : gmine[(size_t)(DP + j0 + k) * 256];
+          }
+#pragma unroll 2
+          for (int i = 0; i < 32; ++i) {
+            const double* __restrict__ xq = Xs + (nbase + i) * DP + j0;  // -> scalar loads
+            const double E = Ct[half * 32 + i][erow];
+#pragma unroll
+            for (int k = 0; k < DG; ++k) {
+              const double df = zg[k] - xq[k];
+              const double t = E * df;
+              if constexpr (GZ) gz[k] += t;
+              gl[k] = fma(t, df, gl[k]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < DG; ++k) {
+            gmine[(size_t)(j0 + k) * 256] = gl[k];
+            if constexpr (GZ) gmine[(size_t)(DP + j0 + k) * 256] = gz[k];
+          }
+        }
+        __syncthreads();
+      }
+      gmine[(size_t)(2 * DP) * 256] = gs;
+    } else {
+    double zrow[DP], gl[DP], gz[DP], gs;
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       zrow[j] = Zs[(size_t)(m0 + erow) * DP + j];
@@ -248,6 +321,7 @@ __global__ __launch_bounds__(256, (DP <= 8 ? 2 : 1)) void kbar_contract_kernel(
       if (want_gz) gmine[(size_t)(DP + j) * 256] = gz[j];
     }
     gmine[(size_t)(2 * DP) * 256] = gs;
+    }
   }
 
   // ---- per-(split, mb) partials ----------------------------------------------------------------------
