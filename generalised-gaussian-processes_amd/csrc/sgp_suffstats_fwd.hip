@@ -188,35 +188,28 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   constexpr int boff = DIAG ? 0 : TILE;   // where the B-operand columns live in the LDS tile
   constexpr int NQ = (DIAG ? 1024 : 2048) / NT;  // 16-byte quads this thread moves per chunk
 
-  // staging role: quad q = tid + 256 i -> LDS row n = q / 128 (off-diagonal) or q / 64 (diagonal),
-  // 64 consecutive threads cover one contiguous 1 KB row segment of K'_fu.
-  int srow[NQ], scol[NQ];
-  int64_t goff[NQ];
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int q = tid + NT * i;
-    if (DIAG) {
-      srow[i] = q >> 6;
-      scol[i] = (q & 63) * 2;
-      goff[i] = (int64_t)srow[i] * Mp + I0 + scol[i];
-    } else {
-      srow[i] = q >> 7;
-      const int r = q & 127;
-      scol[i] = r < 64 ? r * 2 : TILE + (r - 64) * 2;
-      goff[i] = (int64_t)srow[i] * Mp + (r < 64 ? I0 + r * 2 : J0 + (r - 64) * 2);
-    }
-  }
+  // staging role: quad q = tid + NT i -> LDS row n = q / 128 (off-diagonal) or q / 64 (diagonal), 64 consecutive threads
+  // cover one contiguous 1 KB row segment of K'_fu.  Row n = row0 + RSTEP i and the column does not depend on i, so ONE
+  // 32-bit lane offset serves all NQ loads (scalar base per i) and ONE LDS address all NQ stores (immediate offsets): the
+  // 64-bit address pair and LDS address per quad this replaced had the kernel spill two registers, with a scratch reload and
+  // s_waitcnt vmcnt(0) at the top of the loop.  (Same-box A/B: 65.1-65.4 TF before, 65.2 after -- no measurable difference.)
+  constexpr int RSTEP = DIAG ? NT / 64 : NT / 128;  // LDS / chunk rows between consecutive quads of a thread
+  const int srow0 = DIAG ? (tid >> 6) : (tid >> 7);
+  const int rq = tid & 127;
+  const int scol0 = DIAG ? (tid & 63) * 2 : (rq < 64 ? rq * 2 : TILE + (rq - 64) * 2);
+  const unsigned goff0 = (unsigned)(srow0 * Mp + (DIAG ? I0 + scol0 : (rq < 64 ? I0 + rq * 2 : J0 + (rq - 64) * 2))) * 8u;  // bytes
   // Two register stages: the loads of chunk c+2 are issued before the MFMAs of chunk c and consumed
   // (written to LDS) after the MFMAs of chunk c+1 -- two MFMA phases of latency cover.
   d2 stA[NQ], stB[NQ];
   auto fetch = [&](int64_t c, d2 (&st)[NQ]) {
-    const double* base = Kfu + c * NB * Mp;
+    const char* base = reinterpret_cast<const char*>(Kfu + c * NB * Mp);  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) st[i] = *reinterpret_cast<const d2*>(base + goff[i]);
+    for (int i = 0; i < NQ; ++i) st[i] = *reinterpret_cast<const d2*>(base + (size_t)i * RSTEP * Mp * 8 + goff0);
   };
   auto stash = [&](int buf, const d2 (&st)[NQ]) {
+    double* dst = &Ks[buf][srow0][scol0];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) *reinterpret_cast<d2*>(&Ks[buf][srow[i]][scol[i]]) = st[i];
+    for (int i = 0; i < NQ; ++i) *reinterpret_cast<d2*>(dst + i * RSTEP * KROW) = st[i];
   };
 
   d4 acc[4][VB];
@@ -248,6 +241,9 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
       __builtin_amdgcn_s_setprio(0);
       return;
     }
+    // (A/B, same box, three alternations: reading the operands of k-step ks + 1 before the MFMAs of k-step ks issue --
+    // explicit double-buffered operand registers behind sched_barriers -- changes nothing, 65.2-65.5 TF either way: with two
+    // waves per SIMD the matrix pipe is fed by the partner wave whenever this one waits for LDS.)
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
       const double* kr = &Ks[buf][ks * 4 + l4][0];
@@ -267,13 +263,13 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
   if constexpr (GLDS) {
     // wave-uniform LDS bases of this thread's NQ row segments (lane l lands at base + 16 l bytes)
     auto dma = [&](int64_t c, int buf) {
-      const double* base = Kfu + c * NB * Mp;
+      const char* base = reinterpret_cast<const char*>(Kfu + c * NB * Mp);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const int qb = wave * 64 + NT * i;  // first quad of this wave's segment
         const int row = DIAG ? (qb >> 6) : (qb >> 7);
         const int col0 = DIAG ? 0 : (((qb & 127) < 64) ? 0 : TILE);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)i * RSTEP * Mp * 8 + goff0),
                                          (__attribute__((address_space(3))) void*)&Ks[buf][row][col0], 16, 0, 0);
       }
     };
