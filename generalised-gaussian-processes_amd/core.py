@@ -48,6 +48,28 @@ class SgpTimeoutError(RuntimeError):
 SGP_INFO_TIMEOUT = -7777
 
 
+def few_host_threads(fn):
+    """Decorator for the host-driven loops (training, sampling): the host side of a step is a handful of torch operations
+    on tensors with d + 2 ... M entries (raw-parameter transforms, a 4 x 4 Cholesky of q(log theta), optimizer updates).
+    With torch's default intra-op pool -- one thread per host core, 128-256 on the GPU boxes -- every such operation pays the
+    pool's wake-up, and the spinning workers starve the HIP runtime's own threads: a BayesianSVGP minibatch step took 37.6 ms
+    with 128 threads and 4.4 ms with one (`tools/bsvgp_rates.py`).  The cap (4) is lifted again when the loop returns."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        n = torch.get_num_threads()
+        if n <= 4:
+            return fn(*args, **kwargs)
+        torch.set_num_threads(4)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            torch.set_num_threads(n)
+
+    return wrapped
+
+
 def _world(group):
     if dist is None or not dist.is_available() or not dist.is_initialized():
         return 1

@@ -399,6 +399,12 @@ def sample_nuts_device(target, n_samples: int, tune: int, seed: Optional[int] = 
     return tr
 
 
+def _few_threads(fn):
+    from .core import few_host_threads  # (core imports nothing from this module)
+    return few_host_threads(fn)
+
+
+@_few_threads
 def sample_nuts(target, n_samples: int, tune: int, seed: Optional[int] = None, start: Optional[Sequence[float]] = None,
                 step_scale=0.25, target_accept=0.8, max_treedepth=10, progress: Optional[Callable[[int, dict], None]] = None,
                 group=None) -> Trace:

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeoutError
+from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeoutError, few_host_threads
 from .gp_shim import (ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, LazyPredictive,
                       MultivariateNormal, RBFKernel, ScaleKernel, TrainPrior, ZeroMean)
 from .hmc import Trace, sample_nuts, sample_nuts_device
@@ -77,6 +77,7 @@ class SparseGPR(ExactGP):
         eng = self._bound().engine
         return MultivariateNormal(mean, cov, variance=var, engine=eng if getattr(eng, "device", None) is not None and eng.device.type == "cuda" else None)
 
+    @few_host_threads
     def train_model(self, optimizer, combine_terms=True, n_restarts=10, max_steps=10000, num_steps=None, verbose=True):
         """Full-batch optimisation of -ELBO/N (reference models/sgpr.py:110-144); one list entry per step."""
         if num_steps is not None:
@@ -184,6 +185,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         elbo.model.base_covar_module.outputscale = hyper_sample['sig_f'] ** 2
         elbo.model.base_covar_module.base_kernel.lengthscale = hyper_sample['ls']
 
+    @few_host_threads
     def train_model(self, optimizer, max_steps=10000, hmc_scheduler=(200, 500, 1000, 1500), verbose=True,
                     num_tune_long=100, num_samples_long=20, num_tune_short=25, num_samples_short=10):
         """Alternates Adam on Z with NUTS on theta (reference models/bayesian_sgpr_hmc.py:88-158).
@@ -366,6 +368,7 @@ class StochasticVariationalGP(torch.nn.Module):
                                   self.inducing_inputs, self.variational_mean, self.chol_variational_covar, self,
                                   self._dev(x_batch), yb)
 
+    @few_host_threads
     def train_model(self, optimizer, train_loader, minibatch_size=100, num_epochs=25, combine_terms=True, verbose=False):
         """Minibatch Adam on -ELBO (reference models/svgp.py:88-127); one loss entry per minibatch."""
         losses = []
@@ -464,6 +467,7 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         return _SVGPBoundFn.apply(theta[1:-1], theta[0], theta[-1] ** 2, self.inducing_inputs, self.variational_mean,
                                   self.chol_variational_covar, self, self._dev(x_batch), self._dev(y_batch).reshape(-1))
 
+    @few_host_threads
     def train_model(self, optimizer, train_loader, minibatch_size=100, num_epochs=25, combine_terms=True):
         """Returns (epoch_losses, batch_losses) like the reference (:144-181)."""
         self.train()
@@ -476,13 +480,16 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
                 loss = 0.0
                 kl = self.log_theta.kl_per_point()
                 # the five bounds are enqueued back to back: no host round trip between them (their status words are read
-                # together, with the loss)
+                # together, with the loss).  (One HIP stream per bound was tried: 3.3-3.65 against 3.55 ms per step -- the step
+                # is bound by the host enqueueing 5 x ~40 launches, not by the device; tools/bsvgp_rates.py.)
                 self._pending_infos = []
                 es = []
+                xb = self._dev(x_batch[:, None] if x_batch.dim() == 1 else x_batch)  # one host-to-device copy per minibatch
+                yb = self._dev(y_batch).reshape(-1)
                 try:
                     for _ in range(self.num_hyper_samples):
                         lt = self.sample_variational_log_hyper(1).flatten()
-                        es.append(self._elbo_at(x_batch, y_batch, lt))
+                        es.append(self._elbo_at(xb, yb, lt))
                     infos = torch.cat(self._pending_infos).to("cpu") if self._pending_infos else torch.zeros(1, dtype=torch.int32)
                 finally:
                     self._pending_infos = None
