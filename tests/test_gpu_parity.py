@@ -714,3 +714,30 @@ def test_kernel_exp_accuracy(engine):
     big = ref > 1e-300
     assert np.max(np.abs(got[big] - ref[big]) / ref[big]) < 2.5e-16, np.max(np.abs(got[big] - ref[big]) / ref[big])
     assert np.all(np.abs(got[~big] - ref[~big]) <= 1e-300) and np.all(np.isfinite(got)) and np.all(got >= 0.0)
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
+    """The multi-rank path on hardware, as far as a 1-GPU box allows: bench.py under torch.distributed.run with two
+    ranks on cuda:0 (gloo carries the all-reduce of the packed statistics and of the gradients; RCCL refuses duplicate
+    devices), HIP engine in both processes, against the same job in one process -- F to 1e-9 relative (the shards' Phi are
+    summed in another order, and W = L^-1 Phi L^-T carries that rounding through cond(K_uu): 4e-11 observed), the leapfrog
+    path exercised as well.  (Throughput of such a run means nothing.)"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    rows = 131072
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--rows", str(rows)]
+    one = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, SGP_BENCH_BACKEND="gloo", SGP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "0", "--rows", str(rows)], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r2["config"]["ranks"] == 2 and r2["config"]["rows_per_rank"] == rows // 2
+    assert abs(r2["F"] - r1["F"]) < 1e-9 * abs(r1["F"]), (r1["F"], r2["F"])
+    assert r2["leapfrog_per_s"] > 0 and r2["value"] > 0
