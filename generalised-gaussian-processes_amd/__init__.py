@@ -4,7 +4,8 @@ The directory name follows the project naming (``generalised-gaussian-processes_
 valid Python identifier: import it through the repo-root shim ``ggp_amd`` (``import ggp_amd``).
 """
 from ._lib import KERNEL_IDS, SgpLibraryError, SgpStatusError, load_library  # noqa: F401
-from .composite import CO2_LOG_PRIOR_SD, CompositeHmcTarget, CompositeKernel, Factor, co2_kernel  # noqa: F401
+from .composite import (CO2_LOG_PRIOR_SD, CompositeBayesianSparseGPR_HMC, CompositeHmcTarget, CompositeKernel, Factor,  # noqa: F401
+                        co2_kernel)
 from .core import CollapsedBound, HmcTarget, NotPositiveDefiniteError, SgpTimeoutError, shard_rows  # noqa: F401
 from . import datasets, experiment_tools  # noqa: F401
 from .gp_shim import (BernoulliLikelihood, ExactMarginalLogLikelihood, GaussianLikelihood, InducingPointKernel, MaternKernel,  # noqa: F401

@@ -17,6 +17,7 @@ from __future__ import annotations
 import math
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from ._lib import COMP_LEN
@@ -201,3 +202,169 @@ class CompositeHmcTarget:
 
     def logp(self, theta):
         return self.logp_and_grad(theta)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's CO2 model class (experiments/co2_bayesian_sgpr_hmc.py:58-300): its own copy of BayesianSparseGPR_HMC with
+# the composite covariance -- warm start with Adam on every raw parameter, then Adam on Z alone against the bound averaged
+# over the current NUTS trace, with NUTS phases at the scheduled iterations.
+# ---------------------------------------------------------------------------------------------------------------------
+def _inv_softplus(v: float) -> float:
+    return v + math.log(-math.expm1(-v)) if v < 30.0 else v
+
+
+class _CompositeBoundFn(torch.autograd.Function):
+    """F(values, s2, Z) / N for a composite kernel; ``values`` = the free parameters in ``CompositeKernel.free_parameters()``
+    order (amplitudes as standard deviations).  Gradients from the HIP library (dF/d block -> chain rule to the values)."""
+
+    @staticmethod
+    def forward(ctx, values, s2, Z, model):
+        cb = model.bound
+        kern = model.kernel.with_values([float(v) for v in values.detach().tolist()])
+        need = any(ctx.needs_input_grad[:3])
+        if need:
+            Fv, g = cb.value_and_grad(Z.detach(), kern.block(), 1.0, float(s2), want_gz=bool(ctx.needs_input_grad[2]))
+            gv = []
+            for (_, slot, role), v in zip(model.params, values.detach().tolist()):
+                dF = float(g["ls"][slot])
+                gv.append(2.0 * v * dF if role == "amp" else dF)  # the block stores amp**2
+            ctx.g = (torch.tensor(gv, dtype=torch.float64), float(g["s2"]), g["Z"])
+        else:
+            Fv, _ = cb.value(Z.detach(), kern.block(), 1.0, float(s2))
+            ctx.g = None
+        ctx.N = cb.N
+        ctx.meta = (values.shape, values.device, Z.shape)
+        return torch.tensor(Fv / cb.N, dtype=torch.float64, device=values.device)
+
+    @staticmethod
+    def backward(ctx, gout):
+        gv, gs2, gz = ctx.g
+        vshape, vdev, zshape = ctx.meta
+        s = gout / ctx.N
+        out_v = (gv.to(vdev).reshape(vshape) * s) if ctx.needs_input_grad[0] else None
+        out_s = (torch.as_tensor(gs2, dtype=torch.float64, device=vdev) * s).reshape(()) if ctx.needs_input_grad[1] else None
+        out_z = (gz.reshape(zshape) * s.to(gz.device)) if ctx.needs_input_grad[2] else None
+        return out_v, out_s, out_z, None
+
+
+class CompositeBayesianSparseGPR_HMC(torch.nn.Module):  # noqa: N801  (after the reference's class name)
+    """Collapsed sparse GP regression with a sum-of-products covariance, hyper-parameters sampled by NUTS at scheduled
+    iterations -- the class of experiments/co2_bayesian_sgpr_hmc.py:58-300 on the HIP core.
+
+    Parameters (all learnable in the warm start): ``raw_values`` (softplus -> the kernel's free parameters, amplitudes as
+    standard deviations), ``raw_noise`` (softplus -> noise variance, + 1e-4 as GPyTorch's GaussianLikelihood) and
+    ``inducing_points``.  ``train_model`` returns (losses, trace_hyper, trace_step_size, trace_perf_time) like the reference
+    (:186-253); ``train_fixed_model`` is its HMC-only run (:257-277, 500 tune / 100 draws)."""
+
+    def __init__(self, train_x, train_y, kernel: CompositeKernel, Z_init, log_prior_sd: Optional[dict] = None, engine=None,
+                 jitter: float = 1e-6, noise: float = 0.1, seed: Optional[int] = None):
+        super().__init__()
+        if train_x.dim() == 1:
+            train_x = train_x[:, None]
+        self.bound = CollapsedBound(train_x, train_y, kernel="composite", jitter=jitter, engine=engine)
+        self.kernel = kernel
+        self.params = kernel.free_parameters()
+        self.log_prior_sd = dict(log_prior_sd or {})
+        dev = self.bound.engine.device
+        self.raw_values = torch.nn.Parameter(torch.tensor([_inv_softplus(v) for v in kernel.values()], dtype=torch.float64))
+        self.raw_noise = torch.nn.Parameter(torch.tensor(_inv_softplus(max(noise - 1e-4, 1e-6)), dtype=torch.float64))
+        Z = torch.as_tensor(Z_init, dtype=torch.float64)
+        self.inducing_points = torch.nn.Parameter((Z[:, None] if Z.dim() == 1 else Z).clone().to(dev))
+        self._seed, self._n_hmc_calls = seed, 0
+        self.device_sampler = True
+
+    # ------------------------------------------------------------------ parameters
+    def values(self) -> torch.Tensor:
+        return torch.nn.functional.softplus(self.raw_values)
+
+    def noise(self) -> torch.Tensor:
+        return torch.nn.functional.softplus(self.raw_noise) + 1e-4
+
+    def current_kernel(self) -> CompositeKernel:
+        return self.kernel.with_values([float(v) for v in self.values().detach().tolist()])
+
+    def freeze_kernel_hyperparameters(self):
+        self.raw_values.requires_grad = False
+        self.raw_noise.requires_grad = False
+
+    def update_model_to_hyper(self, hyper_sample):
+        """Set kernel parameters and noise to one draw of the trace (reference :162-184); period lengths stay fixed."""
+        with torch.no_grad():
+            vals = np.asarray(hyper_sample["ls"], dtype=np.float64)
+            self.raw_values.copy_(torch.tensor([_inv_softplus(float(v)) for v in vals], dtype=torch.float64))
+            self.raw_noise.copy_(torch.tensor(_inv_softplus(max(float(hyper_sample["sig_n"]) ** 2 - 1e-4, 1e-12)), dtype=torch.float64))
+
+    # ------------------------------------------------------------------ bound
+    def neg_bound_per_datum(self):
+        return -_CompositeBoundFn.apply(self.values(), self.noise(), self.inducing_points, self)
+
+    def sample_optimal_variational_hyper_dist(self, n_samples, Z_opt, tune, sampler_params=None):
+        """NUTS over the log-parameters with Z fixed (reference :99-160).  Starts at the current parameter values."""
+        from .hmc import sample_nuts, sample_nuts_device
+        Z = torch.as_tensor(np.asarray(Z_opt), dtype=torch.float64)
+        target = CompositeHmcTarget(self.bound, Z, self.current_kernel(), self.log_prior_sd)
+        start = [math.log(float(v)) for v in self.values().detach().tolist()] + [0.5 * math.log(float(self.noise().detach()))]
+        scale = 0.25 if not sampler_params else sampler_params.get("step_scale", 0.25)
+        seed = None if self._seed is None else self._seed + self._n_hmc_calls
+        self._n_hmc_calls += 1
+        fn = sample_nuts_device if (self.device_sampler and target.device_sampler_ok()) else sample_nuts
+        return fn(target, n_samples, tune, seed=seed, start=start, step_scale=scale)
+
+    def train_model(self, optimizer, max_steps=10000, hmc_scheduler=(200, 500, 1000, 1500), verbose=False,
+                    num_tune_long=200, num_samples_long=50, num_tune_short=25, num_samples_short=10):
+        from .core import few_host_threads
+        return few_host_threads(self._train_model)(optimizer, max_steps, list(hmc_scheduler), verbose, num_tune_long,
+                                                    num_samples_long, num_tune_short, num_samples_short)
+
+    def _train_model(self, optimizer, max_steps, hmc_scheduler, verbose, num_tune_long, num_samples_long, num_tune_short,
+                     num_samples_short):
+        self.train()
+        losses, trace_hyper, trace_step_size, trace_perf_time = [], None, [], []
+        for n_iter in range(max_steps):
+            optimizer.zero_grad()
+            if n_iter < hmc_scheduler[0]:  # warm start: every raw parameter
+                loss = self.neg_bound_per_datum()
+                losses.append(loss.item())
+                loss.backward()
+                optimizer.step()
+                continue
+            self.freeze_kernel_hyperparameters()
+            if trace_hyper is not None:  # the bound averaged over the current trace, differentiable in Z only
+                loss = 0.0
+                for i in range(len(trace_hyper)):
+                    self.update_model_to_hyper(trace_hyper[i])
+                    loss = loss + self.neg_bound_per_datum() / len(trace_hyper)
+                if verbose:
+                    print('Iter %d/%d - Loss: %.3f ' % (n_iter, max_steps, loss.item()))
+                losses.append(loss.item())
+                loss.backward()
+                optimizer.step()
+            if n_iter in hmc_scheduler:
+                Z_opt = self.inducing_points.detach().cpu().numpy()
+                long_phase = n_iter in (hmc_scheduler[0], hmc_scheduler[-1])
+                trace_hyper = self.sample_optimal_variational_hyper_dist(num_samples_long if long_phase else num_samples_short, Z_opt,
+                                                                         num_tune_long if long_phase else num_tune_short)
+                trace_step_size.append(trace_hyper.get_sampler_stats('step_size')[0])
+                trace_perf_time.append(trace_hyper.get_sampler_stats('perf_counter_diff').sum())
+        return losses, trace_hyper, trace_step_size, trace_perf_time
+
+    def train_fixed_model(self, num_tune=500, num_samples=100):
+        """NUTS over the hyper-parameters with Z fixed at its current value (reference :257-277)."""
+        trace = self.sample_optimal_variational_hyper_dist(num_samples, self.inducing_points.detach().cpu().numpy(), num_tune)
+        return trace, [trace.get_sampler_stats('step_size')[0]], [trace.get_sampler_stats('perf_counter_diff').sum()]
+
+    # ------------------------------------------------------------------ predictive
+    def posterior_predictive(self, test_x, full_cov=False):
+        """(mean, variance[, covariance]) of y* at test_x, observation noise included (reference :283-300)."""
+        with torch.no_grad():
+            mean, var, cov = self.bound.predict(test_x, self.inducing_points.detach(), self.current_kernel().block(), 1.0,
+                                                float(self.noise()), pred_noise=True, full_cov=full_cov)
+        return (mean, var, cov) if full_cov else (mean, var)
+
+    def mixture_posterior_predictive(self, test_x, trace_hyper):
+        """One (mean, variance) per draw of the trace (reference :302-340); the model is left at the last draw."""
+        out = []
+        for i in range(len(trace_hyper)):
+            self.update_model_to_hyper(trace_hyper[i])
+            out.append(self.posterior_predictive(test_x))
+        return out

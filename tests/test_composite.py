@@ -379,3 +379,77 @@ def test_composite_single_launch_two_tile_size_class(engine):
     r = engine.small_nuts(X, yd, Zd, np.array(th), 8, 8, 5, jitter=1e-6, kernel="composite", max_treedepth=4,
                           **tgt.device_sampler_args())
     assert r["info"] == 0 and r["draws"] == 16 and np.all(np.isfinite(r["samples"].numpy()))
+
+
+# ---- the reference's CO2 model class with the alternating schedule --------------------------------------------------
+def _keeling(n=240, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.linspace(0.0, 20.0, n, dtype=torch.float64)[:, None]
+    y = 0.15 * t[:, 0] + 0.3 * torch.sin(2 * math.pi * t[:, 0]) + 0.05 * torch.randn(n, dtype=torch.float64, generator=g)
+    return t, (y - y[0]) / y.std()
+
+
+@pytest.mark.gpu
+def test_composite_model_class_gradients_match_finite_differences(engine):
+    """-F/N of ``CompositeBayesianSparseGPR_HMC`` (experiments/co2_bayesian_sgpr_hmc.py:58-98 upstream): autograd through the
+    raw softplus parameters, the noise and Z against central differences of the same loss."""
+    import ggp_amd
+    t, y = _keeling()
+    model = ggp_amd.CompositeBayesianSparseGPR_HMC(t.to(engine.device), y.to(engine.device), ggp_amd.co2_kernel(0.5, 1.0, 5.0, 1.0, 3.0, 1.0, 0.5, 2.0, 0.1, 0.5),
+                                                   t[::12].clone(), ggp_amd.CO2_LOG_PRIOR_SD, engine=engine, noise=0.05)
+    loss = model.neg_bound_per_datum()
+    loss.backward()
+    g_raw, g_noise, g_Z = model.raw_values.grad.clone(), float(model.raw_noise.grad), model.inducing_points.grad.clone().cpu()
+
+    def at(param, idx, h):
+        with torch.no_grad():
+            old = param.view(-1)[idx].clone()
+            param.view(-1)[idx] = old + h
+            v = float(model.neg_bound_per_datum())
+            param.view(-1)[idx] = old
+        return v
+
+    for k in range(model.raw_values.numel()):
+        fd = (at(model.raw_values, k, 1e-5) - at(model.raw_values, k, -1e-5)) / 2e-5
+        assert abs(fd - float(g_raw[k])) < 2e-5 * max(1.0, abs(fd)), (k, fd, float(g_raw[k]))
+    fd = (at(model.raw_noise, 0, 1e-5) - at(model.raw_noise, 0, -1e-5)) / 2e-5
+    assert abs(fd - g_noise) < 2e-5 * max(1.0, abs(fd))
+    for k in (0, 7, 19):
+        fd = (at(model.inducing_points, k, 1e-5) - at(model.inducing_points, k, -1e-5)) / 2e-5
+        assert abs(fd - float(g_Z.view(-1)[k])) < 2e-5 * max(1.0, abs(fd)), (k, fd, float(g_Z.view(-1)[k]))
+
+
+@pytest.mark.gpu
+def test_composite_model_class_alternating_schedule_on_device(engine):
+    """Warm start (Adam on everything), then NUTS phases at the scheduled iterations with Adam on Z alone against the bound
+    averaged over the trace (experiments/co2_bayesian_sgpr_hmc.py:186-253 upstream), the HMC-only run (:257-277) and the
+    mixture predictive."""
+    import ggp_amd
+    t, y = _keeling()
+    model = ggp_amd.CompositeBayesianSparseGPR_HMC(t.to(engine.device), y.to(engine.device), ggp_amd.co2_kernel(), t[::12].clone(),
+                                                   ggp_amd.CO2_LOG_PRIOR_SD, engine=engine, seed=5)
+    opt = torch.optim.Adam(model.parameters(), lr=0.02)
+    raw0 = model.raw_values.detach().clone()
+    losses, trace, steps, perf = model.train_model(opt, max_steps=46, hmc_scheduler=(30, 36, 42), num_tune_long=30, num_samples_long=8,
+                                                   num_tune_short=10, num_samples_short=4)
+    assert len(losses) == 30 + 15 and all(math.isfinite(v) for v in losses)  # iteration 30 samples first, then 15 averaged steps
+    assert losses[29] < losses[0]                                            # the warm start optimises
+    assert not torch.equal(model.raw_values.detach(), raw0)                 # ... and moved the kernel parameters
+    assert len(trace) == 8 and len(steps) == 3 and len(perf) == 3 and all(s > 0 for s in steps)
+    assert not model.raw_values.requires_grad and model.inducing_points.requires_grad
+    assert trace["ls"].shape == (8, len(model.params)) and np.all(trace["ls"] > 0)
+    Z_after = model.inducing_points.detach().cpu().clone()
+    assert float((Z_after - t[::12]).abs().max()) > 0.0                      # Z kept moving in the frozen phase
+    tr2, st2, pf2 = model.train_fixed_model(num_tune=20, num_samples=6)
+    assert len(tr2) == 6 and st2[0] > 0 and pf2[0] > 0
+    tt = torch.linspace(20.0, 22.0, 25, dtype=torch.float64)[:, None].to(engine.device)
+    preds = model.mixture_posterior_predictive(tt, tr2)
+    assert len(preds) == 6 and preds[0][0].shape == (25,) and bool(torch.all(preds[0][1] > 0))
+    mean, var = model.posterior_predictive(tt)
+    assert torch.equal(mean, preds[-1][0]) and bool(torch.isfinite(mean).all())
+
+
+def test_composite_model_class_parameter_transforms():
+    from ggp_amd.composite import _inv_softplus
+    for v in (1e-6, 1e-3, 0.3, 2.0, 40.0):
+        assert abs(math.log1p(math.exp(_inv_softplus(v))) - v) < 1e-12 * max(1.0, v) or v > 30.0
