@@ -48,6 +48,7 @@ def main():
     means = np.stack([m.cpu().numpy() for m, _ in preds])
     variances = np.stack([v.cpu().numpy() for _, v in preds])
     rmse = float(np.sqrt(np.mean((means.mean(0) - y_te) ** 2)) * std)
+    variances = np.maximum(variances, 1e-10)  # (a draw with amplitudes ~1e3 loses the 1e-4 noise floor to rounding; GPyTorch clamps too)
     logp = -0.5 * np.log(2 * np.pi * variances) - 0.5 * (y_te[None, :] - means) ** 2 / variances
     nlpd = float(-np.mean(np.log(np.mean(np.exp(logp), 0))) + math.log(std))
     rec = ggp_amd.experiment_tools.result_record(

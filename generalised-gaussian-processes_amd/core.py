@@ -128,6 +128,7 @@ class CollapsedBound:
         # 16 GiB super-chunks and pass 2 re-assembles.
         self._kfu = None
         self.kfu_budget_bytes = 64 << 30
+        self.factored_adjoint = True  # whitened order: pass 2 from L^-T Cw L^-1 applied factor by factor (sgp_suffstats_bwd_factored)
         self.fused = True          # single-launch path for small problems (M <= 128, one rank): sgp_small_eval
         self._small = None         # (pinned host theta, device theta, result buffer) of the single-launch path
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
@@ -235,10 +236,14 @@ class CollapsedBound:
             linv, _ = e.kuu_factor(Kuu, info=result[2])
             packed = e.suffstats_whitened(self.X, self.y, Z, ls, sf2, linv, self.kernel)
             self._allreduce_stats(packed, int(Z.shape[0]))
+            # with adjoints: also the whitened core Cw of Phibar, so that pass 2 applies L^-T Cw L^-1 factor by factor
+            factored = with_adjoints and self.factored_adjoint and hasattr(e, "suffstats_bwd_factored")
+            kw = {"want_cw": True} if factored else {}
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
-                          result=result, whitened=True)
+                          result=result, whitened=True, **kw)
             res["packed"] = packed
             res["kfu"] = None
+            res["linv"] = linv
             return res
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
         # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
@@ -370,8 +375,13 @@ class CollapsedBound:
                 return float("nan"), {"info": info}
         g = res["buf"][head:]
         # kappabar = dF/dkappa = -1 / (2 s2) needs nothing from the device (same value the tail writes to out)
-        e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
-                        self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
+        if res.get("Cw") is not None:
+            # whitened order: Phibar's cond(K_uu)-sized entries would cancel in Phibar K_uf -- its factors are applied instead
+            e.suffstats_bwd_factored(self.X, self.y, Z, ls, sf2, res["linv"], res["Cw"], s2, res["bbar"], -1.0 / (2.0 * float(s2)),
+                                     self.kernel, want_gz=want_gz, out=g)
+        else:
+            e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
+                            self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
         self._allreduce(g)
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
         o, info, host = self._fetch(res, upto=head + nh + 1)

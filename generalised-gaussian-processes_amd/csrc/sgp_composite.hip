@@ -224,10 +224,13 @@ size_t comp_bwd_workspace_bytes(int64_t N, int M, int d) {
   return c.used();
 }
 
-int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
-                       const double* Phibar, const double* bbar, double kappabar, int64_t N, int M, int d, double* g_blk,
-                       double* g_Z, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (!ws || ws_bytes < comp_bwd_workspace_bytes(N, M, d)) return SGP_ERR_WORKSPACE;
+// Phibar == nullptr: the factored form (Linv, Cw, s2), see sgp_composite.hpp
+static int comp_bwd_impl(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
+                         const double* Phibar, const double* Linv, const double* Cw, double s2, const double* bbar,
+                         double kappabar, int64_t N, int M, int d, double* g_blk, double* g_Z, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+  const bool factored = Phibar == nullptr;
+  if (!ws || ws_bytes < (factored ? comp_bwd_factored_workspace_bytes(N, M, d) : comp_bwd_workspace_bytes(N, M, d))) return SGP_ERR_WORKSPACE;
   const int Mp = padded_m(M);
   const int64_t Rc = chunk_rows(N);
   const GradGeom gg = grad_geom(N, M);
@@ -238,16 +241,32 @@ int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const doub
   double* P2 = c.take<double>((size_t)Mp * Mp);
   double* gpp = c.take<double>(nblk_max * SGP_COMP_LEN);
   double* gzp = c.take<double>(nblk_max * gg.RL * (size_t)M * d);
-  comp_pad2_kernel<<<grid_for_c((int64_t)Mp * Mp), 256, 0, st>>>(Phibar, M, Mp, 2.0, P2);
+  double* T1 = factored ? c.take<double>((size_t)Rc * Mp) : nullptr;
+  comp_pad2_kernel<<<grid_for_c((int64_t)Mp * Mp), 256, 0, st>>>(factored ? Cw : Phibar, M, Mp, factored ? 1.0 / s2 : 2.0, P2);
   int64_t blk0 = 0;
   for (int64_t r0 = 0; r0 < N; r0 += Rc) {
     const int64_t rn = (N - r0) < Rc ? (N - r0) : Rc;
     const int64_t rp = round_up64(rn, 64);
     comp_k_kernel<<<grid_for_c(rp * Mp), 256, 0, st>>>(X + r0 * ldx, ldx, Z, ldz, cs, d, rn, M, rp, Mp, 0.0, Kc);
-    GemmDesc g;  // Cc = Kc (2 Phibar)
-    g.A = Kc; g.lda = Mp; g.B = P2; g.ldb = Mp; g.C = Cc; g.ldc = Mp;
-    g.m = (int)rp; g.n = Mp; g.k = Mp;
-    gemm(g, st);
+    if (factored) {
+      GemmDesc g1;  // T1 = Kc L^-T      (rows a_n^T = (L^-1 k_n)^T)
+      g1.A = Kc; g1.lda = Mp; g1.B = Linv; g1.ldb = Mp; g1.tb = true; g1.C = T1; g1.ldc = Mp;
+      g1.m = (int)rp; g1.n = Mp; g1.k = Mp;
+      gemm(g1, st);
+      GemmDesc g2;  // Kc <- T1 (Cw / s2)   (the chunk of K_fu is not needed again: comp_grad_kernel re-evaluates the kernel)
+      g2.A = T1; g2.lda = Mp; g2.B = P2; g2.ldb = Mp; g2.C = Kc; g2.ldc = Mp;
+      g2.m = (int)rp; g2.n = Mp; g2.k = Mp;
+      gemm(g2, st);
+      GemmDesc g3;  // Cc = Kc L^-1
+      g3.A = Kc; g3.lda = Mp; g3.B = Linv; g3.ldb = Mp; g3.C = Cc; g3.ldc = Mp;
+      g3.m = (int)rp; g3.n = Mp; g3.k = Mp;
+      gemm(g3, st);
+    } else {
+      GemmDesc g;  // Cc = Kc (2 Phibar)
+      g.A = Kc; g.lda = Mp; g.B = P2; g.ldb = Mp; g.C = Cc; g.ldc = Mp;
+      g.m = (int)rp; g.n = Mp; g.k = Mp;
+      gemm(g, st);
+    }
     const int nb = (int)((rn + gg.blk_rows - 1) / gg.blk_rows);
     comp_grad_kernel<<<nb, 256, 0, st>>>(X + r0 * ldx, ldx, y + r0, Z, ldz, cs, Cc, Mp, bbar, rn, M, d, blk0, gg.MC, gg.RL,
                                          gg.blk_rows, gpp, g_Z ? gzp : nullptr);
@@ -256,6 +275,24 @@ int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const doub
   comp_grad_reduce_kernel<<<grid_for_c((int64_t)M * d, 256), 256, 0, st>>>(gpp, g_Z ? gzp : nullptr, blk0, blk0 * gg.RL, M, d, cs,
                                                                             kappabar * (double)N, 1.0, 0, g_blk, g_Z);
   return check_launch();
+}
+
+size_t comp_bwd_factored_workspace_bytes(int64_t N, int M, int d) {
+  return comp_bwd_workspace_bytes(N, M, d) + round_up64((int64_t)chunk_rows(N) * padded_m(M) * 8, 256) + 256;
+}
+
+int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
+                       const double* Phibar, const double* bbar, double kappabar, int64_t N, int M, int d, double* g_blk,
+                       double* g_Z, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!Phibar) return SGP_ERR_ARG;
+  return comp_bwd_impl(X, ldx, y, Z, ldz, cs, Phibar, nullptr, nullptr, 1.0, bbar, kappabar, N, M, d, g_blk, g_Z, ws, ws_bytes, st);
+}
+
+int comp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
+                                const double* Linv, const double* Cw, double s2, const double* bbar, double kappabar, int64_t N,
+                                int M, int d, double* g_blk, double* g_Z, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!Linv || !Cw || !(s2 > 0.0)) return SGP_ERR_ARG;
+  return comp_bwd_impl(X, ldx, y, Z, ldz, cs, nullptr, Linv, Cw, s2, bbar, kappabar, N, M, d, g_blk, g_Z, ws, ws_bytes, st);
 }
 
 size_t comp_kuu_bwd_workspace_bytes(int M, int d) {

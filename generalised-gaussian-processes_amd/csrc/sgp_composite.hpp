@@ -160,10 +160,18 @@ int comp_suffstats_fwd(const double* X, int64_t ldx, const double* y, const doub
                        int64_t N, int M, int d, double* Phi, double* b, double* yy, double* kappa, void* ws, size_t ws_bytes,
                        hipStream_t st);
 size_t comp_bwd_workspace_bytes(int64_t N, int M, int d);
+size_t comp_bwd_factored_workspace_bytes(int64_t N, int M, int d);
 // g_blk[SGP_COMP_LEN] and g_Z (may be null) are OVERWRITTEN; includes the kappa term kappabar * N on every amplitude
 int comp_suffstats_bwd(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
                        const double* Phibar, const double* bbar, double kappabar, int64_t N, int M, int d, double* g_blk,
                        double* g_Z, void* ws, size_t ws_bytes, hipStream_t st);
+// The same gradients from the FACTORED adjoint 2 Phibar = L^-T (Cw / s2) L^-1 (Linv: Mp x Mp from sgp_kuu_factor, Cw: M x M):
+// the three factors are applied to every K_fu chunk one after the other.  Phibar itself has entries of size cond(K_uu)
+// that cancel in Phibar K_uf; formed explicitly it left 1e-2 .. 1e-1 relative error on the gradients of the CO2 model at
+// cond 3e9 .. 5e10 (M = 64 .. 480), applied as factors 1e-5 (tests/studies/logp_noise.py).
+int comp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const CompSpec& cs,
+                                const double* Linv, const double* Cw, double s2, const double* bbar, double kappabar, int64_t N,
+                                int M, int d, double* g_blk, double* g_Z, void* ws, size_t ws_bytes, hipStream_t st);
 size_t comp_kuu_bwd_workspace_bytes(int M, int d);
 // ADDS the Kuu contribution (Kuubar used as a symmetric matrix)
 int comp_kuu_bwd(const double* Z, int64_t ldz, const CompSpec& cs, const double* Kuubar, int M, int d, double* g_blk,

@@ -52,6 +52,23 @@ __global__ void bwd_pad_sym_kernel(const double* __restrict__ P, int M, int Mp, 
   }
 }
 
+// Pb (Mp x Mp) <- scale * P (Mp x Mp in, rows / columns >= M zeroed): no symmetrisation (the factored mode's triangular L^-1)
+__global__ void bwd_pad_plain_kernel(const double* __restrict__ P, int M, int Mp, double scale, double* __restrict__ out) {
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    out[e] = (r < M && c < M) ? scale * P[e] : 0.0;
+  }
+}
+// out (Mp x Mp) <- scale * P (M x M in), zero padding
+__global__ void bwd_pad_small_kernel(const double* __restrict__ P, int M, int Mp, double scale, double* __restrict__ out) {
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    out[e] = (r < M && c < M) ? scale * P[(int64_t)r * M + c] : 0.0;
+  }
+}
+
 // dk'/dr2 from k' itself (and r2 for the Matern profiles): no second exp
 template <int KID>
 __device__ __forceinline__ double hprime_from_k(double kp, double r2) {
@@ -75,17 +92,19 @@ __device__ __forceinline__ double hprime_from_k(double kp, double r2) {
 // epilogue needs neither r2 nor exp(): pass A turns the C^T image in LDS into dF/dr2 in place (one coalesced load of k'
 // per element), pass B walks the dimensions eight at a time with the DP <= 8 register budget -> two workgroups per CU
 // for every d.  The Matern profiles need r2 and keep the one-pass epilogue (one workgroup per CU when d > 8).
-template <int DP, int KID>
+// KP: the streamed matrix IS K'_fu (false in the factored mode of sgp_suffstats_bwd_factored, where it is K'_fu L^-T Cw / s2 and
+// the epilogue must recompute k')
+template <int DP, int KID, bool KP>
 constexpr bool kbar_two_pass() {
 #ifdef SGP_AB_KBAR_TWO_PASS_ALL  // A/B (tools/ab_build.sh): the two-pass epilogue for every d
-  return KID == SGP_KERNEL_RBF;
+  return KP && KID == SGP_KERNEL_RBF;
 #else
-  return DP > 8 && KID == SGP_KERNEL_RBF;
+  return KP && DP > 8 && KID == SGP_KERNEL_RBF;
 #endif
 }
 
-template <int DP, int KID, bool GZ>
-__global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID>()) ? 2 : 1)) void kbar_contract_kernel(
+template <int DP, int KID, bool GZ, bool KP = true>
+__global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID, KP>()) ? 2 : 1)) void kbar_contract_kernel(
     const double* __restrict__ Kfu, const double* __restrict__ Xs, const double* __restrict__ ys,
     const double* __restrict__ Zs, const double* __restrict__ Pb, const double* __restrict__ bb, double sf2,
     int64_t row0, int64_t nblocks, SplitMap bmap, int64_t N, int M, int Mp, int nmb, int want_gz, int accumulate,
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID>()) ? 2 : 1
 
     // ---- epilogue: two 64-row halves of C^T through LDS, thread <-> inducing column ----------------
     const bool first = nb == nb0;
-    if constexpr (kbar_two_pass<DP, KID>()) {
+    if constexpr (kbar_two_pass<DP, KID, KP>()) {
       double gs = first ? 0.0 : gmine[(size_t)(2 * DP) * 256];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -420,7 +439,7 @@ static BwdWs carve_bwd(void* ws, const StreamPlan& p, bool need_kfu) {
   return w;
 }
 
-template <int DP>
+template <int DP, bool KP = true>
 static void launch_bwd(int kid, int grid, hipStream_t st, const double* Kfu, const BwdWs& w, double sf2, int64_t row0,
                        int64_t nblocks, int bps, int64_t N, int M, const StreamPlan& p, int want_gz, int accumulate) {
   const SplitMap bmap{{p.taper_b[0], p.taper_b[1], p.taper_b[2], p.taper_b[3]}, bps};
@@ -428,8 +447,8 @@ static void launch_bwd(int kid, int grid, hipStream_t st, const double* Kfu, con
   switch (kid) {
 #define SGP_BWD_LAUNCH(K) \
   do { \
-    if (want_gz) kbar_contract_kernel<DP, K, true><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); \
-    else kbar_contract_kernel<DP, K, false><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); \
+    if (want_gz) kbar_contract_kernel<DP, K, true, KP><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); \
+    else kbar_contract_kernel<DP, K, false, KP><<<grid, 256, 0, st>>>(SGP_BWD_ARGS); \
   } while (0)
     case SGP_KERNEL_RBF: SGP_BWD_LAUNCH(SGP_KERNEL_RBF); break;
     case SGP_KERNEL_MATERN32: SGP_BWD_LAUNCH(SGP_KERNEL_MATERN32); break;
@@ -512,6 +531,91 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
     timing_begin(TIMING_KBAR, st);
     launch(Kfu, r0, rows / TILE, r0 > 0 ? 1 : 0);
     timing_end(TIMING_KBAR, st);
+  }
+  const int64_t tot = (int64_t)M * d;
+  const int rg = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
+  bwd_reduce_kernel<<<rg < 1 ? 1 : rg, 256, 0, st>>>(w.gzpart, w.glpart, p.nsplit_b, p.nmb, p.Mp, M, p.DP, ka,
+                                                    kappabar * (double)N, g_ls, g_sf2, g_Z);
+  return check_launch();
+}
+
+// ---- factored pass 2 (the whitened evaluation order, ill-conditioned K_uu) -----------------------------------------------
+// 2 Phibar = L^-T (Cw / s2) L^-1 is never formed: its entries are of size cond(K_uu) and cancel in Phibar K_uf (1e-2 .. 1e-1
+// relative error on the gradients of the CO2 model at cond 3e9 .. 5e10, tests/studies/logp_noise.py).  Instead
+//     Kbar_fu = ((K_fu L^-T)(Cw / s2)) L^-1 + y bbar^T
+// one factor after the other: two plain GEMMs on the materialised K'_fu (these shards are small: N M <= 2^20 in
+// CollapsedBound), the third product inside kbar_contract_kernel (Pb = L^-1 / 2, epilogue recomputing k').
+static size_t bwd_factored_workspace_bytes(int64_t N, int M, int d) {
+  if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  StreamPlan p = make_stream_plan(N, M, d);
+  p.sc_rows = p.Npad;
+  const size_t fast = carve_bwd(nullptr, p, true).bytes + 2 * round_up64((int64_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp * 8 + 256, 256) +
+                      round_up64((int64_t)p.Mp * p.Mp * 8 + 256, 256);
+  const size_t comp = d <= COMP_MAX_DIM ? comp_bwd_factored_workspace_bytes(N, M, d) : 0;
+  return fast > comp ? fast : comp;
+}
+extern "C" size_t sgp_suffstats_bwd_factored_workspace_bytes(int64_t N, int M, int d) { return bwd_factored_workspace_bytes(N, M, d); }
+
+extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                          const double* inv_ls, double sf2, const double* kuu_linv, const double* Cw, double s2,
+                                          const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id,
+                                          double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
+                                          sgp_stream_t stream) {
+  if (!Z || !inv_ls || !kuu_linv || !Cw || !bbar || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d || !(s2 > 0.0))
+    return SGP_ERR_ARG;
+  if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  hipStream_t st = (hipStream_t)stream;
+  if (!ws || ws_bytes < bwd_factored_workspace_bytes(N, M, d)) return SGP_ERR_WORKSPACE;
+  if (kernel_id == SGP_KERNEL_COMPOSITE) {
+    CompSpec cs;
+    if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
+    fill_zero(g_sf2, 1, st);
+    return comp_suffstats_bwd_factored(X, ldx, y, Z, ldz, cs, kuu_linv, Cw, s2, bbar, kappabar, N, M, d, g_ls, g_Z, ws, ws_bytes, st);
+  }
+  StreamPlan p = make_stream_plan(N, M, d);
+  p.sc_rows = p.Npad;  // one super-chunk: the whole K'_fu is materialised
+  BwdWs w = carve_bwd(ws, p, true);
+  Carver c(static_cast<char*>(ws) + round_up64((int64_t)w.bytes, 256));
+  const size_t rows = (size_t)(p.Npad > 0 ? p.Npad : 1);
+  double* T1 = c.take<double>(rows * p.Mp);
+  double* T2 = c.take<double>(rows * p.Mp);
+  double* P2 = c.take<double>((size_t)p.Mp * p.Mp);
+
+  KernArgs ka;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  ka.sf2 = sf2;
+  ka.d = d;
+  stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
+  bwd_pad_plain_kernel<<<2048, 256, 0, st>>>(kuu_linv, M, p.Mp, 0.5, w.Pb);          // the kernel forms 2 sf2 (T2 Pb)
+  bwd_pad_small_kernel<<<2048, 256, 0, st>>>(Cw, M, p.Mp, 1.0 / s2, P2);
+  bwd_pad_vec_kernel<<<(p.Mp + 255) / 256, 256, 0, st>>>(bbar, M, p.Mp, w.bb);
+  const int want_gz = g_Z != nullptr;
+  const int grid = p.nmb * p.nsplit_b;
+  if (p.Npad > 0) {
+    stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, 0, p.Npad, N, M, w.Kfu, w.bpart, st);
+    GemmDesc g1;  // T1 = K'_fu L^-T   (kuu_linv is Mp x Mp: its padding rows hold an identity block that K'_fu's zero columns never meet)
+    g1.A = w.Kfu; g1.lda = p.Mp; g1.B = kuu_linv; g1.ldb = p.Mp; g1.tb = true; g1.C = T1; g1.ldc = p.Mp;
+    g1.m = (int)p.Npad; g1.n = p.Mp; g1.k = p.Mp;
+    gemm(g1, st);
+    GemmDesc g2;  // T2 = T1 (Cw / s2)
+    g2.A = T1; g2.lda = p.Mp; g2.B = P2; g2.ldb = p.Mp; g2.C = T2; g2.ldc = p.Mp;
+    g2.m = (int)p.Npad; g2.n = p.Mp; g2.k = p.Mp;
+    gemm(g2, st);
+  }
+  {
+    const int64_t nblocks = p.Npad / TILE;
+    int bps = (int)((nblocks + p.nsplit_b - 1) / p.nsplit_b);
+    if (bps < 1) bps = 1;
+    switch (p.DP) {
+      case 2: launch_bwd<2, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 4: launch_bwd<4, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 8: launch_bwd<8, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 16: launch_bwd<16, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 24: launch_bwd<24, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      default: launch_bwd<32, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+    }
   }
   const int64_t tot = (int64_t)M * d;
   const int rg = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);

@@ -602,7 +602,7 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
                       const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
                       double* Phibar, double* bbar, double* Kuubar, double* factors,
                       const double* kuu_linv, int* info, void* ws, size_t ws_bytes,
-                      sgp_stream_t stream, bool whitened) {
+                      sgp_stream_t stream, bool whitened, double* Cw_out = nullptr) {
   if ((!Kuu && !kuu_linv) || !Phi || !b || !yy || !kappa || !out || !info || M <= 0 || N < 0 || !(s2 > 0.0)) return SGP_ERR_ARG;
   if (whitened && !kuu_linv) return SGP_ERR_ARG;
   if (with_adjoints && (!Phibar || !bbar || !Kuubar)) return SGP_ERR_ARG;
@@ -682,6 +682,7 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     double* CS = w.M0;
     double* TT = w.M4;
     whitened_cs_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, w.M2, w.alpha, Mp, s2, CS);
+    if (Cw_out) crop_copy(CS, ld, Cw_out, M, M, M, st);  // C itself, before the sandwich (factored pass 2)
     GemmDesc t1;
     t1.A = CS; t1.lda = ld; t1.sA = (int64_t)mm; t1.B = w.M1; t1.ldb = ld; t1.sB = 0; t1.C = TT; t1.ldc = ld; t1.sC = (int64_t)mm;
     t1.m = Mp; t1.n = Mp; t1.k = Mp; t1.batch = 2; t1.klo_mask = 2;
@@ -718,6 +719,17 @@ extern "C" int sgp_bound_from_whitened_stats(const double* W, const double* u, c
                                              size_t ws_bytes, sgp_stream_t stream) {
   return bound_impl(nullptr, W, u, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info, ws,
                     ws_bytes, stream, true);
+}
+
+// as sgp_bound_from_whitened_stats, plus C = I - B^-1 - g g^T / s2^2 (M x M) for the factored pass 2
+// (sgp_suffstats_bwd_factored): 2 s2 Phibar = L^-T C L^-1 without ever forming Phibar's cond(K_uu)-sized entries
+extern "C" int sgp_bound_from_whitened_stats_ex(const double* W, const double* u, const double* yy, const double* kappa, double s2,
+                                                int64_t N, int M, int with_adjoints, double* out, double* Phibar, double* bbar,
+                                                double* Kuubar, double* factors, const double* kuu_linv, int* info, double* Cw_out,
+                                                void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (Cw_out && !with_adjoints) return SGP_ERR_ARG;
+  return bound_impl(nullptr, W, u, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info, ws,
+                    ws_bytes, stream, true, Cw_out);
 }
 
 // ---- whitened pass 1 -------------------------------------------------------------------------------------------

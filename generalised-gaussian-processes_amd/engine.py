@@ -225,11 +225,12 @@ class HipEngine:
         return ent
 
     def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None, kuu_info=None, result=None,
-              whitened=False):
+              whitened=False, want_cw=False):
         """Runs the O(M^3) tail on (already all-reduced) packed statistics.
 
         Returns dict(out=[8] device tensor, info=int32 device tensor, buf=the ``result_buffer`` both live in, and
-        when asked Phibar, bbar, Kuubar, factors).  Nothing is synchronised.  With ``kuu_linv`` (from ``kuu_factor``)
+        when asked Phibar, bbar, Kuubar, factors; ``want_cw`` (whitened order, with adjoints) adds Cw, the whitened core
+        of the adjoint that ``suffstats_bwd_factored`` takes).  Nothing is synchronised.  With ``kuu_linv`` (from ``kuu_factor``)
         the status word must already hold that call's status: pass ``result`` whose info word ``kuu_factor`` wrote,
         or ``kuu_info`` (copied in with one tiny launch).
         """
@@ -258,7 +259,11 @@ class HipEngine:
                  C.c_void_p(base + 8 * (M * M + M + 1)))
         tail = (float(s2), int(N), M, 1 if with_adjoints else 0, self._ptr(out), self._ptr(Phibar), self._ptr(bbar),
                 self._ptr(Kuubar), self._ptr(factors), self._ptr(kuu_linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
-        if whitened:
+        if whitened and want_cw and with_adjoints:
+            res["Cw"] = self.empty(M, M)
+            _lib.check("sgp_bound_from_whitened_stats_ex",
+                       self.lib.sgp_bound_from_whitened_stats_ex(*stats, *tail[:-3], self._ptr(res["Cw"]), *tail[-3:]))
+        elif whitened:
             _lib.check("sgp_bound_from_whitened_stats", self.lib.sgp_bound_from_whitened_stats(*stats, *tail))
         else:
             _lib.check("sgp_bound_from_stats", self.lib.sgp_bound_from_stats(self._ptr(Kuu), *stats, *tail))
@@ -428,6 +433,27 @@ class HipEngine:
             C.c_void_p(base + 8 * nh),
             C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_bwd", st)
+        return out
+
+    def suffstats_bwd_factored(self, X, y, Z, ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, kernel="rbf", want_gz=False,
+                               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``suffstats_bwd`` from the factored adjoint 2 s2 Phibar = L^-T Cw L^-1 (``kuu_linv`` from ``kuu_factor``, ``Cw``
+        from ``bound(..., whitened=True, want_cw=True)``): same packed gradients, without the cancellation of an explicit
+        Phibar on ill-conditioned K_uu."""
+        N, d = X.shape
+        M = Z.shape[0]
+        nh = self.hyper_len(kernel, d)
+        if out is None:
+            out = self.empty(nh + 1 + (M * d if want_gz else 0))
+        nbytes = self.lib.sgp_suffstats_bwd_factored_workspace_bytes(N, M, d)
+        ws = self._workspace("bwd_factored", nbytes)
+        base = out.data_ptr()
+        st = self.lib.sgp_suffstats_bwd_factored(
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(kuu_linv),
+            self._ptr(Cw), float(s2), self._ptr(bbar), float(kappabar), N, M, d, _kernel_id(kernel), C.c_void_p(base),
+            C.c_void_p(base + 8 * nh), C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(),
+            self._stream())
+        _lib.check("sgp_suffstats_bwd_factored", st)
         return out
 
     def kuu_bwd(self, Z, ls, sf2, Kuubar, grads: torch.Tensor, kernel="rbf", want_gz=False) -> torch.Tensor:

@@ -199,6 +199,14 @@ int sgp_bound_from_whitened_stats(const double* W, const double* u, const double
                                   double* Phibar, double* bbar, double* Kuubar, double* factors,
                                   const double* kuu_linv, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 
+/* The same call with one more output, Cw (M x M, DEVICE, may be NULL): C = I - B^-1 - g g^T / s2^2, the whitened core of the
+ * adjoint 2 s2 Phibar = L^-T C L^-1 -- what sgp_suffstats_bwd_factored takes instead of Phibar.  Needs with_adjoints = 1.   */
+int sgp_bound_from_whitened_stats_ex(const double* W, const double* u, const double* yy, const double* kappa,
+                                     double s2, int64_t N, int M, int with_adjoints, double* out,
+                                     double* Phibar, double* bbar, double* Kuubar, double* factors,
+                                     const double* kuu_linv, int* info, double* Cw,
+                                     void* ws, size_t ws_bytes, sgp_stream_t stream);
+
 /* ---- single-launch evaluation for small problems (M <= 128; stationary kernels d <= 16, composite d <= 8) -------------------------
  * The size class of the reference's own HMC runs (models/bayesian_sgpr_hmc.py:58-80,144-157: N ~ 250-1300, M = 100).
  * ONE cooperative kernel launch evaluates the bound and its gradient in the PyMC3 op order (A = L^-1 K_uf by blocked
@@ -290,6 +298,21 @@ int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y,
                       int64_t N, int M, int d, int kernel_id,
                       double* g_ls, double* g_sf2, double* g_Z,
                       void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* Pass 2 from the FACTORED adjoint, for the whitened evaluation order on ill-conditioned K_uu (inducing inputs closer than the
+ * lengthscale: the reference's CO2 model with M = 480 random training times, experiments/co2_bayesian_sgpr_hmc.py:384).
+ * Phibar = L^-T C L^-1 / (2 s2) has entries of size cond(K_uu) that cancel in Phibar K_uf: formed explicitly it leaves 1e-2 ..
+ * 1e-1 relative error on the gradients at cond 3e9 .. 5e10; applied to K_fu one factor after the other, 1e-5
+ * (tests/studies/logp_noise.py).  kuu_linv: Mp x Mp from sgp_kuu_factor, Cw: M x M from sgp_bound_from_whitened_stats_ex, bbar
+ * and kappabar as for sgp_suffstats_bwd; same outputs.  K_fu is materialised whole (meant for N M <= ~2^22).               */
+size_t sgp_suffstats_bwd_factored_workspace_bytes(int64_t N, int M, int d);
+int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y,
+                               const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                               const double* kuu_linv, const double* Cw, double s2,
+                               const double* bbar, double kappabar,
+                               int64_t N, int M, int d, int kernel_id,
+                               double* g_ls, double* g_sf2, double* g_Z,
+                               void* ws, size_t ws_bytes, sgp_stream_t stream);
+
 /* gradient through Kuu: ADDS sum(Kuubar o dKuu/d(.)) into g_ls, g_sf2, g_Z (g_Z may be NULL).
  * Kuubar is used as a symmetric matrix.  Replicated on every rank (call it after the all-reduce of
  * the streamed gradients, or on one rank before it).                                             */
