@@ -662,13 +662,10 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
   }
 
   if (factors) {
-    // G = LB^-1 L^-1 in M4 (both lower triangular): what sgp_predict needs
-    GemmDesc g;
-    g.A = w.M7; g.lda = ld; g.B = w.M1; g.ldb = ld; g.C = w.M4; g.ldc = ld;
-    g.m = Mp; g.n = Mp; g.k = Mp; g.khi_mask = 1; g.klo_mask = 2;
-    gemm(g, st);
+    // what sgp_predict needs: L^-1, LB^-1 and q.  The product G = LB^-1 L^-1 is deliberately NOT formed: on ill-conditioned
+    // K_uu its entries are of size sqrt(cond) and cancel in G k_u*; the predictive applies the two factors one after the other
     crop_copy(w.M1, ld, factors, M, M, M, st);
-    crop_copy(w.M4, ld, factors + (size_t)M * M, M, M, M, st);
+    crop_copy(w.M7, ld, factors + (size_t)M * M, M, M, M, st);
     crop_copy(w.q, 1, factors + (size_t)2 * M * M, 1, M, 1, st);
   }
   if (with_adjoints) {
@@ -871,8 +868,8 @@ extern "C" int sgp_predict(const double* Xs, int64_t ldxs, int64_t T, const doub
     a.A = Li; a.lda = Mp; a.B = Ks; a.ldb = Tp; a.C = As; a.ldc = Tp;
     a.m = Mp; a.n = Tp; a.k = Mp; a.khi_mask = 1;
     gemm(a, st);
-    GemmDesc b;
-    b.A = G; b.lda = Mp; b.B = Ks; b.ldb = Tp; b.C = Cm; b.ldc = Tp;
+    GemmDesc b;  // C = LB^-1 (L^-1 K_u*): the second slot of `factors` holds LB^-1
+    b.A = G; b.lda = Mp; b.B = As; b.ldb = Tp; b.C = Cm; b.ldc = Tp;
     b.m = Mp; b.n = Tp; b.k = Mp; b.khi_mask = 1;
     gemm(b, st);
     pred_cols_kernel<<<Tp / 64, 256, 0, st>>>(As, Cm, q, Mp, Tp, Tn, sf2, s2, pred_noise, mean + t0, var ? var + t0 : nullptr);

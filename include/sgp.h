@@ -157,7 +157,8 @@ int sgp_logdiag_sum(const double* L, int64_t ldl, int M, double* out, sgp_stream
  * F = -[ N/2 log 2pi + N/2 log s2 + sum log diag LB + (yy/s2 - q.q/s2^2)/2 + (kappa - tr W)/(2 s2) ]
  * with_adjoints != 0 additionally writes Phibar, bbar, Kuubar (M x M / M / M x M, ld M) and the
  * S2BAR / KAPPABAR slots of out.  `factors` (optional, may be NULL) receives what sgp_predict needs:
- * [ Linv (M*M) | G = LB^-1 L^-1 (M*M) | q (M) ].  yy, kappa are device scalars.                     */
+ * [ L^-1 (M*M) | LB^-1 (M*M) | q (M) ] (opaque; the predictive applies the two inverses one after the other -- their
+ * product has entries of size sqrt(cond K_uu) that cancel against k_u*).  yy, kappa are device scalars.               */
 size_t sgp_bound_workspace_bytes(int M, int with_adjoints);
 size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
 /* Optional split of the tail: chol(Kuu) and its inverse depend on (Z, theta) only, not on the streamed

@@ -121,8 +121,8 @@ class OracleEngine:
         if want_factors:
             I = torch.eye(M, dtype=torch.float64)
             Linv = torch.linalg.solve_triangular(r["L"], I, upper=False)
-            G = torch.linalg.solve_triangular(r["LB"], Linv, upper=False)
-            res["factors"] = torch.cat([Linv.reshape(-1), G.reshape(-1), r["q"]])
+            LBinv = torch.linalg.solve_triangular(r["LB"], I, upper=False)
+            res["factors"] = torch.cat([Linv.reshape(-1), LBinv.reshape(-1), r["q"]])
         return res
 
     def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False, out=None, kfu=None):
@@ -173,10 +173,11 @@ class OracleEngine:
         M, d = Z.shape
         lst = self._ls(ls, d)
         Linv = factors[: M * M].reshape(M, M)
-        G = factors[M * M: 2 * M * M].reshape(M, M)
+        LBinv = factors[M * M: 2 * M * M].reshape(M, M)
         q = factors[2 * M * M:]
         Kus = O.kernel_from_r2(O.sqdist(Z, Xs, lst), float(sf2), KID[kernel])
-        As, C = Linv @ Kus, G @ Kus
+        As = Linv @ Kus
+        C = LBinv @ As
         mean = C.T @ q / s2
         var = sf2 - (As * As).sum(0) + (C * C).sum(0) + (s2 if pred_noise else 0.0)
         cov = None
