@@ -214,3 +214,32 @@ def test_lower_triangle_exchange_round_trip():
     assert tri.numel() == M * (M + 1) // 2 + M + 2
     back = eng.unpack_lower(tri, M, torch.zeros_like(stats))
     assert torch.equal(back, stats)
+
+
+def test_few_host_threads_caps_and_restores_the_intra_op_pool():
+    """core.few_host_threads: the host-driven loops run with at most 4 torch intra-op threads (a 128-thread pool made a
+    BayesianSVGP minibatch step 10x slower on the GPU box) and the caller's setting comes back, also after an exception."""
+    import torch
+    from ggp_amd.core import few_host_threads
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(8)
+        seen = []
+
+        @few_host_threads
+        def loop(fail):
+            seen.append(torch.get_num_threads())
+            if fail:
+                raise RuntimeError("boom")
+            return 7
+
+        assert loop(False) == 7 and seen[-1] == 4 and torch.get_num_threads() == 8
+        try:
+            loop(True)
+        except RuntimeError:
+            pass
+        assert seen[-1] == 4 and torch.get_num_threads() == 8
+        torch.set_num_threads(2)
+        assert loop(False) == 7 and seen[-1] == 2 and torch.get_num_threads() == 2
+    finally:
+        torch.set_num_threads(before)
