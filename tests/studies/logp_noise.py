@@ -265,6 +265,24 @@ def main():
         except Exception as ex:  # pragma: no cover
             r["cond_Kuu"] = str(ex)
         out["cases"].append(r)
+
+    # Above the single launch's M <= 128 (the reference runs this model with M = 480 random training times): the multi-launch
+    # whitened order at the last MAP point (jitter 1e-6), with pass 2 from the factored adjoint (default) and from an explicit Phibar
+    for M2 in (200, 480):
+        Z2 = Xc[torch.linspace(0, Xc.shape[0] - 1, M2).round().long()].clone()
+        for factored in (True, False):
+            def target_factory2(eng_, jitter, _Z=Z2, _f=factored):
+                cb = ggp_amd.CollapsedBound(Xc.to(eng_.device), yc.to(eng_.device), kernel="composite", jitter=jitter, engine=eng_)
+                cb.factored_adjoint = _f
+                return cb, ggp_amd.CompositeHmcTarget(cb, _Z.to(eng_.device), kernel, ggp_amd.CO2_LOG_PRIOR_SD)
+            c = composite_case("CO2 composite, theta of the M = 64 MAP point (N 634, M %d, jitter 1e-06), multi-launch whitened order, %s"
+                               % (M2, "factored pass 2" if factored else "explicit Phibar"), Xc.numpy(), yc.numpy(), Z2.numpy(), kernel, theta,
+                               1e-6, target_factory2)
+            r = run_case(c, eng, np.random.default_rng(1))
+            blk0 = np.asarray(kernel.with_values([math.exp(v) for v in theta[:-1]]).block())
+            Kuu = CO.composite_k(torch.as_tensor(Z2), torch.as_tensor(Z2), torch.as_tensor(blk0)).numpy() + 1e-6 * np.eye(M2)
+            r["cond_Kuu"] = float(np.linalg.cond(Kuu))
+            out["cases"].append(r)
     print(json.dumps(out, indent=1))
 
 
