@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import math
 from concurrent.futures import ThreadPoolExecutor
-from typing import Optional
 
 import torch
 

@@ -12,7 +12,6 @@ accepts ``num_steps`` as an alias of ``max_steps`` (R5); the bound subtracts the
 from __future__ import annotations
 
 import math
-import time
 from typing import Optional
 
 import numpy as np

@@ -3,7 +3,6 @@
 oracle (PyMC3 op order, chunked) on ALL rows -- bench.py's cpu_baseline only times a 100k-row sample.  Takes ~2 minutes of
 host time on the GPU box.  Prints one JSON object (kept under profiles/).  Test infrastructure: imports oracle/."""
 import json
-import math
 import os
 import sys
 import time
