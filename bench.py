@@ -251,7 +251,10 @@ def main():
                                % (args.n, DIM, args.m, world), "N": args.n, "M": args.m, "d": DIM, "jitter": JITTER,
                    "theta": {"ls": LS, "sig_f": SF, "sig_n": SN}, "ranks": world, "collective_backend": backend if world > 1 else None,
                    "devices": devices, "device_check": device_check, "rows_per_rank": n_local,
-                   "evaluation_order": "streaming (Phi = K_uf K_fu over the row shards, W = L^-1 Phi L^-T in the replicated tail)"},
+                   "evaluation_order": ("single launch (M <= 128)" if cb._small_ok(args.m) else
+                                        "whitened (A = L^-1 K_uf materialised, B = I + A A^T / s2; pass 2 from the factored adjoint)"
+                                        if cb._whitened(args.m) else
+                                        "streaming (Phi = K_uf K_fu over the row shards, W = L^-1 Phi L^-T in the replicated tail)")},
         "leapfrog_per_s": leap_per_s, "ms_per_leapfrog": 1e3 / leap_per_s,
         "F": last["F"], "F_per_datum": last["F"] / args.n,
         "roofline": {"bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction, this rank's shard)",
