@@ -733,8 +733,12 @@ def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
     env = dict(os.environ, SGP_BENCH_BACKEND="gloo", SGP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sk:  # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--cpu-sample", "0", "--rows", str(rows)], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
     r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
