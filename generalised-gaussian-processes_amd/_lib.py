@@ -72,6 +72,7 @@ PROTOTYPES = {
     "sgp_suffstats_bwd_factored_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_bwd_factored": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _dbl, _i64, _i32, _i32, _i32,
                                           _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_set_cu_budget": (None, [_i32]),
     "sgp_small_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "sgp_small_debug_stamps": (None, [_vp]),
     "sgp_small_workspace_bytes": (_sz, [_i64, _i32, _i32]),

@@ -309,6 +309,11 @@ const int* potrf_abort_flag(const int* scratch, int Mp) {
 // Workgroups of the dataflow launch: one per CU at most (112 KB of LDS each), so that every workgroup of the launch is
 // resident and the smallest unfinished item always has an owner that can run (forward progress, see sgp_potrf.hpp).  The CU
 // count is the device's, not a constant: on a partitioned (CPX / DPX) device a launch of 256 could not be co-resident.
+// A caller that enqueues on a CU-masked stream (hipExtStreamCreateWithCUMask: CollapsedBound reserves a few CUs for the K_uu
+// chain beside pass 1 on small shards) tells this host thread how many CUs its launches can occupy: sgp_set_cu_budget(n),
+// 0 = the whole device.  Per host thread, because the side chain is enqueued by a helper thread.
+static thread_local int g_cu_budget = 0;
+void set_cu_budget(int n) { g_cu_budget = n > 0 ? n : 0; }
 static int df_max_workgroups() {
   static int n = 0;
   if (n == 0) {
@@ -317,7 +322,7 @@ static int df_max_workgroups() {
       cus = DF_MAX_WG;
     n = cus < DF_MAX_WG ? cus : DF_MAX_WG;
   }
-  return n;
+  return (g_cu_budget > 0 && g_cu_budget < n) ? g_cu_budget : n;
 }
 
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,

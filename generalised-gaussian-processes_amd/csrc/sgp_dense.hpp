@@ -23,6 +23,7 @@ struct GemmDesc {
   bool lower_only = false;
 };
 void gemm(const GemmDesc& g, hipStream_t st);
+void set_cu_budget(int n);  // CUs the calling host thread's launches may occupy (CU-masked streams); 0 = all
 // the same product with the contraction cut into S slices (S * m * n doubles of scratch; falls back to gemm() when k is
 // not a multiple of 16 S): for few output tiles and a long k
 void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st);

@@ -471,6 +471,7 @@ static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
 using namespace sgp;
 
 extern "C" int sgp_abi_version(void) { return SGP_ABI_VERSION; }
+extern "C" void sgp_set_cu_budget(int n) { set_cu_budget(n); }
 
 extern "C" const char* sgp_status_string(int status) {
   switch (status) {

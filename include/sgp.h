@@ -94,6 +94,10 @@ typedef void* sgp_stream_t; /* hipStream_t */
 #define SGP_OUT_LEN 8
 
 int sgp_abi_version(void);
+/* The single-launch dataflow factorization keeps every workgroup resident (one per CU) and sizes its grid from the device's CU
+ * count.  A caller that enqueues on a CU-masked stream (hipExtStreamCreateWithCUMask) must say how many CUs the mask leaves:
+ * n CUs for the calling HOST THREAD's following launches, 0 = the whole device (default).                                   */
+void sgp_set_cu_budget(int n);
 const char* sgp_status_string(int status);
 
 /* Optional measurement aid: with timing enabled the library records HIP events on the launch stream
