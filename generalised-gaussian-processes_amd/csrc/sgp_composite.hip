@@ -127,6 +127,10 @@ static GradGeom grad_geom(int64_t rows, int M) {
   g.RL = 256 / g.MC;
   int64_t br = (rows + 1023) / 1024;  // ~1024 workgroups at most
   if (br < 2 * g.RL) br = 2 * g.RL;
+  {  // between one and two rounds of the 256 CUs (N = 634: 317 workgroups of 2 rows): one full round instead
+    const int64_t nb = (rows + br - 1) / br;
+    if (nb > 256 && nb <= 512) br = (rows + 255) / 256;
+  }
   br = (br + g.RL - 1) / g.RL * g.RL;
   if (br > COMP_BLK_ROWS) br = COMP_BLK_ROWS;
   g.blk_rows = (int)br;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void comp_grad_kernel(const double* __restrict
                                                         const double* __restrict__ C, int64_t ldc, const double* __restrict__ bb,
                                                         int64_t nrows, int M, int d, int64_t blk0, int MC, int RL, int blk_rows,
                                                         double* __restrict__ gppart, double* __restrict__ gzpart) {
-  __shared__ double red[4];
+  __shared__ double red[4 * SGP_COMP_LEN];
   const int64_t r0 = (int64_t)blockIdx.x * blk_rows;
   const int64_t r1 = (r0 + blk_rows) < nrows ? (r0 + blk_rows) : nrows;
   const int64_t blk = blk0 + blockIdx.x;
@@ -166,9 +170,17 @@ __global__ __launch_bounds__(256) void comp_grad_kernel(const double* __restrict
     if (gzpart)
       for (int j = 0; j < d; ++j) gzpart[((blk * RL + rl) * M + m) * d + j] = gz[j];
   }
+  // all SGP_COMP_LEN sums behind ONE barrier (a block_sum256 per parameter -- 66 barriers -- cost more than the block's
+  // few rows of derivatives: 120 us for the kernel at N = 634, M = 480)
+#pragma unroll
   for (int p = 0; p < SGP_COMP_LEN; ++p) {
-    const double s = block_sum256(acc[p], red);
-    if (threadIdx.x == 0) gppart[blk * SGP_COMP_LEN + p] = s;
+    const double s = wave_sum(acc[p]);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * SGP_COMP_LEN + p] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < SGP_COMP_LEN) {
+    const int p = threadIdx.x;
+    gppart[blk * SGP_COMP_LEN + p] = (red[p] + red[SGP_COMP_LEN + p]) + (red[2 * SGP_COMP_LEN + p] + red[3 * SGP_COMP_LEN + p]);
   }
 }
 
@@ -177,22 +189,40 @@ __global__ __launch_bounds__(256) void comp_grad_reduce_kernel(const double* __r
                                                                int64_t nblk, int64_t nzslice, int M, int d, CompSpec cs, double amp_extra,
                                                                double scale_z, int accumulate, double* __restrict__ g_blk,
                                                                double* __restrict__ g_Z) {
-  if (blockIdx.x == 0 && threadIdx.x < SGP_COMP_LEN) {
-    const int p = threadIdx.x;
-    double s = 0.0;
-    for (int64_t k = 0; k < nblk; ++k) s += gppart[k * SGP_COMP_LEN + p];
-    bool is_amp = false;
-    for (int t = 0; t < cs.nterms; ++t) is_amp = is_amp || (p == 1 + 8 * t);
-    if (is_amp) s += amp_extra;
-    g_blk[p] = accumulate ? g_blk[p] + s : s;
+  // Fixed thread <-> partial mapping and fixed trees: deterministic.  (One thread per parameter walking all the partials one
+  // dependent load after the other took 75 us for 317 blocks.)
+  __shared__ double zred[4][64];
+  if (blockIdx.x == 0) {
+    // wave w sums parameters w, w + 4, ...: lanes stride over the partials, one wave reduction each, no barrier
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = wave; p < SGP_COMP_LEN; p += 4) {
+      double s = 0.0;
+      for (int64_t k = lane; k < nblk; k += 64) s += gppart[k * SGP_COMP_LEN + p];
+      s = wave_sum(s);
+      if (lane == 0) {
+        bool is_amp = false;
+        for (int t = 0; t < cs.nterms; ++t) is_amp = is_amp || (p == 1 + 8 * t);
+        if (is_amp) s += amp_extra;
+        g_blk[p] = accumulate ? g_blk[p] + s : s;
+      }
+    }
   }
   if (g_Z) {
+    // 64 elements per pass of a block, four slice lanes each
     const int64_t total = (int64_t)M * d;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {
+      const int64_t e = e0 + el;
       double s = 0.0;
-      for (int64_t k = 0; k < nzslice; ++k) s += gzpart[k * total + e];
-      s *= scale_z;
-      g_Z[e] = accumulate ? g_Z[e] + s : s;
+      if (e < total)
+        for (int64_t k = kl; k < nzslice; k += 4) s += gzpart[k * total + e];
+      zred[kl][el] = s;
+      __syncthreads();
+      if (kl == 0 && e < total) {
+        const double v = ((zred[0][el] + zred[1][el]) + (zred[2][el] + zred[3][el])) * scale_z;
+        g_Z[e] = accumulate ? g_Z[e] + v : v;
+      }
+      __syncthreads();
     }
   }
 }
