@@ -391,15 +391,17 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const double* __restric
                                                          double kappa_term, double* __restrict__ g_ls,
                                                          double* __restrict__ g_sf2, double* __restrict__ g_Z) {
   const int d = ka.d;
-  __shared__ double red[4];
   if (blockIdx.x == 0) {
+    // wave w sums parameters w, w + 4, ...: lanes stride over the (split, column block) partials, one wave reduction each --
+    // a fixed thread <-> partial mapping and a fixed tree (deterministic), no barriers
     const int np = nsplit * nmb;
-    for (int q = 0; q <= d; ++q) {  // fixed thread <-> partial mapping and a fixed tree: deterministic
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q <= d; q += 4) {
       const int j = q == d ? DP : q;
       double s = 0.0;
-      for (int p = threadIdx.x; p < np; p += 256) s += glpart[(size_t)p * (DP + 1) + j];
-      s = block_sum256(s, red);
-      if (threadIdx.x == 0) {
+      for (int p = lane; p < np; p += 64) s += glpart[(size_t)p * (DP + 1) + j];
+      s = wave_sum(s);
+      if (lane == 0) {
         if (q == d) *g_sf2 = s + kappa_term;
         else g_ls[q] = -2.0 * ka.inv_ls[q] * s;
       }

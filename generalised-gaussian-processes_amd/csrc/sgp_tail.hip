@@ -42,7 +42,7 @@ template <int KID>
 __global__ __launch_bounds__(256) void kuu_bwd_kernel(const double* __restrict__ Z, int64_t ldz, KernArgs ka,
                                                       const double* __restrict__ Kb, int M,
                                                       double* __restrict__ part, double* __restrict__ gzraw) {
-  __shared__ double red[4];
+  __shared__ double red[4][2 * SGP_MAX_DIM + 1];
   const int m = blockIdx.x;
   const int d = ka.d;
   constexpr int MAXC = SGP_MAX_INDUCING / 256;
@@ -65,11 +65,14 @@ __global__ __launch_bounds__(256) void kuu_bwd_kernel(const double* __restrict__
       KK[c] = kb * kp;
     }
   }
+  // all 2 d + 1 sums of the row behind ONE barrier (a block_sum256 each -- 74 barriers at d = 18 -- was most of the kernel's
+  // 38 us at C3): wave sums into LDS, then one thread per sum adds the four waves in a fixed order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double s = 0.0;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) s += KK[c];
-  s = block_sum256(s, red);
-  if (threadIdx.x == 0) part[(size_t)m * (d + 1) + d] = s;
+  s = wave_sum(s);
+  if (lane == 0) red[wave][2 * d] = s;
   for (int q = 0; q < d; ++q) {
     double s2 = 0.0, s1 = 0.0;
     const double zm = Z[m * ldz + q];
@@ -82,24 +85,33 @@ __global__ __launch_bounds__(256) void kuu_bwd_kernel(const double* __restrict__
         s2 = fma(E[c] * df, df, s2);
       }
     }
-    s2 = block_sum256(s2, red);
-    s1 = block_sum256(s1, red);
-    if (threadIdx.x == 0) {
-      part[(size_t)m * (d + 1) + q] = s2;
-      gzraw[(size_t)m * d + q] = s1;
+    s2 = wave_sum(s2);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      red[wave][q] = s2;
+      red[wave][d + q] = s1;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x <= 2 * d) {
+    const int t = threadIdx.x;
+    const double v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (t < d) part[(size_t)m * (d + 1) + t] = v;
+    else if (t < 2 * d) gzraw[(size_t)m * d + (t - d)] = v;
+    else part[(size_t)m * (d + 1) + d] = v;
   }
 }
 __global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __restrict__ part, const double* __restrict__ gzraw,
                                                              int M, KernArgs ka, double* g_ls, double* g_sf2, double* g_Z) {
   const int d = ka.d;
-  __shared__ double red[4];
   if (blockIdx.x == 0) {
-    for (int q = 0; q <= d; ++q) {
+    // wave w sums parameters w, w + 4, ...: lanes stride over the rows, one wave reduction each, no barrier; fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q <= d; q += 4) {
       double s = 0.0;
-      for (int m = threadIdx.x; m < M; m += 256) s += part[(size_t)m * (d + 1) + q];
-      s = block_sum256(s, red);
-      if (threadIdx.x == 0) {
+      for (int m = lane; m < M; m += 64) s += part[(size_t)m * (d + 1) + q];
+      s = wave_sum(s);
+      if (lane == 0) {
         if (q == d) *g_sf2 += s;
         else g_ls[q] += -2.0 * ka.inv_ls[q] * s;
       }
