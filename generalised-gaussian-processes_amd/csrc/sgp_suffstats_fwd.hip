@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m < M) {
     double s = 0.0;
-    for (int g = 0; g < G; ++g) s += btmp[(size_t)g * Mp + m];
+#pragma unroll 8
+    for (int g = 0; g < G; ++g) s += btmp[(size_t)g * Mp + m];  // same order of additions; the loads of eight steps in flight
     b[m] = s * sf2;
   }
   if (blockIdx.x == 0) {  // fixed-order block reduction (one thread walking the 256 partials took 30 us)
