@@ -118,6 +118,29 @@ def cpu_baseline(X, y, Z, sample_rows, full):
                                    "%.2f s, fitted and evaluated at N = %d -> %.1f s" % (g1, tg1, g2, tg2, N, gfull)}}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): run the N ranks as fresh child processes
+    under torch.distributed.run -- one rank per GPU, RCCL over xGMI -- relay their output (rank 0 prints the JSON
+    line) and return the launcher's exit code.  Nothing here initialises HIP: `torch.cuda.device_count()` only counts."""
+    import socket
+    import subprocess
+    share = os.environ.get("SGP_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        print("bench.py: --gpus %d asks for %d ranks but this node shows %d device(s); refusing to run several ranks on "
+              "one GPU (functional check only: SGP_BENCH_SHARE_GPU=1 SGP_BENCH_BACKEND=gloo)" % (n, n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,7 +154,14 @@ def main():
                     help="how chol(Kuu) is enqueued on the side stream (A/B knob; default = the product default)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything in this process
+        # touches the GPU (a process that has initialised HIP must never exec / fork GPU workers on this pool)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -191,6 +221,7 @@ def main():
         last["Fg"], last["g"] = cb.value_and_grad(Zd, ls, sf2, s2, want_gz=False)
 
     dt_val = timed(step_value, args.steps, args.warmup)
+    coll_per_eval = cb.n_collectives / max(1, cb.n_evals)  # 1 with several ranks (the packed statistics), 0 with one
     dt_grad = timed(step_grad, max(2, args.steps // 2), 1)
     evals_per_s = args.steps / dt_val
     leap_per_s = max(2, args.steps // 2) / dt_grad
@@ -233,15 +264,39 @@ def main():
 
     devices = [torch.cuda.get_device_properties(dev).name + " #%d" % local_rank]
     device_check = "single rank"
+    allreduce_ms = None
     if world > 1:
+        share = os.environ.get("SGP_BENCH_SHARE_GPU") == "1"
+        props = torch.cuda.get_device_properties(dev)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (rank, local_rank, torch.cuda.current_device(), str(torch.cuda.get_device_properties(dev).uuid)
-                                         if hasattr(torch.cuda.get_device_properties(dev), "uuid") else ""))
-        devices = ["rank %d: cuda:%d %s" % (r, cur, u) for r, lr, cur, u in gathered]
-        distinct = dist.get_world_size() == world and len({(cur, u) for _, _, cur, u in gathered}) == world
-        device_check = "distinct device per rank" if distinct else "NOT verified distinct (same index and no / equal uuid): %r" % (gathered,)
-        if not distinct and os.environ.get("SGP_BENCH_SHARE_GPU") != "1" and rank == 0:
-            print("bench.py: ranks may share a device: %r" % (gathered,), file=sys.stderr)
+        dist.all_gather_object(gathered, (rank, local_rank, torch.cuda.current_device(), str(getattr(props, "uuid", "")),
+                                         dist.get_backend()))
+        devices = ["rank %d: cuda:%d %s" % (r, cur, u) for r, lr, cur, u, _ in gathered]
+        # what "N GPUs" must mean: N ranks in the group, the collective library is RCCL, every rank on its own device
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        distinct = len({(cur, u) for _, _, cur, u, _ in gathered}) == world
+        backends = sorted({b for *_, b in gathered})
+        if share:
+            device_check = "SGP_BENCH_SHARE_GPU=1: ranks share cuda:0 (functional check, numbers meaningless), backend %s" % backends
+        else:
+            if not distinct:
+                raise SystemExit("bench.py: %d ranks but not %d distinct devices: %r" % (world, world, gathered))
+            if backends != ["nccl"]:
+                raise SystemExit("bench.py: collectives must run over RCCL (backend 'nccl'), got %r" % (backends,))
+            device_check = "distinct device per rank, backend nccl (RCCL), world size %d" % world
+        # THE exchange of an evaluation, timed alone: all-reduce of [lower triangle of Phi | b | yy | kappa]
+        tri = torch.zeros(args.m * (args.m + 1) // 2 + args.m + 2, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            dist.all_reduce(tri)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(tri)
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_ms = 1e3 * float(t.item())
+        allreduce_bytes = tri.numel() * 8
 
     res = {
         "metric": "ELBO evals/sec", "value": evals_per_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
@@ -251,6 +306,8 @@ def main():
                                % (args.n, DIM, args.m, world), "N": args.n, "M": args.m, "d": DIM, "jitter": JITTER,
                    "theta": {"ls": LS, "sig_f": SF, "sig_n": SN}, "ranks": world, "collective_backend": backend if world > 1 else None,
                    "devices": devices, "device_check": device_check, "rows_per_rank": n_local,
+                   "allreduce_ms": allreduce_ms, "allreduce_bytes": allreduce_bytes if world > 1 else None,
+                   "collectives_per_eval": coll_per_eval,
                    "evaluation_order": ("single launch (M <= 128)" if cb._small_ok(args.m) else
                                         "whitened (A = L^-1 K_uf materialised, B = I + A A^T / s2; pass 2 from the factored adjoint)"
                                         if cb._whitened(args.m) else

@@ -16,7 +16,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libsgp_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ["sgp_suffstats_fwd.hip", "sgp_suffstats_bwd.hip", "sgp_dense.hip", "sgp_tail.hip", "sgp_svgp.hip", "sgp_composite.hip", "sgp_small.hip"]
-HEADERS = ["sgp_common.hpp", "sgp_dense.hpp", "sgp_potrf.hpp", "sgp_stream.hpp", "sgp_composite.hpp", os.path.join("..", "..", "include", "sgp.h")]
+VERSION_SCRIPT = "libsgp.map"
+PUBLIC_HEADER = os.path.join("..", "..", "include", "sgp.h")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]  # only the SGP_API symbols of include/sgp.h leave the library
+
+
+def _headers():
+    """Every header a translation unit can reach: all of csrc/*.hpp (globbed, so a new #include cannot be forgotten --
+    sgp_nuts.hpp once was and the sampler could be edited without a rebuild) plus the public C header."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [PUBLIC_HEADER]
 ARCH = "gfx950"
 
 
@@ -29,7 +37,9 @@ def _hipcc() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    h.update((" ".join(FLAGS) + " " + os.environ.get("SGP_EXTRA_HIPCC_FLAGS", "")).encode())
+    for f in SOURCES + _headers() + [VERSION_SCRIPT]:
+        h.update(os.path.basename(f).encode())
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -48,7 +58,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         cmd += os.environ.get("SGP_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds (tools/ab_build.sh); empty for the product
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -58,7 +68,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, VERSION_SCRIPT),
+           "-o", LIB_PATH] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)

@@ -117,8 +117,13 @@ class CollapsedBound:
             t = torch.tensor([n_local], dtype=torch.int64, device=engine.device)
             dist.all_reduce(t, group=group)
             self.N = int(t.item())
+            # form="auto" must come out the same on every rank (the two orders all-reduce different matrices into the
+            # same buffer): decide from the LARGEST shard, not from the local one
+            dist.all_reduce(t.fill_(n_local), op=dist.ReduceOp.MAX, group=group)
+            self._rows_for_form = int(t.item())
         else:
             self.N = n_local
+            self._rows_for_form = n_local
         self.n_evals = 0
         self.n_grads = 0
         self.n_collectives = 0
@@ -223,7 +228,7 @@ class CollapsedBound:
 
     def _whitened(self, M):
         if self.form == "auto":
-            return hasattr(self.engine, "suffstats_whitened") and int(self.X.shape[0]) * int(M) <= self.WHITENED_MAX_WORK
+            return hasattr(self.engine, "suffstats_whitened") and self._rows_for_form * int(M) <= self.WHITENED_MAX_WORK
         return self.form == "whitened"
 
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0):

@@ -41,7 +41,7 @@ __device__ __forceinline__ double sgp_exp(double x) {
 #if defined(SGP_AB_LIBRARY_EXP)  // A/B knob of tools/ab_build.sh only: the device library's routine
   return exp(x);
 #endif
-  x = fmax(x, -800.0);
+  x = (x < -800.0) ? -800.0 : x;  // not fmax(): a NaN distance (NaN in X / Z / a lengthscale) must stay NaN, not become k = 0
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
   r = fma(k, -1.90821492927058770002e-10, r);

@@ -18,6 +18,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .core import SgpTimeoutError
+
 NOISE_FLOOR = 1e-4
 
 
@@ -207,7 +209,10 @@ class MultivariateNormal:
             A = self._cov.detach().clone()
             A.diagonal().add_(jitter)
             _, info = self._engine.chol_lower(A)
-            return int(info.to("cpu")[0]) == 0
+            info = int(info.to("cpu")[0])
+            if info < 0:  # SGP_INFO_TIMEOUT from the dataflow factorization: not a statement about the matrix
+                raise SgpTimeoutError()
+            return info == 0
         cov = self._cov.detach().to("cpu", torch.float64)
         try:
             torch.linalg.cholesky(cov + torch.eye(cov.shape[0], dtype=cov.dtype) * jitter)
@@ -225,6 +230,8 @@ class MultivariateNormal:
             r = (y.detach().to(device=self._cov.device, dtype=torch.float64).reshape(-1) - self.loc.detach()).reshape(T, 1).contiguous()
             a = e.trsm_lower(L, r)
             ld = e.logdiag_sum(L)
+            if int(info.to("cpu")[0]) < 0:
+                raise SgpTimeoutError()
             if int(info.to("cpu")[0]) != 0:
                 raise RuntimeError("predictive covariance is not positive definite (leading minor %d)" % int(info.to("cpu")[0]))
             return (-0.5 * (a * a).sum() - ld[0] - 0.5 * T * math.log(2.0 * math.pi)).to("cpu")

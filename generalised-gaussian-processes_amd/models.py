@@ -271,6 +271,8 @@ def mixture_posterior_predictive(model, test_x, trace_hyper):
                 if not pred.is_psd(1e-4):
                     raise RuntimeError("predictive covariance not positive definite")
                 preds.append(pred)
+            except SgpTimeoutError:
+                raise  # a device scheduling fault is never a numerical outcome: it must not thin the mixture silently
             except (RuntimeError, NotPositiveDefiniteError):
                 print('Not psd for sample ' + str(i))
     return preds

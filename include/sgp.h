@@ -44,6 +44,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is the whole exported surface. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef void* sgp_stream_t; /* hipStream_t */
 
@@ -360,6 +364,9 @@ int sgp_svgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z,
 /* host utility: n-point Gauss-Hermite rule for the standard normal (sum w_i f(x_i) ~ E f(N(0,1))) */
 int sgp_gauss_hermite(int n, double* x, double* w);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -714,6 +714,10 @@ def test_kernel_exp_accuracy(engine):
     big = ref > 1e-300
     assert np.max(np.abs(got[big] - ref[big]) / ref[big]) < 2.5e-16, np.max(np.abs(got[big] - ref[big]) / ref[big])
     assert np.all(np.abs(got[~big] - ref[~big]) <= 1e-300) and np.all(np.isfinite(got)) and np.all(got >= 0.0)
+    # a NaN input must come out as NaN (a clamp by fmax() would turn a corrupt distance into k = 0 and a finite, meaningless bound)
+    zn = np.array([[0.0], [1.0], [np.nan]])
+    Kn = engine.kuu(dev(zn, engine), [1.0], 1.0, 0.0, "rbf").cpu().numpy()
+    assert np.isnan(Kn[2]).all() and np.isnan(Kn[:, 2]).all() and np.isfinite(Kn[:2, :2]).all()
 
 
 @pytest.mark.gpu
@@ -732,16 +736,20 @@ def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
     one = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
-    env = dict(os.environ, SGP_BENCH_BACKEND="gloo", SGP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    import socket
-    with socket.socket() as sk:  # a port nobody holds right now
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--cpu-sample", "0", "--rows", str(rows)], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    # bench.py's own launcher (`python bench.py --gpus 2`, what the driver's SCALE command runs): it starts the two ranks
+    env = dict(os.environ, SGP_BENCH_BACKEND="gloo", SGP_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    two = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
     r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert r2["n_gpus"] == 2 and r2["config"]["ranks"] == 2 and r2["config"]["rows_per_rank"] == rows // 2
     assert abs(r2["F"] - r1["F"]) < 1e-9 * abs(r1["F"]), (r1["F"], r2["F"])
     assert r2["leapfrog_per_s"] > 0 and r2["value"] > 0
+    assert r2["config"]["allreduce_ms"] > 0 and r2["config"]["collectives_per_eval"] == 1.0
+    assert r2["config"]["allreduce_bytes"] == 8 * (1024 * 1025 // 2 + 1024 + 2)
+    # and without the sharing override a 1-GPU box must refuse, loudly, instead of printing n_gpus: 1
+    import torch
+    if torch.cuda.device_count() < 2:
+        env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "SGP_BENCH_SHARE_GPU", "SGP_BENCH_BACKEND")}
+        bad = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
+        assert bad.returncode != 0 and "2 ranks" in bad.stderr and not bad.stdout.strip().startswith("{"), (bad.stdout, bad.stderr[-500:])

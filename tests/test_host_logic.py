@@ -158,6 +158,50 @@ def test_two_rank_gloo_matches_single_process(name):
     assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][5], outs[1][5])
 
 
+def _uneven_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ggp_amd as pkg
+    from fake_engine import OracleEngine as Eng
+    from conftest import load_golden as lg
+    G = lg("rbf_d3_small")
+    X, y, Z = T(G["X"]), T(G["y"]), T(G["Z"])
+    lo, hi = (0, 150) if rank == 0 else (150, X.shape[0])  # 150 and 250 rows, M = 30
+    pkg.CollapsedBound.WHITENED_MAX_WORK = 200 * 30        # ... straddle the threshold of form="auto"
+    cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=float(G["jitter"]), engine=Eng())
+    choice = cb._whitened(Z.shape[0])
+    F, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+    q.put((rank, choice, F, g["ls"].numpy(), g["Z"].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_uneven_shards_agree_on_the_evaluation_order():
+    """form="auto" picks whitened / streaming from the shard size: with uneven shards either side of the threshold every rank
+    must still make the SAME choice (they all-reduce W = L^-1 Phi L^-T or the raw Phi into one buffer) -- ADVICE r2, core.py:226."""
+    G = load_golden("rbf_d3_small")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[0][1] == outs[1][1] is False  # the largest shard (250 x 30) is above the threshold: streaming on both
+    for _, _, F, gls, gZ in outs:
+        assert abs(F - float(G["F"])) < 1e-9 * max(1.0, abs(float(G["F"])))
+        assert np.abs(gls - G["g_ls"]).max() < 1e-6 * max(1.0, np.abs(G["g_ls"]).max())
+        assert np.abs(gZ - G["g_Z"]).max() < 1e-6 * max(1.0, np.abs(G["g_Z"]).max())
+    assert outs[0][2] == outs[1][2]
+
+
 # ---------------------------------------------------------------------------------------------
 # world_size = 2: NUTS with the DEFAULT seed -- every rank must build the same trees (each leapfrog issues
 # collectives: ranks that draw different momenta would issue different numbers of all-reduces and hang)
@@ -243,3 +287,24 @@ def test_few_host_threads_caps_and_restores_the_intra_op_pool():
         assert loop(False) == 7 and seen[-1] == 2 and torch.get_num_threads() == 2
     finally:
         torch.set_num_threads(before)
+
+
+def test_bench_gpus_n_refuses_to_run_n_ranks_on_fewer_devices():
+    """`python bench.py --gpus 2` is the driver's SCALE command: without WORLD_SIZE it must start its own ranks, and on a node with
+    fewer than 2 devices fail loudly ("2 ranks ... 1 device") rather than print a one-GPU number labelled n_gpus: 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SGP_BENCH_SHARE_GPU")}
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("node has two devices: the launcher would start the job")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "2 ranks" in r.stderr and "device" in r.stderr
+    assert "{" not in r.stdout
+    # a launcher that started a different number of ranks than --gpus says is refused as well
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
