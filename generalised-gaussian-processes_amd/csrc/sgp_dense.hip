@@ -325,6 +325,19 @@ static int df_max_workgroups() {
   return (g_cu_budget > 0 && g_cu_budget < n) ? g_cu_budget : n;
 }
 
+// CUs a launch of the calling host thread can occupy: the device's count, or the caller's budget for a CU-masked stream.
+// Used by every kernel whose workgroups wait for each other (all of them must be resident at once).
+int available_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = DF_MAX_WG;  // no device visible (CPU-only build check): the shape-only answer
+    cus = n;
+  }
+  return (g_cu_budget > 0 && g_cu_budget < cus) ? g_cu_budget : cus;
+}
+
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
                  const double* rhs, double* sol, bool caller_managed) {
   const int nb = Mp / DB;

@@ -36,7 +36,7 @@ constexpr int SM_MAXD = 16;
 constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
-enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_WORDS = 11 };
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_ACK = 11, SY_WORDS = 12 };
 constexpr int SM_GP = 40;  // doubles per gradient partial.  Stationary: g_ls[d] at 0.., g_sf2 at 16; composite: dF/d(block) at its
                           // 33 slots.  Both: tr B^-1, u.g, g.g at SM_XTRA + 0, 1, 2
 constexpr int SM_XTRA = 34;
@@ -121,6 +121,19 @@ __device__ __forceinline__ bool sm_wait_ge(int* word, int target, int* abort_wor
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return *dead == 0;
+}
+// thread 0 of the chain workgroup only: wait until the other workgroups have READ request r's theta (cumulative
+// acknowledgements) before theta is overwritten for request r + 1 -- nothing is read behind this wait, so no fence
+__device__ __forceinline__ bool sm_wait_ack(int* word, int target, int* abort_word) {
+  int spins = 0;
+  while (sm_ld(word) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > SM_SPIN_LIMIT || ((spins & 127) == 0 && sm_ld(abort_word) != 0)) {
+      __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+  return true;
 }
 __device__ __forceinline__ void sm_publish_set(int* word, int v) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1520,8 +1533,12 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
     }
     if (wg == 0) {
       if (tid == 0) {
+        // theta of request req - 1 may only be overwritten once every other workgroup has read it: on the skip path below
+        // (theta out of range) and in value-only batches nothing else makes this workgroup wait for the others
+        const int acks = (req - 1) * ((int)gridDim.x - 1);
         if (batch) {
           cmd = req <= na.S ? NUTS_EVAL : NUTS_DONE;
+          if (!sm_wait_ack(sy + SY_ACK * SM_SYNC_STRIDE, acks, abortw)) ks.dead = 1;  // also before DONE: the word is reset below
           if (req <= na.S)
             for (int i = 0; i < ndim; ++i) na.theta_w[i] = na.batch_theta[(size_t)(req - 1) * ndim + i];
         } else {
@@ -1534,6 +1551,7 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
             if (row >= 0) na.stats[(size_t)na.n_draws * NST_COLS + row] = (double)(now - t_draw) * 1e-8;
             t_draw = now;
           }
+          if (!sm_wait_ack(sy + SY_ACK * SM_SYNC_STRIDE, acks, abortw)) ks.dead = 1;  // also before DONE: the word is reset below
           if (c == NUTS_EVAL)
             for (int i = 0; i < ndim; ++i) na.theta_w[i] = qn[i];
           cmd = c;
@@ -1556,6 +1574,12 @@ __global__ __launch_bounds__(256) void small_nuts_kernel(SmallArgs a, NutsArgs n
       if (sm_ld(sy + SY_DONE * SM_SYNC_STRIDE) != 0) break;
     }
     sm_hypers<COMP>(al, ks.hyp);  // every workgroup from the same theta: the same decision everywhere
+    if (wg != 0 && tid == 0)     // theta has been read (its values are in LDS): the chain workgroup may write the next one
+      __hip_atomic_fetch_add(sy + SY_ACK * SM_SYNC_STRIDE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (ks.dead) {
+      if (wg == 0 && tid == 0) *al.info = SGP_INFO_TIMEOUT;
+      break;
+    }
     if (!ks.hyp.ok) {
       if (wg == 0 && tid == 0) {
         al.out[0] = -INFINITY;
@@ -1586,6 +1610,23 @@ struct SmallWs {
   SmallArgs a;
   size_t bytes;
 };
+
+// The workgroups of these launches wait for each other, so ALL of them have to be resident at once.  The grid (<= 67) is
+// checked against what the device can hold -- occupancy of this very kernel x the CUs the calling thread's launches can use
+// (device count, or sgp_set_cu_budget() on a CU-masked stream) -- and refused with SGP_ERR_LAUNCH otherwise, instead of
+// spinning into SGP_INFO_TIMEOUT.  (hipLaunchCooperativeKernel would make the runtime do the same check, at the price of its
+// cooperative-queue hand-over on every 70 us evaluation.)
+template <auto K>
+static bool small_grid_is_resident(int grid) {
+  static int per_cu = -1;
+  if (per_cu < 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K, 256, 0) != hipSuccess || n < 1) n = 1;
+    per_cu = n;
+  }
+  return (long long)per_cu * available_cus() >= grid;
+}
+static int small_grid(int M, int grow) { return 1 + (M <= 64 ? 1 : 2) + grow; }
 static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
   (void)d;
   const int MP = M <= 64 ? 64 : 128, NB64 = MP / 64;
@@ -1628,6 +1669,10 @@ extern "C" void sgp_small_debug_stamps(void* dev_buffer) { g_small_stamps = stat
 
 extern "C" int sgp_small_supported(int64_t N, int M, int d, int kernel_id) {
   if (!(N >= 1 && N <= (int64_t)1 << 22 && M >= 1 && M <= 128 && d >= 1)) return 0;
+  // every workgroup of the launch must be resident (they wait for each other): at least one per available CU is assumed
+  // here, the launch itself checks the kernel's real occupancy.  Callers fall back to the multi-launch path on 0.
+  const int64_t nslab = (N + SM_SLAB - 1) / SM_SLAB;
+  if (small_grid(M, (int)(nslab < SM_MAX_ROWWG ? nslab : SM_MAX_ROWWG)) > available_cus()) return 0;
   if (kernel_id == SGP_KERNEL_COMPOSITE) return d <= COMP_MAX_DIM;
   return d <= SM_MAXD && kernel_id >= SGP_KERNEL_RBF && kernel_id <= SGP_KERNEL_MATERN52;
 }
@@ -1698,15 +1743,20 @@ static int small_eval_impl(const double* X, int64_t ldx, const double* y, const 
   a.jitter = jitter;
   a.info = info; a.out = out; a.gZ = g_Z;
   a.stamps = g_small_stamps;
-  const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
+  const int grid = small_grid(M, a.grow);
   hipStream_t st = (hipStream_t)stream;
   const bool comp = kernel_id == SGP_KERNEL_COMPOSITE;
+#define SGP_SMALL_LAUNCH(KERNEL, ...)                                  \
+  do {                                                                 \
+    if (!small_grid_is_resident<KERNEL>(grid)) return SGP_ERR_LAUNCH;  \
+    KERNEL<<<grid, 256, 0, st>>>(__VA_ARGS__);                         \
+  } while (0)
   if (M <= 64) {
-    if (comp) small_eval_kernel<64, true><<<grid, 256, 0, st>>>(a);
-    else small_eval_kernel<64, false><<<grid, 256, 0, st>>>(a);
+    if (comp) SGP_SMALL_LAUNCH((small_eval_kernel<64, true>), a);
+    else SGP_SMALL_LAUNCH((small_eval_kernel<64, false>), a);
   } else {
-    if (comp) small_eval_kernel<128, true><<<grid, 256, 0, st>>>(a);
-    else small_eval_kernel<128, false><<<grid, 256, 0, st>>>(a);
+    if (comp) SGP_SMALL_LAUNCH((small_eval_kernel<128, true>), a);
+    else SGP_SMALL_LAUNCH((small_eval_kernel<128, false>), a);
   }
   return check_launch();
 }
@@ -1753,11 +1803,14 @@ static int small_nuts_impl(const double* X, int64_t ldx, const double* y, const 
   a.stamps = nullptr;
   NutsArgs na{q0, theta_scratch, samples, stats, counters, n_tune, n_draws, max_treedepth, step_scale, target_accept, seed,
               0, nullptr, nullptr, nullptr, nullptr};
-  const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
+  const int grid = small_grid(M, a.grow);
   hipStream_t st = (hipStream_t)stream;
+  const bool comp = kernel_id == SGP_KERNEL_COMPOSITE;
+  if (!(M <= 64 ? (comp ? small_grid_is_resident<small_nuts_kernel<64, true>>(grid) : small_grid_is_resident<small_nuts_kernel<64, false>>(grid))
+                : (comp ? small_grid_is_resident<small_nuts_kernel<128, true>>(grid) : small_grid_is_resident<small_nuts_kernel<128, false>>(grid))))
+    return SGP_ERR_LAUNCH;
   // the request / done words of the previous run (the only sync words a run leaves non-zero)
   zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
-  const bool comp = kernel_id == SGP_KERNEL_COMPOSITE;
   if (M <= 64) {
     if (comp) small_nuts_kernel<64, true><<<grid, 256, 0, st>>>(a, na);
     else small_nuts_kernel<64, false><<<grid, 256, 0, st>>>(a, na);
@@ -1813,8 +1866,10 @@ extern "C" int sgp_small_eval_batch(const double* X, int64_t ldx, const double* 
   a.info = infos; a.out = outs; a.gZ = g_Z;
   a.stamps = nullptr;
   NutsArgs na{thetas, theta_scratch, nullptr, nullptr, nullptr, 0, 0, 1, 0.25, 0.8, 0, S, thetas, outs, g_Z, infos};
-  const int grid = 1 + (M <= 64 ? 1 : 2) + a.grow;
+  const int grid = small_grid(M, a.grow);
   hipStream_t st = (hipStream_t)stream;
+  if (!(M <= 64 ? small_grid_is_resident<small_nuts_kernel<64, false>>(grid) : small_grid_is_resident<small_nuts_kernel<128, false>>(grid)))
+    return SGP_ERR_LAUNCH;
   zero_ints(a.sync + SY_REQ * SM_SYNC_STRIDE, 2 * SM_SYNC_STRIDE, st);
   if (M <= 64) small_nuts_kernel<64, false><<<grid, 256, 0, st>>>(a, na);
   else small_nuts_kernel<128, false><<<grid, 256, 0, st>>>(a, na);

@@ -227,7 +227,14 @@ int sgp_bound_from_whitened_stats_ex(const double* W, const double* u, const dou
  * out (d + 5 doubles), g_Z (M*d, ld d, optional: NULL skips dF/dZ) and info are DEVICE pointers; nothing is synchronised.
  * want_grad = 0 writes out[0] (and the two parts) only.  The first sgp_small_sync_bytes() bytes of `ws` must be zero
  * before the FIRST launch on a workspace (the kernel leaves them zero; after info = SGP_INFO_TIMEOUT zero them again).
- * All workgroups (1 + ceil(M/64) + min(ceil(N/64), 64)) must be co-resident: do not run it beside a kernel that fills the device.   */
+ * All workgroups (1 + ceil(M/64) + min(ceil(N/64), 64)) must be co-resident.  The library checks the grid against
+ * (occupancy of the kernel) x (CUs of the device, or the calling thread's sgp_set_cu_budget() for a CU-masked stream):
+ * sgp_small_supported() answers 0 and the launch returns SGP_ERR_LAUNCH when it cannot fit (use the multi-launch entry
+ * points then).  A plain launch, not hipLaunchCooperativeKernel: beside a kernel that already FILLS the device the
+ * workgroups become resident as that kernel's retire -- late, never deadlocked (the chain workgroup is block 0 and is
+ * dispatched first) -- and a bounded spin reports SGP_INFO_TIMEOUT instead of hanging.
+ * One workspace = one stream: the sync words live in `ws`, so two launches on the same workspace must not overlap
+ * (give every concurrent stream its own workspace).                                                                       */
 #define SGP_SMALL_NATURAL 0
 #define SGP_SMALL_HMC 1
 int sgp_small_supported(int64_t N, int M, int d, int kernel_id);

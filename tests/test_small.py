@@ -231,3 +231,68 @@ def test_small_eval_batch_equals_single_evaluations(engine):
     o = outs.cpu().numpy()
     assert abs(o[0, 0] - G["hmc_logp"][0]) < 1e-9 * abs(G["hmc_logp"][0]) and abs(o[2, 0] - G["hmc_logp"][1]) < 1e-9 * abs(G["hmc_logp"][1])
     assert o[1, 0] == -np.inf and infos.cpu().tolist() == [0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_batch_skip_path_keeps_every_workgroup_on_its_own_request(engine):
+    """Out-of-range thetas (the chain workgroup skips the evaluation and moves on) interleaved with valid ones, value only (no
+    gradient hand-shake that would make the chain workgroup wait): every slot must still equal its stand-alone evaluation.  Before
+    the read acknowledgement (SY_ACK) a lagging workgroup could pick up the NEXT request's theta -- ADVICE r2, sgp_small.hip:1559."""
+    G = load_golden("rbf_d3_small")
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    good = [G["hmc_theta"][0] + 0.05 * k for k in range(12)]
+    bad = np.array([400.0, 0.0, 0.0, 0.0, 0.0])
+    rows, expect_inf = [], []
+    for k, t in enumerate(good):
+        for _ in range(k % 4):  # runs of 0-3 skipped requests between evaluations
+            rows.append(bad)
+            expect_inf.append(True)
+        rows.append(t)
+        expect_inf.append(False)
+    rows += [bad, bad]  # ... and right before DONE
+    expect_inf += [True, True]
+    th = np.stack(rows)
+    singles = {}
+    for want_grad in (False, True):
+        for rep in range(20):
+            outs, _, infos = engine.small_eval_batch(X, y, Z, dev(th, engine), 1e-6, "rbf", mode=1, want_grad=want_grad)
+            o = outs.cpu().numpy()
+            assert infos.cpu().tolist() == [0] * len(rows)
+            for i, t in enumerate(rows):
+                if expect_inf[i]:
+                    assert o[i, 0] == -np.inf
+                    continue
+                key = (want_grad, tuple(t))
+                if key not in singles:
+                    singles[key] = engine.small_eval(X, y, Z, dev(t, engine), 1e-6, "rbf", mode=1, want_grad=want_grad)[0].cpu().numpy()
+                assert o[i, 0] == singles[key][0], (rep, i)
+                if want_grad:
+                    assert np.array_equal(o[i, 1:6], singles[key][1:6]), (rep, i)
+
+
+@pytest.mark.gpu
+def test_small_launch_is_refused_when_its_workgroups_cannot_all_be_resident(engine):
+    """The single launch's workgroups wait for each other: with a CU budget (CU-masked stream) smaller than the grid the library
+    says so up front -- sgp_small_supported() = 0, the entry point returns SGP_ERR_LAUNCH -- instead of spinning into a time-out."""
+    import ctypes as C
+    G = load_golden("rbf_d3_small")
+    X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
+    N, d = G["X"].shape
+    M = G["Z"].shape[0]
+    assert engine.small_supported(N, M, d, "rbf")
+    ws = engine._small_ws(N, M, d)
+    out = engine.empty(d + 5)
+    info = torch.zeros(1, dtype=torch.int32, device=engine.device)
+    th = _theta(G, engine)
+    try:
+        engine.lib.sgp_set_cu_budget(4)  # grid = 1 + 1 + ceil(400 / 64) = 9 workgroups
+        assert not engine.small_supported(N, M, d, "rbf")
+        st = engine.lib.sgp_small_eval(engine._ptr(X), d, engine._ptr(y), engine._ptr(Z), d, engine._ptr(th), N, M, d, 0, 1e-6, 0, 1,
+                                       engine._ptr(out), None, C.c_void_p(info.data_ptr()), engine._ptr(ws), ws.numel(), engine._stream())
+        assert st in (-2, -4)  # SGP_ERR_DIM from the shape gate or SGP_ERR_LAUNCH from the launch check
+        engine.lib.sgp_set_cu_budget(16)
+        assert engine.small_supported(N, M, d, "rbf")
+    finally:
+        engine.lib.sgp_set_cu_budget(0)
+    o, _, i = engine.small_eval(X, y, Z, th, float(G["jitter"]), KNAME[int(G["kernel_id"])], mode=0, want_grad=True)
+    assert int(i.item()) == 0 and abs(float(o[0]) - float(G["F"])) < 1e-9 * abs(float(G["F"]))
