@@ -25,6 +25,8 @@ struct GemmP {
   int m, n, k;
   double alpha, beta;
   int klo_mask, khi_mask, lower_only;
+  int batch;
+  int64_t s2A, s2B, s2C;
 };
 
 // Operand tiles in LDS: S[k][col'] with 64-double rows and col' = (col + rot(k)) & 63, rot(k) = 4 (k >> 2) + 16 (k & 1).
@@ -81,10 +83,10 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
   __shared__ GemmShared sh;
   const int bj = blockIdx.x, bi = blockIdx.y;
   if (p.lower_only && bj > bi) return;
-  const int64_t bz = blockIdx.z;
-  const double* A = p.A + bz * p.sA;
-  const double* B = p.B + bz * p.sB;
-  double* C = p.C + bz * p.sC;
+  const int64_t bo = (int)blockIdx.z / p.batch, bz = (int)blockIdx.z - bo * p.batch;  // (outer, inner) batch index
+  const double* A = p.A + bz * p.sA + bo * p.s2A;
+  const double* B = p.B + bz * p.sB + bo * p.s2B;
+  double* C = p.C + bz * p.sC + bo * p.s2C;
 
   int klo = 0, khi = p.k;
   if (p.klo_mask & 1) klo = max(klo, bi * GT);
@@ -202,8 +204,10 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
 // M x M x B products of the SVGP reverse pass: 16 tiles, k = 4096) -- S workgroups per tile write partial tiles, a
 // second launch adds them in slice order.  scratch: S * m * n doubles.  No k-range masks, no batch.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ part, int S, int m, int n, double* __restrict__ C,
-                                                            int64_t ldc, double alpha, double beta) {
+                                                            int64_t ldc, double alpha, double beta, int64_t s2C) {
   const int64_t total = (int64_t)m * n;
+  part += (int64_t)blockIdx.y * S * total;  // outer batch (GemmDesc::batch2)
+  C += (int64_t)blockIdx.y * s2C;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / n), c = (int)(e - (int64_t)r * n);
     double s = 0.0;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __rest
   }
 }
 void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st) {
-  if (g.m <= 0 || g.n <= 0 || S <= 1 || g.k % (S * GK) != 0) {
+  if (g.m <= 0 || g.n <= 0 || S <= 1 || g.k % (S * GK) != 0 || g.batch != 1) {
     gemm(g, st);
     return;
   }
@@ -226,19 +230,21 @@ void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st) {
   p.C = scratch;
   p.ldc = g.n;
   p.sC = (int64_t)g.m * g.n;
+  p.s2C = (int64_t)S * g.m * g.n;  // outer batch: every problem has its own S partial tiles (s2A / s2B as given)
   p.alpha = 1.0;
   p.beta = 0.0;
   gemm(p, st);
   const int64_t total = (int64_t)g.m * g.n;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  splitk_reduce_kernel<<<blocks, 256, 0, st>>>(scratch, S, g.m, g.n, g.C, g.ldc, g.alpha, g.beta);
+  splitk_reduce_kernel<<<dim3(blocks, g.batch2), 256, 0, st>>>(scratch, S, g.m, g.n, g.C, g.ldc, g.alpha, g.beta, g.s2C);
 }
 
 void gemm(const GemmDesc& g, hipStream_t st) {
   if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return;
   GemmP p{g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.sA, g.sB, g.sC, g.m, g.n, g.k,
-          g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? 1 : 0};
-  dim3 grid(g.n / GT, g.m / GT, g.batch);
+          g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? 1 : 0, g.batch, g.s2A, g.s2B, g.s2C};
+  if (g.batch2 <= 0) return;
+  dim3 grid(g.n / GT, g.m / GT, g.batch * g.batch2);
   if (!g.ta && !g.tb) gemm64_kernel<false, false><<<grid, 512, 0, st>>>(p);
   else if (!g.ta && g.tb) gemm64_kernel<false, true><<<grid, 512, 0, st>>>(p);
   else if (g.ta && !g.tb) gemm64_kernel<true, false><<<grid, 512, 0, st>>>(p);
@@ -270,6 +276,20 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
                                                               int info_base, const double* rhs, double* sol, double* Linv) {
   __shared__ DfShared sh;
   potrf_dataflow_body(A, ld, nb, ready, dinv_g, info, info_base, rhs, sol, Linv, sh, blockIdx.x, gridDim.x);
+}
+
+// S factorizations side by side: blockIdx.y selects the matrix, its flags / block inverses and its status word
+__global__ __launch_bounds__(256) void potrf_dataflow_batch_kernel(double* A, int64_t ld, int nb, int* scratch, int64_t scratch_ints,
+                                                                    int64_t flag_ints, int* info, double* Linv, int64_t stride) {
+  __shared__ DfShared sh;
+  const int64_t s = blockIdx.y;
+  int* ready = scratch + s * scratch_ints;
+  potrf_dataflow_body(A + s * stride, ld, nb, ready, reinterpret_cast<double*>(ready + flag_ints), info + s, 0, nullptr, nullptr,
+                      Linv ? Linv + s * stride : nullptr, sh, blockIdx.x, gridDim.x);
+}
+__global__ void potrf_timeout_batch_kernel(const int* scratch, int64_t scratch_ints, int abort_off, int* info, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S && scratch[s * scratch_ints + abort_off] != 0) info[s] = POTRF_TIMEOUT;
 }
 
 #ifdef SGP_POTRF_STAMPS
@@ -352,7 +372,20 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
 }
 
-void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st) {
+void potrf_lower_batch(double* A, double* Linv, int64_t ld, int Mp, int S, int64_t stride, int* info, int* scratch, hipStream_t st) {
+  const int nb = Mp / DB;
+  const int ntile = nb * (nb + 1) / 2;
+  const int64_t sints = (int64_t)potrf_scratch_ints(Mp), fints = (int64_t)potrf_flag_ints(Mp);
+  // every workgroup of the launch must be resident: the S groups share the device's CUs
+  int per = df_max_workgroups() / S;
+  if (per < 1) per = 1;
+  zero_ints(scratch, (int)(sints * S), st);
+  if (Linv) fill_zero(Linv, (size_t)stride * (S - 1) + (size_t)Mp * ld, st);
+  potrf_dataflow_batch_kernel<<<dim3(ntile < per ? ntile : per, S), 256, 0, st>>>(A, ld, nb, scratch, sints, fints, info, Linv, stride);
+  potrf_timeout_batch_kernel<<<1, 64, 0, st>>>(scratch, sints, ntile * DF_FLAG_STRIDE, info, S);
+}
+
+void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st, int nbatch, int64_t stride) {
   for (int s = DB; s < Mp; s *= 2) {
     const int np = Mp / (2 * s);
     const int rem = Mp - np * 2 * s;
@@ -364,6 +397,7 @@ void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp,
       a.B = Linv + o * (ld + 1); a.ldb = ld; a.sB = pstride;
       a.C = tmp + o * (ld + 1) + (int64_t)s * ld; a.ldc = ld; a.sC = pstride;
       a.m = n2; a.n = s; a.k = s; a.batch = batch; a.klo_mask = 2;
+      a.batch2 = nbatch; a.s2A = a.s2B = a.s2C = stride;
       gemm(a, st);
       // Inv21 = -Inv22 * T   (n2 x s) = (n2 x n2)(n2 x s), Inv22 lower-triangular -> k <= row tile end
       GemmDesc b;
@@ -371,6 +405,7 @@ void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp,
       b.B = tmp + o * (ld + 1) + (int64_t)s * ld; b.ldb = ld; b.sB = pstride;
       b.C = Linv + o * (ld + 1) + (int64_t)s * ld; b.ldc = ld; b.sC = pstride;
       b.m = n2; b.n = s; b.k = n2; b.batch = batch; b.alpha = -1.0; b.khi_mask = 1;
+      b.batch2 = nbatch; b.s2A = b.s2B = b.s2C = stride;
       gemm(b, st);
     };
     if (np > 0) level(0, np, s);

@@ -17,6 +17,10 @@ struct GemmDesc {
   int64_t lda = 0, ldb = 0, ldc = 0;
   int64_t sA = 0, sB = 0, sC = 0;
   int m = 0, n = 0, k = 0, batch = 1;
+  // a second, outer batch level (blockIdx.z = outer * batch + inner) with its own strides: S independent problems
+  // (the SVGP bound at S hyper-parameter samples) around a product that is already batched (tri_inverse levels, k-slices)
+  int batch2 = 1;
+  int64_t s2A = 0, s2B = 0, s2C = 0;
   double alpha = 1.0, beta = 0.0;
   bool ta = false, tb = false;
   int klo_mask = 0, khi_mask = 0;
@@ -27,6 +31,7 @@ int available_cus();       // CUs a launch of this host thread can occupy (devic
 void set_cu_budget(int n);  // CUs the calling host thread's launches may occupy (CU-masked streams); 0 = all
 // the same product with the contraction cut into S slices (S * m * n doubles of scratch; falls back to gemm() when k is
 // not a multiple of 16 S): for few output tiles and a long k
+// (batch must be 1; batch2 problems are cut alike: scratch = batch2 * S * m * n doubles)
 void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st);
 
 // In-place lower Cholesky of the Mp x Mp matrix A (Mp multiple of 64); strictly-upper part of the
@@ -45,10 +50,14 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
                  const double* rhs = nullptr, double* sol = nullptr, bool caller_managed = false);
 // the word of `scratch` the dataflow launch raises when it gave up waiting (then info must become SGP_INFO_TIMEOUT)
 const int* potrf_abort_flag(const int* scratch, int Mp);
+// S independent factorizations in ONE dataflow launch (grid = workgroups x S): matrix s at A + s * stride (Linv likewise),
+// its status word info[s], its scratch at scratch + s * potrf_scratch_ints(Mp).  4 launches whatever S is.
+void potrf_lower_batch(double* A, double* Linv, int64_t ld, int Mp, int S, int64_t stride, int* info, int* scratch, hipStream_t st);
 
 // Completes Linv (diagonal 64-blocks already inverted by potrf_lower) to the full inverse of L.
 // tmp: Mp x Mp scratch with the same ld.
-void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st);
+// nbatch > 1: the same for nbatch matrices `stride` doubles apart (L, Linv and tmp alike), in the same number of launches.
+void tri_inverse(const double* L, double* Linv, double* tmp, int64_t ld, int Mp, hipStream_t st, int nbatch = 1, int64_t stride = 0);
 
 // y = op(A) x for a lower-triangular (or general) Mp x Mp matrix; one wave per row.
 void gemv(const double* A, int64_t ld, int Mp, bool trans, const double* x, double* y, hipStream_t st);

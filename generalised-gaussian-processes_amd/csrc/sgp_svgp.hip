@@ -402,6 +402,343 @@ static void svgp_forward(const SvgpWs& w, const double* Xb, int64_t ldx, int64_t
   svgp_cols_kernel<<<Bp / 64, 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, sf2, w.mu, w.v);
 }
 
+
+// =====================================================================================================================
+// The bound at S hyper-parameter samples in ONE chain of launches (sgp_svgp_elbo_batch) -- the five theta samples per
+// minibatch of the reference's BayesianStochasticVariationalGP (models/bayesian_svgp.py:156-167).  Every launch below
+// carries the sample index in blockIdx.y (GEMMs: GemmDesc::batch2), every per-sample buffer is an array of S equal
+// slices, so the chain is ~36 launches whatever S is (5 x 41 before: the step was bound by the host enqueueing them).
+// What does not depend on theta is done once: padded tril(L_S), padded m, the KL term.
+// =====================================================================================================================
+constexpr int SVGP_MAX_S = 8;
+struct SvgpThetaS {  // a kernel argument (2.2 KB): theta never makes a host-to-device copy of its own
+  KernArgs ka[SVGP_MAX_S];
+  double s2[SVGP_MAX_S];
+};
+
+// LSp = tril(LS) padded to Mp x Mp with a unit diagonal ; mp = m zero padded ; status words <- 0
+__global__ __launch_bounds__(256) void svgp_prep_batch_kernel(const double* __restrict__ LS, const double* __restrict__ m, int M, int Mp,
+                                                              double* __restrict__ LSp, double* __restrict__ mp, int* __restrict__ info, int S) {
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    double v = 0.0;
+    if (r < M && c <= r) v = LS[(int64_t)r * M + c];
+    else if (r >= M && r == c) v = 1.0;
+    LSp[e] = v;
+    if (e < Mp) mp[e] = e < M ? m[e] : 0.0;
+    if (e < S) info[e] = 0;
+  }
+}
+
+// Kp[s] = Kuu(theta_s) + jitter I, padded with the identity (the factorization's input), Mp x Mp
+template <int KID>
+__global__ __launch_bounds__(256) void svgp_kuu_batch_kernel(const double* __restrict__ Z, int64_t ldz, SvgpThetaS th, double jitter, int M,
+                                                             int Mp, double* __restrict__ Kp) {
+  const KernArgs& ka = th.ka[blockIdx.y];
+  double* K = Kp + (int64_t)blockIdx.y * Mp * Mp;
+  const int64_t total = (int64_t)Mp * Mp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / Mp), j = (int)(e - (int64_t)i * Mp);
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < M && j < M) {
+      double r2 = 0.0;
+      for (int q = 0; q < ka.d; ++q) {
+        const double df = (Z[i * ldz + q] - Z[j * ldz + q]) * ka.inv_ls[q];
+        r2 = fma(df, df, r2);
+      }
+      v = ka.sf2 * kprofile<KID>(r2);
+      if (i == j) v += jitter;
+    }
+    K[e] = v;
+  }
+}
+
+template <int KID>
+__global__ __launch_bounds__(256) void svgp_kub_batch_kernel(const double* __restrict__ Z, int64_t ldz, const double* __restrict__ Xb,
+                                                             int64_t ldx, SvgpThetaS th, int M, int Mp, int B, int Bp,
+                                                             double* __restrict__ Kub) {
+  const KernArgs& ka = th.ka[blockIdx.y];
+  const int64_t total = (int64_t)Mp * Bp;
+  double* K = Kub + (int64_t)blockIdx.y * total;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / Bp), b = (int)(e - (int64_t)m * Bp);
+    double v = 0.0;
+    if (m < M && b < B) {
+      double r2 = 0.0;
+      for (int q = 0; q < ka.d; ++q) {
+        const double df = (Z[m * ldz + q] - Xb[b * ldx + q]) * ka.inv_ls[q];
+        r2 = fma(df, df, r2);
+      }
+      v = ka.sf2 * kprofile<KID>(r2);
+    }
+    K[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void svgp_cols_batch_kernel(const double* __restrict__ A, const double* __restrict__ T,
+                                                              const double* __restrict__ mp, int Mp, int Bp, int B, SvgpThetaS th,
+                                                              double* __restrict__ mu, double* __restrict__ v) {
+  __shared__ double pm[4][64], pa[4][64], pt[4][64];
+  const int64_t off = (int64_t)blockIdx.y * Mp * Bp;
+  A += off; T += off; mu += (int64_t)blockIdx.y * Bp; v += (int64_t)blockIdx.y * Bp;
+  const double kbb = th.ka[blockIdx.y].sf2;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  double sm = 0.0, sa = 0.0, st = 0.0;
+  for (int m = w; m < Mp; m += 4) {
+    const double a = A[(int64_t)m * Bp + col], t = T[(int64_t)m * Bp + col];
+    sm = fma(a, mp[m], sm);
+    sa = fma(a, a, sa);
+    st = fma(t, t, st);
+  }
+  pm[w][l] = sm; pa[w][l] = sa; pt[w][l] = st;
+  __syncthreads();
+  if (w == 0) {
+    mu[col] = (pm[0][l] + pm[1][l]) + (pm[2][l] + pm[3][l]);
+    v[col] = col < B ? kbb - ((pa[0][l] + pa[1][l]) + (pa[2][l] + pa[3][l])) + ((pt[0][l] + pt[1][l]) + (pt[2][l] + pt[3][l])) : 1.0;
+  }
+}
+
+// expected log-likelihood of sample blockIdx.y: same arithmetic as svgp_ell_kernel, 64 blocks per sample
+__global__ __launch_bounds__(256) void svgp_ell_batch_kernel(const double* __restrict__ y, const double* __restrict__ mu,
+                                                             const double* __restrict__ v, int B, int Bp, SvgpThetaS th, int lik, GHTable gh,
+                                                             double* __restrict__ dmu, double* __restrict__ dv, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t ob = (int64_t)blockIdx.y * Bp;
+  mu += ob; v += ob; dmu += ob; dv += ob; part += (int64_t)blockIdx.y * 128;
+  const double s2 = th.s2[blockIdx.y];
+  double se = 0.0, ss = 0.0;
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+    const double yb = y[b], m = mu[b], vv = v[b];
+    double ell, gm, gv, gs = 0.0;
+    if (lik == 0) {
+      const double r = yb - m, q = r * r + vv;
+      ell = -0.9189385332046727 - 0.5 * log(s2) - q / (2.0 * s2);
+      gm = r / s2;
+      gv = -0.5 / s2;
+      gs = -0.5 / s2 + q / (2.0 * s2 * s2);
+    } else {
+      const double sd = sqrt(vv);
+      ell = 0.0; gm = 0.0; gv = 0.0;
+      for (int i = 0; i < GH_N; ++i) {
+        const double z = yb * (m + sd * gh.x[i]);
+        ell = fma(gh.w[i], log_ndtr_dev(z), ell);
+        const double r = gh.w[i] * yb * mills_dev(z);
+        gm += r;
+        gv = fma(r, gh.x[i], gv);
+      }
+      gv = gv / (2.0 * sd);
+    }
+    dmu[b] = gm;
+    dv[b] = gv;
+    se += ell;
+    ss += gs;
+  }
+  se = block_sum256(se, red);
+  ss = block_sum256(ss, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = se;
+    part[2 * blockIdx.x + 1] = ss;
+  }
+}
+
+// out[s] = [ELBO per datum | sum_b E log p | KL], g_s2[s]; one thread per sample, fixed summation order
+__global__ void svgp_finalize_batch_kernel(const double* __restrict__ part, const double* __restrict__ kl, int M, int B, double N_total,
+                                           int S, double* __restrict__ out, double* __restrict__ g_s2) {
+  const int s = threadIdx.x;
+  if (blockIdx.x != 0 || s >= S) return;
+  double se = 0.0, ss = 0.0;
+  for (int i = 0; i < 64; ++i) {
+    se += part[(int64_t)s * 128 + 2 * i];
+    ss += part[(int64_t)s * 128 + 2 * i + 1];
+  }
+  double klsum = 0.0;
+  for (int i = 0; i < 64; ++i) klsum += kl[i];
+  const double klv = 0.5 * (klsum - (double)M);
+  out[3 * s] = se / (double)B - klv / N_total;
+  out[3 * s + 1] = se;
+  out[3 * s + 2] = klv;
+  if (g_s2) g_s2[s] = ss / (double)B;
+}
+
+__global__ __launch_bounds__(256) void svgp_abar_batch_kernel(const double* __restrict__ A, const double* __restrict__ U,
+                                                              const double* __restrict__ mp, const double* __restrict__ dmu,
+                                                              const double* __restrict__ dv, int Mp, int Bp, int B, double invB,
+                                                              double* __restrict__ Abar, double* __restrict__ Av) {
+  const int64_t total = (int64_t)Mp * Bp, off = (int64_t)blockIdx.y * total, ob = (int64_t)blockIdx.y * Bp;
+  A += off; U += off; Abar += off; Av += off; dmu += ob; dv += ob;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / Bp), b = (int)(e - (int64_t)m * Bp);
+    double ab = 0.0, av = 0.0;
+    if (b < B) {
+      const double mb = dmu[b] * invB, vb = dv[b] * invB;
+      ab = mp[m] * mb + 2.0 * vb * (U[e] - A[e]);
+      av = A[e] * vb;
+    }
+    Abar[e] = ab;
+    Av[e] = av;
+  }
+}
+
+__global__ __launch_bounds__(256) void svgp_gm_batch_kernel(const double* __restrict__ A, const double* __restrict__ dmu,
+                                                            const double* __restrict__ m, int M, int Mp, int Bp, int B, double invB,
+                                                            double invN, double* __restrict__ g_m) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  A += (int64_t)blockIdx.y * Mp * Bp; dmu += (int64_t)blockIdx.y * Bp; g_m += (int64_t)blockIdx.y * M;
+  double s = 0.0;
+  for (int b = lane; b < B; b += 64) s = fma(A[(int64_t)row * Bp + b], dmu[b], s);
+  s = wave_sum(s);
+  if (lane == 0) g_m[row] = s * invB - m[row] * invN;
+}
+
+__global__ __launch_bounds__(256) void svgp_gls_batch_kernel(const double* __restrict__ G, int Mp, const double* __restrict__ LS,
+                                                             int M, double invN, double* __restrict__ g_LS) {
+  const int64_t total = (int64_t)M * M;
+  G += (int64_t)blockIdx.y * Mp * Mp; g_LS += (int64_t)blockIdx.y * total;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+    double v = 0.0;
+    if (c <= r) {
+      v = 2.0 * G[(int64_t)r * Mp + c] - LS[e] * invN;
+      if (c == r) v += invN / LS[e];
+    }
+    g_LS[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void svgp_tril_batch_kernel(double* __restrict__ X, int Mp, double scale, int halve_diag) {
+  const int64_t total = (int64_t)Mp * Mp;
+  X += (int64_t)blockIdx.y * total;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    double v = X[e] * scale;
+    if (c > r) v = 0.0;
+    else if (c == r && halve_diag) v *= 0.5;
+    X[e] = v;
+  }
+}
+
+// Kernel-derivative contractions of sample blockIdx.y, one workgroup per inducing row and source:
+//   blockIdx.x <  M : row m of Kubbar (Mp x Bp)   against d Kub[m][.]  (data = the minibatch rows)
+//   blockIdx.x >= M : row m of sym(P) (Mp x Mp)   against d Kuu[m][.]  (data = the inducing inputs; Kuubar = (P + P^T) / 2)
+// part[src][m][q] = sum E df_q^2 (q < d), part[src][m][d] = sum Kbar k', gz[src][m][q] = sum E df_q, E = Kbar sf2 dk'/dr2
+template <int KID>
+__global__ __launch_bounds__(256) void svgp_kbwd_batch_kernel(const double* __restrict__ Z, int64_t ldz, const double* __restrict__ Xb,
+                                                              int64_t ldx, SvgpThetaS th, const double* __restrict__ Kbb,
+                                                              const double* __restrict__ P, int M, int Mp, int Bp, int B,
+                                                              double* __restrict__ part, double* __restrict__ gzraw) {
+  __shared__ double red[4];
+  const KernArgs& ka = th.ka[blockIdx.y];
+  const int d = ka.d;
+  const bool uu = (int)blockIdx.x >= M;
+  const int m = uu ? (int)blockIdx.x - M : (int)blockIdx.x;
+  const double* data = uu ? Z : Xb;
+  const int64_t ldd = uu ? ldz : ldx;
+  const int n = uu ? M : B;
+  Kbb += (int64_t)blockIdx.y * Mp * Bp;
+  P += (int64_t)blockIdx.y * Mp * Mp;
+  part += ((int64_t)blockIdx.y * 2 + (uu ? 1 : 0)) * M * (d + 1);
+  gzraw += ((int64_t)blockIdx.y * 2 + (uu ? 1 : 0)) * M * d;
+  for (int q = 0; q <= d; ++q) {
+    double s2 = 0.0, s1 = 0.0;
+    for (int b = threadIdx.x; b < n; b += 256) {
+      double r2 = 0.0, dfq = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double df = (Z[m * ldz + j] - data[b * ldd + j]) * ka.inv_ls[j];
+        r2 = fma(df, df, r2);
+        if (j == q) dfq = df;
+      }
+      double kp, hp;
+      kprofile_grad<KID>(r2, kp, hp);
+      const double kb = uu ? 0.5 * (P[(int64_t)m * Mp + b] + P[(int64_t)b * Mp + m]) : Kbb[(int64_t)m * Bp + b];
+      if (q == d) {
+        s2 = fma(kb, kp, s2);
+      } else {
+        const double E = kb * ka.sf2 * hp;
+        s1 = fma(E, dfq, s1);
+        s2 = fma(E * dfq, dfq, s2);
+      }
+    }
+    s2 = block_sum256(s2, red);
+    s1 = block_sum256(s1, red);
+    if (threadIdx.x == 0) {
+      part[(size_t)m * (d + 1) + q] = s2;
+      if (q < d) gzraw[(size_t)m * d + q] = s1;
+    }
+  }
+}
+// g_ls[s][q] = -2 inv_ls_q (sum_m part_ub + sum_m part_uu) ; g_sf2[s] = the two k' sums + sum_b dv / B ;
+// g_Z[s][m][q] = inv_ls_q (2 gz_ub + 4 gz_uu): row AND column m of the symmetric Kuubar move with z_m
+__global__ __launch_bounds__(256) void svgp_kbwd_reduce_batch_kernel(const double* __restrict__ part, const double* __restrict__ gzraw,
+                                                                     int M, SvgpThetaS th, const double* __restrict__ dv, int B, int Bp,
+                                                                     double invB, double* g_ls, double* g_sf2, double* g_Z) {
+  __shared__ double red[4];
+  const KernArgs& ka = th.ka[blockIdx.y];
+  const int d = ka.d;
+  const double* pub = part + (int64_t)blockIdx.y * 2 * M * (d + 1);
+  const double* puu = pub + (int64_t)M * (d + 1);
+  const double* zub = gzraw + (int64_t)blockIdx.y * 2 * M * d;
+  const double* zuu = zub + (int64_t)M * d;
+  dv += (int64_t)blockIdx.y * Bp;
+  if (blockIdx.x == 0) {
+    for (int q = 0; q <= d; ++q) {
+      double s = 0.0;
+      for (int m = threadIdx.x; m < M; m += 256) s += pub[(size_t)m * (d + 1) + q] + puu[(size_t)m * (d + 1) + q];
+      s = block_sum256(s, red);
+      if (q == d) {
+        double t = 0.0;
+        for (int b = threadIdx.x; b < B; b += 256) t += dv[b];
+        t = block_sum256(t, red);
+        if (threadIdx.x == 0) g_sf2[blockIdx.y] = s + t * invB;
+      } else if (threadIdx.x == 0) {
+        g_ls[(int64_t)blockIdx.y * d + q] = -2.0 * ka.inv_ls[q] * s;
+      }
+    }
+  }
+  const int64_t total = (int64_t)M * d;
+  double* gz = g_Z + (int64_t)blockIdx.y * total;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    gz[e] = ka.inv_ls[(int)(e % d)] * (2.0 * zub[e] + 4.0 * zuu[e]);
+}
+
+struct SvgpBatchWs {
+  double *Kp, *Linv, *tmp, *LSp, *S1, *Q, *P, *Kub, *A, *T, *U, *Abar, *Av, *mp, *mu, *v, *dmu, *dv, *part, *kl, *splitk, *kpart, *gzraw;
+  int* flags;
+  size_t bytes;
+};
+static SvgpBatchWs carve_svgp_batch(void* ws, int Mp, int Bp, int M, int d, int S) {
+  Carver c(ws);
+  SvgpBatchWs w;
+  const size_t mm = (size_t)Mp * Mp, mb = (size_t)Mp * Bp;
+  w.LSp = c.take<double>(mm);
+  w.mp = c.take<double>(Mp);
+  w.kl = c.take<double>(64);
+  w.Kp = c.take<double>(S * mm);
+  w.Linv = c.take<double>(S * mm);
+  w.tmp = c.take<double>(S * mm);
+  w.S1 = c.take<double>(S * mm);
+  w.Q = c.take<double>(S * mm);
+  w.P = c.take<double>(S * mm);
+  w.Kub = c.take<double>(S * mb);
+  w.A = c.take<double>(S * mb);
+  w.T = c.take<double>(S * mb);
+  w.U = c.take<double>(S * mb);
+  w.Abar = c.take<double>(S * mb);
+  w.Av = c.take<double>(S * mb);
+  w.mu = c.take<double>((size_t)S * Bp);
+  w.v = c.take<double>((size_t)S * Bp);
+  w.dmu = c.take<double>((size_t)S * Bp);
+  w.dv = c.take<double>((size_t)S * Bp);
+  w.part = c.take<double>((size_t)S * 128);
+  w.splitk = c.take<double>((size_t)S * SVGP_SPLITK * mm);
+  w.kpart = c.take<double>((size_t)S * 2 * M * (d + 1));
+  w.gzraw = c.take<double>((size_t)S * 2 * M * d);
+  w.flags = c.take<int>((size_t)S * potrf_scratch_ints(Mp));
+  w.bytes = c.used();
+  return w;
+}
+
 }  // namespace sgp
 
 using namespace sgp;
@@ -487,6 +824,115 @@ extern "C" int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, in
   svgp_kub_bwd_reduce_kernel<<<grid_for_s((int64_t)M * d, 256), 256, 0, st>>>(w.kpart, w.gzraw, M, ka, w.dv, (int)B, invB, g_ls, g_sf2, g_Z);
   const int rc = sgp_kuu_bwd(Z, ldz, inv_ls, sf2, w.Kuubar, M, d, kernel_id, g_ls, g_sf2, g_Z, w.kuu_ws, w.kuu_ws_bytes, st);
   if (rc != SGP_OK) return rc;
+  return check_launch();
+}
+
+extern "C" size_t sgp_svgp_batch_workspace_bytes(int64_t B, int M, int d, int S) {
+  if (B <= 0 || B > (1 << 20) || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || S < 1 || S > SVGP_MAX_S) return 0;
+  return carve_svgp_batch(nullptr, padded_m(M), (int)round_up64(B, 64), M, d, S).bytes;
+}
+
+extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                                   int S, const double* inv_ls, const double* sf2, const double* s2, double jitter, const double* m,
+                                   const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id, int with_grads,
+                                   double* out, double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
+                                   int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!Xb || !yb || !Z || !inv_ls || !sf2 || !s2 || !m || !LS || !out || !info || B <= 0 || M <= 0 || d <= 0 || ldx < d || ldz < d ||
+      N_total <= 0)
+    return SGP_ERR_ARG;
+  if (S < 1 || S > SVGP_MAX_S) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52 || likelihood_id < 0 || likelihood_id > 1) return SGP_ERR_ARG;
+  if (with_grads && (!g_m || !g_LS || !g_Z || !g_ls || !g_sf2 || !g_s2)) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || B > (1 << 20)) return SGP_ERR_DIM;
+  SvgpThetaS th{};
+  for (int s = 0; s < S; ++s) {
+    if (likelihood_id == 0 && !(s2[s] > 0.0)) return SGP_ERR_ARG;
+    th.ka[s] = make_ka_s(inv_ls + (size_t)s * d, sf2[s], d);
+    th.s2[s] = s2[s];
+  }
+  const int Mp = padded_m(M), Bp = (int)round_up64(B, 64);
+  SvgpBatchWs w = carve_svgp_batch(ws, Mp, Bp, M, d, S);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  static const GHTable gh = make_gh();
+  const double invB = 1.0 / (double)B, invN = 1.0 / (double)N_total;
+  const int64_t mm = (int64_t)Mp * Mp, mb = (int64_t)Mp * Bp;
+  const int gmm = grid_for_s(mm), gmb = grid_for_s(mb);
+  auto gemm_s = [&](GemmDesc g, int64_t sa, int64_t sb, int64_t sc) {
+    g.batch2 = S; g.s2A = sa; g.s2B = sb; g.s2C = sc;
+    gemm(g, st);
+  };
+
+  // ---- forward ------------------------------------------------------------------------------------------------
+  svgp_prep_batch_kernel<<<gmm, 256, 0, st>>>(LS, m, M, Mp, w.LSp, w.mp, info, S);
+  svgp_kl_kernel<<<64, 256, 0, st>>>(m, LS, M, w.kl);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: svgp_kuu_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+    case SGP_KERNEL_MATERN32: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+    default: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+  }
+  potrf_lower_batch(w.Kp, w.Linv, Mp, Mp, S, mm, info, w.flags, st);
+  tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st, S, mm);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: svgp_kub_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
+    case SGP_KERNEL_MATERN32: svgp_kub_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
+    default: svgp_kub_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
+  }
+  GemmDesc a;  // A = L^-1 Kub
+  a.A = w.Linv; a.lda = Mp; a.B = w.Kub; a.ldb = Bp; a.C = w.A; a.ldc = Bp;
+  a.m = Mp; a.n = Bp; a.k = Mp; a.khi_mask = 1;
+  gemm_s(a, mm, mb, mb);
+  GemmDesc t;  // T = LS^T A   (LS shared by the samples)
+  t.A = w.LSp; t.lda = Mp; t.ta = true; t.B = w.A; t.ldb = Bp; t.C = w.T; t.ldc = Bp;
+  t.m = Mp; t.n = Bp; t.k = Mp; t.klo_mask = 1;
+  gemm_s(t, 0, mb, mb);
+  svgp_cols_batch_kernel<<<dim3(Bp / 64, S), 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, th, w.mu, w.v);
+  svgp_ell_batch_kernel<<<dim3(64, S), 256, 0, st>>>(yb, w.mu, w.v, (int)B, Bp, th, likelihood_id, gh, w.dmu, w.dv, w.part);
+  svgp_finalize_batch_kernel<<<1, 64, 0, st>>>(w.part, w.kl, M, (int)B, (double)N_total, S, out, with_grads ? g_s2 : nullptr);
+  if (!with_grads) return check_launch();
+
+  // ---- reverse (the closed-form adjoint of sgp_svgp_elbo, sample by sample in blockIdx.y) ------------------------
+  GemmDesc u;  // U = LS T
+  u.A = w.LSp; u.lda = Mp; u.B = w.T; u.ldb = Bp; u.C = w.U; u.ldc = Bp;
+  u.m = Mp; u.n = Bp; u.k = Mp; u.khi_mask = 1;
+  gemm_s(u, 0, mb, mb);
+  svgp_abar_batch_kernel<<<dim3(gmb, S), 256, 0, st>>>(w.A, w.U, w.mp, w.dmu, w.dv, Mp, Bp, (int)B, invB, w.Abar, w.Av);
+  svgp_gm_batch_kernel<<<dim3((M + 3) / 4, S), 256, 0, st>>>(w.A, w.dmu, m, M, Mp, Bp, (int)B, invB, invN, g_m);
+  GemmDesc gl;  // G = (A diag(vbar)) T^T -> g_LS
+  gl.A = w.Av; gl.lda = Bp; gl.B = w.T; gl.ldb = Bp; gl.tb = true; gl.C = w.S1; gl.ldc = Mp;
+  gl.m = Mp; gl.n = Mp; gl.k = Bp;
+  gl.batch2 = S; gl.s2A = mb; gl.s2B = mb; gl.s2C = mm;
+  gemm_splitk(gl, SVGP_SPLITK, w.splitk, st);
+  svgp_gls_batch_kernel<<<dim3(grid_for_s((int64_t)M * M), S), 256, 0, st>>>(w.S1, Mp, LS, M, invN, g_LS);
+  GemmDesc bb;  // Kubbar = L^-T Abar (into U)
+  bb.A = w.Linv; bb.lda = Mp; bb.ta = true; bb.B = w.Abar; bb.ldb = Bp; bb.C = w.U; bb.ldc = Bp;
+  bb.m = Mp; bb.n = Bp; bb.k = Mp; bb.klo_mask = 1;
+  gemm_s(bb, mm, mb, mb);
+  GemmDesc s1;  // S1 = Kubbar A^T ; Lbar = -tril(S1)
+  s1.A = w.U; s1.lda = Bp; s1.B = w.A; s1.ldb = Bp; s1.tb = true; s1.C = w.S1; s1.ldc = Mp;
+  s1.m = Mp; s1.n = Mp; s1.k = Bp;
+  s1.batch2 = S; s1.s2A = mb; s1.s2B = mb; s1.s2C = mm;
+  gemm_splitk(s1, SVGP_SPLITK, w.splitk, st);
+  svgp_tril_batch_kernel<<<dim3(gmm, S), 256, 0, st>>>(w.S1, Mp, -1.0, 0);
+  GemmDesc q;  // Q = L^T Lbar ; Phi(Q)
+  q.A = w.Kp; q.lda = Mp; q.ta = true; q.B = w.S1; q.ldb = Mp; q.C = w.Q; q.ldc = Mp;
+  q.m = Mp; q.n = Mp; q.k = Mp; q.klo_mask = 3;
+  gemm_s(q, mm, mm, mm);
+  svgp_tril_batch_kernel<<<dim3(gmm, S), 256, 0, st>>>(w.Q, Mp, 1.0, 1);
+  GemmDesc p1;  // tmp = L^-T Phi(Q)
+  p1.A = w.Linv; p1.lda = Mp; p1.ta = true; p1.B = w.Q; p1.ldb = Mp; p1.C = w.tmp; p1.ldc = Mp;
+  p1.m = Mp; p1.n = Mp; p1.k = Mp; p1.klo_mask = 3;
+  gemm_s(p1, mm, mm, mm);
+  GemmDesc p2;  // P = tmp L^-1 ; Kuubar = sym(P), read in place by the contraction kernel
+  p2.A = w.tmp; p2.lda = Mp; p2.B = w.Linv; p2.ldb = Mp; p2.C = w.P; p2.ldc = Mp;
+  p2.m = Mp; p2.n = Mp; p2.k = Mp; p2.klo_mask = 2;
+  gemm_s(p2, mm, mm, mm);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: svgp_kbwd_batch_kernel<SGP_KERNEL_RBF><<<dim3(2 * M, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, w.U, w.P, M, Mp, Bp, (int)B, w.kpart, w.gzraw); break;
+    case SGP_KERNEL_MATERN32: svgp_kbwd_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(2 * M, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, w.U, w.P, M, Mp, Bp, (int)B, w.kpart, w.gzraw); break;
+    default: svgp_kbwd_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(2 * M, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, w.U, w.P, M, Mp, Bp, (int)B, w.kpart, w.gzraw); break;
+  }
+  svgp_kbwd_reduce_batch_kernel<<<dim3(grid_for_s((int64_t)M * d, 256), S), 256, 0, st>>>(w.kpart, w.gzraw, M, th, w.dv, (int)B, Bp, invB, g_ls, g_sf2, g_Z);
   return check_launch();
 }
 

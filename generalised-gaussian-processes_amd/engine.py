@@ -516,6 +516,44 @@ class HipEngine:
         _lib.check("sgp_svgp_elbo", st)
         return res
 
+    def svgp_elbo_batch(self, Xb, yb, Z, ls, sf2, s2, m, LS, N_total, jitter=1e-6, kernel="rbf", likelihood="gaussian",
+                        with_grads=False):
+        """The bound of one minibatch at S hyper-parameter samples in ONE chain of launches (sgp_svgp_elbo_batch).
+        ls: S x d, sf2, s2: S (host sequences / arrays).  Returns dict(out [S, 3], info [S], and with ``with_grads``
+        g_m [S, M], g_LS [S, M, M], g_Z [S, M, d], g_ls [S, d], g_sf2 [S], g_s2 [S]); device tensors, nothing synchronised."""
+        import ctypes
+        B, d = Xb.shape
+        M = Z.shape[0]
+        for t, n in ((Xb, "Xb"), (yb, "yb"), (Z, "Z"), (m, "m"), (LS, "LS")):
+            self._chk(t, n)
+        lsv = [[float(v) for v in row] for row in ls]
+        S = len(lsv)
+        if any(len(row) != d for row in lsv) or len(sf2) != S or len(s2) != S:
+            raise ValueError("ls must be S x d, sf2 and s2 of length S")
+        lik = {"gaussian": 0, "bernoulli": 1, "bernoulli_probit": 1}[likelihood]
+        inv = (ctypes.c_double * (S * d))(*[1.0 / v for row in lsv for v in row])
+        sf2c = (ctypes.c_double * S)(*[float(v) for v in sf2])
+        s2c = (ctypes.c_double * S)(*[float(v) for v in s2])
+        out = self.empty(S, 3)
+        info = torch.empty(S, dtype=torch.int32, device=self.device)
+        res = {"out": out, "info": info}
+        g = {}
+        if with_grads:
+            g = {"g_m": self.empty(S, M), "g_LS": self.empty(S, M, M), "g_Z": self.empty(S, M, d), "g_ls": self.empty(S, d),
+                 "g_sf2": self.empty(S), "g_s2": self.empty(S)}
+            res.update(g)
+        nbytes = self.lib.sgp_svgp_batch_workspace_bytes(B, M, d, S)
+        if nbytes == 0:
+            raise ValueError("unsupported SVGP batch shape B=%d M=%d d=%d S=%d (S <= 8)" % (B, M, d, S))
+        ws = self._workspace("svgp_batch", nbytes)
+        st = self.lib.sgp_svgp_elbo_batch(
+            self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, S, inv, sf2c, s2c, float(jitter), self._ptr(m), self._ptr(LS),
+            int(N_total), M, d, _kernel_id(kernel), lik, 1 if with_grads else 0, self._ptr(out),
+            self._ptr(g.get("g_m")), self._ptr(g.get("g_LS")), self._ptr(g.get("g_Z")), self._ptr(g.get("g_ls")),
+            self._ptr(g.get("g_sf2")), self._ptr(g.get("g_s2")), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_svgp_elbo_batch", st)
+        return res
+
     def svgp_predict(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
         T, d = Xs.shape
         M = Z.shape[0]

@@ -322,6 +322,43 @@ class _SVGPBoundFn(torch.autograd.Function):
         return (*outs, None, None, None)
 
 
+class _SVGPBatchBoundFn(torch.autograd.Function):
+    """ELBO per datum of one minibatch at S hyper-parameter samples: ONE sgp_svgp_elbo_batch call evaluates all S bounds and
+    their whole reverse pass (~36 launches whatever S is).  theta: S x (d + 2) host tensor [sf2 | ls_1..d | s2] (s2 column
+    ignored by the Bernoulli likelihood); returns the S bounds as a device tensor."""
+
+    @staticmethod
+    def forward(ctx, theta, Z, m, LS, model, xb, yb):
+        eng = model._engine_obj()
+        need = any(ctx.needs_input_grad[:4])
+        th = theta.detach().to("cpu", torch.float64)
+        d = Z.shape[1]
+        res = eng.svgp_elbo_batch(xb, yb, Z.detach().contiguous(), th[:, 1:1 + d].tolist(), th[:, 0].tolist(), th[:, 1 + d].tolist(),
+                                  m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
+                                  kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
+        model._last_infos = res["info"]  # read by the caller together with the loss: one host round trip per minibatch
+        ctx.res = res if need else None
+        ctx.theta_meta = (theta.shape, theta.device, theta.dtype)
+        return res["out"][:, 0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        r = ctx.res
+        n = ctx.needs_input_grad
+        g = gout.to(r["out"].device, torch.float64)
+        g_theta = g_Z = g_m = g_LS = None
+        if n[0]:
+            shape, dev, dt = ctx.theta_meta
+            g_theta = (torch.cat([r["g_sf2"][:, None], r["g_ls"], r["g_s2"][:, None]], 1) * g[:, None]).to(dev, dt).reshape(shape)
+        if n[1]:
+            g_Z = torch.einsum("s,smd->md", g, r["g_Z"])
+        if n[2]:
+            g_m = torch.einsum("s,sm->m", g, r["g_m"])
+        if n[3]:
+            g_LS = torch.einsum("s,smk->mk", g, r["g_LS"])
+        return g_theta, g_Z, g_m, g_LS, None, None, None
+
+
 class StochasticVariationalGP(torch.nn.Module):
     """The sparse GP class with the uncollapsed stochastic bound; q(u) = N(m, S) is learnt numerically
     (reference models/svgp.py:24-141): whitened variational strategy, Cholesky variational distribution
@@ -446,7 +483,9 @@ class VariationalHyperDist(torch.nn.Module):
 class BayesianStochasticVariationalGP(StochasticVariationalGP):
     """SVGP with a variational distribution over log-hyperparameters, 5 reparametrised theta samples per
     minibatch (reference models/bayesian_svgp.py:87-181): theta = exp(log theta), outputscale = theta_0,
-    lengthscale = theta_1..d, noise = theta_{d+1}^2.  The five bounds are five sgp_svgp_elbo launches.
+    lengthscale = theta_1..d, noise = theta_{d+1}^2.  The five bounds of a minibatch are ONE sgp_svgp_elbo_batch call.
+    Bernoulli-probit likelihood (BASELINE config C4; the reference's classification use is scratch_pymc3.py:78-88): labels
+    are mapped to {-1, +1} and there is no noise hyper-parameter, so q(log theta) has d + 1 dimensions.
     Deliberate deviations: the reparametrisation gradient reaches q(log theta) (upstream
     assigns theta through GPyTorch setters, which detaches it), and prediction uses exp() like training."""
 
@@ -455,18 +494,43 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         self.n = self.num_data
         self.input_dim = self.train_x.shape[1]
         self.num_hyper_samples = num_hyper_samples
-        self.log_theta = VariationalHyperDist(self.input_dim + 2, prior_var=0.01, n=self.n, seed=seed)
+        self.bernoulli = getattr(self.likelihood, "name", "gaussian") == "bernoulli"
+        self.hyper_dim = self.input_dim + (1 if self.bernoulli else 2)
+        self.log_theta = VariationalHyperDist(self.hyper_dim, prior_var=0.01, n=self.n, seed=seed)
         self.log_theta.to("cpu")
+        self.batched = True  # one launch chain for all hyper-samples; False = one sgp_svgp_elbo chain per sample (A/B, tests)
 
     def sample_variational_log_hyper(self, num_samples):
         return self.log_theta(num_samples)
 
-    def _elbo_at(self, x_batch, y_batch, log_theta):
+    def _labels(self, y_batch):
+        yb = self._dev(y_batch).reshape(-1)
+        if self.bernoulli:  # {0, 1} or {-1, +1} labels -> {-1, +1}, as elbo_minibatch does
+            yb = torch.where(yb > 0, torch.ones_like(yb), -torch.ones_like(yb))
+        return yb
+
+    def _theta_of(self, log_theta):
+        """[outputscale | lengthscales | noise variance] of one or several log-theta samples (rows); the Bernoulli likelihood
+        has no noise: its column is the constant 1 the kernel ignores."""
         theta = torch.exp(log_theta)
+        if self.bernoulli:
+            return torch.cat([theta, torch.ones_like(theta[..., :1])], -1)
+        return torch.cat([theta[..., :-1], theta[..., -1:] ** 2], -1)
+
+    def _elbo_at(self, x_batch, y_batch, log_theta):
+        th = self._theta_of(log_theta)
         if x_batch.dim() == 1:
             x_batch = x_batch[:, None]
-        return _SVGPBoundFn.apply(theta[1:-1], theta[0], theta[-1] ** 2, self.inducing_inputs, self.variational_mean,
-                                  self.chol_variational_covar, self, self._dev(x_batch), self._dev(y_batch).reshape(-1))
+        s2 = torch.ones(1, dtype=torch.float64, device=self._engine_obj().device) if self.bernoulli else th[-1]
+        return _SVGPBoundFn.apply(th[1:-1], th[0], s2, self.inducing_inputs, self.variational_mean,
+                                  self.chol_variational_covar, self, self._dev(x_batch), self._labels(y_batch))
+
+    def elbo_hyper_samples(self, x_batch, y_batch, log_thetas):
+        """The S bounds (device tensor, differentiable wrt q(u), Z and log_thetas) of one minibatch at the rows of log_thetas."""
+        if x_batch.dim() == 1:
+            x_batch = x_batch[:, None]
+        return _SVGPBatchBoundFn.apply(self._theta_of(log_thetas), self.inducing_inputs, self.variational_mean,
+                                       self.chol_variational_covar, self, self._dev(x_batch), self._labels(y_batch))
 
     @few_host_threads
     def train_model(self, optimizer, train_loader, minibatch_size=100, num_epochs=25, combine_terms=True):
@@ -474,31 +538,33 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         self.train()
         self.likelihood.train()
         epoch_losses, batch_losses = [], []
+        S = self.num_hyper_samples
         for i in range(num_epochs):
             batch_losses = []
             for x_batch, y_batch in train_loader:
                 optimizer.zero_grad()
-                loss = 0.0
                 kl = self.log_theta.kl_per_point()
-                # the five bounds are enqueued back to back: no host round trip between them (their status words are read
-                # together, with the loss).  (One HIP stream per bound was tried: 3.3-3.65 against 3.55 ms per step -- the step
-                # is bound by the host enqueueing 5 x ~40 launches, not by the device; tools/bsvgp_rates.py.)
-                self._pending_infos = []
-                es = []
                 xb = self._dev(x_batch[:, None] if x_batch.dim() == 1 else x_batch)  # one host-to-device copy per minibatch
-                yb = self._dev(y_batch).reshape(-1)
-                try:
-                    for _ in range(self.num_hyper_samples):
-                        lt = self.sample_variational_log_hyper(1).flatten()
-                        es.append(self._elbo_at(xb, yb, lt))
-                    infos = torch.cat(self._pending_infos).to("cpu") if self._pending_infos else torch.zeros(1, dtype=torch.int32)
-                finally:
-                    self._pending_infos = None
+                # one reparametrised draw at a time, as the reference consumes its random stream (:159-160)
+                lts = torch.stack([self.sample_variational_log_hyper(1).flatten() for _ in range(S)])
+                if self.batched and hasattr(self._engine_obj(), "svgp_elbo_batch"):
+                    es = self.elbo_hyper_samples(xb, y_batch, lts)
+                    infos = self._last_infos.to("cpu")
+                    host = es.to("cpu")  # differentiable copy
+                else:
+                    # one launch chain per sample, enqueued back to back; status words read together
+                    self._pending_infos = []
+                    try:
+                        es = [self._elbo_at(xb, y_batch, lts[k]) for k in range(S)]
+                        infos = torch.cat(self._pending_infos).to("cpu") if self._pending_infos else torch.zeros(1, dtype=torch.int32)
+                    finally:
+                        self._pending_infos = None
+                    host = torch.stack(es).to("cpu")
                 for v in infos.tolist():
                     _raise_on_info(int(v))
-                host = torch.stack(es).to("cpu")  # one copy; differentiable
-                for k in range(self.num_hyper_samples):
-                    loss = loss + (-host[k] + kl) / self.num_hyper_samples
+                loss = 0.0
+                for k in range(S):
+                    loss = loss + (-host[k] + kl) / S
                 batch_losses.append(loss.item())
                 loss.backward()
                 optimizer.step()
@@ -512,12 +578,16 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         out = []
         with torch.no_grad():
             for lt in self.sample_variational_log_hyper(num_samples):
-                th = torch.exp(lt)
+                th = self._theta_of(lt)
                 if test_x.dim() == 1:
                     test_x = test_x[:, None]
                 mean, var, info = self._engine_obj().svgp_predict(self._dev(test_x), self._dev(self.inducing_inputs), th[1:-1].tolist(),
                                                                   float(th[0]), self._dev(self.variational_mean),
                                                                   self._dev(self.chol_variational_covar), jitter=self.jitter)
-                if int(info.to("cpu").item()) == 0:
-                    out.append(MultivariateNormal(mean, None, variance=var + float(th[-1]) ** 2))
+                if int(info.to("cpu").item()) != 0:
+                    continue
+                if self.bernoulli:  # class-1 probabilities through the probit link
+                    out.append(self.likelihood(MultivariateNormal(mean, None, variance=var)))
+                else:
+                    out.append(MultivariateNormal(mean, None, variance=var + float(th[-1])))
         return out

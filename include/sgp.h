@@ -364,6 +364,19 @@ int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, int64_t B,
                   int with_grads, double* out,
                   double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
                   int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* The same bound at S hyper-parameter samples in ONE chain of launches (S <= 8): the 5 reparametrised theta samples per
+ * minibatch of BayesianStochasticVariationalGP (models/bayesian_svgp.py:156-167) share the minibatch, Z, m, L_S and the KL
+ * term; every launch carries the sample index, so the chain is ~36 launches whatever S is.
+ *   inv_ls (S x d), sf2 (S), s2 (S): HOST arrays, sample-major (s2 ignored for SGP_LIK_BERNOULLI_PROBIT)
+ *   out (S x 3, layout of sgp_svgp_elbo's out per sample), info (S ints), and with_grads: g_m (S x M), g_LS (S x M x M),
+ *   g_Z (S x M x d), g_ls (S x d), g_sf2 (S), g_s2 (S) -- DEVICE arrays, the gradient of out[s][0] in slice s.            */
+size_t sgp_svgp_batch_workspace_bytes(int64_t B, int M, int d, int S);
+int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                        int S, const double* inv_ls, const double* sf2, const double* s2, double jitter,
+                        const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
+                        int with_grads, double* out,
+                        double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
+                        int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 /* latent predictive mean / variance of q(f*) at T rows (models/svgp.py:132-141 continues through the likelihood) */
 int sgp_svgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, const double* inv_ls,
                      double sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,

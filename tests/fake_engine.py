@@ -204,6 +204,19 @@ class OracleEngine:
         out = torch.tensor([float(ell.mean() - kl / N_total), float(ell.sum()), float(kl)], dtype=torch.float64)
         return {"out": out, "info": info}
 
+    def svgp_elbo_batch(self, Xb, yb, Z, ls, sf2, s2, m, LS, N_total, jitter=1e-6, kernel="rbf", likelihood="gaussian",
+                        with_grads=False):
+        """S hyper-parameter samples: the oracle, sample by sample (layout of HipEngine.svgp_elbo_batch)."""
+        rs = [self.svgp_elbo(Xb, yb, Z, list(ls[k]), float(sf2[k]), float(s2[k]) if likelihood == "gaussian" else 1.0, m, LS, N_total,
+                             jitter, kernel, likelihood, with_grads) for k in range(len(ls))]
+        res = {"out": torch.stack([r["out"] for r in rs]), "info": torch.cat([r["info"] for r in rs])}
+        if with_grads:
+            for key in ("g_m", "g_LS", "g_Z", "g_ls"):
+                res[key] = torch.stack([r[key] for r in rs])
+            for key in ("g_sf2", "g_s2"):
+                res[key] = torch.cat([r[key] for r in rs])
+        return res
+
     def svgp_predict(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
         from oracle import svgp_oracle as S
         mu, v = S.svgp_predict(Xs, Z, self._ls(ls, Z.shape[1]), float(sf2), m, LS, jitter, KID[kernel])

@@ -197,3 +197,154 @@ def test_bayesian_svgp_hyper_distribution_and_training():
     assert model.variational_mean.grad is not None and model.inducing_inputs.grad is not None
     preds = model.mixture_posterior_predictive(X[:9], num_samples=6)
     assert len(preds) == 6 and preds[0].loc.shape == (9,) and torch.all(preds[0].variance > 0)
+
+
+# ------------------------------------------------------------------------------------------------- batched hyper-samples (C4)
+def bayes_reference_trace(X, y, Z0, batches, lr, lik, N, seed, S_hyper=5):
+    """Independent statement of the Bayesian SVGP step (reference models/bayesian_svgp.py:144-181): q(log theta) =
+    N(q_mu, L L^T + 1e-5 I), S reparametrised draws per minibatch, loss = mean_k(-ELBO(exp(log theta_k)) + KL_theta / n), torch autograd
+    on the oracle graph, Adam.  Bernoulli (lik = 1): labels -> +-1, no noise hyper-parameter, q has d + 1 dimensions."""
+    d, M = X.shape[1], Z0.shape[0]
+    hd = d + (1 if lik == 1 else 2)
+    g = torch.Generator().manual_seed(seed)
+    q_mu = (torch.randn(hd, dtype=DT, generator=g) * 1e-3).requires_grad_(True)
+    q_vec = (torch.randn(hd * (hd + 1) // 2, dtype=DT, generator=g) * 1e-3).requires_grad_(True)
+    Z = Z0.clone().requires_grad_(True)
+    m = torch.zeros(M, dtype=DT, requires_grad=True)
+    LS = torch.eye(M, dtype=DT, requires_grad=True)
+    # the model registers: likelihood / kernel raw parameters (unused by the Bayesian loss), Z, m, LS, then q -- Adam treats every
+    # parameter independently, so only the ones the loss reaches matter
+    opt = torch.optim.Adam([Z, m, LS, q_mu, q_vec], lr=lr)
+    rows, cols = torch.tril_indices(hd, hd)
+    out = []
+    for xb, yb in batches:
+        opt.zero_grad()
+        lower = torch.zeros(hd, hd, dtype=DT).index_put((rows, cols), q_vec)
+        Sg = lower @ lower.T + 1e-5 * torch.eye(hd, dtype=DT)
+        kl = 0.5 * (torch.trace(Sg) / 0.01 + (q_mu @ q_mu) / 0.01 - hd + hd * math.log(0.01) - torch.logdet(Sg)) / N
+        Lq = torch.linalg.cholesky(Sg)
+        yy = torch.where(yb > 0, torch.ones_like(yb), -torch.ones_like(yb)) if lik == 1 else yb
+        loss = 0.0
+        for _ in range(S_hyper):
+            eps = torch.randn(1, hd, dtype=DT, generator=g)
+            th = torch.exp((q_mu[None, :] + eps @ Lq.T).flatten())
+            s2 = torch.tensor(1.0, dtype=DT) if lik == 1 else th[-1] ** 2
+            ls = th[1:] if lik == 1 else th[1:-1]
+            loss = loss + (-S.svgp_elbo(xb, yy, Z, ls, th[0], s2, m, LS, N, 1e-6, 0, lik) + kl) / S_hyper
+        out.append(float(loss.detach()))
+        loss.backward()
+        opt.step()
+    return out
+
+
+@pytest.mark.parametrize("classify", [False, True])
+def test_bayesian_svgp_trace_matches_autograd_reference_and_batched_equals_chains(classify):
+    """Model-level C4 wiring on the CPU double: Bernoulli-probit gets +-1 labels and a (d + 1)-dimensional q(log theta) -- no noise
+    hyper-parameter --, the five bounds of a minibatch come from ONE svgp_elbo_batch call, and the loss trace equals an
+    independent autograd loop; the per-sample launch chains (batched = False) give the same trace."""
+    X, y, Z0, _, _, _ = problem(N=240, M=10, classify=classify)
+    if classify:
+        y = (y > 0).to(DT)  # {0, 1} labels, as a data set would hold them
+    lik = ggp_amd.BernoulliLikelihood() if classify else ggp_amd.GaussianLikelihood()
+    batches = [(X[i:i + 80], y[i:i + 80]) for i in (0, 80, 160)]
+    ref = bayes_reference_trace(X, y, Z0, batches, 0.02, 1 if classify else 0, 240, seed=5)
+    traces = []
+    for batched in (True, False):
+        eng = OracleEngine()
+        calls = {"batch": 0, "single": 0}
+        inner_b, inner_s = eng.svgp_elbo_batch, eng.svgp_elbo
+        eng.svgp_elbo_batch = lambda *a, **k: (calls.__setitem__("batch", calls["batch"] + 1), inner_b(*a, **k))[1]
+        model = ggp_amd.BayesianStochasticVariationalGP(X, y, lik, Z0, engine=eng, seed=5)
+        model.batched = batched
+        assert model.hyper_dim == (3 if classify else 4) and model.log_theta.hyper_dim == model.hyper_dim
+        _, bl = model.train_model(torch.optim.Adam(model.parameters(), lr=0.02), batches, num_epochs=1)
+        traces.append(bl)
+        assert calls["batch"] == (3 if batched else 0)
+        assert model.log_theta.q_mu.grad is not None and float(model.log_theta.q_mu.grad.abs().max()) > 0
+    assert np.max(np.abs(np.array(traces[0]) - np.array(ref))) < 1e-9, (traces[0], ref)
+    assert np.max(np.abs(np.array(traces[0]) - np.array(traces[1]))) < 1e-12
+    preds = model.mixture_posterior_predictive(X[:9], num_samples=4)
+    assert len(preds) == 4
+    if classify:
+        assert preds[0].shape == (9,) and bool(torch.all((preds[0] > 0) & (preds[0] < 1)))
+    else:
+        assert preds[0].loc.shape == (9,) and bool(torch.all(preds[0].variance > 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lik,kern,B,M,d,S_hyper", [("bernoulli", "rbf", 4096, 256, 2, 5), ("gaussian", "rbf", 1000, 70, 3, 3),
+                                                    ("gaussian", "matern32", 333, 40, 2, 8), ("bernoulli", "rbf", 65, 5, 1, 1)])
+def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d, S_hyper):
+    """sgp_svgp_elbo_batch (S hyper-parameter samples, one launch chain) against oracle/svgp_oracle.py sample by sample -- bound 1e-9,
+    gradients 1e-6 -- and against S calls of sgp_svgp_elbo.  First case = BASELINE C4's minibatch: B 4096, M 256, Bernoulli, 5 samples."""
+    X, y, Z, m, LS, ls0 = problem(B, d, M, seed=B + M, classify=(lik == "bernoulli"))
+    kid = {"rbf": 0, "matern32": 1}[kern]
+    likid = 1 if lik == "bernoulli" else 0
+    N_total = 100_000
+    g = torch.Generator().manual_seed(7)
+    ls = ls0[None, :] * torch.exp(0.2 * torch.randn(S_hyper, d, dtype=DT, generator=g))
+    sf2 = 1.3 * torch.exp(0.2 * torch.randn(S_hyper, dtype=DT, generator=g))
+    s2 = 0.1 * torch.exp(0.3 * torch.randn(S_hyper, dtype=DT, generator=g))
+    D = lambda t: t.to(engine.device).contiguous()  # noqa: E731
+    res = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
+                                 likelihood=lik, with_grads=True)
+    assert res["info"].cpu().tolist() == [0] * S_hyper
+    val = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
+                                 likelihood=lik)
+    assert torch.equal(val["out"], res["out"])
+
+    def close(a, b, rt):
+        a, b = a.cpu().reshape(-1), torch.as_tensor(b).reshape(-1)
+        return float((a - b).abs().max()) < rt * max(1e-3, float(b.abs().max()))
+    for k in range(S_hyper):
+        one = engine.svgp_elbo(D(X), D(y), D(Z), ls[k].tolist(), float(sf2[k]), float(s2[k]), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
+                               likelihood=lik, with_grads=True)
+        assert abs(float(res["out"][k, 0]) - float(one["out"][0])) < 1e-11 * max(1.0, abs(float(one["out"][0])))
+        for key in ("g_m", "g_LS", "g_Z", "g_ls"):
+            assert close(res[key][k], one[key].cpu(), 1e-8), (k, key)
+        assert close(res["g_sf2"][k], one["g_sf2"].cpu(), 1e-8)
+        if kid != 0:
+            continue
+        ref = S.svgp_elbo_and_grads(X, y, Z, ls[k], float(sf2[k]), float(s2[k]), m, LS, N_total, 1e-6, kid, likid)
+        assert abs(float(res["out"][k, 0]) - ref["elbo"]) < 1e-9 * max(1.0, abs(ref["elbo"])), (k, float(res["out"][k, 0]), ref["elbo"])
+        assert close(res["g_m"][k], ref["g_m"], 1e-6) and close(res["g_LS"][k], ref["g_LS"], 1e-6)
+        assert close(res["g_Z"][k], ref["g_Z"], 1e-6) and close(res["g_ls"][k], ref["g_ls"], 1e-6)
+        assert close(res["g_sf2"][k], torch.tensor([ref["g_sf2"]]), 1e-6)
+        if lik == "gaussian":
+            assert close(res["g_s2"][k], torch.tensor([ref["g_s2"]]), 1e-6)
+    # a non-PD sample reports its own status word and leaves the others alone
+    if S_hyper >= 3:
+        Zd = Z.clone()
+        Zd[1] = Zd[0]
+        bad = engine.svgp_elbo_batch(D(X), D(y), D(Zd), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=0.0, kernel=kern,
+                                     likelihood=lik)
+        assert all(v > 0 for v in bad["info"].cpu().tolist())
+
+
+@pytest.mark.gpu
+def test_bayesian_svgp_bernoulli_c4_as_named(engine):
+    """BASELINE config C4 AS NAMED: BayesianStochasticVariationalGP x Bernoulli-probit, synthetic 2-D classification, N = 100 000,
+    M = 256, SVI minibatch 4096, five hyper-samples per minibatch (reference models/bayesian_svgp.py:144-181; Bernoulli use
+    scratch_pymc3.py:78-88).  First minibatches against the same model on the oracle-backed CPU double with the same seeds, then
+    two epochs over all 100k rows that must reduce the loss and classify."""
+    g = torch.Generator().manual_seed(4)
+    N, M, Bsz = 100_000, 256, 4096
+    X = torch.randn(N, 2, dtype=DT, generator=g)
+    y = (torch.sin(2 * X[:, 0]) * torch.cos(X[:, 1]) + 0.1 * torch.randn(N, dtype=DT, generator=g) > 0).to(DT)  # {0, 1}
+    Z0 = X[torch.randperm(N, generator=g)[:M]].clone()
+    traces = []
+    for eng in (engine, OracleEngine()):
+        model = ggp_amd.BayesianStochasticVariationalGP(X.to(eng.device), y.to(eng.device), ggp_amd.BernoulliLikelihood(), Z0, engine=eng, seed=3)
+        assert model.hyper_dim == 3
+        batches = [(X[i:i + Bsz].to(eng.device), y[i:i + Bsz].to(eng.device)) for i in (0, Bsz)]
+        _, bl = model.train_model(torch.optim.Adam(model.parameters(), lr=0.02), batches, num_epochs=1)
+        traces.append(bl)
+    assert np.max(np.abs(np.array(traces[0]) - np.array(traces[1]))) < 1e-8 * max(1.0, np.max(np.abs(traces[1]))), traces
+    Xd, yd = X.to(engine.device), y.to(engine.device)
+    model = ggp_amd.BayesianStochasticVariationalGP(Xd, yd, ggp_amd.BernoulliLikelihood(), Z0, engine=engine, seed=3)
+    batches = [(Xd[i:i + Bsz], yd[i:i + Bsz]) for i in range(0, N - Bsz + 1, Bsz)]
+    ep, bl = model.train_model(torch.optim.Adam(model.parameters(), lr=0.05), batches, num_epochs=2)
+    assert len(ep) == 2 and len(bl) == 24 and ep[1] < ep[0] and all(math.isfinite(v) for v in ep)
+    probs = torch.stack(model.mixture_posterior_predictive(Xd[:4000], num_samples=5)).mean(0).cpu()
+    acc = float(((probs > 0.5) == (y[:4000] > 0)).double().mean())
+    assert acc > 0.85, acc

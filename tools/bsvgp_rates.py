@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Minibatch steps per second of BayesianStochasticVariationalGP at the C4 shape (N = 100k, d = 2, M = 256, B = 4096, five
-hyper-samples per minibatch = five bound + gradient chains, one backward, one Adam step), with torch's default host thread
-pool and with the cap the training loops apply (core.few_host_threads)."""
+hyper-samples per minibatch, one backward, one Adam step): the five bounds in ONE launch chain (sgp_svgp_elbo_batch, the
+default) against five sgp_svgp_elbo chains, Gaussian and Bernoulli-probit (BASELINE C4 as named), with the host-thread cap the
+training loops apply (core.few_host_threads) and, for the record, with torch's default pool."""
 import json
 import os
 import sys
@@ -23,19 +24,41 @@ def main():
     Xd, yd = X.to(eng.device), y.to(eng.device)
     batches = [(Xd[i:i + B], yd[i:i + B]) for i in range(0, 16 * B, B)]
     default_threads = torch.get_num_threads()
-    for label, capped in (("capped (4)", True), ("torch default (%d)" % default_threads, False)):
+    yc = (y > 0).to(torch.float64).to(eng.device)
+    cases = [("bernoulli", True, True), ("bernoulli", False, True), ("gaussian", True, True), ("gaussian", False, True),
+             ("gaussian", True, False)]
+    for lik, batched, capped in cases:
         torch.manual_seed(0)
-        model = ggp_amd.BayesianStochasticVariationalGP(Xd, yd, ggp_amd.GaussianLikelihood(), Z0, engine=eng, seed=3)
+        like = ggp_amd.BernoulliLikelihood() if lik == "bernoulli" else ggp_amd.GaussianLikelihood()
+        yy = yc if lik == "bernoulli" else yd
+        model = ggp_amd.BayesianStochasticVariationalGP(Xd, yy, like, Z0, engine=eng, seed=3)
+        model.batched = batched
+        bt = [(Xd[i:i + B], yy[i:i + B]) for i in range(0, 16 * B, B)]
         opt = torch.optim.Adam(model.parameters(), lr=0.01)
         train = model.train_model if capped else (lambda *a, **k: type(model).train_model.__wrapped__(model, *a, **k))
-        train(opt, batches[:4], num_epochs=1)
+        train(opt, bt[:4], num_epochs=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        _, bl = train(opt, batches, num_epochs=2)
+        _, bl = train(opt, bt, num_epochs=2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(json.dumps({"config": "C4 BayesianSVGP minibatch step", "host_threads": label, "steps_per_s": 2 * len(batches) / dt,
-                          "ms_per_step": dt / (2 * len(batches)) * 1e3, "last_batch_loss": bl[-1]}), flush=True)
+        print(json.dumps({"config": "C4 BayesianSVGP minibatch step (N 100k, M 256, B 4096, 5 hyper-samples)", "likelihood": lik,
+                          "hyper_samples": "one launch chain (sgp_svgp_elbo_batch)" if batched else "five sgp_svgp_elbo chains",
+                          "host_threads": "capped (4)" if capped else "torch default (%d)" % default_threads,
+                          "steps_per_s": 2 * len(bt) / dt, "ms_per_step": dt / (2 * len(bt)) * 1e3, "last_batch_loss": bl[-1]}), flush=True)
+    # device time of the chain alone: 50 back-to-back bound + gradient calls for 5 samples, no host work in between
+    model = ggp_amd.BayesianStochasticVariationalGP(Xd, yc, ggp_amd.BernoulliLikelihood(), Z0, engine=eng, seed=3)
+    xb, yb = Xd[:B].contiguous(), torch.where(yc[:B] > 0, 1.0, -1.0).to(torch.float64)
+    th = [[1.0, 1.0]] * 5
+    args = (xb, yb, model.inducing_inputs.detach(), th, [1.0] * 5, [1.0] * 5, model.variational_mean.detach(), model.chol_variational_covar.detach(), N)
+    for _ in range(3):
+        eng.svgp_elbo_batch(*args, likelihood="bernoulli", with_grads=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.svgp_elbo_batch(*args, likelihood="bernoulli", with_grads=True)
+    torch.cuda.synchronize()
+    print(json.dumps({"config": "sgp_svgp_elbo_batch alone, S = 5, bound + gradients, back to back", "ms_per_call": (time.perf_counter() - t0) / 50 * 1e3}), flush=True)
 
 
 if __name__ == "__main__":
