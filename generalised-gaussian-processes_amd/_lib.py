@@ -99,6 +99,7 @@ PROTOTYPES = {
     "sgp_svgp_batch_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_svgp_elbo_batch": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                    _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_svgp_batch_combine": (_i32, [_i32, _dp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgp_svgp_predict": (_i32, [_vp, _i64, _i64, _vp, _i64, _dp, _dbl, _dbl, _vp, _vp, _i32, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_gauss_hermite": (_i32, [_i32, _dp, _dp]),

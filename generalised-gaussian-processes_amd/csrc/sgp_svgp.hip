@@ -542,9 +542,9 @@ __global__ __launch_bounds__(256) void svgp_ell_batch_kernel(const double* __res
   }
 }
 
-// out[s] = [ELBO per datum | sum_b E log p | KL], g_s2[s]; one thread per sample, fixed summation order
+// out[s] = [ELBO per datum | sum_b E log p | KL | status word as a double], g_s2[s]; one thread per sample, fixed summation order
 __global__ void svgp_finalize_batch_kernel(const double* __restrict__ part, const double* __restrict__ kl, int M, int B, double N_total,
-                                           int S, double* __restrict__ out, double* __restrict__ g_s2) {
+                                           int S, const int* __restrict__ info, double* __restrict__ out, double* __restrict__ g_s2) {
   const int s = threadIdx.x;
   if (blockIdx.x != 0 || s >= S) return;
   double se = 0.0, ss = 0.0;
@@ -555,9 +555,10 @@ __global__ void svgp_finalize_batch_kernel(const double* __restrict__ part, cons
   double klsum = 0.0;
   for (int i = 0; i < 64; ++i) klsum += kl[i];
   const double klv = 0.5 * (klsum - (double)M);
-  out[3 * s] = se / (double)B - klv / N_total;
-  out[3 * s + 1] = se;
-  out[3 * s + 2] = klv;
+  out[4 * s] = se / (double)B - klv / N_total;
+  out[4 * s + 1] = se;
+  out[4 * s + 2] = klv;
+  out[4 * s + 3] = (double)info[s];  // the factorization's status rides along: ONE device-to-host copy brings bounds and statuses
   if (g_s2) g_s2[s] = ss / (double)B;
 }
 
@@ -700,6 +701,39 @@ __global__ __launch_bounds__(256) void svgp_kbwd_reduce_batch_kernel(const doubl
   double* gz = g_Z + (int64_t)blockIdx.y * total;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
     gz[e] = ka.inv_ls[(int)(e % d)] * (2.0 * zub[e] + 4.0 * zuu[e]);
+}
+
+// The reverse pass of a loss sum_s w_s ELBO_s in ONE launch: weighted sums over the S gradient slices (fixed order) for the
+// parameters the samples share, and the per-sample hyper-parameter gradients scaled and packed for a single copy to the host:
+//   gm = sum_s w_s g_m[s], gLS, gZ likewise ; gtheta[s] = w_s [g_sf2[s] | g_ls[s][0..d) | g_s2[s]]
+struct SvgpWeights {
+  double w[SVGP_MAX_S];
+};
+__global__ __launch_bounds__(256) void svgp_combine_kernel(SvgpWeights wt, int S, int M, int d, const double* __restrict__ g_m,
+                                                           const double* __restrict__ g_LS, const double* __restrict__ g_Z,
+                                                           const double* __restrict__ g_ls, const double* __restrict__ g_sf2,
+                                                           const double* __restrict__ g_s2, double* __restrict__ gm, double* __restrict__ gLS,
+                                                           double* __restrict__ gZ, double* __restrict__ gtheta) {
+  const int64_t nm = M, nl = (int64_t)M * M, nz = (int64_t)M * d, nt = (int64_t)S * (d + 2);
+  const int64_t total = nm + nl + nz + nt;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    if (e >= nm + nl + nz) {
+      const int64_t t = e - (nm + nl + nz);
+      const int sidx = (int)(t / (d + 2)), c = (int)(t - (int64_t)sidx * (d + 2));
+      const double v = c == 0 ? g_sf2[sidx] : (c == d + 1 ? g_s2[sidx] : g_ls[(int64_t)sidx * d + c - 1]);
+      gtheta[t] = wt.w[sidx] * v;
+      continue;
+    }
+    const double* src;
+    double* dst;
+    int64_t n, i;
+    if (e < nm) { src = g_m; dst = gm; n = nm; i = e; }
+    else if (e < nm + nl) { src = g_LS; dst = gLS; n = nl; i = e - nm; }
+    else { src = g_Z; dst = gZ; n = nz; i = e - nm - nl; }
+    double acc = 0.0;
+    for (int k = 0; k < S; ++k) acc = fma(wt.w[k], src[(int64_t)k * n + i], acc);
+    dst[i] = acc;
+  }
 }
 
 struct SvgpBatchWs {
@@ -888,7 +922,7 @@ extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* 
   gemm_s(t, 0, mb, mb);
   svgp_cols_batch_kernel<<<dim3(Bp / 64, S), 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, th, w.mu, w.v);
   svgp_ell_batch_kernel<<<dim3(64, S), 256, 0, st>>>(yb, w.mu, w.v, (int)B, Bp, th, likelihood_id, gh, w.dmu, w.dv, w.part);
-  svgp_finalize_batch_kernel<<<1, 64, 0, st>>>(w.part, w.kl, M, (int)B, (double)N_total, S, out, with_grads ? g_s2 : nullptr);
+  svgp_finalize_batch_kernel<<<1, 64, 0, st>>>(w.part, w.kl, M, (int)B, (double)N_total, S, info, out, with_grads ? g_s2 : nullptr);
   if (!with_grads) return check_launch();
 
   // ---- reverse (the closed-form adjoint of sgp_svgp_elbo, sample by sample in blockIdx.y) ------------------------
@@ -933,6 +967,20 @@ extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* 
     default: svgp_kbwd_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(2 * M, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, w.U, w.P, M, Mp, Bp, (int)B, w.kpart, w.gzraw); break;
   }
   svgp_kbwd_reduce_batch_kernel<<<dim3(grid_for_s((int64_t)M * d, 256), S), 256, 0, st>>>(w.kpart, w.gzraw, M, th, w.dv, (int)B, Bp, invB, g_ls, g_sf2, g_Z);
+  return check_launch();
+}
+
+extern "C" int sgp_svgp_batch_combine(int S, const double* weights, int M, int d, const double* g_m, const double* g_LS,
+                                      const double* g_Z, const double* g_ls, const double* g_sf2, const double* g_s2, double* gm_out,
+                                      double* gLS_out, double* gZ_out, double* gtheta_out, sgp_stream_t stream) {
+  if (S < 1 || S > SVGP_MAX_S || !weights || M <= 0 || d <= 0 || !g_m || !g_LS || !g_Z || !g_ls || !g_sf2 || !g_s2 || !gm_out ||
+      !gLS_out || !gZ_out || !gtheta_out)
+    return SGP_ERR_ARG;
+  SvgpWeights wt{};
+  for (int k = 0; k < S; ++k) wt.w[k] = weights[k];
+  const int64_t total = (int64_t)M + (int64_t)M * M + (int64_t)M * d + (int64_t)S * (d + 2);
+  svgp_combine_kernel<<<grid_for_s(total), 256, 0, (hipStream_t)stream>>>(wt, S, M, d, g_m, g_LS, g_Z, g_ls, g_sf2, g_s2, gm_out, gLS_out,
+                                                                          gZ_out, gtheta_out);
   return check_launch();
 }
 

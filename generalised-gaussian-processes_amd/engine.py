@@ -519,7 +519,7 @@ class HipEngine:
     def svgp_elbo_batch(self, Xb, yb, Z, ls, sf2, s2, m, LS, N_total, jitter=1e-6, kernel="rbf", likelihood="gaussian",
                         with_grads=False):
         """The bound of one minibatch at S hyper-parameter samples in ONE chain of launches (sgp_svgp_elbo_batch).
-        ls: S x d, sf2, s2: S (host sequences / arrays).  Returns dict(out [S, 3], info [S], and with ``with_grads``
+        ls: S x d, sf2, s2: S (host sequences / arrays).  Returns dict(out [S, 4] = [bound per datum | sum E log p | KL | status], info [S], and with ``with_grads``
         g_m [S, M], g_LS [S, M, M], g_Z [S, M, d], g_ls [S, d], g_sf2 [S], g_s2 [S]); device tensors, nothing synchronised."""
         import ctypes
         B, d = Xb.shape
@@ -534,7 +534,7 @@ class HipEngine:
         inv = (ctypes.c_double * (S * d))(*[1.0 / v for row in lsv for v in row])
         sf2c = (ctypes.c_double * S)(*[float(v) for v in sf2])
         s2c = (ctypes.c_double * S)(*[float(v) for v in s2])
-        out = self.empty(S, 3)
+        out = self.empty(S, 4)
         info = torch.empty(S, dtype=torch.int32, device=self.device)
         res = {"out": out, "info": info}
         g = {}
@@ -553,6 +553,19 @@ class HipEngine:
             self._ptr(g.get("g_sf2")), self._ptr(g.get("g_s2")), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_svgp_elbo_batch", st)
         return res
+
+    def svgp_batch_combine(self, res, weights):
+        """Reverse pass of sum_s weights[s] * bound_s from a ``svgp_elbo_batch(..., with_grads=True)`` result, one launch.
+        Returns (g_m [M], g_LS [M, M], g_Z [M, d], g_theta [S, d + 2] = w_s [d/dsf2 | d/dls | d/ds2]) on the device."""
+        import ctypes
+        S, M, d = res["g_Z"].shape
+        w = (ctypes.c_double * S)(*[float(v) for v in weights])
+        gm, gLS, gZ, gth = self.empty(M), self.empty(M, M), self.empty(M, d), self.empty(S, d + 2)
+        st = self.lib.sgp_svgp_batch_combine(S, w, M, d, self._ptr(res["g_m"]), self._ptr(res["g_LS"]), self._ptr(res["g_Z"]),
+                                             self._ptr(res["g_ls"]), self._ptr(res["g_sf2"]), self._ptr(res["g_s2"]), self._ptr(gm),
+                                             self._ptr(gLS), self._ptr(gZ), self._ptr(gth), self._stream())
+        _lib.check("sgp_svgp_batch_combine", st)
+        return gm, gLS, gZ, gth
 
     def svgp_predict(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
         T, d = Xs.shape

@@ -325,7 +325,9 @@ class _SVGPBoundFn(torch.autograd.Function):
 class _SVGPBatchBoundFn(torch.autograd.Function):
     """ELBO per datum of one minibatch at S hyper-parameter samples: ONE sgp_svgp_elbo_batch call evaluates all S bounds and
     their whole reverse pass (~36 launches whatever S is).  theta: S x (d + 2) host tensor [sf2 | ls_1..d | s2] (s2 column
-    ignored by the Bernoulli likelihood); returns the S bounds as a device tensor."""
+    ignored by the Bernoulli likelihood).  Returns the S bounds as a HOST tensor -- the one device-to-host copy of the forward
+    pass brings them together with the S status words (``model._last_infos``) -- so the incoming gradient is a host tensor too,
+    and backward is one launch (sgp_svgp_batch_combine) plus one copy of the S x (d + 2) hyper-parameter gradients."""
 
     @staticmethod
     def forward(ctx, theta, Z, m, LS, model, xb, yb):
@@ -336,27 +338,28 @@ class _SVGPBatchBoundFn(torch.autograd.Function):
         res = eng.svgp_elbo_batch(xb, yb, Z.detach().contiguous(), th[:, 1:1 + d].tolist(), th[:, 0].tolist(), th[:, 1 + d].tolist(),
                                   m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
                                   kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
-        model._last_infos = res["info"]  # read by the caller together with the loss: one host round trip per minibatch
+        host = res["out"].to("cpu")
+        model._last_infos = host[:, 3].to(torch.int32)
         ctx.res = res if need else None
+        ctx.eng = eng
         ctx.theta_meta = (theta.shape, theta.device, theta.dtype)
-        return res["out"][:, 0].clone()
+        return host[:, 0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         r = ctx.res
         n = ctx.needs_input_grad
-        g = gout.to(r["out"].device, torch.float64)
-        g_theta = g_Z = g_m = g_LS = None
+        if hasattr(ctx.eng, "svgp_batch_combine"):
+            gm, gLS, gZ, gth = ctx.eng.svgp_batch_combine(r, gout.detach().reshape(-1).tolist())
+        else:  # test double: the same sums in torch
+            g = gout.to(r["g_Z"].device, torch.float64)
+            gZ, gm, gLS = torch.einsum("s,smd->md", g, r["g_Z"]), torch.einsum("s,sm->m", g, r["g_m"]), torch.einsum("s,smk->mk", g, r["g_LS"])
+            gth = torch.cat([r["g_sf2"][:, None], r["g_ls"], r["g_s2"][:, None]], 1) * g[:, None]
+        g_theta = None
         if n[0]:
             shape, dev, dt = ctx.theta_meta
-            g_theta = (torch.cat([r["g_sf2"][:, None], r["g_ls"], r["g_s2"][:, None]], 1) * g[:, None]).to(dev, dt).reshape(shape)
-        if n[1]:
-            g_Z = torch.einsum("s,smd->md", g, r["g_Z"])
-        if n[2]:
-            g_m = torch.einsum("s,sm->m", g, r["g_m"])
-        if n[3]:
-            g_LS = torch.einsum("s,smk->mk", g, r["g_LS"])
-        return g_theta, g_Z, g_m, g_LS, None, None, None
+            g_theta = gth.to(dev, dt).reshape(shape)
+        return g_theta, gZ if n[1] else None, gm if n[2] else None, gLS if n[3] else None, None, None, None
 
 
 class StochasticVariationalGP(torch.nn.Module):
@@ -473,10 +476,17 @@ class VariationalHyperDist(torch.nn.Module):
                     + k * math.log(self.prior_var) - torch.logdet(S))
         return kl / self.n
 
-    def forward(self, num_samples):
-        S = self.construct_sigma()
-        L = torch.linalg.cholesky(S)
+    def forward(self, num_samples, chol=None):
+        L = torch.linalg.cholesky(self.construct_sigma()) if chol is None else chol
         eps = torch.randn(num_samples, self.hyper_dim, dtype=torch.float64, generator=self._gen)
+        return self.q_mu[None, :] + eps @ L.T
+
+    def draws(self, count):
+        """``count`` reparametrised samples drawn ONE AT A TIME from the random stream, as the reference's training loop does
+        (models/bayesian_svgp.py:159-160), with Sigma and its Cholesky factor formed once instead of once per draw (the
+        parameters do not change inside a minibatch step; ~40 host operations fewer).  Returns count x hyper_dim."""
+        L = torch.linalg.cholesky(self.construct_sigma())
+        eps = torch.cat([torch.randn(1, self.hyper_dim, dtype=torch.float64, generator=self._gen) for _ in range(count)])
         return self.q_mu[None, :] + eps @ L.T
 
 
@@ -526,7 +536,7 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
                                   self.chol_variational_covar, self, self._dev(x_batch), self._labels(y_batch))
 
     def elbo_hyper_samples(self, x_batch, y_batch, log_thetas):
-        """The S bounds (device tensor, differentiable wrt q(u), Z and log_thetas) of one minibatch at the rows of log_thetas."""
+        """The S bounds (host tensor, differentiable wrt q(u), Z and log_thetas) of one minibatch at the rows of log_thetas."""
         if x_batch.dim() == 1:
             x_batch = x_batch[:, None]
         return _SVGPBatchBoundFn.apply(self._theta_of(log_thetas), self.inducing_inputs, self.variational_mean,
@@ -546,11 +556,10 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
                 kl = self.log_theta.kl_per_point()
                 xb = self._dev(x_batch[:, None] if x_batch.dim() == 1 else x_batch)  # one host-to-device copy per minibatch
                 # one reparametrised draw at a time, as the reference consumes its random stream (:159-160)
-                lts = torch.stack([self.sample_variational_log_hyper(1).flatten() for _ in range(S)])
+                lts = self.log_theta.draws(S)
                 if self.batched and hasattr(self._engine_obj(), "svgp_elbo_batch"):
-                    es = self.elbo_hyper_samples(xb, y_batch, lts)
-                    infos = self._last_infos.to("cpu")
-                    host = es.to("cpu")  # differentiable copy
+                    host = self.elbo_hyper_samples(xb, y_batch, lts)  # host tensor: bounds and status words came in one copy
+                    infos = self._last_infos
                 else:
                     # one launch chain per sample, enqueued back to back; status words read together
                     self._pending_infos = []
@@ -562,9 +571,7 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
                     host = torch.stack(es).to("cpu")
                 for v in infos.tolist():
                     _raise_on_info(int(v))
-                loss = 0.0
-                for k in range(S):
-                    loss = loss + (-host[k] + kl) / S
+                loss = kl - host.sum() / S  # = sum_k (-elbo_k + kl) / S, the reference's accumulation (:161-166)
                 batch_losses.append(loss.item())
                 loss.backward()
                 optimizer.step()

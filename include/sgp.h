@@ -368,8 +368,12 @@ int sgp_svgp_elbo(const double* Xb, int64_t ldx, const double* yb, int64_t B,
  * minibatch of BayesianStochasticVariationalGP (models/bayesian_svgp.py:156-167) share the minibatch, Z, m, L_S and the KL
  * term; every launch carries the sample index, so the chain is ~36 launches whatever S is.
  *   inv_ls (S x d), sf2 (S), s2 (S): HOST arrays, sample-major (s2 ignored for SGP_LIK_BERNOULLI_PROBIT)
- *   out (S x 3, layout of sgp_svgp_elbo's out per sample), info (S ints), and with_grads: g_m (S x M), g_LS (S x M x M),
- *   g_Z (S x M x d), g_ls (S x d), g_sf2 (S), g_s2 (S) -- DEVICE arrays, the gradient of out[s][0] in slice s.            */
+ *   out (S x 4: sgp_svgp_elbo's three values per sample, then the sample's status word as a double, so that one copy brings
+ *   bounds and statuses to the host), info (S ints), and with_grads: g_m (S x M), g_LS (S x M x M), g_Z (S x M x d),
+ *   g_ls (S x d), g_sf2 (S), g_s2 (S) -- DEVICE arrays, the gradient of out[s][0] in slice s.
+ * sgp_svgp_batch_combine: the reverse pass of a loss sum_s w_s out[s][0] in one launch (weights: HOST, S doubles) -- the shared
+ *   parameters' gradients summed over the samples (gm_out [M], gLS_out [M x M], gZ_out [M x d]) and the per-sample
+ *   hyper-parameter gradients scaled and packed, gtheta_out [S x (d + 2)] = w_s [d/dsf2 | d/dls_1..d | d/ds2].            */
 size_t sgp_svgp_batch_workspace_bytes(int64_t B, int M, int d, int S);
 int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
                         int S, const double* inv_ls, const double* sf2, const double* s2, double jitter,
@@ -377,6 +381,9 @@ int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t
                         int with_grads, double* out,
                         double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
                         int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_svgp_batch_combine(int S, const double* weights, int M, int d, const double* g_m, const double* g_LS, const double* g_Z,
+                           const double* g_ls, const double* g_sf2, const double* g_s2, double* gm_out, double* gLS_out,
+                           double* gZ_out, double* gtheta_out, sgp_stream_t stream);
 /* latent predictive mean / variance of q(f*) at T rows (models/svgp.py:132-141 continues through the likelihood) */
 int sgp_svgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, const double* inv_ls,
                      double sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,

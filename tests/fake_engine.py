@@ -209,7 +209,8 @@ class OracleEngine:
         """S hyper-parameter samples: the oracle, sample by sample (layout of HipEngine.svgp_elbo_batch)."""
         rs = [self.svgp_elbo(Xb, yb, Z, list(ls[k]), float(sf2[k]), float(s2[k]) if likelihood == "gaussian" else 1.0, m, LS, N_total,
                              jitter, kernel, likelihood, with_grads) for k in range(len(ls))]
-        res = {"out": torch.stack([r["out"] for r in rs]), "info": torch.cat([r["info"] for r in rs])}
+        info = torch.cat([r["info"] for r in rs])
+        res = {"out": torch.cat([torch.stack([r["out"] for r in rs]), info.to(torch.float64)[:, None]], 1), "info": info}
         if with_grads:
             for key in ("g_m", "g_LS", "g_Z", "g_ls"):
                 res[key] = torch.stack([r[key] for r in rs])

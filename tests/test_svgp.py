@@ -312,13 +312,23 @@ def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d,
         assert close(res["g_sf2"][k], torch.tensor([ref["g_sf2"]]), 1e-6)
         if lik == "gaussian":
             assert close(res["g_s2"][k], torch.tensor([ref["g_s2"]]), 1e-6)
-    # a non-PD sample reports its own status word and leaves the others alone
+    assert res["out"][:, 3].cpu().tolist() == [0.0] * S_hyper  # the status words ride along in the result rows
+    # reverse pass of a weighted sum of the S bounds in one launch (sgp_svgp_batch_combine)
+    wts = torch.linspace(-0.7, 1.1, S_hyper, dtype=DT)
+    gm, gLS, gZ, gth = engine.svgp_batch_combine(res, wts.tolist())
+    wd = wts.to(engine.device)
+    assert close(gm, torch.einsum("s,sm->m", wd, res["g_m"]).cpu(), 1e-13) and close(gLS, torch.einsum("s,smk->mk", wd, res["g_LS"]).cpu(), 1e-13)
+    assert close(gZ, torch.einsum("s,smd->md", wd, res["g_Z"]).cpu(), 1e-13)
+    assert close(gth, (torch.cat([res["g_sf2"][:, None], res["g_ls"], res["g_s2"][:, None]], 1) * wd[:, None]).cpu(), 1e-14)
+    # every sample has its own status word: K_uu - I is indefinite for each of them (a smooth kernel on M >= 40 points has
+    # eigenvalues far below 1), and the next call on the same workspace is clean again
     if S_hyper >= 3:
-        Zd = Z.clone()
-        Zd[1] = Zd[0]
-        bad = engine.svgp_elbo_batch(D(X), D(y), D(Zd), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=0.0, kernel=kern,
+        bad = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=-1.0, kernel=kern,
                                      likelihood=lik)
-        assert all(v > 0 for v in bad["info"].cpu().tolist())
+        assert all(1 <= v <= M for v in bad["info"].cpu().tolist()), bad["info"].cpu().tolist()
+        again = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
+                                       likelihood=lik)
+        assert again["info"].cpu().tolist() == [0] * S_hyper and torch.equal(again["out"], val["out"])
 
 
 @pytest.mark.gpu

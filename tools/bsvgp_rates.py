@@ -61,5 +61,30 @@ def main():
     print(json.dumps({"config": "sgp_svgp_elbo_batch alone, S = 5, bound + gradients, back to back", "ms_per_call": (time.perf_counter() - t0) / 50 * 1e3}), flush=True)
 
 
+def profile_step():
+    """Where the host time of a step goes (cProfile over 32 steps of the batched Bernoulli model) -- stderr."""
+    import cProfile
+    import pstats
+    eng = ggp_amd.HipEngine()
+    g = torch.Generator().manual_seed(4)
+    N, M, B = 100_000, 256, 4096
+    X = torch.randn(N, 2, dtype=torch.float64, generator=g)
+    y = (torch.sin(2 * X[:, 0]) * torch.cos(X[:, 1]) > 0).to(torch.float64)
+    Z0 = X[torch.randperm(N, generator=g)[:M]].clone()
+    Xd, yd = X.to(eng.device), y.to(eng.device)
+    model = ggp_amd.BayesianStochasticVariationalGP(Xd, yd, ggp_amd.BernoulliLikelihood(), Z0, engine=eng, seed=3)
+    bt = [(Xd[i:i + B], yd[i:i + B]) for i in range(0, 16 * B, B)]
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    model.train_model(opt, bt[:4], num_epochs=1)
+    pr = cProfile.Profile()
+    pr.enable()
+    model.train_model(opt, bt, num_epochs=2)
+    pr.disable()
+    pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
+
+
 if __name__ == "__main__":
+    if "--profile" in sys.argv:
+        profile_step()
+        sys.exit(0)
     main()

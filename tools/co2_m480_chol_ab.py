@@ -104,7 +104,20 @@ def run_seed(seed, args, eng):
         rec.update(lapack_at(th, target, Xc, yc, Zc, args.jitter))
         points.append(rec)
     # control: the same LAPACK factorizations at thetas the HIP path evaluated fine (the post-tuning draws)
-    control = [lapack_at([float(v) for v in row["theta_unc"]], target, Xc, yc, Zc, args.jitter) for row in trace[:: max(1, len(trace) // 8)]]
+    control = []
+    for row in trace[:: max(1, len(trace) // 8)]:
+        th = [float(v) for v in row["theta_unc"]]
+        rec = lapack_at(th, target, Xc, yc, Zc, args.jitter)
+        # the same bound F (no priors) from the HIP path at the same theta, and at theta moved by 1e-7 in every coordinate: the
+        # second difference against the analytic gradient's prediction is the evaluation's own noise floor
+        vals = [math.exp(v) for v in th[:-1]]
+        F, g = inner(Z, target.kernel.with_values(vals).block(), 1.0, math.exp(th[-1]) ** 2, raise_on_fail=False)
+        vals2 = [math.exp(v + 1e-7) for v in th[:-1]]
+        F2, _ = inner(Z, target.kernel.with_values(vals2).block(), 1.0, math.exp(th[-1] + 1e-7) ** 2, raise_on_fail=False)
+        rec.update({"theta": th, "hip_F": F, "hip_F_at_theta_plus_1e-7": F2,
+                    "hip_minus_lapack_F": (F - rec["oracle_F"]) if "oracle_F" in rec else None})
+        control.append(rec)
+    stats = {k: np.asarray(trace.get_sampler_stats(k)) for k in ("step_size", "tree_size", "energy")}
     both = sum(1 for p in points if p["lapack_info_Kuu"] != 0 or p.get("lapack_info_B", 0) != 0)
     return {"seed": seed, "logp_after_map": lp_map, "evaluations": n_calls[0], "hip_failures": len(failed), "hip_failures_during_map": n_map_fail,
             "diverging_draws": int(trace.get_sampler_stats("diverging").sum()), "num_samples": len(trace),
@@ -117,6 +130,11 @@ def run_seed(seed, args, eng):
             "median_cond_at_failures": float(np.median([p["cond_Kuu_plus_jitter"] for p in points])) if points else None,
             "median_cond_at_accepted_draws": float(np.median([c["cond_Kuu_plus_jitter"] for c in control])),
             "lapack_failures_at_accepted_draws": sum(1 for c in control if c["lapack_info_Kuu"] != 0 or c.get("lapack_info_B", 0) != 0),
+            "median_abs_hip_minus_lapack_F_at_accepted_draws": float(np.median([abs(c["hip_minus_lapack_F"]) for c in control if c["hip_minus_lapack_F"] is not None]))
+            if any(c["hip_minus_lapack_F"] is not None for c in control) else None,
+            "median_abs_F_change_for_1e-7_step": float(np.median([abs(c["hip_F_at_theta_plus_1e-7"] - c["hip_F"]) for c in control])),
+            "mean_tree_size": float(stats["tree_size"].mean()), "energy_sd_over_draws": float(stats["energy"].std()),
+            "accepted_draws_checked": control[:3],
             "points": points[: args.keep_points]}
 
 
