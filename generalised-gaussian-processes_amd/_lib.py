@@ -39,6 +39,8 @@ PROTOTYPES = {
     "sgp_status_string": (C.c_char_p, [_i32]),
     "sgp_timing_enable": (None, [_i32]),
     "sgp_timing_last_ms": (_i32, [_i32, C.POINTER(C.c_float)]),
+    "sgp_timing_last_rows": (_i64, [_i32]),
+    "sgp_set_asm_overlap": (None, [_i32]),
     "sgp_suffstats_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_suffstats_bwd_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),

@@ -36,6 +36,7 @@ static size_t g_kfu_budget = KFU_BUDGET_DEFAULT;
 size_t stream_kfu_budget() { return g_kfu_budget; }
 
 static int g_timing = 0;
+static int64_t g_syrk_timed_rows = 0;  // data rows of the contraction launch the TIMING_SYRK events bracket (sgp_timing_last_rows)
 static hipEvent_t g_ev[TIMING_SLOTS][2];
 static int g_ev_ready = 0, g_ev_used[TIMING_SLOTS] = {0, 0, 0};
 // (a failed event call only leaves the optional timing slot unused: sgp_timing_last_ms then reports SGP_ERR_ARG)
@@ -336,14 +337,27 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
 template <int NW, bool GLDS, bool SKIP>
 __global__ __launch_bounds__(NW * 64, NW / 2) void syrk_tile_kernel(const double* __restrict__ Kfu, int Mp, int64_t nchunks,
                                                                     SplitMap smap, int ntiles, int accumulate,
-                                                                    double* __restrict__ slab) {
+                                                                    double* __restrict__ slab, int nsplit) {
   __shared__ double Ks[2][NB][KROW];
-  // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch
+  // id -> (xcd, tile, split group): all tiles of a split share id % 8, i.e. one XCD under round-robin dispatch.  When nsplit is
+  // not a multiple of 8 (the one-round head block: 14 splits x 36 tiles = 504 workgroups) the last nsplit % 8 splits are dealt
+  // to the XCDs as one run of (split, tile) tasks cut into 8 equal pieces: every XCD gets the same number of workgroups and
+  // the tiles of at most two splits (grid = 8 (nsplit / 8 * ntiles + ceil((nsplit % 8) ntiles / 8)), see syrk_grid()).
   const int id = blockIdx.x;
   const int xcd = id & 7;
   const int jj = id >> 3;
-  const int t = jj % ntiles;
-  const int split = (jj / ntiles) * 8 + xcd;
+  const int full = (nsplit >> 3) * ntiles;
+  int t, split;
+  if (jj < full) {
+    t = jj % ntiles;
+    split = (jj / ntiles) * 8 + xcd;
+  } else {
+    const int rem = (nsplit & 7) * ntiles, per = (rem + 7) >> 3;
+    const int u = xcd * per + (jj - full);
+    if (jj - full >= per || u >= rem) return;
+    t = u % ntiles;
+    split = (nsplit & ~7) + u / ntiles;
+  }
   int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while (ti * (ti + 1) / 2 > t) --ti;
@@ -472,6 +486,57 @@ void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, i
   prep_y_kernel<<<256, 256, 0, st>>>(y, N, p.Npad, ys, yypart);
 }
 
+static int syrk_grid(int nsplit, int ntiles) { return 8 * ((nsplit >> 3) * ntiles + (((nsplit & 7) * ntiles + 7) >> 3)); }
+
+// ---- kernel assembly beside the contraction: an A/B knob, OFF by default (measured: a loss) ------------------------------
+// Assembly is HBM-write bound, the contraction matrix-core bound, and the contraction needs all of K'_fu only at its very
+// end -- so VERDICT r2 asked for the assembly of row block r + 1 on a second stream beside the contraction of block r.  With
+// the whole K'_fu resident, mode 1 runs pass 1 as
+//     main stream:  prologue, assembly(head rows), contraction(head: ONE round of resident workgroups), contraction(tail)
+//     side stream:                                 assembly(tail rows)  -- beside the head contraction
+// (head = 14 splits x 36 tiles at M = 1024, its splits as long as the tail's full-size ones; the tail launch waits for the
+// side stream's event).  Same-box alternations at C5 (profiles/r03_overlap_ab.jsonl): one block 18.93 / 19.00 ms per
+// evaluation, head + tail enqueued serially (mode 2) 19.47, overlapped (mode 1) 19.71-19.83.  Two effects, both losses:
+// (i) a lone round of workgroups costs 2.2 ms for 1/9 of the rows (nothing fills its ragged end; the tail's rounds cost 1.6),
+// (ii) there is no overlap to be had between these two kernels as launched: the contraction's two workgroups take a CU's whole
+// register file and the assembly's eight take all of its wave slots, so whichever stream gets a CU first owns it until its
+// workgroups retire -- [head contraction || tail assembly] took 3.6 ms, the sum of the two alone.  Real overlap would need the
+// assembly INSIDE the contraction's launch (producer workgroups in its grid); its ceiling is the 0.8 ms by which the assembly's
+// HBM time exceeds its fp64 VALU time, because fp64 VALU and MFMA share the datapath.  Kept for A/B.
+constexpr int HEAD_SPLITS_MAX = 24;
+static int g_asm_overlap = -1;  // -1: read SGP_ASM_OVERLAP (default on) at first use
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static bool side_stream_ready() {
+  if (g_side) return true;
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
+  if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi) != hipSuccess) { g_side = nullptr; return false; }
+  if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(g_side);
+    g_side = nullptr;
+    return false;
+  }
+  return true;
+}
+// chunks of the head block (0 = no head): one round of resident workgroups whose splits are as long as the tail's full-size ones
+static void head_block(const StreamPlan& p, int64_t nchunks, int* head_ns, int64_t* head_chunks) {
+  *head_ns = 0;
+  *head_chunks = 0;
+  if (g_asm_overlap < 0) g_asm_overlap = getenv("SGP_ASM_OVERLAP") ? atoi(getenv("SGP_ASM_OVERLAP")) : 0;
+  int hs = RESIDENT_WGS / p.ntiles;
+  if (hs > HEAD_SPLITS_MAX) hs = HEAD_SPLITS_MAX;
+  const int64_t w = 8 * (int64_t)p.taper[0] + 4 * p.taper[1] + 2 * p.taper[2] + p.taper[3];  // tapered plans only (big shards)
+  if (g_asm_overlap == 0 || hs < 8 || w == 0 || p.sc_rows != p.Npad) return;
+  // a full-size tail split has 8 nchunks_tail / (8 w) chunks; head split = the same length: nh = hs c, c = (nchunks - nh) / w
+  int64_t c = nchunks / (w + hs);
+  int64_t nh = (hs * c) / (ASM_ROWS / NB) * (ASM_ROWS / NB);  // whole assembly row blocks
+  if (c < 64 || nh <= 0 || nh * 4 > nchunks) return;
+  *head_ns = hs;
+  *head_chunks = nh;
+}
+
 constexpr int BRED_G = 64;  // row groups of the two-stage b reduction
 struct FwdWs {
   double *Xs, *ys, *Zs, *Kfu, *slab, *bpart, *btmp, *yypart;
@@ -483,7 +548,7 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
   w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
   w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
   w.Zs = c.take<double>((size_t)p.Mp * p.DP);
-  w.slab = c.take<double>((size_t)p.nsplit * p.ntiles * TILE * TILE);
+  w.slab = c.take<double>((size_t)(p.nsplit + HEAD_SPLITS_MAX) * p.ntiles * TILE * TILE);  // + the head block's splits
   w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
@@ -504,6 +569,10 @@ extern "C" int sgp_timing_last_ms(int slot, float* ms) {
   if (hipEventSynchronize(g_ev[slot][1]) != hipSuccess) return SGP_ERR_LAUNCH;
   return hipEventElapsedTime(ms, g_ev[slot][0], g_ev[slot][1]) == hipSuccess ? SGP_OK : SGP_ERR_LAUNCH;
 }
+
+extern "C" int64_t sgp_timing_last_rows(int slot) { return slot == TIMING_SYRK ? g_syrk_timed_rows : -1; }
+
+extern "C" void sgp_set_asm_overlap(int mode) { g_asm_overlap = mode < 0 ? -1 : mode; }
 
 extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { g_kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
 
@@ -552,23 +621,15 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   const int grid = p.ntiles * p.nsplit;
   if (p.Npad == 0) {
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
-    syrk_tile_kernel<4, false, false><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.slab);
+    syrk_tile_kernel<4, false, false><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.slab, p.nsplit);
   }
-  for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
-    const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
-    timing_begin(TIMING_ASSEMBLE, st);
-    stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Kfu, w.bpart, st);
-    timing_end(TIMING_ASSEMBLE, st);
-    const int64_t nchunks = rows / NB;
-    const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
-    const SplitMap smap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, cps < 1 ? 1 : cps};
-    timing_begin(TIMING_SYRK, st);
-    static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // 0 = full diagonal tiles (A/B knob)
-    static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
-    static const int glds = getenv("SGP_SYRK_GLDS") ? atoi(getenv("SGP_SYRK_GLDS")) : 0;
-    const int accum = r0 > 0 ? 1 : 0;
+  static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // 0 = full diagonal tiles (A/B knob)
+  static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
+  static const int glds = getenv("SGP_SYRK_GLDS") ? atoi(getenv("SGP_SYRK_GLDS")) : 0;
+  auto contract = [&](const double* K, int64_t nchunks, const SplitMap& smap, int nsplit, int accum, double* slab) {
+    const int g = syrk_grid(nsplit, p.ntiles);
 #define SGP_SYRK_LAUNCH(NWV, GL, SK) \
-  syrk_tile_kernel<NWV, GL, SK><<<grid, NWV * 64, 0, st>>>(Kfu, p.Mp, nchunks, smap, p.ntiles, accum, w.slab)
+  syrk_tile_kernel<NWV, GL, SK><<<g, NWV * 64, 0, st>>>(K, p.Mp, nchunks, smap, p.ntiles, accum, slab, nsplit)
     if (glds) {
       if (skip_upper) SGP_SYRK_LAUNCH(4, true, true); else SGP_SYRK_LAUNCH(4, true, false);
     } else if (nwaves == 8) {
@@ -577,10 +638,56 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
       if (skip_upper) SGP_SYRK_LAUNCH(4, false, true); else SGP_SYRK_LAUNCH(4, false, false);
     }
 #undef SGP_SYRK_LAUNCH
+  };
+  int nslabs = p.nsplit;
+  int head_ns = 0;
+  int64_t head_chunks = 0;
+  if (p.Npad > 0) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
+  if (head_ns > 0) {
+    // head block [0, hrows) | tail [hrows, Npad): the tail's assembly runs on the side stream beside the head's contraction
+    // (serially on the main stream when the side stream cannot be had or SGP_ASM_OVERLAP=2: same blocks, same numbers)
+    const int64_t hrows = head_chunks * NB, trows = p.Npad - hrows, tchunks = trows / NB;
+    const bool side = g_asm_overlap == 1 && side_stream_ready();
+    double* head_slab = w.slab + (size_t)p.nsplit * p.ntiles * TILE * TILE;
+    const int hcps = (int)((head_chunks + head_ns - 1) / head_ns);
+    const int tcps = (int)((tchunks + p.nsplit - 1) / p.nsplit);
+    const SplitMap hmap{{0, 0, 0, 0}, hcps < 1 ? 1 : hcps};
+    const SplitMap tmap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, tcps < 1 ? 1 : tcps};
+    timing_begin(TIMING_ASSEMBLE, st);
+    stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, 0, hrows, N, M, Kfu, w.bpart, st);
+    bool forked = false;
+    if (side && hipEventRecord(g_ev_fork, st) == hipSuccess && hipStreamWaitEvent(g_side, g_ev_fork, 0) == hipSuccess) {
+      stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, hrows, trows, N, M, Kfu + (size_t)hrows * p.Mp, w.bpart, g_side);
+      forked = hipEventRecord(g_ev_join, g_side) == hipSuccess;
+      if (!forked) (void)hipStreamSynchronize(g_side);  // never expected: fall back to a blocking join
+    } else {
+      stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, hrows, trows, N, M, Kfu + (size_t)hrows * p.Mp, w.bpart, st);
+    }
+    timing_end(TIMING_ASSEMBLE, st);  // overlapped: the head's assembly only (what stays on the critical path)
+    contract(Kfu, head_chunks, hmap, head_ns, 0, head_slab);
+    if (forked && hipStreamWaitEvent(st, g_ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(g_side);
+    timing_begin(TIMING_SYRK, st);  // the dominant launch: the tail's contraction, alone on the device
+    contract(Kfu + (size_t)hrows * p.Mp, tchunks, tmap, p.nsplit, 0, w.slab);
     timing_end(TIMING_SYRK, st);
+    g_syrk_timed_rows = trows;
+    nslabs = p.nsplit + head_ns;
+  } else {
+    for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
+      const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
+      timing_begin(TIMING_ASSEMBLE, st);
+      stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Kfu, w.bpart, st);
+      timing_end(TIMING_ASSEMBLE, st);
+      const int64_t nchunks = rows / NB;
+      const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
+      const SplitMap smap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, cps < 1 ? 1 : cps};
+      timing_begin(TIMING_SYRK, st);
+      contract(Kfu, nchunks, smap, p.nsplit, r0 > 0 ? 1 : 0, w.slab);
+      timing_end(TIMING_SYRK, st);
+      g_syrk_timed_rows = rows;
+    }
   }
   const int nb32 = p.Mp / 32;
-  reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, p.nsplit, p.ntiles, M, sf2 * sf2, Phi);
+  reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, nslabs, p.ntiles, M, sf2 * sf2, Phi);
   bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);
   finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.btmp, BRED_G, p.Mp, M, w.yypart, 256, sf2,
                                                          sf2 * (double)N, b, yy, kappa);

@@ -338,11 +338,20 @@ class _SVGPBatchBoundFn(torch.autograd.Function):
         res = eng.svgp_elbo_batch(xb, yb, Z.detach().contiguous(), th[:, 1:1 + d].tolist(), th[:, 0].tolist(), th[:, 1 + d].tolist(),
                                   m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
                                   kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
-        host = res["out"].to("cpu")
-        model._last_infos = host[:, 3].to(torch.int32)
         ctx.res = res if need else None
         ctx.eng = eng
         ctx.theta_meta = (theta.shape, theta.device, theta.dtype)
+        if getattr(model, "_async_bounds", False) and res["out"].is_cuda:
+            # the training loop's variant: the copy is enqueued behind the chain into pinned memory and the caller waits for the
+            # stream itself (model._wait_bounds()) AFTER it has done the host work that does not need the bounds (the KL term)
+            pin = getattr(model, "_pinned_out", None)
+            if pin is None or pin.shape != res["out"].shape:
+                pin = model._pinned_out = torch.empty(res["out"].shape, dtype=torch.float64, pin_memory=True)
+            pin.copy_(res["out"], non_blocking=True)
+            model._pending_out = pin
+            return pin[:, 0]  # valid once the stream has been synchronised; NOT read before (see train_model)
+        host = res["out"].to("cpu")
+        model._last_infos = host[:, 3].to(torch.int32)
         return host[:, 0].clone()
 
     @staticmethod
@@ -535,6 +544,15 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         return _SVGPBoundFn.apply(th[1:-1], th[0], s2, self.inducing_inputs, self.variational_mean,
                                   self.chol_variational_covar, self, self._dev(x_batch), self._labels(y_batch))
 
+    def _wait_bounds(self):
+        """Completes an asynchronous ``elbo_hyper_samples`` (training loop only): waits for the stream, returns the status words."""
+        pin = getattr(self, "_pending_out", None)
+        self._pending_out = None
+        if pin is None:
+            return self._last_infos
+        torch.cuda.current_stream(self._engine_obj().device).synchronize()
+        return pin[:, 3].to(torch.int32)
+
     def elbo_hyper_samples(self, x_batch, y_batch, log_thetas):
         """The S bounds (host tensor, differentiable wrt q(u), Z and log_thetas) of one minibatch at the rows of log_thetas."""
         if x_batch.dim() == 1:
@@ -553,14 +571,21 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
             batch_losses = []
             for x_batch, y_batch in train_loader:
                 optimizer.zero_grad()
-                kl = self.log_theta.kl_per_point()
                 xb = self._dev(x_batch[:, None] if x_batch.dim() == 1 else x_batch)  # one host-to-device copy per minibatch
                 # one reparametrised draw at a time, as the reference consumes its random stream (:159-160)
                 lts = self.log_theta.draws(S)
                 if self.batched and hasattr(self._engine_obj(), "svgp_elbo_batch"):
-                    host = self.elbo_hyper_samples(xb, y_batch, lts)  # host tensor: bounds and status words came in one copy
-                    infos = self._last_infos
+                    # the chain is enqueued first; the KL term of q(log theta) (a dozen host operations) is formed while the
+                    # device works; then ONE wait brings the S bounds and their status words
+                    self._async_bounds = True
+                    try:
+                        host = self.elbo_hyper_samples(xb, y_batch, lts)
+                    finally:
+                        self._async_bounds = False
+                    kl = self.log_theta.kl_per_point()
+                    infos = self._wait_bounds()
                 else:
+                    kl = self.log_theta.kl_per_point()
                     # one launch chain per sample, enqueued back to back; status words read together
                     self._pending_infos = []
                     try:

@@ -110,6 +110,15 @@ const char* sgp_status_string(int status);
  * the closing event of the slot and returns the elapsed device time of the most recent launch.        */
 void sgp_timing_enable(int on);
 int sgp_timing_last_ms(int slot, float* ms);
+/* data rows of the contraction launch the slot-1 events bracketed (the tail block when pass 1 runs head + tail, below); -1 for
+ * the other slots */
+int64_t sgp_timing_last_rows(int slot);
+/* A/B knob (measured a loss, off by default; csrc/sgp_suffstats_fwd.hip): pass 1 as head block (one round of resident
+ * workgroups) + tail block with the tail's kernel assembly on a library-owned side stream beside the head's contraction.
+ * mode 0 (default): one block; 1: head + tail, overlapped; 2: head + tail enqueued serially on the caller's stream (the same
+ * numbers as mode 1 bit for bit; another split geometry than mode 0, so those differ at rounding level); -1: back to the
+ * environment variable SGP_ASM_OVERLAP / the default.                                                                     */
+void sgp_set_asm_overlap(int mode);
 
 /* ---- streaming pass 1: sufficient statistics over the local row shard -------------------------
  * Phi = Kuf Kuf^T (M x M, ld M, full symmetric), b = Kuf y (M), yy = y^T y, kappa = sum_n k(x_n,x_n).

@@ -29,7 +29,9 @@ def _few_host_threads():
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """The bound / gradient / predictive fixtures of make_golden.py (posterior_*.npz are the sampler's exact-moment fixtures)."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("posterior_")]
 
 
 def load_golden(name):

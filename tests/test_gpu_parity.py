@@ -753,3 +753,36 @@ def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
         env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "SGP_BENCH_SHARE_GPU", "SGP_BENCH_BACKEND")}
         bad = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
         assert bad.returncode != 0 and "2 ranks" in bad.stderr and not bad.stdout.strip().startswith("{"), (bad.stdout, bad.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
+    """The A/B knob sgp_set_asm_overlap (pass 1 as head block + tail block, the tail's kernel assembly on the library's side stream
+    beside the head's contraction): mode 1 (overlapped) and mode 2 (the same blocks enqueued serially) must agree bit for bit, and
+    both with the one-block default to rounding -- on a shard big enough for the tapered plan (400k x 512) and with a caller-owned
+    K'_fu, which pass 2 then reads: its gradients must not depend on the mode either."""
+    g = torch.Generator().manual_seed(11)
+    N, M, d = 400_000, 512, 4
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X.sum(1)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[torch.randperm(N, generator=g)[:M]].clone()
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    ls = [1.5, 2.0, 1.2, 1.8]
+    out = {}
+    try:
+        for mode in (0, 1, 2, 1):
+            engine.lib.sgp_set_asm_overlap(mode)
+            kfu = engine.kfu_buffer(N, M)
+            st = engine.suffstats(Xd, yd, Zd, ls, 1.3, "rbf", kfu=kfu).clone()
+            cb = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine, form="streaming")
+            F, gr = cb.value_and_grad(Zd, ls, 1.3, 0.05, want_gz=False)
+            out.setdefault(mode, []).append((st, kfu.clone(), F, gr["ls"].clone(), gr["sf2"], gr["s2"]))
+            del kfu
+    finally:
+        engine.lib.sgp_set_asm_overlap(-1)
+    (s0, k0, F0, g0, a0, b0), (s1, k1, F1, g1, a1, b1), (s2, k2, F2, g2, a2, b2) = out[0][0], out[1][0], out[2][0]
+    assert torch.equal(k0, k1) and torch.equal(k1, k2)                       # K'_fu itself does not depend on the blocks
+    assert torch.equal(s1, s2) and F1 == F2 and torch.equal(g1, g2) and (a1, b1) == (a2, b2)
+    assert torch.equal(out[1][1][0], s1) and out[1][1][2] == F1              # and run to run
+    assert float((s0 - s1).abs().max()) < 1e-12 * float(s0.abs().max())
+    assert abs(F0 - F1) < 1e-11 * abs(F0) and float((g0 - g1).abs().max()) < 1e-9 * float(g0.abs().max())

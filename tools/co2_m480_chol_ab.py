@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """Does LAPACK fail where the HIP evaluation fails?  
 
+Answer recorded in profiles/r03_co2_m480_chol_ab.json: NEITHER fails.  The seed whose 200 draws are all flagged never sees a failed
+factorization -- its Adam warm start ran the medium-term amplitude to ~1.5e3 (lambda_max(K_uu) = 1e9, cond(K_uu + 1e-6 I) = 1e15),
+where fp64 cannot evaluate the density: the bound changes by O(1e3) when theta moves by 1e-7, so the first leapfrog of every
+trajectory has an energy error > 1000 and is flagged; the chain never moves.  The other seeds sample at cond ~ 2e10 with the HIP
+and LAPACK values agreeing to 1e-5.  (The tool still captures failed factorizations should a build produce them.)
+
 The CO2 NUTS stage at the reference's M = 480 (experiments/co2_bayesian_sgpr_hmc.py:384) flagged 200 of 200 draws as divergent
 for one seed of three in round 2; DESIGN section 4a-3 blamed the MODEL at PyMC3's jitter 1e-6 (cond K_uu > 1e10), without a record
 of the LAPACK-based oracle failing at the same theta.  This tool makes that record.  It runs experiments/co2_composite_hmc.py's
@@ -114,6 +120,9 @@ def run_seed(seed, args, eng):
         F, g = inner(Z, target.kernel.with_values(vals).block(), 1.0, math.exp(th[-1]) ** 2, raise_on_fail=False)
         vals2 = [math.exp(v + 1e-7) for v in th[:-1]]
         F2, _ = inner(Z, target.kernel.with_values(vals2).block(), 1.0, math.exp(th[-1] + 1e-7) ** 2, raise_on_fail=False)
+        th2 = [v + 1e-7 for v in th]
+        rec2 = lapack_at(th2, target, Xc, yc, Zc, args.jitter)
+        rec["oracle_F_at_theta_plus_1e-7"] = rec2.get("oracle_F")
         rec.update({"theta": th, "hip_F": F, "hip_F_at_theta_plus_1e-7": F2,
                     "hip_minus_lapack_F": (F - rec["oracle_F"]) if "oracle_F" in rec else None})
         control.append(rec)
@@ -133,6 +142,8 @@ def run_seed(seed, args, eng):
             "median_abs_hip_minus_lapack_F_at_accepted_draws": float(np.median([abs(c["hip_minus_lapack_F"]) for c in control if c["hip_minus_lapack_F"] is not None]))
             if any(c["hip_minus_lapack_F"] is not None for c in control) else None,
             "median_abs_F_change_for_1e-7_step": float(np.median([abs(c["hip_F_at_theta_plus_1e-7"] - c["hip_F"]) for c in control])),
+            "median_abs_LAPACK_F_change_for_1e-7_step": float(np.median([abs(c["oracle_F_at_theta_plus_1e-7"] - c["oracle_F"]) for c in control
+                                                                         if c.get("oracle_F") is not None and c.get("oracle_F_at_theta_plus_1e-7") is not None] or [float("nan")])),
             "mean_tree_size": float(stats["tree_size"].mean()), "energy_sd_over_draws": float(stats["energy"].std()),
             "accepted_draws_checked": control[:3],
             "points": points[: args.keep_points]}
