@@ -41,6 +41,7 @@ PROTOTYPES = {
     "sgp_timing_last_ms": (_i32, [_i32, C.POINTER(C.c_float)]),
     "sgp_timing_last_rows": (_i64, [_i32]),
     "sgp_set_asm_overlap": (None, [_i32]),
+    "sgp_set_cond_limit": (None, [_dbl]),
     "sgp_suffstats_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_suffstats_bwd_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
@@ -101,6 +102,10 @@ PROTOTYPES = {
     "sgp_svgp_batch_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_svgp_elbo_batch": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                    _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_svgp_elbo_batch_forward": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
+                                           _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_svgp_elbo_batch_reverse": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
+                                           _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_svgp_batch_combine": (_i32, [_i32, _dp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgp_svgp_predict": (_i32, [_vp, _i64, _i64, _vp, _i64, _dp, _dbl, _dbl, _vp, _vp, _i32, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -866,17 +866,19 @@ extern "C" size_t sgp_svgp_batch_workspace_bytes(int64_t B, int M, int d, int S)
   return carve_svgp_batch(nullptr, padded_m(M), (int)round_up64(B, 64), M, d, S).bytes;
 }
 
-extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
-                                   int S, const double* inv_ls, const double* sf2, const double* s2, double jitter, const double* m,
-                                   const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id, int with_grads,
-                                   double* out, double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
-                                   int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
-  if (!Xb || !yb || !Z || !inv_ls || !sf2 || !s2 || !m || !LS || !out || !info || B <= 0 || M <= 0 || d <= 0 || ldx < d || ldz < d ||
-      N_total <= 0)
+// phase: 1 = forward (bounds, statuses, the likelihood's d/ds2), 2 = reverse from the state the forward left in `ws`, 3 = both
+static int svgp_batch_impl(int phase, const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                           int S, const double* inv_ls, const double* sf2, const double* s2, double jitter, const double* m,
+                           const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
+                           double* out, double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
+                           int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  const bool fwd = (phase & 1) != 0, with_grads = (phase & 2) != 0;
+  if (!Xb || !yb || !Z || !inv_ls || !sf2 || !s2 || !m || !LS || B <= 0 || M <= 0 || d <= 0 || ldx < d || ldz < d || N_total <= 0)
     return SGP_ERR_ARG;
+  if (fwd && (!out || !info)) return SGP_ERR_ARG;
   if (S < 1 || S > SVGP_MAX_S) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52 || likelihood_id < 0 || likelihood_id > 1) return SGP_ERR_ARG;
-  if (with_grads && (!g_m || !g_LS || !g_Z || !g_ls || !g_sf2 || !g_s2)) return SGP_ERR_ARG;
+  if (with_grads && (!g_m || !g_LS || !g_Z || !g_ls || !g_sf2)) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || B > (1 << 20)) return SGP_ERR_DIM;
   SvgpThetaS th{};
   for (int s = 0; s < S; ++s) {
@@ -896,34 +898,36 @@ extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* 
     g.batch2 = S; g.s2A = sa; g.s2B = sb; g.s2C = sc;
     gemm(g, st);
   };
-
-  // ---- forward ------------------------------------------------------------------------------------------------
-  svgp_prep_batch_kernel<<<gmm, 256, 0, st>>>(LS, m, M, Mp, w.LSp, w.mp, info, S);
-  svgp_kl_kernel<<<64, 256, 0, st>>>(m, LS, M, w.kl);
-  switch (kernel_id) {
-    case SGP_KERNEL_RBF: svgp_kuu_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
-    case SGP_KERNEL_MATERN32: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
-    default: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+  if (fwd) {
+    // ---- forward ------------------------------------------------------------------------------------------------
+    svgp_prep_batch_kernel<<<gmm, 256, 0, st>>>(LS, m, M, Mp, w.LSp, w.mp, info, S);
+    svgp_kl_kernel<<<64, 256, 0, st>>>(m, LS, M, w.kl);
+    switch (kernel_id) {
+      case SGP_KERNEL_RBF: svgp_kuu_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+      case SGP_KERNEL_MATERN32: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+      default: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+    }
+    potrf_lower_batch(w.Kp, w.Linv, Mp, Mp, S, mm, info, w.flags, st);
+    tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st, S, mm);
+    switch (kernel_id) {
+      case SGP_KERNEL_RBF: svgp_kub_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
+      case SGP_KERNEL_MATERN32: svgp_kub_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
+      default: svgp_kub_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
+    }
+    GemmDesc a;  // A = L^-1 Kub
+    a.A = w.Linv; a.lda = Mp; a.B = w.Kub; a.ldb = Bp; a.C = w.A; a.ldc = Bp;
+    a.m = Mp; a.n = Bp; a.k = Mp; a.khi_mask = 1;
+    gemm_s(a, mm, mb, mb);
+    GemmDesc t;  // T = LS^T A   (LS shared by the samples)
+    t.A = w.LSp; t.lda = Mp; t.ta = true; t.B = w.A; t.ldb = Bp; t.C = w.T; t.ldc = Bp;
+    t.m = Mp; t.n = Bp; t.k = Mp; t.klo_mask = 1;
+    gemm_s(t, 0, mb, mb);
+    svgp_cols_batch_kernel<<<dim3(Bp / 64, S), 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, th, w.mu, w.v);
+    svgp_ell_batch_kernel<<<dim3(64, S), 256, 0, st>>>(yb, w.mu, w.v, (int)B, Bp, th, likelihood_id, gh, w.dmu, w.dv, w.part);
+    svgp_finalize_batch_kernel<<<1, 64, 0, st>>>(w.part, w.kl, M, (int)B, (double)N_total, S, info, out, g_s2);
   }
-  potrf_lower_batch(w.Kp, w.Linv, Mp, Mp, S, mm, info, w.flags, st);
-  tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st, S, mm);
-  switch (kernel_id) {
-    case SGP_KERNEL_RBF: svgp_kub_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
-    case SGP_KERNEL_MATERN32: svgp_kub_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
-    default: svgp_kub_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmb, S), 256, 0, st>>>(Z, ldz, Xb, ldx, th, M, Mp, (int)B, Bp, w.Kub); break;
-  }
-  GemmDesc a;  // A = L^-1 Kub
-  a.A = w.Linv; a.lda = Mp; a.B = w.Kub; a.ldb = Bp; a.C = w.A; a.ldc = Bp;
-  a.m = Mp; a.n = Bp; a.k = Mp; a.khi_mask = 1;
-  gemm_s(a, mm, mb, mb);
-  GemmDesc t;  // T = LS^T A   (LS shared by the samples)
-  t.A = w.LSp; t.lda = Mp; t.ta = true; t.B = w.A; t.ldb = Bp; t.C = w.T; t.ldc = Bp;
-  t.m = Mp; t.n = Bp; t.k = Mp; t.klo_mask = 1;
-  gemm_s(t, 0, mb, mb);
-  svgp_cols_batch_kernel<<<dim3(Bp / 64, S), 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, th, w.mu, w.v);
-  svgp_ell_batch_kernel<<<dim3(64, S), 256, 0, st>>>(yb, w.mu, w.v, (int)B, Bp, th, likelihood_id, gh, w.dmu, w.dv, w.part);
-  svgp_finalize_batch_kernel<<<1, 64, 0, st>>>(w.part, w.kl, M, (int)B, (double)N_total, S, info, out, with_grads ? g_s2 : nullptr);
   if (!with_grads) return check_launch();
+
 
   // ---- reverse (the closed-form adjoint of sgp_svgp_elbo, sample by sample in blockIdx.y) ------------------------
   GemmDesc u;  // U = LS T
@@ -968,6 +972,39 @@ extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* 
   }
   svgp_kbwd_reduce_batch_kernel<<<dim3(grid_for_s((int64_t)M * d, 256), S), 256, 0, st>>>(w.kpart, w.gzraw, M, th, w.dv, (int)B, Bp, invB, g_ls, g_sf2, g_Z);
   return check_launch();
+}
+
+
+extern "C" int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                                   int S, const double* inv_ls, const double* sf2, const double* s2, double jitter, const double* m,
+                                   const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id, int with_grads,
+                                   double* out, double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
+                                   int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (with_grads && !g_s2) return SGP_ERR_ARG;
+  return svgp_batch_impl(with_grads ? 3 : 1, Xb, ldx, yb, B, Z, ldz, S, inv_ls, sf2, s2, jitter, m, LS, N_total, M, d, kernel_id,
+                         likelihood_id, out, g_m, g_LS, g_Z, g_ls, g_sf2, with_grads ? g_s2 : nullptr, info, ws, ws_bytes, stream);
+}
+
+// The reverse pass alone, from the state a sgp_svgp_elbo_batch(with_grads = 0) call with the SAME arguments left in `ws`
+// (nothing else may have used the workspace in between).  Lets a caller read the bounds back -- they are final after the
+// forward -- and do its host-side bookkeeping while the device runs the reverse chain.  g_s2 is the forward's output.
+extern "C" int sgp_svgp_elbo_batch_reverse(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                                           int S, const double* inv_ls, const double* sf2, const double* s2, double jitter,
+                                           const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id,
+                                           int likelihood_id, double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2,
+                                           void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  return svgp_batch_impl(2, Xb, ldx, yb, B, Z, ldz, S, inv_ls, sf2, s2, jitter, m, LS, N_total, M, d, kernel_id, likelihood_id,
+                         nullptr, g_m, g_LS, g_Z, g_ls, g_sf2, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+// forward with the likelihood's d/ds2 (g_s2, S doubles, may be NULL): the first half of the split call
+extern "C" int sgp_svgp_elbo_batch_forward(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                                           int S, const double* inv_ls, const double* sf2, const double* s2, double jitter,
+                                           const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id,
+                                           int likelihood_id, double* out, double* g_s2, int* info, void* ws, size_t ws_bytes,
+                                           sgp_stream_t stream) {
+  return svgp_batch_impl(1, Xb, ldx, yb, B, Z, ldz, S, inv_ls, sf2, s2, jitter, m, LS, N_total, M, d, kernel_id, likelihood_id,
+                         out, nullptr, nullptr, nullptr, nullptr, nullptr, g_s2, info, ws, ws_bytes, stream);
 }
 
 extern "C" int sgp_svgp_batch_combine(int S, const double* weights, int M, int d, const double* g_m, const double* g_LS,

@@ -590,6 +590,37 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
   c.take<int>(potrf_scratch_ints((int)Mp));
   return c.used();
 }
+// Conditioning gate of the explicit-inverse path.  Everything downstream of sgp_kuu_factor multiplies by the explicit L^-1;
+// unlike LAPACK's substitution that is not backward stable, and once cond(K_uu + J I) passes ~1e13 the bound it produces is
+// noise (measured at the CO2 model's M = 480, profiles/r03_co2_m480_chol_ab.json: cond 1e15, F = 7776 / 9440 for theta 1e-7
+// apart where LAPACK gives 1706.7726 / 1706.7731 -- a spurious spike that traps a Markov chain).  A Cholesky factor gives a
+// cheap LOWER bound of the condition number, (max_i L_ii / min_i L_ii)^2; above g_cond_limit the factorization is reported as
+// numerically not positive definite at its smallest pivot (info = argmin + 1), so samplers see a zero-density region (a
+// divergence, as PyMC3 treats a failed factorization) instead of a finite, meaningless density.  The single-launch path
+// (M <= 128, substitution solves) is not gated: it tracks LAPACK to cond 9e8 and beyond.
+static double g_cond_limit = 1e12;
+__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ L, int64_t ld, int M, double limit, int* info) {
+  __shared__ double smin[256], smax[256];
+  __shared__ int imin[256];
+  double lo = 1e300, hi = 0.0;
+  int at = 0;
+  for (int i = threadIdx.x; i < M; i += 256) {
+    const double v = L[(int64_t)i * ld + i];
+    if (v < lo) { lo = v; at = i; }
+    if (v > hi) hi = v;
+  }
+  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi; imin[threadIdx.x] = at;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 1; t < 256; ++t) {  // fixed order: the first smallest pivot wins
+      if (smin[t] < lo) { lo = smin[t]; at = imin[t]; }
+      if (smax[t] > hi) hi = smax[t];
+    }
+    const double r = hi / lo;
+    if (*info == 0 && !(r * r <= limit)) *info = at + 1;  // also catches a NaN / zero pivot the factorization let through
+  }
+}
+
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
 // caller can run it on a second stream underneath pass 1.
 extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
@@ -606,9 +637,11 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   zero_ints(info, 1, st);
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
+  if (g_cond_limit > 0.0) cond_gate_kernel<<<1, 256, 0, st>>>(L, Mp, M, g_cond_limit, info);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   return check_launch();
 }
+extern "C" void sgp_set_cond_limit(double limit) { g_cond_limit = limit >= 0.0 ? limit : 1e12; }
 
 // whitened: Phi / b already are W = A A^T and u = A y with A = L^-1 K_uf (sgp_suffstats_fwd_whitened); kuu_linv required
 static int bound_impl(const double* Kuu, const double* Phi, const double* b, const double* yy,

@@ -517,7 +517,7 @@ class HipEngine:
         return res
 
     def svgp_elbo_batch(self, Xb, yb, Z, ls, sf2, s2, m, LS, N_total, jitter=1e-6, kernel="rbf", likelihood="gaussian",
-                        with_grads=False):
+                        with_grads=False, defer_reverse=False):
         """The bound of one minibatch at S hyper-parameter samples in ONE chain of launches (sgp_svgp_elbo_batch).
         ls: S x d, sf2, s2: S (host sequences / arrays).  Returns dict(out [S, 4] = [bound per datum | sum E log p | KL | status], info [S], and with ``with_grads``
         g_m [S, M], g_LS [S, M, M], g_Z [S, M, d], g_ls [S, d], g_sf2 [S], g_s2 [S]); device tensors, nothing synchronised."""
@@ -546,6 +546,24 @@ class HipEngine:
         if nbytes == 0:
             raise ValueError("unsupported SVGP batch shape B=%d M=%d d=%d S=%d (S <= 8)" % (B, M, d, S))
         ws = self._workspace("svgp_batch", nbytes)
+        if with_grads and defer_reverse:
+            # two halves: the forward now; res["reverse"]() enqueues the reverse chain (the caller copies the bounds out in
+            # between, so that they reach the host while the device is still busy with the gradients)
+            head = (self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, S, inv, sf2c, s2c, float(jitter), self._ptr(m), self._ptr(LS),
+                    int(N_total), M, d, _kernel_id(kernel), lik)
+            st = self.lib.sgp_svgp_elbo_batch_forward(*head, self._ptr(out), self._ptr(g["g_s2"]), self._ptr(info), self._ptr(ws),
+                                                      ws.numel(), self._stream())
+            _lib.check("sgp_svgp_elbo_batch_forward", st)
+            keep = (Xb, yb, Z, m, LS, ws)  # the buffers the deferred call reads
+
+            def reverse():
+                st2 = self.lib.sgp_svgp_elbo_batch_reverse(*head, self._ptr(g["g_m"]), self._ptr(g["g_LS"]), self._ptr(g["g_Z"]),
+                                                           self._ptr(g["g_ls"]), self._ptr(g["g_sf2"]), self._ptr(keep[5]), keep[5].numel(),
+                                                           self._stream())
+                _lib.check("sgp_svgp_elbo_batch_reverse", st2)
+
+            res["reverse"] = reverse
+            return res
         st = self.lib.sgp_svgp_elbo_batch(
             self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, S, inv, sf2c, s2c, float(jitter), self._ptr(m), self._ptr(LS),
             int(N_total), M, d, _kernel_id(kernel), lik, 1 if with_grads else 0, self._ptr(out),

@@ -335,21 +335,28 @@ class _SVGPBatchBoundFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:4])
         th = theta.detach().to("cpu", torch.float64)
         d = Z.shape[1]
+        asyn = bool(getattr(model, "_async_bounds", False)) and hasattr(eng, "lib")
+        kw = {"defer_reverse": True} if (asyn and need) else {}
         res = eng.svgp_elbo_batch(xb, yb, Z.detach().contiguous(), th[:, 1:1 + d].tolist(), th[:, 0].tolist(), th[:, 1 + d].tolist(),
                                   m.detach().contiguous(), LS.detach().contiguous(), model.num_data, jitter=model.jitter,
-                                  kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need)
+                                  kernel=model.covar_module.base_kernel.kernel_name, likelihood=model.likelihood.name, with_grads=need, **kw)
         ctx.res = res if need else None
         ctx.eng = eng
         ctx.theta_meta = (theta.shape, theta.device, theta.dtype)
-        if getattr(model, "_async_bounds", False) and res["out"].is_cuda:
-            # the training loop's variant: the copy is enqueued behind the chain into pinned memory and the caller waits for the
-            # stream itself (model._wait_bounds()) AFTER it has done the host work that does not need the bounds (the KL term)
+        if asyn and res["out"].is_cuda:
+            # the training loop's variant: the forward half of the chain, then the copy of the bounds into pinned memory and an
+            # event, then the reverse half.  The caller waits for the EVENT (model._wait_bounds()) after it has formed the KL term,
+            # and runs its autograd bookkeeping while the device is still busy with the gradients.
             pin = getattr(model, "_pinned_out", None)
             if pin is None or pin.shape != res["out"].shape:
                 pin = model._pinned_out = torch.empty(res["out"].shape, dtype=torch.float64, pin_memory=True)
+                model._bounds_event = torch.cuda.Event()
             pin.copy_(res["out"], non_blocking=True)
+            model._bounds_event.record(torch.cuda.current_stream(res["out"].device))
+            if "reverse" in res:
+                res.pop("reverse")()
             model._pending_out = pin
-            return pin[:, 0]  # valid once the stream has been synchronised; NOT read before (see train_model)
+            return pin[:, 0]  # valid once the event has completed; NOT read before (see train_model)
         host = res["out"].to("cpu")
         model._last_infos = host[:, 3].to(torch.int32)
         return host[:, 0].clone()
@@ -550,7 +557,7 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         self._pending_out = None
         if pin is None:
             return self._last_infos
-        torch.cuda.current_stream(self._engine_obj().device).synchronize()
+        self._bounds_event.synchronize()
         return pin[:, 3].to(torch.int32)
 
     def elbo_hyper_samples(self, x_batch, y_batch, log_thetas):

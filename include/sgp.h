@@ -184,6 +184,11 @@ size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
  * sgp_bound_from_stats skip that part (Kuu may then be NULL).  In that case `info` is NOT cleared on entry:
  * pass the word sgp_kuu_factor wrote (the first failure stays; chol(B) reports M+1..2M only into a word
  * that is still 0), so one status word -- one host read -- covers the whole evaluation.                 */
+/* Conditioning gate: the explicit-inverse products downstream of sgp_kuu_factor turn to noise once cond(K_uu + J I) passes
+ * ~1e13 (where LAPACK's substitution still evaluates the bound).  sgp_kuu_factor therefore reports a factor whose pivots
+ * satisfy (max L_ii / min L_ii)^2 > limit -- a lower bound of the condition number -- as numerically not positive definite
+ * at its smallest pivot (info = argmin + 1).  Default limit 1e12; 0 disables the gate; negative restores the default.    */
+void sgp_set_cond_limit(double limit);
 size_t sgp_kuu_factor_len(int M);
 size_t sgp_kuu_factor_workspace_bytes(int M);
 int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info,
@@ -390,6 +395,18 @@ int sgp_svgp_elbo_batch(const double* Xb, int64_t ldx, const double* yb, int64_t
                         int with_grads, double* out,
                         double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
                         int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* The same call in two halves, for callers that want the bounds back while the device still runs the reverse chain:
+ * _forward = sgp_svgp_elbo_batch(with_grads = 0) plus the likelihood's d/ds2 (g_s2: S doubles, may be NULL); _reverse runs the
+ * reverse pass from the state _forward left in `ws` (same arguments, same workspace, nothing else in between).            */
+int sgp_svgp_elbo_batch_forward(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                                int S, const double* inv_ls, const double* sf2, const double* s2, double jitter,
+                                const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
+                                double* out, double* g_s2, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_svgp_elbo_batch_reverse(const double* Xb, int64_t ldx, const double* yb, int64_t B, const double* Z, int64_t ldz,
+                                int S, const double* inv_ls, const double* sf2, const double* s2, double jitter,
+                                const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
+                                double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2,
+                                void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_svgp_batch_combine(int S, const double* weights, int M, int d, const double* g_m, const double* g_LS, const double* g_Z,
                            const double* g_ls, const double* g_sf2, const double* g_s2, double* gm_out, double* gLS_out,
                            double* gZ_out, double* gtheta_out, sgp_stream_t stream);

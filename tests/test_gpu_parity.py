@@ -761,6 +761,7 @@ def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
     beside the head's contraction): mode 1 (overlapped) and mode 2 (the same blocks enqueued serially) must agree bit for bit, and
     both with the one-block default to rounding -- on a shard big enough for the tapered plan (400k x 512) and with a caller-owned
     K'_fu, which pass 2 then reads: its gradients must not depend on the mode either."""
+    import ggp_amd
     g = torch.Generator().manual_seed(11)
     N, M, d = 400_000, 512, 4
     X = torch.randn(N, d, dtype=torch.float64, generator=g)
@@ -786,3 +787,34 @@ def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
     assert torch.equal(out[1][1][0], s1) and out[1][1][2] == F1              # and run to run
     assert float((s0 - s1).abs().max()) < 1e-12 * float(s0.abs().max())
     assert abs(F0 - F1) < 1e-11 * abs(F0) and float((g0 - g1).abs().max()) < 1e-9 * float(g0.abs().max())
+
+
+@pytest.mark.gpu
+def test_conditioning_gate_of_the_explicit_inverse_path(engine):
+    """sgp_kuu_factor refuses a K_uu whose Cholesky pivots span more than sqrt(limit) (default 1e12 on the squared ratio, a lower
+    bound of cond): downstream the explicit L^-1 would turn the bound into noise (profiles/r03_co2_m480_chol_ab.json: cond 1e15,
+    F off by 6e3 where LAPACK is smooth), and a sampler must see a zero-density region rather than a spurious spike.
+    A well-conditioned matrix passes; with the gate switched off the same ill-conditioned matrix factors (as in LAPACK)."""
+    z = torch.linspace(0.0, 52.0, 300, dtype=torch.float64)[:, None]
+    ok = engine.kuu(dev(z.numpy(), engine), [0.5], 2.0, 1e-6, "rbf")          # cond ~ 1e7
+    bad = engine.kuu(dev(z.numpy(), engine), [3.0], 1.0e9, 1e-6, "rbf")       # lambda_max ~ 1e10 against the 1e-6 jitter
+    assert int(engine.kuu_factor(ok)[1].cpu()[0]) == 0
+    info = int(engine.kuu_factor(bad)[1].cpu()[0])
+    assert 1 <= info <= 300
+    assert np.linalg.cholesky(bad.cpu().numpy()) is not None                   # LAPACK itself does not fail here
+    try:
+        engine.lib.sgp_set_cond_limit(0.0)
+        assert int(engine.kuu_factor(bad)[1].cpu()[0]) == 0
+    finally:
+        engine.lib.sgp_set_cond_limit(-1.0)
+    assert int(engine.kuu_factor(bad)[1].cpu()[0]) == info
+    # through the model layer: the NUTS target reports -inf there, never a finite garbage value
+    X = torch.linspace(0.0, 52.0, 634, dtype=torch.float64)[:, None]
+    yv = torch.sin(X[:, 0])
+    cb = ggp_amd.CollapsedBound(dev(X.numpy(), engine), dev(yv.numpy(), engine), jitter=1e-6, engine=engine, form="whitened")
+    cb.fused = False
+    tgt = ggp_amd.HmcTarget(cb, dev(z.numpy(), engine))
+    lp, _ = tgt.logp_and_grad([math.log(3.0), 0.5 * math.log(1.0e9), math.log(0.01)])
+    assert lp == -math.inf
+    lp2, _ = tgt.logp_and_grad([math.log(0.5), 0.0, math.log(0.1)])
+    assert math.isfinite(lp2)

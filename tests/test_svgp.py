@@ -313,6 +313,12 @@ def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d,
         if lik == "gaussian":
             assert close(res["g_s2"][k], torch.tensor([ref["g_s2"]]), 1e-6)
     assert res["out"][:, 3].cpu().tolist() == [0.0] * S_hyper  # the status words ride along in the result rows
+    # the two-halves form (forward, [the caller's copy of the bounds], reverse) gives the same numbers bit for bit
+    sp = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
+                                likelihood=lik, with_grads=True, defer_reverse=True)
+    early = sp["out"].clone()
+    sp.pop("reverse")()
+    assert torch.equal(early, res["out"]) and all(torch.equal(sp[k], res[k]) for k in ("g_m", "g_LS", "g_Z", "g_ls", "g_sf2", "g_s2"))
     # reverse pass of a weighted sum of the S bounds in one launch (sgp_svgp_batch_combine)
     wts = torch.linspace(-0.7, 1.1, S_hyper, dtype=DT)
     gm, gLS, gZ, gth = engine.svgp_batch_combine(res, wts.tolist())
