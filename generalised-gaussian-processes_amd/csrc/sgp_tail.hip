@@ -593,31 +593,34 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
 // Conditioning gate of the explicit-inverse path.  Everything downstream of sgp_kuu_factor multiplies by the explicit L^-1;
 // unlike LAPACK's substitution that is not backward stable, and once cond(K_uu + J I) passes ~1e13 the bound it produces is
 // noise (measured at the CO2 model's M = 480, profiles/r03_co2_m480_chol_ab.json: cond 1e15, F = 7776 / 9440 for theta 1e-7
-// apart where LAPACK gives 1706.7726 / 1706.7731 -- a spurious spike that traps a Markov chain).  A Cholesky factor gives a
-// cheap LOWER bound of the condition number, (max_i L_ii / min_i L_ii)^2; above g_cond_limit the factorization is reported as
-// numerically not positive definite at its smallest pivot (info = argmin + 1), so samplers see a zero-density region (a
-// divergence, as PyMC3 treats a failed factorization) instead of a finite, meaningless density.  The single-launch path
-// (M <= 128, substitution solves) is not gated: it tracks LAPACK to cond 9e8 and beyond.
-static double g_cond_limit = 1e12;
-__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ L, int64_t ld, int M, double limit, int* info) {
-  __shared__ double smin[256], smax[256];
+// apart where LAPACK gives 1706.7726 / 1706.7731 -- a spurious spike that traps a Markov chain).  The factorization gives a
+// cheap estimate of the condition number: lambda_max <= trace(K) (and ~ trace for the strongly correlated inducing sets that
+// get into trouble), lambda_min <= every pivot L_ii^2, so  est = trace(K) / min_i L_ii^2  (>= cond / 1 for a dominant
+// eigenvalue, <= M cond always).  Above g_cond_limit the matrix is reported as numerically not positive definite at its
+// smallest pivot (info = argmin + 1), so samplers see a zero-density region (a divergence, as PyMC3 treats a failed
+// factorization) instead of a finite, meaningless density.  (The pivot ratio (max L_ii / min L_ii)^2 alone says 2e11 at that
+// cond-1e15 point: the diagonal of K is 2e6 while lambda_max is 1e9.)  The single-launch path (M <= 128, substitution solves)
+// is not gated: it tracks LAPACK.
+static double g_cond_limit = 1e13;
+__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ K, const double* __restrict__ L, int64_t ld, int M,
+                                                        double limit, int* info) {
+  __shared__ double smin[256], str[256];
   __shared__ int imin[256];
-  double lo = 1e300, hi = 0.0;
+  double lo = 1e300, tr = 0.0;
   int at = 0;
   for (int i = threadIdx.x; i < M; i += 256) {
     const double v = L[(int64_t)i * ld + i];
     if (v < lo) { lo = v; at = i; }
-    if (v > hi) hi = v;
+    tr += K[(int64_t)i * M + i];
   }
-  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi; imin[threadIdx.x] = at;
+  smin[threadIdx.x] = lo; str[threadIdx.x] = tr; imin[threadIdx.x] = at;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int t = 1; t < 256; ++t) {  // fixed order: the first smallest pivot wins
       if (smin[t] < lo) { lo = smin[t]; at = imin[t]; }
-      if (smax[t] > hi) hi = smax[t];
+      tr += str[t];
     }
-    const double r = hi / lo;
-    if (*info == 0 && !(r * r <= limit)) *info = at + 1;  // also catches a NaN / zero pivot the factorization let through
+    if (*info == 0 && !(tr <= limit * lo * lo)) *info = at + 1;  // also catches a NaN / zero pivot the factorization let through
   }
 }
 
@@ -637,11 +640,11 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   zero_ints(info, 1, st);
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
-  if (g_cond_limit > 0.0) cond_gate_kernel<<<1, 256, 0, st>>>(L, Mp, M, g_cond_limit, info);
+  if (g_cond_limit > 0.0) cond_gate_kernel<<<1, 256, 0, st>>>(Kuu, L, Mp, M, g_cond_limit, info);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   return check_launch();
 }
-extern "C" void sgp_set_cond_limit(double limit) { g_cond_limit = limit >= 0.0 ? limit : 1e12; }
+extern "C" void sgp_set_cond_limit(double limit) { g_cond_limit = limit >= 0.0 ? limit : 1e13; }
 
 // whitened: Phi / b already are W = A A^T and u = A y with A = L^-1 K_uf (sgp_suffstats_fwd_whitened); kuu_linv required
 static int bound_impl(const double* Kuu, const double* Phi, const double* b, const double* yy,

@@ -185,9 +185,9 @@ size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
  * pass the word sgp_kuu_factor wrote (the first failure stays; chol(B) reports M+1..2M only into a word
  * that is still 0), so one status word -- one host read -- covers the whole evaluation.                 */
 /* Conditioning gate: the explicit-inverse products downstream of sgp_kuu_factor turn to noise once cond(K_uu + J I) passes
- * ~1e13 (where LAPACK's substitution still evaluates the bound).  sgp_kuu_factor therefore reports a factor whose pivots
- * satisfy (max L_ii / min L_ii)^2 > limit -- a lower bound of the condition number -- as numerically not positive definite
- * at its smallest pivot (info = argmin + 1).  Default limit 1e12; 0 disables the gate; negative restores the default.    */
+ * ~1e13 (where LAPACK's substitution still evaluates the bound).  sgp_kuu_factor therefore reports a matrix whose estimate
+ * trace(K_uu) / min_i L_ii^2 (lambda_max <= trace, lambda_min <= every pivot) exceeds `limit` as numerically not positive
+ * definite at its smallest pivot (info = argmin + 1).  Default limit 1e13; 0 disables the gate; negative restores the default. */
 void sgp_set_cond_limit(double limit);
 size_t sgp_kuu_factor_len(int M);
 size_t sgp_kuu_factor_workspace_bytes(int M);

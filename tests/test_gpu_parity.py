@@ -768,7 +768,7 @@ def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
     y = torch.sin(X.sum(1)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
     Z = X[torch.randperm(N, generator=g)[:M]].clone()
     Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
-    ls = [1.5, 2.0, 1.2, 1.8]
+    ls = [0.6, 0.7, 0.5, 0.8]  # short lengthscales: a well-conditioned K_uu, so F itself can be compared to rounding
     out = {}
     try:
         for mode in (0, 1, 2, 1):
@@ -791,8 +791,7 @@ def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
 
 @pytest.mark.gpu
 def test_conditioning_gate_of_the_explicit_inverse_path(engine):
-    """sgp_kuu_factor refuses a K_uu whose Cholesky pivots span more than sqrt(limit) (default 1e12 on the squared ratio, a lower
-    bound of cond): downstream the explicit L^-1 would turn the bound into noise (profiles/r03_co2_m480_chol_ab.json: cond 1e15,
+    """sgp_kuu_factor refuses a K_uu whose condition estimate trace(K) / min pivot exceeds the limit (default 1e13): downstream the explicit L^-1 would turn the bound into noise (profiles/r03_co2_m480_chol_ab.json: cond 1e15,
     F off by 6e3 where LAPACK is smooth), and a sampler must see a zero-density region rather than a spurious spike.
     A well-conditioned matrix passes; with the gate switched off the same ill-conditioned matrix factors (as in LAPACK)."""
     z = torch.linspace(0.0, 52.0, 300, dtype=torch.float64)[:, None]
