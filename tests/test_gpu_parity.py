@@ -796,7 +796,7 @@ def test_conditioning_gate_of_the_explicit_inverse_path(engine):
     A well-conditioned matrix passes; with the gate switched off the same ill-conditioned matrix factors (as in LAPACK)."""
     z = torch.linspace(0.0, 52.0, 300, dtype=torch.float64)[:, None]
     ok = engine.kuu(dev(z.numpy(), engine), [0.5], 2.0, 1e-6, "rbf")          # cond ~ 1e7
-    bad = engine.kuu(dev(z.numpy(), engine), [3.0], 1.0e9, 1e-6, "rbf")       # lambda_max ~ 1e10 against the 1e-6 jitter
+    bad = engine.kuu(dev(z.numpy(), engine), [3.0], 2.0e6, 1e-6, "rbf")       # lambda_max ~ 5e8 against the 1e-6 jitter: cond ~ 1e14-1e15
     assert int(engine.kuu_factor(ok)[1].cpu()[0]) == 0
     info = int(engine.kuu_factor(bad)[1].cpu()[0])
     assert 1 <= info <= 300
@@ -813,7 +813,7 @@ def test_conditioning_gate_of_the_explicit_inverse_path(engine):
     cb = ggp_amd.CollapsedBound(dev(X.numpy(), engine), dev(yv.numpy(), engine), jitter=1e-6, engine=engine, form="whitened")
     cb.fused = False
     tgt = ggp_amd.HmcTarget(cb, dev(z.numpy(), engine))
-    lp, _ = tgt.logp_and_grad([math.log(3.0), 0.5 * math.log(1.0e9), math.log(0.01)])
+    lp, _ = tgt.logp_and_grad([math.log(3.0), 0.5 * math.log(2.0e6), math.log(0.01)])
     assert lp == -math.inf
     lp2, _ = tgt.logp_and_grad([math.log(0.5), 0.0, math.log(0.1)])
     assert math.isfinite(lp2)
