@@ -193,7 +193,7 @@ class CollapsedBound:
     # ------------------------------------------------------------------ single-launch path (small problems)
     def _small_ok(self, M, want_gz=False, sf2=1.0):
         """One cooperative launch instead of ~60: M <= 128, this rank holds all rows, and the caller did not insist on the
-        streaming order (the launch evaluates the whitened / PyMC3 order).  Stationary kernels d <= 16; composite kernels
+        streaming order (the launch evaluates the whitened / PyMC3 order).  Stationary kernels d <= 24; composite kernels
         d <= 8, without dF/dZ (that goes through the materialised path) and with the block's own amplitudes (sf2 = 1)."""
         e = self.engine
         if self.kernel == "composite" and (want_gz or float(sf2) != 1.0):

@@ -21,7 +21,7 @@
 
 namespace sgp {
 
-constexpr int NUTS_MAXD = 18;      // dimension of theta (d + 2 for the collapsed bound, d <= 16)
+constexpr int NUTS_MAXD = 26;      // dimension of theta (d + 2 for the collapsed bound, d <= 24)
 constexpr int NUTS_MAXDEPTH = 12;  // stack entries (max_treedepth <= 11)
 enum { NUTS_EVAL = 1, NUTS_DONE = 2 };
 enum { NS_INIT = 0, NS_WAIT_INIT, NS_BEGIN_DRAW, NS_WAIT_LEAF, NS_FINISHED };

@@ -32,7 +32,7 @@
 namespace sgp {
 
 constexpr int SM_SLAB = 64;
-constexpr int SM_MAXD = 16;
+constexpr int SM_MAXD = 24;  // input dimensions of the stationary kernels (Elevator: d = 18); LDS of the M <= 128 class is full at 24
 constexpr int SM_MAX_ROWWG = 64;
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
@@ -83,7 +83,6 @@ struct SmSlabShared {
   double ys[SM_SLAB];
   double gv[MP], hv[MP];
   double red[4][MP];
-  double gz[MP * SM_MAXD];
   double acc[SM_GP];
 };
 
@@ -957,6 +956,9 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
 
   // =================================================================================================================
   // slab pipeline shared by the row workgroups (role 2) and the Kuu-adjoint workgroup (role 1)
+  // dF/dZ partial of this workgroup (slot wg - 1 of gzpart): accumulated in its own line of global scratch -- L2 resident, 8 of its
+  // M d entries per thread and slab -- rather than in LDS, which at M <= 128 has no room for M x d more doubles beside d <= 24
+  double* __restrict__ gzmine = a.gzpart + (size_t)(wg > 0 ? wg - 1 : 0) * MP * SM_MAXD;
   // contraction of kbar (in Y, dF/dK_uf of this slab) with dK/d(ls, sf2, Z); data rows in sl.xs (scaled), validity masks
   auto contract = [&](const SlabRegs<NB16>& Y, int nvalid, double zscale) __attribute__((always_inline)) {
     // nvalid: slab rows that are real ; zscale: 1 for K_uf, 2 for the symmetric K_uu (both arguments are inducing inputs)
@@ -1054,7 +1056,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         const double zj = sl.zs[m][j];
         double s = 0.0;
         for (int r = 0; r < SM_SLAB; ++r) s = fma(sl.S[r][m], sl.xs[r][j] - zj, s);
-        sl.gz[e] += -2.0 * zscale * hyp.inv_ls[j] * s;  // d r2 / d z_mj = -2 (x~ - z~) / ls_j
+        gzmine[e] += -2.0 * zscale * hyp.inv_ls[j] * s;  // d r2 / d z_mj = -2 (x~ - z~) / ls_j
       }
     }
     __syncthreads();
@@ -1063,7 +1065,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
   stage_z();
   if (tid < SM_GP) sl.acc[tid] = 0.0;
   if (a.want_gz)
-    for (int e = tid; e < MP * SM_MAXD; e += 256) sl.gz[e] = 0.0;
+    for (int e = tid; e < M * d; e += 256) gzmine[e] = 0.0;  // element e is read, summed into and written by this thread only
   __syncthreads();
 
   if (role == 2) {
@@ -1329,8 +1331,6 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     }
     stamp(7);
     if (tid < SM_GP) a.gpart[(size_t)(rw + NB64) * SM_GP + tid] = sl.acc[tid];
-    if (a.want_gz)
-      for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)(rw + NB64) * MP * SM_MAXD + e] = sl.gz[e];
     sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
     return;
   }
@@ -1455,8 +1455,6 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
   }
   stamp(3);
   if (tid < SM_GP) a.gpart[(size_t)v * SM_GP + tid] = sl.acc[tid];
-  if (a.want_gz)
-    for (int e = tid; e < MP * SM_MAXD; e += 256) a.gzpart[(size_t)v * MP * SM_MAXD + e] = sl.gz[e];
   sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
 }
 

@@ -354,7 +354,7 @@ def sample_nuts_device(target, n_samples: int, tune: int, seed: Optional[int] = 
     (``trace['ls']``, ``trace[i]``, ``get_sampler_stats('step_size' | 'perf_counter_diff')``)."""
     b = target.bound
     if not target.device_sampler_ok():
-        raise ValueError("the device sampler needs the single-launch path (M <= 128, one rank; stationary kernels d <= 16, "
+        raise ValueError("the device sampler needs the single-launch path (M <= 128, one rank; stationary kernels d <= 24, "
                          "composite kernels d <= 8)")
     nd = target.ndim
     if seed is None:

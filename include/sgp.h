@@ -230,7 +230,7 @@ int sgp_bound_from_whitened_stats_ex(const double* W, const double* u, const dou
                                      const double* kuu_linv, int* info, double* Cw,
                                      void* ws, size_t ws_bytes, sgp_stream_t stream);
 
-/* ---- single-launch evaluation for small problems (M <= 128; stationary kernels d <= 16, composite d <= 8) -------------------------
+/* ---- single-launch evaluation for small problems (M <= 128; stationary kernels d <= 24, composite d <= 8) -------------------------
  * The size class of the reference's own HMC runs (models/bayesian_sgpr_hmc.py:58-80,144-157: N ~ 250-1300, M = 100).
  * ONE cooperative kernel launch evaluates the bound and its gradient in the PyMC3 op order (A = L^-1 K_uf by blocked
  * substitution on the matrix cores; B = I + A A^T / s2), reading the hyper-parameters from DEVICE memory:

@@ -8,7 +8,7 @@ import torch
 from conftest import dev, golden_names, load_golden
 
 KNAME = {0: "rbf", 1: "matern32", 2: "matern52"}
-SMALL = [n for n in golden_names() if load_golden(n)["X"].shape[1] <= 16]
+SMALL = [n for n in golden_names() if load_golden(n)["X"].shape[1] <= 24]  # incl. rbf_d18_mid: Elevator's d = 18 at M = 128
 
 
 def relerr(a, b):
@@ -68,10 +68,12 @@ def test_small_hmc_target_golden(engine, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,M,d,kern", [(1, 1, 1, "rbf"), (63, 7, 2, "rbf"), (64, 64, 3, "matern32"), (65, 65, 1, "rbf"),
                                          (634, 128, 1, "rbf"), (500, 50, 1, "matern52"), (1300, 100, 13, "rbf"),
-                                         (5000, 100, 8, "rbf")])
+                                         (5000, 100, 8, "rbf"), (1300, 100, 18, "rbf"), (700, 60, 24, "matern32"),
+                                         (13279, 100, 18, "rbf")])
 def test_small_shapes_vs_oracle(engine, N, M, d, kern):
     """Edge shapes: one row, slab boundaries, both padded sizes, several slabs per workgroup (N = 5000 -> 79 slabs on 64
-    workgroups), d up to 13 (the reference's UCI sets)."""
+    workgroups), d up to 13 (the reference's small UCI sets), d = 18 (Elevator, also at its full 13 279 training rows with the
+    reference's default M = 100: large_scale_regression_SGHMC.py:39-51,244) and the limit d = 24."""
     from oracle import vfe_oracle as O
     kid = {"rbf": 0, "matern32": 1, "matern52": 2}[kern]
     g = torch.Generator().manual_seed(N + M)
@@ -136,7 +138,7 @@ def test_fused_launch_agrees_with_the_multi_launch_whitened_path(engine, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["rbf_d3_small", "rbf_d1_tiny"])
+@pytest.mark.parametrize("name", ["rbf_d3_small", "rbf_d1_tiny", "rbf_d18_mid"])
 def test_device_resident_nuts_matches_the_host_driven_sampler(engine, name):
     """sgp_small_nuts (one persistent launch) against hmc.NUTS driven from the host with the same splitmix stream and the
     same evaluations (the single-launch NUTS target): identical trees, draws equal to rounding (the sampler's own exp / log
@@ -296,3 +298,23 @@ def test_small_launch_is_refused_when_its_workgroups_cannot_all_be_resident(engi
         engine.lib.sgp_set_cu_budget(0)
     o, _, i = engine.small_eval(X, y, Z, th, float(G["jitter"]), KNAME[int(G["kernel_id"])], mode=0, want_grad=True)
     assert int(i.item()) == 0 and abs(float(o[0]) - float(G["F"])) < 1e-9 * abs(float(G["F"]))
+
+
+@pytest.mark.gpu
+def test_small_dimension_limit(engine):
+    """d = 24 is the last dimension the single launch takes (LDS of the M <= 128 class is full there); d = 25 is answered with 0 by
+    sgp_small_supported and the Python layer falls back to the multi-launch path with the same numbers."""
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    assert engine.small_supported(500, 100, 24, "rbf") and not engine.small_supported(500, 100, 25, "rbf")
+    g = torch.Generator().manual_seed(3)
+    N, M, d = 500, 40, 25
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X.sum(1) / 5.0) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[:M].clone()
+    ls = torch.full((d,), 4.0, dtype=torch.float64)
+    cb = ggp_amd.CollapsedBound(X.to(engine.device), y.to(engine.device), jitter=1e-6, engine=engine)
+    assert not cb._small_ok(M)
+    F, gr = cb.value_and_grad(Z.to(engine.device), ls.tolist(), 1.2, 0.05, want_gz=False)
+    ref = O.grads_autograd(X, y, Z, ls, 1.2, 0.05, 1e-6)
+    assert abs(F - ref["F"]) < 1e-9 * abs(ref["F"]) and relerr(gr["ls"].numpy(), ref["g_ls"].numpy()) < 1e-6

@@ -19,7 +19,7 @@ K = 200
 
 def main():
     eng = ggp_amd.HipEngine()
-    shapes = os.environ.get("SHAPES", "382,1,25;500,1,50;634,1,64;634,1,128;1300,8,100;1300,13,100;5000,8,100;13279,16,100")
+    shapes = os.environ.get("SHAPES", "382,1,25;500,1,50;634,1,64;634,1,128;1300,8,100;1300,13,100;5000,8,100;13279,16,100;13279,18,100;13279,18,128")
     for spec in shapes.split(";"):
         N, d, M = (int(v) for v in spec.split(","))
         g = torch.Generator().manual_seed(0)
