@@ -33,7 +33,8 @@ namespace sgp {
 
 constexpr int SM_SLAB = 64;
 constexpr int SM_MAXD = 24;  // input dimensions of the stationary kernels (Elevator: d = 18); LDS of the M <= 128 class is full at 24
-constexpr int SM_MAX_ROWWG = 64;
+constexpr int SM_MAX_ROWWG = 208;  // row workgroups at most (one 64-row slab each up to N = 13 312: Elevator's 13 279 training rows;
+                                   // 64 until round 3 -- N = 13 279 then walked 3-4 slabs per workgroup on a quarter of the chip)
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
 enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_ACK = 11, SY_WORDS = 12 };
@@ -1609,7 +1610,7 @@ struct SmallWs {
   size_t bytes;
 };
 
-// The workgroups of these launches wait for each other, so ALL of them have to be resident at once.  The grid (<= 67) is
+// The workgroups of these launches wait for each other, so ALL of them have to be resident at once.  The grid (<= 211) is
 // checked against what the device can hold -- occupancy of this very kernel x the CUs the calling thread's launches can use
 // (device count, or sgp_set_cu_budget() on a CU-masked stream) -- and refused with SGP_ERR_LAUNCH otherwise, instead of
 // spinning into SGP_INFO_TIMEOUT.  (hipLaunchCooperativeKernel would make the runtime do the same check, at the price of its
@@ -1625,11 +1626,23 @@ static bool small_grid_is_resident(int grid) {
   return (long long)per_cu * available_cus() >= grid;
 }
 static int small_grid(int M, int grow) { return 1 + (M <= 64 ? 1 : 2) + grow; }
+// Row workgroups of a launch over nslab 64-row slabs: as many as there are slabs, CUs (one workgroup per CU, minus the chain and
+// the K_uu-adjoint workgroups) and SM_MAX_ROWWG allow -- then evened out, so that no workgroup walks a slab more than the others
+// (65 slabs on 64 workgroups would cost two rounds for one slab: 33 workgroups x 2 slabs instead).
+static int small_row_workgroups(int nslab, int NB64) {
+  int cap = available_cus() - 1 - NB64;
+  if (cap > SM_MAX_ROWWG) cap = SM_MAX_ROWWG;
+  if (cap < 1) cap = 1;
+  if (nslab <= cap) return nslab;
+  const int rounds = (nslab + cap - 1) / cap;
+  return (nslab + rounds - 1) / rounds;
+}
 static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
   (void)d;
   const int MP = M <= 64 ? 64 : 128, NB64 = MP / 64;
   const int nslab = (int)((N + SM_SLAB - 1) / SM_SLAB) > 0 ? (int)((N + SM_SLAB - 1) / SM_SLAB) : 1;
-  const int grow = nslab < SM_MAX_ROWWG ? nslab : SM_MAX_ROWWG;
+  const int grow_cap = nslab < SM_MAX_ROWWG ? nslab : SM_MAX_ROWWG;  // buffers are sized for the cap, whatever the CU budget is
+  const int grow = small_row_workgroups(nslab, NB64);
   const size_t mm = (size_t)MP * MP;
   Carver c(ws);
   SmallWs w{};
@@ -1640,15 +1653,15 @@ static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
   w.a.Lb = c.take<double>(mm);
   w.a.dinvB = c.take<double>((size_t)(MP / 16) * 256);
   w.a.A = c.take<double>((size_t)nslab * SM_SLAB * MP);
-  w.a.Ppart = c.take<double>((size_t)grow * mm);
-  w.a.upart = c.take<double>((size_t)grow * MP);
-  w.a.spart = c.take<double>(2 + 2 * (size_t)grow);
+  w.a.Ppart = c.take<double>((size_t)grow_cap * mm);
+  w.a.upart = c.take<double>((size_t)grow_cap * MP);
+  w.a.spart = c.take<double>(2 + 2 * (size_t)grow_cap);
   w.a.u = c.take<double>(MP);
   w.a.c0 = c.take<double>(MP);
   w.a.g = c.take<double>(MP);
   w.a.h = c.take<double>(MP);
-  w.a.gpart = c.take<double>((size_t)(grow + NB64) * SM_GP);
-  w.a.gzpart = c.take<double>((size_t)(grow + NB64) * MP * SM_MAXD);
+  w.a.gpart = c.take<double>((size_t)(grow_cap + NB64) * SM_GP);
+  w.a.gzpart = c.take<double>((size_t)(grow_cap + NB64) * MP * SM_MAXD);
   w.a.Qm = c.take<double>(mm);
   w.a.nslab = nslab;
   w.a.grow = grow;
@@ -1661,7 +1674,7 @@ static SmallWs carve_small(void* ws, int64_t N, int M, int d) {
 using namespace sgp;
 
 static unsigned long long* g_small_stamps = nullptr;
-// measurement aid (tools/small_eval_phases.py): a device buffer of (2 + 64) x 16 uint64 that the next launches fill with
+// measurement aid (tools/small_eval_phases.py): a device buffer of (3 + 208) x 16 uint64 that the next launches fill with
 // s_memrealtime stamps at their phase boundaries; NULL switches it off
 extern "C" void sgp_small_debug_stamps(void* dev_buffer) { g_small_stamps = static_cast<unsigned long long*>(dev_buffer); }
 
@@ -1669,8 +1682,7 @@ extern "C" int sgp_small_supported(int64_t N, int M, int d, int kernel_id) {
   if (!(N >= 1 && N <= (int64_t)1 << 22 && M >= 1 && M <= 128 && d >= 1)) return 0;
   // every workgroup of the launch must be resident (they wait for each other): at least one per available CU is assumed
   // here, the launch itself checks the kernel's real occupancy.  Callers fall back to the multi-launch path on 0.
-  const int64_t nslab = (N + SM_SLAB - 1) / SM_SLAB;
-  if (small_grid(M, (int)(nslab < SM_MAX_ROWWG ? nslab : SM_MAX_ROWWG)) > available_cus()) return 0;
+  if (available_cus() < 4) return 0;  // chain + K_uu-adjoint workgroups + at least one row workgroup (the grid adapts to the budget)
   if (kernel_id == SGP_KERNEL_COMPOSITE) return d <= COMP_MAX_DIM;
   return d <= SM_MAXD && kernel_id >= SGP_KERNEL_RBF && kernel_id <= SGP_KERNEL_MATERN52;
 }

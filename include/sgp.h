@@ -241,7 +241,7 @@ int sgp_bound_from_whitened_stats_ex(const double* W, const double* u, const dou
  * out (d + 5 doubles), g_Z (M*d, ld d, optional: NULL skips dF/dZ) and info are DEVICE pointers; nothing is synchronised.
  * want_grad = 0 writes out[0] (and the two parts) only.  The first sgp_small_sync_bytes() bytes of `ws` must be zero
  * before the FIRST launch on a workspace (the kernel leaves them zero; after info = SGP_INFO_TIMEOUT zero them again).
- * All workgroups (1 + ceil(M/64) + min(ceil(N/64), 64)) must be co-resident.  The library checks the grid against
+ * All workgroups (1 + ceil(M/64) + row workgroups: one per 64-row slab up to min(208, CUs - 3), evened out beyond) must be co-resident.  The library checks the grid against
  * (occupancy of the kernel) x (CUs of the device, or the calling thread's sgp_set_cu_budget() for a CU-masked stream):
  * sgp_small_supported() answers 0 and the launch returns SGP_ERR_LAUNCH when it cannot fit (use the multi-launch entry
  * points then).  A plain launch, not hipLaunchCooperativeKernel: beside a kernel that already FILLS the device the
@@ -252,7 +252,7 @@ int sgp_bound_from_whitened_stats_ex(const double* W, const double* u, const dou
 #define SGP_SMALL_NATURAL 0
 #define SGP_SMALL_HMC 1
 int sgp_small_supported(int64_t N, int M, int d, int kernel_id);
-/* measurement aid: device buffer of (3 + 64) * 16 uint64 filled with s_memrealtime ticks (100 MHz) at the phase
+/* measurement aid: device buffer of (3 + 208) * 16 uint64 filled with s_memrealtime ticks (100 MHz) at the phase
  * boundaries of every workgroup by the following launches; NULL (default) switches it off */
 void sgp_small_debug_stamps(void* dev_buffer);
 size_t sgp_small_workspace_bytes(int64_t N, int M, int d);

@@ -794,6 +794,7 @@ def test_conditioning_gate_of_the_explicit_inverse_path(engine):
     """sgp_kuu_factor refuses a K_uu whose condition estimate trace(K) / min pivot exceeds the limit (default 1e13): downstream the explicit L^-1 would turn the bound into noise (profiles/r03_co2_m480_chol_ab.json: cond 1e15,
     F off by 6e3 where LAPACK is smooth), and a sampler must see a zero-density region rather than a spurious spike.
     A well-conditioned matrix passes; with the gate switched off the same ill-conditioned matrix factors (as in LAPACK)."""
+    import ggp_amd
     z = torch.linspace(0.0, 52.0, 300, dtype=torch.float64)[:, None]
     ok = engine.kuu(dev(z.numpy(), engine), [0.5], 2.0, 1e-6, "rbf")          # cond ~ 1e7
     bad = engine.kuu(dev(z.numpy(), engine), [3.0], 2.0e6, 1e-6, "rbf")       # lambda_max ~ 5e8 against the 1e-6 jitter: cond ~ 1e14-1e15

@@ -31,13 +31,13 @@ def main():
         blk = ggp_amd.co2_kernel(0.5, 1.0, 5.0, 1.0, 3.0, 1.0, 0.5, 2.0, 0.1, 0.5).block()
         th = torch.tensor(blk + [0.09], dtype=torch.float64).to(eng.device)
         kern, kw = "composite", {"composite": {"structure": blk}}
-    stamps = torch.zeros(67 * 16, dtype=torch.int64, device=eng.device)
+    stamps = torch.zeros(211 * 16, dtype=torch.int64, device=eng.device)
     eng.lib.sgp_small_debug_stamps(C.c_void_p(stamps.data_ptr()))
     for _ in range(20):
         eng.small_eval(X, y, Z, th, 1e-6, kern, mode=0, want_grad=True, **kw)
     torch.cuda.synchronize()
     eng.lib.sgp_small_debug_stamps(C.c_void_p(0))
-    s = stamps.cpu().reshape(67, 16)
+    s = stamps.cpu().reshape(211, 16)
     t0 = int(s[0, 0])
     grow = min((N + 63) // 64, 64)
 
