@@ -27,6 +27,7 @@ struct GemmDesc {
   bool lower_only = false;
 };
 void gemm(const GemmDesc& g, hipStream_t st);
+double cond_gate_limit();   // sgp_set_cond_limit's current value (sgp_tail.hip): the explicit-inverse paths refuse above it
 int available_cus();       // CUs a launch of this host thread can occupy (device count, or the budget below)
 void set_cu_budget(int n);  // CUs the calling host thread's launches may occupy (CU-masked streams); 0 = all
 // the same product with the contraction cut into S slices (S * m * n doubles of scratch; falls back to gemm() when k is

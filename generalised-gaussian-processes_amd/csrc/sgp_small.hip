@@ -1217,35 +1217,39 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     // ---- slices: B = I + sum_g P_g / s2 (mirrored), u, scalars -- fixed order over g ---------------------------------
     {
       const double is2 = 1.0 / s2;
-      for (int e = rw * 256 + tid; e < NBL * 256; e += a.grow * 256) {
+      // 64 matrix entries per workgroup and pass; the four waves split the partials of an entry (g = wave, wave + 4, ...: with
+      // up to 208 row workgroups one thread walking them all was 13 dependent batches of loads on 36 of the workgroups while
+      // the others idled) and combine through LDS in a fixed order -- bit-reproducible for a given launch geometry
+      const int el = tid & 63;
+      for (int e0 = rw * 64; e0 < NBL * 256; e0 += a.grow * 64) {
+        const int e = e0 + el;
         const int b = e >> 8, i = (e >> 4) & 15, j = e & 15;
         int bi = 0;
         while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
         const int bj = b - bi * (bi + 1) / 2;
         const int gi = 16 * bi + i, gj = 16 * bj + j;
-        if (gi < gj) continue;  // upper half of a diagonal block
+        const bool live = e < NBL * 256 && gi >= gj;  // not the upper half of a diagonal block
         double s = 0.0;
-        const double* pp = a.Ppart + (size_t)gi * MP + gj;
-        int g = 0;
-        for (; g + 16 <= a.grow; g += 16) {  // sixteen loads in flight; the additions keep the fixed order
-          double t[16];
+        if (live) {
+          const double* pp = a.Ppart + (size_t)gi * MP + gj;
+          for (int g = w; g < a.grow; g += 64) {  // sixteen loads in flight; the additions keep the fixed order
+            double t[16];
 #pragma unroll
-          for (int k = 0; k < 16; ++k) t[k] = pp[(size_t)(g + k) * MP * MP];
+            for (int k = 0; k < 16; ++k) t[k] = g + 4 * k < a.grow ? pp[(size_t)(g + 4 * k) * MP * MP] : 0.0;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) s += t[k];
+            for (int k = 0; k < 16; ++k) s += t[k];
+          }
         }
-        {
-          double t[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) t[k] = g + k < a.grow ? pp[(size_t)(g + k) * MP * MP] : 0.0;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) s += t[k];
+        sl.red[w][el] = s;
+        __syncthreads();
+        if (w == 0 && live) {
+          const double v = (gi == gj ? 1.0 : 0.0) + ((sl.red[0][el] + sl.red[1][el]) + (sl.red[2][el] + sl.red[3][el])) * is2;
+          a.Bm[(size_t)gi * MP + gj] = v;
+          a.Bm[(size_t)gj * MP + gi] = v;
+          a.Lb[(size_t)gi * MP + gj] = v;  // factored in place by the chain (only the lower triangle is read)
+          a.Lb[(size_t)gj * MP + gi] = v;
         }
-        const double v = (gi == gj ? 1.0 : 0.0) + s * is2;
-        a.Bm[(size_t)gi * MP + gj] = v;
-        a.Bm[(size_t)gj * MP + gi] = v;
-        a.Lb[(size_t)gi * MP + gj] = v;  // factored in place by the chain (only the lower triangle is read)
-        a.Lb[(size_t)gj * MP + gi] = v;
+        __syncthreads();
       }
       if (rw == 0) {
         if (tid < MP) {

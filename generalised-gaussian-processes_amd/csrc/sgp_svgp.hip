@@ -773,6 +773,156 @@ static SvgpBatchWs carve_svgp_batch(void* ws, int Mp, int Bp, int M, int d, int 
   return w;
 }
 
+
+// =====================================================================================================================
+// Mixture posterior predictive: the collapsed bound's predictive at S hyper-parameter samples in ONE chain of launches
+// (sgp_mixture_predict) -- SURVEY section 8 f-2 "batched over S samples"; the reference recomputes everything per sample in a
+// Python loop (models/bayesian_sgpr_hmc.py:198-231).  Same machinery as the batched SVGP bound above (sample index in
+// blockIdx.y, two-level batched GEMMs, S factorizations per dataflow launch), PyMC3 op order per sample:
+//   L = chol(Kuu + J I), A = L^-1 K_uf, B = I + A A^T / s2, L_B = chol(B), q = L_B^-1 A y,
+//   A* = L^-1 K_u*, C* = L_B^-1 A*:  mean = C*^T q / s2,  var = k** - colsum(A* o A*) + colsum(C* o C*) (+ s2),
+//   cov = K** - A*^T A* + C*^T C* (+ s2 I)          [models/sgpr.py:256-286 algebra]
+// =====================================================================================================================
+// u[s][m] (+)= sum_t A[s][m][t] y[t]   (one wave per row; rows >= Mp never launched)
+__global__ __launch_bounds__(256) void mix_rowsdot_kernel(const double* __restrict__ A, int Mp, int Tp, int Tn, const double* __restrict__ y,
+                                                          int accumulate, double* __restrict__ u) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= Mp) return;
+  A += (int64_t)blockIdx.y * Mp * Tp;
+  u += (int64_t)blockIdx.y * Mp;
+  double s = 0.0;
+  for (int t = lane; t < Tn; t += 64) s = fma(A[(int64_t)row * Tp + t], y[t], s);
+  s = wave_sum(s);
+  if (lane == 0) u[row] = accumulate ? u[row] + s : s;
+}
+// Bm[s] = I + W[s] / s2[s]
+__global__ __launch_bounds__(256) void mix_bmat_kernel(const double* __restrict__ W, SvgpThetaS th, int Mp, double* __restrict__ Bm) {
+  const int64_t total = (int64_t)Mp * Mp, off = (int64_t)blockIdx.y * total;
+  const double is2 = 1.0 / th.s2[blockIdx.y];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    Bm[off + e] = (r == c ? 1.0 : 0.0) + W[off + e] * is2;
+  }
+}
+// after chol(Kuu): conditioning gate (sgp_tail.hip: cond_gate_kernel; trace(Kuu) = M (sf2 + J) for a stationary kernel);
+// after chol(B): a failure there is reported as M + pivot (only into a status word that is still 0)
+__global__ void mix_status_kernel(const double* __restrict__ L, int Mp, int M, SvgpThetaS th, double jitter, double limit, int* __restrict__ info,
+                                  const int* __restrict__ infoB, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  if (infoB) {
+    if (info[s] == 0 && infoB[s] != 0) info[s] = infoB[s] < 0 ? infoB[s] : M + infoB[s];
+    return;
+  }
+  if (info[s] != 0 || !(limit > 0.0)) return;
+  const double* Ls = L + (int64_t)s * Mp * Mp;
+  double lo = 1e300;
+  int at = 0;
+  for (int i = 0; i < M; ++i) {
+    const double v = Ls[(int64_t)i * Mp + i];
+    if (v < lo) { lo = v; at = i; }
+  }
+  if (!((double)M * (th.ka[s].sf2 + jitter) <= limit * lo * lo)) info[s] = at + 1;
+}
+// q[s] = LBinv[s] u[s]   (lower triangular, one wave per row)
+__global__ __launch_bounds__(256) void mix_trmv_kernel(const double* __restrict__ Li, int Mp, const double* __restrict__ u, double* __restrict__ q) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= Mp) return;
+  Li += (int64_t)blockIdx.y * Mp * Mp;
+  u += (int64_t)blockIdx.y * Mp;
+  double s = 0.0;
+  for (int j = lane; j <= row; j += 64) s = fma(Li[(int64_t)row * Mp + j], u[j], s);
+  s = wave_sum(s);
+  if (lane == 0) q[(int64_t)blockIdx.y * Mp + row] = s;
+}
+// mean[s][t] = sum_m C[m][t] q[m] / s2 ; var[s][t] = sf2 - sum A^2 + sum C^2 (+ s2)      (pred_cols_kernel per sample)
+__global__ __launch_bounds__(256) void mix_pred_cols_kernel(const double* __restrict__ As, const double* __restrict__ Cm,
+                                                            const double* __restrict__ q, int Mp, int Tp, int Tn, SvgpThetaS th, int pred_noise,
+                                                            int64_t T, double* __restrict__ mean, double* __restrict__ var) {
+  __shared__ double pm[4][64], pa[4][64], pc[4][64];
+  const int64_t off = (int64_t)blockIdx.y * Mp * Tp;
+  As += off; Cm += off; q += (int64_t)blockIdx.y * Mp;
+  const double sf2 = th.ka[blockIdx.y].sf2, s2 = th.s2[blockIdx.y];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  double sm = 0.0, sa = 0.0, scc = 0.0;
+  for (int m = w; m < Mp; m += 4) {
+    const double a = As[(int64_t)m * Tp + col], c = Cm[(int64_t)m * Tp + col];
+    sm = fma(c, q[m], sm);
+    sa = fma(a, a, sa);
+    scc = fma(c, c, scc);
+  }
+  pm[w][threadIdx.x & 63] = sm; pa[w][threadIdx.x & 63] = sa; pc[w][threadIdx.x & 63] = scc;
+  __syncthreads();
+  if (w == 0 && col < Tn) {
+    const int l = threadIdx.x;
+    mean[(int64_t)blockIdx.y * T + col] = (pm[0][l] + pm[1][l] + pm[2][l] + pm[3][l]) / s2;
+    if (var)
+      var[(int64_t)blockIdx.y * T + col] = sf2 - (pa[0][l] + pa[1][l] + pa[2][l] + pa[3][l]) + (pc[0][l] + pc[1][l] + pc[2][l] + pc[3][l]) +
+                                          (pred_noise ? s2 : 0.0);
+  }
+}
+// cov[s][t][t'] = k(xs_t, xs_t') - AtA[t][t'] + CtC[t][t'] (+ s2 on the diagonal) ; gate (Tp x Tp, optional) = cov + gate_jitter I
+// padded with the identity: the input of the reference's PSD gate cholesky(cov + 1e-4 I), factored in place afterwards
+template <int KID>
+__global__ __launch_bounds__(256) void mix_pred_cov_kernel(const double* __restrict__ Xs, int64_t ldxs, SvgpThetaS th, const double* __restrict__ AtA,
+                                                           const double* __restrict__ CtC, int Tp, int T, int pred_noise, double gate_jitter,
+                                                           double* __restrict__ cov, double* __restrict__ gate) {
+  const KernArgs& ka = th.ka[blockIdx.y];
+  const double s2 = th.s2[blockIdx.y];
+  const int64_t total = (int64_t)Tp * Tp, offp = (int64_t)blockIdx.y * total;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / Tp), j = (int)(e - (int64_t)i * Tp);
+    double v = (i == j) ? 1.0 : 0.0, g = v;
+    if (i < T && j < T) {
+      double r2 = 0.0;
+      for (int q = 0; q < ka.d; ++q) {
+        const double df = (Xs[i * ldxs + q] - Xs[j * ldxs + q]) * ka.inv_ls[q];
+        r2 = fma(df, df, r2);
+      }
+      v = ka.sf2 * kprofile<KID>(r2) - AtA[offp + e] + CtC[offp + e];
+      if (i == j && pred_noise) v += s2;
+      cov[(int64_t)blockIdx.y * T * T + (int64_t)i * T + j] = v;
+      g = (i == j) ? v + gate_jitter : v;
+    }
+    if (gate) gate[offp + e] = g;
+  }
+}
+
+struct MixWs {
+  double *Kp, *Linv, *tmp, *W, *Bm, *LBinv, *u, *q, *Ks, *As, *Cm, *AtA, *CtC, *gate;
+  int *infoB, *flags, *gflags;
+  size_t bytes;
+};
+static int64_t mix_chunk(int64_t n) { return n < 8192 ? round_up64(n > 0 ? n : 1, 64) : 8192; }
+static MixWs carve_mix(void* ws, int Mp, int64_t Cc, int64_t Tp, int S, bool want_cov, bool want_gate) {
+  Carver c(ws);
+  MixWs w{};
+  const size_t mm = (size_t)Mp * Mp;
+  w.Kp = c.take<double>(S * mm);
+  w.Linv = c.take<double>(S * mm);
+  w.tmp = c.take<double>(S * mm);
+  w.W = c.take<double>(S * mm);
+  w.Bm = c.take<double>(S * mm);
+  w.LBinv = c.take<double>(S * mm);
+  w.u = c.take<double>((size_t)S * Mp);
+  w.q = c.take<double>((size_t)S * Mp);
+  w.Ks = c.take<double>((size_t)S * Mp * Cc);
+  w.As = c.take<double>((size_t)S * Mp * Cc);
+  w.Cm = c.take<double>((size_t)S * Mp * Cc);
+  if (want_cov) {
+    w.AtA = c.take<double>((size_t)S * Tp * Tp);
+    w.CtC = c.take<double>((size_t)S * Tp * Tp);
+    if (want_gate) {
+      w.gate = c.take<double>((size_t)S * Tp * Tp);
+      w.gflags = c.take<int>((size_t)S * potrf_scratch_ints((int)Tp));
+    }
+  }
+  w.infoB = c.take<int>(64);
+  w.flags = c.take<int>((size_t)S * potrf_scratch_ints(Mp));
+  w.bytes = c.used();
+  return w;
+}
+
 }  // namespace sgp
 
 using namespace sgp;
@@ -1018,6 +1168,125 @@ extern "C" int sgp_svgp_batch_combine(int S, const double* weights, int M, int d
   const int64_t total = (int64_t)M + (int64_t)M * M + (int64_t)M * d + (int64_t)S * (d + 2);
   svgp_combine_kernel<<<grid_for_s(total), 256, 0, (hipStream_t)stream>>>(wt, S, M, d, g_m, g_LS, g_Z, g_ls, g_sf2, g_s2, gm_out, gLS_out,
                                                                           gZ_out, gtheta_out);
+  return check_launch();
+}
+
+extern "C" size_t sgp_mixture_predict_workspace_bytes(int64_t N, int64_t T, int M, int d, int S, int want_cov, int want_gate) {
+  if (N < 1 || T < 1 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || S < 1 || S > SVGP_MAX_S) return 0;
+  if (want_cov && T > 8192) return 0;
+  const int64_t Tp = round_up64(T, 64);
+  const int64_t Cc = want_cov ? (Tp > mix_chunk(N) ? Tp : mix_chunk(N)) : (mix_chunk(N) > mix_chunk(T) ? mix_chunk(N) : mix_chunk(T));
+  return carve_mix(nullptr, padded_m(M), Cc, Tp, S, want_cov != 0, want_gate != 0).bytes;
+}
+
+extern "C" int sgp_mixture_predict(const double* X, int64_t ldx, const double* y, int64_t N, const double* Xs, int64_t ldxs, int64_t T,
+                                   const double* Z, int64_t ldz, int S, const double* inv_ls, const double* sf2, const double* s2,
+                                   double jitter, int M, int d, int kernel_id, int pred_noise, double gate_jitter, double* mean,
+                                   double* var, double* cov, int* info, int* gate_info, void* ws, size_t ws_bytes,
+                                   sgp_stream_t stream) {
+  if (!X || !y || !Xs || !Z || !inv_ls || !sf2 || !s2 || !mean || !info || N < 1 || T < 1 || M <= 0 || d <= 0 || ldx < d || ldxs < d || ldz < d)
+    return SGP_ERR_ARG;
+  if (S < 1 || S > SVGP_MAX_S || kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52) return SGP_ERR_ARG;
+  if (gate_info && !cov) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || (cov && T > 8192)) return SGP_ERR_DIM;
+  SvgpThetaS th{};
+  for (int s = 0; s < S; ++s) {
+    if (!(s2[s] > 0.0) || !(sf2[s] > 0.0)) return SGP_ERR_ARG;
+    th.ka[s] = make_ka_s(inv_ls + (size_t)s * d, sf2[s], d);
+    th.s2[s] = s2[s];
+  }
+  const int Mp = padded_m(M);
+  const int64_t Tp = round_up64(T, 64);
+  const bool want_cov = cov != nullptr, want_gate = gate_info != nullptr;
+  const int64_t Cc = want_cov ? (Tp > mix_chunk(N) ? Tp : mix_chunk(N)) : (mix_chunk(N) > mix_chunk(T) ? mix_chunk(N) : mix_chunk(T));
+  MixWs w = carve_mix(ws, Mp, Cc, Tp, S, want_cov, want_gate);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t mm = (int64_t)Mp * Mp;
+  const int gmm = grid_for_s(mm);
+  auto gemm_s = [&](GemmDesc g, int64_t sa, int64_t sb, int64_t sc) {
+    g.batch2 = S; g.s2A = sa; g.s2B = sb; g.s2C = sc;
+    gemm(g, st);
+  };
+  auto kmat = [&](const double* P, int64_t ldp, int n, int np, double* out) {  // K(Z, P) for every sample: Mp x np, zero padded
+    const dim3 grid(grid_for_s((int64_t)Mp * np), S);
+    switch (kernel_id) {
+      case SGP_KERNEL_RBF: svgp_kub_batch_kernel<SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Z, ldz, P, ldp, th, M, Mp, n, np, out); break;
+      case SGP_KERNEL_MATERN32: svgp_kub_batch_kernel<SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Z, ldz, P, ldp, th, M, Mp, n, np, out); break;
+      default: svgp_kub_batch_kernel<SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Z, ldz, P, ldp, th, M, Mp, n, np, out); break;
+    }
+  };
+
+  // ---- train side: L, L^-1, W = A A^T, u = A y over row chunks, B, L_B^-1, q -------------------------------------------
+  zero_ints(info, S, st);
+  switch (kernel_id) {
+    case SGP_KERNEL_RBF: svgp_kuu_batch_kernel<SGP_KERNEL_RBF><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+    case SGP_KERNEL_MATERN32: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN32><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+    default: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
+  }
+  potrf_lower_batch(w.Kp, w.Linv, Mp, Mp, S, mm, info, w.flags, st);
+  mix_status_kernel<<<1, 64, 0, st>>>(w.Kp, Mp, M, th, jitter, cond_gate_limit(), info, nullptr, S);
+  tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st, S, mm);
+  const int64_t Nc = mix_chunk(N);
+  for (int64_t t0 = 0; t0 < N; t0 += Nc) {
+    const int Tn = (int)((N - t0) < Nc ? (N - t0) : Nc);
+    const int Np = (int)round_up64(Tn, 64);
+    const int64_t mb = (int64_t)Mp * Np;
+    kmat(X + t0 * ldx, ldx, Tn, Np, w.Ks);
+    GemmDesc a;  // A = L^-1 K_uf
+    a.A = w.Linv; a.lda = Mp; a.B = w.Ks; a.ldb = Np; a.C = w.As; a.ldc = Np;
+    a.m = Mp; a.n = Np; a.k = Mp; a.khi_mask = 1;
+    gemm_s(a, mm, mb, mb);
+    GemmDesc ww;  // W (+)= A A^T
+    ww.A = w.As; ww.lda = Np; ww.B = w.As; ww.ldb = Np; ww.tb = true; ww.C = w.W; ww.ldc = Mp;
+    ww.m = Mp; ww.n = Mp; ww.k = Np; ww.beta = t0 > 0 ? 1.0 : 0.0;
+    gemm_s(ww, mb, mb, mm);
+    mix_rowsdot_kernel<<<dim3(Mp / 4, S), 256, 0, st>>>(w.As, Mp, Np, Tn, y + t0, t0 > 0 ? 1 : 0, w.u);
+  }
+  mix_bmat_kernel<<<dim3(gmm, S), 256, 0, st>>>(w.W, th, Mp, w.Bm);
+  zero_ints(w.infoB, S, st);
+  potrf_lower_batch(w.Bm, w.LBinv, Mp, Mp, S, mm, w.infoB, w.flags, st);
+  mix_status_kernel<<<1, 64, 0, st>>>(nullptr, Mp, M, th, jitter, 0.0, info, w.infoB, S);
+  tri_inverse(w.Bm, w.LBinv, w.tmp, Mp, Mp, st, S, mm);
+  mix_trmv_kernel<<<dim3(Mp / 4, S), 256, 0, st>>>(w.LBinv, Mp, w.u, w.q);
+
+  // ---- test side ------------------------------------------------------------------------------------------------------
+  const int64_t Tc = want_cov ? Tp : mix_chunk(T);
+  for (int64_t t0 = 0; t0 < T; t0 += Tc) {
+    const int Tn = (int)((T - t0) < Tc ? (T - t0) : Tc);
+    const int Tq = (int)round_up64(Tn, 64);
+    const int64_t mb = (int64_t)Mp * Tq;
+    const double* xs = Xs + t0 * ldxs;
+    kmat(xs, ldxs, Tn, Tq, w.Ks);
+    GemmDesc a;  // A* = L^-1 K_u*
+    a.A = w.Linv; a.lda = Mp; a.B = w.Ks; a.ldb = Tq; a.C = w.As; a.ldc = Tq;
+    a.m = Mp; a.n = Tq; a.k = Mp; a.khi_mask = 1;
+    gemm_s(a, mm, mb, mb);
+    GemmDesc b;  // C* = L_B^-1 A*
+    b.A = w.LBinv; b.lda = Mp; b.B = w.As; b.ldb = Tq; b.C = w.Cm; b.ldc = Tq;
+    b.m = Mp; b.n = Tq; b.k = Mp; b.khi_mask = 1;
+    gemm_s(b, mm, mb, mb);
+    mix_pred_cols_kernel<<<dim3(Tq / 64, S), 256, 0, st>>>(w.As, w.Cm, w.q, Mp, Tq, Tn, th, pred_noise, T, mean + t0, var ? var + t0 : nullptr);
+    if (want_cov) {  // one chunk: Tc = Tp
+      const int64_t tt = (int64_t)Tq * Tq;
+      GemmDesc x;
+      x.A = w.As; x.lda = Tq; x.ta = true; x.B = w.As; x.ldb = Tq; x.C = w.AtA; x.ldc = Tq;
+      x.m = Tq; x.n = Tq; x.k = Mp;
+      gemm_s(x, mb, mb, tt);
+      GemmDesc yv;
+      yv.A = w.Cm; yv.lda = Tq; yv.ta = true; yv.B = w.Cm; yv.ldb = Tq; yv.C = w.CtC; yv.ldc = Tq;
+      yv.m = Tq; yv.n = Tq; yv.k = Mp;
+      gemm_s(yv, mb, mb, tt);
+      const dim3 gc(grid_for_s(tt), S);
+      switch (kernel_id) {
+        case SGP_KERNEL_RBF: mix_pred_cov_kernel<SGP_KERNEL_RBF><<<gc, 256, 0, st>>>(xs, ldxs, th, w.AtA, w.CtC, Tq, Tn, pred_noise, gate_jitter, cov, w.gate); break;
+        case SGP_KERNEL_MATERN32: mix_pred_cov_kernel<SGP_KERNEL_MATERN32><<<gc, 256, 0, st>>>(xs, ldxs, th, w.AtA, w.CtC, Tq, Tn, pred_noise, gate_jitter, cov, w.gate); break;
+        default: mix_pred_cov_kernel<SGP_KERNEL_MATERN52><<<gc, 256, 0, st>>>(xs, ldxs, th, w.AtA, w.CtC, Tq, Tn, pred_noise, gate_jitter, cov, w.gate); break;
+      }
+      if (want_gate) zero_ints(gate_info, S, st);
+      if (want_gate) potrf_lower_batch(w.gate, nullptr, Tq, Tq, S, tt, gate_info, w.gflags, st);  // the reference's PSD gate, S at a time
+    }
+  }
   return check_launch();
 }
 

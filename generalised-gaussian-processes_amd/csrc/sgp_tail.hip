@@ -602,6 +602,7 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
 // cond-1e15 point: the diagonal of K is 2e6 while lambda_max is 1e9.)  The single-launch path (M <= 128, substitution solves)
 // is not gated: it tracks LAPACK.
 static double g_cond_limit = 1e13;
+double sgp::cond_gate_limit() { return g_cond_limit; }
 __global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ K, const double* __restrict__ L, int64_t ld, int M,
                                                         double limit, int* info) {
   __shared__ double smin[256], str[256];

@@ -585,6 +585,44 @@ class HipEngine:
         _lib.check("sgp_svgp_batch_combine", st)
         return gm, gLS, gZ, gth
 
+    MIXTURE_BATCH = 8  # hyper-parameter samples per sgp_mixture_predict call
+
+    def mixture_predict(self, X, y, Xs, Z, ls, sf2, s2, jitter=1e-6, kernel="rbf", pred_noise=True, full_cov=False, gate_jitter=None):
+        """Predictive of the collapsed bound at S hyper-parameter samples (ls: S x d, sf2, s2: S host sequences), eight samples
+        per chain of launches.  Returns dict(mean [S, T], var [S, T], cov [S, T, T] or None, info [S] int32, gate [S] int32 or
+        None: status of cholesky(cov + gate_jitter I), the reference's PSD gate) -- device tensors, nothing synchronised."""
+        import ctypes
+        N, d = X.shape
+        T = Xs.shape[0]
+        M = Z.shape[0]
+        for t, n in ((X, "X"), (y, "y"), (Xs, "Xs"), (Z, "Z")):
+            self._chk(t, n)
+        lsv = [[float(v) for v in row] for row in ls]
+        S = len(lsv)
+        if any(len(row) != d for row in lsv) or len(sf2) != S or len(s2) != S:
+            raise ValueError("ls must be S x d, sf2 and s2 of length S")
+        want_gate = full_cov and gate_jitter is not None
+        mean, var = self.empty(S, T), self.empty(S, T)
+        cov = self.empty(S, T, T) if full_cov else None
+        info = torch.empty(S, dtype=torch.int32, device=self.device)
+        gate = torch.empty(S, dtype=torch.int32, device=self.device) if want_gate else None
+        for s0 in range(0, S, self.MIXTURE_BATCH):
+            n = min(self.MIXTURE_BATCH, S - s0)
+            nbytes = self.lib.sgp_mixture_predict_workspace_bytes(N, T, M, d, n, 1 if full_cov else 0, 1 if want_gate else 0)
+            if nbytes == 0:
+                raise ValueError("unsupported mixture-predictive shape N=%d T=%d M=%d d=%d (full covariance needs T <= 8192)" % (N, T, M, d))
+            ws = self._workspace("mixture", nbytes)
+            inv = (ctypes.c_double * (n * d))(*[1.0 / v for row in lsv[s0:s0 + n] for v in row])
+            sf2c = (ctypes.c_double * n)(*[float(v) for v in sf2[s0:s0 + n]])
+            s2c = (ctypes.c_double * n)(*[float(v) for v in s2[s0:s0 + n]])
+            st = self.lib.sgp_mixture_predict(
+                self._ptr(X), d, self._ptr(y), N, self._ptr(Xs), d, T, self._ptr(Z), d, n, inv, sf2c, s2c, float(jitter), M, d,
+                _kernel_id(kernel), 1 if pred_noise else 0, float(gate_jitter) if want_gate else 0.0, self._ptr(mean[s0:]), self._ptr(var[s0:]),
+                self._ptr(cov[s0:]) if full_cov else None, C.c_void_p(info[s0:].data_ptr()),
+                C.c_void_p(gate[s0:].data_ptr()) if want_gate else None, self._ptr(ws), ws.numel(), self._stream())
+            _lib.check("sgp_mixture_predict", st)
+        return {"mean": mean, "var": var, "cov": cov, "info": info, "gate": gate}
+
     def svgp_predict(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
         T, d = Xs.shape
         M = Z.shape[0]

@@ -250,9 +250,55 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
                 [trace_hyper.get_sampler_stats('perf_counter_diff').sum()])
 
 
+def _mixture_batched(model, test_x, trace_hyper):
+    """The same list of predictives from sgp_mixture_predict: eight theta samples per chain of launches, the PSD gate
+    cholesky(cov + 1e-4 I) of all of them in one dataflow launch, ONE status copy for the whole trace.
+    Returns None when the batched call does not apply (test double, several ranks, composite kernels, T beyond the full-
+    covariance limit, ``model.batched_mixture = False``): the caller then runs the reference's per-sample loop."""
+    b = model._bound()
+    e = b.engine
+    if (not getattr(model, "batched_mixture", True) or not hasattr(e, "mixture_predict") or b.world != 1 or b.kernel == "composite"
+            or len(trace_hyper) == 0):
+        return None
+    tx = test_x[:, None] if test_x.dim() == 1 else test_x
+    if tx.shape[0] > FULL_COV_MAX_T or tx.shape[0] > 8192:
+        return None
+    S = len(trace_hyper)
+    ls = [np.asarray(trace_hyper[i]['ls'], dtype=np.float64).reshape(-1) for i in range(S)]
+    d = b.d
+    ls = [np.repeat(v, d) if v.size == 1 and d > 1 else v for v in ls]
+    sf2 = [float(trace_hyper[i]['sig_f']) ** 2 for i in range(S)]
+    s2 = [float(trace_hyper[i]['sig_n']) ** 2 for i in range(S)]
+    Xs = tx.detach().to(dtype=torch.float64, device=e.device).contiguous()
+    with torch.no_grad():
+        r = e.mixture_predict(b.X, b.y, Xs, b._prep_Z(model.covar_module.inducing_points), ls, sf2, s2, jitter=b.jitter, kernel=b.kernel,
+                              pred_noise=True, full_cov=True, gate_jitter=1e-4)
+        status = torch.stack([r["info"], r["gate"]]).to("cpu")  # the one host round trip of the whole mixture
+    # the loop leaves the model at the last sample's hyper-parameters (models/bayesian_sgpr_hmc.py:206-208): so does this
+    last = trace_hyper[S - 1]
+    model.likelihood.noise_covar.noise = last['sig_n'] ** 2
+    model.base_covar_module.outputscale = last['sig_f'] ** 2
+    model.base_covar_module.base_kernel.lengthscale = last['ls']
+    model.eval()
+    model.likelihood.eval()
+    preds = []
+    for i in range(S):
+        info, gate = int(status[0, i]), int(status[1, i])
+        if info < 0 or gate < 0:
+            raise SgpTimeoutError()
+        if info != 0 or gate != 0:
+            print('Not psd for sample ' + str(i))
+            continue
+        preds.append(MultivariateNormal(r["mean"][i], r["cov"][i], variance=r["var"][i], engine=e))
+    return preds
+
+
 def mixture_posterior_predictive(model, test_x, trace_hyper):
     """One predictive per theta sample; samples whose predictive covariance fails the reference's PSD gate
     (cholesky(cov + 1e-4 I)) are skipped, never raised (reference models/bayesian_sgpr_hmc.py:198-231)."""
+    batched = _mixture_batched(model, test_x, trace_hyper)
+    if batched is not None:
+        return batched
     preds = []
     for i in range(len(trace_hyper)):
         hyper_sample = trace_hyper[i]

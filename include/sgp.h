@@ -410,6 +410,20 @@ int sgp_svgp_elbo_batch_reverse(const double* Xb, int64_t ldx, const double* yb,
 int sgp_svgp_batch_combine(int S, const double* weights, int M, int d, const double* g_m, const double* g_LS, const double* g_Z,
                            const double* g_ls, const double* g_sf2, const double* g_s2, double* gm_out, double* gLS_out,
                            double* gZ_out, double* gtheta_out, sgp_stream_t stream);
+/* ---- mixture posterior predictive of the collapsed bound: S hyper-parameter samples per chain of launches (S <= 8) -----------
+ * mixture_posterior_predictive(model, test_x, trace_hyper) of models/bayesian_sgpr_hmc.py:198-231 evaluates one full
+ * predictive per theta sample in a Python loop; here the S samples ride in the launch grid.  PyMC3 op
+ * order per sample (A = L^-1 K_uf, B = I + A A^T / s2); stationary kernels; X, y: ALL training rows (single rank).
+ *   inv_ls (S x d), sf2 (S), s2 (S): HOST arrays;   mean, var (S x T; var may be NULL), cov (S x T x T or NULL; T <= 8192): DEVICE
+ *   info (S ints): 0, 1..M (K_uu, incl. the conditioning gate of sgp_set_cond_limit), M+1..2M (B)
+ *   gate_info (S ints or NULL, needs cov): status of cholesky(cov + gate_jitter I) per sample -- the reference's PSD gate
+ *   (cov + 1e-4 I, :225-229) for all S samples in one dataflow launch; 0 = positive definite.                              */
+size_t sgp_mixture_predict_workspace_bytes(int64_t N, int64_t T, int M, int d, int S, int want_cov, int want_gate);
+int sgp_mixture_predict(const double* X, int64_t ldx, const double* y, int64_t N, const double* Xs, int64_t ldxs, int64_t T,
+                        const double* Z, int64_t ldz, int S, const double* inv_ls, const double* sf2, const double* s2,
+                        double jitter, int M, int d, int kernel_id, int pred_noise, double gate_jitter,
+                        double* mean, double* var, double* cov, int* info, int* gate_info,
+                        void* ws, size_t ws_bytes, sgp_stream_t stream);
 /* latent predictive mean / variance of q(f*) at T rows (models/svgp.py:132-141 continues through the likelihood) */
 int sgp_svgp_predict(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, const double* inv_ls,
                      double sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,

@@ -818,3 +818,50 @@ def test_conditioning_gate_of_the_explicit_inverse_path(engine):
     assert lp == -math.inf
     lp2, _ = tgt.logp_and_grad([math.log(0.5), 0.0, math.log(0.1)])
     assert math.isfinite(lp2)
+
+
+@pytest.mark.gpu
+def test_mixture_predictive_batched_over_the_samples(engine):
+    """sgp_mixture_predict (row f-2: eight theta samples per chain of launches, PSD gates in one dataflow launch) against the
+    oracle's predictive sample by sample, against the per-sample loop of the reference (model.batched_mixture = False), with
+    N > 8192 (two row chunks of the train side), T not a multiple of 64, 11 samples (two batches) and one sample whose K_uu is
+    hopeless (amplitude 3e3 against the 1e-6 jitter): both paths drop exactly that one."""
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    from ggp_amd.hmc import Trace
+    g = torch.Generator().manual_seed(8)
+    N, M, T, d = 9000, 70, 333, 3
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X[:, 0]) * torch.cos(X[:, 1]) + 0.3 * X[:, 2] + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Xt = torch.randn(T, d, dtype=torch.float64, generator=g)
+    Z0 = X[torch.randperm(N, generator=g)[:M]].clone()
+    Xd, yd, Xtd, Zd = X.to(engine.device), y.to(engine.device), Xt.to(engine.device), Z0.to(engine.device)
+    rows = [{"ls": np.array([0.9 + 0.05 * i, 1.2 - 0.03 * i, 1.5]), "sig_f": 1.0 + 0.05 * i, "sig_n": 0.3 + 0.02 * i} for i in range(11)]
+    rows[4] = {"ls": np.array([30.0, 30.0, 30.0]), "sig_f": 3.0e3, "sig_n": 0.3}
+    for kern, kid in (("rbf", 0), ("matern32", 1)):
+        r = engine.mixture_predict(Xd, yd, Xtd, Zd, [q["ls"] for q in rows], [q["sig_f"] ** 2 for q in rows], [q["sig_n"] ** 2 for q in rows],
+                                   jitter=1e-6, kernel=kern, full_cov=True, gate_jitter=1e-4)
+        info, gate = r["info"].cpu().tolist(), r["gate"].cpu().tolist()
+        assert [i for i, v in enumerate(info) if v != 0] == [4] and 1 <= info[4] <= M
+        for i in (0, 7, 8, 10):  # first / last of both batches
+            q = rows[i]
+            mu, cov = O.predict(Xt, X, y, Z0, torch.as_tensor(q["ls"]), q["sig_f"] ** 2, q["sig_n"] ** 2, 1e-6, kernel_id=kid, full_cov=True)
+            assert float((r["mean"][i].cpu() - mu).abs().max()) < 1e-8
+            assert float((r["cov"][i].cpu() - cov).abs().max()) < 1e-8
+            assert float((r["var"][i].cpu() - torch.diagonal(cov)).abs().max()) < 1e-8
+            assert gate[i] == 0
+        val = engine.mixture_predict(Xd, yd, Xtd, Zd, [q["ls"] for q in rows], [q["sig_f"] ** 2 for q in rows], [q["sig_n"] ** 2 for q in rows],
+                                     jitter=1e-6, kernel=kern)
+        assert val["cov"] is None and torch.equal(val["mean"][0], r["mean"][0]) and torch.equal(val["var"][10], r["var"][10])
+    # the model-level list of predictives, batched and in the reference's loop
+    model = ggp_amd.BayesianSparseGPR_HMC(Xd, yd, ggp_amd.GaussianLikelihood(), Z0, engine=engine, jitter=1e-6)
+    trace = Trace(rows, {"step_size": np.zeros(len(rows))})
+    pb = ggp_amd.mixture_posterior_predictive(model, Xtd, trace)
+    assert abs(float(model.likelihood.noise) - rows[-1]["sig_n"] ** 2) < 1e-12      # left at the last sample, as the loop does
+    model.batched_mixture = False
+    pl = ggp_amd.mixture_posterior_predictive(model, Xtd, trace)
+    assert len(pb) == len(pl) == 10
+    for a, b in zip(pb, pl):
+        assert float((a.loc - b.loc).abs().max()) < 1e-8 and float((a.covariance_matrix - b.covariance_matrix).abs().max()) < 1e-8
+    yt = torch.sin(Xt[:, 0]) * torch.cos(Xt[:, 1]) + 0.3 * Xt[:, 2]
+    assert abs(ggp_amd.nlpd_mixture(pb, yt, torch.tensor([1.0])) - ggp_amd.nlpd_mixture(pl, yt, torch.tensor([1.0]))) < 1e-7

@@ -273,31 +273,38 @@ def test_batch_skip_path_keeps_every_workgroup_on_its_own_request(engine):
 
 
 @pytest.mark.gpu
-def test_small_launch_is_refused_when_its_workgroups_cannot_all_be_resident(engine):
-    """The single launch's workgroups wait for each other: with a CU budget (CU-masked stream) smaller than the grid the library
-    says so up front -- sgp_small_supported() = 0, the entry point returns SGP_ERR_LAUNCH -- instead of spinning into a time-out."""
+def test_small_launch_adapts_to_the_cu_budget_and_refuses_below_four(engine):
+    """The single launch's workgroups wait for each other, so all of them must be resident: its grid is cut to the CUs the calling
+    thread may use (sgp_set_cu_budget, for CU-masked streams) -- 7 slabs walked by ONE row workgroup at a budget of 4, same bound
+    and gradient to rounding -- and below 4 CUs (chain + two K_uu-adjoint + one row workgroup) the library says so up front:
+    sgp_small_supported() = 0, the entry point returns an error instead of spinning into a time-out."""
     import ctypes as C
     G = load_golden("rbf_d3_small")
     X, y, Z = dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine)
     N, d = G["X"].shape
     M = G["Z"].shape[0]
-    assert engine.small_supported(N, M, d, "rbf")
+    th = _theta(G, engine)
+    kn = KNAME[int(G["kernel_id"])]
+    o0, _, i0 = engine.small_eval(X, y, Z, th, float(G["jitter"]), kn, mode=0, want_grad=True)
+    assert int(i0.item()) == 0 and abs(float(o0[0]) - float(G["F"])) < 1e-9 * abs(float(G["F"]))
     ws = engine._small_ws(N, M, d)
     out = engine.empty(d + 5)
     info = torch.zeros(1, dtype=torch.int32, device=engine.device)
-    th = _theta(G, engine)
     try:
-        engine.lib.sgp_set_cu_budget(4)  # grid = 1 + 1 + ceil(400 / 64) = 9 workgroups
+        engine.lib.sgp_set_cu_budget(4)
+        assert engine.small_supported(N, M, d, "rbf")
+        o4, _, i4 = engine.small_eval(X, y, Z, th, float(G["jitter"]), kn, mode=0, want_grad=True)
+        assert int(i4.item()) == 0
+        assert float((o4[:d + 3] - o0[:d + 3]).abs().max()) < 1e-10 * float(o0[:d + 3].abs().max())
+        engine.lib.sgp_set_cu_budget(3)
         assert not engine.small_supported(N, M, d, "rbf")
         st = engine.lib.sgp_small_eval(engine._ptr(X), d, engine._ptr(y), engine._ptr(Z), d, engine._ptr(th), N, M, d, 0, 1e-6, 0, 1,
                                        engine._ptr(out), None, C.c_void_p(info.data_ptr()), engine._ptr(ws), ws.numel(), engine._stream())
         assert st in (-2, -4)  # SGP_ERR_DIM from the shape gate or SGP_ERR_LAUNCH from the launch check
-        engine.lib.sgp_set_cu_budget(16)
-        assert engine.small_supported(N, M, d, "rbf")
     finally:
         engine.lib.sgp_set_cu_budget(0)
-    o, _, i = engine.small_eval(X, y, Z, th, float(G["jitter"]), KNAME[int(G["kernel_id"])], mode=0, want_grad=True)
-    assert int(i.item()) == 0 and abs(float(o[0]) - float(G["F"])) < 1e-9 * abs(float(G["F"]))
+    o, _, i = engine.small_eval(X, y, Z, th, float(G["jitter"]), kn, mode=0, want_grad=True)
+    assert int(i.item()) == 0 and torch.equal(o[:d + 5], o0[:d + 5])
 
 
 @pytest.mark.gpu
