@@ -882,14 +882,26 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       return;
     }
     stamp(8);
-    if (tid < SM_GP) {
+    {
+      // slot = tid & 63 (< SM_GP), the four waves split the partials (g = w, w + 4, ...), eight loads in flight, combined
+      // through LDS in a fixed order: with 210 partials one thread per slot was 53 us of dependent loads at the very end
+      const int slot = tid & 63;
       double s = 0.0;
-      for (int g = 0; g < ngrad; ++g) s += a.gpart[(size_t)g * SM_GP + tid];
-      gsum[tid] = s;
+      if (slot < SM_GP) {
+#pragma unroll 8
+        for (int g = w; g < ngrad; g += 4) s += a.gpart[(size_t)g * SM_GP + slot];
+      }
+      __syncthreads();
+      double* red4 = reinterpret_cast<double*>(&sh.ch.df);  // 256 doubles of the factorization's tile scratch: free by now
+      static_assert(sizeof(DfShared) >= 256 * sizeof(double), "scratch for the gradient partial sums");
+      if (slot < SM_GP) red4[w * 64 + slot] = s;
+      __syncthreads();
+      if (tid < SM_GP) gsum[tid] = (red4[tid] + red4[64 + tid]) + (red4[128 + tid] + red4[192 + tid]);
     }
     if (a.want_gz && a.gZ) {
       for (int e = tid; e < M * d; e += 256) {
         double s = 0.0;
+#pragma unroll 8
         for (int g = 0; g < ngrad; ++g) s += a.gzpart[(size_t)g * MP * SM_MAXD + e];
         a.gZ[e] = s;
       }
@@ -1029,18 +1041,31 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     }
     ksum = wave_sum(ksum);
     if (lane == 0) sl.red[w][SM_MAXD] = ksum;
-    for (int j = 0; j < d; ++j) {
-      const double xj = sl.xs[nl][j];
-      double sj = 0.0;
+    // two dimensions per trip and four partial sums each: the 32-term sums were one dependent FMA chain per dimension followed
+    // by a dependent wave reduction -- at d = 18 (Elevator) that latency, not the arithmetic, was most of the contraction's 45 us.
+    // (xs / zs are zero beyond column d - 1 and have SM_MAXD + 1 columns: j + 1 = d reads zeros.)
+    for (int j = 0; j < d; j += 2) {
+      const double x0 = sl.xs[nl][j], x1 = sl.xs[nl][j + 1];
+      double p0[4] = {0.0, 0.0, 0.0, 0.0}, p1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int pb = 0; pb < NB16; ++pb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const double df = xj - sl.zs[16 * pb + 4 * s + l4][j];
-          sj = fma(E[pb][s] * df, df, sj);
+          const double* zr = &sl.zs[16 * pb + 4 * s + l4][j];
+          const double d0 = x0 - zr[0], d1 = x1 - zr[1];
+          p0[s] = fma(E[pb][s] * d0, d0, p0[s]);
+          p1[s] = fma(E[pb][s] * d1, d1, p1[s]);
         }
-      sj = wave_sum(sj);
-      if (lane == 0) sl.red[w][j] = -2.0 * hyp.inv_ls[j] * sj;  // d r2 / d ls_j = -2 df_j^2 / ls_j
+      double s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {  // the two wave reductions interleaved
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+      }
+      if (lane == 0) {
+        sl.red[w][j] = -2.0 * hyp.inv_ls[j] * s0;  // d r2 / d ls_j = -2 df_j^2 / ls_j
+        if (j + 1 < d) sl.red[w][j + 1] = -2.0 * hyp.inv_ls[j + 1] * s1;
+      }
     }
     __syncthreads();
     if (tid <= SM_MAXD && (tid < d || tid == SM_MAXD)) sl.acc[tid] += (sl.red[0][tid] + sl.red[1][tid]) + (sl.red[2][tid] + sl.red[3][tid]);
@@ -1254,17 +1279,18 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       if (rw == 0) {
         if (tid < MP) {
           double s = 0.0;
+#pragma unroll 8
           for (int g = 0; g < a.grow; ++g) s += a.upart[(size_t)g * MP + tid];
           a.u[tid] = s;
         }
-        if (tid == 0) {
-          double sa = 0.0, sy2 = 0.0;
-          for (int g = 0; g < a.grow; ++g) {
-            sa += a.spart[2 + 2 * g];
-            sy2 += a.spart[3 + 2 * g];
-          }
-          a.spart[0] = sa;
-          a.spart[1] = sy2;
+        // the two scalar sums over the row workgroups: one wave each, lanes stride the partials (with 208 of them one thread
+        // walking 416 dependent loads was 70 us on the critical path of chol(B)); fixed tree, bit-reproducible
+        if (w >= 2) {
+          const int which = w - 2;
+          double sv = 0.0;
+          for (int g = lane; g < a.grow; g += 64) sv += a.spart[2 + which + 2 * g];
+          sv = wave_sum(sv);
+          if (lane == 0) a.spart[which] = sv;
         }
       }
     }

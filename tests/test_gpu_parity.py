@@ -836,7 +836,9 @@ def test_mixture_predictive_batched_over_the_samples(engine):
     Xt = torch.randn(T, d, dtype=torch.float64, generator=g)
     Z0 = X[torch.randperm(N, generator=g)[:M]].clone()
     Xd, yd, Xtd, Zd = X.to(engine.device), y.to(engine.device), Xt.to(engine.device), Z0.to(engine.device)
-    rows = [{"ls": np.array([0.9 + 0.05 * i, 1.2 - 0.03 * i, 1.5]), "sig_f": 1.0 + 0.05 * i, "sig_n": 0.3 + 0.02 * i} for i in range(11)]
+    # lengthscales below the typical inducing-point spacing: K_uu well conditioned, so 1e-8 against the (streaming-order) oracle is
+    # a statement about the kernels, not about cond(K_uu) eps
+    rows = [{"ls": np.array([0.6 + 0.02 * i, 0.8 - 0.01 * i, 0.7]), "sig_f": 1.0 + 0.05 * i, "sig_n": 0.3 + 0.02 * i} for i in range(11)]
     rows[4] = {"ls": np.array([30.0, 30.0, 30.0]), "sig_f": 3.0e3, "sig_n": 0.3}
     for kern, kid in (("rbf", 0), ("matern32", 1)):
         r = engine.mixture_predict(Xd, yd, Xtd, Zd, [q["ls"] for q in rows], [q["sig_f"] ** 2 for q in rows], [q["sig_n"] ** 2 for q in rows],
