@@ -1245,22 +1245,38 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       // 64 matrix entries per workgroup and pass; the four waves split the partials of an entry (g = wave, wave + 4, ...: with
       // up to 208 row workgroups one thread walking them all was 13 dependent batches of loads on 36 of the workgroups while
       // the others idled) and combine through LDS in a fixed order -- bit-reproducible for a given launch geometry
+      // element space: the NBL x 256 entries of the lower blocks of B, then the MP entries of u = sum of the A y partials, then
+      // the two scalars (sum A o A, y^T y) -- every one of them a sum over the row workgroups' partials
       const int el = tid & 63;
-      for (int e0 = rw * 64; e0 < NBL * 256; e0 += a.grow * 64) {
+      constexpr int EB = NBL * 256, EU = EB + MP, ET = EU + 2;
+      for (int e0 = rw * 64; e0 < ET; e0 += a.grow * 64) {
         const int e = e0 + el;
-        const int b = e >> 8, i = (e >> 4) & 15, j = e & 15;
-        int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-        const int bj = b - bi * (bi + 1) / 2;
-        const int gi = 16 * bi + i, gj = 16 * bj + j;
-        const bool live = e < NBL * 256 && gi >= gj;  // not the upper half of a diagonal block
+        int gi = 0, gj = 0;
+        const double* pp = a.Ppart;
+        size_t pstride = (size_t)MP * MP;
+        bool live = e < ET;
+        if (e < EB) {
+          const int b = e >> 8, i = (e >> 4) & 15, j = e & 15;
+          int bi = 0;
+          while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+          const int bj = b - bi * (bi + 1) / 2;
+          gi = 16 * bi + i;
+          gj = 16 * bj + j;
+          live = gi >= gj;  // not the upper half of a diagonal block
+          pp = a.Ppart + (size_t)gi * MP + gj;
+        } else if (e < EU) {
+          pp = a.upart + (e - EB);
+          pstride = MP;
+        } else {
+          pp = a.spart + 2 + (e - EU);
+          pstride = 2;
+        }
         double s = 0.0;
         if (live) {
-          const double* pp = a.Ppart + (size_t)gi * MP + gj;
           for (int g = w; g < a.grow; g += 64) {  // sixteen loads in flight; the additions keep the fixed order
             double t[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = g + 4 * k < a.grow ? pp[(size_t)(g + 4 * k) * MP * MP] : 0.0;
+            for (int k = 0; k < 16; ++k) t[k] = g + 4 * k < a.grow ? pp[(size_t)(g + 4 * k) * pstride] : 0.0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += t[k];
           }
@@ -1268,30 +1284,20 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
         sl.red[w][el] = s;
         __syncthreads();
         if (w == 0 && live) {
-          const double v = (gi == gj ? 1.0 : 0.0) + ((sl.red[0][el] + sl.red[1][el]) + (sl.red[2][el] + sl.red[3][el])) * is2;
-          a.Bm[(size_t)gi * MP + gj] = v;
-          a.Bm[(size_t)gj * MP + gi] = v;
-          a.Lb[(size_t)gi * MP + gj] = v;  // factored in place by the chain (only the lower triangle is read)
-          a.Lb[(size_t)gj * MP + gi] = v;
+          const double tot = (sl.red[0][el] + sl.red[1][el]) + (sl.red[2][el] + sl.red[3][el]);
+          if (e < EB) {
+            const double v = (gi == gj ? 1.0 : 0.0) + tot * is2;
+            a.Bm[(size_t)gi * MP + gj] = v;
+            a.Bm[(size_t)gj * MP + gi] = v;
+            a.Lb[(size_t)gi * MP + gj] = v;  // factored in place by the chain (only the lower triangle is read)
+            a.Lb[(size_t)gj * MP + gi] = v;
+          } else if (e < EU) {
+            a.u[e - EB] = tot;
+          } else {
+            a.spart[e - EU] = tot;
+          }
         }
         __syncthreads();
-      }
-      if (rw == 0) {
-        if (tid < MP) {
-          double s = 0.0;
-#pragma unroll 8
-          for (int g = 0; g < a.grow; ++g) s += a.upart[(size_t)g * MP + tid];
-          a.u[tid] = s;
-        }
-        // the two scalar sums over the row workgroups: one wave each, lanes stride the partials (with 208 of them one thread
-        // walking 416 dependent loads was 70 us on the critical path of chol(B)); fixed tree, bit-reproducible
-        if (w >= 2) {
-          const int which = w - 2;
-          double sv = 0.0;
-          for (int g = lane; g < a.grow; g += 64) sv += a.spart[2 + which + 2 * g];
-          sv = wave_sum(sv);
-          if (lane == 0) a.spart[which] = sv;
-        }
       }
     }
     sm_publish_add(sy + SY_SLICE * SM_SYNC_STRIDE);

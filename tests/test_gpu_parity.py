@@ -825,7 +825,7 @@ def test_mixture_predictive_batched_over_the_samples(engine):
     """sgp_mixture_predict (row f-2: eight theta samples per chain of launches, PSD gates in one dataflow launch) against the
     oracle's predictive sample by sample, against the per-sample loop of the reference (model.batched_mixture = False), with
     N > 8192 (two row chunks of the train side), T not a multiple of 64, 11 samples (two batches) and one sample whose K_uu is
-    hopeless (amplitude 3e3 against the 1e-6 jitter): both paths drop exactly that one."""
+    hopeless (amplitude 1e5, lengthscale 30 against the 1e-6 jitter): both paths drop exactly that one."""
     import ggp_amd
     from oracle import vfe_oracle as O
     from ggp_amd.hmc import Trace
@@ -839,7 +839,7 @@ def test_mixture_predictive_batched_over_the_samples(engine):
     # lengthscales below the typical inducing-point spacing: K_uu well conditioned, so 1e-8 against the (streaming-order) oracle is
     # a statement about the kernels, not about cond(K_uu) eps
     rows = [{"ls": np.array([0.6 + 0.02 * i, 0.8 - 0.01 * i, 0.7]), "sig_f": 1.0 + 0.05 * i, "sig_n": 0.3 + 0.02 * i} for i in range(11)]
-    rows[4] = {"ls": np.array([30.0, 30.0, 30.0]), "sig_f": 3.0e3, "sig_n": 0.3}
+    rows[4] = {"ls": np.array([30.0, 30.0, 30.0]), "sig_f": 1.0e5, "sig_n": 0.3}
     for kern, kid in (("rbf", 0), ("matern32", 1)):
         r = engine.mixture_predict(Xd, yd, Xtd, Zd, [q["ls"] for q in rows], [q["sig_f"] ** 2 for q in rows], [q["sig_n"] ** 2 for q in rows],
                                    jitter=1e-6, kernel=kern, full_cov=True, gate_jitter=1e-4)
