@@ -1245,8 +1245,49 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       // 64 matrix entries per workgroup and pass; the four waves split the partials of an entry (g = wave, wave + 4, ...: with
       // up to 208 row workgroups one thread walking them all was 13 dependent batches of loads on 36 of the workgroups while
       // the others idled) and combine through LDS in a fixed order -- bit-reproducible for a given launch geometry
-      // element space: the NBL x 256 entries of the lower blocks of B, then the MP entries of u = sum of the A y partials, then
-      // the two scalars (sum A o A, y^T y) -- every one of them a sum over the row workgroups' partials
+      if (a.grow <= 32) {
+        // few partials (N <= 2048, the reference's own HMC sizes): one thread per entry walks them all -- no barriers
+        for (int e = rw * 256 + tid; e < NBL * 256; e += a.grow * 256) {
+          const int b = e >> 8, i = (e >> 4) & 15, j = e & 15;
+          int bi = 0;
+          while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+          const int bj = b - bi * (bi + 1) / 2;
+          const int gi = 16 * bi + i, gj = 16 * bj + j;
+          if (gi < gj) continue;  // upper half of a diagonal block
+          double s = 0.0;
+          const double* pp = a.Ppart + (size_t)gi * MP + gj;
+          for (int g = 0; g < a.grow; g += 16) {  // sixteen loads in flight; the additions keep the fixed order
+            double t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = g + k < a.grow ? pp[(size_t)(g + k) * MP * MP] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += t[k];
+          }
+          const double v = (gi == gj ? 1.0 : 0.0) + s * is2;
+          a.Bm[(size_t)gi * MP + gj] = v;
+          a.Bm[(size_t)gj * MP + gi] = v;
+          a.Lb[(size_t)gi * MP + gj] = v;  // factored in place by the chain (only the lower triangle is read)
+          a.Lb[(size_t)gj * MP + gi] = v;
+        }
+        if (rw == 0) {
+          if (tid < MP) {
+            double s = 0.0;
+            for (int g = 0; g < a.grow; ++g) s += a.upart[(size_t)g * MP + tid];
+            a.u[tid] = s;
+          }
+          if (tid == 0) {
+            double sa = 0.0, sy2 = 0.0;
+            for (int g = 0; g < a.grow; ++g) {
+              sa += a.spart[2 + 2 * g];
+              sy2 += a.spart[3 + 2 * g];
+            }
+            a.spart[0] = sa;
+            a.spart[1] = sy2;
+          }
+        }
+      } else {
+      // many partials.  Element space: the NBL x 256 entries of the lower blocks of B, then the MP entries of u = sum of the A y
+      // partials, then the two scalars (sum A o A, y^T y) -- every one of them a sum over the row workgroups' partials
       const int el = tid & 63;
       constexpr int EB = NBL * 256, EU = EB + MP, ET = EU + 2;
       for (int e0 = rw * 64; e0 < ET; e0 += a.grow * 64) {
@@ -1298,6 +1339,7 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
           }
         }
         __syncthreads();
+      }
       }
     }
     sm_publish_add(sy + SY_SLICE * SM_SYNC_STRIDE);
