@@ -261,6 +261,13 @@ def main():
     kbar_tf = kbar_flops / (kbar_ms * 1e-3) / 1e12
     note = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE in separate passes "
             "(tools/profile_round.sh), read from %s; not collected in this run")
+    # the binary these numbers come from: sha256 over every kernel source / header / linker script (build.py), so a traffic
+    # figure read from profiles/ can be matched to the build it was collected on
+    try:
+        with open(os.path.join(ROOT, "generalised-gaussian-processes_amd", "csrc", "libsgp_hip.so.sha256")) as fh:
+            source_digest = fh.read().strip()[:16]
+    except OSError:
+        source_digest = None
 
     devices = [torch.cuda.get_device_properties(dev).name + " #%d" % local_rank]
     device_check = "single rank"
@@ -307,7 +314,7 @@ def main():
                    "theta": {"ls": LS, "sig_f": SF, "sig_n": SN}, "ranks": world, "collective_backend": backend if world > 1 else None,
                    "devices": devices, "device_check": device_check, "rows_per_rank": n_local,
                    "allreduce_ms": allreduce_ms, "allreduce_bytes": allreduce_bytes if world > 1 else None,
-                   "collectives_per_eval": coll_per_eval,
+                   "collectives_per_eval": coll_per_eval, "source_digest": source_digest,
                    "evaluation_order": ("single launch (M <= 128)" if cb._small_ok(args.m) else
                                         "whitened (A = L^-1 K_uf materialised, B = I + A A^T / s2; pass 2 from the factored adjoint)"
                                         if cb._whitened(args.m) else
