@@ -106,6 +106,7 @@ PROTOTYPES = {
                                            _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_svgp_elbo_batch_reverse": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                            _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_svgp_predict_batch": (_i32, [_vp, _i64, _i64, _vp, _i64, _i32, _dp, _dp, _dbl, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_svgp_batch_combine": (_i32, [_i32, _dp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgp_mixture_predict_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32, _i32]),
     "sgp_mixture_predict": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _i32, _i32, _i32, _i32, _dbl,

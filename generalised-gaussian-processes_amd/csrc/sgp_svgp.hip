@@ -1022,17 +1022,19 @@ static int svgp_batch_impl(int phase, const double* Xb, int64_t ldx, const doubl
                            const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
                            double* out, double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2, double* g_s2,
                            int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
-  const bool fwd = (phase & 1) != 0, with_grads = (phase & 2) != 0;
-  if (!Xb || !yb || !Z || !inv_ls || !sf2 || !s2 || !m || !LS || B <= 0 || M <= 0 || d <= 0 || ldx < d || ldz < d || N_total <= 0)
+  const bool predict = phase == 4;  // latent predictive only: out = mean (S x B), g_m = variance (S x B), no labels, no likelihood
+  const bool fwd = (phase & 1) != 0 || predict, with_grads = (phase & 2) != 0;
+  if (!Xb || (!yb && !predict) || !Z || !inv_ls || !sf2 || !s2 || !m || !LS || B <= 0 || M <= 0 || d <= 0 || ldx < d || ldz < d || N_total <= 0)
     return SGP_ERR_ARG;
   if (fwd && (!out || !info)) return SGP_ERR_ARG;
+  if (predict && !g_m) return SGP_ERR_ARG;
   if (S < 1 || S > SVGP_MAX_S) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id > SGP_KERNEL_MATERN52 || likelihood_id < 0 || likelihood_id > 1) return SGP_ERR_ARG;
   if (with_grads && (!g_m || !g_LS || !g_Z || !g_ls || !g_sf2)) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING || B > (1 << 20)) return SGP_ERR_DIM;
   SvgpThetaS th{};
   for (int s = 0; s < S; ++s) {
-    if (likelihood_id == 0 && !(s2[s] > 0.0)) return SGP_ERR_ARG;
+    if (likelihood_id == 0 && !predict && !(s2[s] > 0.0)) return SGP_ERR_ARG;
     th.ka[s] = make_ka_s(inv_ls + (size_t)s * d, sf2[s], d);
     th.s2[s] = s2[s];
   }
@@ -1073,6 +1075,11 @@ static int svgp_batch_impl(int phase, const double* Xb, int64_t ldx, const doubl
     t.m = Mp; t.n = Bp; t.k = Mp; t.klo_mask = 1;
     gemm_s(t, 0, mb, mb);
     svgp_cols_batch_kernel<<<dim3(Bp / 64, S), 256, 0, st>>>(w.A, w.T, w.mp, Mp, Bp, (int)B, th, w.mu, w.v);
+    if (predict) {  // q(f*) per sample: mean and variance of the first B columns of every slice
+      crop_copy(w.mu, Bp, out, B, S, (int)B, st);
+      crop_copy(w.v, Bp, g_m, B, S, (int)B, st);
+      return check_launch();
+    }
     svgp_ell_batch_kernel<<<dim3(64, S), 256, 0, st>>>(yb, w.mu, w.v, (int)B, Bp, th, likelihood_id, gh, w.dmu, w.dv, w.part);
     svgp_finalize_batch_kernel<<<1, 64, 0, st>>>(w.part, w.kl, M, (int)B, (double)N_total, S, info, out, g_s2);
   }
@@ -1145,6 +1152,19 @@ extern "C" int sgp_svgp_elbo_batch_reverse(const double* Xb, int64_t ldx, const 
                                            void* ws, size_t ws_bytes, sgp_stream_t stream) {
   return svgp_batch_impl(2, Xb, ldx, yb, B, Z, ldz, S, inv_ls, sf2, s2, jitter, m, LS, N_total, M, d, kernel_id, likelihood_id,
                          nullptr, g_m, g_LS, g_Z, g_ls, g_sf2, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+// latent predictive mean / variance of q(f*) at T rows for S hyper-parameter samples (the mixture predictive of
+// BayesianStochasticVariationalGP, models/bayesian_svgp.py:183-207): the forward half of the chain above with the test rows in
+// place of the minibatch.  mean, var: S x T (device); info: S ints.  Workspace: sgp_svgp_batch_workspace_bytes(T, M, d, S).
+extern "C" int sgp_svgp_predict_batch(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, int S, const double* inv_ls,
+                                      const double* sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,
+                                      double* mean, double* var, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!sf2 || S < 1 || S > SVGP_MAX_S) return SGP_ERR_ARG;
+  double ones[SVGP_MAX_S];
+  for (int s = 0; s < SVGP_MAX_S; ++s) ones[s] = 1.0;
+  return svgp_batch_impl(4, Xs, ldxs, nullptr, T, Z, ldz, S, inv_ls, sf2, ones, jitter, m, LS, 1, M, d, kernel_id, 0, mean, var, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, info, ws, ws_bytes, stream);
 }
 
 // forward with the likelihood's d/ds2 (g_s2, S doubles, may be NULL): the first half of the split call

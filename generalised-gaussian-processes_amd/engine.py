@@ -572,6 +572,30 @@ class HipEngine:
         _lib.check("sgp_svgp_elbo_batch", st)
         return res
 
+    def svgp_predict_batch(self, Xs, Z, ls, sf2, m, LS, jitter=1e-6, kernel="rbf"):
+        """q(f*) at the rows of Xs for S hyper-parameter samples (ls: S x d, sf2: S), eight per chain of launches.
+        Returns (mean [S, T], var [S, T], info [S] int32) on the device."""
+        import ctypes
+        T, d = Xs.shape
+        M = Z.shape[0]
+        lsv = [[float(v) for v in row] for row in ls]
+        S = len(lsv)
+        mean, var = self.empty(S, T), self.empty(S, T)
+        info = torch.empty(S, dtype=torch.int32, device=self.device)
+        for s0 in range(0, S, 8):
+            n = min(8, S - s0)
+            nbytes = self.lib.sgp_svgp_batch_workspace_bytes(T, M, d, n)
+            if nbytes == 0:
+                raise ValueError("unsupported SVGP predictive shape T=%d M=%d d=%d" % (T, M, d))
+            ws = self._workspace("svgp_batch", nbytes)
+            inv = (ctypes.c_double * (n * d))(*[1.0 / v for row in lsv[s0:s0 + n] for v in row])
+            sf2c = (ctypes.c_double * n)(*[float(v) for v in sf2[s0:s0 + n]])
+            st = self.lib.sgp_svgp_predict_batch(self._ptr(Xs), d, T, self._ptr(Z), d, n, inv, sf2c, float(jitter), self._ptr(m), self._ptr(LS),
+                                                 M, d, _kernel_id(kernel), self._ptr(mean[s0:]), self._ptr(var[s0:]),
+                                                 C.c_void_p(info[s0:].data_ptr()), self._ptr(ws), ws.numel(), self._stream())
+            _lib.check("sgp_svgp_predict_batch", st)
+        return mean, var, info
+
     def svgp_batch_combine(self, res, weights):
         """Reverse pass of sum_s weights[s] * bound_s from a ``svgp_elbo_batch(..., with_grads=True)`` result, one launch.
         Returns (g_m [M], g_LS [M, M], g_Z [M, d], g_theta [S, d + 2] = w_s [d/dsf2 | d/dls | d/ds2]) on the device."""

@@ -661,6 +661,26 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         self.eval()
         self.likelihood.eval()
         out = []
+        eng = self._engine_obj()
+        if getattr(self, "batched", True) and hasattr(eng, "svgp_predict_batch"):
+            # every hyper-sample's q(f*) from ONE chain of launches per eight samples, one status copy for all of them
+            with torch.no_grad():
+                th = self._theta_of(self.sample_variational_log_hyper(num_samples))
+                tx = self._dev(test_x[:, None] if test_x.dim() == 1 else test_x)
+                mean, var, info = eng.svgp_predict_batch(tx, self._dev(self.inducing_inputs), th[:, 1:-1].tolist(), th[:, 0].tolist(),
+                                                         self._dev(self.variational_mean), self._dev(self.chol_variational_covar),
+                                                         jitter=self.jitter, kernel=self.covar_module.base_kernel.kernel_name)
+                ok = info.to("cpu").tolist()
+                for k in range(num_samples):
+                    if ok[k] < 0:
+                        raise SgpTimeoutError()
+                    if ok[k] != 0:
+                        continue
+                    if self.bernoulli:
+                        out.append(self.likelihood(MultivariateNormal(mean[k], None, variance=var[k])))
+                    else:
+                        out.append(MultivariateNormal(mean[k], None, variance=var[k] + float(th[k, -1])))
+            return out
         with torch.no_grad():
             for lt in self.sample_variational_log_hyper(num_samples):
                 th = self._theta_of(lt)

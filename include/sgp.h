@@ -407,6 +407,11 @@ int sgp_svgp_elbo_batch_reverse(const double* Xb, int64_t ldx, const double* yb,
                                 const double* m, const double* LS, int64_t N_total, int M, int d, int kernel_id, int likelihood_id,
                                 double* g_m, double* g_LS, double* g_Z, double* g_ls, double* g_sf2,
                                 void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* latent predictive of q(f*) at T rows for S hyper-parameter samples in one chain (mean, var: S x T on the device; the mixture
+ * predictive of BayesianStochasticVariationalGP, models/bayesian_svgp.py:183-207); workspace: sgp_svgp_batch_workspace_bytes(T, ..) */
+int sgp_svgp_predict_batch(const double* Xs, int64_t ldxs, int64_t T, const double* Z, int64_t ldz, int S, const double* inv_ls,
+                           const double* sf2, double jitter, const double* m, const double* LS, int M, int d, int kernel_id,
+                           double* mean, double* var, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_svgp_batch_combine(int S, const double* weights, int M, int d, const double* g_m, const double* g_LS, const double* g_Z,
                            const double* g_ls, const double* g_sf2, const double* g_s2, double* gm_out, double* gLS_out,
                            double* gZ_out, double* gtheta_out, sgp_stream_t stream);

@@ -313,6 +313,13 @@ def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d,
         if lik == "gaussian":
             assert close(res["g_s2"][k], torch.tensor([ref["g_s2"]]), 1e-6)
     assert res["out"][:, 3].cpu().tolist() == [0.0] * S_hyper  # the status words ride along in the result rows
+    # q(f*) for all samples in one chain (the mixture predictive of BayesianStochasticVariationalGP) = the per-sample call
+    Tn = min(B, 77)
+    mu_b, v_b, info_b = engine.svgp_predict_batch(D(X[:Tn]), D(Z), ls.tolist(), sf2.tolist(), D(m), D(LS), jitter=1e-6, kernel=kern)
+    assert info_b.cpu().tolist() == [0] * S_hyper and mu_b.shape == (S_hyper, Tn)
+    for k in range(S_hyper):
+        mu1, v1, _ = engine.svgp_predict(D(X[:Tn]), D(Z), ls[k].tolist(), float(sf2[k]), D(m), D(LS), jitter=1e-6, kernel=kern)
+        assert float((mu_b[k] - mu1).abs().max()) < 1e-10 and float(((v_b[k] - v1) / v1).abs().max()) < 1e-10
     # the two-halves form (forward, [the caller's copy of the bounds], reverse) gives the same numbers bit for bit
     sp = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
                                 likelihood=lik, with_grads=True, defer_reverse=True)
