@@ -605,8 +605,8 @@ static double g_cond_limit = 1e13;
 double sgp::cond_gate_limit() { return g_cond_limit; }
 __global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ K, const double* __restrict__ L, int64_t ld, int M,
                                                         double limit, int* info) {
-  __shared__ double smin[256], str[256];
-  __shared__ int imin[256];
+  __shared__ double smin[4], str[4];
+  __shared__ int imin[4];
   double lo = 1e300, tr = 0.0;
   int at = 0;
   for (int i = threadIdx.x; i < M; i += 256) {
@@ -614,15 +614,24 @@ __global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict
     if (v < lo) { lo = v; at = i; }
     tr += K[(int64_t)i * M + i];
   }
-  smin[threadIdx.x] = lo; str[threadIdx.x] = tr; imin[threadIdx.x] = at;
+  // wave level: butterfly on (value, index) pairs -- ties go to the smaller index, so every lane ends with the same pair
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(lo, o, 64);
+    const int oi = __shfl_xor(at, o, 64);
+    if (ov < lo || (ov == lo && oi < at)) { lo = ov; at = oi; }
+    tr += __shfl_xor(tr, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { smin[w] = lo; str[w] = tr; imin[w] = at; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int t = 1; t < 256; ++t) {  // fixed order: the first smallest pivot wins
-      if (smin[t] < lo) { lo = smin[t]; at = imin[t]; }
+    for (int t = 1; t < 4; ++t) {
+      if (smin[t] < lo || (smin[t] == lo && imin[t] < at)) { lo = smin[t]; at = imin[t]; }
       tr += str[t];
     }
-    if (*info == 0 && !(tr <= limit * lo * lo)) *info = at + 1;  // also catches a NaN / zero pivot the factorization let through
-  }
+    if (*info == 0 && !(tr <= limit * lo * lo)) *info = at + 1;  // (a NaN pivot the factorization let through never becomes `lo`:
+  }                                                              //  potrf itself reports those)
 }
 
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
