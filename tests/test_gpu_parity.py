@@ -871,3 +871,28 @@ def test_mixture_predictive_batched_over_the_samples(engine):
         assert float((a.loc - b.loc).abs().max()) < 1e-8 and float((a.covariance_matrix - b.covariance_matrix).abs().max()) < 1e-8
     yt = torch.sin(Xt[:, 0]) * torch.cos(Xt[:, 1]) + 0.3 * Xt[:, 2]
     assert abs(ggp_amd.nlpd_mixture(pb, yt, torch.tensor([1.0])) - ggp_amd.nlpd_mixture(pl, yt, torch.tensor([1.0]))) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,T,d,S", [(50, 5, 1, 1, 1), (8193, 129, 65, 2, 3), (700, 64, 64, 5, 8), (130, 128, 200, 3, 9)])
+def test_mixture_predictive_edge_shapes(engine, N, M, T, d, S):
+    """sgp_mixture_predict at the edges of its tiling: a single test row, one row past the 8192-row training chunk, M one past a
+    128 boundary, exact multiples of 64, more samples than one batch -- mean / variance / covariance against the oracle per sample."""
+    from oracle import vfe_oracle as O
+    g = torch.Generator().manual_seed(N + M + T)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X.sum(1)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Xt = torch.randn(T, d, dtype=torch.float64, generator=g)
+    Z = (X[torch.randperm(N, generator=g)[:M]] if M <= N else torch.randn(M, d, dtype=torch.float64, generator=g)).clone()
+    ls = 0.5 + 0.3 * torch.rand(S, d, dtype=torch.float64, generator=g)
+    sf2 = 0.8 + 0.5 * torch.rand(S, dtype=torch.float64, generator=g)
+    s2 = 0.05 + 0.1 * torch.rand(S, dtype=torch.float64, generator=g)
+    D = lambda t: t.to(engine.device).contiguous()  # noqa: E731
+    r = engine.mixture_predict(D(X), D(y), D(Xt), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), jitter=1e-6, kernel="rbf", full_cov=True,
+                               gate_jitter=1e-4)
+    assert r["info"].cpu().tolist() == [0] * S and r["gate"].cpu().tolist() == [0] * S
+    for k in range(S):
+        mu, cov = O.predict(Xt, X, y, Z, ls[k], float(sf2[k]), float(s2[k]), 1e-6, full_cov=True)
+        assert float((r["mean"][k].cpu() - mu).abs().max()) < 1e-8, k
+        assert float((r["cov"][k].cpu() - cov).abs().max()) < 1e-8, k
+        assert float((r["var"][k].cpu() - torch.diagonal(cov)).abs().max()) < 1e-8, k
