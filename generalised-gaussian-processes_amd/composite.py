@@ -158,10 +158,13 @@ class CompositeHmcTarget:
         return {"structure": self.kernel.block(),
                 "free": [(slot, self._ROLE_ID[role], sd) for (_, slot, role), sd in zip(self.params, self.sd)]}
 
-    def device_sampler_ok(self):
-        """True when ``hmc.sample_nuts_device`` can run this target (single-launch path, at most 17 sampled parameters)."""
+    def device_sampler_ok(self, n_draws_total=None, max_treedepth=10):
+        """True when ``hmc.sample_nuts_device`` can run this target (single-launch path, at most 17 sampled parameters, and -- when
+        the run length is given -- a worst case inside the persistent kernel's counters, ``core.device_run_fits``)."""
+        from .core import device_run_fits
         b = self.bound
-        return (hasattr(b, "_small_ok") and hasattr(b.engine, "small_nuts") and b._small_ok(self.Z.shape[0]) and self.ndim <= 18)
+        ok = hasattr(b, "_small_ok") and hasattr(b.engine, "small_nuts") and b._small_ok(self.Z.shape[0]) and self.ndim <= 18
+        return ok and (n_draws_total is None or device_run_fits(int(b.X.shape[0]), n_draws_total, max_treedepth))
 
     def device_sampler_args(self):
         return {"composite": self.device_description()}
@@ -307,7 +310,7 @@ class CompositeBayesianSparseGPR_HMC(torch.nn.Module):  # noqa: N801  (after the
         scale = 0.25 if not sampler_params else sampler_params.get("step_scale", 0.25)
         seed = None if self._seed is None else self._seed + self._n_hmc_calls
         self._n_hmc_calls += 1
-        fn = sample_nuts_device if (self.device_sampler and target.device_sampler_ok()) else sample_nuts
+        fn = sample_nuts_device if (self.device_sampler and target.device_sampler_ok(n_samples + tune)) else sample_nuts
         return fn(target, n_samples, tune, seed=seed, start=start, step_scale=scale)
 
     def train_model(self, optimizer, max_steps=10000, hmc_scheduler=(200, 500, 1000, 1500), verbose=False,

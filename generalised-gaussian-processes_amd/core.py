@@ -421,6 +421,13 @@ class CollapsedBound:
         return self.engine.predict(Xs, Z, ls, sf2, s2, factors, self.kernel, pred_noise=pred_noise, full_cov=full_cov)
 
 
+def device_run_fits(n_rows: int, n_draws_total: int, max_treedepth: int) -> bool:
+    """sgp_small_nuts refuses (SGP_ERR_DIM) a run whose worst case -- (draws + 2) x 2^depth evaluations x workgroups of the launch
+    (3 + one per 64-row slab, at most 211) -- could pass 2^31, the range of its cumulative sync counters."""
+    grid = 3 + min((int(n_rows) + 63) // 64, 208)
+    return (float(n_draws_total) + 2.0) * float(1 << int(max_treedepth)) * grid <= 2.0e9
+
+
 def shard_rows(N: int, rank: int, world: int):
     """Contiguous row block [lo, hi) of rank ``rank`` (X[g N/G : (g+1) N/G])."""
     base, rem = divmod(N, world)
@@ -451,9 +458,12 @@ class HmcTarget:
         """PyMC3's test point in the unconstrained space: Gamma(2,1) -> mean 2, HalfCauchy(1) -> 1."""
         return [math.log(2.0)] * self.d + [0.0, 0.0]
 
-    def device_sampler_ok(self):
-        """True when ``hmc.sample_nuts_device`` can run this target: the bound takes the single-launch path."""
-        return hasattr(self.bound.engine, "small_nuts") and self.bound._small_ok(self.Z.shape[0])
+    def device_sampler_ok(self, n_draws_total=None, max_treedepth=10):
+        """True when ``hmc.sample_nuts_device`` can run this target: the bound takes the single-launch path -- and, when the run
+        length is given, its worst case (every tree at the depth limit) stays inside the persistent kernel's cumulative int
+        counters (``device_run_fits``); the host-driven sampler over the same single launch takes the longer runs."""
+        ok = hasattr(self.bound.engine, "small_nuts") and self.bound._small_ok(self.Z.shape[0])
+        return ok and (n_draws_total is None or device_run_fits(int(self.bound.X.shape[0]), n_draws_total, max_treedepth))
 
     @staticmethod
     def _prior(ls, sf, sn):

@@ -1884,6 +1884,12 @@ static int small_nuts_impl(const double* X, int64_t ldx, const double* y, const 
   SmallArgs& a = w.a;
   if (int rc = small_kernel_fields(a, d, kernel_id, SGP_SMALL_HMC, ch)) return rc;
   if (a.ndim > NUTS_MAXD) return SGP_ERR_DIM;
+  {
+    // the sync counters are cumulative ints (evaluations x contributing workgroups): a run whose worst case -- every tree at its
+    // depth limit -- could pass 2^31 is refused up front (2 000 draws at depth 10 on 211 workgroups is 4.3e8)
+    const double worst = ((double)n_tune + (double)n_draws + 2.0) * (double)(1 << max_treedepth) * (double)small_grid(M, a.grow);
+    if (worst > 2.0e9) return SGP_ERR_DIM;
+  }
   a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta_scratch;
   a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = SGP_SMALL_HMC; a.want_grad = 1; a.want_gz = 0;
   a.jitter = jitter;
@@ -1946,6 +1952,7 @@ extern "C" int sgp_small_eval_batch(const double* X, int64_t ldx, const double* 
   SmallWs w = carve_small(ws, N, M, d);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
   SmallArgs& a = w.a;
+  if ((double)S * (double)small_grid(M, a.grow) > 2.0e9) return SGP_ERR_DIM;  // cumulative int sync counters
   if (int rc = small_kernel_fields(a, d, kernel_id, mode, nullptr)) return rc;
   a.X = X; a.ldx = ldx; a.y = y; a.Z = Z; a.ldz = ldz; a.theta = theta_scratch;
   a.N = (int)N; a.M = M; a.d = d; a.kid = kernel_id; a.mode = mode; a.want_grad = want_grad ? 1 : 0;

@@ -356,6 +356,10 @@ def sample_nuts_device(target, n_samples: int, tune: int, seed: Optional[int] = 
     if not target.device_sampler_ok():
         raise ValueError("the device sampler needs the single-launch path (M <= 128, one rank; stationary kernels d <= 24, "
                          "composite kernels d <= 8)")
+    from .core import device_run_fits
+    if not device_run_fits(int(b.X.shape[0]), n_samples + tune, max_treedepth):
+        raise ValueError("a run of %d draws at tree depth %d could overflow the persistent kernel's counters: use sample_nuts "
+                         "(host-driven, same single-launch evaluations) or a smaller max_treedepth" % (n_samples + tune, max_treedepth))
     nd = target.ndim
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)

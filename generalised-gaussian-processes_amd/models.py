@@ -174,7 +174,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         scale = 0.25 if not sampler_params else sampler_params.get('step_scale', 0.25)
         seed = None if self._seed is None else self._seed + self._n_hmc_calls
         self._n_hmc_calls += 1
-        if self.device_sampler and target.device_sampler_ok():
+        if self.device_sampler and target.device_sampler_ok(n_samples + tune):
             # the whole of pm.sample() in one persistent launch: theta, momentum and the tree never leave the GPU
             return sample_nuts_device(target, n_samples, tune, seed=seed, step_scale=scale)
         return sample_nuts(target, n_samples, tune, seed=seed, step_scale=scale)

@@ -308,3 +308,12 @@ def test_bench_gpus_n_refuses_to_run_n_ranks_on_fewer_devices():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
                        env=env, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_device_sampler_run_length_guard():
+    """The persistent sampler's sync counters are cumulative ints: a run whose worst case could pass 2^31 is not sent to it
+    (HmcTarget.device_sampler_ok(n) answers False and the host-driven sampler takes over; sample_nuts_device itself raises)."""
+    from ggp_amd.core import device_run_fits
+    assert device_run_fits(500, 3000, 10) and device_run_fits(13279, 3000, 10)      # the reference's runs, Elevator included
+    assert not device_run_fits(13279, 12000, 10) and device_run_fits(13279, 12000, 7)
+    assert device_run_fits(500, 100000, 10) and not device_run_fits(500, 1000000, 10)
