@@ -295,16 +295,43 @@ __device__ __forceinline__ void syrk_tile(double (*Ks)[NB][KROW], const double* 
       // invariant at the top of iteration c: LDS buffer (c-c0)&1 holds chunk c; chunk c+1 is in flight / in
       // stage B (even trips) or stage A (odd trips)
       int64_t c = c0;
+#ifdef SGP_AB_DIAG_DUMMY_ASM
+      // A/B cost model (tools/ab_build.sh -DSGP_AB_DIAG_DUMMY_ASM): what would the contraction cost if the diagonal-tile
+      // workgroups GENERATED their K' column block (8 exp() per thread and chunk) and wrote it out for the off-diagonal tiles
+      // (8 doubles per thread and chunk), i.e. if kernel assembly lived inside this launch?  The values written back are the
+      // ones just loaded, so results do not change.
+      double sink = 0.0;
+      auto dummy = [&](int64_t cc, const d2 (&st)[NQ]) {
+        if constexpr (DIAG) {
+          char* base = const_cast<char*>(reinterpret_cast<const char*>(Kfu + cc * NB * Mp));
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) {
+            sink += sgp_exp(-st[i][0]) + sgp_exp(-st[i][1]);
+            double* dst = reinterpret_cast<double*>(base + (size_t)i * RSTEP * Mp * 8 + goff0);
+            __builtin_nontemporal_store(st[i][0], dst);
+            __builtin_nontemporal_store(st[i][1], dst + 1);
+          }
+        }
+      };
+#define SGP_DUMMY(cc, st) dummy(cc, st)
+#else
+#define SGP_DUMMY(cc, st)
+#endif
       for (; c + 1 < c1; c += 2) {
         if (c + 2 < c1) fetch(c + 2, stA);
         mfma_chunk(0);
+        SGP_DUMMY(c + 1, stB);
         stash(1, stB);  // chunk c+1
         __syncthreads();
         if (c + 3 < c1) fetch(c + 3, stB);
         mfma_chunk(1);
+        if (c + 2 < c1) { SGP_DUMMY(c + 2, stA); }
         if (c + 2 < c1) stash(0, stA);  // chunk c+2
         __syncthreads();
       }
+#ifdef SGP_AB_DIAG_DUMMY_ASM
+      if (sink == 1.2345e300) out[0] = sink;  // keeps the exps alive
+#endif
       if (c < c1) mfma_chunk(0);  // odd chunk count: the last chunk sits in buffer 0
     }
   
