@@ -277,10 +277,13 @@ class HipEngine:
         nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
         if nbytes == 0:
             raise ValueError("shape N=%d M=%d d=%d is outside the single-launch path" % (N, M, d))
-        ws = self._ws.get("small")
+        # one workspace per HIP stream: the launch's sync words live in it, so two evaluations in flight on different streams
+        # of one engine must not share them
+        key = ("small", int(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else 0)
+        ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)  # zeroed once: the sync words
-            self._ws["small"] = ws
+            self._ws[key] = ws
         return ws
 
     @staticmethod
@@ -411,9 +414,9 @@ class HipEngine:
 
     def small_reset(self):
         """Zero the sync words again (only needed after a SGP_INFO_TIMEOUT)."""
-        ws = self._ws.get("small")
-        if ws is not None:
-            ws[: self.lib.sgp_small_sync_bytes()].zero_()
+        for key, ws in self._ws.items():
+            if isinstance(key, tuple) and key[0] == "small":
+                ws[: self.lib.sgp_small_sync_bytes()].zero_()
 
     # ------------------------------------------------------------------ pass 2
     def suffstats_bwd(self, X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel="rbf", want_gz=False,

@@ -325,3 +325,29 @@ def test_small_dimension_limit(engine):
     F, gr = cb.value_and_grad(Z.to(engine.device), ls.tolist(), 1.2, 0.05, want_gz=False)
     ref = O.grads_autograd(X, y, Z, ls, 1.2, 0.05, 1e-6)
     assert abs(F - ref["F"]) < 1e-9 * abs(ref["F"]) and relerr(gr["ls"].numpy(), ref["g_ls"].numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_small_evaluations_in_flight_on_two_streams(engine):
+    """The single launch's sync words live in its workspace: the engine keeps one workspace per HIP stream, so evaluations enqueued
+    on two streams at once (each a different problem) neither corrupt each other's flags nor time out -- 200 alternating launches,
+    every result equal to the one obtained alone."""
+    Ga, Gb = load_golden("rbf_d3_small"), load_golden("rbf_d1_tiny")
+    prob = []
+    for G in (Ga, Gb):
+        prob.append((dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine), _theta(G, engine), float(G["jitter"])))
+    alone = [engine.small_eval(X, y, Z, th, j, "rbf", mode=0, want_grad=True)[0].clone() for X, y, Z, th, j in prob]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=engine.device), torch.cuda.Stream(device=engine.device)]
+    outs = [[], []]
+    for it in range(100):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                X, y, Z, th, j = prob[k]
+                o, _, info = engine.small_eval(X, y, Z, th, j, "rbf", mode=0, want_grad=True)
+                outs[k].append((o, info))
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        n = alone[k].numel()
+        for o, info in outs[k][-5:] + outs[k][:5]:
+            assert int(info.item()) == 0 and torch.equal(o[:n], alone[k][:n])
