@@ -347,7 +347,7 @@ def test_small_evaluations_in_flight_on_two_streams(engine):
                 o, _, info = engine.small_eval(X, y, Z, th, j, "rbf", mode=0, want_grad=True)
                 outs[k].append((o, info))
     torch.cuda.synchronize()
-    for k in (0, 1):
-        n = alone[k].numel()
+    for k, G in ((0, Ga), (1, Gb)):
+        n = G["X"].shape[1] + 5  # [value | d + 2 gradients | logmarg | trace]; the buffer's tail (status word, padding) is not compared
         for o, info in outs[k][-5:] + outs[k][:5]:
             assert int(info.item()) == 0 and torch.equal(o[:n], alone[k][:n])
