@@ -37,10 +37,11 @@ constexpr int SM_MAX_ROWWG = 208;  // row workgroups at most (one 64-row slab ea
                                    // 64 until round 3 -- N = 13 279 then walked 3-4 slabs per workgroup on a quarter of the chip)
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_SYNC_STRIDE = 32;  // ints between sync words: one cache line each
-enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_ACK = 11, SY_WORDS = 12 };
+enum { SY_L = 0, SY_PART = 1, SY_SLICE = 2, SY_LB = 3, SY_GRAD = 4, SY_ABORT = 5, SY_Q = 6, SY_REQ = 7, SY_DONE = 8, SY_G = 9, SY_KUU = 10, SY_ACK = 11, SY_GZ = 12, SY_WORDS = 13 };
 constexpr int SM_GP = 40;  // doubles per gradient partial.  Stationary: g_ls[d] at 0.., g_sf2 at 16; composite: dF/d(block) at its
                           // 33 slots.  Both: tr B^-1, u.g, g.g at SM_XTRA + 0, 1, 2
 constexpr int SM_XTRA = 34;
+constexpr int SM_GZ_SPREAD = 32;  // gradient partials (workgroups) above which the row workgroups share the dF/dZ reduction
 constexpr int SM_MAXCP = 20;  // free parameters of a composite kernel (4 terms x (amplitude + 2 x (lengthscale, aux)))
 
 struct SmallArgs {
@@ -899,11 +900,18 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
       if (tid < SM_GP) gsum[tid] = (red4[tid] + red4[64 + tid]) + (red4[128 + tid] + red4[192 + tid]);
     }
     if (a.want_gz && a.gZ) {
-      for (int e = tid; e < M * d; e += 256) {
-        double s = 0.0;
+      if (ngrad > SM_GZ_SPREAD) {  // the row workgroups reduce dF/dZ between them (see their last phase)
+        if (!sm_wait_ge(sy + SY_GZ * SM_SYNC_STRIDE, ev * a.grow, abortw, &dead)) {
+          if (tid == 0) *a.info = SGP_INFO_TIMEOUT;
+          return;
+        }
+      } else {
+        for (int e = tid; e < M * d; e += 256) {
+          double s = 0.0;
 #pragma unroll 8
-        for (int g = 0; g < ngrad; ++g) s += a.gzpart[(size_t)g * MP * SM_MAXD + e];
-        a.gZ[e] = s;
+          for (int g = 0; g < ngrad; ++g) s += a.gzpart[(size_t)g * MP * SM_MAXD + e];
+          a.gZ[e] = s;
+        }
       }
     }
     __syncthreads();
@@ -1411,6 +1419,19 @@ __device__ __forceinline__ void sm_eval_body(const SmallArgs& a, SmKernelShared<
     stamp(7);
     if (tid < SM_GP) a.gpart[(size_t)(rw + NB64) * SM_GP + tid] = sl.acc[tid];
     sm_publish_add(sy + SY_GRAD * SM_SYNC_STRIDE);
+    if (a.want_gz && a.gZ && ngrad > SM_GZ_SPREAD) {
+      // dF/dZ = sum over ALL workgroups' partials, M d entries: with ~210 partials the chain workgroup alone needed 185 us for it
+      // (3 MB through one CU).  The row workgroups share the entries instead -- entry e by workgroup e mod grow, its 256 threads
+      // striding the partials, one fixed-order block sum each -- once every partial is in
+      if (!sm_wait_ge(sy + SY_GRAD * SM_SYNC_STRIDE, ev * ngrad, abortw, &dead)) return;
+      for (int e = rw; e < M * d; e += a.grow) {
+        double sv = 0.0;
+        for (int g = tid; g < ngrad; g += 256) sv += a.gzpart[(size_t)g * MP * SM_MAXD + e];
+        sv = block_sum(sv);
+        if (tid == 0) a.gZ[e] = sv;
+      }
+      sm_publish_add(sy + SY_GZ * SM_SYNC_STRIDE);
+    }
     return;
   }
 
