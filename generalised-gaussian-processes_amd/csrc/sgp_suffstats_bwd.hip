@@ -103,6 +103,13 @@ constexpr bool kbar_two_pass() {
 #endif
 }
 
+// rows of the one-pass epilogue in flight per thread (A/B: -DSGP_AB_KBAR_UNROLL4, tools/ab_build.sh)
+#ifdef SGP_AB_KBAR_UNROLL4
+#define SGP_KBAR_EPI_UNROLL _Pragma("unroll 4")
+#else
+#define SGP_KBAR_EPI_UNROLL _Pragma("unroll 2")
+#endif
+
 template <int DP, int KID, bool GZ, bool KP = true>
 __global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID, KP>()) ? 2 : 1)) void kbar_contract_kernel(
     const double* __restrict__ Kfu, const double* __restrict__ Xs, const double* __restrict__ ys,
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID, KP>()) ? 2
             for (int r = 0; r < 4; ++r) Ct[u * 16 + l4 + 4 * r][wj * 64 + v * 16 + l15] = acc[u][v][r];
       }
       __syncthreads();
-#pragma unroll 2
+      SGP_KBAR_EPI_UNROLL
       for (int i = 0; i < 32; ++i) {
         const int nl = half * 32 + i;                       // wave-uniform row inside this half
         const int64_t n = row0 + r0 + h * 64 + nl;          // global (padded) data row
