@@ -103,7 +103,8 @@ constexpr bool kbar_two_pass() {
 #endif
 }
 
-// rows of the one-pass epilogue in flight per thread (A/B: -DSGP_AB_KBAR_UNROLL4, tools/ab_build.sh)
+// rows of the one-pass epilogue in flight per thread (A/B: -DSGP_AB_KBAR_UNROLL4, tools/ab_build.sh -- four rows: 33.58 / 33.61 / 33.74
+// against 33.50 / 33.39 / 33.52 ms for two, three alternations on one box, profiles/r03_ab_kbar_unroll4.txt: no gain, two stays)
 #ifdef SGP_AB_KBAR_UNROLL4
 #define SGP_KBAR_EPI_UNROLL _Pragma("unroll 4")
 #else
