@@ -131,12 +131,6 @@ __global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID, KP>()) ? 2
   int64_t nb0, nb1;
   split_range(bmap, split, nblocks, nb0, nb1);
   const int m0 = mb * TILE;
-#ifdef SGP_AB_KBAR_STAGGER
-  // A/B (tools/ab_build.sh -DSGP_AB_KBAR_STAGGER): every other workgroup starts half a row block (~17 us) late, so that two
-  // workgroups sharing a CU are less likely to sit in their (MFMA-free) epilogues at the same time
-  if ((blockIdx.x >> 3) & 1)
-    for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
