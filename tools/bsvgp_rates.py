@@ -46,6 +46,21 @@ def main():
                           "hyper_samples": "one launch chain (sgp_svgp_elbo_batch)" if batched else "five sgp_svgp_elbo chains",
                           "host_threads": "capped (4)" if capped else "torch default (%d)" % default_threads,
                           "steps_per_s": 2 * len(bt) / dt, "ms_per_step": dt / (2 * len(bt)) * 1e3, "last_batch_loss": bl[-1]}), flush=True)
+    # the plain (non-Bayesian) SVGP of models/svgp.py at the same shape: one bound + gradient per minibatch step
+    for lik in ("bernoulli", "gaussian"):
+        like = ggp_amd.BernoulliLikelihood() if lik == "bernoulli" else ggp_amd.GaussianLikelihood()
+        yy = yc if lik == "bernoulli" else yd
+        model = ggp_amd.StochasticVariationalGP(Xd, yy, like, Z0, engine=eng)
+        bt = [(Xd[i:i + B], yy[i:i + B]) for i in range(0, 16 * B, B)]
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        model.train_model(opt, bt[:4], num_epochs=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = model.train_model(opt, bt, num_epochs=2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": "C4-shaped StochasticVariationalGP minibatch step (one bound + gradient)", "likelihood": lik,
+                          "steps_per_s": 2 * len(bt) / dt, "ms_per_step": dt / (2 * len(bt)) * 1e3, "last_loss": losses[-1]}), flush=True)
     # device time of the chain alone: 50 back-to-back bound + gradient calls for 5 samples, no host work in between
     model = ggp_amd.BayesianStochasticVariationalGP(Xd, yc, ggp_amd.BernoulliLikelihood(), Z0, engine=eng, seed=3)
     xb, yb = Xd[:B].contiguous(), torch.where(yc[:B] > 0, 1.0, -1.0).to(torch.float64)
