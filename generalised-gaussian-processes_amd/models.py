@@ -405,6 +405,8 @@ class _SVGPBatchBoundFn(torch.autograd.Function):
             return pin[:, 0]  # valid once the event has completed; NOT read before (see train_model)
         host = res["out"].to("cpu")
         model._last_infos = host[:, 3].to(torch.int32)
+        for v in model._last_infos.tolist():  # synchronous use: a failed factorization raises here, as sgp_svgp_elbo's wrapper does
+            _raise_on_info(int(v))
         return host[:, 0].clone()
 
     @staticmethod
@@ -447,12 +449,38 @@ class StochasticVariationalGP(torch.nn.Module):
         self.chol_variational_covar = torch.nn.Parameter(torch.eye(self.num_inducing, dtype=torch.float64))
         self._engine = engine
         self.to(engine.device if engine is not None else train_x.device)
+        # The d + 2 kernel / likelihood hyper-parameters stay on the HOST (the inducing inputs and q(u) live on the device): the
+        # library takes them as kernel arguments, and reading d + 2 scalars from device tensors cost three blocking copies per
+        # minibatch step (the step was host-bound: 0.95 ms around 0.40 ms of device work)
+        self.covar_module.to("cpu")
+        self.likelihood.to("cpu")
+        self.batched = True  # bounds through sgp_svgp_elbo_batch (S = 1 here): asynchronous forward, one-launch reverse combine
 
     def _engine_obj(self):
         if self._engine is None:
             from .engine import HipEngine
             self._engine = HipEngine(self.train_x.device if self.train_x.is_cuda else None)
         return self._engine
+
+    def _theta_row(self):
+        """[outputscale | lengthscales | noise variance] as a 1 x (d + 2) host tensor (differentiable wrt the raw parameters)."""
+        sf2 = self.covar_module.outputscale.reshape(1)
+        ls = self.covar_module.base_kernel.lengthscale.reshape(-1)
+        if getattr(self.likelihood, "name", "gaussian") == "bernoulli":
+            s2 = torch.ones(1, dtype=torch.float64, device=sf2.device)
+        else:
+            s2 = self.likelihood.noise.reshape(1).to(sf2.device)
+        return torch.cat([sf2, ls, s2])[None, :]
+
+    def _wait_bounds(self):
+        """Completes an asynchronous bound evaluation (training loops only): waits for the event recorded behind the forward
+        half of the chain, returns the status words."""
+        pin = getattr(self, "_pending_out", None)
+        self._pending_out = None
+        if pin is None:
+            return self._last_infos
+        self._bounds_event.synchronize()
+        return pin[:, 3].to(torch.int32)
 
     def _dev(self, t):
         return t.detach().to(dtype=torch.float64, device=self._engine_obj().device).contiguous()
@@ -464,6 +492,12 @@ class StochasticVariationalGP(torch.nn.Module):
         yb = self._dev(y_batch).reshape(-1)
         if getattr(self.likelihood, "name", "gaussian") == "bernoulli":
             yb = torch.where(yb > 0, torch.ones_like(yb), -torch.ones_like(yb))
+        if getattr(self, "batched", True) and hasattr(self._engine_obj(), "svgp_elbo_batch"):
+            # the batched chain with one sample: a host tensor comes back (the bound and its status word in one copy; inside a
+            # training loop asynchronously, see train_model)
+            return _SVGPBatchBoundFn.apply(self._theta_row(), self.inducing_inputs, self.variational_mean, self.chol_variational_covar,
+                                           self, self._dev(x_batch), yb)[0]
+        if getattr(self.likelihood, "name", "gaussian") == "bernoulli":
             s2 = torch.ones(1, dtype=torch.float64, device=yb.device)
         else:
             s2 = self.likelihood.noise
@@ -480,7 +514,15 @@ class StochasticVariationalGP(torch.nn.Module):
                 self.train()
                 self.likelihood.train()
                 optimizer.zero_grad()
-                loss = -self.elbo_minibatch(x_batch, y_batch).sum()
+                asyn = getattr(self, "batched", True) and hasattr(self._engine_obj(), "svgp_elbo_batch")
+                self._async_bounds = asyn  # forward half, copy of the bound + event, reverse half: all enqueued, nothing waited for
+                try:
+                    loss = -self.elbo_minibatch(x_batch, y_batch).sum()
+                finally:
+                    self._async_bounds = False
+                if asyn:
+                    for v in self._wait_bounds().tolist():
+                        _raise_on_info(int(v))
                 losses.append(loss.item())
                 loss.backward()
                 optimizer.step()
@@ -596,15 +638,6 @@ class BayesianStochasticVariationalGP(StochasticVariationalGP):
         s2 = torch.ones(1, dtype=torch.float64, device=self._engine_obj().device) if self.bernoulli else th[-1]
         return _SVGPBoundFn.apply(th[1:-1], th[0], s2, self.inducing_inputs, self.variational_mean,
                                   self.chol_variational_covar, self, self._dev(x_batch), self._labels(y_batch))
-
-    def _wait_bounds(self):
-        """Completes an asynchronous ``elbo_hyper_samples`` (training loop only): waits for the stream, returns the status words."""
-        pin = getattr(self, "_pending_out", None)
-        self._pending_out = None
-        if pin is None:
-            return self._last_infos
-        self._bounds_event.synchronize()
-        return pin[:, 3].to(torch.int32)
 
     def elbo_hyper_samples(self, x_batch, y_batch, log_thetas):
         """The S bounds (host tensor, differentiable wrt q(u), Z and log_thetas) of one minibatch at the rows of log_thetas."""
