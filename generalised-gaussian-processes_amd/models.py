@@ -517,12 +517,13 @@ class StochasticVariationalGP(torch.nn.Module):
                 asyn = getattr(self, "batched", True) and hasattr(self._engine_obj(), "svgp_elbo_batch")
                 self._async_bounds = asyn  # forward half, copy of the bound + event, reverse half: all enqueued, nothing waited for
                 try:
-                    loss = -self.elbo_minibatch(x_batch, y_batch).sum()
+                    elbo = self.elbo_minibatch(x_batch, y_batch)  # asynchronous: a view of pinned memory, NOT read before the wait
                 finally:
                     self._async_bounds = False
                 if asyn:
                     for v in self._wait_bounds().tolist():
                         _raise_on_info(int(v))
+                loss = -elbo.sum()
                 losses.append(loss.item())
                 loss.backward()
                 optimizer.step()
