@@ -47,6 +47,8 @@ PROTOTYPES = {
     "sgp_suffstats_bwd_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
     "sgp_kfu_len": (_sz, [_i64, _i32]),
     "sgp_set_kfu_budget_bytes": (None, [_sz]),
+    "sgp_set_contraction": (_i32, [_i32]),
+    "sgp_contraction_last": (_i32, []),
     "sgp_suffstats_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_stats_packed_len": (_sz, [_i32]),

@@ -564,6 +564,14 @@ static void head_block(const StreamPlan& p, int64_t nchunks, int* head_ns, int64
   *head_chunks = nh;
 }
 
+// ---- which matrix cores contract (value-only evaluations) ------------------------------------------------------------------
+// 0: fp64 (syrk_tile_kernel), 1 (default): the integer cores (sgp_suffstats_i8.hip) where they win -- big shards whose K'_fu
+// nobody keeps -- 2: the integer cores whenever the call allows it (tests).  SGP_CONTRACTION / sgp_set_contraction.
+static int g_contraction = -1;
+static int g_contraction_used = 0;  // what the last sgp_suffstats_fwd call ran: 0 fp64, 1 int8 digit planes
+constexpr int64_t I8_MIN_ROWS = 65536;
+constexpr int I8_MIN_MP = 256;
+
 constexpr int BRED_G = 64;  // row groups of the two-stage b reduction
 struct FwdWs {
   double *Xs, *ys, *Zs, *Kfu, *slab, *bpart, *btmp, *yypart;
@@ -575,7 +583,9 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
   w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
   w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
   w.Zs = c.take<double>((size_t)p.Mp * p.DP);
-  w.slab = c.take<double>((size_t)(p.nsplit + HEAD_SPLITS_MAX) * p.ntiles * TILE * TILE);  // + the head block's splits
+  int nslab = p.nsplit + HEAD_SPLITS_MAX;  // + the head block's splits
+  if (p.sc_rows > 0 && i8_nsplit(p.sc_rows, p.Mp) > nslab) nslab = i8_nsplit(p.sc_rows, p.Mp);  // the int8 contraction's own split count
+  w.slab = c.take<double>((size_t)nslab * p.ntiles * TILE * TILE);
   w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
@@ -600,6 +610,13 @@ extern "C" int sgp_timing_last_ms(int slot, float* ms) {
 extern "C" int64_t sgp_timing_last_rows(int slot) { return slot == TIMING_SYRK ? g_syrk_timed_rows : -1; }
 
 extern "C" void sgp_set_asm_overlap(int mode) { g_asm_overlap = mode < 0 ? -1 : mode; }
+
+extern "C" int sgp_set_contraction(int mode) {
+  const int prev = g_contraction;
+  g_contraction = (mode < 0 || mode > 2) ? -1 : mode;
+  return prev;
+}
+extern "C" int sgp_contraction_last(void) { return g_contraction_used; }
 
 extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { g_kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
 
@@ -669,8 +686,26 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   int nslabs = p.nsplit;
   int head_ns = 0;
   int64_t head_chunks = 0;
-  if (p.Npad > 0) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
-  if (head_ns > 0) {
+  if (g_contraction < 0) g_contraction = getenv("SGP_CONTRACTION") ? atoi(getenv("SGP_CONTRACTION")) : 1;
+  const bool use_i8 = !Kfu_out && p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && p.Npad >= I8_MIN_ROWS && p.Mp >= I8_MIN_MP));
+  g_contraction_used = use_i8 ? 1 : 0;
+  if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
+  if (use_i8) {
+    // digit planes (7 bytes per element) live where the fp64 K'_fu (8 bytes) would; the split count is that of a full super-chunk
+    uint8_t* Q = reinterpret_cast<uint8_t*>(Kfu);
+    const int ns = i8_nsplit(p.sc_rows, p.Mp);
+    for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
+      const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
+      timing_begin(TIMING_ASSEMBLE, st);
+      i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Q, w.bpart, st);
+      timing_end(TIMING_ASSEMBLE, st);
+      timing_begin(TIMING_SYRK, st);
+      if (i8_contract(Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st) != SGP_OK) return SGP_ERR_LAUNCH;
+      timing_end(TIMING_SYRK, st);
+      g_syrk_timed_rows = rows;
+    }
+    nslabs = ns;
+  } else if (head_ns > 0) {
     // head block [0, hrows) | tail [hrows, Npad): the tail's assembly runs on the side stream beside the head's contraction
     // (serially on the main stream when the side stream cannot be had or SGP_ASM_OVERLAP=2: same blocks, same numbers)
     const int64_t hrows = head_chunks * NB, trows = p.Npad - hrows, tchunks = trows / NB;

@@ -1,0 +1,311 @@
+// Pass-1 contraction on the INTEGER matrix cores: Phi = K'^T K' by an error-free splitting of K' (value-only evaluations).
+//
+// Every entry of K'_fu lies in [0, 1] (a stationary profile without its amplitude), so it IS a fixed-point number:
+//
+//   q = rint(K' 2^53) = sum_p a_p 256^p,   a_p in [-128, 127],  p = 0..6      (balanced digits: the bytes of (q + C) ^ C,
+//                                                                              C = 0x80 in each of the seven bytes)
+//   Phi_IJ = 2^-106 sum_n q_nI q_nJ = 2^-106 sum_{p + r >= 6} 256^(p + r) sum_n a_p,nI a_r,nJ  +  truncation
+//
+// * |K' - q 2^-53| <= 2^-54: exact for K' >= 1/2, an ABSOLUTE error below half an ulp of 1.0 otherwise.
+// * digit products are exact in int32: a group g = p + r - 6 holds 7 - g pairs of |a_p a_r| <= 2^14 -- 7 x 2^14 x 16384 rows < 2^31,
+//   so a split never spans more than I8_SPLIT_ROWS = 16384 rows; the fold to fp64 (7 terms) happens once per split and tile.
+// * 28 of the 49 digit pairs are kept (p + r >= 6); the dropped ones are < 6 x 2^-52 per product in the worst case, zero-mean
+//   (balanced digits) and ~2^-52 typically: below the rounding of ONE fp64 product, where the fp64 SYRK rounds every one of its
+//   N accumulation steps.  Measured against long-double arithmetic (tools/i8_syrk_proto.hip): 2.4-2.8e-16 of max |Phi|.
+//
+// Why: v_mfma_i32_32x32x32_i8 runs 32 768 MACs in 32 cycles against 1 024 in 64 for v_mfma_f64_16x16x4_f64 -- 64 x the rate for
+// 28 x the MACs.  What is left of that on real operands is decided by POWER, not issue slots: on full-entropy bytes the chip
+// clocks the int8 pipe down to ~1.78 GHz (profiles/r03_i8_rates.txt: 1 764 TMAC/s sustained), and every byte moved costs
+// clock as well.  Measured at C5 (N = 2^20, M = 1024): 13.6 ms against 16.0 ms for the fp64 contraction.
+//
+// Layout.  Digit planes Q[rb][p][m][16 bytes]: digit p of data rows 16 rb .. 16 rb + 15 of inducing column m -- 7 bytes per
+// element (the fp64 K'_fu has 8) and ONE ds_read_b128 is a lane's whole MFMA operand (lane l <-> column l % 32, rows
+// 16 (l / 32) + 0..15 of a 32-row step; both operands are the same K' rows, so the k-order inside an operand cancels).
+// Workgroup = 128 x 64 tile of the lower triangle x one split of the rows; 4 waves (one per SIMD), each 64 x 32 = two 32 x 32
+// MFMA tiles x 7 group accumulators = 224 accumulator registers.  32-row stages (42 KB) travel global -> LDS by LDS-DMA through a
+// ring of three; per step a wave issues its 21 operand reads FIRST, then its 11 DMA pieces of the next-but-one stage, then the
+// 56 MFMAs -- a ds_read issued behind a global_load_lds of the same wave waits for that DMA to land (measured: +430 cycles per
+// step).  Register staging instead of LDS-DMA was slower (15.5 ms), see the prototype.
+#include "sgp_common.hpp"
+#include "sgp_stream.hpp"
+
+namespace sgp {
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
+
+constexpr int I8_NP = 7;                                  // digit planes
+constexpr int I8_TR = 128, I8_TC = 64;                    // tile of Phi per workgroup
+constexpr int I8_SCOLS = I8_TR + I8_TC;                   // columns staged per workgroup
+constexpr int I8_STAGE_BYTES = 2 * I8_NP * I8_SCOLS * 16; // 32 rows = 2 row blocks of 16
+constexpr int I8_NSTAGE = 3;
+constexpr int I8_PIECES = 2 * I8_NP * 3;                  // 1 KB LDS-DMA pieces per stage (3 groups of 64 columns)
+constexpr int I8_PPW = (I8_PIECES + 3) / 4;               // pieces per wave (the last slots of waves 2, 3 repeat a piece)
+constexpr int I8_LDS_BYTES = I8_NSTAGE * I8_STAGE_BYTES;  // 129 024
+
+// ---------------------------------------------------------------------------------------------
+// 1. kernel assembly into digit planes:  thread <-> inducing column m, 256 rows per workgroup (as kfu_assemble_kernel);
+//    per 16 rows a thread stores seven 16-byte vectors, consecutive threads consecutive addresses (4 KB per plane and workgroup).
+//    bpart[rowblock][m] = sum_n k'(x_n, z_m) y_n falls out of the same loop in fp64 (the digits are not involved).
+// ---------------------------------------------------------------------------------------------
+template <int DP, int KID>
+__global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
+                                                         const double* __restrict__ Zs, int64_t row0, int64_t N, int M, int Mp,
+                                                         uint8_t* __restrict__ Q, double* __restrict__ bpart) {
+  __shared__ double xs[ASM_ROWS][DP];
+  __shared__ double ysh[ASM_ROWS];
+  const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;  // row inside this super-chunk's Q
+  {
+    const double* src = Xs + (row0 + rbase) * DP;
+    double* dst = &xs[0][0];
+    for (int e = threadIdx.x; e < ASM_ROWS * DP; e += 256) dst[e] = src[e];
+    ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
+  }
+  __syncthreads();
+  const int m = blockIdx.y * 256 + threadIdx.x;
+  if (m >= Mp) return;
+  const double zmask = m < M ? 1.0 : 0.0;
+  double zr[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) zr[j] = Zs[(size_t)m * DP + j];
+
+  constexpr unsigned long long C = 0x0080808080808080ULL;
+  double bacc = 0.0;
+  for (int g = 0; g < ASM_ROWS / 16; ++g) {
+    unsigned lo[16], hi[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = g * 16 + e;
+      const int64_t n = row0 + rbase + i;
+      double r2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const double df = xs[i][j] - zr[j];
+        r2 = fma(df, df, r2);
+      }
+      const double msk = n < N ? zmask : 0.0;
+      double kv = kprofile<KID>(r2) * msk;
+      bacc = fma(kv, ysh[i], bacc);
+      // a NaN distance (NaN in X / Z / a lengthscale) has no digits: it reaches the bound through b (fp64) instead; values a
+      // hair above 1 (the Matern polynomials round there) clamp to 1
+      kv = kv < 1.0 ? kv : (kv == kv ? 1.0 : 0.0);
+      const unsigned long long q = (unsigned long long)__builtin_rint(kv * 0x1p53);
+      const unsigned long long qq = (q + C) ^ C;
+      lo[e] = (unsigned)qq;
+      hi[e] = (unsigned)(qq >> 32);
+    }
+    const size_t rb = (size_t)(rbase / 16 + g);
+#pragma unroll
+    for (int p = 0; p < I8_NP; ++p) {
+      const unsigned* src = p < 4 ? lo : hi;
+      const unsigned b = p & 3;
+      const unsigned sel = b | ((4 + b) << 8);  // byte b of the second operand, then byte b of the first
+      i4v v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned t01 = __builtin_amdgcn_perm(src[4 * j + 1], src[4 * j], sel);
+        const unsigned t23 = __builtin_amdgcn_perm(src[4 * j + 3], src[4 * j + 2], sel);
+        v[j] = (int)__builtin_amdgcn_perm(t23, t01, 0x05040100u);
+      }
+      __builtin_nontemporal_store(v, reinterpret_cast<i4v*>(Q + ((rb * I8_NP + p) * Mp + m) * 16));
+    }
+  }
+  bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bacc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. contraction.  UM = which of the wave's two 32 x 32 MFMA tiles lie on or below the diagonal (bit u): diagonal tiles skip
+//    the rest -- an idle matrix pipe is clock headroom for the other SIMDs here, not a wasted slot.
+// ---------------------------------------------------------------------------------------------
+template <int UM>
+__device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
+                                             int J0, int accumulate, double* __restrict__ out, int wave, int lane) {
+  const int wi = wave >> 1, wj = wave & 1;
+  const int l32 = lane & 31, lh = lane >> 5;
+  i16v acc[2][I8_NP];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int g = 0; g < I8_NP; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][g][r] = 0;
+
+  // DMA piece k of this wave: e = wave + 4 k -> (row block in the stage, plane, column group)
+  auto dma_piece = [&](int64_t c, int slot, int k) {
+    const uint8_t* gbase = Q + (size_t)(2 * c) * I8_NP * Mp * 16;
+    uint8_t* sbase = lds + slot * I8_STAGE_BYTES;
+    int e = wave + 4 * k;
+    if (e >= I8_PIECES) e -= I8_PIECES;  // repeat: the same bytes to the same place
+    const int rbl = e / (I8_NP * 3), rem = e % (I8_NP * 3), p = rem / 3, cg = rem % 3;
+    const int col = cg < 2 ? I0 + cg * 64 : J0;
+    const uint8_t* g = gbase + (((size_t)rbl * I8_NP + p) * Mp + col + lane) * 16;
+    uint8_t* s = sbase + ((rbl * I8_NP + p) * I8_SCOLS + cg * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)s, 16, 0, 0);
+  };
+  auto dma = [&](int64_t c, int slot) {
+#pragma unroll
+    for (int k = 0; k < I8_PPW; ++k) dma_piece(c, slot, k);
+  };
+  // batch p = A-plane p against B-planes 6 - p .. 6 (2, 4, .. 14 MFMAs); operands are read in the order the batches need them
+  auto compute = [&](int slot, int64_t cn, int slotn, bool pre) {
+    const uint8_t* sbase = lds + slot * I8_STAGE_BYTES + lh * (I8_NP * I8_SCOLS * 16);
+    i4v b[I8_NP], a[I8_NP][2];
+    if (UM != 0) {
+#pragma unroll
+      for (int p = 0; p < I8_NP; ++p) {
+        b[I8_NP - 1 - p] = *reinterpret_cast<const i4v*>(sbase + ((I8_NP - 1 - p) * I8_SCOLS + I8_TR + wj * 32 + l32) * 16);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (UM & (1 << u)) a[p][u] = *reinterpret_cast<const i4v*>(sbase + (p * I8_SCOLS + wi * 64 + u * 32 + l32) * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (pre) {
+#pragma unroll
+      for (int k = 0; k < I8_PPW; ++k) dma_piece(cn, slotn, k);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (UM != 0) {
+#pragma unroll
+      for (int p = 0; p < I8_NP; ++p)
+#pragma unroll
+        for (int r = I8_NP - 1 - p; r < I8_NP; ++r)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            if (UM & (1 << u))
+              acc[u][p + r - (I8_NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p][u], b[r], acc[u][p + r - (I8_NP - 1)], 0, 0, 0);
+    }
+  };
+
+  if (c0 < c1) {
+    dma(c0, 0);
+    if (c0 + 1 < c1) dma(c0 + 1, 1);
+    for (int64_t c = c0; c < c1; ++c) {
+      const int slot = (int)((c - c0) % I8_NSTAGE);
+      // my pieces of stage c have landed once at most one younger stage's pieces are outstanding; the raw barrier (no fence:
+      // a __syncthreads() would drain the DMA in flight) then makes everybody's pieces visible
+      if (c + 1 < c1)
+        __builtin_amdgcn_s_waitcnt((I8_PPW & 15) | ((I8_PPW >> 4) << 14) | (7 << 4) | (15 << 8));  // vmcnt(11)
+      else
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));                                         // vmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(slot, c + 2, (int)((c + 2 - c0) % I8_NSTAGE), c + 2 < c1);
+    }
+  }
+  // fold the significance groups: value = sum_g acc_g 2^(8 g - 58)   (= 2^-106 256^(g + 6)); 128 x 128 slab tile, this half
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!(UM & (1 << u))) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int g = 0; g < I8_NP; ++g) v = fma((double)acc[u][g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
+      const int row = wi * 64 + u * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+      double* dst = out + row * TILE + wj * 32 + l32;
+      *dst = accumulate ? *dst + v : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void i8_syrk_tile_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit,
+                                                              int ntiles, int ntiles128, int accumulate, double* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t i8_lds[];
+  // id -> (xcd, tile, split group): the tiles of a split share id % 8, i.e. one XCD under round-robin dispatch (as syrk_tile_kernel)
+  const int id = blockIdx.x;
+  const int xcd = id & 7, jj = id >> 3;
+  const int t = jj % ntiles, split = (jj / ntiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  // tile t -> (ti, tj): row block ti (128 rows) has 2 (ti + 1) column blocks of 64
+  int ti = (int)((sqrtf(4.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) <= t) ++ti;
+  while (ti * (ti + 1) > t) --ti;
+  const int tj = t - ti * (ti + 1);
+  const int I0 = ti * I8_TR, J0 = tj * I8_TC;
+  const int64_t per = (nsteps + nsplit - 1) / nsplit;
+  int64_t c0 = split * per, c1 = c0 + per;
+  if (c0 > nsteps) c0 = nsteps;
+  if (c1 > nsteps) c1 = nsteps;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* out = slab + ((size_t)split * ntiles128 + (ti * (ti + 1) / 2 + (tj >> 1))) * (TILE * TILE) + (tj & 1) * I8_TC;
+  // 32 x 32 MFMA tile u of wave (wi, wj): rows I0 + 64 wi + 32 u .., columns J0 + 32 wj ..; strictly above the diagonal iff
+  // its first column lies beyond its last row
+  const int wi = wave >> 1, wj = wave & 1;
+  int um = 0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (J0 + 32 * wj <= I0 + 64 * wi + 32 * u + 31) um |= 1 << u;
+  switch (um) {
+    case 3: i8_tile_loop<3>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
+    case 2: i8_tile_loop<2>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
+    case 1: i8_tile_loop<1>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
+    default: i8_tile_loop<0>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// splits of at most I8_SPLIT_ROWS rows (the int32 bound), a multiple of 8 (one XCD per residue), and -- when the rows allow
+// splits of >= 2048 rows -- the count below twice the minimum whose last round of 256 resident workgroups is fullest
+int i8_nsplit(int64_t rows, int Mp) {
+  const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1);
+  int64_t lo = (rows + I8_SPLIT_ROWS - 1) / I8_SPLIT_ROWS;
+  lo = (lo + 7) / 8 * 8;
+  if (lo < 8) lo = 8;
+  int64_t best = lo;
+  double best_waste = 2.0;
+  for (int64_t cand = lo; cand <= 2 * lo + 8; cand += 8) {
+    if (cand > lo && rows / cand < 2048) break;
+    const double r = (double)ntiles * (double)cand / 256.0;
+    const double rounds = (double)(int64_t)(r + 0.999999);
+    const double waste = (rounds - r) / rounds;
+    if (waste < best_waste - 1e-9) {
+      best_waste = waste;
+      best = cand;
+    }
+  }
+  return (int)best;
+}
+
+template <int DP>
+static void launch_digits(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs, int64_t row0,
+                          int64_t N, int M, int Mp, uint8_t* Q, double* bpart) {
+  switch (kid) {
+    case SGP_KERNEL_RBF: kfu_digits_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, bpart); break;
+    case SGP_KERNEL_MATERN32: kfu_digits_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, bpart); break;
+    default: kfu_digits_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, bpart); break;
+  }
+}
+
+// Digit planes of rows [row0, row0 + rows) (rows a multiple of ASM_ROWS) into Q (which starts at row0).
+void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0, int64_t rows,
+                 int64_t N, int M, uint8_t* Q, double* bpart, hipStream_t st) {
+  dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256);
+  switch (p.DP) {
+    case 2: launch_digits<2>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
+    case 4: launch_digits<4>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
+    case 8: launch_digits<8>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
+    case 16: launch_digits<16>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
+    case 24: launch_digits<24>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
+    default: launch_digits<32>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
+  }
+}
+
+// slab[split][128 x 128 tile of the lower triangle] (+)= this split's part of K'^T K' (without sf2^2), as syrk_tile_kernel
+// leaves it for reduce_phi_kernel.  rows: a multiple of 32; nsplit from i8_nsplit() (the same for every super-chunk).
+int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) != hipSuccess)
+      return SGP_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
+  i8_syrk_tile_kernel<<<nsplit * ntiles, 256, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab);
+  return SGP_OK;
+}
+
+}  // namespace sgp

@@ -1,0 +1,183 @@
+"""Pass-1 contraction on the integer matrix cores (csrc/sgp_suffstats_i8.hip, include/sgp.h: sgp_set_contraction).
+
+K'_fu in [0, 1] is split into seven balanced 8-bit digit planes, the 28 digit-pair GEMMs are exact int32 sums, the fold to
+fp64 happens once per split -- so the statistics have to meet the SAME tolerances as the fp64 contraction: against the golden
+fixtures (generated from the reference's stack, tests/golden/), against the CPU oracle on ragged shapes, through the bound,
+and at BASELINE's full size against the fp64 contraction of the same rows.  Every test forces the integer path (mode 2; the
+default mode 1 takes it for value-only calls on shards of >= 65536 rows) and checks that it actually ran.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import dev, golden_names, load_golden  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+KNAME = {0: "rbf", 1: "matern32", 2: "matern52"}
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def unpack(packed, M):
+    h = packed.cpu().numpy()
+    return h[:M * M].reshape(M, M), h[M * M:M * M + M], float(h[M * M + M]), float(h[M * M + M + 1])
+
+
+@pytest.fixture()
+def int8(engine):
+    prev = engine.lib.sgp_set_contraction(2)
+    yield engine
+    engine.lib.sgp_set_contraction(prev)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if int(load_golden(n)["kernel_id"]) in KNAME])
+def test_int8_suffstats_golden(int8, name):
+    engine = int8
+    G = load_golden(name)
+    M = G["Z"].shape[0]
+    packed = engine.suffstats(dev(G["X"], engine), dev(G["y"], engine), dev(G["Z"], engine), G["ls"], float(G["sf2"]),
+                              KNAME[int(G["kernel_id"])])
+    assert engine.lib.sgp_contraction_last() == 1
+    Phi, b, yy, kappa = unpack(packed, M)
+    assert relerr(Phi, G["Phi"]) < 1e-12
+    assert relerr(b, G["b"]) < 1e-12
+    assert abs(yy - float(G["yy"])) < 1e-12 * abs(float(G["yy"]))
+    assert abs(kappa - float(G["kappa"])) < 1e-12 * abs(float(G["kappa"]))
+    assert np.array_equal(Phi, Phi.T)
+
+
+@pytest.mark.parametrize("kid", [0, 1, 2])
+@pytest.mark.parametrize("N,M,d", [(1, 1, 1), (15, 3, 2), (17, 130, 4), (1000, 129, 5), (4097, 257, 8), (333, 64, 18), (2500, 40, 32),
+                                   (700, 384, 3), (33000, 640, 2)])
+def test_int8_suffstats_vs_oracle_shapes(int8, N, M, d, kid):
+    from oracle import vfe_oracle as O
+    engine = int8
+    g = torch.Generator().manual_seed(N * 7 + M)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.randn(N, dtype=torch.float64, generator=g)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g)
+    Z[0] = X[0]  # k' = 1 exactly: the top of the digit range
+    ls = 0.7 + torch.rand(d, dtype=torch.float64, generator=g) * math.sqrt(d)
+    st = O.suffstats(X, y, Z, ls, 1.7, kid)
+    packed = engine.suffstats(X.to(engine.device), y.to(engine.device), Z.to(engine.device), ls.tolist(), 1.7, KNAME[kid])
+    assert engine.lib.sgp_contraction_last() == 1
+    Phi, b, yy, kappa = unpack(packed, M)
+    assert relerr(Phi, st.Phi.numpy()) < 1e-12
+    assert relerr(b, st.b.numpy()) < 1e-11
+    assert abs(yy - st.yy) <= 1e-12 * abs(st.yy)
+    assert abs(kappa - st.kappa) <= 1e-12 * abs(st.kappa)
+
+
+def test_int8_phi_is_the_exact_sum_of_digitised_products(int8):
+    """The property the design rests on: Phi from the integer cores equals the EXACT sum of products of the digitised values
+    q = rint(K' 2^53) -- up to the dropped digit pairs (< 6 x 2^-52 per product, zero-mean) and one fp64 fold.  Host side: q from
+    the fp64 K'_fu the library itself assembles (Kfu_out), the products in Python integers."""
+    engine = int8
+    g = torch.Generator().manual_seed(5)
+    N, M, d = 777, 9, 2
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
+    kfu = engine.kfu_buffer(N, M)
+    engine.suffstats(X, y, Z, [1.1, 0.9], 1.0, "rbf", kfu=kfu)  # fp64 path (a kept K'_fu rules the integer path out)
+    assert engine.lib.sgp_contraction_last() == 0
+    Mp = 128
+    K = kfu.view(-1, Mp)[:N, :M].cpu().numpy()
+    q = np.rint(K * 2.0 ** 53).astype(np.int64)
+    exact = [[sum(int(a) * int(b) for a, b in zip(q[:, i], q[:, j])) for j in range(M)] for i in range(M)]
+    packed = engine.suffstats(X, y, Z, [1.1, 0.9], 1.0, "rbf")
+    assert engine.lib.sgp_contraction_last() == 1
+    Phi = packed[:M * M].view(M, M).cpu().numpy()
+    worst = 0.0
+    for i in range(M):
+        for j in range(M):
+            ref = exact[i][j] / 2.0 ** 106  # one rounding of an exact rational
+            worst = max(worst, abs(Phi[i, j] - ref))
+    # dropped digit pairs: < 6 x 2^-52 per product in the worst case, zero-mean; N products
+    assert worst < 6 * 2.0 ** -52 * math.sqrt(N) * 4, worst
+    assert worst < 5e-16 * float(np.abs(Phi).max())
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if int(load_golden(n)["kernel_id"]) in KNAME])
+def test_int8_bound_golden(int8, name):
+    """The bound through the streaming order with the statistics from the integer cores: the tolerances of
+    test_bound_and_grads_golden (1e-9 on F; 1e-8 on the duplicate-inducing-row fixture)."""
+    import ggp_amd
+    engine = int8
+    G = load_golden(name)
+    cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), kernel=KNAME[int(G["kernel_id"])], jitter=float(G["jitter"]),
+                                engine=engine, form="streaming")
+    F, parts = cb.value(dev(G["Z"], engine), G["ls"], float(G["sf2"]), float(G["s2"]))
+    assert engine.lib.sgp_contraction_last() == 1
+    ill = float(G["grad_rtol"]) > 1e-6
+    tolF = (1e-8 if ill else 1e-9) * max(1.0, abs(float(G["F"])))
+    assert abs(F - float(G["F"])) < tolF, (F, float(G["F"]))
+
+
+def test_int8_super_chunks_accumulate(int8):
+    """K'_fu budget below the shard: the digit planes are built and contracted super-chunk by super-chunk into the same slabs."""
+    engine = int8
+    g = torch.Generator().manual_seed(11)
+    N, M, d = 3000, 140, 3
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
+    ref = engine.suffstats(X, y, Z, [1.0] * d, 1.2, "rbf").clone()
+    engine.lib.sgp_set_kfu_budget_bytes(1024 * 256 * 8)  # 1024 rows of the padded 256 columns at a time: 3 super-chunks
+    try:
+        got = engine.suffstats(X, y, Z, [1.0] * d, 1.2, "rbf").clone()
+        assert engine.lib.sgp_contraction_last() == 1
+    finally:
+        engine.lib.sgp_set_kfu_budget_bytes(0)
+    assert relerr(got[:M * M].cpu().numpy(), ref[:M * M].cpu().numpy()) < 1e-14
+    assert relerr(got[M * M:].cpu().numpy(), ref[M * M:].cpu().numpy()) < 1e-13
+
+
+def test_int8_nan_input_reaches_the_bound(int8):
+    engine = int8
+    X = torch.randn(300, 2, dtype=torch.float64)
+    X[17, 1] = float("nan")
+    y = torch.randn(300, dtype=torch.float64)
+    Z = torch.randn(20, 2, dtype=torch.float64)
+    packed = engine.suffstats(X.to(engine.device), y.to(engine.device), Z.to(engine.device), [1.0, 1.0], 1.0, "rbf")
+    assert engine.lib.sgp_contraction_last() == 1
+    assert bool(torch.isnan(packed).any())
+
+
+def test_int8_full_size_against_fp64_contraction(engine):
+    """BASELINE C5 (N = 2^20 padded rows of the 1M, M = 1024, d = 8): the default mode takes the integer cores for the value-only
+    evaluation; its statistics against the fp64 contraction of the same rows, and the bound from both."""
+    import bench
+    import ggp_amd
+    N, M, d = bench.N_TOTAL, bench.M_IND, bench.DIM
+    X, y, Z = bench.synth(N, M, d)
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    prev = engine.lib.sgp_set_contraction(1)
+    try:
+        a = engine.suffstats(Xd, yd, Zd, [bench.LS] * d, bench.SF ** 2, "rbf").clone()
+        assert engine.lib.sgp_contraction_last() == 1, "the default rule must take the integer cores at the headline shape"
+        engine.lib.sgp_set_contraction(0)
+        b = engine.suffstats(Xd, yd, Zd, [bench.LS] * d, bench.SF ** 2, "rbf").clone()
+        assert engine.lib.sgp_contraction_last() == 0
+        pa, pb = a[:M * M], b[:M * M]
+        # the fp64 contraction rounds each of its 2^20 / splits accumulation steps: ~1e-14 of max |Phi| between the two
+        assert float((pa - pb).abs().max()) < 5e-14 * float(pb.abs().max())
+        assert torch.equal(a[M * M:], b[M * M:])  # b, yy, kappa never touch the digits
+        cb = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=engine)
+        engine.lib.sgp_set_contraction(1)
+        F1, _ = cb.value(Zd, [bench.LS] * d, bench.SF ** 2, bench.SN ** 2)
+        assert engine.lib.sgp_contraction_last() == 1
+        engine.lib.sgp_set_contraction(0)
+        F0, _ = cb.value(Zd, [bench.LS] * d, bench.SF ** 2, bench.SN ** 2)
+        assert abs(F1 - F0) < 1e-9 * abs(F0), (F1, F0)
+    finally:
+        engine.lib.sgp_set_contraction(prev)
