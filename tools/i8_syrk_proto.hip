@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(const uint8_t* __restri
 
   // DMA pieces of this wave: e = wave + 4 k -> (row block in stage, plane, column group)
   auto dma_piece = [&](int64_t c, int slot, int k) {
-    const uint8_t* gbase = Q + (size_t)(2 * c) * NP * Mp * 16;
+    const uint8_t* gbase = Q + (size_t)(2 * (MODE == 5 ? (c & 63) : c)) * NP * Mp * 16;  // MODE 5: every workgroup re-reads 2048 rows (L2-resident)
     uint8_t* sbase = lds + slot * STAGE_BYTES;
     int e = wave + 4 * k;
     if (e >= PIECES) e -= PIECES;  // repeat: same bytes to the same place
@@ -339,9 +339,157 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_rs_kernel(const uint8_t* __res
     }
 }
 
+
+// ---- v4: DMA pieces issued in the shadow of the MFMAs (precomputed offsets: saddr + 32-bit lane offset, M0 = base + constant), and
+//      the last HOLD_N MFMAs of a step held back to cover the next step's operand reads ----------------------------------------
+#ifndef HOLD_R
+#define HOLD_R 3   // batch 6 (A-plane 6) against B-planes HOLD_R .. 6 is issued after the NEXT step's reads
+#endif
+#ifndef DMA_EVERY
+#define DMA_EVERY 4
+#endif
+#ifndef DMA_FIRST
+#define DMA_FIRST 6
+#endif
+__constant__ int g_map;  // 0: the tiles of a split on one XCD (id % 8), 1: split-major ids (a split's tiles dispatched together, over all XCDs)
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void i8_syrk_v4_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit, int ntiles,
+                                                            double* __restrict__ slab, unsigned long long* __restrict__ stamp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int id = blockIdx.x;
+  int t, split;
+  if (g_map == 0) {
+    const int xcd = id & 7, jj = id >> 3;
+    t = jj % ntiles;
+    split = (jj / ntiles) * 8 + xcd;
+  } else {
+    t = id % ntiles;
+    split = id / ntiles;
+  }
+  if (split >= nsplit) return;
+  int ti = (int)((sqrtf(4.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) <= t) ++ti;
+  while (ti * (ti + 1) > t) --ti;
+  const int tj = t - ti * (ti + 1);
+  const int I0 = ti * TR, J0 = tj * TC;
+  const int64_t per = (nsteps + nsplit - 1) / nsplit;
+  const int64_t c0 = split * per, c1 = (c0 + per < nsteps) ? c0 + per : nsteps;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int l32 = lane & 31, lh = lane >> 5;
+
+  i16 acc[2][NP];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int g = 0; g < NP; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][g][r] = 0;
+
+  unsigned goff[PPW];
+  int soff[PPW];
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {
+    int e = wave + 4 * k;
+    if (e >= PIECES) e -= PIECES;
+    const int rbl = e / (NP * 3), rem = e % (NP * 3), p = rem / 3, cg = rem % 3;
+    const int col = cg < 2 ? I0 + cg * 64 : J0;
+    goff[k] = (unsigned)(((rbl * NP + p) * Mp + col + lane) * 16);
+    soff[k] = __builtin_amdgcn_readfirstlane(((rbl * NP + p) * SCOLS + cg * 64) * 16);
+  }
+  const size_t gstride = (size_t)2 * NP * Mp * 16;  // bytes per 32-row step
+  auto dma_piece = [&](const uint8_t* gbase, int sbase, int k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + goff[k]),
+                                     (__attribute__((address_space(3))) void*)(lds + sbase + soff[k]), 16, 0, 0);
+  };
+
+  const unsigned long long cy0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  i4 ao[2], bo[NP];  // operands of the held-back MFMAs
+  if (c0 < c1) {
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) dma_piece(Q + (size_t)c0 * gstride, 0, k);
+    if (c0 + 1 < c1) {
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) dma_piece(Q + (size_t)(c0 + 1) * gstride, STAGE_BYTES, k);
+    }
+    for (int64_t c = c0; c < c1; ++c) {
+      const int slot = (int)((c - c0) % NSTAGE), slot2 = (int)((c + 2 - c0) % NSTAGE);
+      if (c + 1 < c1)
+        __builtin_amdgcn_s_waitcnt((PPW & 15) | ((PPW >> 4) << 14) | (7 << 4) | (15 << 8));
+      else
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const uint8_t* sb = lds + slot * STAGE_BYTES + lh * (NP * SCOLS * 16);
+      i4 b[NP], a[NP][2];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        b[NP - 1 - p] = *reinterpret_cast<const i4*>(sb + ((NP - 1 - p) * SCOLS + TR + wj * 32 + l32) * 16);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a[p][u] = *reinterpret_cast<const i4*>(sb + (p * SCOLS + wi * 64 + u * 32 + l32) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c > c0) {  // the previous step's held-back MFMAs: the matrix pipe works while this step's operands arrive
+#pragma unroll
+        for (int r = HOLD_R; r < NP; ++r)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[u][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ao[u], bo[r], acc[u][r], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool pre = MODE != 1 && c + 2 < c1;
+      const uint8_t* gnext = Q + (size_t)(MODE == 5 ? ((c + 2) & 63) : (c + 2)) * gstride;
+      const int snext = slot2 * STAGE_BYTES;
+      int issued = 0, kpiece = 0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int r = NP - 1 - p; r < (p == NP - 1 ? HOLD_R : NP); ++r) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            acc[u][p + r - (NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p][u], b[r], acc[u][p + r - (NP - 1)], 0, 0, 0);
+            ++issued;
+            if (issued >= DMA_FIRST && (issued - DMA_FIRST) % DMA_EVERY == 0 && kpiece < PPW) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (pre) dma_piece(gnext, snext, kpiece);
+              __builtin_amdgcn_sched_barrier(0);
+              ++kpiece;
+            }
+          }
+        }
+      }
+      static_assert(DMA_FIRST + DMA_EVERY * (PPW - 1) <= 56 - 2 * (NP - HOLD_R), "every DMA piece must find its MFMA");
+      ao[0] = a[NP - 1][0];
+      ao[1] = a[NP - 1][1];
+#pragma unroll
+      for (int r = HOLD_R; r < NP; ++r) bo[r] = b[r];
+    }
+#pragma unroll
+    for (int r = HOLD_R; r < NP; ++r)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ao[u], bo[r], acc[u][r], 0, 0, 0);
+  }
+  if (tid == 0 && id == 0) {
+    stamp[0] = __builtin_amdgcn_s_memtime() - cy0;
+    stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    stamp[2] = (unsigned long long)(c1 - c0);
+  }
+  double* out = slab + ((size_t)split * ntiles + t) * (TR * TC);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int g = 0; g < NP; ++g) v = fma((double)acc[u][g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
+      const int row = wi * 64 + u * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+      out[row * TC + wj * 32 + l32] = v;
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int MODE, bool RS = false>
+template <int MODE, int RS = 0>
 static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384) {
   const int Mp = (M + 127) / 128 * 128;
   const int64_t nsteps = N / 32;
@@ -358,7 +506,7 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
   digits_kernel<<<dim3((Mp + 255) / 256, (unsigned)(N / 16)), 256>>>(N / 16, Mp, Q);
   CK(hipDeviceSynchronize());
   const size_t shm = (size_t)NSTAGE * STAGE_BYTES;
-  auto kern = RS ? i8_syrk_rs_kernel<MODE> : i8_syrk_kernel<MODE>;
+  auto kern = RS == 2 ? i8_syrk_v4_kernel<MODE> : RS == 1 ? i8_syrk_rs_kernel<MODE> : i8_syrk_kernel<MODE>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const int grid = nsplit * ntiles;
   hipEvent_t e0, e1;
@@ -376,7 +524,7 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
   const double f64_equiv = (double)N * M * M * 1e-9 / ms;  // the accounting of bench.py: N M^2 flops for the lower triangle, GFLOP/ms = TFLOP/s
   const double macs = (double)N * ntiles * TR * TC * 28.0;
   printf("%s mode %d  N %lld M %d: %d splits x %d tiles = %d workgroups, %.3f ms, int8 %.1f TMAC/s (%.2f of 2447), fp64-equivalent %.1f TFLOP/s\n",
-         RS ? "reg-staged" : "lds-dma", MODE, (long long)N, Mp, nsplit, ntiles, grid, ms, macs / (ms * 1e-3) / 1e12, macs / (ms * 1e-3) / 1e12 / 2447.0, f64_equiv);
+         RS == 2 ? "v4" : RS == 1 ? "reg-staged" : "lds-dma", MODE, (long long)N, Mp, nsplit, ntiles, grid, ms, macs / (ms * 1e-3) / 1e12, macs / (ms * 1e-3) / 1e12 / 2447.0, f64_equiv);
   unsigned long long hs[3];
   CK(hipMemcpy(hs, stamp, 24, hipMemcpyDeviceToHost));
   printf("  workgroup 0: %.0f cycles per 32-row step (1792 = matrix pipe alone), clock %.0f MHz\n", (double)hs[0] / (double)hs[2], (double)hs[0] / ((double)hs[1] * 10.0) * 1e3);
@@ -411,16 +559,15 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 1048576;
   const int M = argc > 2 ? atoi(argv[2]) : 1024;
-  run<0>(8192, 256, true, 1);
-  run<0, true>(8192, 256, true, 1);
-  run<0, true>(40960, 384, true, 1, 4096);
-  run<0>(N, M, false, 3);
-  run<1>(N, M, false, 3);
-  run<2>(N, M, false, 3);
-  for (int sr = 16384; sr >= 4096; sr /= 4) {
+  int one = 1, zero = 0;
+  run<0, 2>(8192, 256, true, 1);
+  for (int sr = 16384; sr >= 4096; sr /= 2) {
     printf("-- %d rows per split\n", sr);
-    run<0, true>(N, M, false, 3, sr);
-    run<1, true>(N, M, false, 3, sr);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &zero, 4));
+    run<0, 2>(N, M, false, 3, sr);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &one, 4));
+    run<0, 2>(N, M, false, 3, sr);
   }
+  run<0, 2>(8192, 256, true, 1);
   return 0;
 }
