@@ -8,8 +8,11 @@ N rows are split into G contiguous shards (strong scaling: the job is fixed, one
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).  Extra keys:
   leapfrog_per_s    : value + gradient wrt (lengthscales, sig_f, sig_n) evaluations / s, same run, same data
-  roofline          : the dominant kernel of an evaluation, `syrk_tile_kernel` (pass-1 contraction), against the fp64
-                      matrix peak.  achieved = the kernel's OWN algorithmic work N M (M + 1) flop / its HIP-event time
+  roofline          : the dominant kernel of the timed evaluations: `i8_syrk_tile_kernel` (pass-1 contraction on the integer
+                      matrix cores, what value-only evaluations of big shards run) against the dense int8 peak, with the
+                      fp64-equivalent rate beside it; `roofline_fp64_contraction` is `syrk_tile_kernel` (the fp64 contraction
+                      of value + gradient evaluations) against the fp64 matrix peak.  achieved = the kernel's OWN algorithmic
+                      work (N M (M + 1) flop; x 28 int8 op for the digit-pair products) / its HIP-event time
                       (events recorded by the library on the launch stream right around the kernel: sgp_timing_*).
                       `pass1` inside it times kernel assembly + contraction together against SURVEY section 8d's
                       whole-evaluation W_fwd; traffic = HBM bytes of the kernel from the newest profiles/*_pmc_hbm_traffic.csv
@@ -38,6 +41,8 @@ M_IND = 1024
 DIM = 8
 LS, SF, SN, JITTER = 2.0, 1.0, 0.3, 1e-6
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= 256 CU x 2.4 GHz x 128 flop/clk/CU); see DESIGN.md
+INT8_MATRIX_PEAK_TOPS = 5033.0  # dense int8 (= 2 x the dense bf16 peak: 256 CU x 4 SIMD x 2.4 GHz x 2048 op/clk), MI355X_MICROARCH.md
+INT8_SUSTAINED_TOPS = 3528.0    # measured: back-to-back 32x32x32 int8 MFMAs on full-entropy operands (profiles/r03_i8_rates.txt)
 
 
 def pmc_traffic(kernel_substr):
@@ -245,10 +250,21 @@ def main():
             t = ctypes.c_float(0.0)
             assert eng.lib.sgp_timing_last_ms(slot, ctypes.byref(t)) == 0
             ms[slot].append(t.value)
-    eng.lib.sgp_timing_enable(0)
     del kfu
     med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
     assemble_ms, syrk_ms, kbar_ms = med[0], med[1], med[2]
+    # pass 1 as the timed evaluations (value only, nobody keeps K'_fu) run it: on big shards the library contracts on the INTEGER
+    # matrix cores (include/sgp.h: sgp_set_contraction; csrc/sgp_suffstats_i8.hip) -- same statistics, different dominant kernel
+    mv = {0: [], 1: []}
+    for _ in range(reps):
+        eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf", out=packed)
+        for slot in mv:
+            t = ctypes.c_float(0.0)
+            assert eng.lib.sgp_timing_last_ms(slot, ctypes.byref(t)) == 0
+            mv[slot].append(t.value)
+    int8_eval = eng.lib.sgp_contraction_last() == 1
+    eng.lib.sgp_timing_enable(0)
+    digits_ms, i8_ms = (sorted(v)[len(v) // 2] for v in (mv[0], mv[1]))
     Mp = (args.m + 127) // 128 * 128
     kfu_bytes = 8.0 * ((n_local + 255) // 256 * 256) * Mp
     syrk_flops = float(n_local) * args.m * (args.m + 1)            # the contraction's own work: lower triangle, 2 flop / MAC
@@ -258,6 +274,10 @@ def main():
     syrk_traffic, syrk_file = pmc_traffic("syrk_tile_kernel") if default_cfg else (None, None)
     kbar_traffic, kbar_file = pmc_traffic("kbar_contract_kernel") if default_cfg else (None, None)
     syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12
+    i8_traffic, i8_file = pmc_traffic("i8_syrk_tile_kernel") if default_cfg else (None, None)
+    q_bytes = 7.0 * ((n_local + 255) // 256 * 256) * Mp          # digit planes: 7 bytes per element of K'_fu
+    i8_ops = 28.0 * syrk_flops                                   # 28 digit-pair products per fp64 product, 2 op per MAC
+    i8_tops = i8_ops / (i8_ms * 1e-3) / 1e12
     kbar_tf = kbar_flops / (kbar_ms * 1e-3) / 1e12
     note = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE in separate passes "
             "(tools/profile_round.sh), read from %s; not collected in this run")
@@ -321,7 +341,10 @@ def main():
                                         "streaming (Phi = K_uf K_fu over the row shards, W = L^-1 Phi L^-T in the replicated tail)")},
         "leapfrog_per_s": leap_per_s, "ms_per_leapfrog": 1e3 / leap_per_s,
         "F": last["F"], "F_per_datum": last["F"] / args.n,
-        "roofline": {"bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction, this rank's shard)",
+        "roofline": None,
+        "roofline_fp64_contraction": {
+                     "bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction on the fp64 matrix cores: what a value + gradient evaluation runs, "
+                                                "and value-only ones with sgp_set_contraction(0))",
                      "achieved": syrk_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tf / FP64_MATRIX_PEAK_TFLOPS,
                      "ms": syrk_ms, "algorithmic_flops": syrk_flops, "algorithmic_flops_formula": "N M (M + 1): lower triangle of Phi, 2 flop per MAC",
                      "algorithmic_bytes": kfu_bytes, "traffic": syrk_traffic,
@@ -342,6 +365,33 @@ def main():
                      "achieved": kfu_bytes / (assemble_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": kfu_bytes / (assemble_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": kfu_bytes},
     }
+    if int8_eval:
+        # the dominant kernel of the timed evaluations: the contraction on the integer matrix cores.  Its roofline is the int8
+        # one; the fp64-equivalent rate (the work it REPLACES over its time) is what compares with the fp64 contraction above.
+        res["roofline"] = {
+            "bound": "mfma", "kernel": "sgp::i8_syrk_tile_kernel (pass-1 contraction of the timed evaluations: K'_fu as 7 balanced 8-bit digit "
+                                       "planes, 28 exact int32 digit-pair products on v_mfma_i32_32x32x32_i8, one fp64 fold per split)",
+            "achieved": i8_tops, "peak": INT8_MATRIX_PEAK_TOPS, "unit": "TOP/s", "frac": i8_tops / INT8_MATRIX_PEAK_TOPS, "ms": i8_ms,
+            "algorithmic_ops": i8_ops, "algorithmic_ops_formula": "28 N M (M + 1): 28 of the 49 digit pairs of every fp64 product, 2 op per MAC",
+            "sustained_peak": INT8_SUSTAINED_TOPS, "frac_of_sustained_peak": i8_tops / INT8_SUSTAINED_TOPS,
+            "sustained_peak_note": "back-to-back v_mfma_i32_32x32x32_i8 on full-entropy operands, no memory traffic: the chip clocks down to "
+                                   "~1.78 GHz (profiles/r03_i8_rates.txt) -- power, not issue slots, bounds this kernel",
+            "fp64_equivalent": {"achieved": syrk_flops / (i8_ms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": syrk_flops / (i8_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                                "note": "N M (M + 1) flop of the fp64 contraction it replaces over its own time; > 1 = faster than the fp64 matrix peak allows"},
+            "algorithmic_bytes": q_bytes, "traffic": i8_traffic, "traffic_ratio": (i8_traffic / q_bytes) if i8_traffic else None,
+            "traffic_note": (note % i8_file) if i8_file else None,
+            "pass1": {"kernels": "kfu_digits_kernel + i8_syrk_tile_kernel", "ms": digits_ms + i8_ms, "fp64_pass1_ms": assemble_ms + syrk_ms},
+            "accuracy": "as the fp64 contraction: |K' - q 2^-53| <= 2^-54, digit products exact, dropped pairs < 6 x 2^-52 per product and "
+                        "zero-mean; 2.4-2.8e-16 of max |Phi| against long double (tests/test_int8_contraction.py, tools/i8_syrk_proto.hip)"}
+        res["config"]["contraction"] = "int8 digit planes on the integer matrix cores (error-free split of K'_fu, fp64 result)"
+        res["assembly_digits"] = {"bound": "valu", "kernel": "sgp::kfu_digits_kernel<8,0>", "ms": digits_ms,
+                                  "achieved": q_bytes / (digits_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": q_bytes / (digits_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": q_bytes,
+                                  "note": "exp + 53-bit fixed-point conversion + byte transposition per element: fp64 / integer VALU bound, not HBM bound"}
+    else:
+        res["roofline"] = dict(res["roofline_fp64_contraction"])
+        res["config"]["contraction"] = "fp64 matrix cores"
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

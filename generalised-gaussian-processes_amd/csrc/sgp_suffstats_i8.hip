@@ -23,9 +23,10 @@
 // 16 (l / 32) + 0..15 of a 32-row step; both operands are the same K' rows, so the k-order inside an operand cancels).
 // Workgroup = 128 x 64 tile of the lower triangle x one split of the rows; 4 waves (one per SIMD), each 64 x 32 = two 32 x 32
 // MFMA tiles x 7 group accumulators = 224 accumulator registers.  32-row stages (42 KB) travel global -> LDS by LDS-DMA through a
-// ring of three; per step a wave issues its 21 operand reads FIRST, then its 11 DMA pieces of the next-but-one stage, then the
-// 56 MFMAs -- a ds_read issued behind a global_load_lds of the same wave waits for that DMA to land (measured: +430 cycles per
-// step).  Register staging instead of LDS-DMA was slower (15.5 ms), see the prototype.
+// ring of three; per step a wave issues its 21 operand reads FIRST -- a ds_read issued behind a global_load_lds of the same wave
+// waits for that DMA to land (measured: +430 cycles per step) -- then 8 MFMAs held back from the previous step, then this
+// step's MFMAs with the 11 DMA pieces of the next-but-one stage in their shadow.  Register staging instead of LDS-DMA was
+// slower (15.5 ms), so was a split-major workgroup order; see tools/i8_syrk_proto.hip for the measured alternatives.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
 
@@ -117,6 +118,16 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 // 2. contraction.  UM = which of the wave's two 32 x 32 MFMA tiles lie on or below the diagonal (bit u): diagonal tiles skip
 //    the rest -- an idle matrix pipe is clock headroom for the other SIMDs here, not a wasted slot.
 // ---------------------------------------------------------------------------------------------
+constexpr int I8_HOLD_R = 3;     // batch 6 (A-plane 6) against B-planes I8_HOLD_R .. 6 is issued after the NEXT step's operand reads
+constexpr int I8_DMA_FIRST = 6;  // the first DMA piece goes out after this many MFMAs of a step, then one every I8_DMA_EVERY
+constexpr int I8_DMA_EVERY = 4;
+static_assert(I8_DMA_FIRST + I8_DMA_EVERY * (I8_PPW - 1) <= 56 - 2 * (I8_NP - I8_HOLD_R), "every DMA piece must find its MFMA");
+
+// One step = 32 data rows: [wait for my pieces of stage c, barrier] -> 21 operand reads -> the 8 MFMAs held back from the previous
+// step (the matrix pipe works while this step's operands arrive) -> this step's 48 MFMAs in batch order (batch p = A-plane p
+// against B-planes 6 - p .. 6) with the 11 LDS-DMA pieces of stage c + 2 issued in their shadow (precomputed lane offsets + a
+// uniform base: 4 instructions per piece).  All reads come before all DMAs of a step: a ds_read issued behind a global_load_lds
+// of the same wave waits for that DMA to land.
 template <int UM>
 __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
                                              int J0, int accumulate, double* __restrict__ out, int wave, int lane) {
@@ -130,58 +141,36 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[u][g][r] = 0;
 
-  // DMA piece k of this wave: e = wave + 4 k -> (row block in the stage, plane, column group)
-  auto dma_piece = [&](int64_t c, int slot, int k) {
-    const uint8_t* gbase = Q + (size_t)(2 * c) * I8_NP * Mp * 16;
-    uint8_t* sbase = lds + slot * I8_STAGE_BYTES;
+  // DMA piece k of this wave: e = wave + 4 k -> (row block in the stage, plane, column group); the last slots of waves 2, 3
+  // repeat their first pieces (the same bytes to the same place) so that every wave counts 11 per stage
+  unsigned goff[I8_PPW];
+  int soff[I8_PPW];
+#pragma unroll
+  for (int k = 0; k < I8_PPW; ++k) {
     int e = wave + 4 * k;
-    if (e >= I8_PIECES) e -= I8_PIECES;  // repeat: the same bytes to the same place
+    if (e >= I8_PIECES) e -= I8_PIECES;
     const int rbl = e / (I8_NP * 3), rem = e % (I8_NP * 3), p = rem / 3, cg = rem % 3;
     const int col = cg < 2 ? I0 + cg * 64 : J0;
-    const uint8_t* g = gbase + (((size_t)rbl * I8_NP + p) * Mp + col + lane) * 16;
-    uint8_t* s = sbase + ((rbl * I8_NP + p) * I8_SCOLS + cg * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)s, 16, 0, 0);
+    goff[k] = (unsigned)(((rbl * I8_NP + p) * Mp + col + lane) * 16);
+    soff[k] = __builtin_amdgcn_readfirstlane(((rbl * I8_NP + p) * I8_SCOLS + cg * 64) * 16);
+  }
+  const size_t gstride = (size_t)2 * I8_NP * Mp * 16;  // bytes of Q per 32-row step
+  auto dma_piece = [&](const uint8_t* gbase, int sbase, int k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + goff[k]),
+                                     (__attribute__((address_space(3))) void*)(lds + sbase + soff[k]), 16, 0, 0);
   };
-  auto dma = [&](int64_t c, int slot) {
-#pragma unroll
-    for (int k = 0; k < I8_PPW; ++k) dma_piece(c, slot, k);
-  };
-  // batch p = A-plane p against B-planes 6 - p .. 6 (2, 4, .. 14 MFMAs); operands are read in the order the batches need them
-  auto compute = [&](int slot, int64_t cn, int slotn, bool pre) {
-    const uint8_t* sbase = lds + slot * I8_STAGE_BYTES + lh * (I8_NP * I8_SCOLS * 16);
-    i4v b[I8_NP], a[I8_NP][2];
-    if (UM != 0) {
-#pragma unroll
-      for (int p = 0; p < I8_NP; ++p) {
-        b[I8_NP - 1 - p] = *reinterpret_cast<const i4v*>(sbase + ((I8_NP - 1 - p) * I8_SCOLS + I8_TR + wj * 32 + l32) * 16);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (UM & (1 << u)) a[p][u] = *reinterpret_cast<const i4v*>(sbase + (p * I8_SCOLS + wi * 64 + u * 32 + l32) * 16);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (pre) {
-#pragma unroll
-      for (int k = 0; k < I8_PPW; ++k) dma_piece(cn, slotn, k);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (UM != 0) {
-#pragma unroll
-      for (int p = 0; p < I8_NP; ++p)
-#pragma unroll
-        for (int r = I8_NP - 1 - p; r < I8_NP; ++r)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-            if (UM & (1 << u))
-              acc[u][p + r - (I8_NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p][u], b[r], acc[u][p + r - (I8_NP - 1)], 0, 0, 0);
-    }
-  };
+  auto mfma = [&](const i4v& a, const i4v& b, i16v& c) { c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); };
 
+  i4v ao[2], bo[I8_NP];  // operands of the held-back MFMAs
   if (c0 < c1) {
-    dma(c0, 0);
-    if (c0 + 1 < c1) dma(c0 + 1, 1);
+#pragma unroll
+    for (int k = 0; k < I8_PPW; ++k) dma_piece(Q + (size_t)c0 * gstride, 0, k);
+    if (c0 + 1 < c1) {
+#pragma unroll
+      for (int k = 0; k < I8_PPW; ++k) dma_piece(Q + (size_t)(c0 + 1) * gstride, I8_STAGE_BYTES, k);
+    }
     for (int64_t c = c0; c < c1; ++c) {
-      const int slot = (int)((c - c0) % I8_NSTAGE);
+      const int slot = (int)((c - c0) % I8_NSTAGE), slot2 = (int)((c + 2 - c0) % I8_NSTAGE);
       // my pieces of stage c have landed once at most one younger stage's pieces are outstanding; the raw barrier (no fence:
       // a __syncthreads() would drain the DMA in flight) then makes everybody's pieces visible
       if (c + 1 < c1)
@@ -190,7 +179,61 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
         __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));                                         // vmcnt(0)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      compute(slot, c + 2, (int)((c + 2 - c0) % I8_NSTAGE), c + 2 < c1);
+      const uint8_t* sb = lds + slot * I8_STAGE_BYTES + lh * (I8_NP * I8_SCOLS * 16);
+      i4v b[I8_NP], a[I8_NP][2];
+      if (UM != 0) {
+#pragma unroll
+        for (int p = 0; p < I8_NP; ++p) {
+          b[I8_NP - 1 - p] = *reinterpret_cast<const i4v*>(sb + ((I8_NP - 1 - p) * I8_SCOLS + I8_TR + wj * 32 + l32) * 16);
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            if (UM & (1 << u)) a[p][u] = *reinterpret_cast<const i4v*>(sb + (p * I8_SCOLS + wi * 64 + u * 32 + l32) * 16);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (UM != 0 && c > c0) {
+#pragma unroll
+        for (int r = I8_HOLD_R; r < I8_NP; ++r)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            if (UM & (1 << u)) mfma(ao[u], bo[r], acc[u][r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool pre = c + 2 < c1;
+      const uint8_t* gnext = Q + (size_t)(c + 2) * gstride;
+      const int snext = slot2 * I8_STAGE_BYTES;
+      int issued = 0, kpiece = 0;
+#pragma unroll
+      for (int p = 0; p < I8_NP; ++p) {
+#pragma unroll
+        for (int r = I8_NP - 1 - p; r < (p == I8_NP - 1 ? I8_HOLD_R : I8_NP); ++r) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (UM & (1 << u)) mfma(a[p][u], b[r], acc[u][p + r - (I8_NP - 1)]);
+            ++issued;
+            if (issued >= I8_DMA_FIRST && (issued - I8_DMA_FIRST) % I8_DMA_EVERY == 0 && kpiece < I8_PPW) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (pre) dma_piece(gnext, snext, kpiece);
+              __builtin_amdgcn_sched_barrier(0);
+              ++kpiece;
+            }
+          }
+        }
+      }
+      if (UM != 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (UM & (1 << u)) ao[u] = a[I8_NP - 1][u];
+#pragma unroll
+        for (int r = I8_HOLD_R; r < I8_NP; ++r) bo[r] = b[r];
+      }
+    }
+    if (UM != 0) {
+#pragma unroll
+      for (int r = I8_HOLD_R; r < I8_NP; ++r)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (UM & (1 << u)) mfma(ao[u], bo[r], acc[u][r]);
     }
   }
   // fold the significance groups: value = sum_g acc_g 2^(8 g - 58)   (= 2^-106 256^(g + 6)); 128 x 128 slab tile, this half
