@@ -271,10 +271,10 @@ def main():
     kbar_flops = 2.0 * float(n_local) * args.m * args.m             # Kbar_uf = 2 Phibar K_uf
     wfwd = algorithmic_flops_fwd(n_local, args.m, DIM)
     default_cfg = (args.n, args.m, world) == (N_TOTAL, M_IND, 1)
-    syrk_traffic, syrk_file = pmc_traffic("syrk_tile_kernel") if default_cfg else (None, None)
+    syrk_traffic, syrk_file = pmc_traffic("sgp::syrk_tile_kernel<") if default_cfg else (None, None)
     kbar_traffic, kbar_file = pmc_traffic("kbar_contract_kernel") if default_cfg else (None, None)
     syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12
-    i8_traffic, i8_file = pmc_traffic("i8_syrk_tile_kernel") if default_cfg else (None, None)
+    i8_traffic, i8_file = pmc_traffic("sgp::i8_syrk_tile_kernel(") if default_cfg else (None, None)
     q_bytes = 7.0 * ((n_local + 255) // 256 * 256) * Mp          # digit planes: 7 bytes per element of K'_fu
     i8_ops = 28.0 * syrk_flops                                   # 28 digit-pair products per fp64 product, 2 op per MAC
     i8_tops = i8_ops / (i8_ms * 1e-3) / 1e12
