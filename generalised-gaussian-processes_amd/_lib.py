@@ -49,6 +49,7 @@ PROTOTYPES = {
     "sgp_set_kfu_budget_bytes": (None, [_sz]),
     "sgp_set_contraction": (_i32, [_i32]),
     "sgp_contraction_last": (_i32, []),
+    "sgp_set_pass1_gate": (None, [_vp]),
     "sgp_suffstats_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_stats_packed_len": (_sz, [_i32]),

@@ -250,6 +250,7 @@ class CollapsedBound:
             res["linv"] = linv
             return res
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
+        gate = None
         # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
         # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)
         overlap = (self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
@@ -286,11 +287,19 @@ class CollapsedBound:
                     return K, e.kuu_factor(K, info=result[2])[0]
 
             result[0].record_stream(side)
-            pending = self._pool.submit(side_chain)
-        packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu)
+            # Value-only evaluations of big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
+            # graph (one cheap replay) this thread enqueues the chain itself and the contraction is gated on its end, so the
+            # chain runs beside kernel assembly; otherwise the helper thread enqueues it and it shares the chip with pass 1
+            if gr is not None and kfu is None and hasattr(e, "lib") and hasattr(e.lib, "sgp_set_pass1_gate"):
+                chain = side_chain()
+                gate = side.record_event()
+                pending = None
+            else:
+                pending = self._pool.submit(side_chain)
+        packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
         self._allreduce_stats(packed, int(Z.shape[0]))
         if overlap:
-            Kuu, linv = pending.result()
+            Kuu, linv = pending.result() if pending is not None else chain
             for t in (Kuu, linv):
                 t.record_stream(main)
             main.wait_stream(self._side)

@@ -569,6 +569,7 @@ static void head_block(const StreamPlan& p, int64_t nchunks, int* head_ns, int64
 // nobody keeps -- 2: the integer cores whenever the call allows it (tests).  SGP_CONTRACTION / sgp_set_contraction.
 static int g_contraction = -1;
 static int g_contraction_used = 0;  // what the last sgp_suffstats_fwd call ran: 0 fp64, 1 int8 digit planes
+static hipEvent_t g_pass1_gate = nullptr;  // one-shot: the integer contraction of the next call waits for it (sgp_set_pass1_gate)
 constexpr int64_t I8_MIN_ROWS = 65536;
 constexpr int I8_MIN_MP = 256;
 
@@ -617,6 +618,7 @@ extern "C" int sgp_set_contraction(int mode) {
   return prev;
 }
 extern "C" int sgp_contraction_last(void) { return g_contraction_used; }
+extern "C" void sgp_set_pass1_gate(void* hip_event) { g_pass1_gate = (hipEvent_t)hip_event; }
 
 extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { g_kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
 
@@ -689,6 +691,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   if (g_contraction < 0) g_contraction = getenv("SGP_CONTRACTION") ? atoi(getenv("SGP_CONTRACTION")) : 1;
   const bool use_i8 = !Kfu_out && p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && p.Npad >= I8_MIN_ROWS && p.Mp >= I8_MIN_MP));
   g_contraction_used = use_i8 ? 1 : 0;
+  if (!use_i8) g_pass1_gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
   if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
   if (use_i8) {
     // digit planes (7 bytes per element) live where the fp64 K'_fu (8 bytes) would; the split count is that of a full super-chunk
@@ -699,6 +702,10 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
       timing_begin(TIMING_ASSEMBLE, st);
       i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Q, w.bpart, st);
       timing_end(TIMING_ASSEMBLE, st);
+      // the integer contraction leaves no register file for anybody else (one 456-register wave per SIMD): a side-stream chain
+      // the caller wants done by the end of pass 1 (chol(K_uu)) has to finish beside the ASSEMBLY, so the contraction waits for it
+      if (g_pass1_gate && hipStreamWaitEvent(st, g_pass1_gate, 0) != hipSuccess) return SGP_ERR_LAUNCH;
+      g_pass1_gate = nullptr;
       timing_begin(TIMING_SYRK, st);
       if (i8_contract(Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st) != SGP_OK) return SGP_ERR_LAUNCH;
       timing_end(TIMING_SYRK, st);

@@ -85,31 +85,42 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
         r2 = fma(df, df, r2);
       }
       const double msk = n < N ? zmask : 0.0;
-      double kv = kprofile<KID>(r2) * msk;
+      const double kv = kprofile<KID>(r2) * msk;
       bacc = fma(kv, ysh[i], bacc);
-      // a NaN distance (NaN in X / Z / a lengthscale) has no digits: it reaches the bound through b (fp64) instead; values a
-      // hair above 1 (the Matern polynomials round there) clamp to 1
-      kv = kv < 1.0 ? kv : (kv == kv ? 1.0 : 0.0);
-      const unsigned long long q = (unsigned long long)__builtin_rint(kv * 0x1p53);
+      // q = rint(kv 2^53) without a 64-bit convert: hi = rint(kv 2^21) and the SIGNED remainder r = rint(kv 2^53 - hi 2^32) in
+      // [-2^31, 2^31], each read off the mantissa of a magic-constant sum (all four operations exact).  r sits in the low 33
+      // mantissa bits of tl as a two's-complement number: q = (hi - bit32) 2^32 + low32 -- also at the ties r = +-2^31, which a
+      // 32-bit reading would get wrong about once in 2^33 elements.  A NaN distance (NaN in X / Z / a lengthscale) gives q = 0 --
+      // it reaches the bound through b (fp64) instead; a Matern value an ulp above 1 gives q = 2^53 + 1, which seven digits hold.
+      const double th = fma(kv, 0x1p21, 0x1p52);
+      const double hf = th - 0x1p52;
+      const double tl = fma(-hf, 0x1p32, kv * 0x1p53) + 0x1.8p52;
+      const unsigned long long tb = (unsigned long long)__double_as_longlong(tl);
+      const unsigned q_hi = (unsigned)__double_as_longlong(th) - ((unsigned)(tb >> 32) & 1u);
+      const unsigned long long q = ((unsigned long long)q_hi << 32) | (unsigned)tb;
       const unsigned long long qq = (q + C) ^ C;
       lo[e] = (unsigned)qq;
       hi[e] = (unsigned)(qq >> 32);
     }
     const size_t rb = (size_t)(rbase / 16 + g);
+    // byte transposition, 4 elements x 4 bytes at a time (8 v_perm_b32 per 4 x 4 block): plane[p][j] = byte p of elements 4 j .. 4 j + 3
+    i4v plane[8];
 #pragma unroll
-    for (int p = 0; p < I8_NP; ++p) {
-      const unsigned* src = p < 4 ? lo : hi;
-      const unsigned b = p & 3;
-      const unsigned sel = b | ((4 + b) << 8);  // byte b of the second operand, then byte b of the first
-      i4v v;
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned t01 = __builtin_amdgcn_perm(src[4 * j + 1], src[4 * j], sel);
-        const unsigned t23 = __builtin_amdgcn_perm(src[4 * j + 3], src[4 * j + 2], sel);
-        v[j] = (int)__builtin_amdgcn_perm(t23, t01, 0x05040100u);
+      for (int h = 0; h < 2; ++h) {
+        const unsigned* s4 = (h ? hi : lo) + 4 * j;
+        const unsigned u0 = __builtin_amdgcn_perm(s4[1], s4[0], 0x05010400u), u1 = __builtin_amdgcn_perm(s4[1], s4[0], 0x07030602u);
+        const unsigned v0 = __builtin_amdgcn_perm(s4[3], s4[2], 0x05010400u), v1 = __builtin_amdgcn_perm(s4[3], s4[2], 0x07030602u);
+        plane[4 * h + 0][j] = (int)__builtin_amdgcn_perm(v0, u0, 0x05040100u);
+        plane[4 * h + 1][j] = (int)__builtin_amdgcn_perm(v0, u0, 0x07060302u);
+        plane[4 * h + 2][j] = (int)__builtin_amdgcn_perm(v1, u1, 0x05040100u);
+        if (h == 0) plane[3][j] = (int)__builtin_amdgcn_perm(v1, u1, 0x07060302u);  // (byte 7 of q is always zero: no eighth plane)
       }
-      __builtin_nontemporal_store(v, reinterpret_cast<i4v*>(Q + ((rb * I8_NP + p) * Mp + m) * 16));
     }
+#pragma unroll
+    for (int p = 0; p < I8_NP; ++p)
+      __builtin_nontemporal_store(plane[p], reinterpret_cast<i4v*>(Q + ((rb * I8_NP + p) * Mp + m) * 16));
   }
   bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bacc;
 }

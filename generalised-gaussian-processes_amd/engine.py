@@ -90,10 +90,11 @@ class HipEngine:
         return self.empty(self.lib.sgp_kfu_len(N, M))
 
     def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out: Optional[torch.Tensor] = None,
-                  kfu: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  kfu: Optional[torch.Tensor] = None, gate: Optional[torch.cuda.Event] = None) -> torch.Tensor:
         """Packed local statistics [Phi (M*M) | b (M) | yy | kappa] -- the buffer the all-reduce sums.
 
-        ``kfu`` (optional, from ``kfu_buffer``) keeps the assembled kernel block for ``suffstats_bwd``."""
+        ``kfu`` (optional, from ``kfu_buffer``) keeps the assembled kernel block for ``suffstats_bwd``.  ``gate``: an event
+        already recorded on another stream that the integer-core contraction waits for (include/sgp.h: sgp_set_pass1_gate)."""
         N, d = X.shape
         M = Z.shape[0]
         self._chk(Z, "Z")
@@ -107,6 +108,8 @@ class HipEngine:
             raise ValueError("unsupported shape N=%d M=%d d=%d (d <= %d, M <= %d)" % (N, M, d, _lib.SGP_MAX_DIM, _lib.SGP_MAX_INDUCING))
         ws = self._workspace("fwd_kfu" if kfu is not None else "fwd", nbytes)
         base = out.data_ptr()
+        if gate is not None and kfu is None:
+            self.lib.sgp_set_pass1_gate(C.c_void_p(gate.cuda_event))
         st = self.lib.sgp_suffstats_fwd(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
