@@ -287,12 +287,12 @@ class CollapsedBound:
                     return K, e.kuu_factor(K, info=result[2])[0]
 
             result[0].record_stream(side)
-            # Value-only evaluations of big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
+            # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
             # graph (one cheap replay) this thread enqueues the chain itself and the contraction is gated on its end, so the
             # chain runs beside kernel assembly; otherwise the helper thread enqueues it and it shares the chip with pass 1
             # (only where assembly outlasts the chain -- 2.0 ms vs 0.6 at N = 1M, M = 1024, but 0.3 vs 0.6 at an eighth of it,
             # where gating costs 0.1 ms: rows >= 300 M)
-            if (gr is not None and kfu is None and hasattr(e, "lib") and hasattr(e.lib, "sgp_set_pass1_gate")
+            if (gr is not None and hasattr(e, "lib") and hasattr(e.lib, "sgp_set_pass1_gate")
                     and int(self.X.shape[0]) >= 300 * int(Z.shape[0])):
                 chain = side_chain()
                 gate = side.record_event()

@@ -157,7 +157,7 @@ void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const doubl
 constexpr int I8_SPLIT_ROWS = 16384;  // rows per split at most: 7 digit pairs x 2^14 x 16384 rows < 2^31
 int i8_nsplit(int64_t rows, int Mp);
 void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0, int64_t rows,
-                 int64_t N, int M, uint8_t* Q, double* bpart, hipStream_t st);
+                 int64_t N, int M, uint8_t* Q, double* Kfu /* optional: the fp64 block too */, double* bpart, hipStream_t st);
 int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st);
 
 }  // namespace sgp

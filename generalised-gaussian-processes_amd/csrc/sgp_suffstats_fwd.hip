@@ -573,24 +573,34 @@ static hipEvent_t g_pass1_gate = nullptr;  // one-shot: the integer contraction 
 constexpr int64_t I8_MIN_ROWS = 65536;
 constexpr int I8_MIN_MP = 256;
 
+static int contraction_mode() {
+  if (g_contraction < 0) g_contraction = getenv("SGP_CONTRACTION") ? atoi(getenv("SGP_CONTRACTION")) : 1;
+  return g_contraction;
+}
+
 constexpr int BRED_G = 64;  // row groups of the two-stage b reduction
 struct FwdWs {
   double *Xs, *ys, *Zs, *Kfu, *slab, *bpart, *btmp, *yypart;
+  uint8_t* Q;  // digit planes of one super-chunk when the caller owns K'_fu (otherwise they live in Kfu)
   size_t bytes;
 };
-static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu) {
+// qrows: rows of one super-chunk of digit planes = the plan's sc_rows BEFORE a caller-owned K'_fu turns it into Npad
+static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qrows) {
   Carver c(ws);
   FwdWs w;
   w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
   w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
   w.Zs = c.take<double>((size_t)p.Mp * p.DP);
   int nslab = p.nsplit + HEAD_SPLITS_MAX;  // + the head block's splits
-  if (p.sc_rows > 0 && i8_nsplit(p.sc_rows, p.Mp) > nslab) nslab = i8_nsplit(p.sc_rows, p.Mp);  // the int8 contraction's own split count
+  if (qrows > 0 && i8_nsplit(qrows, p.Mp) > nslab) nslab = i8_nsplit(qrows, p.Mp);  // the int8 contraction's own split count
   w.slab = c.take<double>((size_t)nslab * p.ntiles * TILE * TILE);
   w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
+  // (own planes only when the integer path is forced for every call: the default rule never contracts a kept K'_fu on it)
+  w.Q = need_kfu ? reinterpret_cast<uint8_t*>(w.Kfu)
+                 : (contraction_mode() == 2 ? c.take<uint8_t>((size_t)(qrows > 0 ? qrows : 1) * p.Mp * 7) : nullptr);
   w.bytes = c.used();
   return w;
 }
@@ -630,7 +640,7 @@ extern "C" size_t sgp_kfu_len(int64_t N, int M) {
 static size_t fwd_workspace_bytes(int64_t N, int M, int d, bool library_kfu) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);
-  const size_t fast = carve_fwd(nullptr, p, library_kfu).bytes, comp = comp_fwd_workspace_bytes(N, M);  // one size for every kernel_id
+  const size_t fast = carve_fwd(nullptr, p, library_kfu, p.sc_rows).bytes, comp = comp_fwd_workspace_bytes(N, M);  // one size for every kernel_id
   return fast > comp ? fast : comp;
 }
 extern "C" size_t sgp_suffstats_workspace_bytes(int64_t N, int M, int d) { return fwd_workspace_bytes(N, M, d, true); }
@@ -652,8 +662,9 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     return comp_suffstats_fwd(X, ldx, y, Z, ldz, cs, N, M, d, Phi, b, yy, kappa, ws, ws_bytes, (hipStream_t)stream);
   }
   StreamPlan p = make_stream_plan(N, M, d);
+  const int64_t qrows = p.sc_rows;  // super-chunk of the digit planes (the library's K'_fu budget also when the caller owns K'_fu)
   if (Kfu_out) p.sc_rows = p.Npad;  // caller keeps the whole K'_fu: one super-chunk
-  FwdWs w = carve_fwd(ws, p, Kfu_out == nullptr);
+  FwdWs w = carve_fwd(ws, p, Kfu_out == nullptr, qrows);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
@@ -688,26 +699,30 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   int nslabs = p.nsplit;
   int head_ns = 0;
   int64_t head_chunks = 0;
-  if (g_contraction < 0) g_contraction = getenv("SGP_CONTRACTION") ? atoi(getenv("SGP_CONTRACTION")) : 1;
-  const bool use_i8 = !Kfu_out && p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && p.Npad >= I8_MIN_ROWS && p.Mp >= I8_MIN_MP));
+  (void)contraction_mode();
+  // (default rule: value-only calls.  With a kept K'_fu the assembly has to write the fp64 block AND the planes: pass 1 alone gains
+  // 1.85 ms at C5 -- 2.92 + 13.14 against 1.79 + 16.11 -- but the leapfrog it belongs to does not, 52.29 against 52.43 ms on one box:
+  // pass 2 runs into the power the integer contraction has just drawn.  Mode 2 takes the integer path there too, for the tests.)
+  const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && !Kfu_out && p.Npad >= I8_MIN_ROWS && p.Mp >= I8_MIN_MP));
   g_contraction_used = use_i8 ? 1 : 0;
   if (!use_i8) g_pass1_gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
   if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
   if (use_i8) {
-    // digit planes (7 bytes per element) live where the fp64 K'_fu (8 bytes) would; the split count is that of a full super-chunk
-    uint8_t* Q = reinterpret_cast<uint8_t*>(Kfu);
-    const int ns = i8_nsplit(p.sc_rows, p.Mp);
-    for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
-      const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
+    // digit planes (7 bytes per element) live where the library's fp64 K'_fu (8 bytes) would; with a caller-owned K'_fu (value +
+    // gradient: pass 2 reads the fp64 block) the assembly writes both and the planes take their own super-chunk of workspace.
+    // The split count is that of a full super-chunk.
+    const int ns = i8_nsplit(qrows, p.Mp);
+    for (int64_t r0 = 0; r0 < p.Npad; r0 += qrows) {
+      const int64_t rows = (p.Npad - r0) < qrows ? (p.Npad - r0) : qrows;
       timing_begin(TIMING_ASSEMBLE, st);
-      i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, Q, w.bpart, st);
+      i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Q, Kfu_out ? Kfu_out + (size_t)r0 * p.Mp : nullptr, w.bpart, st);
       timing_end(TIMING_ASSEMBLE, st);
       // the integer contraction leaves no register file for anybody else (one 456-register wave per SIMD): a side-stream chain
       // the caller wants done by the end of pass 1 (chol(K_uu)) has to finish beside the ASSEMBLY, so the contraction waits for it
       if (g_pass1_gate && hipStreamWaitEvent(st, g_pass1_gate, 0) != hipSuccess) return SGP_ERR_LAUNCH;
       g_pass1_gate = nullptr;
       timing_begin(TIMING_SYRK, st);
-      if (i8_contract(Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st) != SGP_OK) return SGP_ERR_LAUNCH;
+      if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st) != SGP_OK) return SGP_ERR_LAUNCH;
       timing_end(TIMING_SYRK, st);
       g_syrk_timed_rows = rows;
     }

@@ -49,10 +49,12 @@ constexpr int I8_LDS_BYTES = I8_NSTAGE * I8_STAGE_BYTES;  // 129 024
 //    per 16 rows a thread stores seven 16-byte vectors, consecutive threads consecutive addresses (4 KB per plane and workgroup).
 //    bpart[rowblock][m] = sum_n k'(x_n, z_m) y_n falls out of the same loop in fp64 (the digits are not involved).
 // ---------------------------------------------------------------------------------------------
-template <int DP, int KID>
+//    WK: the fp64 block K'_fu is written as well (a value + gradient evaluation: pass 2 reads it) -- 15 instead of 7 bytes per
+//    element, which puts the kernel back at the HBM-write ceiling.
+template <int DP, int KID, bool WK>
 __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
                                                          const double* __restrict__ Zs, int64_t row0, int64_t N, int M, int Mp,
-                                                         uint8_t* __restrict__ Q, double* __restrict__ bpart) {
+                                                         uint8_t* __restrict__ Q, double* __restrict__ Kfu, double* __restrict__ bpart) {
   __shared__ double xs[ASM_ROWS][DP];
   __shared__ double ysh[ASM_ROWS];
   const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;  // row inside this super-chunk's Q
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
       const double msk = n < N ? zmask : 0.0;
       const double kv = kprofile<KID>(r2) * msk;
       bacc = fma(kv, ysh[i], bacc);
+      if constexpr (WK) __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);
       // q = rint(kv 2^53) without a 64-bit convert: hi = rint(kv 2^21) and the SIGNED remainder r = rint(kv 2^53 - hi 2^32) in
       // [-2^31, 2^31], each read off the mantissa of a magic-constant sum (all four operations exact).  r sits in the low 33
       // mantissa bits of tl as a two's-complement number: q = (hi - bit32) 2^32 + low32 -- also at the ties r = +-2^31, which a
@@ -324,28 +327,37 @@ int i8_nsplit(int64_t rows, int Mp) {
   return (int)best;
 }
 
-template <int DP>
+template <int DP, bool WK>
 static void launch_digits(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs, int64_t row0,
-                          int64_t N, int M, int Mp, uint8_t* Q, double* bpart) {
+                          int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, double* bpart) {
   switch (kid) {
-    case SGP_KERNEL_RBF: kfu_digits_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, bpart); break;
-    case SGP_KERNEL_MATERN32: kfu_digits_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, bpart); break;
-    default: kfu_digits_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, bpart); break;
+    case SGP_KERNEL_RBF: kfu_digits_kernel<DP, SGP_KERNEL_RBF, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case SGP_KERNEL_MATERN32: kfu_digits_kernel<DP, SGP_KERNEL_MATERN32, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    default: kfu_digits_kernel<DP, SGP_KERNEL_MATERN52, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+  }
+}
+template <bool WK>
+static void launch_digits_dp(int DP, int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
+                             int64_t row0, int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, double* bpart) {
+  switch (DP) {
+    case 2: launch_digits<2, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case 4: launch_digits<4, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case 8: launch_digits<8, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case 16: launch_digits<16, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case 24: launch_digits<24, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    default: launch_digits<32, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
   }
 }
 
-// Digit planes of rows [row0, row0 + rows) (rows a multiple of ASM_ROWS) into Q (which starts at row0).
+// Digit planes of rows [row0, row0 + rows) (rows a multiple of ASM_ROWS) into Q (which starts at row0); Kfu (optional, starts at
+// row0 as well): the fp64 block of the same rows.
 void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0, int64_t rows,
-                 int64_t N, int M, uint8_t* Q, double* bpart, hipStream_t st) {
+                 int64_t N, int M, uint8_t* Q, double* Kfu, double* bpart, hipStream_t st) {
   dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256);
-  switch (p.DP) {
-    case 2: launch_digits<2>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
-    case 4: launch_digits<4>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
-    case 8: launch_digits<8>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
-    case 16: launch_digits<16>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
-    case 24: launch_digits<24>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
-    default: launch_digits<32>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, bpart); break;
-  }
+  if (Kfu)
+    launch_digits_dp<true>(p.DP, kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, Kfu, bpart);
+  else
+    launch_digits_dp<false>(p.DP, kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, nullptr, bpart);
 }
 
 // slab[split][128 x 128 tile of the lower triangle] (+)= this split's part of K'^T K' (without sf2^2), as syrk_tile_kernel

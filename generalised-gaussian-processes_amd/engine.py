@@ -108,7 +108,7 @@ class HipEngine:
             raise ValueError("unsupported shape N=%d M=%d d=%d (d <= %d, M <= %d)" % (N, M, d, _lib.SGP_MAX_DIM, _lib.SGP_MAX_INDUCING))
         ws = self._workspace("fwd_kfu" if kfu is not None else "fwd", nbytes)
         base = out.data_ptr()
-        if gate is not None and kfu is None:
+        if gate is not None:
             self.lib.sgp_set_pass1_gate(C.c_void_p(gate.cuda_event))
         st = self.lib.sgp_suffstats_fwd(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),

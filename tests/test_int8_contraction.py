@@ -80,7 +80,7 @@ def test_int8_suffstats_vs_oracle_shapes(int8, N, M, d, kid):
 def test_int8_phi_is_the_exact_sum_of_digitised_products(int8):
     """The property the design rests on: Phi from the integer cores equals the EXACT sum of products of the digitised values
     q = rint(K' 2^53) -- up to the dropped digit pairs (< 6 x 2^-52 per product, zero-mean) and one fp64 fold.  Host side: q from
-    the fp64 K'_fu the library itself assembles (Kfu_out), the products in Python integers."""
+    the fp64 K'_fu the same assembly launch writes beside the digit planes (Kfu_out), the products in Python integers."""
     engine = int8
     g = torch.Generator().manual_seed(5)
     N, M, d = 777, 9, 2
@@ -88,14 +88,12 @@ def test_int8_phi_is_the_exact_sum_of_digitised_products(int8):
     y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
     Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
     kfu = engine.kfu_buffer(N, M)
-    engine.suffstats(X, y, Z, [1.1, 0.9], 1.0, "rbf", kfu=kfu)  # fp64 path (a kept K'_fu rules the integer path out)
-    assert engine.lib.sgp_contraction_last() == 0
+    packed = engine.suffstats(X, y, Z, [1.1, 0.9], 1.0, "rbf", kfu=kfu)  # digit planes AND the fp64 block from one assembly
+    assert engine.lib.sgp_contraction_last() == 1
     Mp = 128
     K = kfu.view(-1, Mp)[:N, :M].cpu().numpy()
     q = np.rint(K * 2.0 ** 53).astype(np.int64)
     exact = [[sum(int(a) * int(b) for a, b in zip(q[:, i], q[:, j])) for j in range(M)] for i in range(M)]
-    packed = engine.suffstats(X, y, Z, [1.1, 0.9], 1.0, "rbf")
-    assert engine.lib.sgp_contraction_last() == 1
     Phi = packed[:M * M].view(M, M).cpu().numpy()
     worst = 0.0
     for i in range(M):
@@ -121,6 +119,48 @@ def test_int8_bound_golden(int8, name):
     ill = float(G["grad_rtol"]) > 1e-6
     tolF = (1e-8 if ill else 1e-9) * max(1.0, abs(float(G["F"])))
     assert abs(F - float(G["F"])) < tolF, (F, float(G["F"]))
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if int(load_golden(n)["kernel_id"]) in KNAME])
+def test_int8_value_and_grad_golden(int8, name):
+    """Value + gradient with pass 1 on the integer cores (the assembly writes the fp64 block pass 2 reads AND the digit planes):
+    the tolerances of test_bound_and_grads_golden."""
+    import ggp_amd
+    engine = int8
+    G = load_golden(name)
+    cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), kernel=KNAME[int(G["kernel_id"])], jitter=float(G["jitter"]),
+                                engine=engine, form="streaming")
+    F, g = cb.value_and_grad(dev(G["Z"], engine), G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
+    assert engine.lib.sgp_contraction_last() == 1
+    ill = float(G["grad_rtol"]) > 1e-6
+    assert abs(F - float(G["F"])) < (1e-8 if ill else 1e-9) * max(1.0, abs(float(G["F"])))
+    rt, rz = 1e-6, (1e-4 if ill else 1e-6)
+    assert relerr(g["ls"].numpy(), G["g_ls"]) < rt
+    assert abs(g["sf2"] - float(G["g_sf2"])) < rt * max(1.0, abs(float(G["g_sf2"])))
+    assert abs(g["s2"] - float(G["g_s2"])) < rt * max(1.0, abs(float(G["g_s2"])))
+    assert relerr(g["Z"].cpu().numpy(), G["g_Z"]) < rz
+
+
+def test_int8_kept_block_equals_the_fp64_assembly(engine):
+    """The fp64 K'_fu written beside the digit planes is bit-identical to the one kfu_assemble_kernel writes."""
+    g = torch.Generator().manual_seed(3)
+    N, M, d = 1500, 200, 5
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
+    blocks = []
+    prev = engine.lib.sgp_set_contraction(0)
+    try:
+        for mode in (0, 2):
+            engine.lib.sgp_set_contraction(mode)
+            kfu = engine.kfu_buffer(N, M)
+            kfu.fill_(float("nan"))
+            engine.suffstats(X, y, Z, [0.9] * d, 1.0, "matern52", kfu=kfu)
+            assert engine.lib.sgp_contraction_last() == (1 if mode == 2 else 0)
+            blocks.append(kfu.clone())
+    finally:
+        engine.lib.sgp_set_contraction(prev)
+    assert torch.equal(blocks[0], blocks[1])
 
 
 def test_int8_super_chunks_accumulate(int8):
