@@ -565,13 +565,14 @@ static void head_block(const StreamPlan& p, int64_t nchunks, int* head_ns, int64
 }
 
 // ---- which matrix cores contract (value-only evaluations) ------------------------------------------------------------------
-// 0: fp64 (syrk_tile_kernel), 1 (default): the integer cores (sgp_suffstats_i8.hip) where they win -- big shards whose K'_fu
+// 0: fp64 (syrk_tile_kernel), 1 (default): the integer cores (sgp_suffstats_i8.hip) where they win -- enough work, and a K'_fu
 // nobody keeps -- 2: the integer cores whenever the call allows it (tests).  SGP_CONTRACTION / sgp_set_contraction.
 static int g_contraction = -1;
 static int g_contraction_used = 0;  // what the last sgp_suffstats_fwd call ran: 0 fp64, 1 int8 digit planes
 static hipEvent_t g_pass1_gate = nullptr;  // one-shot: the integer contraction of the next call waits for it (sgp_set_pass1_gate)
-constexpr int64_t I8_MIN_ROWS = 65536;
-constexpr int I8_MIN_MP = 256;
+// default rule: rows x Mp^2 >= 2^32 (profiles/r03_i8_boundary.jsonl: 8192 x 1024, 30000 x 512, 65536 x 256, 1M x 128 win by 5-36 %;
+// 16384 x 256, 20000 x 384, 200000 x 100, 4096 x 512 lose -- too few 128 x 64 tiles x 16384-row splits to fill 256 CUs)
+constexpr double I8_MIN_WORK = 4294967296.0;
 
 static int contraction_mode() {
   if (g_contraction < 0) g_contraction = getenv("SGP_CONTRACTION") ? atoi(getenv("SGP_CONTRACTION")) : 1;
@@ -703,7 +704,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   // (default rule: value-only calls.  With a kept K'_fu the assembly has to write the fp64 block AND the planes: pass 1 alone gains
   // 1.85 ms at C5 -- 2.92 + 13.14 against 1.79 + 16.11 -- but the leapfrog it belongs to does not, 52.29 against 52.43 ms on one box:
   // pass 2 runs into the power the integer contraction has just drawn.  Mode 2 takes the integer path there too, for the tests.)
-  const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && !Kfu_out && p.Npad >= I8_MIN_ROWS && p.Mp >= I8_MIN_MP));
+  const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && !Kfu_out && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
   g_contraction_used = use_i8 ? 1 : 0;
   if (!use_i8) g_pass1_gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
   if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);

@@ -4,7 +4,7 @@ K'_fu in [0, 1] is split into seven balanced 8-bit digit planes, the 28 digit-pa
 fp64 happens once per split -- so the statistics have to meet the SAME tolerances as the fp64 contraction: against the golden
 fixtures (generated from the reference's stack, tests/golden/), against the CPU oracle on ragged shapes, through the bound,
 and at BASELINE's full size against the fp64 contraction of the same rows.  Every test forces the integer path (mode 2; the
-default mode 1 takes it for value-only calls on shards of >= 65536 rows) and checks that it actually ran.
+default mode 1 takes it for value-only calls with rows x M_p^2 >= 2^32) and checks that it actually ran.
 """
 import math
 import os

@@ -64,6 +64,12 @@ def time_eval(eng, N, M, d, reps=8):
 
 def main():
     eng = ggp_amd.HipEngine()
+    if "--boundary" in sys.argv:  # shapes around the default rule's thresholds (rows >= 65536, M > 128) and the multi-GPU shards of C5
+        for (N, M, d) in ((65536, 256, 8), (65536, 384, 2), (100000, 256, 2), (131072, 256, 8), (65536, 2048, 8), (500000, 1024, 8),
+                          (250000, 1024, 8), (40000, 1024, 8), (30000, 512, 18), (65536, 200, 8),
+                          (13279, 512, 18), (16384, 256, 8), (20000, 384, 4), (1000000, 128, 8), (200000, 100, 8), (8192, 1024, 8), (4096, 512, 8)):
+            print(json.dumps(time_eval(eng, N, M, d, reps=20)), flush=True)
+        return
     for (N, M, d, k) in ((500, 50, 1, "rbf"), (5000, 300, 8, "rbf"), (5000, 300, 3, "matern32"), (20000, 129, 2, "matern52"),
                          (70000, 1024, 8, "rbf"), (33000, 513, 18, "rbf")):
         print(json.dumps(stats_pair(eng, N, M, d, k)), flush=True)
