@@ -24,8 +24,8 @@
 // Workgroup = 128 x 64 tile of the lower triangle x one split of the rows; 4 waves (one per SIMD), each 64 x 32 = two 32 x 32
 // MFMA tiles x 7 group accumulators = 224 accumulator registers.  32-row stages (42 KB) travel global -> LDS by LDS-DMA through a
 // ring of three; per step a wave issues its 21 operand reads FIRST -- a ds_read issued behind a global_load_lds of the same wave
-// waits for that DMA to land (measured: +430 cycles per step) -- then 8 MFMAs held back from the previous step, then this
-// step's MFMAs with the 11 DMA pieces of the next-but-one stage in their shadow.  Register staging instead of LDS-DMA was
+// waits for that DMA to land (measured: +430 cycles per step) -- then the step's MFMAs with the 11 DMA pieces of the
+// next-but-one stage in their shadow.  Register staging instead of LDS-DMA was
 // slower (15.5 ms), so was a split-major workgroup order; see tools/i8_syrk_proto.hip for the measured alternatives.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
@@ -132,16 +132,15 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 // 2. contraction.  UM = which of the wave's two 32 x 32 MFMA tiles lie on or below the diagonal (bit u): diagonal tiles skip
 //    the rest -- an idle matrix pipe is clock headroom for the other SIMDs here, not a wasted slot.
 // ---------------------------------------------------------------------------------------------
-constexpr int I8_HOLD_R = 3;     // batch 6 (A-plane 6) against B-planes I8_HOLD_R .. 6 is issued after the NEXT step's operand reads
 constexpr int I8_DMA_FIRST = 6;  // the first DMA piece goes out after this many MFMAs of a step, then one every I8_DMA_EVERY
 constexpr int I8_DMA_EVERY = 4;
-static_assert(I8_DMA_FIRST + I8_DMA_EVERY * (I8_PPW - 1) <= 56 - 2 * (I8_NP - I8_HOLD_R), "every DMA piece must find its MFMA");
+static_assert(I8_DMA_FIRST + I8_DMA_EVERY * (I8_PPW - 1) <= 56, "every DMA piece must find its MFMA");
 
-// One step = 32 data rows: [wait for my pieces of stage c, barrier] -> 21 operand reads -> the 8 MFMAs held back from the previous
-// step (the matrix pipe works while this step's operands arrive) -> this step's 48 MFMAs in batch order (batch p = A-plane p
-// against B-planes 6 - p .. 6) with the 11 LDS-DMA pieces of stage c + 2 issued in their shadow (precomputed lane offsets + a
-// uniform base: 4 instructions per piece).  All reads come before all DMAs of a step: a ds_read issued behind a global_load_lds
-// of the same wave waits for that DMA to land.
+// One step = 32 data rows: [wait for my pieces of stage c, barrier] -> 21 operand reads -> the step's 56 MFMAs in batch order
+// (batch p = A-plane p against B-planes 6 - p .. 6: the first batches need the fewest operands) with the 11 LDS-DMA pieces of
+// stage c + 2 issued in their shadow (precomputed lane offsets + a uniform base: 4 instructions per piece).  All reads come before
+// all DMAs of a step: a ds_read issued behind a global_load_lds of the same wave waits for that DMA to land.  (Holding the last
+// 4-10 MFMAs of a step back to cover the next step's operand reads measured 1-2 % SLOWER: tools/i8_syrk_proto.hip -DHOLD_R.)
 template <int UM>
 __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
                                              int J0, int accumulate, double* __restrict__ out, int wave, int lane) {
@@ -175,7 +174,6 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
   };
   auto mfma = [&](const i4v& a, const i4v& b, i16v& c) { c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); };
 
-  i4v ao[2], bo[I8_NP];  // operands of the held-back MFMAs
   if (c0 < c1) {
 #pragma unroll
     for (int k = 0; k < I8_PPW; ++k) dma_piece(Q + (size_t)c0 * gstride, 0, k);
@@ -205,14 +203,6 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (UM != 0 && c > c0) {
-#pragma unroll
-        for (int r = I8_HOLD_R; r < I8_NP; ++r)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-            if (UM & (1 << u)) mfma(ao[u], bo[r], acc[u][r]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
       const bool pre = c + 2 < c1;
       const uint8_t* gnext = Q + (size_t)(c + 2) * gstride;
       const int snext = slot2 * I8_STAGE_BYTES;
@@ -220,7 +210,7 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
 #pragma unroll
       for (int p = 0; p < I8_NP; ++p) {
 #pragma unroll
-        for (int r = I8_NP - 1 - p; r < (p == I8_NP - 1 ? I8_HOLD_R : I8_NP); ++r) {
+        for (int r = I8_NP - 1 - p; r < I8_NP; ++r) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if (UM & (1 << u)) mfma(a[p][u], b[r], acc[u][p + r - (I8_NP - 1)]);
@@ -234,20 +224,6 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
           }
         }
       }
-      if (UM != 0) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (UM & (1 << u)) ao[u] = a[I8_NP - 1][u];
-#pragma unroll
-        for (int r = I8_HOLD_R; r < I8_NP; ++r) bo[r] = b[r];
-      }
-    }
-    if (UM != 0) {
-#pragma unroll
-      for (int r = I8_HOLD_R; r < I8_NP; ++r)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (UM & (1 << u)) mfma(ao[u], bo[r], acc[u][r]);
     }
   }
   // fold the significance groups: value = sum_g acc_g 2^(8 g - 58)   (= 2^-106 256^(g + 6)); 128 x 128 slab tile, this half

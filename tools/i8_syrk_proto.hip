@@ -560,14 +560,19 @@ int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 1048576;
   const int M = argc > 2 ? atoi(argv[2]) : 1024;
   int one = 1, zero = 0;
-  run<0, 2>(8192, 256, true, 1);
-  for (int sr = 16384; sr >= 4096; sr /= 2) {
-    printf("-- %d rows per split\n", sr);
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &zero, 4));
-    run<0, 2>(N, M, false, 3, sr);
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &one, 4));
-    run<0, 2>(N, M, false, 3, sr);
+  (void)one;
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &zero, 4));
+  if (argc > 3) {  // parameter sweep builds (-DHOLD_R= -DDMA_FIRST= -DDMA_EVERY=): the v4 kernel alone
+    run<0, 2>(8192, 256, true, 1);
+    run<0, 2>(N, M, false, 5);
+    run<0, 2>(N, M, false, 5);
+    return 0;
   }
   run<0, 2>(8192, 256, true, 1);
+  run<0>(N, M, false, 3);
+  run<0, 1>(N, M, false, 3);
+  run<0, 2>(N, M, false, 3);
+  run<5, 2>(N, M, false, 3);
+  run<1, 2>(N, M, false, 3);
   return 0;
 }
