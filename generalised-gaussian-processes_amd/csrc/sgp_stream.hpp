@@ -155,7 +155,35 @@ void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const doubl
 
 // implemented in sgp_suffstats_i8.hip: the pass-1 contraction on the integer matrix cores (error-free digit planes of K'_fu)
 constexpr int I8_SPLIT_ROWS = 16384;  // rows per split at most: 7 digit pairs x 2^14 x 16384 rows < 2^31
-int i8_nsplit(int64_t rows, int Mp);
+// splits of at most I8_SPLIT_ROWS rows (the int32 bound), a multiple of 8 (one XCD per residue), and -- when the rows allow
+// splits of >= 2048 rows -- the count below twice the minimum whose last round of 256 resident workgroups is fullest
+static inline int i8_nsplit(int64_t rows, int Mp) {
+  const int nrt = Mp / 128, ntiles = nrt * (nrt + 1);  // 128 x 64 tiles of the lower triangle
+  int64_t lo = (rows + I8_SPLIT_ROWS - 1) / I8_SPLIT_ROWS;
+  lo = (lo + 7) / 8 * 8;
+  if (lo < 8) lo = 8;
+  int64_t best = lo;
+  double best_waste = 2.0;
+  for (int64_t cand = lo; cand <= 2 * lo + 8; cand += 8) {
+    if (cand > lo && rows / cand < 2048) break;
+    const double r = (double)ntiles * (double)cand / 256.0;
+    const double rounds = (double)(int64_t)(r + 0.999999);
+    const double waste = (rounds - r) / rounds;
+    if (waste < best_waste - 1e-9) {
+      best_waste = waste;
+      best = cand;
+    }
+  }
+  return (int)best;
+}
+// 32-row steps [c0, c1) of split `split`: equal shares, the last ones short or empty
+__host__ __device__ inline void i8_split_steps(int64_t nsteps, int nsplit, int split, int64_t& c0, int64_t& c1) {
+  const int64_t per = (nsteps + nsplit - 1) / nsplit;
+  c0 = (int64_t)split * per;
+  c1 = c0 + per;
+  if (c0 > nsteps) c0 = nsteps;
+  if (c1 > nsteps) c1 = nsteps;
+}
 void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0, int64_t rows,
                  int64_t N, int M, uint8_t* Q, double* Kfu /* optional: the fp64 block too */, double* bpart, hipStream_t st);
 int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st);

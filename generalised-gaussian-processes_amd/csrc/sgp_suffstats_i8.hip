@@ -256,10 +256,8 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_tile_kernel(const uint8_t* __r
   while (ti * (ti + 1) > t) --ti;
   const int tj = t - ti * (ti + 1);
   const int I0 = ti * I8_TR, J0 = tj * I8_TC;
-  const int64_t per = (nsteps + nsplit - 1) / nsplit;
-  int64_t c0 = split * per, c1 = c0 + per;
-  if (c0 > nsteps) c0 = nsteps;
-  if (c1 > nsteps) c1 = nsteps;
+  int64_t c0, c1;
+  i8_split_steps(nsteps, nsplit, split, c0, c1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* out = slab + ((size_t)split * ntiles128 + (ti * (ti + 1) / 2 + (tj >> 1))) * (TILE * TILE) + (tj & 1) * I8_TC;
@@ -281,28 +279,6 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_tile_kernel(const uint8_t* __r
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// splits of at most I8_SPLIT_ROWS rows (the int32 bound), a multiple of 8 (one XCD per residue), and -- when the rows allow
-// splits of >= 2048 rows -- the count below twice the minimum whose last round of 256 resident workgroups is fullest
-int i8_nsplit(int64_t rows, int Mp) {
-  const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1);
-  int64_t lo = (rows + I8_SPLIT_ROWS - 1) / I8_SPLIT_ROWS;
-  lo = (lo + 7) / 8 * 8;
-  if (lo < 8) lo = 8;
-  int64_t best = lo;
-  double best_waste = 2.0;
-  for (int64_t cand = lo; cand <= 2 * lo + 8; cand += 8) {
-    if (cand > lo && rows / cand < 2048) break;
-    const double r = (double)ntiles * (double)cand / 256.0;
-    const double rounds = (double)(int64_t)(r + 0.999999);
-    const double waste = (rounds - r) / rounds;
-    if (waste < best_waste - 1e-9) {
-      best_waste = waste;
-      best = cand;
-    }
-  }
-  return (int)best;
-}
-
 template <int DP, bool WK>
 static void launch_digits(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs, int64_t row0,
                           int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, double* bpart) {

@@ -33,6 +33,22 @@ int main() {
         const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit), bps = (int)((nblocks + p.nsplit_b - 1) / p.nsplit_b);
         bad += check(SplitMap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, cps < 1 ? 1 : cps}, p.nsplit, nchunks, "pass1", N, M);
         bad += check(SplitMap{{p.taper_b[0], p.taper_b[1], p.taper_b[2], p.taper_b[3]}, bps < 1 ? 1 : bps}, p.nsplit_b, nblocks, "pass2", N, M);
+        // the integer contraction's splits: a multiple of 8, at most I8_SPLIT_ROWS rows each (the int32 bound of the digit-pair sums),
+        // tiling the 32-row steps of a super-chunk exactly once -- also for the short last super-chunk contracted with the same count
+        const int ns8 = i8_nsplit(p.sc_rows, p.Mp);
+        if (ns8 < 8 || ns8 % 8 != 0) { printf("FAIL i8 nsplit %d N=%lld M=%d\n", ns8, (long long)N, M); ++bad; }
+        for (int64_t rows : {p.sc_rows, p.Npad % p.sc_rows}) {
+          if (rows == 0) continue;
+          const int64_t nsteps = rows / 32;
+          int64_t expect = 0;
+          for (int sidx = 0; sidx < ns8; ++sidx) {
+            int64_t c0, c1;
+            i8_split_steps(nsteps, ns8, sidx, c0, c1);
+            if (c0 > c1 || (c1 - c0) * 32 > I8_SPLIT_ROWS || (c0 != c1 && c0 != expect)) { printf("FAIL i8 split %d N=%lld M=%d [%lld,%lld)\n", sidx, (long long)N, M, (long long)c0, (long long)c1); ++bad; break; }
+            if (c0 != c1) expect = c1;
+          }
+          if (expect != nsteps) { printf("FAIL i8 splits cover %lld of %lld steps N=%lld M=%d\n", (long long)expect, (long long)nsteps, (long long)N, M); ++bad; }
+        }
       }
   printf("stream plan check: %d cases, %d failures\n", cases, bad);
   return bad != 0;
