@@ -77,18 +77,27 @@ def test_int8_suffstats_vs_oracle_shapes(int8, N, M, d, kid):
     assert abs(kappa - st.kappa) <= 1e-12 * abs(st.kappa)
 
 
-def test_int8_phi_is_the_exact_sum_of_digitised_products(int8):
+@pytest.mark.parametrize("data", ["random", "lattice", "near_one"])
+def test_int8_phi_is_the_exact_sum_of_digitised_products(int8, data):
     """The property the design rests on: Phi from the integer cores equals the EXACT sum of products of the digitised values
     q = rint(K' 2^53) -- up to the dropped digit pairs (< 6 x 2^-52 per product, zero-mean) and one fp64 fold.  Host side: q from
     the fp64 K'_fu the same assembly launch writes beside the digit planes (Kfu_out), the products in Python integers."""
     engine = int8
     g = torch.Generator().manual_seed(5)
     N, M, d = 777, 9, 2
-    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g)
+    lsv = [1.1, 0.9]
+    if data == "lattice":   # the same few kernel values over and over: truncation errors that repeat instead of averaging out
+        gx = torch.arange(N, dtype=torch.float64)
+        X = torch.stack([(gx % 37) * 0.125, (gx // 37) * 0.25], 1)
+        Z = X[::97][:M].clone()
+    elif data == "near_one":  # lengthscale >> the data: every k' within 1e-3 of 1, the top of the digit range
+        lsv = [60.0, 45.0]
+    X, Z = X.to(engine.device), Z.to(engine.device)
     y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
-    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
     kfu = engine.kfu_buffer(N, M)
-    packed = engine.suffstats(X, y, Z, [1.1, 0.9], 1.0, "rbf", kfu=kfu)  # digit planes AND the fp64 block from one assembly
+    packed = engine.suffstats(X, y, Z, lsv, 1.0, "rbf", kfu=kfu)  # digit planes AND the fp64 block from one assembly
     assert engine.lib.sgp_contraction_last() == 1
     Mp = 128
     K = kfu.view(-1, Mp)[:N, :M].cpu().numpy()
