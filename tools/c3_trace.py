@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""C3 (N 13 279, d 18, M 512) value + gradient evaluations for a rocprofv3 --kernel-trace timeline (tools/last_eval_timeline.py)."""
 import sys, math, time, json, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ggp_amd
 eng = ggp_amd.HipEngine()
 N, d, M = 13279, 18, 512

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""One C5 evaluation (CollapsedBound.value) with the contraction on the fp64 cores (0) and under the default rule (1), with and
+without the side-stream K_uu chain; then pass 1 alone with its per-kernel HIP-event times.  One JSON object per line."""
 import sys, time, json, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, ggp_amd
 eng = ggp_amd.HipEngine()
 N, M, d = bench.N_TOTAL, bench.M_IND, bench.DIM
