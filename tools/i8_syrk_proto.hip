@@ -487,6 +487,121 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_v4_kernel(const uint8_t* __res
     }
 }
 
+
+// ---- v5: eight waves (two per SIMD), each one 32 x 32 MFMA tile x 7 group accumulators (112 registers): when one wave of a SIMD waits
+//      (barrier, operand reads, the ~60 cycles an LDS-DMA piece costs its issuer) the other one feeds the matrix pipe.  LDS reads
+//      go up by a third (14 per 28 MFMAs instead of 21 per 56); the LDS array has room (12 % active in v4).
+constexpr int PPW8 = (PIECES + 7) / 8;  // 6 pieces per wave and stage (the last slots repeat pieces)
+#ifndef DMA8_FIRST
+#define DMA8_FIRST 4
+#endif
+#ifndef DMA8_EVERY
+#define DMA8_EVERY 4
+#endif
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void i8_syrk_v5_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit, int ntiles,
+                                                            double* __restrict__ slab, unsigned long long* __restrict__ stamp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int id = blockIdx.x;
+  const int xcd = id & 7, jj = id >> 3;
+  const int t = jj % ntiles, split = (jj / ntiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  int ti = (int)((sqrtf(4.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) <= t) ++ti;
+  while (ti * (ti + 1) > t) --ti;
+  const int tj = t - ti * (ti + 1);
+  const int I0 = ti * TR, J0 = tj * TC;
+  const int64_t per = (nsteps + nsplit - 1) / nsplit;
+  const int64_t c0 = split * per, c1 = (c0 + per < nsteps) ? c0 + per : nsteps;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int l32 = lane & 31, lh = lane >> 5;
+
+  i16 acc[NP];
+#pragma unroll
+  for (int g = 0; g < NP; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+
+  unsigned goff[PPW8];
+  int soff[PPW8];
+#pragma unroll
+  for (int k = 0; k < PPW8; ++k) {
+    int e = wave + 8 * k;
+    if (e >= PIECES) e -= PIECES;
+    const int rbl = e / (NP * 3), rem = e % (NP * 3), p = rem / 3, cg = rem % 3;
+    const int col = cg < 2 ? I0 + cg * 64 : J0;
+    goff[k] = (unsigned)(((rbl * NP + p) * Mp + col + lane) * 16);
+    soff[k] = __builtin_amdgcn_readfirstlane(((rbl * NP + p) * SCOLS + cg * 64) * 16);
+  }
+  const size_t gstride = (size_t)2 * NP * Mp * 16;
+  auto dma_piece = [&](const uint8_t* gbase, int sbase, int k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + goff[k]),
+                                     (__attribute__((address_space(3))) void*)(lds + sbase + soff[k]), 16, 0, 0);
+  };
+
+  const unsigned long long cy0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  if (c0 < c1) {
+#pragma unroll
+    for (int k = 0; k < PPW8; ++k) dma_piece(Q + (size_t)c0 * gstride, 0, k);
+    if (c0 + 1 < c1) {
+#pragma unroll
+      for (int k = 0; k < PPW8; ++k) dma_piece(Q + (size_t)(c0 + 1) * gstride, STAGE_BYTES, k);
+    }
+    for (int64_t c = c0; c < c1; ++c) {
+      const int slot = (int)((c - c0) % NSTAGE), slot2 = (int)((c + 2 - c0) % NSTAGE);
+      if (MODE != 1 && c + 1 < c1)
+        __builtin_amdgcn_s_waitcnt((PPW8 & 15) | ((PPW8 >> 4) << 14) | (7 << 4) | (15 << 8));
+      else
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const uint8_t* sb = lds + slot * STAGE_BYTES + lh * (NP * SCOLS * 16);
+      i4 b[NP], a[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        b[NP - 1 - p] = *reinterpret_cast<const i4*>(sb + ((NP - 1 - p) * SCOLS + TR + wj * 32 + l32) * 16);
+        a[p] = *reinterpret_cast<const i4*>(sb + (p * SCOLS + wi * 32 + l32) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool pre = MODE != 1 && c + 2 < c1;
+      const uint8_t* gnext = Q + (size_t)(c + 2) * gstride;
+      const int snext = slot2 * STAGE_BYTES;
+      int issued = 0, kpiece = 0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int r = NP - 1 - p; r < NP; ++r) {
+          acc[p + r - (NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[r], acc[p + r - (NP - 1)], 0, 0, 0);
+          ++issued;
+          if (issued >= DMA8_FIRST && (issued - DMA8_FIRST) % DMA8_EVERY == 0 && kpiece < PPW8) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (pre) dma_piece(gnext, snext, kpiece);
+            __builtin_amdgcn_sched_barrier(0);
+            ++kpiece;
+          }
+        }
+      }
+      static_assert(DMA8_FIRST + DMA8_EVERY * (PPW8 - 1) <= 28, "every DMA piece must find its MFMA");
+    }
+  }
+  if (tid == 0 && id == 0) {
+    stamp[0] = __builtin_amdgcn_s_memtime() - cy0;
+    stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    stamp[2] = (unsigned long long)(c1 - c0);
+  }
+  double* out = slab + ((size_t)split * ntiles + t) * (TR * TC);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    double v = 0.0;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
+    const int row = wi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+    out[row * TC + wj * 32 + l32] = v;
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int MODE, int RS = 0>
@@ -506,16 +621,17 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
   digits_kernel<<<dim3((Mp + 255) / 256, (unsigned)(N / 16)), 256>>>(N / 16, Mp, Q);
   CK(hipDeviceSynchronize());
   const size_t shm = (size_t)NSTAGE * STAGE_BYTES;
-  auto kern = RS == 2 ? i8_syrk_v4_kernel<MODE> : RS == 1 ? i8_syrk_rs_kernel<MODE> : i8_syrk_kernel<MODE>;
+  auto kern = RS == 3 ? i8_syrk_v5_kernel<MODE> : RS == 2 ? i8_syrk_v4_kernel<MODE> : RS == 1 ? i8_syrk_rs_kernel<MODE> : i8_syrk_kernel<MODE>;
+  const int nthreads = RS == 3 ? 512 : 256;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const int grid = nsplit * ntiles;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  kern<<<grid, 256, shm>>>(Q, Mp, nsteps, nsplit, ntiles, slab, stamp);
+  kern<<<grid, nthreads, shm>>>(Q, Mp, nsteps, nsplit, ntiles, slab, stamp);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; ++r) kern<<<grid, 256, shm>>>(Q, Mp, nsteps, nsplit, ntiles, slab, stamp);
+  for (int r = 0; r < reps; ++r) kern<<<grid, nthreads, shm>>>(Q, Mp, nsteps, nsplit, ntiles, slab, stamp);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -524,7 +640,7 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
   const double f64_equiv = (double)N * M * M * 1e-9 / ms;  // the accounting of bench.py: N M^2 flops for the lower triangle, GFLOP/ms = TFLOP/s
   const double macs = (double)N * ntiles * TR * TC * 28.0;
   printf("%s mode %d  N %lld M %d: %d splits x %d tiles = %d workgroups, %.3f ms, int8 %.1f TMAC/s (%.2f of 2447), fp64-equivalent %.1f TFLOP/s\n",
-         RS == 2 ? "v4" : RS == 1 ? "reg-staged" : "lds-dma", MODE, (long long)N, Mp, nsplit, ntiles, grid, ms, macs / (ms * 1e-3) / 1e12, macs / (ms * 1e-3) / 1e12 / 2447.0, f64_equiv);
+         RS == 3 ? "v5 (8 waves)" : RS == 2 ? "v4" : RS == 1 ? "reg-staged" : "lds-dma", MODE, (long long)N, Mp, nsplit, ntiles, grid, ms, macs / (ms * 1e-3) / 1e12, macs / (ms * 1e-3) / 1e12 / 2447.0, f64_equiv);
   unsigned long long hs[3];
   CK(hipMemcpy(hs, stamp, 24, hipMemcpyDeviceToHost));
   printf("  workgroup 0: %.0f cycles per 32-row step (1792 = matrix pipe alone), clock %.0f MHz\n", (double)hs[0] / (double)hs[2], (double)hs[0] / ((double)hs[1] * 10.0) * 1e3);
@@ -569,6 +685,10 @@ int main(int argc, char** argv) {
     return 0;
   }
   run<0, 2>(8192, 256, true, 1);
+  run<0, 3>(8192, 256, true, 1);
+  run<0, 3>(40960, 384, true, 1, 4096);
+  run<0, 3>(N, M, false, 3);
+  run<1, 3>(N, M, false, 3);
   run<0>(N, M, false, 3);
   run<0, 1>(N, M, false, 3);
   run<0, 2>(N, M, false, 3);
