@@ -21,12 +21,10 @@
 // Layout.  Digit planes Q[rb][p][m][16 bytes]: digit p of data rows 16 rb .. 16 rb + 15 of inducing column m -- 7 bytes per
 // element (the fp64 K'_fu has 8) and ONE ds_read_b128 is a lane's whole MFMA operand (lane l <-> column l % 32, rows
 // 16 (l / 32) + 0..15 of a 32-row step; both operands are the same K' rows, so the k-order inside an operand cancels).
-// Workgroup = 128 x 64 tile of the lower triangle x one split of the rows; 4 waves (one per SIMD), each 64 x 32 = two 32 x 32
-// MFMA tiles x 7 group accumulators = 224 accumulator registers.  32-row stages (42 KB) travel global -> LDS by LDS-DMA through a
-// ring of three; per step a wave issues its 21 operand reads FIRST -- a ds_read issued behind a global_load_lds of the same wave
-// waits for that DMA to land (measured: +430 cycles per step) -- then the step's MFMAs with the 11 DMA pieces of the
-// next-but-one stage in their shadow.  Register staging instead of LDS-DMA was
-// slower (15.5 ms), so was a split-major workgroup order; see tools/i8_syrk_proto.hip for the measured alternatives.
+// Workgroup = 128 x 64 tile of the lower triangle x one split of the rows; 8 waves (two per SIMD), each one 32 x 32 MFMA tile x 7
+// group accumulators = 112 accumulator registers.  32-row stages (42 KB) travel global -> LDS by LDS-DMA through a ring of three;
+// the waves run as two groups half a step apart so that one of them always has its operands in registers (see i8_tile_loop).
+// Measured alternatives (register staging, lockstep waves, held-back MFMAs, split-major order): tools/i8_syrk_proto.hip, DESIGN.md 4d.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
 
@@ -41,7 +39,7 @@ constexpr int I8_SCOLS = I8_TR + I8_TC;                   // columns staged per 
 constexpr int I8_STAGE_BYTES = 2 * I8_NP * I8_SCOLS * 16; // 32 rows = 2 row blocks of 16
 constexpr int I8_NSTAGE = 3;
 constexpr int I8_PIECES = 2 * I8_NP * 3;                  // 1 KB LDS-DMA pieces per stage (3 groups of 64 columns)
-constexpr int I8_PPW = (I8_PIECES + 3) / 4;               // pieces per wave (the last slots of waves 2, 3 repeat a piece)
+constexpr int I8_PPW = (I8_PIECES + 7) / 8;               // pieces per wave and stage (8 waves; the last slots repeat a piece)
 constexpr int I8_LDS_BYTES = I8_NSTAGE * I8_STAGE_BYTES;  // 129 024
 
 // ---------------------------------------------------------------------------------------------
@@ -129,38 +127,43 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2. contraction.  UM = which of the wave's two 32 x 32 MFMA tiles lie on or below the diagonal (bit u): diagonal tiles skip
-//    the rest -- an idle matrix pipe is clock headroom for the other SIMDs here, not a wasted slot.
+// 2. contraction
 // ---------------------------------------------------------------------------------------------
-constexpr int I8_DMA_FIRST = 6;  // the first DMA piece goes out after this many MFMAs of a step, then one every I8_DMA_EVERY
-constexpr int I8_DMA_EVERY = 4;
-static_assert(I8_DMA_FIRST + I8_DMA_EVERY * (I8_PPW - 1) <= 56, "every DMA piece must find its MFMA");
+constexpr int I8_PSPLIT = 5;  // MFMA batches 0 .. 4 (15 MFMAs) in the first half of a step, batches 5, 6 (13) in the second
 
-// One step = 32 data rows: [wait for my pieces of stage c, barrier] -> 21 operand reads -> the step's 56 MFMAs in batch order
-// (batch p = A-plane p against B-planes 6 - p .. 6: the first batches need the fewest operands) with the 11 LDS-DMA pieces of
-// stage c + 2 issued in their shadow (precomputed lane offsets + a uniform base: 4 instructions per piece).  All reads come before
-// all DMAs of a step: a ds_read issued behind a global_load_lds of the same wave waits for that DMA to land.  (Holding the last
-// 4-10 MFMAs of a step back to cover the next step's operand reads measured 1-2 % SLOWER: tools/i8_syrk_proto.hip -DHOLD_R.)
-template <int UM>
+// Eight waves in two groups (waves 0-3 / 4-7: one of each per SIMD) that run HALF A STEP apart.  A step = 32 data rows = 28 MFMAs per
+// wave (batch p = A-plane p against B-planes 6 - p .. 6: the first batches need the fewest operands), two workgroup barriers:
+//
+//     E(0) O(0) E(1) O(1) .. E(n-1) O(n-1) E(n)      E(s) = group A's top of step s = group B's middle of step s - 1
+//                                                    O(s) = group A's middle of step s = group B's top of step s
+//
+// At its step top a wave issues its 14 operand reads, then its 6 LDS-DMA pieces of stage s + 2 in the shadow of the first 15 MFMAs;
+// in its second half it has every operand in registers -- so whenever one group waits for operands (or pays the ~40-60 cycles an
+// LDS-DMA piece costs its issuer) the other group's wave on the same SIMD feeds the matrix pipe: 2 180 instead of 2 710 cycles per
+// step, the pipe 0.82 instead of 0.66 busy (most of which the chip takes back as clock: 1.73 instead of 1.89 GHz, 12.7 vs 13.5 ms
+// in tools/i8_syrk_proto.hip).  Ordering: before every E(s) each wave waits for its own pieces of stage s (counted vmcnt: at most
+// one younger stage outstanding); group A reads the stage right after E(s), group B after O(s); the slot of stage s + 2 held
+// stage s - 1, last read after O(s - 1); all reads of a step precede its DMAs (a ds_read behind a global_load_lds of the same wave
+// waits for that DMA to land).  Lockstep variants measured slower: four waves with 64 x 32 tiles 13.5 ms, eight unstaggered 13.5.
+template <bool ACT>
 __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
                                              int J0, int accumulate, double* __restrict__ out, int wave, int lane) {
-  const int wi = wave >> 1, wj = wave & 1;
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;  // 32 x 32 tile (wi, wj) of the 128 x 64 tile: the groups interleave the row blocks
   const int l32 = lane & 31, lh = lane >> 5;
-  i16v acc[2][I8_NP];
+  i16v acc[I8_NP];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int g = 0; g < I8_NP; ++g)
 #pragma unroll
-    for (int g = 0; g < I8_NP; ++g)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[u][g][r] = 0;
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0;
 
-  // DMA piece k of this wave: e = wave + 4 k -> (row block in the stage, plane, column group); the last slots of waves 2, 3
-  // repeat their first pieces (the same bytes to the same place) so that every wave counts 11 per stage
+  // DMA piece k of this wave: e = wave + 8 k -> (row block in the stage, plane, column group); the last slots repeat the first
+  // pieces (the same bytes to the same place) so that every wave counts 6 per stage
   unsigned goff[I8_PPW];
   int soff[I8_PPW];
 #pragma unroll
   for (int k = 0; k < I8_PPW; ++k) {
-    int e = wave + 4 * k;
+    int e = wave + 8 * k;
     if (e >= I8_PIECES) e -= I8_PIECES;
     const int rbl = e / (I8_NP * 3), rem = e % (I8_NP * 3), p = rem / 3, cg = rem % 3;
     const int col = cg < 2 ? I0 + cg * 64 : J0;
@@ -172,77 +175,95 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + goff[k]),
                                      (__attribute__((address_space(3))) void*)(lds + sbase + soff[k]), 16, 0, 0);
   };
-  auto mfma = [&](const i4v& a, const i4v& b, i16v& c) { c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); };
-
-  if (c0 < c1) {
+  const int64_t nst = c1 - c0;
+  auto wait_stage = [&](int64_t sE) {  // my pieces of stage sE have landed once at most one younger stage's pieces are outstanding
+    if (sE + 1 >= nst)
+      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));                                           // vmcnt(0)
+    else
+      __builtin_amdgcn_s_waitcnt((I8_PPW & 15) | ((I8_PPW >> 4) << 14) | (7 << 4) | (15 << 8));      // vmcnt(6)
+  };
+  auto bar = [&]() {  // raw barrier, no fence: a __syncthreads() would drain the DMA in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  i4v b[I8_NP], a[I8_NP];
+  auto reads = [&](int64_t sidx) {
+    if (ACT) {
+      const uint8_t* sb = lds + (int)(sidx % I8_NSTAGE) * I8_STAGE_BYTES + lh * (I8_NP * I8_SCOLS * 16);
+#pragma unroll
+      for (int p = 0; p < I8_NP; ++p) {
+        b[I8_NP - 1 - p] = *reinterpret_cast<const i4v*>(sb + ((I8_NP - 1 - p) * I8_SCOLS + I8_TR + wj * 32 + l32) * 16);
+        a[p] = *reinterpret_cast<const i4v*>(sb + (p * I8_SCOLS + wi * 32 + l32) * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // MFMA batches [p0, p1); with dma_on the pieces of stage sE + 2 go out in their shadow, one every two MFMAs
+  auto half = [&](int p0, int p1, bool dma_on, int64_t sE) {
+    const bool pre = dma_on && sE + 2 < nst;
+    const uint8_t* gnext = Q + (size_t)(c0 + sE + 2) * gstride;
+    const int snext = (int)((sE + 2) % I8_NSTAGE) * I8_STAGE_BYTES;
+    int issued = 0, kpiece = 0;
+#pragma unroll
+    for (int p = p0; p < p1; ++p)
+#pragma unroll
+      for (int r = I8_NP - 1 - p; r < I8_NP; ++r) {
+        if (ACT) acc[p + r - (I8_NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[r], acc[p + r - (I8_NP - 1)], 0, 0, 0);
+        ++issued;
+        if (dma_on && issued >= 2 && (issued - 2) % 2 == 0 && kpiece < I8_PPW) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (pre) dma_piece(gnext, snext, kpiece);
+          __builtin_amdgcn_sched_barrier(0);
+          ++kpiece;
+        }
+      }
+  };
+  if (nst > 0) {
 #pragma unroll
     for (int k = 0; k < I8_PPW; ++k) dma_piece(Q + (size_t)c0 * gstride, 0, k);
-    if (c0 + 1 < c1) {
+    if (nst > 1) {
 #pragma unroll
       for (int k = 0; k < I8_PPW; ++k) dma_piece(Q + (size_t)(c0 + 1) * gstride, I8_STAGE_BYTES, k);
     }
-    for (int64_t c = c0; c < c1; ++c) {
-      const int slot = (int)((c - c0) % I8_NSTAGE), slot2 = (int)((c + 2 - c0) % I8_NSTAGE);
-      // my pieces of stage c have landed once at most one younger stage's pieces are outstanding; the raw barrier (no fence:
-      // a __syncthreads() would drain the DMA in flight) then makes everybody's pieces visible
-      if (c + 1 < c1)
-        __builtin_amdgcn_s_waitcnt((I8_PPW & 15) | ((I8_PPW >> 4) << 14) | (7 << 4) | (15 << 8));  // vmcnt(11)
-      else
-        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));                                         // vmcnt(0)
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const uint8_t* sb = lds + slot * I8_STAGE_BYTES + lh * (I8_NP * I8_SCOLS * 16);
-      i4v b[I8_NP], a[I8_NP][2];
-      if (UM != 0) {
-#pragma unroll
-        for (int p = 0; p < I8_NP; ++p) {
-          b[I8_NP - 1 - p] = *reinterpret_cast<const i4v*>(sb + ((I8_NP - 1 - p) * I8_SCOLS + I8_TR + wj * 32 + l32) * 16);
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-            if (UM & (1 << u)) a[p][u] = *reinterpret_cast<const i4v*>(sb + (p * I8_SCOLS + wi * 64 + u * 32 + l32) * 16);
-        }
+    if (grp == 0) {
+      for (int64_t sidx = 0; sidx < nst; ++sidx) {
+        wait_stage(sidx);
+        bar();  // E(s): my step top
+        reads(sidx);
+        half(0, I8_PSPLIT, true, sidx);
+        bar();  // O(s): my middle
+        half(I8_PSPLIT, I8_NP, false, sidx);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const bool pre = c + 2 < c1;
-      const uint8_t* gnext = Q + (size_t)(c + 2) * gstride;
-      const int snext = slot2 * I8_STAGE_BYTES;
-      int issued = 0, kpiece = 0;
-#pragma unroll
-      for (int p = 0; p < I8_NP; ++p) {
-#pragma unroll
-        for (int r = I8_NP - 1 - p; r < I8_NP; ++r) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (UM & (1 << u)) mfma(a[p][u], b[r], acc[u][p + r - (I8_NP - 1)]);
-            ++issued;
-            if (issued >= I8_DMA_FIRST && (issued - I8_DMA_FIRST) % I8_DMA_EVERY == 0 && kpiece < I8_PPW) {
-              __builtin_amdgcn_sched_barrier(0);
-              if (pre) dma_piece(gnext, snext, kpiece);
-              __builtin_amdgcn_sched_barrier(0);
-              ++kpiece;
-            }
-          }
-        }
+      wait_stage(nst);
+      bar();    // E(n): group B's last middle
+    } else {
+      wait_stage(0);
+      bar();    // E(0)
+      for (int64_t sidx = 0; sidx < nst; ++sidx) {
+        bar();  // O(s): my step top
+        reads(sidx);
+        half(0, I8_PSPLIT, true, sidx);
+        wait_stage(sidx + 1);
+        bar();  // E(s + 1): my middle
+        half(I8_PSPLIT, I8_NP, false, sidx + 1);
       }
     }
   }
   // fold the significance groups: value = sum_g acc_g 2^(8 g - 58)   (= 2^-106 256^(g + 6)); 128 x 128 slab tile, this half
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (!(UM & (1 << u))) continue;
+  if (ACT) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int g = 0; g < I8_NP; ++g) v = fma((double)acc[u][g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
-      const int row = wi * 64 + u * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+      for (int g = 0; g < I8_NP; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
+      const int row = wi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
       double* dst = out + row * TILE + wj * 32 + l32;
       *dst = accumulate ? *dst + v : v;
     }
   }
 }
 
-__global__ __launch_bounds__(256, 1) void i8_syrk_tile_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit,
+__global__ __launch_bounds__(512, 1) void i8_syrk_tile_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit,
                                                               int ntiles, int ntiles128, int accumulate, double* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) uint8_t i8_lds[];
   // id -> (xcd, tile, split group): the tiles of a split share id % 8, i.e. one XCD under round-robin dispatch (as syrk_tile_kernel)
@@ -261,19 +282,14 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_tile_kernel(const uint8_t* __r
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* out = slab + ((size_t)split * ntiles128 + (ti * (ti + 1) / 2 + (tj >> 1))) * (TILE * TILE) + (tj & 1) * I8_TC;
-  // 32 x 32 MFMA tile u of wave (wi, wj): rows I0 + 64 wi + 32 u .., columns J0 + 32 wj ..; strictly above the diagonal iff
-  // its first column lies beyond its last row
-  const int wi = wave >> 1, wj = wave & 1;
-  int um = 0;
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    if (J0 + 32 * wj <= I0 + 64 * wi + 32 * u + 31) um |= 1 << u;
-  switch (um) {
-    case 3: i8_tile_loop<3>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
-    case 2: i8_tile_loop<2>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
-    case 1: i8_tile_loop<1>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
-    default: i8_tile_loop<0>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane); break;
-  }
+  // the wave's 32 x 32 tile: rows I0 + 32 wi .., columns J0 + 32 wj ..; strictly above the diagonal iff its first column lies beyond
+  // its last row -- diagonal workgroups skip those MFMAs (an idle matrix pipe is clock headroom for the other SIMDs here)
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;
+  if (J0 + 32 * wj <= I0 + 32 * wi + 31)
+    i8_tile_loop<true>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane);
+  else
+    i8_tile_loop<false>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -322,7 +338,7 @@ int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumula
     attr_set = true;
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
-  i8_syrk_tile_kernel<<<nsplit * ntiles, 256, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab);
+  i8_syrk_tile_kernel<<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab);
   return SGP_OK;
 }
 
