@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 // 2. contraction
 // ---------------------------------------------------------------------------------------------
 constexpr int I8_PSPLIT = 5;  // MFMA batches 0 .. 4 (15 MFMAs) in the first half of a step, batches 5, 6 (13) in the second
+static_assert(2 * I8_PPW - 1 <= I8_PSPLIT * (I8_PSPLIT + 1) / 2, "every DMA piece must find its MFMA in the first half");
 
 // Eight waves in two groups (waves 0-3 / 4-7: one of each per SIMD) that run HALF A STEP apart.  A step = 32 data rows = 28 MFMAs per
 // wave (batch p = A-plane p against B-planes 6 - p .. 6: the first batches need the fewest operands), two workgroup barriers:
@@ -198,7 +199,7 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // MFMA batches [p0, p1); with dma_on the pieces of stage sE + 2 go out in their shadow, one every two MFMAs
+  // MFMA batches [p0, p1); with dma_on the pieces of stage sE + 2 go out in their shadow, one every two MFMAs from the first
   auto half = [&](int p0, int p1, bool dma_on, int64_t sE) {
     const bool pre = dma_on && sE + 2 < nst;
     const uint8_t* gnext = Q + (size_t)(c0 + sE + 2) * gstride;
@@ -210,7 +211,7 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
       for (int r = I8_NP - 1 - p; r < I8_NP; ++r) {
         if (ACT) acc[p + r - (I8_NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[r], acc[p + r - (I8_NP - 1)], 0, 0, 0);
         ++issued;
-        if (dma_on && issued >= 2 && (issued - 2) % 2 == 0 && kpiece < I8_PPW) {
+        if (dma_on && (issued & 1) && kpiece < I8_PPW) {  // after MFMAs 1, 3, .. 11 (earlier is better: 12.15 vs 12.35 ms from the 2nd, 12.45 from the 4th)
           __builtin_amdgcn_sched_barrier(0);
           if (pre) dma_piece(gnext, snext, kpiece);
           __builtin_amdgcn_sched_barrier(0);

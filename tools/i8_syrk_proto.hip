@@ -653,7 +653,17 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_v6_kernel(const uint8_t* __res
                                      (__attribute__((address_space(3))) void*)(lds + sbase + soff[k]), 16, 0, 0);
   };
   auto mfma = [&](const i4& a, const i4& b, i16& c) { c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); };
-  constexpr int PSPLIT = 5;  // batches 0 .. PSPLIT - 1 (15 MFMAs) in the first half of a step, the rest (13) in the second
+#ifndef PSPLIT_V
+#define PSPLIT_V 5
+#endif
+#ifndef DMA6_FIRST
+#define DMA6_FIRST 1
+#endif
+#ifndef DMA6_EVERY
+#define DMA6_EVERY 2
+#endif
+  static_assert(DMA6_FIRST + DMA6_EVERY * (PPW8 - 1) <= PSPLIT_V * (PSPLIT_V + 1) / 2, "every DMA piece must find its MFMA in the first half");
+  constexpr int PSPLIT = PSPLIT_V;  // batches 0 .. PSPLIT - 1 (15 MFMAs at 5) in the first half of a step, the rest (13) in the second
 
   const unsigned long long cy0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
   const int64_t nst = c1 - c0;
@@ -693,7 +703,7 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_v6_kernel(const uint8_t* __res
       for (int r = NP - 1 - p; r < NP; ++r) {
         mfma(a[p], b[r], acc[p + r - (NP - 1)]);
         ++issued;
-        if (dma_on && issued >= 2 && (issued - 2) % 2 == 0 && kpiece < PPW8) {
+        if (dma_on && issued >= DMA6_FIRST && (issued - DMA6_FIRST) % DMA6_EVERY == 0 && kpiece < PPW8) {
           __builtin_amdgcn_sched_barrier(0);
           if (pre) dma_piece(gnext, snext, kpiece);
           __builtin_amdgcn_sched_barrier(0);
@@ -824,10 +834,10 @@ int main(int argc, char** argv) {
   int one = 1, zero = 0;
   (void)one;
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &zero, 4));
-  if (argc > 3) {  // parameter sweep builds (-DHOLD_R= -DDMA_FIRST= -DDMA_EVERY=): the v4 kernel alone
-    run<0, 2>(8192, 256, true, 1);
-    run<0, 2>(N, M, false, 5);
-    run<0, 2>(N, M, false, 5);
+  if (argc > 3) {  // parameter sweep builds (-DHOLD_R= -DDMA_FIRST= -DDMA_EVERY= for v4, -DPSPLIT_V= for v6)
+    run<0, 4>(8192, 256, true, 1);
+    run<0, 4>(N, M, false, 5);
+    run<0, 4>(N, M, false, 5);
     return 0;
   }
   run<0, 2>(8192, 256, true, 1);
