@@ -9,9 +9,9 @@ N rows are split into G contiguous shards (strong scaling: the job is fixed, one
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).  Extra keys:
   leapfrog_per_s    : value + gradient wrt (lengthscales, sig_f, sig_n) evaluations / s, same run, same data
   roofline          : the dominant kernel of the timed evaluations: `i8_syrk_tile_kernel` (pass-1 contraction on the integer
-                      matrix cores, what value-only evaluations of big shards run) against the dense int8 peak, with the
-                      fp64-equivalent rate beside it; `roofline_fp64_contraction` is `syrk_tile_kernel` (the fp64 contraction
-                      of value + gradient evaluations) against the fp64 matrix peak.  achieved = the kernel's OWN algorithmic
+                      matrix cores, what evaluations of big shards run) against the dense int8 peak, with the
+                      fp64-equivalent rate beside it; `roofline_fp64_contraction` is `syrk_tile_kernel` (the fp64 contraction:
+                      sgp_set_contraction(0), timed for the record) against the fp64 matrix peak.  achieved = the kernel's OWN algorithmic
                       work (N M (M + 1) flop; x 28 int8 op for the digit-pair products) / its HIP-event time
                       (events recorded by the library on the launch stream right around the kernel: sgp_timing_*).
                       `pass1` inside it times kernel assembly + contraction together against SURVEY section 8d's
@@ -252,7 +252,7 @@ def main():
             assert eng.lib.sgp_timing_last_ms(slot, ctypes.byref(t)) == 0
             ms[slot].append(t.value)
     eng.lib.sgp_set_contraction(prev_mode)
-    # pass 1 of a value + gradient evaluation as the timed leapfrogs run it (the default rule keeps it on the fp64 cores: DESIGN 4d)
+    # pass 1 of a value + gradient evaluation as the timed leapfrogs run it: on the integer cores the assembly writes the fp64 block too
     mg = {0: [], 1: []}
     for _ in range(reps):
         eng.suffstats(Xd, yd, Zd, ls, sf2, "rbf", out=packed, kfu=kfu)
@@ -355,8 +355,8 @@ def main():
         "F": last["F"], "F_per_datum": last["F"] / args.n,
         "roofline": None,
         "roofline_fp64_contraction": {
-                     "bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction on the fp64 matrix cores: what a value + gradient evaluation runs, "
-                                                "and value-only ones with sgp_set_contraction(0))",
+                     "bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction on the fp64 matrix cores: sgp_set_contraction(0), and shards below the "
+                                                "integer path's threshold)",
                      "achieved": syrk_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tf / FP64_MATRIX_PEAK_TFLOPS,
                      "ms": syrk_ms, "algorithmic_flops": syrk_flops, "algorithmic_flops_formula": "N M (M + 1): lower triangle of Phi, 2 flop per MAC",
                      "algorithmic_bytes": kfu_bytes, "traffic": syrk_traffic,

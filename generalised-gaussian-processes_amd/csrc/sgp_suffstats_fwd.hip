@@ -599,9 +599,9 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qro
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
-  // (own planes only when the integer path is forced for every call: the default rule never contracts a kept K'_fu on it)
-  w.Q = need_kfu ? reinterpret_cast<uint8_t*>(w.Kfu)
-                 : (contraction_mode() == 2 ? c.take<uint8_t>((size_t)(qrows > 0 ? qrows : 1) * p.Mp * 7) : nullptr);
+  // (with a caller-owned K'_fu the planes need a super-chunk of their own -- only where the contraction rule can pick the integer path)
+  const bool own_q = !need_kfu && (contraction_mode() == 2 || (contraction_mode() == 1 && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
+  w.Q = need_kfu ? reinterpret_cast<uint8_t*>(w.Kfu) : (own_q ? c.take<uint8_t>((size_t)(qrows > 0 ? qrows : 1) * p.Mp * 7) : nullptr);
   w.bytes = c.used();
   return w;
 }
@@ -701,10 +701,10 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   int head_ns = 0;
   int64_t head_chunks = 0;
   (void)contraction_mode();
-  // (default rule: value-only calls.  With a kept K'_fu the assembly has to write the fp64 block AND the planes: pass 1 alone gains
-  // 1.85 ms at C5 -- 2.92 + 13.14 against 1.79 + 16.11 -- but the leapfrog it belongs to does not, 52.29 against 52.43 ms on one box:
-  // pass 2 runs into the power the integer contraction has just drawn.  Mode 2 takes the integer path there too, for the tests.)
-  const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && !Kfu_out && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
+  // With a kept K'_fu (value + gradient: pass 2 reads the fp64 block) the assembly writes the fp64 block AND the planes.  Pass 1 alone
+  // gains 3.0 ms at C5 (2.6 + 12.9 against 1.7 + 16.0 ms), the leapfrog it belongs to 1.1 ms (50.4 against 51.5, same box, alternating:
+  // profiles/r03_i8_leapfrog_ab.jsonl) -- pass 2 runs 1.4 ms longer behind the integer contraction, whose power draw it inherits.
+  const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
   g_contraction_used = use_i8 ? 1 : 0;
   if (!use_i8) g_pass1_gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
   if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);

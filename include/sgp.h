@@ -139,12 +139,13 @@ size_t sgp_suffstats_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns
 size_t sgp_kfu_len(int64_t N, int M);
 /* Which matrix cores run the pass-1 contraction Phi = K_uf K_fu of sgp_suffstats_fwd (csrc/sgp_suffstats_i8.hip):
  *   0  fp64 (v_mfma_f64_16x16x4_f64) always;
- *   1  (default, SGP_CONTRACTION) the integer cores where they win: value-only calls (Kfu_out == NULL, nobody keeps K'_fu) with
- *      rows x padded-M^2 >= 2^32 (65536 rows at M <= 256, 4096 at M = 1024).  K'_fu in [0, 1] is split into seven balanced 8-bit digit planes
- *      (|K' - q 2^-53| <= 2^-54), the 28 digit-pair products p + r >= 6 are exact int32 sums, folded to fp64 once per 16384 rows:
- *      the result is as accurate as the fp64 contraction (2.4-2.8e-16 of max |Phi| against long-double arithmetic);
- *   2  the integer cores for every call (tests); with Kfu_out != NULL kernel assembly then writes the fp64 block AND the digit
- *      planes (the planes in the workspace -- query the workspace size in the same mode).  Measured: no gain for a leapfrog.
+ *   1  (default, SGP_CONTRACTION) the integer cores where they win: rows x padded-M^2 >= 2^32 (65536 rows at M <= 256, 4096 at
+ *      M = 1024).  K'_fu in [0, 1] is split into seven balanced 8-bit digit planes (|K' - q 2^-53| <= 2^-54), the 28 digit-pair
+ *      products p + r >= 6 are exact int32 sums, folded to fp64 once per 16384 rows: the result is as accurate as the fp64
+ *      contraction (2.4-2.8e-16 of max |Phi| against long-double arithmetic).  With Kfu_out != NULL (value + gradient: pass 2
+ *      reads the fp64 block) kernel assembly writes the fp64 block AND the digit planes (the planes a super-chunk at a time in
+ *      the workspace -- query the workspace size in the mode the call will run in);
+ *   2  the integer cores for every call (tests).
  * Returns the previous mode (-1 = never set).  sgp_contraction_last(): what the last sgp_suffstats_fwd call ran (0 fp64, 1 int8).
  * Replaces nothing in the reference -- torch.matmul in gpytorch's InducingPointKernel (models/sgpr.py:37) is the fp64 GEMM. */
 int sgp_set_contraction(int mode);
