@@ -399,6 +399,8 @@ def main():
             "accuracy": "as the fp64 contraction: |K' - q 2^-53| <= 2^-54, digit products exact, dropped pairs < 6 x 2^-52 per product and "
                         "zero-mean; 2.4-2.8e-16 of max |Phi| against long double (tests/test_int8_contraction.py, tools/i8_syrk_proto.hip)"}
         res["config"]["contraction"] = "int8 digit planes on the integer matrix cores (error-free split of K'_fu, fp64 result)"
+        res["dtype_note"] = ("fp64 kernel values, statistics, factorizations and gradients; the pass-1 contraction multiplies exact 8-bit digits of the "
+                             "fp64 kernel values on the integer matrix cores (int32 sums, folded to fp64): as accurate as the fp64 contraction, not a reduced precision")
         res["assembly_digits"] = {"bound": "valu", "kernel": "sgp::kfu_digits_kernel<8,0>", "ms": digits_ms,
                                   "achieved": q_bytes / (digits_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": q_bytes / (digits_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": q_bytes,
