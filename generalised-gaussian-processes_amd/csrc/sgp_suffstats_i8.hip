@@ -144,7 +144,7 @@ static_assert(2 * I8_PPW - 1 <= I8_PSPLIT * (I8_PSPLIT + 1) / 2, "every DMA piec
 // step, the pipe 0.82 instead of 0.66 busy (most of which the chip takes back as clock: 1.73 instead of 1.89 GHz, 12.7 vs 13.5 ms
 // in tools/i8_syrk_proto.hip).  Ordering: before every E(s) each wave waits for its own pieces of stage s (counted vmcnt: at most
 // one younger stage outstanding); group A reads the stage right after E(s), group B after O(s); the slot of stage s + 2 held
-// stage s - 1, last read after O(s - 1); all reads of a step precede its DMAs (a ds_read behind a global_load_lds of the same wave
+// stage s - 1, whose last reads group B issued after O(s - 1) and retires (lgkmcnt(0)) before E(s); all reads of a step precede its DMAs (a ds_read behind a global_load_lds of the same wave
 // waits for that DMA to land).  Lockstep variants measured slower: four waves with 64 x 32 tiles 13.5 ms, eight unstaggered 13.5.
 template <bool ACT>
 __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
@@ -244,6 +244,9 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
         bar();  // O(s): my step top
         reads(sidx);
         half(0, I8_PSPLIT, true, sidx);
+        // my reads of stage s (issued a phase ago, the last of them consumed only AFTER this barrier) must have left the LDS queue
+        // before group A restages their slot (stage s + 3) right after E(s + 1): lgkmcnt(0), long satisfied by now
+        __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8));
         wait_stage(sidx + 1);
         bar();  // E(s + 1): my middle
         half(I8_PSPLIT, I8_NP, false, sidx + 1);

@@ -736,6 +736,7 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_v6_kernel(const uint8_t* __res
         bar();                                  // O(s): my step top
         reads(sidx);
         half(0, PSPLIT, true, sidx);            // (DMA after my reads, as in group A: a ds_read behind an LDS-DMA of the same wave waits for it)
+        __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8));  // lgkmcnt(0): my reads of stage s are out of the LDS queue before E(s + 1)
         wait_stage(sidx + 1);
         bar();                                  // E(s + 1): my middle
         half(PSPLIT, NP, false, sidx + 1);
