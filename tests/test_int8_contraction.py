@@ -191,6 +191,24 @@ def test_int8_super_chunks_accumulate(int8):
     assert relerr(got[M * M:].cpu().numpy(), ref[M * M:].cpu().numpy()) < 1e-13
 
 
+def test_int8_bit_reproducible_under_repetition(int8):
+    """The digit-pair sums are exact integers and every fp64 fold / slab sum has a fixed order: repeated launches must agree bit for
+    bit.  A race in the staged LDS ring (a stage read before it has landed, a slot restaged before its reads retired) would show up
+    here as a flipped digit somewhere among 60 launches of 1 000+ workgroups each."""
+    engine = int8
+    g = torch.Generator().manual_seed(21)
+    N, M, d = 150_000, 640, 3
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
+    ref = engine.suffstats(X, y, Z, [1.0, 0.8, 1.3], 1.1, "rbf").clone()
+    assert engine.lib.sgp_contraction_last() == 1
+    out = torch.empty_like(ref)
+    for _ in range(60):
+        engine.suffstats(X, y, Z, [1.0, 0.8, 1.3], 1.1, "rbf", out=out)
+        assert torch.equal(out, ref)
+
+
 def test_int8_nan_input_reaches_the_bound(int8):
     engine = int8
     X = torch.randn(300, 2, dtype=torch.float64)
