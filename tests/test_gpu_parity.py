@@ -532,7 +532,8 @@ def test_tapered_splits_match_equal_splits(engine):
         "                  'gzn': float(gr['Z'].norm())}))\n" % ROOT)
     outs = []
     for taper in ("1", "0"):
-        env = dict(os.environ, SGP_SYRK_TAPER=taper, SGP_KBAR_TAPER=taper)
+        # (SGP_CONTRACTION=0: the tapered splits of pass 1 belong to the fp64 contraction; pass 2 tapers either way)
+        env = dict(os.environ, SGP_SYRK_TAPER=taper, SGP_KBAR_TAPER=taper, SGP_CONTRACTION="0")
         r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
@@ -752,6 +753,8 @@ def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
     assert two.returncode == 0, two.stderr[-3000:]
     r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert r2["n_gpus"] == 2 and r2["config"]["ranks"] == 2 and r2["config"]["rows_per_rank"] == rows // 2
+    # both jobs contract on the integer matrix cores (65536 rows x 1024^2 >= 2^32 per rank): the shards' statistics add up across ranks
+    assert r1["config"]["contraction"].startswith("int8") and r2["config"]["contraction"].startswith("int8")
     assert abs(r2["F"] - r1["F"]) < 1e-9 * abs(r1["F"]), (r1["F"], r2["F"])
     assert r2["leapfrog_per_s"] > 0 and r2["value"] > 0
     assert r2["config"]["allreduce_ms"] > 0 and r2["config"]["collectives_per_eval"] == 1.0
@@ -779,6 +782,7 @@ def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
     Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
     ls = [0.6, 0.7, 0.5, 0.8]  # short lengthscales: a well-conditioned K_uu, so F itself can be compared to rounding
     out = {}
+    prev = engine.lib.sgp_set_contraction(0)  # the head / tail blocks belong to the fp64 contraction (the integer one would bypass them)
     try:
         for mode in (0, 1, 2, 1):
             engine.lib.sgp_set_asm_overlap(mode)
@@ -788,8 +792,10 @@ def test_pass1_head_tail_blocks_and_side_stream_assembly(engine):
             F, gr = cb.value_and_grad(Zd, ls, 1.3, 0.05, want_gz=False)
             out.setdefault(mode, []).append((st, kfu.clone(), F, gr["ls"].clone(), gr["sf2"], gr["s2"]))
             del kfu
+            assert engine.lib.sgp_contraction_last() == 0
     finally:
         engine.lib.sgp_set_asm_overlap(-1)
+        engine.lib.sgp_set_contraction(prev)
     (s0, k0, F0, g0, a0, b0), (s1, k1, F1, g1, a1, b1), (s2, k2, F2, g2, a2, b2) = out[0][0], out[1][0], out[2][0]
     assert torch.equal(k0, k1) and torch.equal(k1, k2)                       # K'_fu itself does not depend on the blocks
     assert torch.equal(s1, s2) and F1 == F2 and torch.equal(g1, g2) and (a1, b1) == (a2, b2)
