@@ -718,7 +718,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
       timing_begin(TIMING_ASSEMBLE, st);
       i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Q, Kfu_out ? Kfu_out + (size_t)r0 * p.Mp : nullptr, w.bpart, st);
       timing_end(TIMING_ASSEMBLE, st);
-      // the integer contraction leaves no register file for anybody else (one 456-register wave per SIMD): a side-stream chain
+      // the integer contraction leaves next to nothing for anybody else (129 KB of LDS, two 188-register waves per SIMD): a side-stream chain
       // the caller wants done by the end of pass 1 (chol(K_uu)) has to finish beside the ASSEMBLY, so the contraction waits for it
       if (g_pass1_gate && hipStreamWaitEvent(st, g_pass1_gate, 0) != hipSuccess) return SGP_ERR_LAUNCH;
       g_pass1_gate = nullptr;

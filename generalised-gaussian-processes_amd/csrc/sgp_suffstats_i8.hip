@@ -1,4 +1,4 @@
-// Pass-1 contraction on the INTEGER matrix cores: Phi = K'^T K' by an error-free splitting of K' (value-only evaluations).
+// Pass-1 contraction on the INTEGER matrix cores: Phi = K'^T K' by an error-free splitting of K'.
 //
 // Every entry of K'_fu lies in [0, 1] (a stationary profile without its amplitude), so it IS a fixed-point number:
 //
@@ -16,7 +16,7 @@
 // Why: v_mfma_i32_32x32x32_i8 runs 32 768 MACs in 32 cycles against 1 024 in 64 for v_mfma_f64_16x16x4_f64 -- 64 x the rate for
 // 28 x the MACs.  What is left of that on real operands is decided by POWER, not issue slots: on full-entropy bytes the chip
 // clocks the int8 pipe down to ~1.78 GHz (profiles/r03_i8_rates.txt: 1 764 TMAC/s sustained), and every byte moved costs
-// clock as well.  Measured at C5 (N = 10^6, M = 1024): 12.9-13.3 ms against 16.0-16.9 ms for the fp64 contraction.
+// clock as well.  Measured at C5 (N = 10^6, M = 1024): 12.0-12.4 ms against 16.0-16.9 ms for the fp64 contraction.
 //
 // Layout.  Digit planes Q[rb][p][m][16 bytes]: digit p of data rows 16 rb .. 16 rb + 15 of inducing column m -- 7 bytes per
 // element (the fp64 K'_fu has 8) and ONE ds_read_b128 is a lane's whole MFMA operand (lane l <-> column l % 32, rows

@@ -152,7 +152,7 @@ int sgp_set_contraction(int mode);
 int sgp_contraction_last(void);
 /* One-shot gate for the NEXT sgp_suffstats_fwd call: if that call contracts on the integer cores, the contraction launch waits for
  * `hip_event` (a hipEvent_t the caller has ALREADY recorded on another stream) between kernel assembly and the contraction.  Why: that
- * kernel runs one 456-register wave per SIMD, so nothing co-schedules with it -- a side-stream chain that must be done by the end of
+ * kernel takes 129 KB of LDS and two 188-register waves per SIMD, so next to nothing co-schedules with it -- a side-stream chain that must be done by the end of
  * pass 1 (the factorization of K_uu, core.py) finishes beside the assembly instead of being starved.  NULL clears; a call that takes the
  * fp64 contraction ignores and clears it. */
 void sgp_set_pass1_gate(void* hip_event);
