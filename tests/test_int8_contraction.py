@@ -114,6 +114,30 @@ def test_int8_phi_is_the_exact_sum_of_digitised_products(int8, data):
     assert worst < 5e-16 * float(np.abs(Phi).max())
 
 
+def test_int8_phi_bit_identical_to_the_cpu_digit_oracle(int8):
+    """oracle/i8_digits_oracle.py restates the kernel pair in numpy integers.  Fed with the fp64 K'_fu the assembly itself wrote, and
+    folded split by split in the kernel's order (8 splits of 128 rows here, summed 0 .. 7 by reduce_phi_kernel), it must reproduce the
+    HIP Phi BIT FOR BIT: every digit, every int32 group sum and every fp64 fold is determined."""
+    from oracle import i8_digits_oracle as D
+    engine = int8
+    g = torch.Generator().manual_seed(8)
+    N, M, d = 1000, 11, 2
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = torch.randn(M, d, dtype=torch.float64, generator=g).to(engine.device)
+    kfu = engine.kfu_buffer(N, M)
+    packed = engine.suffstats(X, y, Z, [0.9, 1.2], 1.0, "matern32", kfu=kfu)
+    assert engine.lib.sgp_contraction_last() == 1
+    K = kfu.view(-1, 128)[:, :M].cpu().numpy()            # all 1024 padded rows (zeros beyond N)
+    a = D.digits(D.quantise(K))
+    Phi = np.zeros((M, M))
+    for s0 in range(0, K.shape[0], 128):                   # nsplit = 8, 4 steps of 32 rows each
+        Phi = Phi + D.phi_from_digits([x[s0:s0 + 128] for x in a])
+    got = packed[:M * M].view(M, M).cpu().numpy()
+    assert np.array_equal(np.tril(got), np.tril(Phi)), float(np.abs(got - Phi).max())
+    assert np.array_equal(got, got.T)
+
+
 @pytest.mark.parametrize("name", [n for n in golden_names() if int(load_golden(n)["kernel_id"]) in KNAME])
 def test_int8_bound_golden(int8, name):
     """The bound through the streaming order with the statistics from the integer cores: the tolerances of
