@@ -16,7 +16,8 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task description)
                       (events recorded by the library on the launch stream right around the kernel: sgp_timing_*).
                       `pass1` inside it times kernel assembly + contraction together against SURVEY section 8d's
                       whole-evaluation W_fwd; traffic = HBM bytes of the kernel from the newest profiles/*_pmc_hbm_traffic.csv
-                      (PMC passes, tools/profile_round.sh), traffic_ratio = traffic / the kernel's algorithmic bytes
+                      (PMC passes, tools/profile_round.sh), traffic_ratio = traffic / the kernel's algorithmic bytes;
+                      mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) from the newest profiles/*_pmc_sq_counters.csv
   roofline_leapfrog : the same for the dominant kernel of the reverse pass, `kbar_contract_kernel` (2 N M^2 flop)
   cpu_baseline      : the oracle's PyMC3-op-order restatement timed on this box's host cores (rank 0, N=1 only): value
                       only at two sample sizes (fixed + per-row cost fitted, then evaluated at N; --cpu-full times all N
@@ -74,6 +75,24 @@ def synth(n_total, m, d):
     y = (y - y.mean()) / y.std()
     Z = X[torch.randperm(n_total, generator=g)[:m]].clone()
     return X, y, Z
+
+
+def pmc_mfma_busy(kernel_substr):
+    """Matrix-pipe utilisation of a kernel from the newest profiles/*_pmc_sq_counters.csv (tools/profile_sq.sh; one counter per rocprofv3
+    pass): SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) -- MFMA-busy cycles per SIMD over the cycles its CU was busy.
+    Returns (fraction, file) or (None, None)."""
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq_counters.csv")),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])
+    for f in reversed(files):
+        val = {}
+        with open(f, newline="") as fh:
+            for row in csv.reader(r for r in fh if not r.startswith("#")):
+                if len(row) == 5 and row[0] in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES") and kernel_substr in row[1] and row[0] not in val:
+                    val[row[0]] = float(row[4])
+        if len(val) == 2 and val["SQ_BUSY_CU_CYCLES"] > 0:
+            return val["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * val["SQ_BUSY_CU_CYCLES"]), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def algorithmic_flops_fwd(n, m, d):
@@ -287,6 +306,9 @@ def main():
     kbar_traffic, kbar_file = pmc_traffic("kbar_contract_kernel") if default_cfg else (None, None)
     syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12
     i8_traffic, i8_file = pmc_traffic("sgp::i8_syrk_tile_kernel(") if default_cfg else (None, None)
+    i8_busy, i8_busy_file = pmc_mfma_busy("sgp::i8_syrk_tile_kernel(") if default_cfg else (None, None)
+    syrk_busy, _ = pmc_mfma_busy("sgp::syrk_tile_kernel<") if default_cfg else (None, None)
+    kbar_busy, _ = pmc_mfma_busy("sgp::kbar_contract_kernel<") if default_cfg else (None, None)
     q_bytes = 7.0 * ((n_local + 255) // 256 * 256) * Mp          # digit planes: 7 bytes per element of K'_fu
     i8_ops = 28.0 * syrk_flops                                   # 28 digit-pair products per fp64 product, 2 op per MAC
     i8_tops = i8_ops / (i8_ms * 1e-3) / 1e12
@@ -358,7 +380,7 @@ def main():
                      "bound": "mfma", "kernel": "sgp::syrk_tile_kernel (pass-1 contraction on the fp64 matrix cores: sgp_set_contraction(0), and shards below the "
                                                 "integer path's threshold)",
                      "achieved": syrk_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tf / FP64_MATRIX_PEAK_TFLOPS,
-                     "ms": syrk_ms, "algorithmic_flops": syrk_flops, "algorithmic_flops_formula": "N M (M + 1): lower triangle of Phi, 2 flop per MAC",
+                     "ms": syrk_ms, "mfma_pipe_busy": syrk_busy, "algorithmic_flops": syrk_flops, "algorithmic_flops_formula": "N M (M + 1): lower triangle of Phi, 2 flop per MAC",
                      "algorithmic_bytes": kfu_bytes, "traffic": syrk_traffic,
                      "traffic_ratio": (syrk_traffic / kfu_bytes) if syrk_traffic else None,
                      "traffic_note": (note % syrk_file) if syrk_file else None,
@@ -369,7 +391,7 @@ def main():
                                           "move 80.5 MB per evaluation instead of ~55 GB, but measured 53 ms (fp64 VALU exp() and MFMA share the datapath)"},
         "roofline_leapfrog": {"bound": "mfma", "kernel": "sgp::kbar_contract_kernel (pass-2 contraction + derivative epilogue)",
                               "achieved": kbar_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kbar_tf / FP64_MATRIX_PEAK_TFLOPS,
-                              "ms": kbar_ms, "algorithmic_flops": kbar_flops, "algorithmic_flops_formula": "2 N M^2 (Kbar_uf = 2 Phibar K_uf)",
+                              "ms": kbar_ms, "mfma_pipe_busy": kbar_busy, "algorithmic_flops": kbar_flops, "algorithmic_flops_formula": "2 N M^2 (Kbar_uf = 2 Phibar K_uf)",
                               "algorithmic_bytes": kfu_bytes, "traffic": kbar_traffic,
                               "traffic_ratio": (kbar_traffic / kfu_bytes) if kbar_traffic else None,
                               "traffic_note": (note % kbar_file) if kbar_file else None},
@@ -391,6 +413,8 @@ def main():
             "fp64_equivalent": {"achieved": syrk_flops / (i8_ms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": syrk_flops / (i8_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                                 "note": "N M (M + 1) flop of the fp64 contraction it replaces over its own time; > 1 = faster than the fp64 matrix peak allows"},
+            "mfma_pipe_busy": i8_busy, "mfma_pipe_busy_note": ("SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) from %s (PMC passes, tools/profile_sq.sh); "
+                                                                 "not collected in this run" % i8_busy_file) if i8_busy_file else None,
             "algorithmic_bytes": q_bytes, "traffic": i8_traffic, "traffic_ratio": (i8_traffic / q_bytes) if i8_traffic else None,
             "traffic_note": (note % i8_file) if i8_file else None,
             "pass1": {"kernels": "kfu_digits_kernel + i8_syrk_tile_kernel", "ms": digits_ms + i8_ms, "fp64_pass1_ms": assemble_ms + syrk_ms},

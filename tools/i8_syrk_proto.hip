@@ -837,7 +837,10 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &zero, 4));
   if (argc > 3) {  // parameter sweep builds (-DHOLD_R= -DDMA_FIRST= -DDMA_EVERY= for v4, -DPSPLIT_V= for v6)
     run<0, 4>(8192, 256, true, 1);
-    run<0, 4>(N, M, false, 5);
+    for (int sr = 16384; sr >= 2048; sr /= 2) {
+      printf("-- %d rows per split\n", sr);
+      run<0, 4>(N, M, false, 5, sr);
+    }
     run<0, 4>(N, M, false, 5);
     return 0;
   }
