@@ -27,6 +27,7 @@
 // Measured alternatives (register staging, lockstep waves, held-back MFMAs, split-major order): tools/i8_syrk_proto.hip, DESIGN.md 4d.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
+#include <cstdlib>
 
 namespace sgp {
 
@@ -148,7 +149,7 @@ static_assert(2 * I8_PPW - 1 <= I8_PSPLIT * (I8_PSPLIT + 1) / 2, "every DMA piec
 // waits for that DMA to land).  Lockstep variants measured slower: four waves with 64 x 32 tiles 13.5 ms, eight unstaggered 13.5.
 template <bool ACT>
 __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
-                                             int J0, int accumulate, double* __restrict__ out, int wave, int lane) {
+                                             int J0, int accumulate, double* __restrict__ out, int wave, int lane, int prio) {
   const int grp = wave >> 2, w4 = wave & 3;
   const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;  // 32 x 32 tile (wi, wj) of the 128 x 64 tile: the groups interleave the row blocks
   const int l32 = lane & 31, lh = lane >> 5;
@@ -201,6 +202,9 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
   };
   // MFMA batches [p0, p1); with dma_on the pieces of stage sE + 2 go out in their shadow, one every two MFMAs from the first
   auto half = [&](int p0, int p1, bool dma_on, int64_t sE) {
+    // A/B knob SGP_I8_PRIO=1 (off by default): the wave at its step top outranks its SIMD partner.  1.5 % faster in the stand-alone
+    // prototype, 5 % SLOWER here (12.03-12.11 vs 11.38-11.53 ms alternating in one process, tools/i8_prio_ab.py).
+    if (prio) { if (dma_on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     const bool pre = dma_on && sE + 2 < nst;
     const uint8_t* gnext = Q + (size_t)(c0 + sE + 2) * gstride;
     const int snext = (int)((sE + 2) % I8_NSTAGE) * I8_STAGE_BYTES;
@@ -268,7 +272,7 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
 }
 
 __global__ __launch_bounds__(512, 1) void i8_syrk_tile_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit,
-                                                              int ntiles, int ntiles128, int accumulate, double* __restrict__ slab) {
+                                                              int ntiles, int ntiles128, int accumulate, double* __restrict__ slab, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t i8_lds[];
   // id -> (xcd, tile, split group): the tiles of a split share id % 8, i.e. one XCD under round-robin dispatch (as syrk_tile_kernel)
   const int id = blockIdx.x;
@@ -291,9 +295,9 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_tile_kernel(const uint8_t* __r
   const int grp = wave >> 2, w4 = wave & 3;
   const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;
   if (J0 + 32 * wj <= I0 + 32 * wi + 31)
-    i8_tile_loop<true>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane);
+    i8_tile_loop<true>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane, prio);
   else
-    i8_tile_loop<false>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane);
+    i8_tile_loop<false>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane, prio);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -342,7 +346,8 @@ int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumula
     attr_set = true;
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
-  i8_syrk_tile_kernel<<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab);
+  const int prio = getenv("SGP_I8_PRIO") ? atoi(getenv("SGP_I8_PRIO")) : 0;  // A/B knob (read per call; measured a loss)
+  i8_syrk_tile_kernel<<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab, prio);
   return SGP_OK;
 }
 

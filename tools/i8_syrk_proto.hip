@@ -692,7 +692,14 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_v6_kernel(const uint8_t* __res
     __builtin_amdgcn_sched_barrier(0);
   };
   // MFMA batches [p0, p1) with (optionally) the DMA pieces of stage sE + 2 in their shadow, one every two MFMAs
+#ifndef PRIO_FIRST
+#define PRIO_FIRST 0
+#endif
+#ifndef PRIO_SECOND
+#define PRIO_SECOND 0
+#endif
   auto half = [&](int p0, int p1, bool dma_on, int64_t sE) {
+    if (dma_on) __builtin_amdgcn_s_setprio(PRIO_FIRST); else __builtin_amdgcn_s_setprio(PRIO_SECOND);
     const bool pre = dma_on && MODE != 1 && sE + 2 < nst;
     const uint8_t* gnext = Q + (size_t)(c0 + sE + 2) * gstride;
     const int snext = (int)((sE + 2) % NSTAGE) * STAGE_BYTES;
