@@ -215,7 +215,9 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
       for (int r = I8_NP - 1 - p; r < I8_NP; ++r) {
         if (ACT) acc[p + r - (I8_NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[r], acc[p + r - (I8_NP - 1)], 0, 0, 0);
         ++issued;
-        if (dma_on && (issued & 1) && kpiece < I8_PPW) {  // after MFMAs 1, 3, .. 11 (earlier is better: 12.15 vs 12.35 ms from the 2nd, 12.45 from the 4th)
+        // after MFMAs 1, 3, .. 11.  Alternating in one process at C5 (profiles/r03_i8_dma_placement_ab.jsonl): 11.27-11.38 ms, against
+        // 11.62-11.68 after 2, 4, .. 12, 11.52-11.64 after 1, 2, .. 6 and 11.75-11.83 after 4, 6, .. 14
+        if (dma_on && (issued & 1) && kpiece < I8_PPW) {
           __builtin_amdgcn_sched_barrier(0);
           if (pre) dma_piece(gnext, snext, kpiece);
           __builtin_amdgcn_sched_barrier(0);

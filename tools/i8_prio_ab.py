@@ -11,10 +11,10 @@ Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
 eng.lib.sgp_timing_enable(1)
 out = eng.suffstats(Xd, yd, Zd, [bench.LS] * d, bench.SF ** 2, "rbf")
 for rep in range(4):
-    for prio in ("0", "1"):
-        os.environ["SGP_I8_PRIO"] = prio
+    for prio in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "1")):
+        os.environ[sys.argv[1] if len(sys.argv) > 1 else "SGP_I8_PRIO"] = prio
         ms = []
         for _ in range(6):
             eng.suffstats(Xd, yd, Zd, [bench.LS] * d, bench.SF ** 2, "rbf", out=out)
             t = ctypes.c_float(); eng.lib.sgp_timing_last_ms(1, ctypes.byref(t)); ms.append(t.value)
-        print(json.dumps({"prio": prio, "contraction_ms_median": sorted(ms)[3]}), flush=True)
+        print(json.dumps({(sys.argv[1] if len(sys.argv) > 1 else "SGP_I8_PRIO"): prio, "contraction_ms_median": sorted(ms)[3]}), flush=True)
