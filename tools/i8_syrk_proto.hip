@@ -766,6 +766,173 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_v6_kernel(const uint8_t* __res
   }
 }
 
+// ---- v7 = v6 with the B operand (the 64 columns of the J block) loaded global -> VGPR one step ahead instead of through LDS: a third
+//      fewer LDS-DMA pieces and half the LDS operand reads, for 7 global_load_dwordx4 per wave and step.
+// ---- (v6:) eight waves in two groups (waves 0-3 / 4-7: one of each per SIMD) that run HALF A STEP apart: two barriers per step;
+//      at every barrier one group is at the top of a step (issues its 14 operand reads, waits for them) while the other is in
+//      the middle of one (all operands in registers, 13 MFMAs to go) -- so the matrix pipe has work while operands are in flight.
+//      DMA: every wave issues its pieces of stage c + 2 after the EVEN barrier of step c (group A's step top, group B's middle)
+//      and waits for its pieces of stage c before the even barrier of step c: A reads the stage right after it, B half a step later.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void i8_syrk_v7_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit, int ntiles,
+                                                            double* __restrict__ slab, unsigned long long* __restrict__ stamp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int id = blockIdx.x;
+  const int xcd = id & 7, jj = id >> 3;
+  const int t = jj % ntiles, split = (jj / ntiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  int ti = (int)((sqrtf(4.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) <= t) ++ti;
+  while (ti * (ti + 1) > t) --ti;
+  const int tj = t - ti * (ti + 1);
+  const int I0 = ti * TR, J0 = tj * TC;
+  const int64_t per = (nsteps + nsplit - 1) / nsplit;
+  const int64_t c0 = split * per, c1 = (c0 + per < nsteps) ? c0 + per : nsteps;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                  // 0: group A, 1: group B (half a step behind)
+  const int w4 = wave & 3;
+  const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;  // the two groups interleave the four 32-row blocks
+  const int l32 = lane & 31, lh = lane >> 5;
+
+  i16 acc[NP];
+#pragma unroll
+  for (int g = 0; g < NP; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+
+  constexpr int PIECES7 = 2 * NP * 2, PPW8 = (PIECES7 + 7) / 8;  // 28 pieces (A columns only), 4 per wave
+  unsigned goff[PPW8];
+  int soff[PPW8];
+#pragma unroll
+  for (int k = 0; k < PPW8; ++k) {
+    int e = wave + 8 * k;
+    if (e >= PIECES7) e -= PIECES7;
+    const int rbl = e / (NP * 2), rem = e % (NP * 2), p = rem / 2, cg = rem % 2;
+    const int col = I0 + cg * 64;
+    goff[k] = (unsigned)(((rbl * NP + p) * Mp + col + lane) * 16);
+    soff[k] = __builtin_amdgcn_readfirstlane(((rbl * NP + p) * SCOLS + cg * 64) * 16);
+  }
+  const size_t gstride = (size_t)2 * NP * Mp * 16;
+  auto dma_piece = [&](const uint8_t* gbase, int sbase, int k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + goff[k]),
+                                     (__attribute__((address_space(3))) void*)(lds + sbase + soff[k]), 16, 0, 0);
+  };
+  auto mfma = [&](const i4& a, const i4& b, i16& c) { c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); };
+  constexpr int PSPLIT = 5;  // batches 0 .. PSPLIT - 1 (15 MFMAs at 5) in the first half of a step, the rest (13) in the second
+
+  const unsigned long long cy0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  const int64_t nst = c1 - c0;
+  // barrier sequence of the workgroup: E(0) O(0) E(1) O(1) .. E(nst-1) O(nst-1) E(nst).  E(s) = group A's top of step s and group
+  // B's middle of step s - 1; O(s) = A's middle of step s and B's top of step s.  Before every E(s) each wave waits for its own
+  // pieces of stage s; after every E(s) each wave issues its pieces of stage s + 2 (that slot held stage s - 1, last read after
+  // O(s - 1) by group B).
+  // vmcnt in program order per step: [7 B loads of step s + 1][4 DMA pieces of stage s + 2].  NTOP: before my step top everything but
+  // the youngest DMA group must be back (my B operands, my pieces of the stage about to be read); NMID (group B's middle): my pieces
+  // of the next stage, older than the B loads and DMA pieces of this step
+  auto wait_n = [&](int64_t sE, bool mid) {
+    if (MODE == 1 || sE + 2 >= nst)
+      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+    else if (mid)
+      __builtin_amdgcn_s_waitcnt(((PPW8 + NP) & 15) | (((PPW8 + NP) >> 4) << 14) | (7 << 4) | (15 << 8));
+    else
+      __builtin_amdgcn_s_waitcnt((PPW8 & 15) | ((PPW8 >> 4) << 14) | (7 << 4) | (15 << 8));
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  i4 b[NP], bn[NP], a[NP];
+  const size_t boff = (size_t)((lh * NP) * Mp + J0 + wj * 32 + l32) * 16;  // + p Mp 16 per plane
+  auto bload = [&](int64_t sidx, i4 (&dst)[NP]) {
+    const uint8_t* gb = Q + (size_t)(c0 + sidx) * gstride + boff;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dst[p] = *reinterpret_cast<const i4*>(gb + (size_t)p * Mp * 16);
+  };
+  auto reads = [&](int64_t sidx) {
+    const uint8_t* sb = lds + (int)(sidx % NSTAGE) * STAGE_BYTES + lh * (NP * SCOLS * 16);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const i4*>(sb + (p * SCOLS + wi * 32 + l32) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE != 1 && sidx + 1 < nst) bload(sidx + 1, bn);   // next step's B operands: one step of latency cover
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // MFMA batches [p0, p1) with (optionally) the DMA pieces of stage sE + 2 in their shadow, one every two MFMAs
+  auto half = [&](int p0, int p1, bool dma_on, int64_t sE) {
+    const bool pre = dma_on && MODE != 1 && sE + 2 < nst;
+    const uint8_t* gnext = Q + (size_t)(c0 + sE + 2) * gstride;
+    const int snext = (int)((sE + 2) % NSTAGE) * STAGE_BYTES;
+    int issued = 0, kpiece = 0;
+#pragma unroll
+    for (int p = p0; p < p1; ++p)
+#pragma unroll
+      for (int r = NP - 1 - p; r < NP; ++r) {
+        mfma(a[p], b[r], acc[p + r - (NP - 1)]);
+        ++issued;
+        if (dma_on && (issued & 1) && issued >= 3 && kpiece < PPW8) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (pre) dma_piece(gnext, snext, kpiece);
+          __builtin_amdgcn_sched_barrier(0);
+          ++kpiece;
+        }
+      }
+  };
+  auto rotate = [&]() {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) b[p] = bn[p];
+  };
+  if (nst > 0) {
+#pragma unroll
+    for (int k = 0; k < PPW8; ++k) dma_piece(Q + (size_t)c0 * gstride, 0, k);
+    if (nst > 1) {
+#pragma unroll
+      for (int k = 0; k < PPW8; ++k) dma_piece(Q + (size_t)(c0 + 1) * gstride, STAGE_BYTES, k);
+    }
+    bload(0, b);
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // prologue: everything back (stage 0, stage 1, my first B operands)
+    if (grp == 0) {
+      for (int64_t sidx = 0; sidx < nst; ++sidx) {
+        if (sidx > 0) wait_n(sidx - 1, false);  // B operands of this step + my pieces of stage s (issued in step s - 2)
+        bar();                                  // E(s): my step top
+        reads(sidx);
+        half(0, PSPLIT, true, sidx);
+        bar();                                  // O(s): my middle
+        half(PSPLIT, NP, false, sidx);
+        rotate();
+      }
+      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+      bar();                                    // E(nst)
+    } else {
+      bar();                                    // E(0)
+      for (int64_t sidx = 0; sidx < nst; ++sidx) {
+        if (sidx > 0) wait_n(sidx - 1, false);  // my B operands of this step
+        bar();                                  // O(s): my step top
+        reads(sidx);
+        half(0, PSPLIT, true, sidx);
+        __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8));  // lgkmcnt(0)
+        wait_n(sidx, true);                     // my pieces of stage s + 1 (older than this step's B loads and DMA pieces)
+        bar();                                  // E(s + 1): my middle
+        half(PSPLIT, NP, false, sidx + 1);
+        rotate();
+      }
+    }
+  }
+  if (tid == 0 && id == 0) {
+    stamp[0] = __builtin_amdgcn_s_memtime() - cy0;
+    stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    stamp[2] = (unsigned long long)(c1 - c0);
+  }
+  double* out = slab + ((size_t)split * ntiles + t) * (TR * TC);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    double v = 0.0;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
+    const int row = wi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+    out[row * TC + wj * 32 + l32] = v;
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int MODE, int RS = 0>
@@ -785,7 +952,7 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
   digits_kernel<<<dim3((Mp + 255) / 256, (unsigned)(N / 16)), 256>>>(N / 16, Mp, Q);
   CK(hipDeviceSynchronize());
   const size_t shm = (size_t)NSTAGE * STAGE_BYTES;
-  auto kern = RS == 4 ? i8_syrk_v6_kernel<MODE> : RS == 3 ? i8_syrk_v5_kernel<MODE> : RS == 2 ? i8_syrk_v4_kernel<MODE> : RS == 1 ? i8_syrk_rs_kernel<MODE> : i8_syrk_kernel<MODE>;
+  auto kern = RS == 5 ? i8_syrk_v7_kernel<MODE> : RS == 4 ? i8_syrk_v6_kernel<MODE> : RS == 3 ? i8_syrk_v5_kernel<MODE> : RS == 2 ? i8_syrk_v4_kernel<MODE> : RS == 1 ? i8_syrk_rs_kernel<MODE> : i8_syrk_kernel<MODE>;
   const int nthreads = RS >= 3 ? 512 : 256;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const int grid = nsplit * ntiles;
@@ -804,7 +971,7 @@ static double run(int64_t N, int M, bool check, int reps, int split_rows = 16384
   const double f64_equiv = (double)N * M * M * 1e-9 / ms;  // the accounting of bench.py: N M^2 flops for the lower triangle, GFLOP/ms = TFLOP/s
   const double macs = (double)N * ntiles * TR * TC * 28.0;
   printf("%s mode %d  N %lld M %d: %d splits x %d tiles = %d workgroups, %.3f ms, int8 %.1f TMAC/s (%.2f of 2447), fp64-equivalent %.1f TFLOP/s\n",
-         RS == 4 ? "v6 (2 staggered groups)" : RS == 3 ? "v5 (8 waves)" : RS == 2 ? "v4" : RS == 1 ? "reg-staged" : "lds-dma", MODE, (long long)N, Mp, nsplit, ntiles, grid, ms, macs / (ms * 1e-3) / 1e12, macs / (ms * 1e-3) / 1e12 / 2447.0, f64_equiv);
+         RS == 5 ? "v7 (v6, B operand direct)" : RS == 4 ? "v6 (2 staggered groups)" : RS == 3 ? "v5 (8 waves)" : RS == 2 ? "v4" : RS == 1 ? "reg-staged" : "lds-dma", MODE, (long long)N, Mp, nsplit, ntiles, grid, ms, macs / (ms * 1e-3) / 1e12, macs / (ms * 1e-3) / 1e12 / 2447.0, f64_equiv);
   unsigned long long hs[3];
   CK(hipMemcpy(hs, stamp, 24, hipMemcpyDeviceToHost));
   printf("  workgroup 0: %.0f cycles per 32-row step (1792 = matrix pipe alone), clock %.0f MHz\n", (double)hs[0] / (double)hs[2], (double)hs[0] / ((double)hs[1] * 10.0) * 1e3);
@@ -844,11 +1011,12 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_map), &zero, 4));
   if (argc > 3) {  // parameter sweep builds (-DHOLD_R= -DDMA_FIRST= -DDMA_EVERY= for v4, -DPSPLIT_V= for v6)
     run<0, 4>(8192, 256, true, 1);
-    for (int sr = 16384; sr >= 2048; sr /= 2) {
-      printf("-- %d rows per split\n", sr);
-      run<0, 4>(N, M, false, 5, sr);
+    run<0, 5>(8192, 256, true, 1);
+    run<0, 5>(40960, 384, true, 1, 4096);
+    for (int rep = 0; rep < 3; ++rep) {
+      run<0, 4>(N, M, false, 5);
+      run<0, 5>(N, M, false, 5);
     }
-    run<0, 4>(N, M, false, 5);
     return 0;
   }
   run<0, 2>(8192, 256, true, 1);
