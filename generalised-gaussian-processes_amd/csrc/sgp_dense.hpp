@@ -27,6 +27,8 @@ struct GemmDesc {
   bool lower_only = false;
 };
 void gemm(const GemmDesc& g, hipStream_t st);
+// part[s][0 .. ceil(M/64)) = column-norm maxima of the S factors L (ld x ld each, `stride` doubles apart): lambda_max >= max of them
+void cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st);
 double cond_gate_limit();   // sgp_set_cond_limit's current value (sgp_tail.hip): the explicit-inverse paths refuse above it
 int available_cus();       // CUs a launch of this host thread can occupy (device count, or the budget below)
 void set_cu_budget(int n);  // CUs the calling host thread's launches may occupy (CU-masked streams); 0 = all

@@ -653,6 +653,10 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
                                  const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
                                  double* Phi, double* b, double* yy, double* kappa, double* Kfu_out, void* ws,
                                  size_t ws_bytes, sgp_stream_t stream) {
+  // the one-shot gate belongs to THIS call whatever path it takes (an early return must not leave a handle behind for a later
+  // call to wait on: the caller's event may be destroyed by then)
+  hipEvent_t gate = g_pass1_gate;
+  g_pass1_gate = nullptr;
   if (!Z || !inv_ls || !Phi || !b || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
@@ -706,7 +710,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   // profiles/r03_i8_leapfrog_ab.jsonl) -- pass 2 runs 1.4 ms longer behind the integer contraction, whose power draw it inherits.
   const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
   g_contraction_used = use_i8 ? 1 : 0;
-  if (!use_i8) g_pass1_gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
+  if (!use_i8) gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
   if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
   if (use_i8) {
     // digit planes (7 bytes per element) live where the library's fp64 K'_fu (8 bytes) would; with a caller-owned K'_fu (value +
@@ -720,8 +724,8 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
       timing_end(TIMING_ASSEMBLE, st);
       // the integer contraction leaves next to nothing for anybody else (129 KB of LDS, two 188-register waves per SIMD): a side-stream chain
       // the caller wants done by the end of pass 1 (chol(K_uu)) has to finish beside the ASSEMBLY, so the contraction waits for it
-      if (g_pass1_gate && hipStreamWaitEvent(st, g_pass1_gate, 0) != hipSuccess) return SGP_ERR_LAUNCH;
-      g_pass1_gate = nullptr;
+      if (gate && hipStreamWaitEvent(st, gate, 0) != hipSuccess) return SGP_ERR_LAUNCH;
+      gate = nullptr;
       timing_begin(TIMING_SYRK, st);
       if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st) != SGP_OK) return SGP_ERR_LAUNCH;
       timing_end(TIMING_SYRK, st);

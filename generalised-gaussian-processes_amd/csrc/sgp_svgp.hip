@@ -804,10 +804,10 @@ __global__ __launch_bounds__(256) void mix_bmat_kernel(const double* __restrict_
     Bm[off + e] = (r == c ? 1.0 : 0.0) + W[off + e] * is2;
   }
 }
-// after chol(Kuu): conditioning gate (sgp_tail.hip: cond_gate_kernel; trace(Kuu) = M (sf2 + J) for a stationary kernel);
+// after chol(Kuu): conditioning gate (sgp_tail.hip: cond_gate_kernel; lambda_max >= the largest column norm of L, `part`);
 // after chol(B): a failure there is reported as M + pivot (only into a status word that is still 0)
-__global__ void mix_status_kernel(const double* __restrict__ L, int Mp, int M, SvgpThetaS th, double jitter, double limit, int* __restrict__ info,
-                                  const int* __restrict__ infoB, int S) {
+__global__ void mix_status_kernel(const double* __restrict__ L, int Mp, int M, const double* __restrict__ part, int npart, double limit,
+                                  int* __restrict__ info, const int* __restrict__ infoB, int S) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   if (infoB) {
@@ -822,7 +822,9 @@ __global__ void mix_status_kernel(const double* __restrict__ L, int Mp, int M, S
     const double v = Ls[(int64_t)i * Mp + i];
     if (v < lo) { lo = v; at = i; }
   }
-  if (!((double)M * (th.ka[s].sf2 + jitter) <= limit * lo * lo)) info[s] = at + 1;
+  double hi = 0.0;
+  for (int i = 0; i < npart; ++i) hi = fmax(hi, part[(int64_t)s * npart + i]);
+  if (!(hi <= limit * lo * lo)) info[s] = at + 1;
 }
 // q[s] = LBinv[s] u[s]   (lower triangular, one wave per row)
 __global__ __launch_bounds__(256) void mix_trmv_kernel(const double* __restrict__ Li, int Mp, const double* __restrict__ u, double* __restrict__ q) {
@@ -1245,7 +1247,8 @@ extern "C" int sgp_mixture_predict(const double* X, int64_t ldx, const double* y
     default: svgp_kuu_batch_kernel<SGP_KERNEL_MATERN52><<<dim3(gmm, S), 256, 0, st>>>(Z, ldz, th, jitter, M, Mp, w.Kp); break;
   }
   potrf_lower_batch(w.Kp, w.Linv, Mp, Mp, S, mm, info, w.flags, st);
-  mix_status_kernel<<<1, 64, 0, st>>>(w.Kp, Mp, M, th, jitter, cond_gate_limit(), info, nullptr, S);
+  if (cond_gate_limit() > 0.0) cond_colnorms(w.Kp, Mp, (int64_t)mm, M, S, w.tmp, st);  // w.tmp is free until tri_inverse
+  mix_status_kernel<<<1, 64, 0, st>>>(w.Kp, Mp, M, w.tmp, (M + 63) / 64, cond_gate_limit(), info, nullptr, S);
   tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st, S, mm);
   const int64_t Nc = mix_chunk(N);
   for (int64_t t0 = 0; t0 < N; t0 += Nc) {
@@ -1266,7 +1269,7 @@ extern "C" int sgp_mixture_predict(const double* X, int64_t ldx, const double* y
   mix_bmat_kernel<<<dim3(gmm, S), 256, 0, st>>>(w.W, th, Mp, w.Bm);
   zero_ints(w.infoB, S, st);
   potrf_lower_batch(w.Bm, w.LBinv, Mp, Mp, S, mm, w.infoB, w.flags, st);
-  mix_status_kernel<<<1, 64, 0, st>>>(nullptr, Mp, M, th, jitter, 0.0, info, w.infoB, S);
+  mix_status_kernel<<<1, 64, 0, st>>>(nullptr, Mp, M, nullptr, 0, 0.0, info, w.infoB, S);
   tri_inverse(w.Bm, w.LBinv, w.tmp, Mp, Mp, st, S, mm);
   mix_trmv_kernel<<<dim3(Mp / 4, S), 256, 0, st>>>(w.LBinv, Mp, w.u, w.q);
 

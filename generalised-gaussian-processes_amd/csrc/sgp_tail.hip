@@ -593,44 +593,68 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
 // Conditioning gate of the explicit-inverse path.  Everything downstream of sgp_kuu_factor multiplies by the explicit L^-1;
 // unlike LAPACK's substitution that is not backward stable, and once cond(K_uu + J I) passes ~1e13 the bound it produces is
 // noise (measured at the CO2 model's M = 480, profiles/r03_co2_m480_chol_ab.json: cond 1e15, F = 7776 / 9440 for theta 1e-7
-// apart where LAPACK gives 1706.7726 / 1706.7731 -- a spurious spike that traps a Markov chain).  The factorization gives a
-// cheap estimate of the condition number: lambda_max <= trace(K) (and ~ trace for the strongly correlated inducing sets that
-// get into trouble), lambda_min <= every pivot L_ii^2, so  est = trace(K) / min_i L_ii^2  (>= cond / 1 for a dominant
-// eigenvalue, <= M cond always).  Above g_cond_limit the matrix is reported as numerically not positive definite at its
-// smallest pivot (info = argmin + 1), so samplers see a zero-density region (a divergence, as PyMC3 treats a failed
-// factorization) instead of a finite, meaningless density.  (The pivot ratio (max L_ii / min L_ii)^2 alone says 2e11 at that
-// cond-1e15 point: the diagonal of K is 2e6 while lambda_max is 1e9.)  The single-launch path (M <= 128, substitution solves)
-// is not gated: it tracks LAPACK.
+// apart where LAPACK gives 1706.7726 / 1706.7731 -- a spurious spike that traps a Markov chain).  The factor itself gives a
+// condition estimate that can only UNDERSHOOT (round 4; round 3 used trace(K) for lambda_max, which overshoots by up to M and
+// refused well-posed problems with a large amplitude, e.g. M sf2 >= 1e7 with one near-duplicate inducing pair):
+//     lambda_max(K) = ||L||_2^2 >= max_j ||L e_j||^2   (a column of L),      lambda_min(K) <= every pivot L_ii^2,
+// so  est = max_j ||L e_j||^2 / min_i L_ii^2 <= cond(K)  always.  For the strongly correlated inducing sets that get into
+// trouble the first columns of L carry the dominant eigenvector (||L e_0||^2 ~ trace K), for a well-spread set the estimate is
+// ~ sf2 / min pivot.  Above g_cond_limit the matrix is reported as numerically not positive definite at its smallest pivot
+// (info = argmin + 1), so samplers see a zero-density region (a divergence, as PyMC3 treats a failed factorization) instead
+// of a finite, meaningless density.  The single-launch path (M <= 128, substitution solves) is not gated: it tracks LAPACK
+// (DESIGN section 4a).
 static double g_cond_limit = 1e13;
 double sgp::cond_gate_limit() { return g_cond_limit; }
-__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ K, const double* __restrict__ L, int64_t ld, int M,
-                                                        double limit, int* info) {
-  __shared__ double smin[4], str[4];
+// part[s][blockIdx.x] = max over 64 columns j of sum_{i >= j, i < M} L[i][j]^2   (L: S matrices of ld x ld, lower triangle)
+__global__ __launch_bounds__(256) void cond_colnorm_kernel(const double* __restrict__ L, int64_t ld, int64_t stride, int M,
+                                                           double* __restrict__ part) {
+  __shared__ double acc[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+  const double* Ls = L + (int64_t)blockIdx.y * stride;
+  double s = 0.0;
+  if (j < M)
+    for (int i = (j & ~3) + r; i < M; i += 4)
+      if (i >= j) { const double v = Ls[(int64_t)i * ld + j]; s = fma(v, v, s); }
+  acc[r][c] = s;
+  __syncthreads();
+  if (r == 0) {
+    s = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    if (c == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+void sgp::cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st) {
+  cond_colnorm_kernel<<<dim3((M + 63) / 64, S), 256, 0, st>>>(L, ld, stride, M, part);
+}
+__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ L, int64_t ld, int M, const double* __restrict__ part,
+                                                        int npart, double limit, int* info) {
+  __shared__ double smin[4], smax[4];
   __shared__ int imin[4];
-  double lo = 1e300, tr = 0.0;
+  double lo = 1e300, hi = 0.0;
   int at = 0;
   for (int i = threadIdx.x; i < M; i += 256) {
     const double v = L[(int64_t)i * ld + i];
     if (v < lo) { lo = v; at = i; }
-    tr += K[(int64_t)i * M + i];
   }
+  for (int i = threadIdx.x; i < npart; i += 256) hi = fmax(hi, part[i]);
   // wave level: butterfly on (value, index) pairs -- ties go to the smaller index, so every lane ends with the same pair
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const double ov = __shfl_xor(lo, o, 64);
     const int oi = __shfl_xor(at, o, 64);
     if (ov < lo || (ov == lo && oi < at)) { lo = ov; at = oi; }
-    tr += __shfl_xor(tr, o, 64);
+    hi = fmax(hi, __shfl_xor(hi, o, 64));
   }
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { smin[w] = lo; str[w] = tr; imin[w] = at; }
+  if ((threadIdx.x & 63) == 0) { smin[w] = lo; smax[w] = hi; imin[w] = at; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int t = 1; t < 4; ++t) {
       if (smin[t] < lo || (smin[t] == lo && imin[t] < at)) { lo = smin[t]; at = imin[t]; }
-      tr += str[t];
+      hi = fmax(hi, smax[t]);
     }
-    if (*info == 0 && !(tr <= limit * lo * lo)) *info = at + 1;  // (a NaN pivot the factorization let through never becomes `lo`:
+    if (*info == 0 && !(hi <= limit * lo * lo)) *info = at + 1;  // (a NaN pivot the factorization let through never becomes `lo`:
   }                                                              //  potrf itself reports those)
 }
 
@@ -650,7 +674,10 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   zero_ints(info, 1, st);
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
-  if (g_cond_limit > 0.0) cond_gate_kernel<<<1, 256, 0, st>>>(Kuu, L, Mp, M, g_cond_limit, info);
+  if (g_cond_limit > 0.0) {  // `tmp` is free until tri_inverse: the column-norm partials live at its start
+    cond_colnorms(L, Mp, 0, M, 1, tmp, st);
+    cond_gate_kernel<<<1, 256, 0, st>>>(L, Mp, M, tmp, (M + 63) / 64, g_cond_limit, info);
+  }
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   return check_launch();
 }

@@ -836,6 +836,30 @@ def test_conditioning_gate_of_the_explicit_inverse_path(engine):
 
 
 @pytest.mark.gpu
+def test_conditioning_gate_accepts_a_well_posed_large_amplitude_problem(engine):
+    """unnormalised targets (CO2 in ppm) put the amplitude at ~1e4; with M = 1000 well-spread inducing inputs and ONE
+    near-duplicate pair (min pivot ~ the jitter) round 3's estimate trace(K) / min pivot = M sf2 / J = 1e13+ refused a matrix whose
+    condition number is ~2 sf2 / J = 2e10 -- which LAPACK, the reference's substitution solves and the single-launch path evaluate.
+    The column-norm estimate can only undershoot cond: the matrix passes, and the bound still agrees with the oracle."""
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    g = torch.Generator().manual_seed(3)
+    M, N, d = 1000, 4000, 2
+    X = torch.rand(N, d, dtype=torch.float64, generator=g) * 40.0
+    y = 100.0 * torch.sin(X[:, 0]) * torch.cos(0.5 * X[:, 1]) + torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[torch.randperm(N, generator=g)[:M]].clone()
+    Z[1] = Z[0] + 1e-9                                     # one near-duplicate pair
+    sf2, ls = 2.0e4, [0.7, 0.7]                              # M sf2 / jitter = 2e13 > the 1e13 limit; cond ~ 4e10
+    K = engine.kuu(dev(Z.numpy(), engine), ls, sf2, 1e-6, "rbf")
+    assert int(engine.kuu_factor(K)[1].cpu()[0]) == 0
+    cb = ggp_amd.CollapsedBound(dev(X.numpy(), engine), dev(y.numpy(), engine), jitter=1e-6, engine=engine)
+    cb.fused = False
+    F, parts = cb.value(dev(Z.numpy(), engine), ls, sf2, 1.0)
+    F_ref = O.vfe_pymc3_order_chunked(X, y, Z, torch.tensor(ls, dtype=torch.float64), math.sqrt(sf2), 1.0, 1e-6)
+    assert abs(F - F_ref) < 1e-6 * abs(F_ref), (F, F_ref)
+
+
+@pytest.mark.gpu
 def test_mixture_predictive_batched_over_the_samples(engine):
     """sgp_mixture_predict (row f-2: eight theta samples per chain of launches, PSD gates in one dataflow launch) against the
     oracle's predictive sample by sample, against the per-sample loop of the reference (model.batched_mixture = False), with
