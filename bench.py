@@ -20,8 +20,9 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task description)
                       mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) from the newest profiles/*_pmc_sq_counters.csv
   roofline_leapfrog : the same for the dominant kernel of the reverse pass, `kbar_contract_kernel` (2 N M^2 flop)
   cpu_baseline      : the oracle's PyMC3-op-order restatement timed on this box's host cores (rank 0, N=1 only): value
-                      only at two sample sizes (fixed + per-row cost fitted, then evaluated at N; --cpu-full times all N
-                      rows instead), and value + autograd gradient next to leapfrog_per_s
+                      only on ALL N rows in 65 536-row chunks (--cpu-fit: two sample sizes, fixed + per-row
+                      cost fitted and evaluated at N), and value + autograd gradient fitted from two samples (its graph does
+                      not fit the host at N = 1M) next to leapfrog_per_s
 """
 import csv
 import glob
@@ -173,7 +174,11 @@ def main():
     ap.add_argument("--rows", dest="n", type=int, default=N_TOTAL)
     ap.add_argument("--inducing", dest="m", type=int, default=M_IND)
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="rows of the larger CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on all N rows (~80-110 s) instead of fitting two samples")
+    ap.add_argument("--cpu-full", dest="cpu_full", action="store_true", default=True,
+                    help="time the CPU baseline's value-only evaluation on ALL N rows in 65 536-row chunks (SURVEY section 8d; ~80-110 s "
+                         "at C5; the default since round 4)")
+    ap.add_argument("--cpu-fit", dest="cpu_full", action="store_false",
+                    help="fit the CPU baseline from two samples (--cpu-sample rows and half of it) instead of timing all N rows")
     ap.add_argument("--side-chain", choices=["graph", "launches", "off"], default="graph",
                     help="how chol(Kuu) is enqueued on the side stream (A/B knob; default = the product default)")
     args = ap.parse_args()

@@ -11,11 +11,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsgp_hip.so")
 
-SGP_ABI_VERSION = 1
+SGP_ABI_VERSION = 2
 SGP_MAX_DIM = 32
 SGP_MAX_INDUCING = 4096
 KERNEL_IDS = {"rbf": 0, "matern32": 1, "matern52": 2, "composite": 3}
 COMP_LEN = 33  # SGP_COMP_LEN: doubles in a composite-kernel parameter block (include/sgp.h)
+OPT_CONTRACTION, OPT_ASM_OVERLAP, OPT_KFU_BUDGET_BYTES, OPT_COND_LIMIT, OPT_CU_BUDGET, OPT_TIMING = range(6)
 OUT_F, OUT_LOGMARG, OUT_TRACE, OUT_LOGDETB, OUT_QUAD, OUT_TRW, OUT_S2BAR, OUT_KAPPABAR, OUT_LEN = range(9)
 
 
@@ -37,6 +38,27 @@ _ip = C.POINTER(C.c_int)
 PROTOTYPES = {
     "sgp_abi_version": (_i32, []),
     "sgp_status_string": (C.c_char_p, [_i32]),
+    # contexts (ABI version 2): first argument = sgp_ctx* (NULL = the default context)
+    "sgp_ctx_create": (_vp, [_i32]),
+    "sgp_ctx_destroy": (None, [_vp]),
+    "sgp_ctx_device": (_i32, [_vp]),
+    "sgp_ctx_set_option": (_i32, [_vp, _i32, _dbl]),
+    "sgp_ctx_get_option": (_dbl, [_vp, _i32]),
+    "sgp_ctx_set_pass1_gate": (None, [_vp, _vp]),
+    "sgp_ctx_contraction_last": (_i32, [_vp]),
+    "sgp_ctx_contraction_would_use_i8": (_i32, [_vp, _i64, _i32]),
+    "sgp_ctx_timing_last_ms": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),
+    "sgp_ctx_timing_last_rows": (_i64, [_vp, _i32]),
+    "sgp_ctx_suffstats_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32, _i32]),
+    "sgp_ctx_suffstats_fwd": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_suffstats_bwd": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _i64, _i32, _i32, _i32,
+                                     _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_kuu_factor": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_mixture_predict": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _i32, _i32, _i32, _i32,
+                                       _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_timing_enable": (None, [_i32]),
     "sgp_timing_last_ms": (_i32, [_i32, C.POINTER(C.c_float)]),
     "sgp_timing_last_rows": (_i64, [_i32]),
@@ -63,6 +85,9 @@ PROTOTYPES = {
     "sgp_logdiag_sum": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "sgp_bound_workspace_bytes": (_sz, [_i32, _i32]),
     "sgp_bound_factors_len": (_sz, [_i32]),
+    "sgp_kuu_inverse_trace_len": (_sz, []),
+    "sgp_kuu_inverse_trace": (_i32, [_vp, _i32, _vp, _vp]),
+    "sgp_streaming_error_estimate": (_i32, [_vp, _vp, _dbl, _i64, _i32, _vp, _vp]),
     "sgp_kuu_factor_len": (_sz, [_i32]),
     "sgp_kuu_factor_workspace_bytes": (_sz, [_i32]),
     "sgp_kuu_factor": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -141,6 +141,13 @@ class CollapsedBound:
         self.early_check_min_work = 1 << 28  # ... from which value_and_grad reads the status before enqueueing pass 2
         self._side = None
         self._pool = None
+        # Guard of the streaming order (form="auto" only): every streaming evaluation carries the library's first-order estimate
+        # of |dF| / N (include/sgp.h: sgp_streaming_error_estimate; one extra word in the evaluation's one host copy).  Above
+        # this tolerance -- long lengthscales x small noise: W = L^-1 Phi L^-T amplifies the rounding of Phi by 1 / lambda(K_uu)
+        # -- the evaluation is repeated in the whitened (PyMC3) order, A = L^-1 K_uf first.  The estimate is a function of the
+        # replicated tail and the all-reduced statistics, bit for bit the same on every rank: all ranks repeat together.
+        self.streaming_tol = 1e-9
+        self.n_guard_reruns = 0
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -231,10 +238,21 @@ class CollapsedBound:
             return hasattr(self.engine, "suffstats_whitened") and self._rows_for_form * int(M) <= self.WHITENED_MAX_WORK
         return self.form == "whitened"
 
-    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0):
+    def _guard_on(self):
+        return self.form == "auto" and self.streaming_tol > 0.0 and hasattr(self.engine, "streaming_error_estimate")
+
+    def _guard_trips(self, res, host):
+        """True when a streaming-order evaluation must be repeated in the whitened order (see ``streaming_tol``)."""
+        if not res.get("guarded"):
+            return False
+        est = self.engine.read_estimate(host)
+        res["estimate"] = est
+        return not (est <= self.streaming_tol)  # NaN trips too
+
+    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=False):
         e = self.engine
         result = e.result_buffer(extra)  # (buf, out, info): everything the host reads back, one allocation
-        if self._whitened(Z.shape[0]):
+        if force_whitened or self._whitened(Z.shape[0]):
             # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
@@ -251,6 +269,8 @@ class CollapsedBound:
             return res
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
         gate = None
+        guard = self._guard_on()
+        trace = None
         # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
         # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)
         overlap = (self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
@@ -282,9 +302,10 @@ class CollapsedBound:
                         K = e.kuu(Z, ls, sf2, jitter, kernel, out=gr["Kuu"])
                         gr["graph"].replay()
                         result[2].copy_(gr["info"])  # the evaluation's status word starts as the Kuu status
-                        return K, gr["Linv"]
+                        return K, gr["Linv"], gr.get("trace")
                     K = e.kuu(Z, ls, sf2, jitter, kernel)
-                    return K, e.kuu_factor(K, info=result[2])[0]
+                    li = e.kuu_factor(K, info=result[2])[0]
+                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0]) if guard else None)
 
             result[0].record_stream(side)
             # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
@@ -292,8 +313,10 @@ class CollapsedBound:
             # chain runs beside kernel assembly; otherwise the helper thread enqueues it and it shares the chip with pass 1
             # (only where assembly outlasts the chain -- 2.0 ms vs 0.6 at N = 1M, M = 1024, but 0.3 vs 0.6 at an eighth of it,
             # where gating costs 0.1 ms: rows >= 300 M)
-            if (gr is not None and hasattr(e, "lib") and hasattr(e.lib, "sgp_set_pass1_gate")
-                    and int(self.X.shape[0]) >= 300 * int(Z.shape[0])):
+            # ... and only where the integer cores will actually contract (the library's own rule for this engine's context: a
+            # shard below it, a pinned fp64 mode or a composite kernel keeps the helper-thread overlap)
+            if (gr is not None and hasattr(e, "would_use_i8") and self.kernel != "composite"
+                    and int(self.X.shape[0]) >= 300 * int(Z.shape[0]) and e.would_use_i8(int(self.X.shape[0]), int(Z.shape[0]))):
                 chain = side_chain()
                 gate = side.record_event()
                 pending = None
@@ -302,15 +325,24 @@ class CollapsedBound:
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
         self._allreduce_stats(packed, int(Z.shape[0]))
         if overlap:
-            Kuu, linv = pending.result() if pending is not None else chain
-            for t in (Kuu, linv):
+            Kuu, linv, trace = pending.result() if pending is not None else chain
+            for t in (Kuu, linv) + ((trace,) if trace is not None else ()):
                 t.record_stream(main)
             main.wait_stream(self._side)
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
+                          result=result)
+        elif guard and hasattr(e, "kuu_factor"):
+            Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
+            linv, _ = e.kuu_factor(Kuu, info=result[2])
+            trace = e.kuu_inverse_trace(linv, Z.shape[0])
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
         else:
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, result=result)
+        if guard and trace is not None:
+            e.streaming_error_estimate(packed, trace, s2, self.N, Z.shape[0], result)
+            res["guarded"] = True
         res["packed"] = packed
         res["kfu"] = kfu
         return res
@@ -330,7 +362,11 @@ class CollapsedBound:
                 return float("nan"), {"info": info}
             return float(h[0]), {"logmarg": float(h[nh + 2]), "trace_term": float(h[nh + 3]), "info": 0}
         res = self._forward(Z, ls, sf2, s2, with_adjoints=False)
-        o, info, _ = self._fetch(res)
+        o, info, host = self._fetch(res)
+        if self._guard_trips(res, host):  # the streaming order is not trustworthy at this theta: PyMC3's order instead
+            self.n_guard_reruns += 1
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=True)
+            o, info, host = self._fetch(res)
         self.n_evals += 1
         if info != 0:
             if raise_on_fail:
@@ -351,7 +387,7 @@ class CollapsedBound:
             raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), self.d))
         return vals + [float(sf2), float(s2)], None
 
-    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True):
+    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True, _force_whitened=False):
         """F and dF/d{lengthscale_j, sf2, s2[, Z]} (natural parameters, not their raw transforms).
 
         Returns (F, grads) with grads = dict(ls=tensor[d] (cpu), sf2=float, s2=float, Z=device tensor or None).
@@ -375,14 +411,18 @@ class CollapsedBound:
             return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
                                  "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0))
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0),
+                            force_whitened=_force_whitened)
         head = res["out"].numel() + 2  # [out | status word | pad], then the packed gradient (16-byte aligned)
         # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the
         # status and the gradient -- a failed factorization then costs a wasted pass 2 (its NaNs are discarded), which
         # is cheaper than idling the GPU for a host round trip on every leapfrog.  Big shards check the status first.
         early = int(self.X.shape[0]) * M >= self.early_check_min_work
         if early:
-            o, info, _ = self._fetch(res, upto=head)
+            o, info, hh = self._fetch(res, upto=head)
+            if self._guard_trips(res, hh):  # before pass 2 is spent on adjoints that cannot be trusted
+                self.n_guard_reruns += 1
+                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=True)
             if info != 0:
                 self.n_evals += 1
                 self.n_grads += 1
@@ -401,6 +441,9 @@ class CollapsedBound:
         self._allreduce(g)
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
         o, info, host = self._fetch(res, upto=head + nh + 1)
+        if not early and self._guard_trips(res, host):
+            self.n_guard_reruns += 1
+            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=True)
         self.n_evals += 1
         self.n_grads += 1
         if info != 0:
@@ -417,7 +460,11 @@ class CollapsedBound:
         """Device tensor [Linv | G | q] for ``predict`` (computed from the current statistics)."""
         Z = self._prep_Z(Z)
         res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True)
-        _, info, _ = self._fetch(res)
+        _, info, host = self._fetch(res)
+        if self._guard_trips(res, host):
+            self.n_guard_reruns += 1
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=True)
+            _, info, _ = self._fetch(res)
         if info != 0:
             raise NotPositiveDefiniteError(info)
         return res["factors"]

@@ -11,6 +11,7 @@
 //   trtri  : recursive doubling on the inverted diagonal blocks, Inv21 = -Inv22 (L21 Inv11), batched GEMMs
 // Triangular structure is exploited by clipping each output tile's k-range (GemmDesc::klo/khi masks).
 #include "sgp_dense.hpp"
+#include "sgp_ctx.hpp"
 #include "sgp_potrf.hpp"
 
 namespace sgp {
@@ -332,8 +333,10 @@ const int* potrf_abort_flag(const int* scratch, int Mp) {
 // A caller that enqueues on a CU-masked stream (hipExtStreamCreateWithCUMask: CollapsedBound reserves a few CUs for the K_uu
 // chain beside pass 1 on small shards) tells this host thread how many CUs its launches can occupy: sgp_set_cu_budget(n),
 // 0 = the whole device.  Per host thread, because the side chain is enqueued by a helper thread.
-static thread_local int g_cu_budget = 0;
-void set_cu_budget(int n) { g_cu_budget = n > 0 ? n : 0; }
+// (round 4: the budget is an option of the call's context, SGP_OPT_CU_BUDGET; the deprecated per-thread setter overrides it)
+static thread_local int t_cu_budget = 0;
+void set_cu_budget(int n) { t_cu_budget = n > 0 ? n : 0; }
+static int cu_budget() { return t_cu_budget > 0 ? t_cu_budget : cur_ctx().cu_budget; }
 static int df_max_workgroups() {
   static int n = 0;
   if (n == 0) {
@@ -342,7 +345,7 @@ static int df_max_workgroups() {
       cus = DF_MAX_WG;
     n = cus < DF_MAX_WG ? cus : DF_MAX_WG;
   }
-  return (g_cu_budget > 0 && g_cu_budget < n) ? g_cu_budget : n;
+  return (cu_budget() > 0 && cu_budget() < n) ? cu_budget() : n;
 }
 
 // CUs a launch of the calling host thread can occupy: the device's count, or the caller's budget for a CU-masked stream.
@@ -355,7 +358,7 @@ int available_cus() {
       n = DF_MAX_WG;  // no device visible (CPU-only build check): the shape-only answer
     cus = n;
   }
-  return (g_cu_budget > 0 && g_cu_budget < cus) ? g_cu_budget : cus;
+  return (cu_budget() > 0 && cu_budget() < cus) ? cu_budget() : cus;
 }
 
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,

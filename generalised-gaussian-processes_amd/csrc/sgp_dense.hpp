@@ -27,8 +27,17 @@ struct GemmDesc {
   bool lower_only = false;
 };
 void gemm(const GemmDesc& g, hipStream_t st);
-// part[s][0 .. ceil(M/64)) = column-norm maxima of the S factors L (ld x ld each, `stride` doubles apart): lambda_max >= max of them
+// part[s][2 b], part[s][2 b + 1], b < ceil(M/64): per 64-column block of the S factors L (ld x ld each, `stride` doubles apart) the
+// largest squared column norm and the sum of squared column sums; cond_lambda_max() turns them into a LOWER bound of lambda_max(L L^T)
 void cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st);
+__device__ __forceinline__ double cond_lambda_max(const double* __restrict__ part, int npart, int M) {
+  double hi = 0.0, rq = 0.0;
+  for (int i = 0; i < npart; ++i) {  // fixed order
+    hi = fmax(hi, part[2 * i]);      // ||L e_j||^2 <= lambda_max
+    rq += part[2 * i + 1];           // ||L^T 1||^2 = 1^T K 1
+  }
+  return fmax(hi, rq / (double)M);
+}
 double cond_gate_limit();   // sgp_set_cond_limit's current value (sgp_tail.hip): the explicit-inverse paths refuse above it
 int available_cus();       // CUs a launch of this host thread can occupy (device count, or the budget below)
 void set_cu_budget(int n);  // CUs the calling host thread's launches may occupy (CU-masked streams); 0 = all

@@ -28,32 +28,32 @@
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
 #include "sgp_composite.hpp"
+#include "sgp_ctx.hpp"
 #include <cstdlib>
 
 namespace sgp {
 
-static size_t g_kfu_budget = KFU_BUDGET_DEFAULT;
-size_t stream_kfu_budget() { return g_kfu_budget; }
+// (every switch and every piece of state below lives in the call's context: sgp_ctx.hpp)
+static_assert(TIMING_SLOTS == CTX_TIMING_SLOTS, "timing slots");
+size_t stream_kfu_budget() { return cur_ctx().kfu_budget; }
 
-static int g_timing = 0;
-static int64_t g_syrk_timed_rows = 0;  // data rows of the contraction launch the TIMING_SYRK events bracket (sgp_timing_last_rows)
-static hipEvent_t g_ev[TIMING_SLOTS][2];
-static int g_ev_ready = 0, g_ev_used[TIMING_SLOTS] = {0, 0, 0};
 // (a failed event call only leaves the optional timing slot unused: sgp_timing_last_ms then reports SGP_ERR_ARG)
 void timing_begin(int slot, hipStream_t st) {
-  if (!g_timing) return;
-  if (!g_ev_ready) {
+  Ctx& c = cur_ctx();
+  if (!c.timing) return;
+  if (!c.ev_ready) {
     bool ok = true;
     for (int s = 0; s < TIMING_SLOTS; ++s)
-      for (int k = 0; k < 2; ++k) ok = (hipEventCreate(&g_ev[s][k]) == hipSuccess) && ok;
+      for (int k = 0; k < 2; ++k) ok = (hipEventCreate(&c.ev[s][k]) == hipSuccess) && ok;
     if (!ok) return;
-    g_ev_ready = 1;
+    c.ev_ready = 1;
   }
-  if (hipEventRecord(g_ev[slot][0], st) != hipSuccess) g_ev_used[slot] = 0;
+  if (hipEventRecord(c.ev[slot][0], st) != hipSuccess) c.ev_used[slot] = 0;
 }
 void timing_end(int slot, hipStream_t st) {
-  if (!g_timing || !g_ev_ready) return;
-  g_ev_used[slot] = hipEventRecord(g_ev[slot][1], st) == hipSuccess ? 1 : 0;
+  Ctx& c = cur_ctx();
+  if (!c.timing || !c.ev_ready) return;
+  c.ev_used[slot] = hipEventRecord(c.ev[slot][1], st) == hipSuccess ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -531,18 +531,15 @@ static int syrk_grid(int nsplit, int ntiles) { return 8 * ((nsplit >> 3) * ntile
 // assembly INSIDE the contraction's launch (producer workgroups in its grid); its ceiling is the 0.8 ms by which the assembly's
 // HBM time exceeds its fp64 VALU time, because fp64 VALU and MFMA share the datapath.  Kept for A/B.
 constexpr int HEAD_SPLITS_MAX = 24;
-static int g_asm_overlap = -1;  // -1: read SGP_ASM_OVERLAP (default on) at first use
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
-static bool side_stream_ready() {
-  if (g_side) return true;
+static bool side_stream_ready(Ctx& c) {
+  if (c.side) return true;
   int lo = 0, hi = 0;
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
-  if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi) != hipSuccess) { g_side = nullptr; return false; }
-  if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
-    (void)hipStreamDestroy(g_side);
-    g_side = nullptr;
+  if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, hi) != hipSuccess) { c.side = nullptr; return false; }
+  if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(c.side);
+    c.side = nullptr;
     return false;
   }
   return true;
@@ -551,7 +548,7 @@ static bool side_stream_ready() {
 static void head_block(const StreamPlan& p, int64_t nchunks, int* head_ns, int64_t* head_chunks) {
   *head_ns = 0;
   *head_chunks = 0;
-  if (g_asm_overlap < 0) g_asm_overlap = getenv("SGP_ASM_OVERLAP") ? atoi(getenv("SGP_ASM_OVERLAP")) : 0;
+  const int g_asm_overlap = cur_ctx().asm_overlap;
   int hs = RESIDENT_WGS / p.ntiles;
   if (hs > HEAD_SPLITS_MAX) hs = HEAD_SPLITS_MAX;
   const int64_t w = 8 * (int64_t)p.taper[0] + 4 * p.taper[1] + 2 * p.taper[2] + p.taper[3];  // tapered plans only (big shards)
@@ -567,16 +564,14 @@ static void head_block(const StreamPlan& p, int64_t nchunks, int* head_ns, int64
 // ---- which matrix cores contract (value-only evaluations) ------------------------------------------------------------------
 // 0: fp64 (syrk_tile_kernel), 1 (default): the integer cores (sgp_suffstats_i8.hip) where they win -- enough work, and a K'_fu
 // nobody keeps -- 2: the integer cores whenever the call allows it (tests).  SGP_CONTRACTION / sgp_set_contraction.
-static int g_contraction = -1;
-static int g_contraction_used = 0;  // what the last sgp_suffstats_fwd call ran: 0 fp64, 1 int8 digit planes
-static hipEvent_t g_pass1_gate = nullptr;  // one-shot: the integer contraction of the next call waits for it (sgp_set_pass1_gate)
 // default rule: rows x Mp^2 >= 2^32 (profiles/r03_i8_boundary.jsonl: 8192 x 1024, 30000 x 512, 65536 x 256, 1M x 128 win by 5-36 %;
 // 16384 x 256, 20000 x 384, 200000 x 100, 4096 x 512 lose -- too few 128 x 64 tiles x 16384-row splits to fill 256 CUs)
 constexpr double I8_MIN_WORK = 4294967296.0;
 
-static int contraction_mode() {
-  if (g_contraction < 0) g_contraction = getenv("SGP_CONTRACTION") ? atoi(getenv("SGP_CONTRACTION")) : 1;
-  return g_contraction;
+static int contraction_mode() { return cur_ctx().contraction; }
+// the rule itself (also sgp_ctx_contraction_would_use_i8): Npad rows of the shard, padded M
+static bool i8_rule(int mode, int64_t Npad, int Mp) {
+  return Npad > 0 && (mode == 2 || (mode == 1 && (double)Npad * Mp * Mp >= I8_MIN_WORK));
 }
 
 constexpr int BRED_G = 64;  // row groups of the two-stage b reduction
@@ -600,7 +595,7 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qro
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
   // (with a caller-owned K'_fu the planes need a super-chunk of their own -- only where the contraction rule can pick the integer path)
-  const bool own_q = !need_kfu && (contraction_mode() == 2 || (contraction_mode() == 1 && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
+  const bool own_q = !need_kfu && i8_rule(contraction_mode(), p.Npad, p.Mp);
   w.Q = need_kfu ? reinterpret_cast<uint8_t*>(w.Kfu) : (own_q ? c.take<uint8_t>((size_t)(qrows > 0 ? qrows : 1) * p.Mp * 7) : nullptr);
   w.bytes = c.used();
   return w;
@@ -610,28 +605,36 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qro
 
 using namespace sgp;
 
-extern "C" void sgp_timing_enable(int on) { g_timing = on; }
-
-extern "C" int sgp_timing_last_ms(int slot, float* ms) {
+static int ctx_timing_last_ms(Ctx& c, int slot, float* ms) {
   if (slot < 0 || slot >= TIMING_SLOTS || !ms) return SGP_ERR_ARG;
-  if (!g_ev_ready || !g_ev_used[slot]) return SGP_ERR_ARG;
-  if (hipEventSynchronize(g_ev[slot][1]) != hipSuccess) return SGP_ERR_LAUNCH;
-  return hipEventElapsedTime(ms, g_ev[slot][0], g_ev[slot][1]) == hipSuccess ? SGP_OK : SGP_ERR_LAUNCH;
+  if (!c.ev_ready || !c.ev_used[slot]) return SGP_ERR_ARG;
+  if (hipEventSynchronize(c.ev[slot][1]) != hipSuccess) return SGP_ERR_LAUNCH;
+  return hipEventElapsedTime(ms, c.ev[slot][0], c.ev[slot][1]) == hipSuccess ? SGP_OK : SGP_ERR_LAUNCH;
+}
+extern "C" int sgp_ctx_timing_last_ms(sgp_ctx* ctx, int slot, float* ms) {
+  return ctx_timing_last_ms(ctx ? *reinterpret_cast<Ctx*>(ctx) : default_ctx(), slot, ms);
+}
+extern "C" int64_t sgp_ctx_timing_last_rows(const sgp_ctx* ctx, int slot) {
+  return slot == TIMING_SYRK ? (ctx ? *reinterpret_cast<const Ctx*>(ctx) : default_ctx()).syrk_timed_rows : -1;
+}
+extern "C" int sgp_ctx_contraction_would_use_i8(const sgp_ctx* ctx, int64_t N, int M) {
+  if (N <= 0 || M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  return i8_rule((ctx ? *reinterpret_cast<const Ctx*>(ctx) : default_ctx()).contraction, round_up64(N, ASM_ROWS), padded_m(M)) ? 1 : 0;
 }
 
-extern "C" int64_t sgp_timing_last_rows(int slot) { return slot == TIMING_SYRK ? g_syrk_timed_rows : -1; }
-
-extern "C" void sgp_set_asm_overlap(int mode) { g_asm_overlap = mode < 0 ? -1 : mode; }
-
+// ---- deprecated process-wide switches: shims over the DEFAULT context (include/sgp.h) ----
+extern "C" void sgp_timing_enable(int on) { default_ctx().timing = on ? 1 : 0; }
+extern "C" int sgp_timing_last_ms(int slot, float* ms) { return ctx_timing_last_ms(default_ctx(), slot, ms); }
+extern "C" int64_t sgp_timing_last_rows(int slot) { return sgp_ctx_timing_last_rows(nullptr, slot); }
+extern "C" void sgp_set_asm_overlap(int mode) { default_ctx().asm_overlap = (mode < 0 || mode > 2) ? 0 : mode; }
 extern "C" int sgp_set_contraction(int mode) {
-  const int prev = g_contraction;
-  g_contraction = (mode < 0 || mode > 2) ? -1 : mode;
+  const int prev = default_ctx().contraction;
+  default_ctx().contraction = (mode < 0 || mode > 2) ? 1 : mode;
   return prev;
 }
-extern "C" int sgp_contraction_last(void) { return g_contraction_used; }
-extern "C" void sgp_set_pass1_gate(void* hip_event) { g_pass1_gate = (hipEvent_t)hip_event; }
-
-extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { g_kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
+extern "C" int sgp_contraction_last(void) { return default_ctx().contraction_used; }
+extern "C" void sgp_set_pass1_gate(void* hip_event) { default_ctx().pass1_gate = (hipEvent_t)hip_event; }
+extern "C" void sgp_set_kfu_budget_bytes(size_t bytes) { default_ctx().kfu_budget = bytes ? bytes : KFU_BUDGET_DEFAULT; }
 
 extern "C" size_t sgp_kfu_len(int64_t N, int M) {
   if (N < 0 || M <= 0 || M > SGP_MAX_INDUCING) return 0;
@@ -655,8 +658,9 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
                                  size_t ws_bytes, sgp_stream_t stream) {
   // the one-shot gate belongs to THIS call whatever path it takes (an early return must not leave a handle behind for a later
   // call to wait on: the caller's event may be destroyed by then)
-  hipEvent_t gate = g_pass1_gate;
-  g_pass1_gate = nullptr;
+  Ctx& cx = cur_ctx();
+  hipEvent_t gate = cx.pass1_gate;
+  cx.pass1_gate = nullptr;
   if (!Z || !inv_ls || !Phi || !b || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
@@ -685,9 +689,8 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
     syrk_tile_kernel<4, false, false><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.slab, p.nsplit);
   }
-  static const int skip_upper = getenv("SGP_SYRK_SKIP_UPPER") ? atoi(getenv("SGP_SYRK_SKIP_UPPER")) : 1;  // 0 = full diagonal tiles (A/B knob)
-  static const int nwaves = getenv("SGP_SYRK_WAVES") ? atoi(getenv("SGP_SYRK_WAVES")) : 4;
-  static const int glds = getenv("SGP_SYRK_GLDS") ? atoi(getenv("SGP_SYRK_GLDS")) : 0;
+  const int skip_upper = cx.syrk_skip_upper;  // 0 = full diagonal tiles (A/B knob SGP_SYRK_SKIP_UPPER, read at context creation)
+  const int nwaves = cx.syrk_waves, glds = cx.syrk_glds;
   auto contract = [&](const double* K, int64_t nchunks, const SplitMap& smap, int nsplit, int accum, double* slab) {
     const int g = syrk_grid(nsplit, p.ntiles);
 #define SGP_SYRK_LAUNCH(NWV, GL, SK) \
@@ -704,12 +707,11 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   int nslabs = p.nsplit;
   int head_ns = 0;
   int64_t head_chunks = 0;
-  (void)contraction_mode();
   // With a kept K'_fu (value + gradient: pass 2 reads the fp64 block) the assembly writes the fp64 block AND the planes.  Pass 1 alone
   // gains 3.0 ms at C5 (2.6 + 12.9 against 1.7 + 16.0 ms), the leapfrog it belongs to 1.1 ms (50.4 against 51.5, same box, alternating:
   // profiles/r03_i8_leapfrog_ab.jsonl) -- pass 2 runs 1.4 ms longer behind the integer contraction, whose power draw it inherits.
-  const bool use_i8 = p.Npad > 0 && (g_contraction == 2 || (g_contraction == 1 && (double)p.Npad * p.Mp * p.Mp >= I8_MIN_WORK));
-  g_contraction_used = use_i8 ? 1 : 0;
+  const bool use_i8 = i8_rule(cx.contraction, p.Npad, p.Mp);
+  cx.contraction_used = use_i8 ? 1 : 0;
   if (!use_i8) gate = nullptr;  // the fp64 contraction shares the chip with a side stream: no gate
   if (p.Npad > 0 && !use_i8) head_block(p, p.Npad / NB, &head_ns, &head_chunks);
   if (use_i8) {
@@ -729,14 +731,14 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
       timing_begin(TIMING_SYRK, st);
       if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st) != SGP_OK) return SGP_ERR_LAUNCH;
       timing_end(TIMING_SYRK, st);
-      g_syrk_timed_rows = rows;
+      cx.syrk_timed_rows = rows;
     }
     nslabs = ns;
   } else if (head_ns > 0) {
     // head block [0, hrows) | tail [hrows, Npad): the tail's assembly runs on the side stream beside the head's contraction
     // (serially on the main stream when the side stream cannot be had or SGP_ASM_OVERLAP=2: same blocks, same numbers)
     const int64_t hrows = head_chunks * NB, trows = p.Npad - hrows, tchunks = trows / NB;
-    const bool side = g_asm_overlap == 1 && side_stream_ready();
+    const bool side = cx.asm_overlap == 1 && side_stream_ready(cx);
     double* head_slab = w.slab + (size_t)p.nsplit * p.ntiles * TILE * TILE;
     const int hcps = (int)((head_chunks + head_ns - 1) / head_ns);
     const int tcps = (int)((tchunks + p.nsplit - 1) / p.nsplit);
@@ -745,20 +747,20 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     timing_begin(TIMING_ASSEMBLE, st);
     stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, 0, hrows, N, M, Kfu, w.bpart, st);
     bool forked = false;
-    if (side && hipEventRecord(g_ev_fork, st) == hipSuccess && hipStreamWaitEvent(g_side, g_ev_fork, 0) == hipSuccess) {
-      stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, hrows, trows, N, M, Kfu + (size_t)hrows * p.Mp, w.bpart, g_side);
-      forked = hipEventRecord(g_ev_join, g_side) == hipSuccess;
-      if (!forked) (void)hipStreamSynchronize(g_side);  // never expected: fall back to a blocking join
+    if (side && hipEventRecord(cx.ev_fork, st) == hipSuccess && hipStreamWaitEvent(cx.side, cx.ev_fork, 0) == hipSuccess) {
+      stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, hrows, trows, N, M, Kfu + (size_t)hrows * p.Mp, w.bpart, cx.side);
+      forked = hipEventRecord(cx.ev_join, cx.side) == hipSuccess;
+      if (!forked) (void)hipStreamSynchronize(cx.side);  // never expected: fall back to a blocking join
     } else {
       stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, hrows, trows, N, M, Kfu + (size_t)hrows * p.Mp, w.bpart, st);
     }
     timing_end(TIMING_ASSEMBLE, st);  // overlapped: the head's assembly only (what stays on the critical path)
     contract(Kfu, head_chunks, hmap, head_ns, 0, head_slab);
-    if (forked && hipStreamWaitEvent(st, g_ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(g_side);
+    if (forked && hipStreamWaitEvent(st, cx.ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(cx.side);
     timing_begin(TIMING_SYRK, st);  // the dominant launch: the tail's contraction, alone on the device
     contract(Kfu + (size_t)hrows * p.Mp, tchunks, tmap, p.nsplit, 0, w.slab);
     timing_end(TIMING_SYRK, st);
-    g_syrk_timed_rows = trows;
+    cx.syrk_timed_rows = trows;
     nslabs = p.nsplit + head_ns;
   } else {
     for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
@@ -772,7 +774,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
       timing_begin(TIMING_SYRK, st);
       contract(Kfu, nchunks, smap, p.nsplit, r0 > 0 ? 1 : 0, w.slab);
       timing_end(TIMING_SYRK, st);
-      g_syrk_timed_rows = rows;
+      cx.syrk_timed_rows = rows;
     }
   }
   const int nb32 = p.Mp / 32;

@@ -27,6 +27,7 @@
 // Measured alternatives (register staging, lockstep waves, held-back MFMAs, split-major order): tools/i8_syrk_proto.hip, DESIGN.md 4d.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
+#include "sgp_ctx.hpp"
 #include <cstdlib>
 
 namespace sgp {
@@ -341,14 +342,14 @@ void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* y
 // slab[split][128 x 128 tile of the lower triangle] (+)= this split's part of K'^T K' (without sf2^2), as syrk_tile_kernel
 // leaves it for reduce_phi_kernel.  rows: a multiple of 32; nsplit from i8_nsplit() (the same for every super-chunk).
 int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  Ctx& cx = cur_ctx();
+  if (!cx.i8_attr_set) {  // per context, i.e. per device (the attribute belongs to the device's copy of the kernel)
     if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) != hipSuccess)
       return SGP_ERR_LAUNCH;
-    attr_set = true;
+    cx.i8_attr_set = true;
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
-  const int prio = getenv("SGP_I8_PRIO") ? atoi(getenv("SGP_I8_PRIO")) : 0;  // A/B knob (read per call; measured a loss)
+  const int prio = cx.i8_prio;  // A/B knob SGP_I8_PRIO (read when the context is created; measured a loss)
   i8_syrk_tile_kernel<<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab, prio);
   return SGP_OK;
 }

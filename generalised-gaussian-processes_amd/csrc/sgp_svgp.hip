@@ -822,8 +822,7 @@ __global__ void mix_status_kernel(const double* __restrict__ L, int Mp, int M, c
     const double v = Ls[(int64_t)i * Mp + i];
     if (v < lo) { lo = v; at = i; }
   }
-  double hi = 0.0;
-  for (int i = 0; i < npart; ++i) hi = fmax(hi, part[(int64_t)s * npart + i]);
+  const double hi = cond_lambda_max(part + (int64_t)s * 2 * npart, npart, M);
   if (!(hi <= limit * lo * lo)) info[s] = at + 1;
 }
 // q[s] = LBinv[s] u[s]   (lower triangular, one wave per row)

@@ -10,6 +10,7 @@
 // padding rows are identity for Kuu / zero for Phi so factors stay exact) through the MFMA GEMM,
 // blocked Cholesky and recursive triangular inverse of sgp_dense.hip; no host round trip.
 #include "sgp_dense.hpp"
+#include "sgp_ctx.hpp"
 #include "sgp_composite.hpp"
 
 namespace sgp {
@@ -597,33 +598,46 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
 // condition estimate that can only UNDERSHOOT (round 4; round 3 used trace(K) for lambda_max, which overshoots by up to M and
 // refused well-posed problems with a large amplitude, e.g. M sf2 >= 1e7 with one near-duplicate inducing pair):
 //     lambda_max(K) = ||L||_2^2 >= max_j ||L e_j||^2   (a column of L),      lambda_min(K) <= every pivot L_ii^2,
-// so  est = max_j ||L e_j||^2 / min_i L_ii^2 <= cond(K)  always.  For the strongly correlated inducing sets that get into
-// trouble the first columns of L carry the dominant eigenvector (||L e_0||^2 ~ trace K), for a well-spread set the estimate is
-// ~ sf2 / min pivot.  Above g_cond_limit the matrix is reported as numerically not positive definite at its smallest pivot
+//     lambda_max(K) >= 1^T K 1 / M = ||L^T 1||^2 / M   (the Rayleigh quotient of the constant vector: the mean row sum of K, within
+//                                                       a small factor of lambda_max for a positive kernel matrix),
+// so  est = max(both) / min_i L_ii^2 <= cond(K)  always.  For one tight cluster the first column of L carries the dominant
+// eigenvector (||L e_0||^2 ~ trace K); for a long 1-D chain (the CO2 inputs: 300 points 0.17 apart, lengthscale 3) no single column
+// does and the mean row sum (~43 sf2 there) is what finds lambda_max; for a well-spread set the estimate is ~ sf2 / min pivot.  Above g_cond_limit the matrix is reported as numerically not positive definite at its smallest pivot
 // (info = argmin + 1), so samplers see a zero-density region (a divergence, as PyMC3 treats a failed factorization) instead
 // of a finite, meaningless density.  The single-launch path (M <= 128, substitution solves) is not gated: it tracks LAPACK
 // (DESIGN section 4a).
-static double g_cond_limit = 1e13;
-double sgp::cond_gate_limit() { return g_cond_limit; }
-// part[s][blockIdx.x] = max over 64 columns j of sum_{i >= j, i < M} L[i][j]^2   (L: S matrices of ld x ld, lower triangle)
+double sgp::cond_gate_limit() { return cur_ctx().cond_limit; }
+// over the 64 columns j of block blockIdx.x, with column j = L[j .. M-1][j] (L: S matrices of ld x ld, lower triangle):
+//   part[s][2 b] = max_j sum_i L[i][j]^2,      part[s][2 b + 1] = sum_j (sum_i L[i][j])^2      (fixed order: bit-reproducible)
 __global__ __launch_bounds__(256) void cond_colnorm_kernel(const double* __restrict__ L, int64_t ld, int64_t stride, int M,
                                                            double* __restrict__ part) {
-  __shared__ double acc[4][64];
+  __shared__ double acc[4][64], acs[4][64];
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
   const double* Ls = L + (int64_t)blockIdx.y * stride;
-  double s = 0.0;
+  double s = 0.0, cs = 0.0;
   if (j < M)
     for (int i = (j & ~3) + r; i < M; i += 4)
-      if (i >= j) { const double v = Ls[(int64_t)i * ld + j]; s = fma(v, v, s); }
+      if (i >= j) { const double v = Ls[(int64_t)i * ld + j]; s = fma(v, v, s); cs += v; }
   acc[r][c] = s;
+  acs[r][c] = cs;
   __syncthreads();
   if (r == 0) {
     s = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
+    cs = (acs[0][c] + acs[1][c]) + (acs[2][c] + acs[3][c]);
+    cs *= cs;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
-    if (c == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    for (int o = 32; o > 0; o >>= 1) {
+      s = fmax(s, __shfl_xor(s, o, 64));
+      cs += __shfl_xor(cs, o, 64);
+    }
+    if (c == 0) {
+      double* dst = part + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+      dst[0] = s;
+      dst[1] = cs;
+    }
   }
 }
+
 void sgp::cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st) {
   cond_colnorm_kernel<<<dim3((M + 63) / 64, S), 256, 0, st>>>(L, ld, stride, M, part);
 }
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict
     const double v = L[(int64_t)i * ld + i];
     if (v < lo) { lo = v; at = i; }
   }
-  for (int i = threadIdx.x; i < npart; i += 256) hi = fmax(hi, part[i]);
+  if (threadIdx.x == 0) hi = cond_lambda_max(part, npart, M);
   // wave level: butterfly on (value, index) pairs -- ties go to the smaller index, so every lane ends with the same pair
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -674,14 +688,73 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   zero_ints(info, 1, st);
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
-  if (g_cond_limit > 0.0) {  // `tmp` is free until tri_inverse: the column-norm partials live at its start
+  if (cond_gate_limit() > 0.0) {  // `tmp` is free until tri_inverse: the column-norm partials live at its start
     cond_colnorms(L, Mp, 0, M, 1, tmp, st);
-    cond_gate_kernel<<<1, 256, 0, st>>>(L, Mp, M, tmp, (M + 63) / 64, g_cond_limit, info);
+    cond_gate_kernel<<<1, 256, 0, st>>>(L, Mp, M, tmp, (M + 63) / 64, cond_gate_limit(), info);
   }
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   return check_launch();
 }
-extern "C" void sgp_set_cond_limit(double limit) { g_cond_limit = limit >= 0.0 ? limit : 1e13; }
+// ---- guard of the streaming evaluation order -----------------------------------------------------------------------------------
+// Phi = K_uf K_fu carries a rounding of ~2^-53 max_i Phi_ii per entry however it was summed (fp64 or integer cores: the result is a
+// double), and W = L^-1 Phi L^-T amplifies it by 1 / lambda_k(K_uu) in the k-th eigen-direction: to first order
+//     |dF| ~ (1 / 2 s2) sum_k |dW_kk| ~ 2^-53 max_i Phi_ii tr(K_uu^-1) / s2,          tr(K_uu^-1) = ||L^-1||_F^2.
+// Calibrated against the PyMC3-order CPU oracle over lengthscales 0.2 .. 20 x noise 0.01 .. 3 at N = 200 000, M = 512 (profiles/
+// r04_theta_sweep_streaming.jsonl): the estimate tracks the measured |dF| / N within a factor of 5 over ten orders of magnitude (it
+// overshoots for exactly duplicated inducing rows, whose eigen-directions carry no error).  The caller (core.py) re-evaluates in the
+// whitened (PyMC3) order when estimate / N exceeds its tolerance.  Both kernels sum in a FIXED order: every rank of a sharded
+// evaluation holds the same L^-1 and the same all-reduced Phi, so every rank gets the same bits and takes the same decision.
+__global__ __launch_bounds__(256) void linv_rowsq_kernel(const double* __restrict__ Li, int64_t ld, int M, double* __restrict__ part) {
+  __shared__ double red[4];
+  // block b: rows 64 b .. 64 b + 63 (< M), columns j <= i
+  const int i0 = blockIdx.x * 64;
+  double s = 0.0;
+  for (int r = threadIdx.x >> 6; r < 64; r += 4) {
+    const int i = i0 + r;
+    if (i >= M) break;
+    for (int j = threadIdx.x & 63; j <= i; j += 64) {
+      const double v = Li[(int64_t)i * ld + j];
+      s = fma(v, v, s);
+    }
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void linv_trace_final_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += part[b];
+  out[0] = s;
+}
+extern "C" size_t sgp_kuu_inverse_trace_len(void) { return 1 + SGP_MAX_INDUCING / 64; }
+extern "C" int sgp_kuu_inverse_trace(const double* kuu_linv, int M, double* trace_out, sgp_stream_t stream) {
+  if (!kuu_linv || !trace_out || M <= 0) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (M + 63) / 64;
+  linv_rowsq_kernel<<<nb, 256, 0, st>>>(kuu_linv, padded_m(M), M, trace_out + 1);
+  linv_trace_final_kernel<<<1, 1, 0, st>>>(trace_out + 1, nb, trace_out);
+  return check_launch();
+}
+__global__ __launch_bounds__(256) void streaming_estimate_kernel(const double* __restrict__ Phi, int M, const double* __restrict__ tr,
+                                                                 double s2, double n, double* __restrict__ est) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  for (int i = threadIdx.x; i < M; i += 256) mx = fmax(mx, Phi[(int64_t)i * M + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) est[0] = 0x1p-53 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) * tr[0] / (s2 * n);
+}
+extern "C" int sgp_streaming_error_estimate(const double* stats, const double* trace_inv, double s2, int64_t N, int M, double* est,
+                                            sgp_stream_t stream) {
+  if (!stats || !trace_inv || !est || M <= 0 || N < 0 || !(s2 > 0.0)) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  streaming_estimate_kernel<<<1, 256, 0, (hipStream_t)stream>>>(stats, M, trace_inv, s2, N > 0 ? (double)N : 1.0, est);
+  return check_launch();
+}
+
+extern "C" void sgp_set_cond_limit(double limit) { default_ctx().cond_limit = limit >= 0.0 ? limit : 1e13; }  // deprecated shim
 
 // whitened: Phi / b already are W = A A^T and u = A y with A = L^-1 K_uf (sgp_suffstats_fwd_whitened); kuu_linv required
 static int bound_impl(const double* Kuu, const double* Phi, const double* b, const double* yy,

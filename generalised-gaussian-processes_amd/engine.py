@@ -33,15 +33,57 @@ def _kernel_id(kernel) -> int:
 
 
 class HipEngine:
-    """Calls the HIP library on ``device`` (default: current CUDA device).  No CPU fallback."""
+    """Calls the HIP library on ``device`` (default: current CUDA device).  No CPU fallback.
 
-    def __init__(self, device: Optional[torch.device] = None):
+    ``own_context=True`` gives the engine a library context of its own (include/sgp.h: sgp_ctx_create): its contraction mode,
+    conditioning limit, budgets and timing events are then independent of every other engine in the process (``set_option`` /
+    ``get_option`` / ``contraction_last``).  The default engine runs in the library's DEFAULT context -- the one the deprecated
+    process-wide setters (``lib.sgp_set_contraction`` ...) act on."""
+
+    OPTIONS = {"contraction": _lib.OPT_CONTRACTION, "asm_overlap": _lib.OPT_ASM_OVERLAP, "kfu_budget_bytes": _lib.OPT_KFU_BUDGET_BYTES,
+               "cond_limit": _lib.OPT_COND_LIMIT, "cu_budget": _lib.OPT_CU_BUDGET, "timing": _lib.OPT_TIMING}
+
+    def __init__(self, device: Optional[torch.device] = None, own_context: bool = False):
         self.lib = _lib.load_library()
         if not torch.cuda.is_available():
             raise _lib.SgpLibraryError("HipEngine needs a HIP device (torch.cuda.is_available() is False); "
                                        "there is no CPU implementation of the sparse-GP core")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._ws = {}
+        self._ctx = None  # NULL = the default context
+        if own_context:
+            self._ctx = self.lib.sgp_ctx_create(self.device.index if self.device.index is not None else torch.cuda.current_device())
+            if not self._ctx:
+                raise _lib.SgpLibraryError("sgp_ctx_create failed")
+
+    def __del__(self):
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx:
+            try:
+                self.lib.sgp_ctx_destroy(C.c_void_p(ctx))
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+    # ------------------------------------------------------------------ context
+    def _c(self):
+        return C.c_void_p(self._ctx) if self._ctx else C.c_void_p(0)
+
+    def set_option(self, name: str, value) -> float:
+        """Sets an option of this engine's context (``OPTIONS``); returns the previous value."""
+        prev = self.lib.sgp_ctx_get_option(self._c(), self.OPTIONS[name])
+        _lib.check("sgp_ctx_set_option", self.lib.sgp_ctx_set_option(self._c(), self.OPTIONS[name], float(value)))
+        return prev
+
+    def get_option(self, name: str) -> float:
+        return self.lib.sgp_ctx_get_option(self._c(), self.OPTIONS[name])
+
+    def contraction_last(self) -> int:
+        """What this engine's last pass 1 ran: 0 fp64 matrix cores, 1 integer matrix cores."""
+        return int(self.lib.sgp_ctx_contraction_last(self._c()))
+
+    def would_use_i8(self, N: int, M: int) -> bool:
+        """The contraction rule of this engine's context for an N-row shard with M inducing inputs."""
+        return bool(self.lib.sgp_ctx_contraction_would_use_i8(self._c(), int(N), int(M)))
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, name: str, nbytes: int) -> torch.Tensor:
@@ -103,15 +145,15 @@ class HipEngine:
         if out is None:
             out = self.empty(M * M + M + 2)
         # with a caller-owned K'_fu the library's own super-chunk (up to 16 GiB) is not part of the workspace
-        nbytes = self.lib.sgp_suffstats_workspace_bytes_ex(N, M, d, 1 if kfu is not None else 0)
+        nbytes = self.lib.sgp_ctx_suffstats_workspace_bytes(self._c(), N, M, d, 1 if kfu is not None else 0)
         if nbytes == 0:
             raise ValueError("unsupported shape N=%d M=%d d=%d (d <= %d, M <= %d)" % (N, M, d, _lib.SGP_MAX_DIM, _lib.SGP_MAX_INDUCING))
         ws = self._workspace("fwd_kfu" if kfu is not None else "fwd", nbytes)
         base = out.data_ptr()
         if gate is not None:
-            self.lib.sgp_set_pass1_gate(C.c_void_p(gate.cuda_event))
-        st = self.lib.sgp_suffstats_fwd(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+            self.lib.sgp_ctx_set_pass1_gate(self._c(), C.c_void_p(gate.cuda_event))
+        st = self.lib.sgp_ctx_suffstats_fwd(
+            self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_fwd", st)
@@ -179,9 +221,29 @@ class HipEngine:
         if info is None:
             info = torch.empty(1, dtype=torch.int32, device=self.device)  # cleared by the call itself
         ws = self._workspace("kuu_factor", self.lib.sgp_kuu_factor_workspace_bytes(M))
-        st = self.lib.sgp_kuu_factor(self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        st = self.lib.sgp_ctx_kuu_factor(self._c(), self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_kuu_factor", st)
         return Linv, info
+
+    def kuu_inverse_trace(self, Linv, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tr(K_uu^-1) = ||L^-1||_F^2 in out[0] (the other entries are scratch) from ``kuu_factor``'s output: the ingredient of the
+        streaming-order guard (include/sgp.h: sgp_streaming_error_estimate) that does not depend on the streamed statistics."""
+        if out is None:
+            out = self.empty(self.lib.sgp_kuu_inverse_trace_len())
+        _lib.check("sgp_kuu_inverse_trace", self.lib.sgp_kuu_inverse_trace(self._ptr(Linv), int(M), self._ptr(out), self._stream()))
+        return out
+
+    def streaming_error_estimate(self, packed, trace, s2, N, M, result) -> None:
+        """Writes the first-order estimate of |dF| / N of the streaming order into the pad word of ``result`` (a
+        ``result_buffer``): it comes back with the evaluation's one host copy (``read_estimate``)."""
+        buf = result[0]
+        est = C.c_void_p(buf.data_ptr() + 8 * (OUT_LEN + 1))
+        _lib.check("sgp_streaming_error_estimate",
+                   self.lib.sgp_streaming_error_estimate(self._ptr(packed), self._ptr(trace), float(s2), int(N), int(M), est, self._stream()))
+
+    @staticmethod
+    def read_estimate(host_buf) -> float:
+        return float(host_buf[OUT_LEN + 1])
 
     def kuu_factor_graph(self, M: int):
         """The ~50 launches of ``kuu_factor`` captured once per M in a hipGraph over static buffers: replaying it costs
@@ -200,9 +262,12 @@ class HipEngine:
             info = torch.zeros(1, dtype=torch.int32, device=self.device)
             ws = torch.empty(self.lib.sgp_kuu_factor_workspace_bytes(M), dtype=torch.uint8, device=self.device)
 
+            trace = self.empty(self.lib.sgp_kuu_inverse_trace_len())
+
             def run():
-                st = self.lib.sgp_kuu_factor(self._ptr(Kst), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+                st = self.lib.sgp_ctx_kuu_factor(self._c(), self._ptr(Kst), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
                 _lib.check("sgp_kuu_factor", st)
+                self.kuu_inverse_trace(Linv, M, out=trace)  # the guard's ingredient rides in the same graph
 
             warm = torch.cuda.Stream(device=self.device)
             warm.wait_stream(torch.cuda.current_stream(self.device))
@@ -215,7 +280,7 @@ class HipEngine:
             # another bound) must neither fail nor invalidate this capture
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 run()
-            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws}
+            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws, "trace": trace}
         except RuntimeError as exc:  # stream capture unavailable / refused: plain launches still work
             import warnings
             warnings.warn("hipGraph capture of the Kuu chain failed (%s); falling back to plain launches" % (exc,))
@@ -269,7 +334,7 @@ class HipEngine:
         elif whitened:
             _lib.check("sgp_bound_from_whitened_stats", self.lib.sgp_bound_from_whitened_stats(*stats, *tail))
         else:
-            _lib.check("sgp_bound_from_stats", self.lib.sgp_bound_from_stats(self._ptr(Kuu), *stats, *tail))
+            _lib.check("sgp_bound_from_stats", self.lib.sgp_ctx_bound_from_stats(self._c(), self._ptr(Kuu), *stats, *tail))
         return res
 
     # ------------------------------------------------------------------ single-launch path for small problems
@@ -433,8 +498,8 @@ class HipEngine:
         nbytes = self.lib.sgp_suffstats_bwd_workspace_bytes_ex(N, M, d, 1 if kfu is not None else 0)
         ws = self._workspace("bwd_kfu" if kfu is not None else "bwd", nbytes)
         base = out.data_ptr()
-        st = self.lib.sgp_suffstats_bwd(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(Phibar),
+        st = self.lib.sgp_ctx_suffstats_bwd(
+            self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(Phibar),
             self._ptr(bbar), float(kappabar), self._ptr(kfu), N, M, d, _kernel_id(kernel), C.c_void_p(base),
             C.c_void_p(base + 8 * nh),
             C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
@@ -587,20 +652,34 @@ class HipEngine:
         lsv = [[float(v) for v in row] for row in ls]
         S = len(lsv)
         mean, var = self.empty(S, T), self.empty(S, T)
-        info = torch.empty(S, dtype=torch.int32, device=self.device)
+        info = torch.zeros(S, dtype=torch.int32, device=self.device)
+        # test rows in chunks: the library carves S x 6 x Mp x Tp doubles for its "minibatch" -- 10 GB at S = 8,
+        # M = 512, T = 50k in one piece, and T > 2^20 is refused outright; 8192 rows at a time as sgp_mixture_predict does
+        TC = self.SVGP_PREDICT_CHUNK
         for s0 in range(0, S, 8):
             n = min(8, S - s0)
-            nbytes = self.lib.sgp_svgp_batch_workspace_bytes(T, M, d, n)
-            if nbytes == 0:
-                raise ValueError("unsupported SVGP predictive shape T=%d M=%d d=%d" % (T, M, d))
-            ws = self._workspace("svgp_batch", nbytes)
             inv = (ctypes.c_double * (n * d))(*[1.0 / v for row in lsv[s0:s0 + n] for v in row])
             sf2c = (ctypes.c_double * n)(*[float(v) for v in sf2[s0:s0 + n]])
-            st = self.lib.sgp_svgp_predict_batch(self._ptr(Xs), d, T, self._ptr(Z), d, n, inv, sf2c, float(jitter), self._ptr(m), self._ptr(LS),
-                                                 M, d, _kernel_id(kernel), self._ptr(mean[s0:]), self._ptr(var[s0:]),
-                                                 C.c_void_p(info[s0:].data_ptr()), self._ptr(ws), ws.numel(), self._stream())
-            _lib.check("sgp_svgp_predict_batch", st)
+            for t0 in range(0, T, TC):
+                tn = min(TC, T - t0)
+                nbytes = self.lib.sgp_svgp_batch_workspace_bytes(tn, M, d, n)
+                if nbytes == 0:
+                    raise ValueError("unsupported SVGP predictive shape T=%d M=%d d=%d" % (T, M, d))
+                ws = self._workspace("svgp_batch", nbytes)
+                whole = tn == T
+                mc, vc = (mean[s0:s0 + n], var[s0:s0 + n]) if whole else (self.empty(n, tn), self.empty(n, tn))
+                ic = info[s0:s0 + n] if whole else torch.empty(n, dtype=torch.int32, device=self.device)
+                st = self.lib.sgp_svgp_predict_batch(self._ptr(Xs[t0:t0 + tn]), d, tn, self._ptr(Z), d, n, inv, sf2c, float(jitter),
+                                                     self._ptr(m), self._ptr(LS), M, d, _kernel_id(kernel), self._ptr(mc), self._ptr(vc),
+                                                     C.c_void_p(ic.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
+                _lib.check("sgp_svgp_predict_batch", st)
+                if not whole:
+                    mean[s0:s0 + n, t0:t0 + tn] = mc
+                    var[s0:s0 + n, t0:t0 + tn] = vc
+                    info[s0:s0 + n] = torch.where(info[s0:s0 + n] != 0, info[s0:s0 + n], ic)  # the first failure stays
         return mean, var, info
+
+    SVGP_PREDICT_CHUNK = 8192  # test rows per sgp_svgp_predict_batch call
 
     def svgp_batch_combine(self, res, weights):
         """Reverse pass of sum_s weights[s] * bound_s from a ``svgp_elbo_batch(..., with_grads=True)`` result, one launch.
@@ -645,8 +724,8 @@ class HipEngine:
             inv = (ctypes.c_double * (n * d))(*[1.0 / v for row in lsv[s0:s0 + n] for v in row])
             sf2c = (ctypes.c_double * n)(*[float(v) for v in sf2[s0:s0 + n]])
             s2c = (ctypes.c_double * n)(*[float(v) for v in s2[s0:s0 + n]])
-            st = self.lib.sgp_mixture_predict(
-                self._ptr(X), d, self._ptr(y), N, self._ptr(Xs), d, T, self._ptr(Z), d, n, inv, sf2c, s2c, float(jitter), M, d,
+            st = self.lib.sgp_ctx_mixture_predict(
+                self._c(), self._ptr(X), d, self._ptr(y), N, self._ptr(Xs), d, T, self._ptr(Z), d, n, inv, sf2c, s2c, float(jitter), M, d,
                 _kernel_id(kernel), 1 if pred_noise else 0, float(gate_jitter) if want_gate else 0.0, self._ptr(mean[s0:]), self._ptr(var[s0:]),
                 self._ptr(cov[s0:]) if full_cov else None, C.c_void_p(info[s0:].data_ptr()),
                 C.c_void_p(gate[s0:].data_ptr()) if want_gate else None, self._ptr(ws), ws.numel(), self._stream())

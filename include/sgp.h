@@ -51,7 +51,7 @@ extern "C" {
 
 typedef void* sgp_stream_t; /* hipStream_t */
 
-#define SGP_ABI_VERSION 1
+#define SGP_ABI_VERSION 2       /* 2: contexts (sgp_ctx_*); the process-wide setters are shims over the default context */
 #define SGP_MAX_DIM 32          /* largest input dimension d the streaming kernels accept */
 #define SGP_MAX_INDUCING 4096   /* largest M */
 
@@ -98,9 +98,61 @@ typedef void* sgp_stream_t; /* hipStream_t */
 #define SGP_OUT_LEN 8
 
 int sgp_abi_version(void);
+
+/* ---- contexts (ABI version 2) -------------------------------------------------------------------------------------------------
+ * A context carries every switch and every piece of library-side state a call consults: which matrix cores contract pass 1, the
+ * conditioning limit, the K'_fu budget, the CU budget, the optional timing events, the one-shot pass-1 gate, the per-device kernel
+ * attributes.  Environment knobs (SGP_CONTRACTION, SGP_ASM_OVERLAP, SGP_SYRK_*, SGP_I8_PRIO) are read ONCE, when a context is
+ * created.  Two contexts in one process are independent (two bounds with different contraction modes on two streams, two devices);
+ * one context must not be used from two host threads at the same time.  The caller still owns every buffer and passes the stream:
+ * a context owns no user-visible memory.  ctx == NULL everywhere means the DEFAULT context, which is also what every entry point
+ * without a context argument runs in and what the deprecated sgp_set_* setters below modify.
+ * The reference has no counterpart (GPyTorch / PyMC3 keep such switches in Python-side settings objects, e.g.
+ * gpytorch.settings.cholesky_jitter used at models/sgpr.py:14).                                                                  */
+typedef struct sgp_ctx sgp_ctx;
+#define SGP_OPT_CONTRACTION 0      /* 0 fp64 matrix cores, 1 (default) integer cores where they win, 2 integer cores always */
+#define SGP_OPT_ASM_OVERLAP 1      /* 0 (default) one block, 1 head + tail overlapped, 2 head + tail serial (A/B knob) */
+#define SGP_OPT_KFU_BUDGET_BYTES 2 /* bytes of K'_fu the library materialises at a time (0 restores the 16 GiB default) */
+#define SGP_OPT_COND_LIMIT 3       /* conditioning gate of the explicit-inverse path (default 1e13; 0 disables; < 0 restores) */
+#define SGP_OPT_CU_BUDGET 4        /* CUs the context's launches may occupy (CU-masked streams); 0 = the whole device */
+#define SGP_OPT_TIMING 5           /* != 0: record HIP events around the dominant kernels (sgp_ctx_timing_last_ms) */
+sgp_ctx* sgp_ctx_create(int device); /* device = the HIP device index the context will be used on (the caller selects it) */
+void sgp_ctx_destroy(sgp_ctx* ctx);
+int sgp_ctx_device(const sgp_ctx* ctx);
+int sgp_ctx_set_option(sgp_ctx* ctx, int option, double value);   /* SGP_OK or SGP_ERR_ARG */
+double sgp_ctx_get_option(const sgp_ctx* ctx, int option);        /* -1 for an unknown option */
+void sgp_ctx_set_pass1_gate(sgp_ctx* ctx, void* hip_event);       /* see sgp_set_pass1_gate */
+int sgp_ctx_contraction_last(const sgp_ctx* ctx);                 /* what the context's last pass 1 ran: 0 fp64, 1 integer cores */
+/* the rule sgp_suffstats_fwd will apply to an N-row shard with M inducing inputs in this context (1 = integer cores) */
+int sgp_ctx_contraction_would_use_i8(const sgp_ctx* ctx, int64_t N, int M);
+int sgp_ctx_timing_last_ms(sgp_ctx* ctx, int slot, float* ms);
+int64_t sgp_ctx_timing_last_rows(const sgp_ctx* ctx, int slot);
+/* The entry points whose behaviour depends on an option, with the context as first argument (same arguments, same return values
+ * as their namesakes below; everything else is context-free): */
+size_t sgp_ctx_suffstats_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_kfu);
+int sgp_ctx_suffstats_fwd(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                          const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id, double* Phi, double* b,
+                          double* yy, double* kappa, double* Kfu_out, void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_ctx_suffstats_bwd(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                          const double* inv_ls, double sf2, const double* Phibar, const double* bbar, double kappabar,
+                          const double* Kfu_in, int64_t N, int M, int d, int kernel_id, double* g_ls, double* g_sf2, double* g_Z,
+                          void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_ctx_kuu_factor(sgp_ctx* ctx, const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
+                       sgp_stream_t stream);
+int sgp_ctx_bound_from_stats(sgp_ctx* ctx, const double* Kuu, const double* Phi, const double* b, const double* yy,
+                             const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out, double* Phibar,
+                             double* bbar, double* Kuubar, double* factors, const double* kuu_linv, int* info, void* ws,
+                             size_t ws_bytes, sgp_stream_t stream);
+int sgp_ctx_mixture_predict(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, int64_t N, const double* Xs, int64_t ldxs,
+                            int64_t T, const double* Z, int64_t ldz, int S, const double* inv_ls, const double* sf2, const double* s2,
+                            double jitter, int M, int d, int kernel_id, int pred_noise, double gate_jitter, double* mean, double* var,
+                            double* cov, int* info, int* gate_info, void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* ---- deprecated process-wide switches (ABI version 1): each one sets the matching option of the DEFAULT context ---- */
 /* The single-launch dataflow factorization keeps every workgroup resident (one per CU) and sizes its grid from the device's CU
  * count.  A caller that enqueues on a CU-masked stream (hipExtStreamCreateWithCUMask) must say how many CUs the mask leaves:
- * n CUs for the calling HOST THREAD's following launches, 0 = the whole device (default).                                   */
+ * n CUs for the calling HOST THREAD's following launches, 0 = the whole device (default).  Deprecated: SGP_OPT_CU_BUDGET of a
+ * context (this per-thread value, while non-zero, overrides the context's).                                                  */
 void sgp_set_cu_budget(int n);
 const char* sgp_status_string(int status);
 
@@ -146,7 +198,12 @@ size_t sgp_kfu_len(int64_t N, int M);
  *      reads the fp64 block) kernel assembly writes the fp64 block AND the digit planes (the planes a super-chunk at a time in
  *      the workspace -- query the workspace size in the mode the call will run in);
  *   2  the integer cores for every call (tests).
- * Returns the previous mode (-1 = never set).  sgp_contraction_last(): what the last sgp_suffstats_fwd call ran (0 fp64, 1 int8).
+ * Returns the previous mode; an out-of-range mode restores the default (1).  sgp_contraction_last(): what the last
+ * sgp_suffstats_fwd call of the default context ran (0 fp64, 1 int8).
+ * Value-only and value + gradient evaluations agree to rounding, not bit for bit, across contraction modes AND inside mode 1: a
+ * value-only call and a value + gradient call at the same theta both contract on the integer cores, but their split geometry
+ * differs (the planes of a kept K'_fu live in their own super-chunk), so F differs at the 1e-14 level between `value()` and
+ * `value_and_grad()`.  NUTS takes its energy from the value + gradient call alone; a caller comparing the two must allow 1e-13.
  * Replaces nothing in the reference -- torch.matmul in gpytorch's InducingPointKernel (models/sgpr.py:37) is the fp64 GEMM. */
 int sgp_set_contraction(int mode);
 int sgp_contraction_last(void);
@@ -154,7 +211,8 @@ int sgp_contraction_last(void);
  * `hip_event` (a hipEvent_t the caller has ALREADY recorded on another stream) between kernel assembly and the contraction.  Why: that
  * kernel takes 129 KB of LDS and two 188-register waves per SIMD, so next to nothing co-schedules with it -- a side-stream chain that must be done by the end of
  * pass 1 (the factorization of K_uu, core.py) finishes beside the assembly instead of being starved.  NULL clears; a call that takes the
- * fp64 contraction ignores and clears it. */
+ * fp64 contraction ignores and clears it; so does any call that returns early (bad argument, composite kernel): the gate belongs to
+ * exactly one call and the event may be destroyed as soon as that call has returned. */
 void sgp_set_pass1_gate(void* hip_event);
 
 /* bytes of K'_fu the library materialises at a time when it owns the buffer (default 16 GiB; 0 restores
@@ -206,9 +264,24 @@ size_t sgp_bound_factors_len(int M); /* number of doubles in `factors` */
  * that is still 0), so one status word -- one host read -- covers the whole evaluation.                 */
 /* Conditioning gate: the explicit-inverse products downstream of sgp_kuu_factor turn to noise once cond(K_uu + J I) passes
  * ~1e13 (where LAPACK's substitution still evaluates the bound).  sgp_kuu_factor therefore reports a matrix whose estimate
- * trace(K_uu) / min_i L_ii^2 (lambda_max <= trace, lambda_min <= every pivot) exceeds `limit` as numerically not positive
- * definite at its smallest pivot (info = argmin + 1).  Default limit 1e13; 0 disables the gate; negative restores the default. */
+ * max_j ||L e_j||^2 / min_i L_ii^2 (lambda_max >= every column norm of L, lambda_min <= every pivot: the estimate can only UNDERSHOOT
+ * cond, so a well-posed problem is never refused; round 3's trace(K_uu) overshot by up to M) exceeds `limit` as numerically not
+ * positive definite at its smallest pivot (info = argmin + 1).  Default limit 1e13; 0 disables the gate; negative restores the
+ * default.  Deprecated shim over SGP_OPT_COND_LIMIT of the default context.                                                       */
 void sgp_set_cond_limit(double limit);
+/* Guard of the streaming evaluation order (sgp_suffstats_fwd + sgp_bound_from_stats).  Phi = K_uf K_fu is stored in fp64, i.e. with
+ * an error of ~2^-53 max_i Phi_ii per entry however it was summed, and W = L^-1 Phi L^-T amplifies it by 1 / lambda_k(K_uu): for long
+ * lengthscales x small noise the bound comes out wrong by far more than the 1e-8 per datum the reference's op order (PyMC3's
+ * MarginalSparse, models/bayesian_sgpr_hmc.py:66-71: A = L^-1 K_uf first) keeps -- measured over lengthscales 0.2 .. 20 x noise
+ * 0.01 .. 3, profiles/r04_theta_sweep_streaming.jsonl.  sgp_kuu_inverse_trace: trace_out[0] = tr(K_uu^-1) = ||L^-1||_F^2 from the
+ * output of sgp_kuu_factor (trace_out: sgp_kuu_inverse_trace_len() doubles, the rest is scratch); sgp_streaming_error_estimate:
+ * est[0] = 2^-53 max_i Phi_ii tr(K_uu^-1) / (s2 N), a first-order estimate of |dF| / N in the streaming order from the (all-reduced)
+ * statistics.  A caller compares it with its tolerance (core.py: 1e-9) and re-evaluates through sgp_suffstats_fwd_whitened when it is
+ * exceeded.  Both sums run in a fixed order: ranks that hold the same inputs get the same bits and take the same decision.       */
+size_t sgp_kuu_inverse_trace_len(void);
+int sgp_kuu_inverse_trace(const double* kuu_linv, int M, double* trace_out, sgp_stream_t stream);
+int sgp_streaming_error_estimate(const double* stats, const double* trace_inv, double s2, int64_t N, int M, double* est,
+                                 sgp_stream_t stream);
 size_t sgp_kuu_factor_len(int M);
 size_t sgp_kuu_factor_workspace_bytes(int M);
 int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info,

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.sgp_abi_version() == 1
+    assert lib.sgp_abi_version() == 2
     assert lib.sgp_status_string(0) == b"ok"
     assert b"workspace" in lib.sgp_status_string(-3)
     assert b"positive definite" in lib.sgp_status_string(7)
@@ -70,6 +70,49 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert lib.sgp_bound_from_stats(null, one, one, one, one, 0.1, 10, 4, 0, one, null, null, null, null, null, one, one, 1 << 30, null) == -1
     assert lib.sgp_kuu_factor(one, 4, one, one, null, 0, null) == -3 and lib.sgp_kuu_factor_len(100) == 128 * 128
     assert lib.sgp_chol_lower(one, 4, 4, one, null, 0, null) == -3
+
+
+def test_contexts_carry_their_own_options_and_the_setters_are_shims_over_the_default_one(lib):
+    """ABI version 2 (include/sgp.h: sgp_ctx_*): no kernel is launched -- options, the contraction rule, the workspace query."""
+    import ggp_amd._lib as L
+    null = C.c_void_p(0)
+    a, b = C.c_void_p(lib.sgp_ctx_create(0)), C.c_void_p(lib.sgp_ctx_create(0))
+    assert a.value and b.value and a.value != b.value and not lib.sgp_ctx_create(-1)
+    try:
+        assert lib.sgp_ctx_get_option(a, L.OPT_CONTRACTION) == 1.0 and lib.sgp_ctx_get_option(a, L.OPT_COND_LIMIT) == 1e13
+        assert lib.sgp_ctx_set_option(a, L.OPT_CONTRACTION, 0.0) == 0
+        assert lib.sgp_ctx_set_option(a, L.OPT_CONTRACTION, 3.0) == -1 and lib.sgp_ctx_set_option(a, 99, 1.0) == -1
+        assert lib.sgp_ctx_get_option(a, L.OPT_CONTRACTION) == 0.0 and lib.sgp_ctx_get_option(b, L.OPT_CONTRACTION) == 1.0
+        assert lib.sgp_ctx_get_option(null, L.OPT_CONTRACTION) == 1.0                       # the default context is untouched
+        # the rule follows the context: rows x Mp^2 >= 2^32 in mode 1, never in mode 0
+        assert lib.sgp_ctx_contraction_would_use_i8(b, 1_000_000, 1024) == 1 and lib.sgp_ctx_contraction_would_use_i8(a, 1_000_000, 1024) == 0
+        assert lib.sgp_ctx_contraction_would_use_i8(b, 30_000, 100) == 0
+        # ... and so does the workspace of a value + gradient call (digit planes beside a caller-owned K'_fu only when they are needed)
+        wa = lib.sgp_ctx_suffstats_workspace_bytes(a, 1_000_000, 1024, 8, 1)
+        wb = lib.sgp_ctx_suffstats_workspace_bytes(b, 1_000_000, 1024, 8, 1)
+        assert 0 < wa < wb and wb - wa >= 7 * 1024 * 1_000_000
+        assert lib.sgp_ctx_suffstats_workspace_bytes(null, 1_000_000, 1024, 8, 1) == lib.sgp_suffstats_workspace_bytes_ex(1_000_000, 1024, 8, 1) == wb
+        # the deprecated setters write the DEFAULT context, and only it
+        prev = lib.sgp_set_contraction(2)
+        assert prev == 1 and lib.sgp_ctx_get_option(null, L.OPT_CONTRACTION) == 2.0 and lib.sgp_ctx_get_option(b, L.OPT_CONTRACTION) == 1.0
+        lib.sgp_set_contraction(prev)
+        lib.sgp_set_cond_limit(5.0)
+        assert lib.sgp_ctx_get_option(null, L.OPT_COND_LIMIT) == 5.0 and lib.sgp_ctx_get_option(a, L.OPT_COND_LIMIT) == 1e13
+        lib.sgp_set_cond_limit(-1.0)
+        assert lib.sgp_ctx_get_option(null, L.OPT_COND_LIMIT) == 1e13
+        lib.sgp_set_kfu_budget_bytes(1 << 20)
+        assert lib.sgp_ctx_get_option(null, L.OPT_KFU_BUDGET_BYTES) == float(1 << 20) and lib.sgp_ctx_get_option(a, L.OPT_KFU_BUDGET_BYTES) == float(16 << 30)
+        lib.sgp_set_kfu_budget_bytes(0)
+        # argument checks run in a context too
+        one = C.c_void_p(8)
+        inv = (C.c_double * 2)(1.0, 1.0)
+        assert lib.sgp_ctx_suffstats_fwd(a, one, 2, one, one, 2, inv, 1.0, 10, 4, 2, 0, one, one, one, one, null, null, 0, null) == -3
+        assert lib.sgp_ctx_kuu_factor(a, one, 4, one, one, null, 0, null) == -3
+        assert lib.sgp_ctx_contraction_last(a) == 0 and lib.sgp_ctx_timing_last_rows(a, 1) == 0 and lib.sgp_ctx_timing_last_rows(a, 0) == -1
+    finally:
+        lib.sgp_ctx_destroy(a)
+        lib.sgp_ctx_destroy(b)
+        lib.sgp_ctx_destroy(null)   # no-op
 
 
 def test_product_has_no_cpu_fallback():

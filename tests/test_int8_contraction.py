@@ -272,3 +272,43 @@ def test_int8_full_size_against_fp64_contraction(engine):
         assert abs(F1 - F0) < 1e-9 * abs(F0), (F1, F0)
     finally:
         engine.lib.sgp_set_contraction(prev)
+
+
+def test_two_contexts_in_one_process_keep_their_own_contraction_mode(engine):
+    """ABI version 2: two engines with a library context each (include/sgp.h: sgp_ctx_create) -- one pinned to the fp64 matrix
+    cores, one to the integer cores -- run the same pass 1 on two streams of one process; each context reports what IT ran, the
+    default context (the session engine, the deprecated setters) is untouched, and the statistics agree to rounding."""
+    import ggp_amd
+    g = torch.Generator().manual_seed(12)
+    N, M, d = 70_000, 256, 4          # rows x Mp^2 = 2^32.1: the default rule takes the integer cores here
+    X = torch.randn(N, d, dtype=torch.float64, generator=g).to(engine.device)
+    y = torch.randn(N, dtype=torch.float64, generator=g).to(engine.device)
+    Z = X[:M].clone()
+    ea, eb = ggp_amd.HipEngine(own_context=True), ggp_amd.HipEngine(own_context=True)
+    assert ea._ctx and eb._ctx and ea._ctx != eb._ctx
+    assert ea.set_option("contraction", 0) == 1.0     # previous value: the default rule
+    eb.set_option("contraction", 2)
+    assert ea.would_use_i8(N, M) is False and eb.would_use_i8(N, M) is True and engine.would_use_i8(N, M) is True
+    sa, sb = torch.cuda.Stream(device=engine.device), torch.cuda.Stream(device=engine.device)
+    ready = torch.cuda.current_stream(engine.device).record_event()
+    with torch.cuda.stream(sa):
+        sa.wait_event(ready)
+        pa = ea.suffstats(X, y, Z, [1.3] * d, 1.0, "rbf")
+    with torch.cuda.stream(sb):
+        sb.wait_event(ready)
+        pb = eb.suffstats(X, y, Z, [1.3] * d, 1.0, "rbf")
+    before = engine.contraction_last()
+    torch.cuda.synchronize()
+    assert ea.contraction_last() == 0 and eb.contraction_last() == 1
+    assert engine.contraction_last() == before == engine.lib.sgp_contraction_last()   # the default context did not run anything
+    assert float((pa - pb).abs().max()) < 1e-13 * float(pa.abs().max())
+    assert torch.equal(pa[M * M:], pb[M * M:])
+    # a small shard in the rule-following default context still takes fp64, and says so in ITS context only
+    engine.suffstats(X[:3000].contiguous(), y[:3000].contiguous(), Z, [1.3] * d, 1.0, "rbf")
+    assert engine.contraction_last() == 0 and eb.contraction_last() == 1
+    # options of one context never leak: the conditioning gate of `ea` switched off, `eb` keeps refusing the same matrix
+    z = torch.linspace(0.0, 52.0, 300, dtype=torch.float64)[:, None].to(engine.device)
+    bad = engine.kuu(z, [3.0], 2.0e6, 1e-6, "rbf")
+    ea.set_option("cond_limit", 0.0)
+    assert int(ea.kuu_factor(bad)[1].cpu()[0]) == 0 and int(eb.kuu_factor(bad)[1].cpu()[0]) > 0
+    del ea, eb

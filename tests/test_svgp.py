@@ -320,6 +320,14 @@ def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d,
     for k in range(S_hyper):
         mu1, v1, _ = engine.svgp_predict(D(X[:Tn]), D(Z), ls[k].tolist(), float(sf2[k]), D(m), D(LS), jitter=1e-6, kernel=kern)
         assert float((mu_b[k] - mu1).abs().max()) < 1e-10 and float(((v_b[k] - v1) / v1).abs().max()) < 1e-10
+    # the test rows travel in chunks (8192 by default; 32 here: three chunks, the last one short): the same numbers
+    try:
+        engine.SVGP_PREDICT_CHUNK = 32
+        mu_c, v_c, info_c = engine.svgp_predict_batch(D(X[:Tn]), D(Z), ls.tolist(), sf2.tolist(), D(m), D(LS), jitter=1e-6, kernel=kern)
+    finally:
+        del engine.SVGP_PREDICT_CHUNK
+    assert info_c.cpu().tolist() == [0] * S_hyper
+    assert float((mu_c - mu_b).abs().max()) < 1e-12 and float(((v_c - v_b) / v_b).abs().max()) < 1e-12
     # the two-halves form (forward, [the caller's copy of the bounds], reverse) gives the same numbers bit for bit
     sp = engine.svgp_elbo_batch(D(X), D(y), D(Z), ls.tolist(), sf2.tolist(), s2.tolist(), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
                                 likelihood=lik, with_grads=True, defer_reverse=True)
