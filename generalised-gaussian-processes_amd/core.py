@@ -302,10 +302,12 @@ class CollapsedBound:
                         K = e.kuu(Z, ls, sf2, jitter, kernel, out=gr["Kuu"])
                         gr["graph"].replay()
                         result[2].copy_(gr["info"])  # the evaluation's status word starts as the Kuu status
-                        return K, gr["Linv"], gr.get("trace")
-                    K = e.kuu(Z, ls, sf2, jitter, kernel)
-                    li = e.kuu_factor(K, info=result[2])[0]
-                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0]) if guard else None)
+                        li = gr["Linv"]
+                    else:
+                        K = e.kuu(Z, ls, sf2, jitter, kernel)
+                        li = e.kuu_factor(K, info=result[2])[0]
+                    ready = side.record_event()  # what pass 1's tail waits for; the guard's tr(Kuu^-1) runs behind it, off the critical path
+                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0]) if guard else None), ready
 
             result[0].record_stream(side)
             # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
@@ -318,19 +320,21 @@ class CollapsedBound:
             if (gr is not None and hasattr(e, "would_use_i8") and self.kernel != "composite"
                     and int(self.X.shape[0]) >= 300 * int(Z.shape[0]) and e.would_use_i8(int(self.X.shape[0]), int(Z.shape[0]))):
                 chain = side_chain()
-                gate = side.record_event()
+                gate = chain[3]
                 pending = None
             else:
                 pending = self._pool.submit(side_chain)
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
         self._allreduce_stats(packed, int(Z.shape[0]))
         if overlap:
-            Kuu, linv, trace = pending.result() if pending is not None else chain
+            Kuu, linv, trace, ready = pending.result() if pending is not None else chain
             for t in (Kuu, linv) + ((trace,) if trace is not None else ()):
                 t.record_stream(main)
-            main.wait_stream(self._side)
+            main.wait_event(ready)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
+            if trace is not None:
+                main.wait_stream(self._side)  # (long done: one single-workgroup kernel behind `ready`)
         elif guard and hasattr(e, "kuu_factor"):
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])

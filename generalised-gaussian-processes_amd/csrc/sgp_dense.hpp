@@ -30,6 +30,16 @@ void gemm(const GemmDesc& g, hipStream_t st);
 // part[s][2 b], part[s][2 b + 1], b < ceil(M/64): per 64-column block of the S factors L (ld x ld each, `stride` doubles apart) the
 // largest squared column norm and the sum of squared column sums; cond_lambda_max() turns them into a LOWER bound of lambda_max(L L^T)
 void cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st);
+// part[s][2 b] = largest squared row norm of L^-1 in row block b, part[s][2 b + 1] = that row: 1 / lambda_min >= the largest of them
+void cond_rownorms(const double* Linv, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st);
+__device__ __forceinline__ double cond_inv_lambda_min(const double* __restrict__ part, int npart, int* at) {
+  double best = -1.0;
+  int a = 0;
+  for (int i = 0; i < npart; ++i)
+    if (part[2 * i] > best) { best = part[2 * i]; a = (int)part[2 * i + 1]; }
+  if (at) *at = a;
+  return best;
+}
 __device__ __forceinline__ double cond_lambda_max(const double* __restrict__ part, int npart, int M) {
   double hi = 0.0, rq = 0.0;
   for (int i = 0; i < npart; ++i) {  // fixed order

@@ -313,6 +313,10 @@ __global__ __launch_bounds__(256, ((DP <= 8 || kbar_two_pass<DP, KID, KP>()) ? 2
             for (int r = 0; r < 4; ++r) Ct[u * 16 + l4 + 4 * r][wj * 64 + v * 16 + l15] = acc[u][v][r];
       }
       __syncthreads();
+#if defined(SGP_AB_KBAR_NO_EPI_MATH)  // A/B (tools/ab_build.sh): the epilogue's LDS traffic and barriers without its arithmetic
+      for (int i = 0; i < 32; ++i) gs += Ct[half * 32 + i][erow];
+      if (false)
+#endif
       SGP_KBAR_EPI_UNROLL
       for (int i = 0; i < 32; ++i) {
         const int nl = half * 32 + i;                       // wave-uniform row inside this half

@@ -597,13 +597,16 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
 // apart where LAPACK gives 1706.7726 / 1706.7731 -- a spurious spike that traps a Markov chain).  The factor itself gives a
 // condition estimate that can only UNDERSHOOT (round 4; round 3 used trace(K) for lambda_max, which overshoots by up to M and
 // refused well-posed problems with a large amplitude, e.g. M sf2 >= 1e7 with one near-duplicate inducing pair):
-//     lambda_max(K) = ||L||_2^2 >= max_j ||L e_j||^2   (a column of L),      lambda_min(K) <= every pivot L_ii^2,
+//     lambda_max(K) = ||L||_2^2 >= max_j ||L e_j||^2   (a column of L)
 //     lambda_max(K) >= 1^T K 1 / M = ||L^T 1||^2 / M   (the Rayleigh quotient of the constant vector: the mean row sum of K, within
-//                                                       a small factor of lambda_max for a positive kernel matrix),
-// so  est = max(both) / min_i L_ii^2 <= cond(K)  always.  For one tight cluster the first column of L carries the dominant
-// eigenvector (||L e_0||^2 ~ trace K); for a long 1-D chain (the CO2 inputs: 300 points 0.17 apart, lengthscale 3) no single column
-// does and the mean row sum (~43 sf2 there) is what finds lambda_max; for a well-spread set the estimate is ~ sf2 / min pivot.  Above g_cond_limit the matrix is reported as numerically not positive definite at its smallest pivot
-// (info = argmin + 1), so samplers see a zero-density region (a divergence, as PyMC3 treats a failed factorization) instead
+//                                                       a small factor of lambda_max for a positive kernel matrix)
+//     1 / lambda_min(K) = ||L^-1||_2^2 >= max_i ||e_i^T L^-1||^2   (a row of the explicit inverse the chain forms anyway; the
+//                                                       smallest PIVOT alone overestimates lambda_min by 24 x on the CO2 chain below)
+// so  est = max(first two) x (third) <= cond(K)  always.  Measured against the eigenvalues (numpy): 7.1e13 for cond 8.6e13 on a
+// long 1-D chain (300 points 0.17 apart, lengthscale 3, amplitude 2e6: refused), 7.2e10 for 9.0e10 on 1000 well-spread 2-D points
+// with one near-duplicate pair and amplitude 2e4 (accepted; round 3's estimate said 2e13), 5.2e6 for 1.4e7 on a benign chain.
+// Above the limit the matrix is reported as numerically not positive definite at the row of L^-1 that carries the estimate
+// (info = row + 1), so samplers see a zero-density region (a divergence, as PyMC3 treats a failed factorization) instead
 // of a finite, meaningless density.  The single-launch path (M <= 128, substitution solves) is not gated: it tracks LAPACK
 // (DESIGN section 4a).
 double sgp::cond_gate_limit() { return cur_ctx().cond_limit; }
@@ -641,35 +644,44 @@ __global__ __launch_bounds__(256) void cond_colnorm_kernel(const double* __restr
 void sgp::cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st) {
   cond_colnorm_kernel<<<dim3((M + 63) / 64, S), 256, 0, st>>>(L, ld, stride, M, part);
 }
-__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ L, int64_t ld, int M, const double* __restrict__ part,
-                                                        int npart, double limit, int* info) {
-  __shared__ double smin[4], smax[4];
-  __shared__ int imin[4];
-  double lo = 1e300, hi = 0.0;
+// rows of L^-1 (S matrices of ld x ld, lower triangle), 64 rows per block, 16 per wave:
+//   part[s][2 b] = max_i ||e_i^T L^-1||^2,      part[s][2 b + 1] = its row index        (ties: the smaller index)
+__global__ __launch_bounds__(256) void cond_rownorm_kernel(const double* __restrict__ Li, int64_t ld, int64_t stride, int M,
+                                                           double* __restrict__ part) {
+  __shared__ double sv[4];
+  __shared__ int si[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* Ls = Li + (int64_t)blockIdx.y * stride;
+  double best = -1.0;
   int at = 0;
-  for (int i = threadIdx.x; i < M; i += 256) {
-    const double v = L[(int64_t)i * ld + i];
-    if (v < lo) { lo = v; at = i; }
+  for (int r = 0; r < 16; ++r) {
+    const int i = blockIdx.x * 64 + w * 16 + r;
+    if (i >= M) break;
+    double s = 0.0;
+    for (int j = lane; j <= i; j += 64) { const double v = Ls[(int64_t)i * ld + j]; s = fma(v, v, s); }
+    s = wave_sum(s);
+    if (s > best) { best = s; at = i; }
   }
-  if (threadIdx.x == 0) hi = cond_lambda_max(part, npart, M);
-  // wave level: butterfly on (value, index) pairs -- ties go to the smaller index, so every lane ends with the same pair
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = __shfl_xor(lo, o, 64);
-    const int oi = __shfl_xor(at, o, 64);
-    if (ov < lo || (ov == lo && oi < at)) { lo = ov; at = oi; }
-    hi = fmax(hi, __shfl_xor(hi, o, 64));
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { smin[w] = lo; smax[w] = hi; imin[w] = at; }
+  if (lane == 0) { sv[w] = best; si[w] = at; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int t = 1; t < 4; ++t) {
-      if (smin[t] < lo || (smin[t] == lo && imin[t] < at)) { lo = smin[t]; at = imin[t]; }
-      hi = fmax(hi, smax[t]);
-    }
-    if (*info == 0 && !(hi <= limit * lo * lo)) *info = at + 1;  // (a NaN pivot the factorization let through never becomes `lo`:
-  }                                                              //  potrf itself reports those)
+    for (int t = 1; t < 4; ++t)
+      if (sv[t] > best) { best = sv[t]; at = si[t]; }
+    double* dst = part + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    dst[0] = best;
+    dst[1] = (double)at;
+  }
+}
+void sgp::cond_rownorms(const double* Linv, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st) {
+  cond_rownorm_kernel<<<dim3((M + 63) / 64, S), 256, 0, st>>>(Linv, ld, stride, M, part);
+}
+// est = lambda_max estimate (from L: partL) x 1 / lambda_min estimate (from L^-1: partR) > limit  ->  info = that row + 1
+__global__ void cond_gate_kernel(const double* __restrict__ partL, const double* __restrict__ partR, int npart, int M, double limit,
+                                 int* info) {
+  const double inv_min = cond_inv_lambda_min(partR, npart, nullptr);
+  int at = 0;
+  (void)cond_inv_lambda_min(partR, npart, &at);
+  if (*info == 0 && !(cond_lambda_max(partL, npart, M) * inv_min <= limit)) *info = at + 1;  // (NaN trips as well)
 }
 
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
@@ -688,11 +700,13 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   zero_ints(info, 1, st);
   pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
-  if (cond_gate_limit() > 0.0) {  // `tmp` is free until tri_inverse: the column-norm partials live at its start
-    cond_colnorms(L, Mp, 0, M, 1, tmp, st);
-    cond_gate_kernel<<<1, 256, 0, st>>>(L, Mp, M, tmp, (M + 63) / 64, cond_gate_limit(), info);
-  }
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
+  if (cond_gate_limit() > 0.0) {  // `tmp` is free again: the partials of L's columns and of L^-1's rows live at its start
+    const int nb = (M + 63) / 64;
+    cond_colnorms(L, Mp, 0, M, 1, tmp, st);
+    cond_rownorms(Linv_out, Mp, 0, M, 1, tmp + 2 * nb, st);
+    cond_gate_kernel<<<1, 1, 0, st>>>(tmp, tmp + 2 * nb, nb, M, cond_gate_limit(), info);
+  }
   return check_launch();
 }
 // ---- guard of the streaming evaluation order -----------------------------------------------------------------------------------
@@ -704,35 +718,30 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
 // overshoots for exactly duplicated inducing rows, whose eigen-directions carry no error).  The caller (core.py) re-evaluates in the
 // whitened (PyMC3) order when estimate / N exceeds its tolerance.  Both kernels sum in a FIXED order: every rank of a sharded
 // evaluation holds the same L^-1 and the same all-reduced Phi, so every rank gets the same bits and takes the same decision.
-__global__ __launch_bounds__(256) void linv_rowsq_kernel(const double* __restrict__ Li, int64_t ld, int M, double* __restrict__ part) {
-  __shared__ double red[4];
-  // block b: rows 64 b .. 64 b + 63 (< M), columns j <= i
-  const int i0 = blockIdx.x * 64;
+// one workgroup, fixed thread <-> element mapping and a fixed tree: the same bits on every rank (and off the critical path: the caller
+// enqueues it on the side stream behind the factorization)
+__global__ __launch_bounds__(1024) void linv_trace_kernel(const double* __restrict__ Li, int64_t ld, int M, double* __restrict__ out) {
+  __shared__ double red[16];
   double s = 0.0;
-  for (int r = threadIdx.x >> 6; r < 64; r += 4) {
-    const int i = i0 + r;
-    if (i >= M) break;
+  for (int i = threadIdx.x >> 6; i < M; i += 16)
     for (int j = threadIdx.x & 63; j <= i; j += 64) {
       const double v = Li[(int64_t)i * ld + j];
       s = fma(v, v, s);
     }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t;
   }
-  s = block_sum256(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ void linv_trace_final_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
-  double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += part[b];
-  out[0] = s;
-}
-extern "C" size_t sgp_kuu_inverse_trace_len(void) { return 1 + SGP_MAX_INDUCING / 64; }
+extern "C" size_t sgp_kuu_inverse_trace_len(void) { return 2; }
 extern "C" int sgp_kuu_inverse_trace(const double* kuu_linv, int M, double* trace_out, sgp_stream_t stream) {
   if (!kuu_linv || !trace_out || M <= 0) return SGP_ERR_ARG;
   if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
-  hipStream_t st = (hipStream_t)stream;
-  const int nb = (M + 63) / 64;
-  linv_rowsq_kernel<<<nb, 256, 0, st>>>(kuu_linv, padded_m(M), M, trace_out + 1);
-  linv_trace_final_kernel<<<1, 1, 0, st>>>(trace_out + 1, nb, trace_out);
+  linv_trace_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kuu_linv, padded_m(M), M, trace_out);
   return check_launch();
 }
 __global__ __launch_bounds__(256) void streaming_estimate_kernel(const double* __restrict__ Phi, int M, const double* __restrict__ tr,

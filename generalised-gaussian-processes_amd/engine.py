@@ -262,12 +262,9 @@ class HipEngine:
             info = torch.zeros(1, dtype=torch.int32, device=self.device)
             ws = torch.empty(self.lib.sgp_kuu_factor_workspace_bytes(M), dtype=torch.uint8, device=self.device)
 
-            trace = self.empty(self.lib.sgp_kuu_inverse_trace_len())
-
             def run():
                 st = self.lib.sgp_ctx_kuu_factor(self._c(), self._ptr(Kst), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
                 _lib.check("sgp_kuu_factor", st)
-                self.kuu_inverse_trace(Linv, M, out=trace)  # the guard's ingredient rides in the same graph
 
             warm = torch.cuda.Stream(device=self.device)
             warm.wait_stream(torch.cuda.current_stream(self.device))
@@ -280,7 +277,7 @@ class HipEngine:
             # another bound) must neither fail nor invalidate this capture
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 run()
-            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws, "trace": trace}
+            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws}
         except RuntimeError as exc:  # stream capture unavailable / refused: plain launches still work
             import warnings
             warnings.warn("hipGraph capture of the Kuu chain failed (%s); falling back to plain launches" % (exc,))
