@@ -167,6 +167,7 @@ def launch_ranks(n, argv):
 
 
 def main():
+    global LS, SN  # (--ls / --sig-n: cpu_baseline() reads the module-level theta too)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -179,9 +180,13 @@ def main():
                          "at C5; the default since round 4)")
     ap.add_argument("--cpu-fit", dest="cpu_full", action="store_false",
                     help="fit the CPU baseline from two samples (--cpu-sample rows and half of it) instead of timing all N rows")
+    ap.add_argument("--ls", type=float, default=LS, help="lengthscale of the timed theta (default: SURVEY section 8d's 2.0; tests use a long "
+                                                         "one to drive the streaming-order guard on several ranks)")
+    ap.add_argument("--sig-n", type=float, default=SN, help="noise standard deviation of the timed theta (default 0.3)")
     ap.add_argument("--side-chain", choices=["graph", "launches", "off"], default="graph",
                     help="how chol(Kuu) is enqueued on the side stream (A/B knob; default = the product default)")
     args = ap.parse_args()
+    LS, SN = float(args.ls), float(args.sig_n)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything in this process
@@ -437,6 +442,11 @@ def main():
     else:
         res["roofline"] = dict(res["roofline_fp64_contraction"])
         res["config"]["contraction"] = "fp64 matrix cores"
+    res["config"]["streaming_guard"] = {
+        "tolerance_per_datum": cb.streaming_tol, "estimate_per_datum": cb.last_estimate, "repeats_in_whitened_order": cb.n_guard_reruns,
+        "note": "first-order estimate of |dF| / N of the streaming order (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N), include/sgp.h: "
+                "sgp_streaming_error_estimate), read back with every evaluation; above the tolerance the evaluation is repeated in the "
+                "whitened (PyMC3) order -- 0 repeats = every timed step ran the streaming design"}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

@@ -148,6 +148,7 @@ class CollapsedBound:
         # replicated tail and the all-reduced statistics, bit for bit the same on every rank: all ranks repeat together.
         self.streaming_tol = 1e-9
         self.n_guard_reruns = 0
+        self.last_estimate = None
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -238,6 +239,11 @@ class CollapsedBound:
             return hasattr(self.engine, "suffstats_whitened") and self._rows_for_form * int(M) <= self.WHITENED_MAX_WORK
         return self.form == "whitened"
 
+    def _trace_buf(self):
+        if getattr(self, "_trace", None) is None:  # tr(Kuu^-1) + its scratch: one buffer per bound, reused by every evaluation
+            self._trace = self.engine.empty(self.engine.lib.sgp_kuu_inverse_trace_len())
+        return self._trace
+
     def _guard_on(self):
         return self.form == "auto" and self.streaming_tol > 0.0 and hasattr(self.engine, "streaming_error_estimate")
 
@@ -247,6 +253,7 @@ class CollapsedBound:
             return False
         est = self.engine.read_estimate(host)
         res["estimate"] = est
+        self.last_estimate = est
         return not (est <= self.streaming_tol)  # NaN trips too
 
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=False):
@@ -307,7 +314,7 @@ class CollapsedBound:
                         K = e.kuu(Z, ls, sf2, jitter, kernel)
                         li = e.kuu_factor(K, info=result[2])[0]
                     ready = side.record_event()  # what pass 1's tail waits for; the guard's tr(Kuu^-1) runs behind it, off the critical path
-                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0]) if guard else None), ready
+                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0], out=self._trace_buf()) if guard else None), ready
 
             result[0].record_stream(side)
             # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
@@ -328,7 +335,7 @@ class CollapsedBound:
         self._allreduce_stats(packed, int(Z.shape[0]))
         if overlap:
             Kuu, linv, trace, ready = pending.result() if pending is not None else chain
-            for t in (Kuu, linv) + ((trace,) if trace is not None else ()):
+            for t in (Kuu, linv):
                 t.record_stream(main)
             main.wait_event(ready)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
@@ -338,7 +345,7 @@ class CollapsedBound:
         elif guard and hasattr(e, "kuu_factor"):
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
-            trace = e.kuu_inverse_trace(linv, Z.shape[0])
+            trace = e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf())
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
         else:

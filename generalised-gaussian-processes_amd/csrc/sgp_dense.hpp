@@ -27,26 +27,49 @@ struct GemmDesc {
   bool lower_only = false;
 };
 void gemm(const GemmDesc& g, hipStream_t st);
-// part[s][2 b], part[s][2 b + 1], b < ceil(M/64): per 64-column block of the S factors L (ld x ld each, `stride` doubles apart) the
-// largest squared column norm and the sum of squared column sums; cond_lambda_max() turns them into a LOWER bound of lambda_max(L L^T)
-void cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st);
-// part[s][2 b] = largest squared row norm of L^-1 in row block b, part[s][2 b + 1] = that row: 1 / lambda_min >= the largest of them
-void cond_rownorms(const double* Linv, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st);
-__device__ __forceinline__ double cond_inv_lambda_min(const double* __restrict__ part, int npart, int* at) {
-  double best = -1.0;
+// Condition estimate of a factored matrix (sgp_tail.hip): cond_stats fills `scratch` (cond_scratch_doubles(M) doubles per matrix) from
+// the factor L and its explicit inverse, cond_gate reports est = lambda_max_estimate / lambda_min_estimate > limit into info[s].
+size_t cond_scratch_doubles(int M);
+void cond_stats(const double* L, const double* Linv, int64_t ld, int64_t stride, int M, int S, double* scratch, hipStream_t st);
+void cond_gate(const double* scratch, int M, int S, double limit, int* info, hipStream_t st);
+// one workgroup of 256 threads over one matrix's scratch:  lam <= lambda_max(L L^T)  from max_j ||L e_j||^2 and ||L^T 1||^2 / M,
+// inv_min <= 1 / lambda_min  from max_i ||e_i^T L^-1||^2 (`at` = that row).  Fixed order throughout; the results are valid in thread 0.
+__device__ __forceinline__ void cond_estimate_block(const double* __restrict__ sc, int M, double* red /* 12 */, int* redi /* 4 */,
+                                                    double& lam, double& inv_min, int& at) {
+  const int nb = (M + 63) / 64, Mc = nb * 64;
+  double hi = 0.0, rq = 0.0, best = -1.0;
   int a = 0;
-  for (int i = 0; i < npart; ++i)
-    if (part[2 * i] > best) { best = part[2 * i]; a = (int)part[2 * i + 1]; }
-  if (at) *at = a;
-  return best;
-}
-__device__ __forceinline__ double cond_lambda_max(const double* __restrict__ part, int npart, int M) {
-  double hi = 0.0, rq = 0.0;
-  for (int i = 0; i < npart; ++i) {  // fixed order
-    hi = fmax(hi, part[2 * i]);      // ||L e_j||^2 <= lambda_max
-    rq += part[2 * i + 1];           // ||L^T 1||^2 = 1^T K 1
+  for (int j = threadIdx.x; j < M; j += 256) {
+    double n2 = 0.0, c1 = 0.0;
+    for (int br = j / 64; br < nb; ++br) {
+      n2 += sc[(int64_t)br * Mc + j];
+      c1 += sc[(int64_t)(nb + br) * Mc + j];
+    }
+    hi = fmax(hi, n2);
+    rq = fma(c1, c1, rq);
   }
-  return fmax(hi, rq / (double)M);
+  const double* rowN = sc + (int64_t)2 * nb * Mc;
+  for (int i = threadIdx.x; i < M; i += 256)
+    if (rowN[i] > best) { best = rowN[i]; a = i; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi = fmax(hi, __shfl_xor(hi, o, 64));
+    rq += __shfl_xor(rq, o, 64);
+    const double ob = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(a, o, 64);
+    if (ob > best || (ob == best && oa < a)) { best = ob; a = oa; }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = hi; red[4 + w] = rq; red[8 + w] = best; redi[w] = a; }
+  __syncthreads();
+  hi = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  rq = (red[4] + red[5]) + (red[6] + red[7]);
+  best = red[8]; a = redi[0];
+  for (int t = 1; t < 4; ++t)
+    if (red[8 + t] > best || (red[8 + t] == best && redi[t] < a)) { best = red[8 + t]; a = redi[t]; }
+  lam = fmax(hi, rq / (double)M);
+  inv_min = best;
+  at = a;
 }
 double cond_gate_limit();   // sgp_set_cond_limit's current value (sgp_tail.hip): the explicit-inverse paths refuse above it
 int available_cus();       // CUs a launch of this host thread can occupy (device count, or the budget below)

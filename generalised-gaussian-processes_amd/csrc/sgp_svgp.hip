@@ -804,20 +804,12 @@ __global__ __launch_bounds__(256) void mix_bmat_kernel(const double* __restrict_
     Bm[off + e] = (r == c ? 1.0 : 0.0) + W[off + e] * is2;
   }
 }
-// after chol(Kuu) and its inverse: conditioning gate (sgp_tail.hip: cond_gate_kernel; lambda_max from L, 1 / lambda_min from L^-1);
+// (after chol(Kuu) and its inverse: the conditioning gate of sgp_tail.hip, cond_stats + cond_gate)
 // after chol(B): a failure there is reported as M + pivot (only into a status word that is still 0)
-__global__ void mix_status_kernel(int M, const double* __restrict__ partL, const double* __restrict__ partR, int npart, double limit,
-                                  int* __restrict__ info, const int* __restrict__ infoB, int S) {
+__global__ void mix_status_kernel(int M, int* __restrict__ info, const int* __restrict__ infoB, int S) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
-  if (infoB) {
-    if (info[s] == 0 && infoB[s] != 0) info[s] = infoB[s] < 0 ? infoB[s] : M + infoB[s];
-    return;
-  }
-  if (info[s] != 0 || !(limit > 0.0)) return;
-  int at = 0;
-  const double inv_min = cond_inv_lambda_min(partR + (int64_t)s * 2 * npart, npart, &at);
-  if (!(cond_lambda_max(partL + (int64_t)s * 2 * npart, npart, M) * inv_min <= limit)) info[s] = at + 1;
+  if (info[s] == 0 && infoB[s] != 0) info[s] = infoB[s] < 0 ? infoB[s] : M + infoB[s];
 }
 // q[s] = LBinv[s] u[s]   (lower triangular, one wave per row)
 __global__ __launch_bounds__(256) void mix_trmv_kernel(const double* __restrict__ Li, int Mp, const double* __restrict__ u, double* __restrict__ q) {
@@ -1241,11 +1233,9 @@ extern "C" int sgp_mixture_predict(const double* X, int64_t ldx, const double* y
   }
   potrf_lower_batch(w.Kp, w.Linv, Mp, Mp, S, mm, info, w.flags, st);
   tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st, S, mm);
-  if (cond_gate_limit() > 0.0) {  // w.tmp is free again: partials of L's columns, then of L^-1's rows
-    const int nb = (M + 63) / 64;
-    cond_colnorms(w.Kp, Mp, (int64_t)mm, M, S, w.tmp, st);
-    cond_rownorms(w.Linv, Mp, (int64_t)mm, M, S, w.tmp + (int64_t)S * 2 * nb, st);
-    mix_status_kernel<<<1, 64, 0, st>>>(M, w.tmp, w.tmp + (int64_t)S * 2 * nb, nb, cond_gate_limit(), info, nullptr, S);
+  if (cond_gate_limit() > 0.0) {  // w.tmp is free again (S Mp^2 doubles >= S cond_scratch_doubles(M))
+    cond_stats(w.Kp, w.Linv, Mp, (int64_t)mm, M, S, w.tmp, st);
+    cond_gate(w.tmp, M, S, cond_gate_limit(), info, st);
   }
   const int64_t Nc = mix_chunk(N);
   for (int64_t t0 = 0; t0 < N; t0 += Nc) {
@@ -1266,7 +1256,7 @@ extern "C" int sgp_mixture_predict(const double* X, int64_t ldx, const double* y
   mix_bmat_kernel<<<dim3(gmm, S), 256, 0, st>>>(w.W, th, Mp, w.Bm);
   zero_ints(w.infoB, S, st);
   potrf_lower_batch(w.Bm, w.LBinv, Mp, Mp, S, mm, w.infoB, w.flags, st);
-  mix_status_kernel<<<1, 64, 0, st>>>(M, nullptr, nullptr, 0, 0.0, info, w.infoB, S);
+  mix_status_kernel<<<1, 64, 0, st>>>(M, info, w.infoB, S);
   tri_inverse(w.Bm, w.LBinv, w.tmp, Mp, Mp, st, S, mm);
   mix_trmv_kernel<<<dim3(Mp / 4, S), 256, 0, st>>>(w.LBinv, Mp, w.u, w.q);
 

@@ -610,78 +610,69 @@ extern "C" size_t sgp_kuu_factor_workspace_bytes(int M) {
 // of a finite, meaningless density.  The single-launch path (M <= 128, substitution solves) is not gated: it tracks LAPACK
 // (DESIGN section 4a).
 double sgp::cond_gate_limit() { return cur_ctx().cond_limit; }
-// over the 64 columns j of block blockIdx.x, with column j = L[j .. M-1][j] (L: S matrices of ld x ld, lower triangle):
-//   part[s][2 b] = max_j sum_i L[i][j]^2,      part[s][2 b + 1] = sum_j (sum_i L[i][j])^2      (fixed order: bit-reproducible)
-__global__ __launch_bounds__(256) void cond_colnorm_kernel(const double* __restrict__ L, int64_t ld, int64_t stride, int M,
-                                                           double* __restrict__ part) {
-  __shared__ double acc[4][64], acs[4][64];
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
-  const double* Ls = L + (int64_t)blockIdx.y * stride;
-  double s = 0.0, cs = 0.0;
-  if (j < M)
-    for (int i = (j & ~3) + r; i < M; i += 4)
-      if (i >= j) { const double v = Ls[(int64_t)i * ld + j]; s = fma(v, v, s); cs += v; }
-  acc[r][c] = s;
-  acs[r][c] = cs;
+// Scratch of one matrix (cond_scratch_doubles(M) doubles; nb = ceil(M / 64), Mc = 64 nb):
+//   colN[br][j], colS[br][j]  (2 nb Mc)  partial sums over the 64 rows of row block br of L[i][j]^2 and L[i][j]   (tiles br >= j / 64)
+//   rowN[i]                   (Mc)       ||e_i^T L^-1||^2
+// Every partial is written by exactly one thread and summed in a fixed order: the same bits on every rank.  (The first version walked
+// whole columns per thread and whole matrices per workgroup: 88 + 57 + 312 us at M = 1024, rocprofv3 -- on the K_uu chain, which IS
+// the critical path at C3; these take ~5 us each.)
+__global__ __launch_bounds__(256) void cond_coltile_kernel(const double* __restrict__ L, int64_t ld, int64_t stride, int M, int64_t sstride,
+                                                           double* __restrict__ scratch) {
+  const int bc = blockIdx.x, br = blockIdx.y;
+  if (br < bc) return;
+  __shared__ double a2[4][64], a1[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6, j = bc * 64 + c;
+  const int nb = gridDim.x, Mc = nb * 64;
+  const double* Ls = L + (int64_t)blockIdx.z * stride;
+  double s2 = 0.0, s1 = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int i = br * 64 + r + 4 * k;
+    if (i < M && j < M && i >= j) { const double v = Ls[(int64_t)i * ld + j]; s2 = fma(v, v, s2); s1 += v; }
+  }
+  a2[r][c] = s2;
+  a1[r][c] = s1;
   __syncthreads();
   if (r == 0) {
-    s = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
-    cs = (acs[0][c] + acs[1][c]) + (acs[2][c] + acs[3][c]);
-    cs *= cs;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s = fmax(s, __shfl_xor(s, o, 64));
-      cs += __shfl_xor(cs, o, 64);
-    }
-    if (c == 0) {
-      double* dst = part + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
-      dst[0] = s;
-      dst[1] = cs;
-    }
+    double* sc = scratch + (int64_t)blockIdx.z * sstride;
+    sc[(int64_t)br * Mc + j] = (a2[0][c] + a2[1][c]) + (a2[2][c] + a2[3][c]);
+    sc[(int64_t)(nb + br) * Mc + j] = (a1[0][c] + a1[1][c]) + (a1[2][c] + a1[3][c]);
   }
 }
-
-void sgp::cond_colnorms(const double* L, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st) {
-  cond_colnorm_kernel<<<dim3((M + 63) / 64, S), 256, 0, st>>>(L, ld, stride, M, part);
+// one wave per row of the lower-triangular Li: out[i] = sum_{j <= i} Li[i][j]^2
+__global__ __launch_bounds__(256) void tri_rowsq_kernel(const double* __restrict__ Li, int64_t ld, int64_t stride, int M, int64_t ostride,
+                                                        double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= M) return;
+  const double* row = Li + (int64_t)blockIdx.y * stride + (int64_t)i * ld;
+  double s = 0.0;
+  for (int j = lane; j <= i; j += 64) { const double v = row[j]; s = fma(v, v, s); }
+  s = wave_sum(s);
+  if (lane == 0) out[(int64_t)blockIdx.y * ostride + i] = s;
 }
-// rows of L^-1 (S matrices of ld x ld, lower triangle), 64 rows per block, 16 per wave:
-//   part[s][2 b] = max_i ||e_i^T L^-1||^2,      part[s][2 b + 1] = its row index        (ties: the smaller index)
-__global__ __launch_bounds__(256) void cond_rownorm_kernel(const double* __restrict__ Li, int64_t ld, int64_t stride, int M,
-                                                           double* __restrict__ part) {
-  __shared__ double sv[4];
-  __shared__ int si[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double* Ls = Li + (int64_t)blockIdx.y * stride;
-  double best = -1.0;
-  int at = 0;
-  for (int r = 0; r < 16; ++r) {
-    const int i = blockIdx.x * 64 + w * 16 + r;
-    if (i >= M) break;
-    double s = 0.0;
-    for (int j = lane; j <= i; j += 64) { const double v = Ls[(int64_t)i * ld + j]; s = fma(v, v, s); }
-    s = wave_sum(s);
-    if (s > best) { best = s; at = i; }
-  }
-  if (lane == 0) { sv[w] = best; si[w] = at; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int t = 1; t < 4; ++t)
-      if (sv[t] > best) { best = sv[t]; at = si[t]; }
-    double* dst = part + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
-    dst[0] = best;
-    dst[1] = (double)at;
-  }
+size_t sgp::cond_scratch_doubles(int M) {
+  const size_t nb = (size_t)(M + 63) / 64, Mc = nb * 64;
+  return 2 * nb * Mc + Mc;
 }
-void sgp::cond_rownorms(const double* Linv, int64_t ld, int64_t stride, int M, int S, double* part, hipStream_t st) {
-  cond_rownorm_kernel<<<dim3((M + 63) / 64, S), 256, 0, st>>>(Linv, ld, stride, M, part);
+void sgp::cond_stats(const double* L, const double* Linv, int64_t ld, int64_t stride, int M, int S, double* scratch, hipStream_t st) {
+  const int nb = (M + 63) / 64;
+  const int64_t ss = (int64_t)cond_scratch_doubles(M);
+  cond_coltile_kernel<<<dim3(nb, nb, S), 256, 0, st>>>(L, ld, stride, M, ss, scratch);
+  tri_rowsq_kernel<<<dim3((M + 3) / 4, S), 256, 0, st>>>(Linv, ld, stride, M, ss, scratch + (size_t)2 * nb * nb * 64);
 }
-// est = lambda_max estimate (from L: partL) x 1 / lambda_min estimate (from L^-1: partR) > limit  ->  info = that row + 1
-__global__ void cond_gate_kernel(const double* __restrict__ partL, const double* __restrict__ partR, int npart, int M, double limit,
-                                 int* info) {
-  const double inv_min = cond_inv_lambda_min(partR, npart, nullptr);
-  int at = 0;
-  (void)cond_inv_lambda_min(partR, npart, &at);
-  if (*info == 0 && !(cond_lambda_max(partL, npart, M) * inv_min <= limit)) *info = at + 1;  // (NaN trips as well)
+// est = lambda_max estimate (columns of L) x 1 / lambda_min estimate (rows of L^-1) > limit  ->  info = that row + 1.  One workgroup per
+// matrix (blockIdx.x = sample); `info` is only written while it is still 0.
+__global__ __launch_bounds__(256) void cond_gate_kernel(const double* __restrict__ scratch, int64_t sstride, int M, double limit,
+                                                        int* __restrict__ info) {
+  __shared__ double red[12];
+  __shared__ int redi[4];
+  double lam, inv_min;
+  int at;
+  cond_estimate_block(scratch + (int64_t)blockIdx.x * sstride, M, red, redi, lam, inv_min, at);
+  if (threadIdx.x == 0 && info[blockIdx.x] == 0 && !(lam * inv_min <= limit)) info[blockIdx.x] = at + 1;  // (NaN trips as well)
+}
+void sgp::cond_gate(const double* scratch, int M, int S, double limit, int* info, hipStream_t st) {
+  cond_gate_kernel<<<S, 256, 0, st>>>(scratch, (int64_t)cond_scratch_doubles(M), M, limit, info);
 }
 
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
@@ -702,10 +693,8 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   if (cond_gate_limit() > 0.0) {  // `tmp` is free again: the partials of L's columns and of L^-1's rows live at its start
-    const int nb = (M + 63) / 64;
-    cond_colnorms(L, Mp, 0, M, 1, tmp, st);
-    cond_rownorms(Linv_out, Mp, 0, M, 1, tmp + 2 * nb, st);
-    cond_gate_kernel<<<1, 1, 0, st>>>(tmp, tmp + 2 * nb, nb, M, cond_gate_limit(), info);
+    cond_stats(L, Linv_out, Mp, 0, M, 1, tmp, st);
+    cond_gate(tmp, M, 1, cond_gate_limit(), info, st);
   }
   return check_launch();
 }
@@ -718,30 +707,22 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
 // overshoots for exactly duplicated inducing rows, whose eigen-directions carry no error).  The caller (core.py) re-evaluates in the
 // whitened (PyMC3) order when estimate / N exceeds its tolerance.  Both kernels sum in a FIXED order: every rank of a sharded
 // evaluation holds the same L^-1 and the same all-reduced Phi, so every rank gets the same bits and takes the same decision.
-// one workgroup, fixed thread <-> element mapping and a fixed tree: the same bits on every rank (and off the critical path: the caller
-// enqueues it on the side stream behind the factorization)
-__global__ __launch_bounds__(1024) void linv_trace_kernel(const double* __restrict__ Li, int64_t ld, int M, double* __restrict__ out) {
-  __shared__ double red[16];
+// row sums of squares by one wave per row, then ONE workgroup adds them with a fixed thread <-> row mapping and a fixed tree: the
+// same bits on every rank
+__global__ __launch_bounds__(256) void ordered_sum_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
+  __shared__ double red[4];
   double s = 0.0;
-  for (int i = threadIdx.x >> 6; i < M; i += 16)
-    for (int j = threadIdx.x & 63; j <= i; j += 64) {
-      const double v = Li[(int64_t)i * ld + j];
-      s = fma(v, v, s);
-    }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < 16; ++w) t += red[w];
-    out[0] = t;
-  }
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) out[0] = s;
 }
-extern "C" size_t sgp_kuu_inverse_trace_len(void) { return 2; }
+extern "C" size_t sgp_kuu_inverse_trace_len(void) { return 1 + SGP_MAX_INDUCING; }
 extern "C" int sgp_kuu_inverse_trace(const double* kuu_linv, int M, double* trace_out, sgp_stream_t stream) {
   if (!kuu_linv || !trace_out || M <= 0) return SGP_ERR_ARG;
   if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
-  linv_trace_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kuu_linv, padded_m(M), M, trace_out);
+  hipStream_t st = (hipStream_t)stream;
+  tri_rowsq_kernel<<<dim3((M + 3) / 4, 1), 256, 0, st>>>(kuu_linv, padded_m(M), 0, M, 0, trace_out + 1);
+  ordered_sum_kernel<<<1, 256, 0, st>>>(trace_out + 1, M, trace_out);
   return check_launch();
 }
 __global__ __launch_bounds__(256) void streaming_estimate_kernel(const double* __restrict__ Phi, int M, const double* __restrict__ tr,

@@ -252,6 +252,11 @@ class HipEngine:
         if not 0 < M <= _lib.SGP_MAX_INDUCING:
             raise ValueError("M = %d inducing points is outside 1 .. %d" % (M, _lib.SGP_MAX_INDUCING))
         ent = self._graphs.get(M, False) if hasattr(self, "_graphs") else False
+        # the conditioning gate's limit is a launch argument baked into the captured chain: an option changed since (this engine's
+        # context, or the deprecated process-wide setter on the default one) means a new capture
+        limit = self.lib.sgp_ctx_get_option(self._c(), self.OPTIONS["cond_limit"])
+        if ent and ent.get("cond_limit") != limit:
+            ent = False
         if ent is not False:
             return ent
         if not hasattr(self, "_graphs"):
@@ -277,7 +282,7 @@ class HipEngine:
             # another bound) must neither fail nor invalidate this capture
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 run()
-            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws}
+            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws, "cond_limit": limit}
         except RuntimeError as exc:  # stream capture unavailable / refused: plain launches still work
             import warnings
             warnings.warn("hipGraph capture of the Kuu chain failed (%s); falling back to plain launches" % (exc,))

@@ -759,6 +759,21 @@ def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
     assert r2["leapfrog_per_s"] > 0 and r2["value"] > 0
     assert r2["config"]["allreduce_ms"] > 0 and r2["config"]["collectives_per_eval"] == 1.0
     assert r2["config"]["allreduce_bytes"] == 8 * (1024 * 1025 // 2 + 1024 + 2)
+    # the streaming-order guard on two ranks: at a long lengthscale x small noise BOTH ranks must decide, from the replicated tail and
+    # the all-reduced statistics, to repeat the evaluation in the whitened order -- a rank deciding otherwise would leave the other
+    # one alone in its all-reduce (the job would hang, not fail).  Same F as the one-process job, which repeats as well.
+    hard = ["--ls", "6.0", "--sig-n", "0.03"]
+    one_h = subprocess.run(base + hard, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert one_h.returncode == 0, one_h.stderr[-2000:]
+    h1 = json.loads(one_h.stdout.strip().splitlines()[-1])
+    two_h = subprocess.run(base + hard + ["--gpus", "2"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert two_h.returncode == 0, two_h.stderr[-3000:]
+    h2 = json.loads([ln for ln in two_h.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    g1, g2 = h1["config"]["streaming_guard"], h2["config"]["streaming_guard"]
+    assert g1["repeats_in_whitened_order"] > 0 and g2["repeats_in_whitened_order"] > 0, (g1, g2)
+    assert g1["estimate_per_datum"] > g1["tolerance_per_datum"] and g2["estimate_per_datum"] > g2["tolerance_per_datum"]
+    assert abs(h2["F"] - h1["F"]) < 1e-9 * abs(h1["F"]), (h1["F"], h2["F"])
+    assert r1["config"]["streaming_guard"]["repeats_in_whitened_order"] == 0      # the benchmark's own theta never repeats
     # and without the sharing override a 1-GPU box must refuse, loudly, instead of printing n_gpus: 1
     import torch
     if torch.cuda.device_count() < 2:
