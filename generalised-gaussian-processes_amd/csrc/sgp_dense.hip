@@ -13,6 +13,7 @@
 #include "sgp_dense.hpp"
 #include "sgp_ctx.hpp"
 #include "sgp_potrf.hpp"
+#include <cstdlib>
 
 namespace sgp {
 
@@ -41,30 +42,35 @@ __device__ __forceinline__ int tile_rot(int k) { return 4 * (k >> 2) + 16 * (k &
 // op(A) tile -> S; "K-contiguous" source (A not transposed / B transposed): thread = (row, k-quad), 32 B along k;
 // "MN-contiguous" source (A transposed / B not transposed): thread = (k, column pair), 2 x 16 B along the row.
 // t = thread index inside its 256-thread group.
-template <bool KCONTIG>
+// T = tile edge (64, or 32: the same image with its first 32 "columns" in use -- the rotation still runs modulo 64).
+template <bool KCONTIG, int T>
 __device__ __forceinline__ void tile_fetch(const double* P, int64_t ld, int r0, int k0, int t, d2 (&v)[2]) {
   if constexpr (KCONTIG) {
     const int row = t >> 2, kq = (t & 3) * 4;
-    const double* s = P + (int64_t)(r0 + row) * ld + k0 + kq;
-    v[0] = *reinterpret_cast<const d2*>(s);
-    v[1] = *reinterpret_cast<const d2*>(s + 2);
+    if (T == 64 || row < T) {
+      const double* s = P + (int64_t)(r0 + row) * ld + k0 + kq;
+      v[0] = *reinterpret_cast<const d2*>(s);
+      v[1] = *reinterpret_cast<const d2*>(s + 2);
+    }
   } else {
     const int kk = t >> 4, c2 = (t & 15) * 2;
     const double* s = P + (int64_t)(k0 + kk) * ld + r0 + c2;
     v[0] = *reinterpret_cast<const d2*>(s);
-    v[1] = *reinterpret_cast<const d2*>(s + 32);
+    if constexpr (T == 64) v[1] = *reinterpret_cast<const d2*>(s + 32);
   }
 }
-template <bool KCONTIG>
+template <bool KCONTIG, int T>
 __device__ __forceinline__ void tile_stash(double (*S)[GT], int t, const d2 (&v)[2]) {
   if constexpr (KCONTIG) {
     const int row = t >> 2, kq = (t & 3) * 4;
+    if (T == 64 || row < T) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) S[kq + e][(row + tile_rot(kq + e)) & 63] = v[e >> 1][e & 1];
+      for (int e = 0; e < 4; ++e) S[kq + e][(row + tile_rot(kq + e)) & 63] = v[e >> 1][e & 1];
+    }
   } else {
     const int kk = t >> 4, c2 = (t & 15) * 2, rot = tile_rot(kk);
     *reinterpret_cast<d2*>(&S[kk][(c2 + rot) & 63]) = v[0];
-    *reinterpret_cast<d2*>(&S[kk][(c2 + 32 + rot) & 63]) = v[1];
+    if constexpr (T == 64) *reinterpret_cast<d2*>(&S[kk][(c2 + 32 + rot) & 63]) = v[1];
   }
 }
 
@@ -79,9 +85,14 @@ struct GemmShared {
 };
 static_assert(sizeof(GemmShared) >= sizeof(double) * GT * GT, "partial tile is exchanged through the operand tiles");
 
-template <bool TA, bool TB>
+//
+// T = 32 (round 4): the same kernel on 32 x 32 output tiles, one MFMA tile per wave -- for the M <= 512 products of the tail, whose
+// 64 x 64 tiling fills a quarter of the chip (512^3: 64 workgroups, 21 us, all of it MFMA time of the 64 CUs in use; C3 runs sixteen
+// such launches on its critical path).  Every output element sees the same k-order and the same group split: bit-identical results.
+template <bool TA, bool TB, int T = 64>
 __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
   __shared__ GemmShared sh;
+  constexpr int NT = T / 32;  // 16 x 16 MFMA tiles per wave and dimension
   const int bj = blockIdx.x, bi = blockIdx.y;
   if (p.lower_only && bj > bi) return;
   const int64_t bo = (int)blockIdx.z / p.batch, bz = (int)blockIdx.z - bo * p.batch;  // (outer, inner) batch index
@@ -90,23 +101,23 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
   double* C = p.C + bz * p.sC + bo * p.s2C;
 
   int klo = 0, khi = p.k;
-  if (p.klo_mask & 1) klo = max(klo, bi * GT);
-  if (p.klo_mask & 2) klo = max(klo, bj * GT);
-  if (p.khi_mask & 1) khi = min(khi, (bi + 1) * GT);
-  if (p.khi_mask & 2) khi = min(khi, (bj + 1) * GT);
+  if (p.klo_mask & 1) klo = max(klo, bi * T) / GK * GK;  // (a 32-row tile may start inside a 64-block of the triangular operand:
+  if (p.klo_mask & 2) klo = max(klo, bj * T) / GK * GK;  //  32 is a multiple of the chunk depth, the division is a no-op kept for clarity)
+  if (p.khi_mask & 1) khi = min(khi, (bi + 1) * T);
+  if (p.khi_mask & 2) khi = min(khi, (bj + 1) * T);
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
-  const int r0 = bi * GT, c0 = bj * GT;
+  const int r0 = bi * T, c0 = bj * T;
   // column of this lane's operands in k-row ks * 4 + l4, before the 4 ks part of the rotation
-  const int ca = wi * 32 + l15 + 16 * (l4 & 1), cb = wj * 32 + l15 + 16 * (l4 & 1);
+  const int ca = wi * (T / 2) + l15 + 16 * (l4 & 1), cb = wj * (T / 2) + l15 + 16 * (l4 & 1);
 
-  d4 acc[2][2];
+  d4 acc[NT][NT];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int v = 0; v < NT; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
   if (klo < khi) {
     // chunk j of this group starts at klo + (2 j + grp) GK; both groups run the same number of barriers
@@ -115,14 +126,14 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
     auto fetch = [&](int j, d2 (&ra)[2], d2 (&rb)[2]) {
       const int c = 2 * j + grp;
       if (c < nchunk) {
-        tile_fetch<!TA>(A, p.lda, r0, klo + c * GK, tid, ra);
-        tile_fetch<TB>(B, p.ldb, c0, klo + c * GK, tid, rb);
+        tile_fetch<!TA, T>(A, p.lda, r0, klo + c * GK, tid, ra);
+        tile_fetch<TB, T>(B, p.ldb, c0, klo + c * GK, tid, rb);
       }
     };
     auto stash = [&](int j, int stage, const d2 (&ra)[2], const d2 (&rb)[2]) {
       if (2 * j + grp < nchunk) {
-        tile_stash<!TA>(sh.As[grp][stage], tid, ra);
-        tile_stash<TB>(sh.Bs[grp][stage], tid, rb);
+        tile_stash<!TA, T>(sh.As[grp][stage], tid, ra);
+        tile_stash<TB, T>(sh.Bs[grp][stage], tid, rb);
       }
     };
     // r holds chunk j + 1 on entry and chunk j + 3 on exit
@@ -136,16 +147,20 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
         for (int ks = 0; ks < GK / 4; ++ks) {
           const int kr = ks * 4 + l4;
           a0[ks] = As[kr][(ca + 4 * ks) & 63];
-          a1[ks] = As[kr][(ca + 16 + 4 * ks) & 63];
           b0[ks] = Bs[kr][(cb + 4 * ks) & 63];
-          b1[ks] = Bs[kr][(cb + 16 + 4 * ks) & 63];
+          if constexpr (NT == 2) {
+            a1[ks] = As[kr][(ca + 16 + 4 * ks) & 63];
+            b1[ks] = Bs[kr][(cb + 16 + 4 * ks) & 63];
+          }
         }
       }
       auto mac = [&](int ks) {
         acc[0][0] = mfma16(a0[ks], b0[ks], acc[0][0]);
-        acc[0][1] = mfma16(a0[ks], b1[ks], acc[0][1]);
-        acc[1][0] = mfma16(a1[ks], b0[ks], acc[1][0]);
-        acc[1][1] = mfma16(a1[ks], b1[ks], acc[1][1]);
+        if constexpr (NT == 2) {
+          acc[0][1] = mfma16(a0[ks], b1[ks], acc[0][1]);
+          acc[1][0] = mfma16(a1[ks], b0[ks], acc[1][0]);
+          acc[1][1] = mfma16(a1[ks], b1[ks], acc[1][1]);
+        }
       };
       if (live) mac(0);
       stash(j + 1, stage ^ 1, ra, rb);  // LDS stores and global loads of later chunks issue under the MFMAs
@@ -170,31 +185,31 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
     double* red = &sh.As[0][0][0][0];
     if (grp == 1) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < NT; ++v)
 #pragma unroll
           for (int r = 0; r < 4; ++r) red[((u * 2 + v) * 4 + r) * 256 + tid] = acc[u][v][r];
     }
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < NT; ++v)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[u][v][r] += red[((u * 2 + v) * 4 + r) * 256 + tid];
     }
   }
   if (grp != 0) return;
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < NT; ++v)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = r0 + wi * 32 + u * 16 + l4 + 4 * r;
-        const int col = c0 + wj * 32 + v * 16 + l15;
+        const int row = r0 + wi * (T / 2) + u * 16 + l4 + 4 * r;
+        const int col = c0 + wj * (T / 2) + v * 16 + l15;
         double* dst = C + (int64_t)row * p.ldc + col;
         const double val = p.alpha * acc[u][v][r];
         *dst = (p.beta == 0.0) ? val : fma(p.beta, *dst, val);
@@ -240,11 +255,26 @@ void gemm_splitk(const GemmDesc& g, int S, double* scratch, hipStream_t st) {
   splitk_reduce_kernel<<<dim3(blocks, g.batch2), 256, 0, st>>>(scratch, S, g.m, g.n, g.C, g.ldc, g.alpha, g.beta, g.s2C);
 }
 
+// 64 x 64 tilings with at most this many tiles x 2 take the 32 x 32 tiles: the CU count (SGP_GEMM_SMALL_TILES=0 switches them off: A/B)
+static int gemm_small_tile_threshold() {
+  static const int v = getenv("SGP_GEMM_SMALL_TILES") ? atoi(getenv("SGP_GEMM_SMALL_TILES")) : 256;
+  return v;
+}
 void gemm(const GemmDesc& g, hipStream_t st) {
   if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return;
   GemmP p{g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.sA, g.sB, g.sC, g.m, g.n, g.k,
           g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? 1 : 0, g.batch, g.s2A, g.s2B, g.s2C};
   if (g.batch2 <= 0) return;
+  // fewer 64 x 64 tiles than half the CUs: four times as many 32 x 32 tiles instead (bit-identical results)
+  const int64_t tiles64 = (int64_t)(g.n / GT) * (g.m / GT) * g.batch * g.batch2;
+  if (tiles64 * 2 <= gemm_small_tile_threshold()) {
+    dim3 grid(g.n / 32, g.m / 32, g.batch * g.batch2);
+    if (!g.ta && !g.tb) gemm64_kernel<false, false, 32><<<grid, 512, 0, st>>>(p);
+    else if (!g.ta && g.tb) gemm64_kernel<false, true, 32><<<grid, 512, 0, st>>>(p);
+    else if (g.ta && !g.tb) gemm64_kernel<true, false, 32><<<grid, 512, 0, st>>>(p);
+    else gemm64_kernel<true, true, 32><<<grid, 512, 0, st>>>(p);
+    return;
+  }
   dim3 grid(g.n / GT, g.m / GT, g.batch * g.batch2);
   if (!g.ta && !g.tb) gemm64_kernel<false, false><<<grid, 512, 0, st>>>(p);
   else if (!g.ta && g.tb) gemm64_kernel<false, true><<<grid, 512, 0, st>>>(p);
