@@ -430,7 +430,7 @@ def main():
             "pass1": {"kernels": "kfu_digits_kernel + i8_syrk_tile_kernel", "ms": digits_ms + i8_ms, "fp64_pass1_ms": assemble_ms + syrk_ms},
             "pass1_of_a_leapfrog": ({"kernels": "kfu_digits_kernel<.., true> (fp64 block + digit planes) + i8_syrk_tile_kernel", "assembly_ms": both_ms,
                                      "contraction_ms": i8g_ms, "ms": both_ms + i8g_ms} if int8_grad else None),
-            "accuracy": "as the fp64 contraction: |K' - q 2^-53| <= 2^-54, digit products exact, dropped pairs < 6 x 2^-52 per product and "
+            "accuracy": "as the fp64 contraction: |K' - q 2^-54| <= 2^-55, digit products exact, dropped pairs < 6 x 2^-54 per product and "
                         "zero-mean; 2.4-2.8e-16 of max |Phi| against long double (tests/test_int8_contraction.py, tools/i8_syrk_proto.hip)"}
         res["config"]["contraction"] = "int8 digit planes on the integer matrix cores (error-free split of K'_fu, fp64 result)"
         res["dtype_note"] = ("fp64 kernel values, statistics, factorizations and gradients; the pass-1 contraction multiplies exact 8-bit digits of the "

@@ -301,7 +301,7 @@ class CollapsedBound:
             z_ready = main.record_event()  # Z is materialised on the main stream
             side, jitter, kernel = self._side, self.jitter, self.kernel
 
-            def side_chain():
+            def side_chain(with_trace=True):
                 torch.cuda.set_device(e.device)  # the current device is per host thread
                 with torch.cuda.stream(side):
                     side.wait_event(z_ready)
@@ -314,7 +314,7 @@ class CollapsedBound:
                         K = e.kuu(Z, ls, sf2, jitter, kernel)
                         li = e.kuu_factor(K, info=result[2])[0]
                     ready = side.record_event()  # what pass 1's tail waits for; the guard's tr(Kuu^-1) runs behind it, off the critical path
-                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0], out=self._trace_buf()) if guard else None), ready
+                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0], out=self._trace_buf()) if guard and with_trace else None), ready
 
             result[0].record_stream(side)
             # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
@@ -326,7 +326,7 @@ class CollapsedBound:
             # shard below it, a pinned fp64 mode or a composite kernel keeps the helper-thread overlap)
             if (gr is not None and hasattr(e, "would_use_i8") and self.kernel != "composite"
                     and int(self.X.shape[0]) >= 300 * int(Z.shape[0]) and e.would_use_i8(int(self.X.shape[0]), int(Z.shape[0]))):
-                chain = side_chain()
+                chain = side_chain(with_trace=False)  # (this thread is about to enqueue pass 1: the guard's launch waits until it has)
                 gate = chain[3]
                 pending = None
             else:
@@ -335,6 +335,9 @@ class CollapsedBound:
         self._allreduce_stats(packed, int(Z.shape[0]))
         if overlap:
             Kuu, linv, trace, ready = pending.result() if pending is not None else chain
+            if guard and trace is None:
+                with torch.cuda.stream(self._side):
+                    trace = e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf())
             for t in (Kuu, linv):
                 t.record_stream(main)
             main.wait_event(ready)

@@ -2,16 +2,19 @@
 //
 // Every entry of K'_fu lies in [0, 1] (a stationary profile without its amplitude), so it IS a fixed-point number:
 //
-//   q = rint(K' 2^53) = sum_p a_p 256^p,   a_p in [-128, 127],  p = 0..6      (balanced digits: the bytes of (q + C) ^ C,
+//   q = rint(K' 2^54) = sum_p a_p 256^p,   a_p in [-128, 127],  p = 0..6      (balanced digits: the bytes of (q + C) ^ C,
 //                                                                              C = 0x80 in each of the seven bytes)
-//   Phi_IJ = 2^-106 sum_n q_nI q_nJ = 2^-106 sum_{p + r >= 6} 256^(p + r) sum_n a_p,nI a_r,nJ  +  truncation
+//   Phi_IJ = 2^-108 sum_n q_nI q_nJ = 2^-108 sum_{p + r >= 6} 256^(p + r) sum_n a_p,nI a_r,nJ  +  truncation
 //
-// * |K' - q 2^-53| <= 2^-54: exact for K' >= 1/2, an ABSOLUTE error below half an ulp of 1.0 otherwise.
+// * |K' - q 2^-54| <= 2^-55: exact for K' >= 1/4, an ABSOLUTE error below a quarter ulp of 1.0 otherwise.  (Round 3 scaled by 2^53;
+//   seven balanced digits hold 2^55, and K' <= 1 (+ an ulp) needs q <= 2^54 + 2, top digit <= 65: the scale 2^54 is free and makes
+//   the truncation below four times smaller.)
 // * digit products are exact in int32: a group g = p + r - 6 holds 7 - g pairs of |a_p a_r| <= 2^14 -- 7 x 2^14 x 16384 rows < 2^31,
 //   so a split never spans more than I8_SPLIT_ROWS = 16384 rows; the fold to fp64 (7 terms) happens once per split and tile.
-// * 28 of the 49 digit pairs are kept (p + r >= 6); the dropped ones are < 6 x 2^-52 per product in the worst case, zero-mean
-//   (balanced digits) and ~2^-52 typically: below the rounding of ONE fp64 product, where the fp64 SYRK rounds every one of its
-//   N accumulation steps.  Measured against long-double arithmetic (tools/i8_syrk_proto.hip): 2.4-2.8e-16 of max |Phi|.
+// * 28 of the 49 digit pairs are kept (p + r >= 6); the dropped ones are < 6 x 2^-54 per product in the worst case, zero-mean
+//   (balanced digits) and ~2^-54 typically: below the rounding of ONE fp64 product, where the fp64 SYRK rounds every one of its
+//   N accumulation steps.  Measured against long-double arithmetic (tools/i8_syrk_proto.hip, at the 2^53 scale): 2.4-2.8e-16 of
+//   max |Phi|.  It is an ABSOLUTE error (against K' <= 1): component-wise statement in DESIGN.md 4d / tests/test_int8_theta_sweep.py.
 //
 // Why: v_mfma_i32_32x32x32_i8 runs 32 768 MACs in 32 cycles against 1 024 in 64 for v_mfma_f64_16x16x4_f64 -- 64 x the rate for
 // 28 x the MACs.  What is left of that on real operands is decided by POWER, not issue slots: on full-entropy bytes the chip
@@ -90,14 +93,14 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
       const double kv = kprofile<KID>(r2) * msk;
       bacc = fma(kv, ysh[i], bacc);
       if constexpr (WK) __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);
-      // q = rint(kv 2^53) without a 64-bit convert: hi = rint(kv 2^21) and the SIGNED remainder r = rint(kv 2^53 - hi 2^32) in
+      // q = rint(kv 2^54) without a 64-bit convert: hi = rint(kv 2^22) and the SIGNED remainder r = rint(kv 2^54 - hi 2^32) in
       // [-2^31, 2^31], each read off the mantissa of a magic-constant sum (all four operations exact).  r sits in the low 33
       // mantissa bits of tl as a two's-complement number: q = (hi - bit32) 2^32 + low32 -- also at the ties r = +-2^31, which a
       // 32-bit reading would get wrong about once in 2^33 elements.  A NaN distance (NaN in X / Z / a lengthscale) gives q = 0 --
-      // it reaches the bound through b (fp64) instead; a Matern value an ulp above 1 gives q = 2^53 + 1, which seven digits hold.
-      const double th = fma(kv, 0x1p21, 0x1p52);
+      // it reaches the bound through b (fp64) instead; a Matern value an ulp above 1 gives q = 2^54 + 2, which seven digits hold.
+      const double th = fma(kv, 0x1p22, 0x1p52);
       const double hf = th - 0x1p52;
-      const double tl = fma(-hf, 0x1p32, kv * 0x1p53) + 0x1.8p52;
+      const double tl = fma(-hf, 0x1p32, kv * 0x1p54) + 0x1.8p52;
       const unsigned long long tb = (unsigned long long)__double_as_longlong(tl);
       const unsigned q_hi = (unsigned)__double_as_longlong(th) - ((unsigned)(tb >> 32) & 1u);
       const unsigned long long q = ((unsigned long long)q_hi << 32) | (unsigned)tb;
@@ -260,13 +263,13 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
       }
     }
   }
-  // fold the significance groups: value = sum_g acc_g 2^(8 g - 58)   (= 2^-106 256^(g + 6)); 128 x 128 slab tile, this half
+  // fold the significance groups: value = sum_g acc_g 2^(8 g - 60)   (= 2^-108 256^(g + 6)); 128 x 128 slab tile, this half
   if (ACT) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int g = 0; g < I8_NP; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * g - 58), v);
+      for (int g = 0; g < I8_NP; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * g - 60), v);
       const int row = wi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
       double* dst = out + row * TILE + wj * 32 + l32;
       *dst = accumulate ? *dst + v : v;

@@ -192,7 +192,7 @@ size_t sgp_kfu_len(int64_t N, int M);
 /* Which matrix cores run the pass-1 contraction Phi = K_uf K_fu of sgp_suffstats_fwd (csrc/sgp_suffstats_i8.hip):
  *   0  fp64 (v_mfma_f64_16x16x4_f64) always;
  *   1  (default, SGP_CONTRACTION) the integer cores where they win: rows x padded-M^2 >= 2^32 (65536 rows at M <= 256, 4096 at
- *      M = 1024).  K'_fu in [0, 1] is split into seven balanced 8-bit digit planes (|K' - q 2^-53| <= 2^-54), the 28 digit-pair
+ *      M = 1024).  K'_fu in [0, 1] is split into seven balanced 8-bit digit planes (|K' - q 2^-54| <= 2^-55), the 28 digit-pair
  *      products p + r >= 6 are exact int32 sums, folded to fp64 once per 16384 rows: the result is as accurate as the fp64
  *      contraction (2.4-2.8e-16 of max |Phi| against long-double arithmetic).  With Kfu_out != NULL (value + gradient: pass 2
  *      reads the fp64 block) kernel assembly writes the fp64 block AND the digit planes (the planes a super-chunk at a time in

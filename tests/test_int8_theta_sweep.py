@@ -7,7 +7,7 @@ several e-folds): lengthscales 0.2 .. 20, noise 0.01 .. 3, inducing inputs with 
 
  * F against the PyMC3-op-order CPU oracle (oracle.vfe_pymc3_order_chunked) to 1e-8 on F / N (north_star's tolerance);
  * grad F against torch autograd through that graph on 50 000 rows to 1e-6;
- * HmcTarget.logp_and_grad against oracle.hmc_logp at five seeded theta of the tuner's range;
+ * HmcTarget.logp_and_grad against oracle.hmc_logp at three seeded theta of the tuner's range;
  * Phi COMPONENT-WISE: |dPhi_IJ| <= c eps sqrt(Phi_II Phi_JJ) -- the scaled bound a Cholesky-based tail is invariant under (the
    norm-wise claim of DESIGN.md 4d stated as a tested inequality; c recorded in the assertion message).
 """
@@ -36,11 +36,12 @@ def _data(N, M, dup):
     return X, y, Z
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def host_threads():
-    n = torch.get_num_threads()
-    yield lambda: torch.set_num_threads(os.cpu_count() or 1)
-    torch.set_num_threads(n)
+    """The CPU oracle's GEMMs want more than conftest's eight threads -- set ONCE per test (switching the pool size back and forth
+    inside a loop cost seconds per switch on the 256-thread GPU box; conftest's own fixture restores the count afterwards)."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    yield lambda: None
 
 
 CELLS_512 = [(ls, sn) for ls in (0.2, 0.5, 1.0, 2.0, 5.0, 20.0) for sn in (0.01, 0.3, 3.0)]
@@ -77,10 +78,10 @@ def test_default_mode_bound_over_the_theta_range(engine, host_threads, M, dup, c
                 Kuu = O.kuu(Z, lst, 1.0, 1e-6)
                 stw = O.suffstats_whitened(X, y, Z, lst, 1.0, torch.linalg.cholesky(Kuu), chunk=65536)
                 ref_cache[ls] = (Kuu, stw)
-                F_direct = O.vfe_pymc3_order_chunked(X, y, Z, lst, 1.0, sn, 1e-6)
-                F_two = O.bound_from_stats(Kuu, stw, sn * sn, stats_whitened=True)["F"]
-                assert abs(F_direct - F_two) / N_SWEEP < 1e-10, (ls, sn, F_direct, F_two)  # the two oracle routes are one
-                torch.set_num_threads(8)
+                if len(ref_cache) == 1:  # the two oracle routes are one: checked at the group's first lengthscale
+                    F_direct = O.vfe_pymc3_order_chunked(X, y, Z, lst, 1.0, sn, 1e-6)
+                    F_two = O.bound_from_stats(Kuu, stw, sn * sn, stats_whitened=True)["F"]
+                    assert abs(F_direct - F_two) / N_SWEEP < 1e-10, (ls, sn, F_direct, F_two)
             Kuu, stw = ref_cache[ls]
             F_ref = O.bound_from_stats(Kuu, stw, sn * sn, stats_whitened=True)["F"]
             err = abs(F - F_ref) / N_SWEEP
@@ -123,7 +124,7 @@ def test_streaming_guard_can_be_switched_off_and_reports_its_estimate(engine):
     assert float((ga["ls"] - gb["ls"]).abs().max()) < 1e-7 * float(gb["ls"].abs().max())
 
 
-@pytest.mark.parametrize("ls", [0.2, 0.5, 1.0, 2.0, 5.0, 20.0])
+@pytest.mark.parametrize("ls", [0.2, 0.5, 2.0, 20.0])
 def test_default_mode_phi_componentwise(engine, host_threads, ls):
     """The component-wise statement of DESIGN.md 4d, as a tested inequality.  Two error sources with different shapes:
       * quantisation, |K' - q 2^-53| <= 2^-54: |dPhi_IJ| <= 1 eps sqrt(Phi_II Phi_JJ) on its own (oracle/i8_digits_oracle.py on the
@@ -146,8 +147,7 @@ def test_default_mode_phi_componentwise(engine, host_threads, ls):
         engine.lib.sgp_set_contraction(prev)
     Phi = packed[: M * M].view(M, M).cpu().numpy()
     host_threads()
-    ref = O.suffstats(X, y, Z, torch.full((D,), ls, dtype=torch.float64), 1.0, 0).Phi.numpy()
-    torch.set_num_threads(8)
+    ref = O.suffstats(X, y, Z, torch.full((D,), ls, dtype=torch.float64), 1.0, 0, chunk=65536).Phi.numpy()
     dg = np.sqrt(np.diag(ref))
     err = np.abs(Phi - ref)
     c = float(np.max(err / (EPS * np.outer(dg, dg))))
@@ -159,7 +159,7 @@ def test_default_mode_phi_componentwise(engine, host_threads, ls):
         assert float(np.max(err / ref)) < 1e-12, (ls, float(np.max(err / ref)))
 
 
-@pytest.mark.parametrize("ls,sn", [(0.5, 0.01), (1.0, 0.3), (2.0, 0.01), (5.0, 3.0), (20.0, 0.3)])
+@pytest.mark.parametrize("ls,sn", [(0.5, 0.01), (2.0, 0.01), (5.0, 3.0), (20.0, 0.3)])
 def test_default_mode_gradients_over_the_theta_range(engine, host_threads, ls, sn):
     """value + gradient (the leapfrog's call) on the first 65 536 rows at M = 512 -- rows x Mp^2 = 2^34: integer cores by default."""
     import ggp_amd
@@ -175,7 +175,6 @@ def test_default_mode_gradients_over_the_theta_range(engine, host_threads, ls, s
         engine.lib.sgp_set_contraction(prev)
     host_threads()
     ref = O.grads_autograd(X, y, Z, [ls] * D, 1.0, sn * sn, 1e-6)
-    torch.set_num_threads(8)
     assert abs(F - ref["F"]) / NG < 1e-8, (F, ref["F"])
     scale = max(1.0, float(ref["g_ls"].abs().max()))
     assert float((g["ls"] - ref["g_ls"]).abs().max()) < 1e-6 * scale, (g["ls"], ref["g_ls"])
@@ -184,7 +183,7 @@ def test_default_mode_gradients_over_the_theta_range(engine, host_threads, ls, s
 
 
 def test_default_mode_hmc_target_at_theta_the_tuner_visits(engine, host_threads):
-    """logp + gradient of the NUTS target (bound + priors + Jacobians) at five seeded theta in the unconstrained range NUTS'
+    """logp + gradient of the NUTS target (bound + priors + Jacobians) at three seeded theta in the unconstrained range NUTS'
     jittered start and first tuning leaps cover (|theta_unc - start| <= 2: lengthscales 0.27 .. 14.8, sig 0.14 .. 7.4)."""
     import ggp_amd
     from oracle import vfe_oracle as O
@@ -196,14 +195,13 @@ def test_default_mode_hmc_target_at_theta_the_tuner_visits(engine, host_threads)
     start = np.array(tgt.start())
     prev = engine.lib.sgp_set_contraction(1)
     try:
-        for _ in range(5):
+        for _ in range(3):
             th = start + rng.uniform(-2.0, 2.0, size=D + 2)
             before = cb.n_guard_reruns
             lp, gr = tgt.logp_and_grad(th.tolist())
             assert cb.n_guard_reruns > before or engine.lib.sgp_contraction_last() == 1
             host_threads()
             lp_ref, g_ref = O.hmc_logp(torch.tensor(th, dtype=torch.float64), X, y, Z, 1e-6, with_grad=True)
-            torch.set_num_threads(8)
             assert abs(lp - float(lp_ref)) / NG < 1e-8, (th, lp, float(lp_ref))
             g_ref = np.asarray(g_ref, dtype=np.float64)
             assert np.max(np.abs(np.asarray(gr) - g_ref)) < 1e-6 * max(1.0, float(np.max(np.abs(g_ref)))), (th, gr, g_ref)
