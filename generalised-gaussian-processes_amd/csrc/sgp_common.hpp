@@ -62,6 +62,54 @@ __device__ __forceinline__ double sgp_exp(double x) {
   return ldexp(p, (int)k);
 }
 
+// The same function for the two kernel-assembly kernels, where it is ~40 % of the arithmetic (round 4): x = (32 k + j) ln2 / 32 + r,
+// exp(x) = 2^k T[j] (1 + q(r)) with T[j] = 2^(j/32) from a 32-entry table in LDS (one ds_read_b64, no bank conflict: 32 entries = the
+// 64 banks) and q = r (1 + r/2 + ... + r^5/720) on |r| <= ln2 / 64 (remainder 3.6e-18): 17 instead of 21 VALU instructions, and
+// fma(T, q, T) rounds ONCE after the table value -- <= 1 ulp against libm (tests/test_gpu_parity.py::test_assembly_exp_accuracy).
+// n = rint(32 x / ln2) is read off the low mantissa bits of a magic-constant sum (|n| < 2^16); C_HI has 17 trailing zero bits, so
+// n C_HI is exact.  NaN stays NaN (the table index is masked), x < -800 saturates to 0.
+constexpr int EXP_TAB_N = 32;
+__device__ const double SGP_EXP2_TAB[EXP_TAB_N] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0, 0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0,
+    0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0, 0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0, 0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0,
+    0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0, 0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0, 0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0,
+    0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
+// call from every thread of the block before the barrier that precedes the first sgp_exp_tab
+__device__ __forceinline__ void sgp_exp_tab_load(double* tab) {
+  if (threadIdx.x < EXP_TAB_N) tab[threadIdx.x] = SGP_EXP2_TAB[threadIdx.x];
+}
+__device__ __forceinline__ double sgp_exp_tab(double x, const double* tab) {
+  x = (x < -800.0) ? -800.0 : x;
+  const double t = fma(x, 0x1.71547652b82fep+5, 0x1.8p52);  // 32 / ln2
+  const int n = (int)__double_as_longlong(t);               // the low 32 bits: n as two's complement
+  const double nf = t - 0x1.8p52;
+  double r = fma(nf, -0x1.62e42fefa0000p-6, x);             // ln2 / 32, high part
+  r = fma(nf, -0x1.cf79abc9e3b3ap-45, r);                   // ... low part
+  const double T = tab[n & (EXP_TAB_N - 1)];
+  double q = 1.388888888888889e-03;                         // 1 / 6!
+  q = fma(q, r, 8.333333333333333e-03);
+  q = fma(q, r, 4.1666666666666664e-02);
+  q = fma(q, r, 1.6666666666666666e-01);
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  q *= r;
+  return ldexp(fma(T, q, T), n >> 5);
+}
+template <int KID>
+__device__ __forceinline__ double kprofile_tab(double r2, const double* tab) {
+  if constexpr (KID == SGP_KERNEL_RBF) {
+    return sgp_exp_tab(-0.5 * r2, tab);
+  } else if constexpr (KID == SGP_KERNEL_MATERN32) {
+    const double a = 1.7320508075688772 * sqrt(r2);
+    return (1.0 + a) * sgp_exp_tab(-a, tab);
+  } else {
+    const double a = 2.23606797749979 * sqrt(r2);
+    return (1.0 + a + a * a * (1.0 / 3.0)) * sgp_exp_tab(-a, tab);
+  }
+}
+
 // k'(r2): the stationary profile WITHOUT the sf2 factor; r2 = scaled squared distance.
 // Also returns h = dk'/d(r2) when asked (used by the backward pass).
 template <int KID>

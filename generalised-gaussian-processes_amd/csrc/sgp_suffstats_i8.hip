@@ -60,12 +60,14 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
                                                          uint8_t* __restrict__ Q, double* __restrict__ Kfu, double* __restrict__ bpart) {
   __shared__ double xs[ASM_ROWS][DP];
   __shared__ double ysh[ASM_ROWS];
+  __shared__ double etab[EXP_TAB_N];
   const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;  // row inside this super-chunk's Q
   {
     const double* src = Xs + (row0 + rbase) * DP;
     double* dst = &xs[0][0];
     for (int e = threadIdx.x; e < ASM_ROWS * DP; e += 256) dst[e] = src[e];
     ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
+    sgp_exp_tab_load(etab);
   }
   __syncthreads();
   const int m = blockIdx.y * 256 + threadIdx.x;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
         r2 = fma(df, df, r2);
       }
       const double msk = n < N ? zmask : 0.0;
-      const double kv = kprofile<KID>(r2) * msk;
+      const double kv = kprofile_tab<KID>(r2, etab) * msk;
       bacc = fma(kv, ysh[i], bacc);
       if constexpr (WK) __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);
       // q = rint(kv 2^54) without a 64-bit convert: hi = rint(kv 2^22) and the SIGNED remainder r = rint(kv 2^54 - hi 2^32) in

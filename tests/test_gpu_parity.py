@@ -731,6 +731,46 @@ def test_kernel_exp_accuracy(engine):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2])
+def test_assembly_exp_accuracy(engine, mode):
+    """The table-based exp() of the two kernel-assembly kernels (csrc/sgp_common.hpp: sgp_exp_tab -- 2^k T[j] (1 + q(r)), 32-entry
+    table in LDS, one rounding after the table value) over its whole range, read back from the K'_fu block that kfu_assemble_kernel
+    (fp64 contraction) and kfu_digits_kernel<.., true> (integer contraction) write: k'(x_n, z_0) = exp(-x_n^2 / 2) with z_0 = 0.
+    <= 1.5 ulp against numpy's libm exp, exact 1 at 0, clean underflow, NaN stays NaN; both kernels write the same bits."""
+    t = np.concatenate([np.linspace(0.0, 40.0, 3000), np.linspace(40.0, 744.0, 3000), [745.2, 760.0, 1.0e4]])
+    x = np.sqrt(2.0 * t)
+    N, M = x.size, 2
+    X = dev(x[:, None], engine)
+    y = dev(np.zeros(N), engine)
+    Z = dev(np.array([[0.0], [np.nan]]), engine)
+    prev = engine.lib.sgp_set_contraction(mode)
+    try:
+        kfu = engine.kfu_buffer(N, M)
+        engine.suffstats(X, y, Z, [1.0], 1.0, "rbf", kfu=kfu)
+        assert engine.lib.sgp_contraction_last() == (1 if mode else 0)
+    finally:
+        engine.lib.sgp_set_contraction(prev)
+    K = kfu.view(-1, 128)[:N, :M].cpu().numpy()
+    got, ref = K[:, 0], np.exp(-0.5 * (x * x))
+    assert got[0] == 1.0
+    big = ref > 1e-300
+    rel = float(np.max(np.abs(got[big] - ref[big]) / ref[big]))
+    ulps = float(np.max(np.abs(got[big] - ref[big]) / np.spacing(ref[big])))
+    assert ulps <= 1.5 and rel < 2.5e-16, (ulps, rel)
+    assert np.all(np.abs(got[~big] - ref[~big]) <= 1e-300) and np.all(np.isfinite(got)) and np.all(got >= 0.0)
+    assert np.isnan(K[:, 1]).all()          # a NaN inducing input: NaN kernel values, never k = 0
+    if mode == 2:
+        kfu0 = engine.kfu_buffer(N, M)
+        p0 = engine.lib.sgp_set_contraction(0)
+        try:
+            engine.suffstats(X, y, Z, [1.0], 1.0, "rbf", kfu=kfu0)
+        finally:
+            engine.lib.sgp_set_contraction(p0)
+        a, b = kfu0.view(-1, 128)[:N, :1].cpu().numpy(), K[:, :1]
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
     """The multi-rank path on hardware, as far as a 1-GPU box allows: bench.py under torch.distributed.run with two
     ranks on cuda:0 (gloo carries the all-reduce of the packed statistics and of the gradients; RCCL refuses duplicate

@@ -147,7 +147,14 @@ def test_default_mode_phi_componentwise(engine, host_threads, ls):
         engine.lib.sgp_set_contraction(prev)
     Phi = packed[: M * M].view(M, M).cpu().numpy()
     host_threads()
-    ref = O.suffstats(X, y, Z, torch.full((D,), ls, dtype=torch.float64), 1.0, 0, chunk=65536).Phi.numpy()
+    # reference: the oracle's K_uf in fp64, products of 2048-row chunks in fp64 (a BLAS dot product of n positive terms is off by
+    # ~n eps / 100: 78 eps at 65 536-row chunks, measured), the chunks added in 80-bit arithmetic
+    acc = np.zeros((M, M), dtype=np.longdouble)
+    lst = torch.full((D,), ls, dtype=torch.float64)
+    for s0 in range(0, N_SWEEP, 2048):
+        K = O.kern(X[s0:s0 + 2048], Z, lst, 1.0)
+        acc += (K.T @ K).numpy()
+    ref = acc.astype(np.float64)
     dg = np.sqrt(np.diag(ref))
     err = np.abs(Phi - ref)
     c = float(np.max(err / (EPS * np.outer(dg, dg))))
