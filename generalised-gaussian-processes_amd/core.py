@@ -241,7 +241,8 @@ class CollapsedBound:
 
     def _trace_buf(self):
         if getattr(self, "_trace", None) is None:  # tr(Kuu^-1) + its scratch: one buffer per bound, reused by every evaluation
-            self._trace = self.engine.empty(self.engine.lib.sgp_kuu_inverse_trace_len())
+            e = self.engine
+            self._trace = e.empty(e.lib.sgp_kuu_inverse_trace_len() if hasattr(e, "lib") else 2)
         return self._trace
 
     def _guard_on(self):

@@ -106,7 +106,9 @@ __device__ __forceinline__ double kprofile_tab(double r2, const double* tab) {
     return (1.0 + a) * sgp_exp_tab(-a, tab);
   } else {
     const double a = 2.23606797749979 * sqrt(r2);
-    return (1.0 + a + a * a * (1.0 / 3.0)) * sgp_exp_tab(-a, tab);
+    // explicit fma: the two assembly kernels must write the same bits (test_int8_kept_block_equals_the_fp64_assembly), and the
+    // compiler's own contraction of 1 + a + a a / 3 came out differently in them
+    return fma(a * a, 1.0 / 3.0, 1.0 + a) * sgp_exp_tab(-a, tab);
   }
 }
 

@@ -222,3 +222,21 @@ class OracleEngine:
         from oracle import svgp_oracle as S
         mu, v = S.svgp_predict(Xs, Z, self._ls(ls, Z.shape[1]), float(sf2), m, LS, jitter, KID[kernel])
         return mu, v, torch.zeros(1, dtype=torch.int32)
+
+
+class GuardedOracleEngine(OracleEngine):
+    """OracleEngine + the three entry points of the streaming-order guard (include/sgp.h: sgp_kuu_inverse_trace,
+    sgp_streaming_error_estimate), so that CollapsedBound's estimate / repeat logic runs on the CPU -- also over gloo ranks."""
+
+    def kuu_inverse_trace(self, Linv, M, out=None):
+        t = torch.zeros(2, dtype=torch.float64) if out is None else out
+        t[0] = float((Linv[:M, :M] ** 2).sum()) if Linv.dim() == 2 else float((Linv.reshape(-1) ** 2).sum())
+        return t
+
+    def streaming_error_estimate(self, packed, trace, s2, N, M, result):
+        phi_max = float(torch.diagonal(packed[: M * M].reshape(M, M)).max())
+        result[0][OUT_LEN + 1] = 2.0 ** -53 * phi_max * float(trace[0]) / (float(s2) * max(1, int(N)))
+
+    @staticmethod
+    def read_estimate(host_buf):
+        return float(host_buf[OUT_LEN + 1])

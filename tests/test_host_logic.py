@@ -317,3 +317,88 @@ def test_device_sampler_run_length_guard():
     assert device_run_fits(500, 3000, 10) and device_run_fits(13279, 3000, 10)      # the reference's runs, Elevator included
     assert not device_run_fits(13279, 12000, 10) and device_run_fits(13279, 12000, 7)
     assert device_run_fits(500, 100000, 10) and not device_run_fits(500, 1000000, 10)
+
+
+# ---------------------------------------------------------------------------------------------
+# the streaming-order guard (core.CollapsedBound.streaming_tol) on the CPU double, one process and two gloo ranks
+# ---------------------------------------------------------------------------------------------
+def _guard_problem():
+    g = torch.Generator().manual_seed(4)
+    N, M, d = 600, 24, 3
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X[:, 0]) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[:M].clone()
+    return X, y, Z
+
+
+def test_streaming_guard_repeats_in_the_whitened_order_on_the_cpu_double():
+    """Host logic of round 4's guard: a streaming-order evaluation whose error estimate (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N)) exceeds
+    `streaming_tol` is repeated in the whitened order -- value, value + gradient and the predictive factors; a benign theta is not;
+    form="streaming" and streaming_tol = 0 never repeat."""
+    import ggp_amd as pkg
+    from fake_engine import GuardedOracleEngine
+    X, y, Z = _guard_problem()
+    old = pkg.CollapsedBound.WHITENED_MAX_WORK
+    pkg.CollapsedBound.WHITENED_MAX_WORK = 0   # form="auto" would take the whitened order for a problem this small
+    try:
+        eng = GuardedOracleEngine()
+        cb = pkg.CollapsedBound(X, y, jitter=1e-6, engine=eng)
+        F0, _ = cb.value(Z, [0.8] * 3, 1.0, 0.3)                       # benign: short lengthscale, moderate noise
+        assert cb.n_guard_reruns == 0 and cb.last_estimate < 1e-9 and eng.calls["suffstats_whitened"] == 0
+        hard = ([25.0] * 3, 1.0, 1e-5)                                  # K_uu at its jitter floor, tiny noise
+        F1, _ = cb.value(Z, *hard)
+        assert cb.n_guard_reruns == 1 and cb.last_estimate > 1e-9 and eng.calls["suffstats_whitened"] == 1
+        cw = pkg.CollapsedBound(X, y, jitter=1e-6, engine=GuardedOracleEngine(), form="whitened")
+        assert F1 == cw.value(Z, *hard)[0]                              # the repeat IS the whitened evaluation
+        F2, g2 = cb.value_and_grad(Z, *hard, want_gz=True)
+        Fw, gw = cw.value_and_grad(Z, *hard, want_gz=True)
+        assert cb.n_guard_reruns == 2 and F2 == Fw and torch.equal(g2["ls"], gw["ls"]) and torch.equal(g2["Z"], gw["Z"])
+        cb.factors(Z, *hard)
+        assert cb.n_guard_reruns == 3
+        cb.streaming_tol = 0.0
+        cb.value(Z, *hard, raise_on_fail=False)
+        cs = pkg.CollapsedBound(X, y, jitter=1e-6, engine=GuardedOracleEngine(), form="streaming")
+        cs.value(Z, *hard, raise_on_fail=False)
+        assert cb.n_guard_reruns == 3 and cs.n_guard_reruns == 0
+    finally:
+        pkg.CollapsedBound.WHITENED_MAX_WORK = old
+
+
+def _guard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ggp_amd as pkg
+    from fake_engine import GuardedOracleEngine
+    X, y, Z = _guard_problem()
+    pkg.CollapsedBound.WHITENED_MAX_WORK = 0
+    lo, hi = pkg.shard_rows(X.shape[0], rank, world)
+    cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=1e-6, engine=GuardedOracleEngine())
+    out = []
+    for ls, s2 in ((0.8, 0.3), (25.0, 1e-5), (3.0, 1e-3), (25.0, 1e-5)):
+        F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
+        out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns, cb.last_estimate, cb.n_collectives))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_guard_decisions_are_identical_on_every_rank():
+    """The estimate is a function of the replicated tail and the all-reduced statistics: both ranks must compute the same bits, repeat
+    the same evaluations (a rank deciding alone would wait in its all-reduce for ever) and issue the same number of collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = outs[0][1], outs[1][1]
+    assert a == b                                        # F, gradients, repeat counts, estimates, collective counts: bit for bit
+    assert [t[2] for t in a][0] == 0 and a[1][2] >= 1 and a[3][2] > a[1][2] - 1 and a[-1][2] >= 2
