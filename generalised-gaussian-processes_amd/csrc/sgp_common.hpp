@@ -81,6 +81,7 @@ __device__ __forceinline__ void sgp_exp_tab_load(double* tab) {
   if (threadIdx.x < EXP_TAB_N) tab[threadIdx.x] = SGP_EXP2_TAB[threadIdx.x];
 }
 __device__ __forceinline__ double sgp_exp_tab(double x, const double* tab) {
+#pragma clang fp contract(off)
   x = (x < -800.0) ? -800.0 : x;
   const double t = fma(x, 0x1.71547652b82fep+5, 0x1.8p52);  // 32 / ln2
   const int n = (int)__double_as_longlong(t);               // the low 32 bits: n as two's complement
@@ -97,18 +98,22 @@ __device__ __forceinline__ double sgp_exp_tab(double x, const double* tab) {
   q *= r;
   return ldexp(fma(T, q, T), n >> 5);
 }
+// The two assembly kernels must write the same bits (test_int8_kept_block_equals_the_fp64_assembly).  The compiler's own contraction of
+// the Matern prefactors came out differently in them (1 + a as fma(sqrt(r2), c, 1) in one, as an add of the rounded a in the other):
+// no implicit contraction here, the fused operations are written out.
 template <int KID>
 __device__ __forceinline__ double kprofile_tab(double r2, const double* tab) {
+#pragma clang fp contract(off)
   if constexpr (KID == SGP_KERNEL_RBF) {
     return sgp_exp_tab(-0.5 * r2, tab);
   } else if constexpr (KID == SGP_KERNEL_MATERN32) {
     const double a = 1.7320508075688772 * sqrt(r2);
-    return (1.0 + a) * sgp_exp_tab(-a, tab);
+    const double p = 1.0 + a;
+    return p * sgp_exp_tab(-a, tab);
   } else {
     const double a = 2.23606797749979 * sqrt(r2);
-    // explicit fma: the two assembly kernels must write the same bits (test_int8_kept_block_equals_the_fp64_assembly), and the
-    // compiler's own contraction of 1 + a + a a / 3 came out differently in them
-    return fma(a * a, 1.0 / 3.0, 1.0 + a) * sgp_exp_tab(-a, tab);
+    const double a2 = a * a, p1 = 1.0 + a;
+    return fma(a2, 1.0 / 3.0, p1) * sgp_exp_tab(-a, tab);
   }
 }
 

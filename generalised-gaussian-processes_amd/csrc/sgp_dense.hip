@@ -392,13 +392,13 @@ int available_cus() {
 }
 
 void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
-                 const double* rhs, double* sol, bool caller_managed) {
+                 const double* rhs, double* sol, bool caller_managed, int prepped) {
   const int nb = Mp / DB;
   const int ntile = nb * (nb + 1) / 2;
   const int nitem = ntile + (rhs ? 1 : 0);
   const int max_wg = df_max_workgroups();
-  if (!caller_managed) zero_ints(scratch, (int)potrf_flag_ints(Mp), st);
-  if (Linv) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
+  if (!caller_managed && !(prepped & 1)) zero_ints(scratch, (int)potrf_flag_ints(Mp), st);
+  if (Linv && !(prepped & 2)) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
   potrf_dataflow_kernel<<<nitem < max_wg ? nitem : max_wg, 256, 0, st>>>(
       A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv);

@@ -135,13 +135,14 @@ __global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __res
 enum { SC_TRW = 0, SC_LOGDET = 1, SC_QQ = 2, SC_TRSP = 3, SC_BA = 4, SC_APA = 5, SC_N = 8 };
 
 __global__ __launch_bounds__(256) void make_B_kernel(const double* __restrict__ W, int Mp, double inv_s2, double* __restrict__ Bm,
-                                                     double* __restrict__ trW) {
+                                                     double* __restrict__ trW, double* __restrict__ zero_me) {
   const int64_t total = (int64_t)Mp * Mp;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
     // symmetrise: the two triangles of L^-1 Phi L^-T differ by rounding only
     const double w = 0.5 * (W[e] + W[(int64_t)c * Mp + r]);
     Bm[e] = (r == c ? 1.0 : 0.0) + w * inv_s2;
+    if (zero_me) zero_me[e] = 0.0;  // the buffer L_B^-1 grows in (potrf_lower's own clearing launch, folded in)
   }
   if (blockIdx.x == gridDim.x - 1) {  // tr W rides along (was a launch of its own)
     __shared__ double red[4];
@@ -616,14 +617,11 @@ double sgp::cond_gate_limit() { return cur_ctx().cond_limit; }
 // Every partial is written by exactly one thread and summed in a fixed order: the same bits on every rank.  (The first version walked
 // whole columns per thread and whole matrices per workgroup: 88 + 57 + 312 us at M = 1024, rocprofv3 -- on the K_uu chain, which IS
 // the critical path at C3; these take ~5 us each.)
-__global__ __launch_bounds__(256) void cond_coltile_kernel(const double* __restrict__ L, int64_t ld, int64_t stride, int M, int64_t sstride,
-                                                           double* __restrict__ scratch) {
-  const int bc = blockIdx.x, br = blockIdx.y;
-  if (br < bc) return;
-  __shared__ double a2[4][64], a1[4][64];
+// column partials of L for tile (br, bc), br >= bc
+__device__ __forceinline__ void cond_coltile_body(const double* __restrict__ Ls, int64_t ld, int M, int bc, int br, int nb,
+                                                  double* __restrict__ sc, double (*a2)[64], double (*a1)[64]) {
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6, j = bc * 64 + c;
-  const int nb = gridDim.x, Mc = nb * 64;
-  const double* Ls = L + (int64_t)blockIdx.z * stride;
+  const int Mc = nb * 64;
   double s2 = 0.0, s1 = 0.0;
 #pragma unroll 4
   for (int k = 0; k < 16; ++k) {
@@ -634,21 +632,39 @@ __global__ __launch_bounds__(256) void cond_coltile_kernel(const double* __restr
   a1[r][c] = s1;
   __syncthreads();
   if (r == 0) {
-    double* sc = scratch + (int64_t)blockIdx.z * sstride;
     sc[(int64_t)br * Mc + j] = (a2[0][c] + a2[1][c]) + (a2[2][c] + a2[3][c]);
     sc[(int64_t)(nb + br) * Mc + j] = (a1[0][c] + a1[1][c]) + (a1[2][c] + a1[3][c]);
   }
 }
-// one wave per row of the lower-triangular Li: out[i] = sum_{j <= i} Li[i][j]^2
-__global__ __launch_bounds__(256) void tri_rowsq_kernel(const double* __restrict__ Li, int64_t ld, int64_t stride, int M, int64_t ostride,
-                                                        double* __restrict__ out) {
-  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+// one wave per row of the lower-triangular Li: out[i] = sum_{j <= i} Li[i][j]^2   (block = 4 rows)
+__device__ __forceinline__ void tri_rowsq_body(const double* __restrict__ Li, int64_t ld, int M, int blk, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, i = blk * 4 + (threadIdx.x >> 6);
   if (i >= M) return;
-  const double* row = Li + (int64_t)blockIdx.y * stride + (int64_t)i * ld;
+  const double* row = Li + (int64_t)i * ld;
   double s = 0.0;
   for (int j = lane; j <= i; j += 64) { const double v = row[j]; s = fma(v, v, s); }
   s = wave_sum(s);
-  if (lane == 0) out[(int64_t)blockIdx.y * ostride + i] = s;
+  if (lane == 0) out[i] = s;
+}
+// ONE launch for both halves of the estimate's inputs: blocks [0, nb (nb + 1) / 2) take the lower-triangle tiles of L, the rest four
+// rows of L^-1 each; blockIdx.y = matrix
+__global__ __launch_bounds__(256) void cond_stats_kernel(const double* __restrict__ L, const double* __restrict__ Linv, int64_t ld,
+                                                         int64_t stride, int M, int nb, int64_t sstride, double* __restrict__ scratch) {
+  __shared__ double a2[4][64], a1[4][64];
+  const int ntile = nb * (nb + 1) / 2;
+  double* sc = scratch + (int64_t)blockIdx.y * sstride;
+  if ((int)blockIdx.x < ntile) {
+    int br = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while ((br + 1) * (br + 2) / 2 <= (int)blockIdx.x) ++br;
+    while (br * (br + 1) / 2 > (int)blockIdx.x) --br;
+    const int bc = blockIdx.x - br * (br + 1) / 2;
+    cond_coltile_body(L + (int64_t)blockIdx.y * stride, ld, M, bc, br, nb, sc, a2, a1);
+  } else {
+    tri_rowsq_body(Linv + (int64_t)blockIdx.y * stride, ld, M, blockIdx.x - ntile, sc + (int64_t)2 * nb * nb * 64);
+  }
+}
+__global__ __launch_bounds__(256) void tri_rowsq_kernel(const double* __restrict__ Li, int64_t ld, int M, double* __restrict__ out) {
+  tri_rowsq_body(Li, ld, M, blockIdx.x, out);
 }
 size_t sgp::cond_scratch_doubles(int M) {
   const size_t nb = (size_t)(M + 63) / 64, Mc = nb * 64;
@@ -657,8 +673,7 @@ size_t sgp::cond_scratch_doubles(int M) {
 void sgp::cond_stats(const double* L, const double* Linv, int64_t ld, int64_t stride, int M, int S, double* scratch, hipStream_t st) {
   const int nb = (M + 63) / 64;
   const int64_t ss = (int64_t)cond_scratch_doubles(M);
-  cond_coltile_kernel<<<dim3(nb, nb, S), 256, 0, st>>>(L, ld, stride, M, ss, scratch);
-  tri_rowsq_kernel<<<dim3((M + 3) / 4, S), 256, 0, st>>>(Linv, ld, stride, M, ss, scratch + (size_t)2 * nb * nb * 64);
+  cond_stats_kernel<<<dim3(nb * (nb + 1) / 2 + (M + 3) / 4, S), 256, 0, st>>>(L, Linv, ld, stride, M, nb, ss, scratch);
 }
 // est = lambda_max estimate (columns of L) x 1 / lambda_min estimate (rows of L^-1) > limit  ->  info = that row + 1.  One workgroup per
 // matrix (blockIdx.x = sample); `info` is only written while it is still 0.
@@ -675,6 +690,18 @@ void sgp::cond_gate(const double* scratch, int M, int S, double limit, int* info
   cond_gate_kernel<<<S, 256, 0, st>>>(scratch, (int64_t)cond_scratch_doubles(M), M, limit, info);
 }
 
+__global__ __launch_bounds__(256) void kuu_factor_prep_kernel(const double* __restrict__ K, int M, int Mp, double* __restrict__ L,
+                                                              double* __restrict__ Linv, int* __restrict__ flags, int nflags,
+                                                              int* __restrict__ info) {
+  const int64_t total = (int64_t)Mp * Mp, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  for (int64_t e = e0; e < total; e += stride) {
+    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+    L[e] = (r < M && c < M) ? K[(int64_t)r * M + c] : (r == c ? 1.0 : 0.0);
+    Linv[e] = 0.0;
+  }
+  for (int64_t e = e0; e < nflags; e += stride) flags[e] = 0;
+  if (e0 == 0) *info = 0;
+}
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
 // caller can run it on a second stream underneath pass 1.
 extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
@@ -688,9 +715,9 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   double* L = c.take<double>((size_t)Mp * Mp);
   double* tmp = c.take<double>((size_t)Mp * Mp);
   int* flags = c.take<int>(potrf_scratch_ints(Mp));
-  zero_ints(info, 1, st);
-  pad_copy(Kuu, M, M, M, L, Mp, Mp, Mp, 1.0, st);
-  potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st);
+  // one launch instead of four: L <- K_uu identity-padded, L^-1's buffer <- 0, the factorization's flags <- 0, status word <- 0
+  kuu_factor_prep_kernel<<<grid_for((int64_t)Mp * Mp), 256, 0, st>>>(Kuu, M, Mp, L, Linv_out, flags, (int)potrf_flag_ints(Mp), info);
+  potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st, nullptr, nullptr, false, /*prepped=*/3);
   tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
   if (cond_gate_limit() > 0.0) {  // `tmp` is free again: the partials of L's columns and of L^-1's rows live at its start
     cond_stats(L, Linv_out, Mp, 0, M, 1, tmp, st);
@@ -721,7 +748,7 @@ extern "C" int sgp_kuu_inverse_trace(const double* kuu_linv, int M, double* trac
   if (!kuu_linv || !trace_out || M <= 0) return SGP_ERR_ARG;
   if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   hipStream_t st = (hipStream_t)stream;
-  tri_rowsq_kernel<<<dim3((M + 3) / 4, 1), 256, 0, st>>>(kuu_linv, padded_m(M), 0, M, 0, trace_out + 1);
+  tri_rowsq_kernel<<<(M + 3) / 4, 256, 0, st>>>(kuu_linv, padded_m(M), M, trace_out + 1);
   ordered_sum_kernel<<<1, 256, 0, st>>>(trace_out + 1, M, trace_out);
   return check_launch();
 }
@@ -802,8 +829,8 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
   }
 
   // B = I + W/s2 in M6 -> LB ; q = LB^-1 u rides along with the factorization; LB^-1 (M7) only when G is wanted
-  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW);
-  potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flagsB, st, w.u, w.q, /*caller_managed=*/true);
+  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW, need_G ? w.M7 : nullptr);
+  potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flagsB, st, w.u, w.q, /*caller_managed=*/true, /*prepped=*/2);
   const int* abort_flag = potrf_abort_flag(w.flagsB, Mp);
   if (need_G) {
     post_potrf_kernel<<<1, 256, 0, st>>>(w.M6, w.q, Mp, abort_flag, info, w.sc);
