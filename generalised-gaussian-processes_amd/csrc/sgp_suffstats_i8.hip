@@ -32,6 +32,7 @@
 #include "sgp_stream.hpp"
 #include "sgp_ctx.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace sgp {
 
@@ -79,6 +80,15 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 
   constexpr unsigned long long C = 0x0080808080808080ULL;
   double bacc = 0.0;
+  // interior blocks (every row < N, every column < M: all but the last row block and the padding columns) skip the mask -- the
+  // kernel is VALU-bound, and the compare + select + multiply per element are 3 of its ~48 lane-operations
+#ifdef SGP_AB_DIGITS_NO_INTERIOR  // A/B (tools/ab_build.sh): one masked loop for every block
+  const bool interior = false;
+#else
+  const bool interior = (row0 + rbase + ASM_ROWS <= N) && ((int)(blockIdx.y * 256 + 255) < M);
+#endif
+  auto run = [&](auto masked_tag) {
+  constexpr bool MASKED = decltype(masked_tag)::value;
   for (int g = 0; g < ASM_ROWS / 16; ++g) {
     unsigned lo[16], hi[16];
 #pragma unroll
@@ -91,8 +101,8 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
         const double df = xs[i][j] - zr[j];
         r2 = fma(df, df, r2);
       }
-      const double msk = n < N ? zmask : 0.0;
-      const double kv = kprofile_tab<KID>(r2, etab) * msk;
+      double kv = kprofile_tab<KID>(r2, etab);
+      if constexpr (MASKED) kv *= (n < N ? zmask : 0.0);
       bacc = fma(kv, ysh[i], bacc);
       if constexpr (WK) __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);
       // q = rint(kv 2^54) without a 64-bit convert: hi = rint(kv 2^22) and the SIGNED remainder r = rint(kv 2^54 - hi 2^32) in
@@ -130,6 +140,8 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
     for (int p = 0; p < I8_NP; ++p)
       __builtin_nontemporal_store(plane[p], reinterpret_cast<i4v*>(Q + ((rb * I8_NP + p) * Mp + m) * 16));
   }
+  };
+  if (interior) run(std::false_type{}); else run(std::true_type{});
   bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bacc;
 }
 
