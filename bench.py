@@ -444,9 +444,11 @@ def main():
         res["config"]["contraction"] = "fp64 matrix cores"
     res["config"]["streaming_guard"] = {
         "tolerance_per_datum": cb.streaming_tol, "estimate_per_datum": cb.last_estimate, "repeats_in_whitened_order": cb.n_guard_reruns,
+        "direct_whitened_evaluations": cb.n_direct_whitened,
         "note": "first-order estimate of |dF| / N of the streaming order (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N), include/sgp.h: "
                 "sgp_streaming_error_estimate), read back with every evaluation; above the tolerance the evaluation is repeated in the "
-                "whitened (PyMC3) order -- 0 repeats = every timed step ran the streaming design"}
+                "whitened (PyMC3) order, and so are the evaluations that follow it until the predicted estimate is below half the tolerance "
+                "-- 0 and 0 = every timed step ran the streaming design"}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

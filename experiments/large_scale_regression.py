@@ -50,7 +50,8 @@ def main():
         "Synthetic_N%d_d%d" % (args.n, args.dim), "SGPR", float(rmse(pred.loc, yte, ystd)), nlpd_marginal(pred, yte, ystd), wall,
         num_inducing=args.num_inducing, max_iter=args.max_iters, train_test_split=args.n / float(args.n + n_test),
         N=args.n, d=args.dim, secs_per_step=wall / max(1, args.max_iters), loss_first=losses[0], loss_last=losses[-1],
-        nlpd_kind="marginal (utils/metrics.py:49-58; the joint form needs a 10 000 x 10 000 covariance)")
+        nlpd_kind="marginal (utils/metrics.py:49-58; the joint form needs a 10 000 x 10 000 covariance)",
+        guard_repeats=int(model._bound().n_guard_reruns))
     if args.hmc_samples > 0:
         hmc = BayesianSparseGPR_HMC(Xtr, ytr, GaussianLikelihood(), model.inducing_points.cpu(), jitter=1e-6, seed=1)
         t0 = time.time()
@@ -60,7 +61,10 @@ def main():
         out["perf_times"] = [float(v) for v in perf]
         out["hmc"] = {"draws": len(trace), "tune": args.hmc_tune, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
                       "leapfrogs_per_sec": trace.n_leapfrog / wall, "step_size": float(steps[0]),
-                      "sig_n_mean": float(trace["sig_n"].mean()), "ls_mean": trace["ls"].mean(0).tolist()}
+                      "sig_n_mean": float(trace["sig_n"].mean()), "ls_mean": trace["ls"].mean(0).tolist(),
+                      # leapfrogs the streaming-order guard sent to the whitened (PyMC3) order
+                      "guard_repeats": int(hmc._hmc_bound().n_guard_reruns), "direct_whitened": int(hmc._hmc_bound().n_direct_whitened), "guard_tolerance_per_datum": hmc._hmc_bound().streaming_tol,
+                      "guard_last_estimate_per_datum": hmc._hmc_bound().last_estimate, "evaluations": int(hmc._hmc_bound().n_evals)}
     print(json.dumps(out))
 
 

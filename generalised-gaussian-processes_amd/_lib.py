@@ -88,6 +88,7 @@ PROTOTYPES = {
     "sgp_kuu_inverse_trace_len": (_sz, []),
     "sgp_kuu_inverse_trace": (_i32, [_vp, _i32, _vp, _vp]),
     "sgp_streaming_error_estimate": (_i32, [_vp, _vp, _dbl, _i64, _i32, _vp, _vp]),
+    "sgp_streaming_error_bound": (_i32, [_vp, _dbl, _dbl, _vp, _vp]),
     "sgp_kuu_factor_len": (_sz, [_i32]),
     "sgp_kuu_factor_workspace_bytes": (_sz, [_i32]),
     "sgp_kuu_factor": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -149,6 +149,14 @@ class CollapsedBound:
         self.streaming_tol = 1e-9
         self.n_guard_reruns = 0
         self.last_estimate = None
+        # ... and once it has tripped the following evaluations go to the whitened order directly (a sampler that sits in such a
+        # region would otherwise pay a wasted streaming attempt per leapfrog: 86 % of the leapfrogs of NUTS at C5's trained Z,
+        # profiles/r04_experiment_large_scale*.json).  The whitened order reports the estimate's upper bound (max Phi_ii <= N sf2^2);
+        # times the ratio estimate / bound seen where the guard tripped it predicts the streaming estimate, and the streaming order
+        # is tried again once that prediction is below half the tolerance.  Same inputs on every rank, same decision.
+        self.n_direct_whitened = 0
+        self._prefer_whitened = False
+        self._est_ratio = 1.0
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -255,7 +263,30 @@ class CollapsedBound:
         est = self.engine.read_estimate(host)
         res["estimate"] = est
         self.last_estimate = est
-        return not (est <= self.streaming_tol)  # NaN trips too
+        trips = not (est <= self.streaming_tol)  # NaN trips too
+        if trips:
+            self._prefer_whitened = True
+            self._tripped_estimate = est
+        return trips
+
+    def _start_whitened(self, M):
+        """True when this evaluation should skip the streaming attempt (the guard tripped recently and nothing says it would pass)."""
+        return self._prefer_whitened and self._guard_on() and not self._whitened(M)
+
+    def _note_whitened(self, res, host):
+        """After a whitened-order evaluation that carries the estimate's upper bound: learn the ratio at the theta where the guard
+        tripped, or -- on later evaluations -- decide whether the streaming order is worth another try."""
+        if not res.get("bounded"):
+            return
+        ub = self.engine.read_estimate(host)
+        if not (ub > 0.0) or not math.isfinite(ub):
+            return
+        tripped = getattr(self, "_tripped_estimate", None)
+        if tripped is not None:  # the repeat right behind the trip: same theta, so estimate / bound is exact here
+            self._est_ratio = min(1.0, tripped / ub) if math.isfinite(tripped) else 1.0
+            self._tripped_estimate = None
+        elif self._est_ratio * ub < 0.5 * self.streaming_tol:
+            self._prefer_whitened = False
 
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=False):
         e = self.engine
@@ -271,6 +302,9 @@ class CollapsedBound:
             kw = {"want_cw": True} if factored else {}
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True, **kw)
+            if force_whitened and self._guard_on() and hasattr(e, "streaming_error_bound") and self.kernel != "composite":
+                e.streaming_error_bound(e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf()), sf2, s2, result)
+                res["bounded"] = True
             res["packed"] = packed
             res["kfu"] = None
             res["linv"] = linv
@@ -376,12 +410,16 @@ class CollapsedBound:
                     raise NotPositiveDefiniteError(info)
                 return float("nan"), {"info": info}
             return float(h[0]), {"logmarg": float(h[nh + 2]), "trace_term": float(h[nh + 3]), "info": 0}
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=False)
+        direct = self._start_whitened(Z.shape[0])
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=direct)
         o, info, host = self._fetch(res)
-        if self._guard_trips(res, host):  # the streaming order is not trustworthy at this theta: PyMC3's order instead
+        if direct:
+            self.n_direct_whitened += 1
+        elif self._guard_trips(res, host):  # the streaming order is not trustworthy at this theta: PyMC3's order instead
             self.n_guard_reruns += 1
             res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=True)
             o, info, host = self._fetch(res)
+        self._note_whitened(res, host)
         self.n_evals += 1
         if info != 0:
             if raise_on_fail:
@@ -426,6 +464,10 @@ class CollapsedBound:
             return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
                                  "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
+        direct = not _force_whitened and self._start_whitened(M)
+        if direct:
+            self.n_direct_whitened += 1
+            _force_whitened = True
         res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0),
                             force_whitened=_force_whitened)
         head = res["out"].numel() + 2  # [out | status word | pad], then the packed gradient (16-byte aligned)
@@ -459,6 +501,7 @@ class CollapsedBound:
         if not early and self._guard_trips(res, host):
             self.n_guard_reruns += 1
             return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=True)
+        self._note_whitened(res, host)
         self.n_evals += 1
         self.n_grads += 1
         if info != 0:
@@ -474,12 +517,16 @@ class CollapsedBound:
     def factors(self, Z, ls, sf2, s2):
         """Device tensor [Linv | G | q] for ``predict`` (computed from the current statistics)."""
         Z = self._prep_Z(Z)
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True)
+        direct = self._start_whitened(Z.shape[0])
+        res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=direct)
         _, info, host = self._fetch(res)
-        if self._guard_trips(res, host):
+        if direct:
+            self.n_direct_whitened += 1
+        elif self._guard_trips(res, host):
             self.n_guard_reruns += 1
             res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=True)
-            _, info, _ = self._fetch(res)
+            _, info, host = self._fetch(res)
+        self._note_whitened(res, host)
         if info != 0:
             raise NotPositiveDefiniteError(info)
         return res["factors"]

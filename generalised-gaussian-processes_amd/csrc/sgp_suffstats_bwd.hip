@@ -612,6 +612,7 @@ extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const do
     GemmDesc g1;  // T1 = K'_fu L^-T   (kuu_linv is Mp x Mp: its padding rows hold an identity block that K'_fu's zero columns never meet)
     g1.A = w.Kfu; g1.lda = p.Mp; g1.B = kuu_linv; g1.ldb = p.Mp; g1.tb = true; g1.C = T1; g1.ldc = p.Mp;
     g1.m = (int)p.Npad; g1.n = p.Mp; g1.k = p.Mp;
+    g1.khi_mask = 2;  // L^-T is upper triangular: column block c needs k < its end only -- half the product (round 4)
     gemm(g1, st);
     GemmDesc g2;  // T2 = T1 (Cw / s2)
     g2.A = T1; g2.lda = p.Mp; g2.B = P2; g2.ldb = p.Mp; g2.C = T2; g2.ldc = p.Mp;

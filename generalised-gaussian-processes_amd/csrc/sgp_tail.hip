@@ -771,6 +771,17 @@ extern "C" int sgp_streaming_error_estimate(const double* stats, const double* t
   return check_launch();
 }
 
+// the same estimate with max_i Phi_ii replaced by its upper bound N sf2^2 (a kernel profile is <= 1): what a caller that is NOT
+// running the streaming order can still compute, to decide when to try it again
+__global__ void streaming_bound_kernel(const double* __restrict__ tr, double sf2, double s2, double* __restrict__ est) {
+  est[0] = 0x1p-53 * sf2 * sf2 * tr[0] / s2;
+}
+extern "C" int sgp_streaming_error_bound(const double* trace_inv, double sf2, double s2, double* est, sgp_stream_t stream) {
+  if (!trace_inv || !est || !(s2 > 0.0) || !(sf2 > 0.0)) return SGP_ERR_ARG;
+  streaming_bound_kernel<<<1, 1, 0, (hipStream_t)stream>>>(trace_inv, sf2, s2, est);
+  return check_launch();
+}
+
 extern "C" void sgp_set_cond_limit(double limit) { default_ctx().cond_limit = limit >= 0.0 ? limit : 1e13; }  // deprecated shim
 
 // whitened: Phi / b already are W = A A^T and u = A y with A = L^-1 K_uf (sgp_suffstats_fwd_whitened); kuu_linv required

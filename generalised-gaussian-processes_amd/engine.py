@@ -241,6 +241,12 @@ class HipEngine:
         _lib.check("sgp_streaming_error_estimate",
                    self.lib.sgp_streaming_error_estimate(self._ptr(packed), self._ptr(trace), float(s2), int(N), int(M), est, self._stream()))
 
+    def streaming_error_bound(self, trace, sf2, s2, result) -> None:
+        """The estimate's upper bound (max Phi_ii <= N sf2^2) into the pad word of ``result``: what a whitened-order evaluation can
+        still report (include/sgp.h: sgp_streaming_error_bound)."""
+        est = C.c_void_p(result[0].data_ptr() + 8 * (OUT_LEN + 1))
+        _lib.check("sgp_streaming_error_bound", self.lib.sgp_streaming_error_bound(self._ptr(trace), float(sf2), float(s2), est, self._stream()))
+
     @staticmethod
     def read_estimate(host_buf) -> float:
         return float(host_buf[OUT_LEN + 1])

@@ -282,6 +282,10 @@ size_t sgp_kuu_inverse_trace_len(void);
 int sgp_kuu_inverse_trace(const double* kuu_linv, int M, double* trace_out, sgp_stream_t stream);
 int sgp_streaming_error_estimate(const double* stats, const double* trace_inv, double s2, int64_t N, int M, double* est,
                                  sgp_stream_t stream);
+/* est[0] = 2^-53 sf2^2 tr(K_uu^-1) / s2: the same estimate with max_i Phi_ii at its upper bound N sf2^2 (a stationary profile is
+ * <= 1) -- for a caller that is evaluating in the WHITENED order and wants to know when the streaming order is worth trying again
+ * (core.py multiplies it by the ratio estimate / bound it saw at the theta where the guard tripped). */
+int sgp_streaming_error_bound(const double* trace_inv, double sf2, double s2, double* est, sgp_stream_t stream);
 size_t sgp_kuu_factor_len(int M);
 size_t sgp_kuu_factor_workspace_bytes(int M);
 int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info,

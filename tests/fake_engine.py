@@ -237,6 +237,9 @@ class GuardedOracleEngine(OracleEngine):
         phi_max = float(torch.diagonal(packed[: M * M].reshape(M, M)).max())
         result[0][OUT_LEN + 1] = 2.0 ** -53 * phi_max * float(trace[0]) / (float(s2) * max(1, int(N)))
 
+    def streaming_error_bound(self, trace, sf2, s2, result):
+        result[0][OUT_LEN + 1] = 2.0 ** -53 * float(sf2) ** 2 * float(trace[0]) / float(s2)
+
     @staticmethod
     def read_estimate(host_buf):
         return float(host_buf[OUT_LEN + 1])

@@ -811,6 +811,7 @@ def test_two_ranks_share_the_gpu_real_engine_matches_one_rank():
     h2 = json.loads([ln for ln in two_h.stdout.strip().splitlines() if ln.startswith("{")][-1])
     g1, g2 = h1["config"]["streaming_guard"], h2["config"]["streaming_guard"]
     assert g1["repeats_in_whitened_order"] > 0 and g2["repeats_in_whitened_order"] > 0, (g1, g2)
+    assert g1["direct_whitened_evaluations"] == g2["direct_whitened_evaluations"] > 0        # the episode continues without streaming attempts
     assert g1["estimate_per_datum"] > g1["tolerance_per_datum"] and g2["estimate_per_datum"] > g2["tolerance_per_datum"]
     assert abs(h2["F"] - h1["F"]) < 1e-9 * abs(h1["F"]), (h1["F"], h2["F"])
     assert r1["config"]["streaming_guard"]["repeats_in_whitened_order"] == 0      # the benchmark's own theta never repeats

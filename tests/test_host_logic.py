@@ -333,8 +333,10 @@ def _guard_problem():
 
 def test_streaming_guard_repeats_in_the_whitened_order_on_the_cpu_double():
     """Host logic of round 4's guard: a streaming-order evaluation whose error estimate (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N)) exceeds
-    `streaming_tol` is repeated in the whitened order -- value, value + gradient and the predictive factors; a benign theta is not;
-    form="streaming" and streaming_tol = 0 never repeat."""
+    `streaming_tol` is repeated in the whitened order -- value, value + gradient and the predictive factors; the evaluations that
+    follow go to the whitened order directly (no wasted streaming attempt) until the predicted estimate (the whitened order's upper
+    bound x the ratio seen at the trip) falls below half the tolerance; a benign theta is streamed; form="streaming" and
+    streaming_tol = 0 never repeat."""
     import ggp_amd as pkg
     from fake_engine import GuardedOracleEngine
     X, y, Z = _guard_problem()
@@ -348,18 +350,27 @@ def test_streaming_guard_repeats_in_the_whitened_order_on_the_cpu_double():
         hard = ([25.0] * 3, 1.0, 1e-5)                                  # K_uu at its jitter floor, tiny noise
         F1, _ = cb.value(Z, *hard)
         assert cb.n_guard_reruns == 1 and cb.last_estimate > 1e-9 and eng.calls["suffstats_whitened"] == 1
+        assert cb._prefer_whitened and 0.0 < cb._est_ratio <= 1.0
         cw = pkg.CollapsedBound(X, y, jitter=1e-6, engine=GuardedOracleEngine(), form="whitened")
         assert F1 == cw.value(Z, *hard)[0]                              # the repeat IS the whitened evaluation
-        F2, g2 = cb.value_and_grad(Z, *hard, want_gz=True)
+        n_stream = eng.calls["suffstats"]
+        F2, g2 = cb.value_and_grad(Z, *hard, want_gz=True)              # straight to the whitened order: no streaming attempt
         Fw, gw = cw.value_and_grad(Z, *hard, want_gz=True)
-        assert cb.n_guard_reruns == 2 and F2 == Fw and torch.equal(g2["ls"], gw["ls"]) and torch.equal(g2["Z"], gw["Z"])
+        assert cb.n_guard_reruns == 1 and cb.n_direct_whitened == 1 and eng.calls["suffstats"] == n_stream
+        assert F2 == Fw and torch.equal(g2["ls"], gw["ls"]) and torch.equal(g2["Z"], gw["Z"])
         cb.factors(Z, *hard)
-        assert cb.n_guard_reruns == 3
+        assert cb.n_direct_whitened == 2 and cb._prefer_whitened
+        Fb, _ = cb.value(Z, [0.8] * 3, 1.0, 0.3)                       # benign again: still whitened (it cannot know yet) ...
+        assert cb.n_direct_whitened == 3 and not cb._prefer_whitened     # ... but the bound it reports ends the episode
+        assert abs(Fb - F0) < 1e-9 * abs(F0)
+        Fc, _ = cb.value(Z, [0.8] * 3, 1.0, 0.3)
+        assert Fc == F0 and cb.n_direct_whitened == 3 and cb.n_guard_reruns == 1   # streamed again, bit for bit as before
+        cb._prefer_whitened = True
         cb.streaming_tol = 0.0
         cb.value(Z, *hard, raise_on_fail=False)
         cs = pkg.CollapsedBound(X, y, jitter=1e-6, engine=GuardedOracleEngine(), form="streaming")
         cs.value(Z, *hard, raise_on_fail=False)
-        assert cb.n_guard_reruns == 3 and cs.n_guard_reruns == 0
+        assert cb.n_guard_reruns == 1 and cb.n_direct_whitened == 3 and cs.n_guard_reruns == 0
     finally:
         pkg.CollapsedBound.WHITENED_MAX_WORK = old
 
@@ -380,7 +391,8 @@ def _guard_worker(rank, world, port, q):
     out = []
     for ls, s2 in ((0.8, 0.3), (25.0, 1e-5), (3.0, 1e-3), (25.0, 1e-5)):
         F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
-        out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns, cb.last_estimate, cb.n_collectives))
+        out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns + cb.n_direct_whitened, cb.last_estimate, cb.n_collectives,
+                    cb._prefer_whitened, cb._est_ratio))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -400,5 +412,5 @@ def test_two_rank_gloo_guard_decisions_are_identical_on_every_rank():
         p.join(60)
         assert p.exitcode == 0
     a, b = outs[0][1], outs[1][1]
-    assert a == b                                        # F, gradients, repeat counts, estimates, collective counts: bit for bit
-    assert [t[2] for t in a][0] == 0 and a[1][2] >= 1 and a[3][2] > a[1][2] - 1 and a[-1][2] >= 2
+    assert a == b                                        # F, gradients, whitened counts, estimates, ratios, collective counts: bit for bit
+    assert a[0][2] == 0 and a[1][2] == 1 and a[-1][2] >= 2
