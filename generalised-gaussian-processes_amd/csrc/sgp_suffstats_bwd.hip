@@ -24,6 +24,7 @@
 #include "sgp_stream.hpp"
 #include "sgp_composite.hpp"
 #include "sgp_dense.hpp"
+#include <cstdlib>
 
 namespace sgp {
 
@@ -564,7 +565,7 @@ static size_t bwd_factored_workspace_bytes(int64_t N, int M, int d) {
   StreamPlan p = make_stream_plan(N, M, d);
   p.sc_rows = p.Npad;
   const size_t fast = carve_bwd(nullptr, p, true).bytes + 2 * round_up64((int64_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp * 8 + 256, 256) +
-                      round_up64((int64_t)p.Mp * p.Mp * 8 + 256, 256);
+                      2 * round_up64((int64_t)p.Mp * p.Mp * 8 + 256, 256);
   const size_t comp = d <= COMP_MAX_DIM ? comp_bwd_factored_workspace_bytes(N, M, d) : 0;
   return fast > comp ? fast : comp;
 }
@@ -596,14 +597,26 @@ extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const do
   double* T1 = c.take<double>(rows * p.Mp);
   double* T2 = c.take<double>(rows * p.Mp);
   double* P2 = c.take<double>((size_t)p.Mp * p.Mp);
+  double* Q0 = c.take<double>((size_t)p.Mp * p.Mp);
+  // Round 4: the last two factors are multiplied FIRST, Q = (Cw / s2)(L^-1 / 2) -- an M^3 product -- so that ONE N M^2 product
+  // (inside kbar_contract_kernel) is left behind T1 = K'_fu L^-T instead of two: what must stay factored is L^-T ... L^-1 around the
+  // whitened core (entries of size cond(K_uu) in the explicit Phibar); Q's are of size sqrt(cond), the same size the last factor
+  // of the fully factored chain has anyway.  SGP_BWD_FULLY_FACTORED=1 keeps the three-product chain (A/B, accuracy studies).
+  static const int fully = getenv("SGP_BWD_FULLY_FACTORED") ? atoi(getenv("SGP_BWD_FULLY_FACTORED")) : 0;
 
   KernArgs ka;
   for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
   ka.sf2 = sf2;
   ka.d = d;
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
-  bwd_pad_plain_kernel<<<2048, 256, 0, st>>>(kuu_linv, M, p.Mp, 0.5, w.Pb);          // the kernel forms 2 sf2 (T2 Pb)
+  bwd_pad_plain_kernel<<<2048, 256, 0, st>>>(kuu_linv, M, p.Mp, 0.5, fully ? w.Pb : Q0);  // the kernel forms 2 sf2 (T Pb)
   bwd_pad_small_kernel<<<2048, 256, 0, st>>>(Cw, M, p.Mp, 1.0 / s2, P2);
+  if (!fully) {
+    GemmDesc q;  // Pb = (Cw / s2)(L^-1 / 2): L^-1 lower triangular -> column block c of the product needs k >= its start
+    q.A = P2; q.lda = p.Mp; q.B = Q0; q.ldb = p.Mp; q.C = w.Pb; q.ldc = p.Mp;
+    q.m = p.Mp; q.n = p.Mp; q.k = p.Mp; q.klo_mask = 2;
+    gemm(q, st);
+  }
   bwd_pad_vec_kernel<<<(p.Mp + 255) / 256, 256, 0, st>>>(bbar, M, p.Mp, w.bb);
   const int want_gz = g_Z != nullptr;
   const int grid = p.nmb * p.nsplit_b;
@@ -614,22 +627,25 @@ extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const do
     g1.m = (int)p.Npad; g1.n = p.Mp; g1.k = p.Mp;
     g1.khi_mask = 2;  // L^-T is upper triangular: column block c needs k < its end only -- half the product (round 4)
     gemm(g1, st);
-    GemmDesc g2;  // T2 = T1 (Cw / s2)
-    g2.A = T1; g2.lda = p.Mp; g2.B = P2; g2.ldb = p.Mp; g2.C = T2; g2.ldc = p.Mp;
-    g2.m = (int)p.Npad; g2.n = p.Mp; g2.k = p.Mp;
-    gemm(g2, st);
+    if (fully) {
+      GemmDesc g2;  // T2 = T1 (Cw / s2)
+      g2.A = T1; g2.lda = p.Mp; g2.B = P2; g2.ldb = p.Mp; g2.C = T2; g2.ldc = p.Mp;
+      g2.m = (int)p.Npad; g2.n = p.Mp; g2.k = p.Mp;
+      gemm(g2, st);
+    }
   }
+  const double* Tin = fully ? T2 : T1;
   {
     const int64_t nblocks = p.Npad / TILE;
     int bps = (int)((nblocks + p.nsplit_b - 1) / p.nsplit_b);
     if (bps < 1) bps = 1;
     switch (p.DP) {
-      case 2: launch_bwd<2, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
-      case 4: launch_bwd<4, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
-      case 8: launch_bwd<8, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
-      case 16: launch_bwd<16, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
-      case 24: launch_bwd<24, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
-      default: launch_bwd<32, false>(kernel_id, grid, st, T2, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 2: launch_bwd<2, false>(kernel_id, grid, st, Tin, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 4: launch_bwd<4, false>(kernel_id, grid, st, Tin, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 8: launch_bwd<8, false>(kernel_id, grid, st, Tin, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 16: launch_bwd<16, false>(kernel_id, grid, st, Tin, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      case 24: launch_bwd<24, false>(kernel_id, grid, st, Tin, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
+      default: launch_bwd<32, false>(kernel_id, grid, st, Tin, w, sf2, 0, nblocks, bps, N, M, p, want_gz, 0); break;
     }
   }
   const int64_t tot = (int64_t)M * d;

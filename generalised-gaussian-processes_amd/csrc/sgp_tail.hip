@@ -922,6 +922,14 @@ static int64_t wh_chunk(int64_t N) {
   const int64_t np = round_up64(N > 0 ? N : 1, 64);
   return np < WH_CHUNK ? np : WH_CHUNK;
 }
+// k-slices of W += A A^T per chunk: its lower 64 x 64 tiles alone (136 at M = 1024) leave half of the 256 CUs idle over a 32768-long
+// contraction, so the contraction is cut until there are ~2 workgroups per CU (round 4; partial tiles summed in slice order)
+static int wh_slices(int Mp, int64_t Tc) {
+  const int nb = Mp / 64, tiles = nb * (nb + 1) / 2;
+  int S = 1;
+  while (S < 8 && tiles * S < 512 && Tc % (2 * S * 16) == 0 && Tc / (2 * S) >= 1024) S *= 2;
+  return S;
+}
 extern "C" size_t sgp_suffstats_whitened_workspace_bytes(int64_t N, int M, int d) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   const size_t Mp = padded_m(M), Tc = (size_t)wh_chunk(N);
@@ -930,6 +938,7 @@ extern "C" size_t sgp_suffstats_whitened_workspace_bytes(int64_t N, int M, int d
   c.take<double>(Mp * Tc);
   c.take<double>(Mp * Mp);
   c.take<double>(Mp);
+  c.take<double>((size_t)wh_slices((int)Mp, (int64_t)Tc) * Mp * Mp);
   return c.used();
 }
 extern "C" int sgp_suffstats_fwd_whitened(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
@@ -955,6 +964,9 @@ extern "C" int sgp_suffstats_fwd_whitened(const double* X, int64_t ldx, const do
   double* As = c.take<double>((size_t)Mp * Tc);
   double* Wp = c.take<double>((size_t)Mp * Mp);
   double* up = c.take<double>(Mp);
+  const int S = wh_slices(Mp, Tc);
+  double* parts = c.take<double>((size_t)S * Mp * Mp);
+  if (S > 1) fill_zero(parts, (size_t)S * Mp * Mp, st);  // the tiles above the diagonal are never written; the reduction reads them
   const KernArgs ka = make_ka(kernel_id == SGP_KERNEL_COMPOSITE ? nullptr : inv_ls, sf2, d);
   if (N == 0) {
     fill_zero(Wp, (size_t)Mp * Mp, st);
@@ -978,7 +990,7 @@ extern "C" int sgp_suffstats_fwd_whitened(const double* X, int64_t ldx, const do
     GemmDesc w;  // W (+)= A A^T, lower tiles only (mirrored below)
     w.A = As; w.lda = Tp; w.B = As; w.ldb = Tp; w.tb = true; w.C = Wp; w.ldc = Mp;
     w.m = Mp; w.n = Mp; w.k = Tp; w.beta = t0 > 0 ? 1.0 : 0.0; w.lower_only = true;
-    gemm(w, st);
+    gemm_splitk(w, S, parts, st);  // (a last, shorter chunk whose length S 16 does not divide takes the plain product)
     rows_dot_y_kernel<<<Mp / 4, 256, 0, st>>>(As, Mp, Tp, Tn, y + t0, t0 > 0 ? 1 : 0, up);
   }
   mirror_lower(Wp, Mp, Mp, st);
