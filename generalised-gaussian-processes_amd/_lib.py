@@ -97,6 +97,9 @@ PROTOTYPES = {
     "sgp_suffstats_whitened_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_fwd_whitened": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_whitened_rows_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "sgp_suffstats_fwd_whitened_rows": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
+                                               _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats_ex": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
@@ -104,6 +107,9 @@ PROTOTYPES = {
     "sgp_suffstats_bwd_factored_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_bwd_factored": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _dbl, _i64, _i32, _i32, _i32,
                                           _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_bwd_factored_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
+    "sgp_suffstats_bwd_factored_ex": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _dbl, _i64, _i32, _i32, _i32,
+                                             _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_set_cu_budget": (None, [_i32]),
     "sgp_small_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "sgp_small_debug_stamps": (None, [_vp]),

@@ -132,6 +132,8 @@ class CollapsedBound:
         # 16 GiB super-chunks and pass 2 re-assembles.
         self._kfu = None
         self.kfu_budget_bytes = 64 << 30
+        # local rows x inducing points from which the whitened order runs in the streaming layout (engine.suffstats_whitened_rows)
+        self.whitened_rows_min_work = 1 << 26
         self.factored_adjoint = True  # whitened order: pass 2 from L^-T Cw L^-1 applied factor by factor (sgp_suffstats_bwd_factored)
         self.fused = True          # single-launch path for small problems (M <= 128, one rank): sgp_small_eval
         self._small = None         # (pinned host theta, device theta, result buffer) of the single-launch path
@@ -295,10 +297,17 @@ class CollapsedBound:
             # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
-            packed = e.suffstats_whitened(self.X, self.y, Z, ls, sf2, linv, self.kernel)
-            self._allreduce_stats(packed, int(Z.shape[0]))
             # with adjoints: also the whitened core Cw of Phibar, so that pass 2 applies L^-T Cw L^-1 factor by factor
             factored = with_adjoints and self.factored_adjoint and hasattr(e, "suffstats_bwd_factored")
+            t_keep = None
+            if (hasattr(e, "suffstats_whitened_rows") and self.kernel != "composite"
+                    and int(self.X.shape[0]) * int(Z.shape[0]) >= self.whitened_rows_min_work):
+                # a large shard (the streaming guard's repeats at 10^6 rows): the streaming layout; T = K'_fu L^-T stays for pass 2
+                t_keep = self._kfu_for(Z.shape[0]) if factored else None
+                packed = e.suffstats_whitened_rows(self.X, self.y, Z, ls, sf2, linv, self.kernel, t_out=t_keep)
+            else:
+                packed = e.suffstats_whitened(self.X, self.y, Z, ls, sf2, linv, self.kernel)
+            self._allreduce_stats(packed, int(Z.shape[0]))
             kw = {"want_cw": True} if factored else {}
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True, **kw)
@@ -307,6 +316,7 @@ class CollapsedBound:
                 res["bounded"] = True
             res["packed"] = packed
             res["kfu"] = None
+            res["t_keep"] = t_keep
             res["linv"] = linv
             return res
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
@@ -491,7 +501,8 @@ class CollapsedBound:
         if res.get("Cw") is not None:
             # whitened order: Phibar's cond(K_uu)-sized entries would cancel in Phibar K_uf -- its factors are applied instead
             e.suffstats_bwd_factored(self.X, self.y, Z, ls, sf2, res["linv"], res["Cw"], s2, res["bbar"], -1.0 / (2.0 * float(s2)),
-                                     self.kernel, want_gz=want_gz, out=g)
+                                     self.kernel, want_gz=want_gz, out=g,
+                                     **({"t_in": res["t_keep"]} if res.get("t_keep") is not None else {}))
         else:
             e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
                             self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])

@@ -560,49 +560,59 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
 //     Kbar_fu = ((K_fu L^-T)(Cw / s2)) L^-1 + y bbar^T
 // one factor after the other: two plain GEMMs on the materialised K'_fu (these shards are small: N M <= 2^20 in
 // CollapsedBound), the third product inside kbar_contract_kernel (Pb = L^-1 / 2, epilogue recomputing k').
-static size_t bwd_factored_workspace_bytes(int64_t N, int M, int d) {
+// SGP_BWD_FULLY_FACTORED=1 keeps the three-product chain (A/B, accuracy studies); read once
+static int bwd_fully_factored() {
+  static const int v = getenv("SGP_BWD_FULLY_FACTORED") ? atoi(getenv("SGP_BWD_FULLY_FACTORED")) : 0;
+  return v;
+}
+// caller_t: T1 = K'_fu L^-T arrives from pass 1 (sgp_suffstats_fwd_whitened_rows kept it): neither K'_fu nor T1 live in the workspace
+static size_t bwd_factored_workspace_bytes(int64_t N, int M, int d, bool caller_t) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);
   p.sc_rows = p.Npad;
-  const size_t fast = carve_bwd(nullptr, p, true).bytes + 2 * round_up64((int64_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp * 8 + 256, 256) +
+  const int nt = (caller_t ? 0 : 1) + (bwd_fully_factored() ? 1 : 0);
+  const size_t fast = carve_bwd(nullptr, p, !caller_t).bytes + nt * round_up64((int64_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp * 8 + 256, 256) +
                       2 * round_up64((int64_t)p.Mp * p.Mp * 8 + 256, 256);
   const size_t comp = d <= COMP_MAX_DIM ? comp_bwd_factored_workspace_bytes(N, M, d) : 0;
   return fast > comp ? fast : comp;
 }
-extern "C" size_t sgp_suffstats_bwd_factored_workspace_bytes(int64_t N, int M, int d) { return bwd_factored_workspace_bytes(N, M, d); }
+extern "C" size_t sgp_suffstats_bwd_factored_workspace_bytes(int64_t N, int M, int d) { return bwd_factored_workspace_bytes(N, M, d, false); }
+extern "C" size_t sgp_suffstats_bwd_factored_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns_t) {
+  return bwd_factored_workspace_bytes(N, M, d, caller_owns_t != 0);
+}
 
-extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
-                                          const double* inv_ls, double sf2, const double* kuu_linv, const double* Cw, double s2,
-                                          const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id,
-                                          double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
-                                          sgp_stream_t stream) {
+static int bwd_factored(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                        const double* kuu_linv, const double* Cw, double s2, const double* bbar, double kappabar, int64_t N, int M,
+                        int d, int kernel_id, const double* T_in, double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
+                        sgp_stream_t stream) {
   if (!Z || !inv_ls || !kuu_linv || !Cw || !bbar || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d || !(s2 > 0.0))
     return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id > SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
+  if (T_in && kernel_id == SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   hipStream_t st = (hipStream_t)stream;
-  if (!ws || ws_bytes < bwd_factored_workspace_bytes(N, M, d)) return SGP_ERR_WORKSPACE;
+  if (!ws || ws_bytes < bwd_factored_workspace_bytes(N, M, d, T_in != nullptr)) return SGP_ERR_WORKSPACE;
   if (kernel_id == SGP_KERNEL_COMPOSITE) {
     CompSpec cs;
     if (comp_parse(inv_ls, d, &cs) != SGP_OK) return SGP_ERR_ARG;
     fill_zero(g_sf2, 1, st);
     return comp_suffstats_bwd_factored(X, ldx, y, Z, ldz, cs, kuu_linv, Cw, s2, bbar, kappabar, N, M, d, g_ls, g_Z, ws, ws_bytes, st);
   }
+  const int fully = bwd_fully_factored();
   StreamPlan p = make_stream_plan(N, M, d);
   p.sc_rows = p.Npad;  // one super-chunk: the whole K'_fu is materialised
-  BwdWs w = carve_bwd(ws, p, true);
+  BwdWs w = carve_bwd(ws, p, T_in == nullptr);
   Carver c(static_cast<char*>(ws) + round_up64((int64_t)w.bytes, 256));
   const size_t rows = (size_t)(p.Npad > 0 ? p.Npad : 1);
-  double* T1 = c.take<double>(rows * p.Mp);
-  double* T2 = c.take<double>(rows * p.Mp);
+  double* T1 = T_in ? nullptr : c.take<double>(rows * p.Mp);
+  double* T2 = fully ? c.take<double>(rows * p.Mp) : nullptr;
   double* P2 = c.take<double>((size_t)p.Mp * p.Mp);
   double* Q0 = c.take<double>((size_t)p.Mp * p.Mp);
   // Round 4: the last two factors are multiplied FIRST, Q = (Cw / s2)(L^-1 / 2) -- an M^3 product -- so that ONE N M^2 product
   // (inside kbar_contract_kernel) is left behind T1 = K'_fu L^-T instead of two: what must stay factored is L^-T ... L^-1 around the
   // whitened core (entries of size cond(K_uu) in the explicit Phibar); Q's are of size sqrt(cond), the same size the last factor
-  // of the fully factored chain has anyway.  SGP_BWD_FULLY_FACTORED=1 keeps the three-product chain (A/B, accuracy studies).
-  static const int fully = getenv("SGP_BWD_FULLY_FACTORED") ? atoi(getenv("SGP_BWD_FULLY_FACTORED")) : 0;
+  // of the fully factored chain has anyway.
 
   KernArgs ka;
   for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
@@ -620,21 +630,24 @@ extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const do
   bwd_pad_vec_kernel<<<(p.Mp + 255) / 256, 256, 0, st>>>(bbar, M, p.Mp, w.bb);
   const int want_gz = g_Z != nullptr;
   const int grid = p.nmb * p.nsplit_b;
+  const double* T1c = T_in ? T_in : T1;
   if (p.Npad > 0) {
-    stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, 0, p.Npad, N, M, w.Kfu, w.bpart, st);
-    GemmDesc g1;  // T1 = K'_fu L^-T   (kuu_linv is Mp x Mp: its padding rows hold an identity block that K'_fu's zero columns never meet)
-    g1.A = w.Kfu; g1.lda = p.Mp; g1.B = kuu_linv; g1.ldb = p.Mp; g1.tb = true; g1.C = T1; g1.ldc = p.Mp;
-    g1.m = (int)p.Npad; g1.n = p.Mp; g1.k = p.Mp;
-    g1.khi_mask = 2;  // L^-T is upper triangular: column block c needs k < its end only -- half the product (round 4)
-    gemm(g1, st);
+    if (!T_in) {
+      stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, 0, p.Npad, N, M, w.Kfu, w.bpart, st);
+      GemmDesc g1;  // T1 = K'_fu L^-T   (kuu_linv is Mp x Mp: its padding rows hold an identity block that K'_fu's zero columns never meet)
+      g1.A = w.Kfu; g1.lda = p.Mp; g1.B = kuu_linv; g1.ldb = p.Mp; g1.tb = true; g1.C = T1; g1.ldc = p.Mp;
+      g1.m = (int)p.Npad; g1.n = p.Mp; g1.k = p.Mp;
+      g1.khi_mask = 2;  // L^-T is upper triangular: column block c needs k < its end only -- half the product (round 4)
+      gemm(g1, st);
+    }
     if (fully) {
       GemmDesc g2;  // T2 = T1 (Cw / s2)
-      g2.A = T1; g2.lda = p.Mp; g2.B = P2; g2.ldb = p.Mp; g2.C = T2; g2.ldc = p.Mp;
+      g2.A = T1c; g2.lda = p.Mp; g2.B = P2; g2.ldb = p.Mp; g2.C = T2; g2.ldc = p.Mp;
       g2.m = (int)p.Npad; g2.n = p.Mp; g2.k = p.Mp;
       gemm(g2, st);
     }
   }
-  const double* Tin = fully ? T2 : T1;
+  const double* Tin = fully ? T2 : T1c;
   {
     const int64_t nblocks = p.Npad / TILE;
     int bps = (int)((nblocks + p.nsplit_b - 1) / p.nsplit_b);
@@ -653,4 +666,21 @@ extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const do
   bwd_reduce_kernel<<<rg < 1 ? 1 : rg, 256, 0, st>>>(w.gzpart, w.glpart, p.nsplit_b, p.nmb, p.Mp, M, p.DP, ka,
                                                     kappabar * (double)N, g_ls, g_sf2, g_Z);
   return check_launch();
+}
+
+extern "C" int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                          const double* inv_ls, double sf2, const double* kuu_linv, const double* Cw, double s2,
+                                          const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id,
+                                          double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
+                                          sgp_stream_t stream) {
+  return bwd_factored(X, ldx, y, Z, ldz, inv_ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, N, M, d, kernel_id, nullptr, g_ls, g_sf2, g_Z, ws,
+                      ws_bytes, stream);
+}
+extern "C" int sgp_suffstats_bwd_factored_ex(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                             const double* inv_ls, double sf2, const double* kuu_linv, const double* Cw, double s2,
+                                             const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id,
+                                             const double* T_in, double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
+                                             sgp_stream_t stream) {
+  return bwd_factored(X, ldx, y, Z, ldz, inv_ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, N, M, d, kernel_id, T_in, g_ls, g_sf2, g_Z, ws,
+                      ws_bytes, stream);
 }

@@ -27,6 +27,7 @@
 //      lower triangle -- no fp64 atomics anywhere, results are bit-reproducible.
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
+#include "sgp_dense.hpp"
 #include "sgp_composite.hpp"
 #include "sgp_ctx.hpp"
 #include <cstdlib>
@@ -603,6 +604,72 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qro
   return w;
 }
 
+// the fp64 contraction of `nchunks` 16-row chunks of a row-major [rows x Mp] matrix into the per-split slabs (options of the context)
+static void launch_syrk(const Ctx& cx, const double* K, int Mp, int64_t nchunks, const SplitMap& smap, int ntiles, int nsplit, int accum,
+                        double* slab, hipStream_t st) {
+  const int skip_upper = cx.syrk_skip_upper;  // 0 = full diagonal tiles (A/B knob SGP_SYRK_SKIP_UPPER, read at context creation)
+  const int nwaves = cx.syrk_waves, glds = cx.syrk_glds;
+  const int g = syrk_grid(nsplit, ntiles);
+#define SGP_SYRK_LAUNCH(NWV, GL, SK) \
+  syrk_tile_kernel<NWV, GL, SK><<<g, NWV * 64, 0, st>>>(K, Mp, nchunks, smap, ntiles, accum, slab, nsplit)
+  if (glds) {
+    if (skip_upper) SGP_SYRK_LAUNCH(4, true, true); else SGP_SYRK_LAUNCH(4, true, false);
+  } else if (nwaves == 8) {
+    if (skip_upper) SGP_SYRK_LAUNCH(8, false, true); else SGP_SYRK_LAUNCH(8, false, false);
+  } else {
+    if (skip_upper) SGP_SYRK_LAUNCH(4, false, true); else SGP_SYRK_LAUNCH(4, false, false);
+  }
+#undef SGP_SYRK_LAUNCH
+}
+
+// ---- whitened pass 1 in the streaming layout (round 4) ---------------------------------------------------------------------
+// out[k][c] = in[c][k] (Mp x Mp, Mp a multiple of 32): R = L^-T as a plain row-major operand
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int Mp, double* __restrict__ out) {
+  __shared__ double t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[ty + 8 * k][tx] = in[(size_t)(by + ty + 8 * k) * Mp + bx + tx];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[(size_t)(bx + ty + 8 * k) * Mp + by + tx] = t[tx][ty + 8 * k];
+}
+// bpart[rowblock][m] = sum over the block's ASM_ROWS rows of T[n][m] y[n] -- the partials kfu_assemble_kernel leaves for K'^T y, here for
+// T^T y (same layout, same fixed-order reduction behind it); T starts at row0, grid = (rows / ASM_ROWS, ceil(Mp / 256))
+__global__ __launch_bounds__(256) void tpart_kernel(const double* __restrict__ T, const double* __restrict__ ys, int64_t row0, int Mp,
+                                                    double* __restrict__ bpart) {
+  __shared__ double ysh[ASM_ROWS];
+  const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;
+  ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
+  __syncthreads();
+  const int m = blockIdx.y * 256 + threadIdx.x;
+  if (m >= Mp) return;
+  const double* src = T + (size_t)rbase * Mp + m;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 2
+  for (int i = 0; i < ASM_ROWS; i += 4) {
+    a0 = fma(__builtin_nontemporal_load(src + (size_t)i * Mp), ysh[i], a0);
+    a1 = fma(__builtin_nontemporal_load(src + (size_t)(i + 1) * Mp), ysh[i + 1], a1);
+    a2 = fma(__builtin_nontemporal_load(src + (size_t)(i + 2) * Mp), ysh[i + 2], a2);
+    a3 = fma(__builtin_nontemporal_load(src + (size_t)(i + 3) * Mp), ysh[i + 3], a3);
+  }
+  bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = (a0 + a1) + (a2 + a3);
+}
+
+struct WhRowsWs {
+  FwdWs f;
+  double *R, *T;
+  size_t bytes;
+};
+static WhRowsWs carve_wh_rows(void* ws, const StreamPlan& p, bool caller_t) {
+  WhRowsWs w;
+  w.f = carve_fwd(ws, p, true, 0);
+  Carver c(ws ? static_cast<char*>(ws) + round_up64((int64_t)w.f.bytes, 256) : nullptr);
+  w.R = c.take<double>((size_t)p.Mp * p.Mp);
+  w.T = caller_t ? nullptr : c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp);
+  w.bytes = (size_t)round_up64((int64_t)w.f.bytes, 256) + c.used();
+  return w;
+}
+
 }  // namespace sgp
 
 using namespace sgp;
@@ -691,20 +758,8 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
     // empty shard: run the contraction over zero chunks so every slab tile is written (zeros)
     syrk_tile_kernel<4, false, false><<<grid, 256, 0, st>>>(Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.slab, p.nsplit);
   }
-  const int skip_upper = cx.syrk_skip_upper;  // 0 = full diagonal tiles (A/B knob SGP_SYRK_SKIP_UPPER, read at context creation)
-  const int nwaves = cx.syrk_waves, glds = cx.syrk_glds;
   auto contract = [&](const double* K, int64_t nchunks, const SplitMap& smap, int nsplit, int accum, double* slab) {
-    const int g = syrk_grid(nsplit, p.ntiles);
-#define SGP_SYRK_LAUNCH(NWV, GL, SK) \
-  syrk_tile_kernel<NWV, GL, SK><<<g, NWV * 64, 0, st>>>(K, p.Mp, nchunks, smap, p.ntiles, accum, slab, nsplit)
-    if (glds) {
-      if (skip_upper) SGP_SYRK_LAUNCH(4, true, true); else SGP_SYRK_LAUNCH(4, true, false);
-    } else if (nwaves == 8) {
-      if (skip_upper) SGP_SYRK_LAUNCH(8, false, true); else SGP_SYRK_LAUNCH(8, false, false);
-    } else {
-      if (skip_upper) SGP_SYRK_LAUNCH(4, false, true); else SGP_SYRK_LAUNCH(4, false, false);
-    }
-#undef SGP_SYRK_LAUNCH
+    launch_syrk(cx, K, p.Mp, nchunks, smap, p.ntiles, nsplit, accum, slab, st);
   };
   int nslabs = p.nsplit;
   int head_ns = 0;
@@ -784,5 +839,68 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);
   finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.btmp, BRED_G, p.Mp, M, w.yypart, 256, sf2,
                                                          sf2 * (double)N, b, yy, kappa);
+  return check_launch();
+}
+
+// ---- whitened pass 1 in the streaming layout ---------------------------------------------------------------------------------
+// W = A A^T, u = A y with A = L^-1 K_uf (PyMC3's op order) for a LARGE shard: sgp_suffstats_fwd's fp64 pipeline with T = K'_fu L^-T in
+// place of K'_fu -- assembly (HBM write bound), ONE N M^2 / 2 product T = K' R with R = L^-T upper triangular (gemm, k clipped to the
+// triangle), u's partials (one read of T), the tuned fp64 contraction T^T T, the fixed-order reductions with sf2^2 / sf2 applied there.
+// sgp_suffstats_fwd_whitened (sgp_tail.hip) walks the same products in 32768-column chunks of an M x T layout: 31 x 4 launches at
+// N = 10^6 whose 136-tile W += A A^T leaves half the chip idle (64.7 ms of kernels at C5 against ~45 here).
+// T_out (optional, sgp_kfu_len(N, M) doubles): T (unit amplitude, no sf2) is left there for sgp_suffstats_bwd_factored_ex, which then
+// needs neither the assembly nor the product again.
+extern "C" size_t sgp_suffstats_whitened_rows_workspace_bytes(int64_t N, int M, int d, int caller_owns_t) {
+  if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  StreamPlan p = make_stream_plan(N, M, d);
+  if (caller_owns_t) p.sc_rows = p.Npad;
+  return carve_wh_rows(nullptr, p, caller_owns_t != 0).bytes;
+}
+extern "C" int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                               const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                               const double* kuu_linv, double* W, double* u, double* yy, double* kappa, double* T_out,
+                                               void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  Ctx& cx = cur_ctx();
+  if (!Z || !inv_ls || !kuu_linv || !W || !u || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id >= SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;  // the composite kernel keeps the chunked routine
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  StreamPlan p = make_stream_plan(N, M, d);
+  if (T_out) p.sc_rows = p.Npad;  // the caller keeps all of T: one super-chunk
+  WhRowsWs w = carve_wh_rows(ws, p, T_out != nullptr);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  KernArgs ka;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  ka.sf2 = sf2;
+  ka.d = d;
+  stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.f.Xs, w.f.ys, w.f.Zs, w.f.yypart, st);
+  transpose_kernel<<<dim3(p.Mp / 32, p.Mp / 32), 256, 0, st>>>(kuu_linv, p.Mp, w.R);
+  if (p.Npad == 0)
+    syrk_tile_kernel<4, false, false><<<p.ntiles * p.nsplit, 256, 0, st>>>(w.f.Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.f.slab,
+                                                                           p.nsplit);
+  for (int64_t r0 = 0; r0 < p.Npad; r0 += p.sc_rows) {
+    const int64_t rows = (p.Npad - r0) < p.sc_rows ? (p.Npad - r0) : p.sc_rows;
+    double* T = T_out ? T_out + (size_t)r0 * p.Mp : w.T;
+    timing_begin(TIMING_ASSEMBLE, st);
+    stream_assemble(p, kernel_id, w.f.Xs, w.f.ys, w.f.Zs, r0, rows, N, M, w.f.Kfu, w.f.bpart, st);  // (its K'^T y partials are overwritten below)
+    timing_end(TIMING_ASSEMBLE, st);
+    GemmDesc g;  // T = K' R: column block c of the upper-triangular R needs k < its end only
+    g.A = w.f.Kfu; g.lda = p.Mp; g.B = w.R; g.ldb = p.Mp; g.C = T; g.ldc = p.Mp;
+    g.m = (int)rows; g.n = p.Mp; g.k = p.Mp; g.khi_mask = 2;
+    gemm(g, st);
+    tpart_kernel<<<dim3((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256), 256, 0, st>>>(T, w.f.ys, r0, p.Mp, w.f.bpart);
+    const int64_t nchunks = rows / NB;
+    const int cps = (int)((nchunks + p.nsplit - 1) / p.nsplit);
+    const SplitMap smap{{p.taper[0], p.taper[1], p.taper[2], p.taper[3]}, cps < 1 ? 1 : cps};
+    timing_begin(TIMING_SYRK, st);
+    launch_syrk(cx, T, p.Mp, nchunks, smap, p.ntiles, p.nsplit, r0 > 0 ? 1 : 0, w.f.slab, st);
+    timing_end(TIMING_SYRK, st);
+    cx.syrk_timed_rows = rows;
+  }
+  const int nb32 = p.Mp / 32;
+  reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.f.slab, p.nsplit, p.ntiles, M, sf2 * sf2, W);
+  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.f.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.f.btmp);
+  finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.f.btmp, BRED_G, p.Mp, M, w.f.yypart, 256, sf2, sf2 * (double)N, u, yy, kappa);
   return check_launch();
 }

@@ -181,6 +181,34 @@ class HipEngine:
         _lib.check("sgp_suffstats_fwd_whitened", st)
         return out
 
+    def suffstats_whitened_rows(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out: Optional[torch.Tensor] = None,
+                                t_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``suffstats_whitened`` for a large shard, in the streaming layout (include/sgp.h: sgp_suffstats_fwd_whitened_rows; stationary
+        kernels).  ``t_out`` (from ``kfu_buffer``) keeps T = K'_fu L^-T for ``suffstats_bwd_factored(..., t_in=)``."""
+        N, d = X.shape
+        M = Z.shape[0]
+        self._chk(Z, "Z"), self._chk(kuu_linv, "kuu_linv")
+        if N > 0:
+            self._chk(X, "X"), self._chk(y, "y")
+        if out is None:
+            out = self.empty(M * M + M + 2)
+        if t_out is not None:
+            self._chk(t_out, "t_out")
+            if t_out.numel() < self.lib.sgp_kfu_len(N, M):
+                raise ValueError("t_out holds %d doubles, sgp_kfu_len(N, M) = %d" % (t_out.numel(), self.lib.sgp_kfu_len(N, M)))
+        nbytes = self.lib.sgp_suffstats_whitened_rows_workspace_bytes(N, M, d, 1 if t_out is not None else 0)
+        if nbytes == 0:
+            raise ValueError("unsupported shape N=%d M=%d d=%d" % (N, M, d))
+        ws = self._workspace("fwd_whitened_rows_t" if t_out is not None else "fwd_whitened_rows", nbytes)
+        base = out.data_ptr()
+        st = self.lib.sgp_suffstats_fwd_whitened_rows(
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+            self._ptr(kuu_linv), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(t_out) if t_out is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
+            self._stream())
+        _lib.check("sgp_suffstats_fwd_whitened_rows", st)
+        return out
+
     def pack_lower(self, stats: torch.Tensor, M: int) -> torch.Tensor:
         """[lower triangle of Phi | b | yy | kappa]: what crosses xGMI (half the bytes of ``stats``)."""
         tri = self.empty(self.lib.sgp_stats_packed_len(M))
@@ -515,24 +543,27 @@ class HipEngine:
         return out
 
     def suffstats_bwd_factored(self, X, y, Z, ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, kernel="rbf", want_gz=False,
-                               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                               out: Optional[torch.Tensor] = None, t_in: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``suffstats_bwd`` from the factored adjoint 2 s2 Phibar = L^-T Cw L^-1 (``kuu_linv`` from ``kuu_factor``, ``Cw``
         from ``bound(..., whitened=True, want_cw=True)``): same packed gradients, without the cancellation of an explicit
-        Phibar on ill-conditioned K_uu."""
+        Phibar on ill-conditioned K_uu.  ``t_in``: T = K'_fu L^-T kept by ``suffstats_whitened_rows(..., t_out=)``."""
         N, d = X.shape
         M = Z.shape[0]
         nh = self.hyper_len(kernel, d)
         if out is None:
             out = self.empty(nh + 1 + (M * d if want_gz else 0))
-        nbytes = self.lib.sgp_suffstats_bwd_factored_workspace_bytes(N, M, d)
-        ws = self._workspace("bwd_factored", nbytes)
+        if t_in is not None:
+            self._chk(t_in, "t_in")
+        nbytes = self.lib.sgp_suffstats_bwd_factored_workspace_bytes_ex(N, M, d, 1 if t_in is not None else 0)
+        ws = self._workspace("bwd_factored_t" if t_in is not None else "bwd_factored", nbytes)
         base = out.data_ptr()
-        st = self.lib.sgp_suffstats_bwd_factored(
+        st = self.lib.sgp_suffstats_bwd_factored_ex(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(kuu_linv),
-            self._ptr(Cw), float(s2), self._ptr(bbar), float(kappabar), N, M, d, _kernel_id(kernel), C.c_void_p(base),
+            self._ptr(Cw), float(s2), self._ptr(bbar), float(kappabar), N, M, d, _kernel_id(kernel),
+            self._ptr(t_in) if t_in is not None else C.c_void_p(0), C.c_void_p(base),
             C.c_void_p(base + 8 * nh), C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(),
             self._stream())
-        _lib.check("sgp_suffstats_bwd_factored", st)
+        _lib.check("sgp_suffstats_bwd_factored_ex", st)
         return out
 
     def kuu_bwd(self, Z, ls, sf2, Kuubar, grads: torch.Tensor, kernel="rbf", want_gz=False) -> torch.Tensor:

@@ -314,6 +314,18 @@ int sgp_suffstats_fwd_whitened(const double* X, int64_t ldx, const double* y,
                                int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
                                double* W, double* u, double* yy, double* kappa,
                                void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* The same statistics for a LARGE shard, in sgp_suffstats_fwd's streaming layout (round 4: the streaming-order guard of a caller sends
+ * whole 10^6-row evaluations here): kernel assembly, ONE product T = K'_fu L^-T (clipped to L^-T's triangle), the tuned
+ * fp64 contraction T^T T and the fixed-order reductions, instead of 31 x 4 launches over 32768-column chunks.  Stationary kernels only
+ * (SGP_ERR_ARG for SGP_KERNEL_COMPOSITE).  T_out (DEVICE, sgp_kfu_len(N, M) doubles, or NULL): T is left there, unit amplitude, for
+ * sgp_suffstats_bwd_factored_ex; the workspace is sized with caller_owns_t = 1 then.  Same outputs and all-reduce as above; the
+ * results agree with sgp_suffstats_fwd_whitened to fp64 rounding of a different summation order, not bit for bit.                   */
+size_t sgp_suffstats_whitened_rows_workspace_bytes(int64_t N, int M, int d, int caller_owns_t);
+int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, const double* y,
+                                    const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                                    int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
+                                    double* W, double* u, double* yy, double* kappa, double* T_out,
+                                    void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_bound_from_whitened_stats(const double* W, const double* u, const double* yy, const double* kappa,
                                   double s2, int64_t N, int M, int with_adjoints, double* out,
                                   double* Phibar, double* bbar, double* Kuubar, double* factors,
@@ -439,6 +451,19 @@ int sgp_suffstats_bwd_factored(const double* X, int64_t ldx, const double* y,
                                int64_t N, int M, int d, int kernel_id,
                                double* g_ls, double* g_sf2, double* g_Z,
                                void* ws, size_t ws_bytes, sgp_stream_t stream);
+
+/* The same with T = K'_fu L^-T handed over from pass 1 (T_in: sgp_suffstats_fwd_whitened_rows' T_out, or NULL = as above): the
+ * assembly and the first N M^2 product are not repeated, and the workspace (caller_owns_t = 1) holds neither K'_fu nor T.
+ * Since round 4 both entry points multiply the two trailing factors first, Q = (Cw / s2)(L^-1 / 2) (an M^3 product), and leave ONE
+ * N M^2 product behind T; SGP_BWD_FULLY_FACTORED=1 in the environment keeps the three-product chain.                              */
+size_t sgp_suffstats_bwd_factored_workspace_bytes_ex(int64_t N, int M, int d, int caller_owns_t);
+int sgp_suffstats_bwd_factored_ex(const double* X, int64_t ldx, const double* y,
+                                  const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                                  const double* kuu_linv, const double* Cw, double s2,
+                                  const double* bbar, double kappabar,
+                                  int64_t N, int M, int d, int kernel_id, const double* T_in,
+                                  double* g_ls, double* g_sf2, double* g_Z,
+                                  void* ws, size_t ws_bytes, sgp_stream_t stream);
 
 /* gradient through Kuu: ADDS sum(Kuubar o dKuu/d(.)) into g_ls, g_sf2, g_Z (g_Z may be NULL).
  * Kuubar is used as a symmetric matrix.  Replicated on every rank (call it after the all-reduce of
