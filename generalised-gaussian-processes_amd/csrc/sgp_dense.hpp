@@ -118,6 +118,8 @@ void crop_copy(const double* src, int64_t lds, double* dst, int64_t ldd, int rs,
 void fill_zero(double* p, size_t n, hipStream_t st);
 // n ints <- 0 by a kernel launch (graph-replay safe; see sgp_dense.hip)
 void zero_ints(int* p, int n, hipStream_t st);
+// out = in^T for an n x n matrix (ld n, n a multiple of 32)
+void transpose_square(const double* in, int n, double* out, hipStream_t st);
 // upper triangle <- transpose of lower triangle
 void mirror_lower(double* A, int64_t ld, int Mp, hipStream_t st);
 

@@ -572,7 +572,7 @@ static size_t bwd_factored_workspace_bytes(int64_t N, int M, int d, bool caller_
   p.sc_rows = p.Npad;
   const int nt = (caller_t ? 0 : 1) + (bwd_fully_factored() ? 1 : 0);
   const size_t fast = carve_bwd(nullptr, p, !caller_t).bytes + nt * round_up64((int64_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp * 8 + 256, 256) +
-                      2 * round_up64((int64_t)p.Mp * p.Mp * 8 + 256, 256);
+                      3 * round_up64((int64_t)p.Mp * p.Mp * 8 + 256, 256);
   const size_t comp = d <= COMP_MAX_DIM ? comp_bwd_factored_workspace_bytes(N, M, d) : 0;
   return fast > comp ? fast : comp;
 }
@@ -609,6 +609,7 @@ static int bwd_factored(const double* X, int64_t ldx, const double* y, const dou
   double* T2 = fully ? c.take<double>(rows * p.Mp) : nullptr;
   double* P2 = c.take<double>((size_t)p.Mp * p.Mp);
   double* Q0 = c.take<double>((size_t)p.Mp * p.Mp);
+  double* R = c.take<double>((size_t)p.Mp * p.Mp);
   // Round 4: the last two factors are multiplied FIRST, Q = (Cw / s2)(L^-1 / 2) -- an M^3 product -- so that ONE N M^2 product
   // (inside kbar_contract_kernel) is left behind T1 = K'_fu L^-T instead of two: what must stay factored is L^-T ... L^-1 around the
   // whitened core (entries of size cond(K_uu) in the explicit Phibar); Q's are of size sqrt(cond), the same size the last factor
@@ -634,10 +635,13 @@ static int bwd_factored(const double* X, int64_t ldx, const double* y, const dou
   if (p.Npad > 0) {
     if (!T_in) {
       stream_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, 0, p.Npad, N, M, w.Kfu, w.bpart, st);
-      GemmDesc g1;  // T1 = K'_fu L^-T   (kuu_linv is Mp x Mp: its padding rows hold an identity block that K'_fu's zero columns never meet)
-      g1.A = w.Kfu; g1.lda = p.Mp; g1.B = kuu_linv; g1.ldb = p.Mp; g1.tb = true; g1.C = T1; g1.ldc = p.Mp;
+      // T1 = K'_fu R, R = L^-T as a row-major operand -- the same product, by the same kernel, that pass 1 keeps for the _ex entry point
+      // (kuu_linv is Mp x Mp: its padding rows hold an identity block that K'_fu's zero columns never meet)
+      transpose_square(kuu_linv, p.Mp, R, st);
+      GemmDesc g1;
+      g1.A = w.Kfu; g1.lda = p.Mp; g1.B = R; g1.ldb = p.Mp; g1.C = T1; g1.ldc = p.Mp;
       g1.m = (int)p.Npad; g1.n = p.Mp; g1.k = p.Mp;
-      g1.khi_mask = 2;  // L^-T is upper triangular: column block c needs k < its end only -- half the product (round 4)
+      g1.khi_mask = 2;  // R is upper triangular: column block c needs k < its end only -- half the product (round 4)
       gemm(g1, st);
     }
     if (fully) {

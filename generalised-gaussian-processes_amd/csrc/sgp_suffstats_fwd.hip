@@ -623,16 +623,6 @@ static void launch_syrk(const Ctx& cx, const double* K, int Mp, int64_t nchunks,
 }
 
 // ---- whitened pass 1 in the streaming layout (round 4) ---------------------------------------------------------------------
-// out[k][c] = in[c][k] (Mp x Mp, Mp a multiple of 32): R = L^-T as a plain row-major operand
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int Mp, double* __restrict__ out) {
-  __shared__ double t[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) t[ty + 8 * k][tx] = in[(size_t)(by + ty + 8 * k) * Mp + bx + tx];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) out[(size_t)(bx + ty + 8 * k) * Mp + by + tx] = t[tx][ty + 8 * k];
-}
 // bpart[rowblock][m] = sum over the block's ASM_ROWS rows of T[n][m] y[n] -- the partials kfu_assemble_kernel leaves for K'^T y, here for
 // T^T y (same layout, same fixed-order reduction behind it); T starts at row0, grid = (rows / ASM_ROWS, ceil(Mp / 256))
 __global__ __launch_bounds__(256) void tpart_kernel(const double* __restrict__ T, const double* __restrict__ ys, int64_t row0, int Mp,
@@ -875,7 +865,7 @@ extern "C" int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, con
   ka.sf2 = sf2;
   ka.d = d;
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.f.Xs, w.f.ys, w.f.Zs, w.f.yypart, st);
-  transpose_kernel<<<dim3(p.Mp / 32, p.Mp / 32), 256, 0, st>>>(kuu_linv, p.Mp, w.R);
+  transpose_square(kuu_linv, p.Mp, w.R, st);  // R = L^-T as a plain row-major operand
   if (p.Npad == 0)
     syrk_tile_kernel<4, false, false><<<p.ntiles * p.nsplit, 256, 0, st>>>(w.f.Kfu, p.Mp, 0, SplitMap{{0, 0, 0, 0}, 1}, p.ntiles, 0, w.f.slab,
                                                                            p.nsplit);

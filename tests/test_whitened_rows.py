@@ -65,6 +65,12 @@ def test_rows_layout_matches_the_chunked_routine_and_the_oracle(engine, kernel, 
     Tg = t[: ((N + 255) // 256 * 256) * Mp].reshape(-1, Mp).cpu()
     assert relerr(Tg[:N, :M], Tr) < 1e-8                              # cond(L) ~ 1e3 .. 1e5 on both sides
     assert float(Tg[N:].abs().max() if Tg.shape[0] > N else 0.0) == 0.0 and float(Tg[:, M:].abs().max() if Mp > M else 0.0) == 0.0
+    # the product itself, against the same factors (the library's own L^-1): componentwise inside the rounding of an M-term dot product
+    # -- Npad >= 2048 takes the 128 x 128-tile kernel (gemm_tall_kernel), smaller shards the 64 x 64 one
+    Li = linv.cpu().reshape(Mp, Mp)[:M, :M]
+    Tp = Kfu1 @ Li.T
+    bound = 2.0 * M * np.finfo(np.float64).eps * (Kfu1.abs() @ Li.abs().T) + 1e-300
+    assert bool(((Tg[:N, :M] - Tp).abs() <= bound).all()), float(((Tg[:N, :M] - Tp).abs() / bound).max())
     A = sf2 * Tr.T
     assert relerr(W1, (A @ A.T).numpy()) < 1e-8 and relerr(u1, (A @ y).numpy()) < 1e-8
 
