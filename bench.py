@@ -449,6 +449,27 @@ def main():
                 "sgp_streaming_error_estimate), read back with every evaluation; above the tolerance the evaluation is repeated in the "
                 "whitened (PyMC3) order, and so are the evaluations that follow it until the predicted estimate is below half the tolerance "
                 "-- 0 and 0 = every timed step ran the streaming design"}
+    if world == 1:
+        # what an evaluation costs where the guard sends it: the whitened (PyMC3) order on the same shard and theta, a few repetitions
+        # outside the timed region (engine.suffstats_whitened_rows + suffstats_bwd_factored)
+        wb = ggp_amd.CollapsedBound(Xd, yd, kernel="rbf", jitter=JITTER, engine=eng, form="whitened")
+        wb._kfu = cb._kfu  # the same N x M block: K'_fu in the streaming order, K'_fu L^-T in this one
+        wv = lambda: wb.value(Zd, ls, sf2, s2)  # noqa: E731
+        wg = lambda: wb.value_and_grad(Zd, ls, sf2, s2, want_gz=False)  # noqa: E731
+        Fw = wv()[0]
+        wg()
+        torch.cuda.synchronize(dev)
+        tw = []
+        for fn in (wv, wg):
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            tw.append((time.perf_counter() - t0) / 3 * 1e3)
+        res["config"]["streaming_guard"]["whitened_order"] = {
+            "ms_per_evaluation": tw[0], "ms_per_leapfrog": tw[1], "F_minus_streaming_F_per_datum": (Fw - last["F"]) / args.n,
+            "note": "not part of `value`: the cost of one evaluation / one value+gradient in the order the guard falls back to"}
+        del wb
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

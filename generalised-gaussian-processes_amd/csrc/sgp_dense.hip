@@ -274,112 +274,121 @@ void transpose_square(const double* in, int n, double* out, hipStream_t st) {
 // on T = K'_fu L^-T (10^6 x 1024 x 1024, clipped to the triangle) it ran at 34 TFLOP/s.  This is the main loop of pass 2
 // (kbar_contract_kernel, sgp_suffstats_bwd.hip) with a plain store behind it: a workgroup of four waves owns a 128 x 128 tile, every
 // wave 64 x 64 of it in 128 accumulator registers (one operand read per two MFMAs); 16-deep slabs of A (k-contiguous rows, from HBM:
-// two register stages) and of B (L2 resident: one) go global -> registers -> LDS, double buffered, two workgroups per CU.  Workgroup
-// ids put the column blocks of one row block on one XCD (round-robin dispatch), whose L2 then serves the re-reads of the A rows.
+// two register stages) and of B (L2 resident: one) go global -> registers -> LDS, double buffered, two workgroups per CU.
 // tri: 0 = full k range, 1 = B upper triangular (column block cb needs k < its end), 2 = B lower triangular (k >= its start).
 constexpr int TT = 128, TBK = 16, TALD = TBK + 2, TBROW = TT + 16;
 constexpr int TA_DBL = TT * TALD, TB_DBL = TBK * TBROW;
 __global__ __launch_bounds__(256, 2) void gemm_tall_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
                                                            int64_t ldb, double* __restrict__ C, int64_t ldc, int nrb, int ncb, int k,
-                                                           int tri, double alpha) {
+                                                           int tri, double alpha, int rb_per_wg) {
   __shared__ double smem[2 * (TA_DBL + TB_DBL)];
   double (*At)[TT][TALD] = reinterpret_cast<double (*)[TT][TALD]>(smem);
   double (*Bt)[TBK][TBROW] = reinterpret_cast<double (*)[TBK][TBROW]>(smem + 2 * TA_DBL);
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int cb = jj % ncb, rb = (jj / ncb) * 8 + xcd;
-  if (rb >= nrb) return;
-  const int m0 = cb * TT;
-  int klo = 0, khi = k;
-  if (tri == 1) khi = min(k, m0 + TT);
-  if (tri == 2) klo = m0;
-  const int ch0 = klo / TBK, nchunks = (khi - klo) / TBK;  // multiples of 8: k and the tile edge are multiples of 128
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const int prow = tid >> 4, pcol = (tid & 15) * 2;
-  int arow[4], acol[4];
-  int64_t aoff[4];
+  // per-thread element offsets (32-bit: the host checks 128 ld < 2^31) relative to wave-uniform bases: one VGPR per address
+  int arow[4], acol[4], aoff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = tid + 256 * i;
     arow[i] = q >> 3;
     acol[i] = (q & 7) * 2;
-    aoff[i] = (int64_t)arow[i] * lda + acol[i];
+    aoff[i] = arow[i] * (int)lda + acol[i];
   }
-  const int64_t poff = (int64_t)prow * ldb + pcol;
-  const double* Ablk = A + (int64_t)rb * TT * lda;
+  const int poff = prow * (int)ldb + pcol;
+  const int coff = (wi * 64 + l4) * (int)ldc + wj * 64 + l15;
 
-  d2 avA[4], avB[4], pv[4];
-  auto fetchA = [&](int ch, d2 (&av)[4]) {
-    const double* ab = Ablk + (int64_t)(ch0 + ch) * TBK;
+  // a workgroup walks its row blocks and, inside one, every column block (widest k range first): the same work per workgroup whatever
+  // the triangle, the A rows of a block come back from this XCD's own L2 for the later column blocks, and a finished tile's stores
+  // drain under the next tile's main loop (one tile per workgroup: 23.6 ms at C5, the short tiles all start-up)
+  const int rb_end = min(nrb, ((int)blockIdx.x + 1) * rb_per_wg);
+#pragma unroll 1
+  for (int rb = (int)blockIdx.x * rb_per_wg; rb < rb_end; ++rb) {
+    const double* Ablk = A + (int64_t)rb * TT * lda;
+#pragma unroll 1
+    for (int cbi = 0; cbi < ncb; ++cbi) {
+      const int cb = tri == 2 ? cbi : ncb - 1 - cbi;
+      const int m0 = cb * TT;
+      int klo = 0, khi = k;
+      if (tri == 1) khi = min(k, m0 + TT);
+      if (tri == 2) klo = m0;
+      const int ch0 = klo / TBK, nchunks = (khi - klo) / TBK;  // multiples of 8: k and the tile edge are multiples of 128
+
+      d2 avA[4], avB[4], pv[4];
+      auto fetchA = [&](int ch, d2 (&av)[4]) {
+        const double* ab = Ablk + (int64_t)(ch0 + ch) * TBK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const d2*>(ab + aoff[i]);
-  };
-  auto fetchP = [&](int ch) {
-    const double* pb = B + (int64_t)(ch0 + ch) * TBK * ldb + m0;
+        for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const d2*>(ab + aoff[i]);
+      };
+      auto fetchP = [&](int ch) {
+        const double* pb = B + (int64_t)(ch0 + ch) * TBK * ldb + m0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) pv[e] = *reinterpret_cast<const d2*>(pb + poff + 32 * e);
-  };
-  auto stashA = [&](int buf, const d2 (&av)[4]) {
+        for (int e = 0; e < 4; ++e) pv[e] = *reinterpret_cast<const d2*>(pb + poff + 32 * e);
+      };
+      auto stashA = [&](int buf, const d2 (&av)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(&At[buf][arow[i]][acol[i]]) = av[i];
-  };
-  auto stashP = [&](int buf) {
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(&At[buf][arow[i]][acol[i]]) = av[i];
+      };
+      auto stashP = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) *reinterpret_cast<d2*>(&Bt[buf][prow][pcol + 32 * e]) = pv[e];
-  };
-  d4 acc[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
-  auto mfma_slab = [&](int buf) {
-#pragma unroll
-    for (int ks = 0; ks < TBK / 4; ++ks) {
-      double a[4], bq[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = At[buf][wi * 64 + u * 16 + l15][ks * 4 + l4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) bq[v] = Bt[buf][ks * 4 + l4][wj * 64 + v * 16 + l15];
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<d2*>(&Bt[buf][prow][pcol + 32 * e]) = pv[e];
+      };
+      d4 acc[4][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
-    }
-  };
-  if (nchunks > 0) {
-    fetchA(0, avA);
-    fetchP(0);
-    stashA(0, avA);
-    stashP(0);
-    fetchA(1, avB);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {
-      if (ch + 2 < nchunks) fetchA(ch + 2, avA);
-      fetchP(ch + 1);
-      mfma_slab(0);
-      stashA(1, avB);
-      stashP(1);
-      __syncthreads();
-      if (ch + 3 < nchunks) fetchA(ch + 3, avB);
-      if (ch + 2 < nchunks) fetchP(ch + 2);
-      mfma_slab(1);
-      if (ch + 2 < nchunks) {
+        for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+      auto mfma_slab = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < TBK / 4; ++ks) {
+          double a[4], bq[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a[u] = At[buf][wi * 64 + u * 16 + l15][ks * 4 + l4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) bq[v] = Bt[buf][ks * 4 + l4][wj * 64 + v * 16 + l15];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = mfma16(a[u], bq[v], acc[u][v]);
+        }
+      };
+      if (nchunks > 0) {
+        fetchA(0, avA);
+        fetchP(0);
         stashA(0, avA);
         stashP(0);
+        fetchA(1, avB);
+        __syncthreads();
+#pragma unroll 1
+        for (int ch = 0; ch < nchunks; ch += 2) {
+          if (ch + 2 < nchunks) fetchA(ch + 2, avA);
+          fetchP(ch + 1);
+          mfma_slab(0);
+          stashA(1, avB);
+          stashP(1);
+          __syncthreads();
+          if (ch + 3 < nchunks) fetchA(ch + 3, avB);
+          if (ch + 2 < nchunks) fetchP(ch + 2);
+          mfma_slab(1);
+          if (ch + 2 < nchunks) {
+            stashA(0, avA);
+            stashP(0);
+          }
+          __syncthreads();
+        }
       }
-      __syncthreads();
+      double* Cblk = C + (int64_t)rb * TT * ldc + m0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            Cblk[coff + (u * 16 + 4 * r) * (int)ldc + v * 16] = alpha * acc[u][v][r];
     }
   }
-  double* Cblk = C + (int64_t)rb * TT * ldc + m0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        Cblk[(int64_t)(wi * 64 + u * 16 + l4 + 4 * r) * ldc + wj * 64 + v * 16 + l15] = alpha * acc[u][v][r];
 }
 // SGP_GEMM_TALL=0 switches the kernel off (A/B); rows from which it is used
 static int gemm_tall_min_rows() {
@@ -390,13 +399,18 @@ static bool gemm_tall(const GemmDesc& g, hipStream_t st) {
   const int minr = gemm_tall_min_rows();
   if (minr <= 0 || g.ta || g.tb || g.batch != 1 || g.batch2 != 1 || g.beta != 0.0 || g.lower_only) return false;
   if (g.m < minr || g.m % TT || g.n % TT || g.k % TT || g.k <= 0) return false;
+  if (g.lda >= (1 << 23) || g.ldb >= (1 << 23) || g.ldc >= (1 << 23)) return false;  // 32-bit offsets inside a 128-row block
   int tri = 0;
   if (g.klo_mask == 0 && g.khi_mask == 2 && g.n == g.k) tri = 1;
   else if (g.klo_mask == 2 && g.khi_mask == 0 && g.n == g.k) tri = 2;
   else if (g.klo_mask != 0 || g.khi_mask != 0) return false;
   const int nrb = g.m / TT, ncb = g.n / TT;
-  const int grid = 8 * ncb * ((nrb + 7) / 8);
-  gemm_tall_kernel<<<grid, 256, 0, st>>>(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, nrb, ncb, g.k, tri, g.alpha);
+  // row blocks per workgroup: ~4 rounds of the 512 resident workgroups when there are that many row blocks, one block each otherwise
+  static const int rounds = getenv("SGP_GEMM_TALL_ROUNDS") ? atoi(getenv("SGP_GEMM_TALL_ROUNDS")) : 4;  // tuning knob
+  int per = (nrb + 512 * rounds - 1) / (512 * rounds);
+  if (per < 1) per = 1;
+  const int grid = (nrb + per - 1) / per;
+  gemm_tall_kernel<<<grid, 256, 0, st>>>(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, nrb, ncb, g.k, tri, g.alpha, per);
   return true;
 }
 
