@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tall_kernel(const double* __restr
 }
 // SGP_GEMM_TALL=0 switches the kernel off (A/B); rows from which it is used
 static int gemm_tall_min_rows() {
-  static const int v = getenv("SGP_GEMM_TALL") ? atoi(getenv("SGP_GEMM_TALL")) : 2048;
+  static const int v = getenv("SGP_GEMM_TALL") ? atoi(getenv("SGP_GEMM_TALL")) : 16384;  // >= 128 workgroups of >= 1 row block
   return v;
 }
 static bool gemm_tall(const GemmDesc& g, hipStream_t st) {

@@ -28,7 +28,6 @@ struct StreamPlan {
   int nsplit;       // pass 1: row-range splits per tile (multiple of 8: one XCD per residue)
   int taper[4];     // pass 1: groups of 8 splits at relative sizes 8, 4, 2, 1 (all 0: equal splits), see split_range()
   int nmb;          // pass 2: 128-column blocks of Phibar
-  int asm_rs;       // kernel assembly: workgroups per 256-row block (1, or 4 where 256-row workgroups would not fill the chip)
   int nsplit_b;     // pass 2: row-range splits per column block
   int taper_b[4];   // pass 2: tapered split sizes (as taper[])
 };
@@ -73,14 +72,6 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.ntiles = p.ntr * (p.ntr + 1) / 2;
   p.DP = dp_for(d);
   p.Npad = N > 0 ? round_up64(N, ASM_ROWS) : 0;
-  {  // fewer 256-row x 256-column assembly workgroups than CUs: SGP_ASM_ROW_SPLIT=4 deals a block to four workgroups of 64 rows (C3:
-    // 104 -> 416 workgroups).  OFF by default -- measured no gain (C3 1 425 / 1 660 evaluations per s without, 1 398 / 1 402 with,
-    // alternating on one box, profiles/r04_asm_split_ab.txt): at that size the chol(K_uu) chain on the side stream, not the assembly,
-    // is what pass 1's tail waits for, and more assembly workgroups only take CUs from it.
-    static const int rs_knob = getenv("SGP_ASM_ROW_SPLIT") ? atoi(getenv("SGP_ASM_ROW_SPLIT")) : 1;
-    const int64_t wgs = (p.Npad / ASM_ROWS) * ((padded_m(M) + 255) / 256);
-    p.asm_rs = (wgs > 0 && wgs < 256 && (rs_knob == 2 || rs_knob == 4)) ? rs_knob : 1;
-  }
   int64_t cap = (int64_t)(stream_kfu_budget() / ((size_t)p.Mp * 8)) / ASM_ROWS * ASM_ROWS;
   if (cap < ASM_ROWS) cap = ASM_ROWS;
   p.sc_rows = p.Npad < cap ? p.Npad : cap;

@@ -95,21 +95,18 @@ __global__ __launch_bounds__(256) void prep_y_kernel(const double* __restrict__ 
 template <int DP, int KID>
 __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
                                                            const double* __restrict__ Zs, int64_t row0, int64_t N, int M,
-                                                           int Mp, double* __restrict__ Kfu, double* __restrict__ bpart, int rs) {
+                                                           int Mp, double* __restrict__ Kfu, double* __restrict__ bpart) {
   // the block's 256 scaled data rows and targets are staged once in LDS (coalesced) and then read as
   // wave-wide broadcasts: measured 80 % of wave time parked on per-row scalar loads before (SQ_WAIT_ANY)
   __shared__ double xs[ASM_ROWS][DP];
   __shared__ double ysh[ASM_ROWS];
   __shared__ double etab[EXP_TAB_N];
-  // rs > 1 (small shards, round 4): the block's 256 rows are dealt to rs workgroups (blockIdx.z), each with its own line of bpart --
-  // C3's 52 x 2 workgroups of 256 rows left 150 CUs idle for 124 us
-  const int nrows = ASM_ROWS / rs;
-  const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS + (int64_t)blockIdx.z * nrows;  // row inside this super-chunk's Kfu
+  const int64_t rbase = (int64_t)blockIdx.x * ASM_ROWS;  // row inside this super-chunk's Kfu
   {
     const double* src = Xs + (row0 + rbase) * DP;
     double* dst = &xs[0][0];
-    for (int e = threadIdx.x; e < nrows * DP; e += 256) dst[e] = src[e];
-    if ((int)threadIdx.x < nrows) ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
+    for (int e = threadIdx.x; e < ASM_ROWS * DP; e += 256) dst[e] = src[e];
+    ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
     sgp_exp_tab_load(etab);
   }
   __syncthreads();
@@ -123,7 +120,7 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
 
   double bacc = 0.0;
 #pragma unroll 4
-  for (int i = 0; i < nrows; ++i) {
+  for (int i = 0; i < ASM_ROWS; ++i) {
     const int64_t n = row0 + rbase + i;                    // global data row, wave-uniform
     double r2 = 0.0;
 #pragma unroll
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
     __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);  // streamed once (1.80 vs 1.90 ms with plain stores)
     bacc = fma(kv, ysh[i], bacc);
   }
-  bpart[(((row0 + rbase) / ASM_ROWS) * rs + blockIdx.z) * Mp + m] = bacc;
+  bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = bacc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -486,18 +483,17 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
 template <int DP>
 static void launch_assemble(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
                             int64_t row0, int64_t N, int M, int Mp, double* Kfu, double* bpart) {
-  const int rs = (int)grid.z;
   switch (kid) {
-    case SGP_KERNEL_RBF: kfu_assemble_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart, rs); break;
-    case SGP_KERNEL_MATERN32: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart, rs); break;
-    default: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart, rs); break;
+    case SGP_KERNEL_RBF: kfu_assemble_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    case SGP_KERNEL_MATERN32: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    default: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
   }
 }
 
 // Assemble rows [row0, row0 + rows) of K'_fu (rows a multiple of ASM_ROWS) into Kfu (which starts at row0).
 void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0,
                      int64_t rows, int64_t N, int M, double* Kfu, double* bpart, hipStream_t st) {
-  dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256, p.asm_rs);
+  dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256);
   switch (p.DP) {
     case 2: launch_assemble<2>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
     case 4: launch_assemble<4>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
@@ -597,7 +593,7 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qro
   int nslab = p.nsplit + HEAD_SPLITS_MAX;  // + the head block's splits
   if (qrows > 0 && i8_nsplit(qrows, p.Mp) > nslab) nslab = i8_nsplit(qrows, p.Mp);  // the int8 contraction's own split count
   w.slab = c.take<double>((size_t)nslab * p.ntiles * TILE * TILE);
-  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.asm_rs * p.Mp);
+  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
@@ -830,8 +826,7 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, nslabs, p.ntiles, M, sf2 * sf2, Phi);
-  // (the digit-plane assembly of the integer path writes one line of partials per 256-row block whatever asm_rs is)
-  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, (p.Npad / ASM_ROWS) * (use_i8 ? 1 : p.asm_rs), p.Mp, BRED_G, w.btmp);
+  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);
   finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.btmp, BRED_G, p.Mp, M, w.yypart, 256, sf2,
                                                          sf2 * (double)N, b, yy, kappa);
   return check_launch();

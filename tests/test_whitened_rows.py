@@ -37,7 +37,7 @@ def problem(N, M, d, seed, ls=1.4):
 
 
 @pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern52"])
-@pytest.mark.parametrize("N,M,d", [(5000, 200, 3), (777, 130, 1), (256, 64, 8), (20000, 384, 5)])
+@pytest.mark.parametrize("N,M,d", [(5000, 200, 3), (777, 130, 1), (256, 64, 8), (20000, 384, 5), (270000, 128, 2)])
 def test_rows_layout_matches_the_chunked_routine_and_the_oracle(engine, kernel, N, M, d):
     from oracle import vfe_oracle as O
     X, y, Z, ls = problem(N, M, d, N + M)
@@ -66,7 +66,8 @@ def test_rows_layout_matches_the_chunked_routine_and_the_oracle(engine, kernel, 
     assert relerr(Tg[:N, :M], Tr) < 1e-8                              # cond(L) ~ 1e3 .. 1e5 on both sides
     assert float(Tg[N:].abs().max() if Tg.shape[0] > N else 0.0) == 0.0 and float(Tg[:, M:].abs().max() if Mp > M else 0.0) == 0.0
     # the product itself, against the same factors (the library's own L^-1): componentwise inside the rounding of an M-term dot product
-    # -- Npad >= 2048 takes the 128 x 128-tile kernel (gemm_tall_kernel), smaller shards the 64 x 64 one
+    # -- Npad >= 16384 takes the 128 x 128-tile kernel (gemm_tall_kernel; 270 000 rows: two row blocks per workgroup, the last
+    # workgroup short), smaller shards the 64 x 64 one
     Li = linv.cpu().reshape(Mp, Mp)[:M, :M]
     Tp = Kfu1 @ Li.T
     bound = 2.0 * M * np.finfo(np.float64).eps * (Kfu1.abs() @ Li.abs().T) + 1e-300
