@@ -243,3 +243,51 @@ class GuardedOracleEngine(OracleEngine):
     @staticmethod
     def read_estimate(host_buf):
         return float(host_buf[OUT_LEN + 1])
+
+
+class FactoredOracleEngine(GuardedOracleEngine):
+    """GuardedOracleEngine + the whitened order in the streaming layout and the factored pass 2 (include/sgp.h:
+    sgp_suffstats_fwd_whitened_rows, sgp_suffstats_bwd_factored_ex), so that CollapsedBound's hand-over of T = K'_fu L^-T from pass 1 to
+    pass 2 runs on the CPU.  T is kept in the caller's K'_fu block exactly as the HIP engine keeps it; pass 2 CHECKS what it is handed."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls.update({"suffstats_whitened_rows": 0, "suffstats_bwd_factored": 0, "t_handed_over": 0})
+
+    def kfu_buffer(self, N, M):
+        return torch.full((max(1, int(N)) * int(M),), float("nan"), dtype=torch.float64)
+
+    def suffstats_whitened_rows(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, t_out=None):
+        self.calls["suffstats_whitened_rows"] += 1
+        n = self.calls["suffstats_whitened"]
+        packed = self.suffstats_whitened(X, y, Z, ls, sf2, kuu_linv, kernel, out)
+        self.calls["suffstats_whitened"] = n                       # (delegation, not a call of the chunked routine)
+        if t_out is not None and X.shape[0] > 0:
+            M, d = Z.shape
+            Kp = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel])  # unit amplitude
+            t_out[: X.shape[0] * M] = (Kp @ kuu_linv.T).reshape(-1)
+        return packed
+
+    def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, result=None, kuu_linv=None, whitened=False,
+              want_cw=False):
+        res = super().bound(Kuu, packed, s2, N, with_adjoints, want_factors, result, kuu_linv, whitened)
+        if want_cw and with_adjoints and kuu_linv is not None:
+            M = Kuu.shape[0]
+            L = torch.linalg.solve_triangular(kuu_linv, torch.eye(M, dtype=torch.float64), upper=False)
+            res["Cw"] = 2.0 * float(s2) * (L.T @ res["Phibar"] @ L)   # 2 s2 Phibar = L^-T Cw L^-1
+        return res
+
+    def suffstats_bwd_factored(self, X, y, Z, ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, kernel="rbf", want_gz=False, out=None,
+                               t_in=None):
+        self.calls["suffstats_bwd_factored"] += 1
+        M, d = Z.shape
+        if t_in is not None:
+            self.calls["t_handed_over"] += 1
+            if X.shape[0] > 0:
+                Kp = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel])
+                assert torch.equal(t_in[: X.shape[0] * M], (Kp @ kuu_linv.T).reshape(-1)), "pass 2 was handed a stale T"
+        Phibar = kuu_linv.T @ Cw @ kuu_linv / (2.0 * float(s2))
+        n = self.calls["suffstats_bwd"]
+        g = self.suffstats_bwd(X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel, want_gz, out)
+        self.calls["suffstats_bwd"] = n
+        return g

@@ -414,3 +414,86 @@ def test_two_rank_gloo_guard_decisions_are_identical_on_every_rank():
     a, b = outs[0][1], outs[1][1]
     assert a == b                                        # F, gradients, whitened counts, estimates, ratios, collective counts: bit for bit
     assert a[0][2] == 0 and a[1][2] == 1 and a[-1][2] >= 2
+
+
+def test_whitened_order_in_the_streaming_layout_hands_T_to_pass_2_on_the_cpu_double():
+    """Host logic of the large-shard whitened order: above `whitened_rows_min_work` local rows x inducing points the
+    statistics come from suffstats_whitened_rows, T = K'_fu L^-T stays in the bound's K'_fu block and pass 2 receives exactly that
+    block (the double asserts its contents); value-only evaluations keep nothing; below the threshold the chunked routine runs.  F and
+    the gradients agree with the chunked order to rounding (the factored adjoint is re-expanded in the double)."""
+    import ggp_amd as pkg
+    from fake_engine import FactoredOracleEngine
+    X, y, Z = _guard_problem()
+    theta = ([1.5] * 3, 1.2, 0.05)
+    eng = FactoredOracleEngine()
+    cb = pkg.CollapsedBound(X, y, jitter=1e-6, engine=eng, form="whitened")
+    cb.whitened_rows_min_work = 0
+    F, _ = cb.value(Z, *theta)
+    assert eng.calls["suffstats_whitened_rows"] == 1 and eng.calls["suffstats_whitened"] == 0 and cb._kfu is None
+    F2, g = cb.value_and_grad(Z, *theta, want_gz=True)
+    assert eng.calls["suffstats_whitened_rows"] == 2 and eng.calls["suffstats_bwd_factored"] == 1 and eng.calls["t_handed_over"] == 1
+    assert cb._kfu is not None and not bool(torch.isnan(cb._kfu[: X.shape[0] * Z.shape[0]]).any())
+    ref_eng = FactoredOracleEngine()
+    ref = pkg.CollapsedBound(X, y, jitter=1e-6, engine=ref_eng, form="whitened")   # default threshold: this problem is far below it
+    Fr, gr = ref.value_and_grad(Z, *theta, want_gz=True)
+    assert ref_eng.calls["suffstats_whitened_rows"] == 0 and ref_eng.calls["suffstats_whitened"] == 1 and ref_eng.calls["t_handed_over"] == 0
+    assert F == F2 == Fr
+    for k in ("ls", "Z"):
+        assert torch.equal(torch.as_tensor(g[k]), torch.as_tensor(gr[k]))
+    assert g["sf2"] == gr["sf2"] and g["s2"] == gr["s2"]
+    # the guard's fallback takes the same route: a streaming bound that trips hands T over on the repeat
+    old = pkg.CollapsedBound.WHITENED_MAX_WORK
+    pkg.CollapsedBound.WHITENED_MAX_WORK = 0
+    try:
+        e2 = FactoredOracleEngine()
+        c2 = pkg.CollapsedBound(X, y, jitter=1e-6, engine=e2)
+        c2.whitened_rows_min_work = 0
+        c2.value_and_grad(Z, [25.0] * 3, 1.0, 1e-5, want_gz=False)
+        assert c2.n_guard_reruns == 1 and e2.calls["suffstats_whitened_rows"] == 1 and e2.calls["t_handed_over"] == 1
+    finally:
+        pkg.CollapsedBound.WHITENED_MAX_WORK = old
+
+
+def _rows_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ggp_amd as pkg
+    from fake_engine import FactoredOracleEngine
+    X, y, Z = _guard_problem()
+    lo, hi = pkg.shard_rows(X.shape[0], rank, world)
+    eng = FactoredOracleEngine()
+    cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=1e-6, engine=eng, form="whitened")
+    # rank 0 takes the streaming layout, rank 1 the chunked routine: the all-reduced statistics mean the same either way
+    cb.whitened_rows_min_work = 0 if rank == 0 else 1 << 40
+    F, g = cb.value_and_grad(Z, [1.5] * 3, 1.2, 0.05, want_gz=True)
+    q.put((rank, F, g["ls"].numpy().tolist(), torch.as_tensor(g["Z"]).numpy().tolist(), eng.calls["suffstats_whitened_rows"], eng.calls["t_handed_over"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_whitened_layouts_may_differ_between_ranks():
+    """A rank picks the whitened layout from its LOCAL shard size: ranks with different choices still all-reduce the same quantities
+    ([W | u | yy | kappa], then the packed gradients) and agree with the one-process evaluation."""
+    import ggp_amd as pkg
+    from fake_engine import FactoredOracleEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[0][1:4] == outs[1][1:4]                                   # F and the gradients: the same bits on both ranks
+    assert outs[0][4:] == (1, 1) and outs[1][4:] == (0, 0)
+    X, y, Z = _guard_problem()
+    one = pkg.CollapsedBound(X, y, jitter=1e-6, engine=FactoredOracleEngine(), form="whitened")
+    F1, g1 = one.value_and_grad(Z, [1.5] * 3, 1.2, 0.05, want_gz=True)
+    assert abs(outs[0][1] - F1) < 1e-9 * abs(F1)
+    assert np.max(np.abs(np.asarray(outs[0][2]) - g1["ls"].numpy())) < 1e-8 * np.max(np.abs(g1["ls"].numpy()))
