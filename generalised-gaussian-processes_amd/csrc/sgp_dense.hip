@@ -275,7 +275,7 @@ void transpose_square(const double* in, int n, double* out, hipStream_t st) {
 // (kbar_contract_kernel, sgp_suffstats_bwd.hip) with a plain store behind it: a workgroup of four waves owns a 128 x 128 tile, every
 // wave 64 x 64 of it in 128 accumulator registers (one operand read per two MFMAs); 16-deep slabs of A (k-contiguous rows, from HBM:
 // two register stages) and of B (L2 resident: one) go global -> registers -> LDS, double buffered, two workgroups per CU.
-// tri: 0 = full k range, 1 = B upper triangular (column block cb needs k < its end), 2 = B lower triangular (k >= its start).
+// tri: 0 = full k range, 1 = B upper triangular (column block cb needs k < its end).
 constexpr int TT = 128, TBK = 16, TALD = TBK + 2, TBROW = TT + 16;
 constexpr int TA_DBL = TT * TALD, TB_DBL = TBK * TBROW;
 __global__ __launch_bounds__(256, 2) void gemm_tall_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
@@ -309,21 +309,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tall_kernel(const double* __restr
     const double* Ablk = A + (int64_t)rb * TT * lda;
 #pragma unroll 1
     for (int cbi = 0; cbi < ncb; ++cbi) {
-      const int cb = tri == 2 ? cbi : ncb - 1 - cbi;
+      const int cb = ncb - 1 - cbi;
       const int m0 = cb * TT;
-      int klo = 0, khi = k;
-      if (tri == 1) khi = min(k, m0 + TT);
-      if (tri == 2) klo = m0;
-      const int ch0 = klo / TBK, nchunks = (khi - klo) / TBK;  // multiples of 8: k and the tile edge are multiples of 128
+      const int khi = tri == 1 ? min(k, m0 + TT) : k;
+      const int nchunks = khi / TBK;  // a multiple of 8: k and the tile edge are multiples of 128
 
       d2 avA[4], avB[4], pv[4];
       auto fetchA = [&](int ch, d2 (&av)[4]) {
-        const double* ab = Ablk + (int64_t)(ch0 + ch) * TBK;
+        const double* ab = Ablk + (int64_t)ch * TBK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const d2*>(ab + aoff[i]);
       };
       auto fetchP = [&](int ch) {
-        const double* pb = B + (int64_t)(ch0 + ch) * TBK * ldb + m0;
+        const double* pb = B + (int64_t)ch * TBK * ldb + m0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) pv[e] = *reinterpret_cast<const d2*>(pb + poff + 32 * e);
       };
@@ -402,7 +400,6 @@ static bool gemm_tall(const GemmDesc& g, hipStream_t st) {
   if (g.lda >= (1 << 23) || g.ldb >= (1 << 23) || g.ldc >= (1 << 23)) return false;  // 32-bit offsets inside a 128-row block
   int tri = 0;
   if (g.klo_mask == 0 && g.khi_mask == 2 && g.n == g.k) tri = 1;
-  else if (g.klo_mask == 2 && g.khi_mask == 0 && g.n == g.k) tri = 2;
   else if (g.klo_mask != 0 || g.khi_mask != 0) return false;
   const int nrb = g.m / TT, ncb = g.n / TT;
   // row blocks per workgroup: ~4 rounds of the 512 resident workgroups when there are that many row blocks, one block each otherwise

@@ -160,3 +160,58 @@ def test_ill_conditioned_inducing_set_rows_layout_agrees_with_the_chunked_order(
     assert abs(Fa - Fb) < 1e-9 * abs(Fa)
     assert relerr(gb["ls"].numpy(), ga["ls"].numpy()) < 1e-6 and abs(gb["s2"] - ga["s2"]) < 1e-6 * abs(ga["s2"])
     assert relerr(gb["Z"].cpu().numpy(), ga["Z"].cpu().numpy()) < 1e-5
+
+
+_CHAIN_SCRIPT = r"""
+import json, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import ggp_amd
+from test_whitened_rows import problem
+eng = ggp_amd.HipEngine()
+X, y, Z, ls = problem(20000, 256, 4, 11)
+Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
+Kuu = eng.kuu(Zd, ls, 1.3, 1e-6, "rbf")
+linv, kinfo = eng.kuu_factor(Kuu)
+t = eng.kfu_buffer(20000, 256)
+packed = eng.suffstats_whitened_rows(Xd, yd, Zd, ls, 1.3, linv, "rbf", t_out=t)
+res = eng.bound(Kuu, packed, 0.04, 20000, with_adjoints=True, kuu_linv=linv, kuu_info=kinfo, whitened=True, want_cw=True)
+g = eng.suffstats_bwd_factored(Xd, yd, Zd, ls, 1.3, linv, res["Cw"], 0.04, res["bbar"], -12.5, "rbf", want_gz=True, t_in=t)
+print(json.dumps(g.cpu().tolist()))
+"""
+
+
+def test_three_product_chain_of_the_factored_pass_2_agrees_with_the_two_product_one():
+    """SGP_BWD_FULLY_FACTORED=1 (read once per process, hence the child processes) keeps T2 = T (Cw / s2) as a product of its own -- a
+    full-range tall GEMM -- in front of pass 2's; the default multiplies (Cw / s2)(L^-1 / 2) first.  Same gradients to 1e-10."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, SGP_BWD_FULLY_FACTORED=flag)
+        r = subprocess.run([sys.executable, "-c", _CHAIN_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.asarray(json.loads(r.stdout.strip().splitlines()[-1])))
+    assert relerr(outs[1], outs[0]) < 1e-10 and not np.array_equal(outs[0], outs[1])   # (two different chains did run)
+
+
+@pytest.mark.parametrize("N", [0, 1, 255])
+def test_rows_layout_handles_empty_and_tiny_shards(engine, N):
+    """An empty shard (a rank of a sharded job can hold no rows) leaves zeros; one row and 255 rows (one padded 256-row block) agree
+    with the chunked routine."""
+    X, y, Z, ls = problem(max(N, 1), 96, 3, 21)
+    X, y = X[:N], y[:N]
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    Kuu = engine.kuu(Zd, ls, 1.0, 1e-6, "rbf")
+    linv, _ = engine.kuu_factor(Kuu)
+    t = engine.kfu_buffer(N, 96)
+    new = engine.suffstats_whitened_rows(Xd, yd, Zd, ls, 1.0, linv, "rbf", t_out=t)
+    old = engine.suffstats_whitened(Xd, yd, Zd, ls, 1.0, linv, "rbf")
+    W1, u1, yy1, ka1 = unpack(new, 96)
+    W0, u0, yy0, ka0 = unpack(old, 96)
+    if N == 0:
+        assert not W1.any() and not u1.any() and yy1 == 0.0 and ka1 == 0.0
+    else:
+        assert relerr(W1, W0) < 1e-10 and relerr(u1, u0) < 1e-10 and abs(yy1 - yy0) <= 1e-13 * abs(yy0) and ka1 == ka0
