@@ -22,6 +22,8 @@ for M, dup in ((512, False), (512, True), (1024, True)):
         Z[1::16] = Z[0::16][: Z[1::16].shape[0]]
     Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
     cb = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=eng)
+    if os.environ.get("GUARD", "1") == "0":
+        cb.streaming_tol = 0.0
     for ls in (0.2, 0.5, 1.0, 2.0, 5.0, 20.0):
         for sn in (0.01, 0.3, 3.0):
             if M == 1024 and sn == 3.0:
@@ -33,6 +35,10 @@ for M, dup in ((512, False), (512, True), (1024, True)):
                 row["F_" + key] = F
                 row["info_" + key] = parts.get("info", 0)
                 row["used_" + key] = eng.lib.sgp_contraction_last()
+                # the guard of DESIGN.md 4f (on unless GUARD=0): the estimate this evaluation carried, and how many evaluations of this
+                # bound have been repeated in / sent directly to the whitened order so far
+                row["estimate_" + key] = cb.last_estimate
+                row["whitened_so_far_" + key] = cb.n_guard_reruns + cb.n_direct_whitened
             eng.lib.sgp_set_contraction(1)
             try:
                 row["F_ref"] = float(O.vfe_pymc3_order_chunked(X, y, Z, torch.full((D,), ls, dtype=torch.float64), 1.0, sn, 1e-6))
