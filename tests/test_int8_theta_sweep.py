@@ -50,7 +50,7 @@ CELLS_512 = [(ls, sn) for ls in (0.2, 0.5, 1.0, 2.0, 5.0, 20.0) for sn in (0.01,
 @pytest.mark.parametrize("M,dup,cells", [(512, False, CELLS_512), (512, True, [(2.0, 0.01), (5.0, 0.3)]),
                                          (1024, True, [(2.0, 0.3), (5.0, 0.01)]), (1024, False, [(20.0, 0.01)])])
 def test_default_mode_bound_over_the_theta_range(engine, host_threads, M, dup, cells):
-    """What round 4's sweep found (tools/theta_sweep_diag.py, profiles/r04_theta_sweep_streaming.jsonl): the integer and the fp64
+    """What round 4's sweep found (tests/studies/theta_sweep_diag.py, profiles/r04_theta_sweep_streaming.jsonl): the integer and the fp64
     contraction agree with each other everywhere -- and BOTH leave the 1e-8 per datum for long lengthscales x small noise (1e-4 at
     l = 5, sig_n = 0.01; B not even positive definite at l = 20), because the STREAMING order amplifies the rounding of Phi by
     1 / lambda(K_uu).  The bound now carries the library's estimate of that error and repeats such evaluations in the whitened
