@@ -149,6 +149,15 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 // 2. contraction
 // ---------------------------------------------------------------------------------------------
 constexpr int I8_PSPLIT = 5;  // MFMA batches 0 .. 4 (15 MFMAs) in the first half of a step, batches 5, 6 (13) in the second
+// A/B (tools/ab_build.sh -DSGP_AB_I8_PAIRS34): keep the digit pairs p + r >= 5 as well -- 34 products in 8 significance groups, the
+// truncation 2^-8 of today's.  What an extended-precision streaming order would pay in pass 1; the fold stays fp64
+// here, so the statistics only gain the smaller truncation.
+#ifdef SGP_AB_I8_PAIRS34
+constexpr int I8_MINSUM = 5;
+#else
+constexpr int I8_MINSUM = 6;
+#endif
+constexpr int I8_NG = 13 - I8_MINSUM;  // significance groups g = p + r - I8_MINSUM
 static_assert(2 * I8_PPW - 1 <= I8_PSPLIT * (I8_PSPLIT + 1) / 2, "every DMA piece must find its MFMA in the first half");
 
 // Eight waves in two groups (waves 0-3 / 4-7: one of each per SIMD) that run HALF A STEP apart.  A step = 32 data rows = 28 MFMAs per
@@ -171,9 +180,9 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
   const int grp = wave >> 2, w4 = wave & 3;
   const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;  // 32 x 32 tile (wi, wj) of the 128 x 64 tile: the groups interleave the row blocks
   const int l32 = lane & 31, lh = lane >> 5;
-  i16v acc[I8_NP];
+  i16v acc[I8_NG];
 #pragma unroll
-  for (int g = 0; g < I8_NP; ++g)
+  for (int g = 0; g < I8_NG; ++g)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[g][r] = 0;
 
@@ -230,8 +239,8 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
 #pragma unroll
     for (int p = p0; p < p1; ++p)
 #pragma unroll
-      for (int r = I8_NP - 1 - p; r < I8_NP; ++r) {
-        if (ACT) acc[p + r - (I8_NP - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[r], acc[p + r - (I8_NP - 1)], 0, 0, 0);
+      for (int r = (I8_MINSUM - p > 0 ? I8_MINSUM - p : 0); r < I8_NP; ++r) {
+        if (ACT) acc[p + r - I8_MINSUM] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b[r], acc[p + r - I8_MINSUM], 0, 0, 0);
         ++issued;
         // after MFMAs 1, 3, .. 11.  Alternating in one process at C5 (profiles/r03_i8_dma_placement_ab.jsonl): 11.27-11.38 ms, against
         // 11.62-11.68 after 2, 4, .. 12, 11.52-11.64 after 1, 2, .. 6 and 11.75-11.83 after 4, 6, .. 14
@@ -283,7 +292,7 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
     for (int r = 0; r < 16; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int g = 0; g < I8_NP; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * g - 60), v);
+      for (int g = 0; g < I8_NG; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * (g + I8_MINSUM) - 108), v);
       const int row = wi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
       double* dst = out + row * TILE + wj * 32 + l32;
       *dst = accumulate ? *dst + v : v;
