@@ -107,8 +107,8 @@ class CollapsedBound:
         self.d = int(self.X.shape[1])
         self.kernel = kernel
         self.jitter = float(jitter)
-        if form not in ("auto", "streaming", "whitened"):
-            raise ValueError("form must be 'auto', 'streaming' or 'whitened'")
+        if form not in ("auto", "streaming", "whitened", "extended"):
+            raise ValueError("form must be 'auto', 'streaming', 'extended' or 'whitened'")
         self.form = form
         self.group = group
         self.world = _world(group)
@@ -159,6 +159,13 @@ class CollapsedBound:
         self.n_direct_whitened = 0
         self._prefer_whitened = False
         self._est_ratio = 1.0
+        # Between the two there is the EXTENDED streaming order (engine.suffstats_extended: Phi on the integer cores to 2^-61, the triple
+        # product in double-double): what the sandwich amplifies is 2^8 times smaller, so an evaluation whose estimate is within
+        # `extended_range` x the tolerance (2^7: half of that factor kept as margin) is repeated THERE -- one N M^2 contraction, 19.4 ms
+        # at C5 -- and only beyond it in the whitened order (39.6 ms).  n_extended counts the evaluations that ran in it.
+        self.extended_range = 128.0
+        self.n_extended = 0
+        self._pred_est = float("inf")
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -269,31 +276,72 @@ class CollapsedBound:
         if trips:
             self._prefer_whitened = True
             self._tripped_estimate = est
+            self._pred_est = est
         return trips
 
+    def _extended_ok(self, M):
+        """The extended order exists for this bound (a rank-invariant statement: the shard size is the largest one of the job)."""
+        e = self.engine
+        return (hasattr(e, "suffstats_extended") and self.kernel != "composite" and self.extended_range > 1.0
+                and self._rows_for_form * int(M) >= self.whitened_rows_min_work)
+
+    def _choose_tier(self, M):
+        """1 = the extended streaming order, 2 = the whitened order, for an evaluation whose streaming estimate is predicted as _pred_est."""
+        within = self._pred_est <= self.extended_range * self.streaming_tol  # (NaN / inf: the whitened order)
+        return 1 if within and self._extended_ok(M) else 2
+
     def _start_whitened(self, M):
-        """True when this evaluation should skip the streaming attempt (the guard tripped recently and nothing says it would pass)."""
-        return self._prefer_whitened and self._guard_on() and not self._whitened(M)
+        """0, or the tier (1 extended, 2 whitened) this evaluation should start in without a streaming attempt (the guard tripped
+        recently and nothing says it would pass)."""
+        if self.form == "extended":
+            return 1
+        if not (self._prefer_whitened and self._guard_on() and not self._whitened(M)):
+            return 0
+        return self._choose_tier(M)
 
     def _note_whitened(self, res, host):
-        """After a whitened-order evaluation that carries the estimate's upper bound: learn the ratio at the theta where the guard
-        tripped, or -- on later evaluations -- decide whether the streaming order is worth another try."""
+        """After an extended- or whitened-order evaluation that carries the estimate's upper bound: learn the ratio at the theta where
+        the guard tripped, or -- on later evaluations -- decide whether the streaming order is worth another try.  True when the
+        evaluation ran in the extended order and the prediction for ITS theta is beyond that order's range: repeat it whitened."""
+        if res.get("tier") == 1:
+            self.n_extended += 1
         if not res.get("bounded"):
-            return
+            return False
         ub = self.engine.read_estimate(host)
         if not (ub > 0.0) or not math.isfinite(ub):
-            return
+            return False
         tripped = getattr(self, "_tripped_estimate", None)
         if tripped is not None:  # the repeat right behind the trip: same theta, so estimate / bound is exact here
             self._est_ratio = min(1.0, tripped / ub) if math.isfinite(tripped) else 1.0
             self._tripped_estimate = None
-        elif self._est_ratio * ub < 0.5 * self.streaming_tol:
+            return False
+        self._pred_est = self._est_ratio * ub
+        if self._pred_est < 0.5 * self.streaming_tol:
             self._prefer_whitened = False
+        return res.get("tier") == 1 and self.form != "extended" and not (self._pred_est <= self.extended_range * self.streaming_tol)
 
-    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=False):
+    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=0):
+        """force_whitened: 0 = by `form`, 1 = the extended streaming order, 2 (or True) = the whitened order."""
         e = self.engine
         result = e.result_buffer(extra)  # (buf, out, info): everything the host reads back, one allocation
-        if force_whitened or self._whitened(Z.shape[0]):
+        tier = 2 if force_whitened is True else int(force_whitened)
+        if tier == 1:
+            # the extended streaming order: the whitened statistics from ONE integer-core contraction (34 digit pairs, double-double fold)
+            # and a double-double triple product; pass 2 from the explicit Phibar on the fp64 K'_fu kept here
+            Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
+            linv, _ = e.kuu_factor(Kuu, info=result[2])
+            kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
+            packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu)
+            self._allreduce_stats(packed, int(Z.shape[0]))
+            res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
+                          result=result, whitened=True)
+            if self._guard_on() and hasattr(e, "streaming_error_bound"):
+                e.streaming_error_bound(e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf()), sf2, s2, result)
+                res["bounded"] = True
+            res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv, tier=1)
+            return res
+        if tier == 2 or self._whitened(Z.shape[0]):
+            force_whitened = tier == 2
             # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
@@ -318,6 +366,7 @@ class CollapsedBound:
             res["kfu"] = None
             res["t_keep"] = t_keep
             res["linv"] = linv
+            res["tier"] = 2
             return res
         kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
         gate = None
@@ -425,11 +474,15 @@ class CollapsedBound:
         o, info, host = self._fetch(res)
         if direct:
             self.n_direct_whitened += 1
-        elif self._guard_trips(res, host):  # the streaming order is not trustworthy at this theta: PyMC3's order instead
+        elif self._guard_trips(res, host):  # the streaming order is not trustworthy at this theta: the extended or PyMC3's order instead
             self.n_guard_reruns += 1
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=True)
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=self._choose_tier(Z.shape[0]))
             o, info, host = self._fetch(res)
-        self._note_whitened(res, host)
+        if self._note_whitened(res, host):  # an extended-order evaluation beyond that order's range
+            self.n_guard_reruns += 1
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=2)
+            o, info, host = self._fetch(res)
+            self._note_whitened(res, host)
         self.n_evals += 1
         if info != 0:
             if raise_on_fail:
@@ -450,7 +503,7 @@ class CollapsedBound:
             raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), self.d))
         return vals + [float(sf2), float(s2)], None
 
-    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True, _force_whitened=False):
+    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True, _force_whitened=0):
         """F and dF/d{lengthscale_j, sf2, s2[, Z]} (natural parameters, not their raw transforms).
 
         Returns (F, grads) with grads = dict(ls=tensor[d] (cpu), sf2=float, s2=float, Z=device tensor or None).
@@ -474,12 +527,13 @@ class CollapsedBound:
             return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
                                  "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
-        direct = not _force_whitened and self._start_whitened(M)
+        direct = 0 if _force_whitened else self._start_whitened(M)
         if direct:
             self.n_direct_whitened += 1
-            _force_whitened = True
+            _force_whitened = direct
         res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0),
                             force_whitened=_force_whitened)
+        noted = False
         head = res["out"].numel() + 2  # [out | status word | pad], then the packed gradient (16-byte aligned)
         # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the
         # status and the gradient -- a failed factorization then costs a wasted pass 2 (its NaNs are discarded), which
@@ -489,7 +543,11 @@ class CollapsedBound:
             o, info, hh = self._fetch(res, upto=head)
             if self._guard_trips(res, hh):  # before pass 2 is spent on adjoints that cannot be trusted
                 self.n_guard_reruns += 1
-                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=True)
+                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M))
+            noted = True
+            if self._note_whitened(res, hh):  # an extended-order evaluation beyond that order's range: the whitened order, before pass 2
+                self.n_guard_reruns += 1
+                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=2)
             if info != 0:
                 self.n_evals += 1
                 self.n_grads += 1
@@ -511,8 +569,10 @@ class CollapsedBound:
         o, info, host = self._fetch(res, upto=head + nh + 1)
         if not early and self._guard_trips(res, host):
             self.n_guard_reruns += 1
-            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=True)
-        self._note_whitened(res, host)
+            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M))
+        if not noted and self._note_whitened(res, host):
+            self.n_guard_reruns += 1
+            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=2)
         self.n_evals += 1
         self.n_grads += 1
         if info != 0:
@@ -535,9 +595,13 @@ class CollapsedBound:
             self.n_direct_whitened += 1
         elif self._guard_trips(res, host):
             self.n_guard_reruns += 1
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=True)
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=self._choose_tier(Z.shape[0]))
             _, info, host = self._fetch(res)
-        self._note_whitened(res, host)
+        if self._note_whitened(res, host):
+            self.n_guard_reruns += 1
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=2)
+            _, info, host = self._fetch(res)
+            self._note_whitened(res, host)
         if info != 0:
             raise NotPositiveDefiniteError(info)
         return res["factors"]

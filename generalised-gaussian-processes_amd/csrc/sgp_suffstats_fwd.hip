@@ -645,6 +645,145 @@ __global__ __launch_bounds__(256) void tpart_kernel(const double* __restrict__ T
   bpart[((row0 + rbase) / ASM_ROWS) * Mp + m] = (a0 + a1) + (a2 + a3);
 }
 
+// ---- the extended streaming order (round 4): Phi to 2^-61, the triple product in double-double -------------------------------------
+// Phi as an unevaluated sum hi + lo: the splits' (slab, slab_lo) tiles added in double-double in a fixed order, both triangles written,
+// Mp x Mp (ld Mp), no amplitude.  One block per 32 x 32 sub-block of the lower triangle, as reduce_phi_kernel.
+__global__ __launch_bounds__(256) void reduce_phi_dd_kernel(const double* __restrict__ slab, const double* __restrict__ slab_lo, int nsplit,
+                                                            int ntiles, int Mp, double* __restrict__ Ph, double* __restrict__ Pl) {
+#pragma clang fp contract(off)
+  __shared__ double th[32][33], tl[32][33];
+  const int t = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  while (bi * (bi + 1) / 2 > t) --bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Ti = (bi * 32) / TILE, Tj = (bj * 32) / TILE;
+  const size_t tbase = (size_t)(Ti * (Ti + 1) / 2 + Tj) * (TILE * TILE), sstride = (size_t)ntiles * (TILE * TILE);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int lr = ty + 8 * k;
+    const int gi = bi * 32 + lr, gj = bj * 32 + tx;
+    double hi = 0.0, lo = 0.0;
+    if (gi >= gj) {
+      const size_t off = tbase + (size_t)(gi - Ti * TILE) * TILE + (gj - Tj * TILE);
+      for (int sp = 0; sp < nsplit; ++sp) {
+        const double a = slab[sp * sstride + off], b = slab_lo[sp * sstride + off];
+        const double sum = hi + a;
+        const double z = sum - hi;
+        lo += ((hi - (sum - z)) + (a - z)) + b;
+        hi = sum;
+      }
+      const double sum = hi + lo;
+      lo -= sum - hi;
+      hi = sum;
+    }
+    th[lr][tx] = hi;
+    tl[lr][tx] = lo;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int lr = ty + 8 * k;
+    const int gi = bi * 32 + lr, gj = bj * 32 + tx;
+    if (gi >= gj) { Ph[(size_t)gi * Mp + gj] = th[lr][tx]; Pl[(size_t)gi * Mp + gj] = tl[lr][tx]; }
+    const int mi = bj * 32 + lr, mj = bi * 32 + tx;  // mirrored element, row-contiguous store
+    if (mj > mi) { Ph[(size_t)mi * Mp + mj] = th[tx][lr]; Pl[(size_t)mi * Mp + mj] = tl[tx][lr]; }
+  }
+}
+
+// C (double-double) = A (double-double, n x n) B^T (fp64, n x n), all ld n, n a multiple of 64; tr: C is written transposed.  Plain fp64
+// VALU: two_prod by fma, two_sum, no contraction -- 64 x 64 tiles of 256 threads, 4 x 4 outputs per thread, 16-deep k-chunks through
+// LDS (tools/dd_gemm_proto.hip: both products of W = L^-1 Phi L^-T in 1.14 ms at n = 1024, 3e-18 of max |W| against long doubles).
+constexpr int DDT = 64, DDK = 16;
+__global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restrict__ Ahi, const double* __restrict__ Alo,
+                                                         const double* __restrict__ B, int n, double* __restrict__ Chi,
+                                                         double* __restrict__ Clo, int tr) {
+#pragma clang fp contract(off)
+  __shared__ double sAh[DDK][DDT + 1], sAl[DDK][DDT + 1], sB[DDK][DDT + 1];
+  const int i0 = blockIdx.y * DDT, j0 = blockIdx.x * DDT, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double hi[4][4], lo[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) hi[a][b] = lo[a][b] = 0.0;
+  for (int k0 = 0; k0 < n; k0 += DDK) {
+    for (int e = tid; e < DDT * DDK; e += 256) {
+      const int r = e / DDK, kk = e % DDK;
+      sAh[kk][r] = Ahi[(size_t)(i0 + r) * n + k0 + kk];
+      sAl[kk][r] = Alo[(size_t)(i0 + r) * n + k0 + kk];
+      sB[kk][r] = B[(size_t)(j0 + r) * n + k0 + kk];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < DDK; ++kk) {
+      double ah[4], al[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { ah[a] = sAh[kk][ti + 16 * a]; al[a] = sAl[kk][ti + 16 * a]; bv[a] = sB[kk][tj + 16 * a]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double pr = ah[a] * bv[b];
+          const double e = fma(ah[a], bv[b], -pr) + al[a] * bv[b];
+          const double sum = hi[a][b] + pr;
+          const double z = sum - hi[a][b];
+          lo[a][b] += ((hi[a][b] - (sum - z)) + (pr - z)) + e;
+          hi[a][b] = sum;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double sum = hi[a][b] + lo[a][b];
+      const double l = lo[a][b] - (sum - hi[a][b]);
+      const int i = i0 + ti + 16 * a, j = j0 + tj + 16 * b;
+      const size_t o = tr ? (size_t)j * n + i : (size_t)i * n + j;
+      Chi[o] = sum;
+      Clo[o] = l;
+    }
+}
+// W (M x M, ld M) = scale * (Wh + Wl), the lower triangle's value on both sides (the two products round the two triangles differently)
+__global__ __launch_bounds__(256) void ext_w_out_kernel(const double* __restrict__ Wh, const double* __restrict__ Wl, int M, int Mp,
+                                                        double scale, double* __restrict__ W) {
+  const int64_t total = (int64_t)M * M;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / M), j = (int)(e - (int64_t)i * M);
+    const int r = i > j ? i : j, c = i > j ? j : i;
+    W[e] = scale * (Wh[(size_t)r * Mp + c] + Wl[(size_t)r * Mp + c]);
+  }
+}
+
+struct ExtWs {
+  double *Xs, *ys, *Zs, *slab, *slab_lo, *bpart, *btmp, *yypart, *Ph, *Pl, *Yh, *Yl, *Wh, *Wl, *bpad, *upad;
+  uint8_t* Q;
+  size_t bytes;
+};
+static ExtWs carve_ext(void* ws, const StreamPlan& p, int64_t qrows) {
+  Carver c(ws);
+  ExtWs w;
+  const size_t mm = (size_t)p.Mp * p.Mp, ns = (size_t)i8_nsplit(qrows > 0 ? qrows : 1, p.Mp) * p.ntiles * TILE * TILE;
+  w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
+  w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
+  w.Zs = c.take<double>((size_t)p.Mp * p.DP);
+  w.slab = c.take<double>(ns);
+  w.slab_lo = c.take<double>(ns);
+  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
+  w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
+  w.yypart = c.take<double>(256);
+  w.Ph = c.take<double>(mm); w.Pl = c.take<double>(mm);
+  w.Yh = c.take<double>(mm); w.Yl = c.take<double>(mm);
+  w.Wh = c.take<double>(mm); w.Wl = c.take<double>(mm);
+  w.bpad = c.take<double>(p.Mp);
+  w.upad = c.take<double>(p.Mp);
+  w.Q = c.take<uint8_t>((size_t)(qrows > 0 ? qrows : 1) * p.Mp * 7);
+  w.bytes = c.used();
+  return w;
+}
+
 struct WhRowsWs {
   FwdWs f;
   double *R, *T;
@@ -892,5 +1031,68 @@ extern "C" int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, con
   reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.f.slab, p.nsplit, p.ntiles, M, sf2 * sf2, W);
   bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.f.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.f.btmp);
   finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.f.btmp, BRED_G, p.Mp, M, w.f.yypart, 256, sf2, sf2 * (double)N, u, yy, kappa);
+  return check_launch();
+}
+
+
+// ---- the extended streaming order ---------------------------------------------------------------------------------------------
+// The same whitened statistics [W = A A^T | u = A y | yy | kappa], A = L^-1 K_uf, from the STREAMING design: Phi = K'^T K' on the integer
+// matrix cores with 34 digit pairs and a double-double fold / slab reduction (exact sums of the fixed-point kernel values to 2^-61 of the
+// largest entry instead of fp64's 2^-53), then W = L^-1 Phi L^-T by two double-double products, u = L^-1 b in fp64 (a CPU study finds it
+// harmless, tests/studies/extended_streaming_order.py).  What the explicit-inverse sandwich amplifies is 2^8 times smaller than in
+// sgp_suffstats_fwd + sgp_bound_from_stats, so the streaming order's guard (sgp_streaming_error_estimate) passes 256 times later; the cost
+// is 14.0 instead of 11.7 ms of contraction and ~1.5 ms of tail at C5 against the whitened order's two extra N M^2 products.
+// Stationary kernels; rows x Mp^2 of any size (the integer contraction is used whatever the context's contraction mode says).
+// Kfu_out (optional, sgp_kfu_len doubles): the fp64 K'_fu for sgp_suffstats_bwd (explicit Phibar).
+extern "C" size_t sgp_suffstats_extended_workspace_bytes(int64_t N, int M, int d) {
+  if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
+  StreamPlan p = make_stream_plan(N, M, d);
+  return carve_ext(nullptr, p, p.sc_rows).bytes;
+}
+extern "C" int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                          const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                          const double* kuu_linv, double* W, double* u, double* yy, double* kappa, double* Kfu_out,
+                                          void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!Z || !inv_ls || !kuu_linv || !W || !u || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id >= SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  StreamPlan p = make_stream_plan(N, M, d);
+  const int64_t qrows = p.sc_rows;
+  ExtWs w = carve_ext(ws, p, qrows);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  KernArgs ka;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  ka.sf2 = sf2;
+  ka.d = d;
+  stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
+  const int ns = i8_nsplit(qrows > 0 ? qrows : 1, p.Mp);
+  const size_t nslab = (size_t)ns * p.ntiles * TILE * TILE;
+  if (p.Npad == 0) {
+    fill_zero(w.slab, nslab, st);
+    fill_zero(w.slab_lo, nslab, st);
+  }
+  for (int64_t r0 = 0; r0 < p.Npad; r0 += qrows) {
+    const int64_t rows = (p.Npad - r0) < qrows ? (p.Npad - r0) : qrows;
+    timing_begin(TIMING_ASSEMBLE, st);
+    i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Q, Kfu_out ? Kfu_out + (size_t)r0 * p.Mp : nullptr, w.bpart, st);
+    timing_end(TIMING_ASSEMBLE, st);
+    timing_begin(TIMING_SYRK, st);
+    if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st, w.slab_lo) != SGP_OK) return SGP_ERR_LAUNCH;
+    timing_end(TIMING_SYRK, st);
+  }
+  const int nb32 = p.Mp / 32;
+  reduce_phi_dd_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, w.slab_lo, ns, p.ntiles, p.Mp, w.Ph, w.Pl);
+  const dim3 g(p.Mp / DDT, p.Mp / DDT);
+  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(w.Ph, w.Pl, kuu_linv, p.Mp, w.Yh, w.Yl, 1);  // Y^T = (Phi L^-T)^T
+  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(w.Yh, w.Yl, kuu_linv, p.Mp, w.Wh, w.Wl, 0);  // W = Y^T L^-T = L^-1 Phi L^-T (symmetric)
+  ext_w_out_kernel<<<1024, 256, 0, st>>>(w.Wh, w.Wl, M, p.Mp, sf2 * sf2, W);
+  // b = K_uf y (fp64, with its amplitude), u = L^-1 b
+  fill_zero(w.bpad, p.Mp, st);
+  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);
+  finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.btmp, BRED_G, p.Mp, M, w.yypart, 256, sf2, sf2 * (double)N, w.bpad, yy, kappa);
+  gemv(kuu_linv, p.Mp, p.Mp, false, w.bpad, w.upad, st);
+  crop_copy(w.upad, 1, u, 1, M, 1, st);
   return check_launch();
 }

@@ -149,15 +149,16 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
 // 2. contraction
 // ---------------------------------------------------------------------------------------------
 constexpr int I8_PSPLIT = 5;  // MFMA batches 0 .. 4 (15 MFMAs) in the first half of a step, batches 5, 6 (13) in the second
-// A/B (tools/ab_build.sh -DSGP_AB_I8_PAIRS34): keep the digit pairs p + r >= 5 as well -- 34 products in 8 significance groups, the
-// truncation 2^-8 of today's.  What an extended-precision streaming order would pay in pass 1; the fold stays fp64
-// here, so the statistics only gain the smaller truncation.
+// MINSUM: the digit pairs p + r >= MINSUM are kept, in 13 - MINSUM significance groups g = p + r - MINSUM.  6 (the statistics of the streaming
+// order): 28 products, truncation < 6 x 2^-54 per product.  5 (the EXTENDED streaming order, sgp_suffstats_fwd_extended): 34 products in 8
+// groups, truncation 2^-8 of that (14.0 against 11.7 ms at C5, profiles/r04_ab_i8_pairs34.txt), and with DD the fold keeps what fp64
+// would round away: the tile leaves as an unevaluated sum hi + lo (lo in a second slab, `lo_off` doubles behind the first).
+// A/B (tools/ab_build.sh -DSGP_AB_I8_PAIRS34): the default contraction with 34 pairs.
 #ifdef SGP_AB_I8_PAIRS34
-constexpr int I8_MINSUM = 5;
+constexpr int I8_MINSUM_DEFAULT = 5;
 #else
-constexpr int I8_MINSUM = 6;
+constexpr int I8_MINSUM_DEFAULT = 6;
 #endif
-constexpr int I8_NG = 13 - I8_MINSUM;  // significance groups g = p + r - I8_MINSUM
 static_assert(2 * I8_PPW - 1 <= I8_PSPLIT * (I8_PSPLIT + 1) / 2, "every DMA piece must find its MFMA in the first half");
 
 // Eight waves in two groups (waves 0-3 / 4-7: one of each per SIMD) that run HALF A STEP apart.  A step = 32 data rows = 28 MFMAs per
@@ -174,9 +175,10 @@ static_assert(2 * I8_PPW - 1 <= I8_PSPLIT * (I8_PSPLIT + 1) / 2, "every DMA piec
 // one younger stage outstanding); group A reads the stage right after E(s), group B after O(s); the slot of stage s + 2 held
 // stage s - 1, whose last reads group B issued after O(s - 1) and retires (lgkmcnt(0)) before E(s); all reads of a step precede its DMAs (a ds_read behind a global_load_lds of the same wave
 // waits for that DMA to land).  Lockstep variants measured slower: four waves with 64 x 32 tiles 13.5 ms, eight unstaggered 13.5.
-template <bool ACT>
+template <bool ACT, int I8_MINSUM, bool DD>
 __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __restrict__ Q, int Mp, int64_t c0, int64_t c1, int I0,
-                                             int J0, int accumulate, double* __restrict__ out, int wave, int lane, int prio) {
+                                             int J0, int accumulate, double* __restrict__ out, size_t lo_off, int wave, int lane, int prio) {
+  constexpr int I8_NG = 13 - I8_MINSUM;
   const int grp = wave >> 2, w4 = wave & 3;
   const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;  // 32 x 32 tile (wi, wj) of the 128 x 64 tile: the groups interleave the row blocks
   const int l32 = lane & 31, lh = lane >> 5;
@@ -290,18 +292,38 @@ __device__ __forceinline__ void i8_tile_loop(uint8_t* lds, const uint8_t* __rest
   if (ACT) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      double v = 0.0;
-#pragma unroll
-      for (int g = 0; g < I8_NG; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * (g + I8_MINSUM) - 108), v);
       const int row = wi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
       double* dst = out + row * TILE + wj * 32 + l32;
-      *dst = accumulate ? *dst + v : v;
+      if constexpr (DD) {
+#pragma clang fp contract(off)
+        // every term acc_g 2^e is exact; the sum of the eight is carried as hi + lo (two_sum per term, least significant first)
+        double hi = 0.0, lo = 0.0;
+        if (accumulate) { hi = dst[0]; lo = dst[lo_off]; }
+#pragma unroll
+        for (int g = 0; g < I8_NG; ++g) {
+          const double t = (double)acc[g][r] * __builtin_ldexp(1.0, 8 * (g + I8_MINSUM) - 108);
+          const double sum = hi + t;
+          const double z = sum - hi;
+          lo += (hi - (sum - z)) + (t - z);
+          hi = sum;
+        }
+        const double sum = hi + lo;
+        dst[lo_off] = lo - (sum - hi);
+        dst[0] = sum;
+      } else {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < I8_NG; ++g) v = fma((double)acc[g][r], __builtin_ldexp(1.0, 8 * (g + I8_MINSUM) - 108), v);
+        *dst = accumulate ? *dst + v : v;
+      }
     }
   }
 }
 
+template <int MINSUM, bool DD>
 __global__ __launch_bounds__(512, 1) void i8_syrk_tile_kernel(const uint8_t* __restrict__ Q, int Mp, int64_t nsteps, int nsplit,
-                                                              int ntiles, int ntiles128, int accumulate, double* __restrict__ slab, int prio) {
+                                                              int ntiles, int ntiles128, int accumulate, double* __restrict__ slab,
+                                                              size_t lo_off, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t i8_lds[];
   // id -> (xcd, tile, split group): the tiles of a split share id % 8, i.e. one XCD under round-robin dispatch (as syrk_tile_kernel)
   const int id = blockIdx.x;
@@ -324,9 +346,9 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_tile_kernel(const uint8_t* __r
   const int grp = wave >> 2, w4 = wave & 3;
   const int wi = (w4 >> 1) * 2 + grp, wj = w4 & 1;
   if (J0 + 32 * wj <= I0 + 32 * wi + 31)
-    i8_tile_loop<true>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane, prio);
+    i8_tile_loop<true, MINSUM, DD>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, lo_off, wave, lane, prio);
   else
-    i8_tile_loop<false>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, wave, lane, prio);
+    i8_tile_loop<false, MINSUM, DD>(i8_lds, Q, Mp, c0, c1, I0, J0, accumulate, out, lo_off, wave, lane, prio);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,16 +389,24 @@ void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* y
 
 // slab[split][128 x 128 tile of the lower triangle] (+)= this split's part of K'^T K' (without sf2^2), as syrk_tile_kernel
 // leaves it for reduce_phi_kernel.  rows: a multiple of 32; nsplit from i8_nsplit() (the same for every super-chunk).
-int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st) {
+int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st, double* slab_lo) {
   Ctx& cx = cur_ctx();
-  if (!cx.i8_attr_set) {  // per context, i.e. per device (the attribute belongs to the device's copy of the kernel)
-    if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) != hipSuccess)
+  if (!cx.i8_attr_set) {  // per context, i.e. per device (the attribute belongs to the device's copy of the kernels)
+    if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<I8_MINSUM_DEFAULT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            I8_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
+            hipSuccess)
       return SGP_ERR_LAUNCH;
     cx.i8_attr_set = true;
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
   const int prio = cx.i8_prio;  // A/B knob SGP_I8_PRIO (read when the context is created; measured a loss)
-  i8_syrk_tile_kernel<<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab, prio);
+  if (slab_lo)  // the extended order: 34 pairs, tiles as hi + lo
+    i8_syrk_tile_kernel<5, true><<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab,
+                                                                             (size_t)(slab_lo - slab), prio);
+  else
+    i8_syrk_tile_kernel<I8_MINSUM_DEFAULT, false><<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128,
+                                                                                               accumulate, slab, 0, prio);
   return SGP_OK;
 }
 

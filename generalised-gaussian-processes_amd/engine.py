@@ -209,6 +209,35 @@ class HipEngine:
         _lib.check("sgp_suffstats_fwd_whitened_rows", st)
         return out
 
+    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out: Optional[torch.Tensor] = None,
+                           kfu: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The whitened statistics [W | u | yy | kappa] from the EXTENDED streaming order (include/sgp.h: sgp_suffstats_fwd_extended):
+        Phi on the integer matrix cores to 2^-61, the triple product in double-double.  ``kfu`` (from ``kfu_buffer``) keeps the fp64
+        K'_fu for ``suffstats_bwd``.  Stationary kernels."""
+        N, d = X.shape
+        M = Z.shape[0]
+        self._chk(Z, "Z"), self._chk(kuu_linv, "kuu_linv")
+        if N > 0:
+            self._chk(X, "X"), self._chk(y, "y")
+        if out is None:
+            out = self.empty(M * M + M + 2)
+        if kfu is not None:
+            self._chk(kfu, "kfu")
+            if kfu.numel() < self.lib.sgp_kfu_len(N, M):
+                raise ValueError("kfu holds %d doubles, sgp_kfu_len(N, M) = %d" % (kfu.numel(), self.lib.sgp_kfu_len(N, M)))
+        nbytes = self.lib.sgp_suffstats_extended_workspace_bytes(N, M, d)
+        if nbytes == 0:
+            raise ValueError("unsupported shape N=%d M=%d d=%d" % (N, M, d))
+        ws = self._workspace("fwd_extended", nbytes)
+        base = out.data_ptr()
+        st = self.lib.sgp_suffstats_fwd_extended(
+            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+            self._ptr(kuu_linv), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu) if kfu is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
+            self._stream())
+        _lib.check("sgp_suffstats_fwd_extended", st)
+        return out
+
     def pack_lower(self, stats: torch.Tensor, M: int) -> torch.Tensor:
         """[lower triangle of Phi | b | yy | kappa]: what crosses xGMI (half the bytes of ``stats``)."""
         tri = self.empty(self.lib.sgp_stats_packed_len(M))

@@ -326,6 +326,21 @@ int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, const double* 
                                     int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
                                     double* W, double* u, double* yy, double* kappa, double* T_out,
                                     void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* The EXTENDED streaming order (round 4): the same statistics [W | u | yy | kappa] from the streaming design -- Phi = K_uf K_fu on the
+ * integer matrix cores with 34 instead of 28 digit pairs and a double-double fold / reduction (2^-61 of the largest entry instead of
+ * fp64's 2^-53), W = L^-1 Phi L^-T by two double-double M^3 products, u = L^-1 (K_uf y) in fp64.  What the explicit-inverse sandwich
+ * amplifies is 2^8 times smaller than in sgp_suffstats_fwd + sgp_bound_from_stats: a caller whose sgp_streaming_error_estimate exceeds its
+ * tolerance by less than that factor can stay in the streaming design (one N M^2 contraction, 14.0 instead of 11.7 ms at C5) instead of
+ * paying the whitened order's two extra N M^2 products.  Stationary kernels only; the integer contraction is used whatever the context's
+ * contraction mode says.  Kfu_out (DEVICE, sgp_kfu_len(N, M) doubles, or NULL): the fp64 K'_fu for sgp_suffstats_bwd with the explicit
+ * Phibar that sgp_bound_from_whitened_stats returns (adequate where this order is: the product Phibar K_uf cancels ~600-fold at the
+ * estimates in question, not cond(K_uu)-fold).  Same all-reduce as the other two orders.                                              */
+size_t sgp_suffstats_extended_workspace_bytes(int64_t N, int M, int d);
+int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y,
+                               const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                               int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
+                               double* W, double* u, double* yy, double* kappa, double* Kfu_out,
+                               void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_bound_from_whitened_stats(const double* W, const double* u, const double* yy, const double* kappa,
                                   double s2, int64_t N, int M, int with_adjoints, double* out,
                                   double* Phibar, double* bbar, double* Kuubar, double* factors,

@@ -291,3 +291,14 @@ class FactoredOracleEngine(GuardedOracleEngine):
         g = self.suffstats_bwd(X, y, Z, ls, sf2, Phibar, bbar, kappabar, kernel, want_gz, out)
         self.calls["suffstats_bwd"] = n
         return g
+
+    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None):
+        """sgp_suffstats_fwd_extended: the same whitened statistics (the oracle has one way to compute them), K'_fu kept in `kfu`."""
+        self.calls["suffstats_extended"] = self.calls.get("suffstats_extended", 0) + 1
+        n = self.calls["suffstats_whitened"]
+        packed = self.suffstats_whitened(X, y, Z, ls, sf2, kuu_linv, kernel, out)
+        self.calls["suffstats_whitened"] = n
+        if kfu is not None and X.shape[0] > 0:
+            M, d = Z.shape
+            kfu[: X.shape[0] * M] = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel]).reshape(-1)
+        return packed

@@ -1,0 +1,126 @@
+"""The EXTENDED streaming order (sgp_suffstats_fwd_extended: Phi on the integer matrix cores with 34 digit pairs and a double-double fold,
+W = L^-1 Phi L^-T by two double-double products) against the whitened order it stands in for, the oracle, and autograd.  Tolerances: W, u
+against the whitened routine 1e-10 of the largest entry on well-conditioned problems (both are accurate there; the explicit inverse's
+rounding is common to both); F against the PyMC3-order oracle 1e-9 per datum where the streaming order itself is off by 1e-7 .. 1e-6;
+gradients (explicit Phibar on the kept K'_fu) against autograd 1e-6."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def unpack(packed, M):
+    p = packed.cpu().numpy()
+    return p[: M * M].reshape(M, M), p[M * M: M * M + M], p[M * M + M], p[M * M + M + 1]
+
+
+def problem(N, M, d, seed, ls=1.4):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X[:, 0]) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[torch.randperm(N, generator=g)[:M]].clone() + 0.05 * torch.randn(M, d, dtype=torch.float64, generator=g)
+    return X, y, Z, [ls * (1.0 + 0.1 * j) for j in range(d)]
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern52"])
+@pytest.mark.parametrize("N,M,d", [(5000, 200, 3), (777, 130, 1), (20000, 384, 5), (0, 96, 2), (1, 64, 2)])
+def test_extended_statistics_match_the_whitened_order(engine, kernel, N, M, d):
+    X, y, Z, ls = problem(max(N, 1), M, d, N + M)
+    X, y = X[:N], y[:N]
+    sf2 = 1.7
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    linv, info = engine.kuu_factor(engine.kuu(Zd, ls, sf2, 1e-6, kernel))
+    assert int(info.item()) == 0
+    ref = engine.suffstats_whitened_rows(Xd, yd, Zd, ls, sf2, linv, kernel)
+    kfu = engine.kfu_buffer(N, M)
+    kfu.fill_(float("nan"))
+    ext = engine.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, kernel, kfu=kfu)
+    assert torch.equal(ext, engine.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, kernel))       # with or without the kept block; reproducible
+    W0, u0, yy0, ka0 = unpack(ref, M)
+    W1, u1, yy1, ka1 = unpack(ext, M)
+    if N == 0:
+        assert not W1.any() and not u1.any() and yy1 == 0.0 and ka1 == 0.0
+        return
+    assert relerr(W1, W0) < 1e-10 and relerr(u1, u0) < 1e-10 and abs(yy1 - yy0) <= 1e-13 * abs(yy0) and ka1 == ka0
+    assert np.array_equal(W1, W1.T)
+    # the kept block is the K'_fu the streaming order keeps, bit for bit
+    k2 = engine.kfu_buffer(N, M)
+    engine.suffstats(Xd, yd, Zd, ls, sf2, kernel, kfu=k2)
+    n = engine.lib.sgp_kfu_len(N, M)
+    assert torch.equal(kfu[:n], k2[:n])
+
+
+def test_extended_statistics_accumulate_over_super_chunks(engine):
+    X, y, Z, ls = problem(9000, 256, 4, 5)
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    linv, _ = engine.kuu_factor(engine.kuu(Zd, ls, 1.0, 1e-6, "rbf"))
+    one = engine.suffstats_extended(Xd, yd, Zd, ls, 1.0, linv, "rbf")
+    try:
+        engine.lib.sgp_set_kfu_budget_bytes(2048 * 256 * 8)            # 2048 rows at a time: 5 super-chunks, the last one short
+        engine._ws.pop("fwd_extended", None)
+        many = engine.suffstats_extended(Xd, yd, Zd, ls, 1.0, linv, "rbf")
+    finally:
+        engine.lib.sgp_set_kfu_budget_bytes(0)
+        engine._ws.pop("fwd_extended", None)
+    Wa, ua, _, _ = unpack(one, 256)
+    Wb, ub, _, _ = unpack(many, 256)
+    assert relerr(Wb, Wa) < 1e-14 and relerr(ub, ua) < 1e-13          # the double-double sums differ in their last bits only
+
+
+def test_extended_order_where_the_streaming_order_fails(engine):
+    """N = 200 000, M = 512, long lengthscales: the streaming order is off by 1e-7 .. 1e-4 per datum, the extended order agrees with the
+    PyMC3-order oracle to 1e-9 per datum where its range (estimate <= 128 x the tolerance) ends, and the bound built with form="auto"
+    picks the tier by itself."""
+    import bench
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    N, M, D = 200000, 512, 8
+    X, y, Z = bench.synth(N, M, D)
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    ce = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine, form="extended")
+    cs = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine)
+    cs.streaming_tol = float("inf")
+    ca = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine)
+    torch.set_num_threads(max(1, (torch.get_num_threads())))
+    seen_tier1 = 0
+    for ls, sn in ((3.0, 0.3), (4.0, 0.3), (5.0, 0.3)):
+        F_ref = float(O.vfe_pymc3_order_chunked(X, y, Z, torch.full((D,), ls, dtype=torch.float64), 1.0, sn, 1e-6))
+        Fs, _ = cs.value(Zd, [ls] * D, 1.0, sn * sn)
+        est = cs.last_estimate
+        Fe, _ = ce.value(Zd, [ls] * D, 1.0, sn * sn)
+        if est <= 128e-9:
+            assert abs(Fe - F_ref) / N < 1e-9, (ls, sn, est, abs(Fe - F_ref) / N, abs(Fs - F_ref) / N)
+        before = ca.n_extended
+        Fa, _ = ca.value(Zd, [ls] * D, 1.0, sn * sn)
+        assert abs(Fa - F_ref) / N < 1e-8, (ls, sn, est)
+        if 1e-9 < est <= 128e-9 and ca.n_extended > before:
+            seen_tier1 += 1
+    assert seen_tier1 >= 1, "no cell of this sweep ran in the extended tier"
+
+
+def test_extended_order_gradients_against_autograd(engine):
+    """50 000 rows x 512 inducing points at a trained-like theta: value + gradient through the extended order (explicit Phibar on the
+    kept K'_fu) against torch autograd through the PyMC3-order graph."""
+    import bench
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    N, M, D = 50000, 512, 8
+    X, y, Z = bench.synth(N, M, D)
+    ls = torch.tensor([3.7, 2.6, 3.4, 5.5, 3.5, 3.2, 2.6, 3.7], dtype=torch.float64)
+    sf2, s2 = 1.1, 0.145 ** 2
+    ref = O.grads_autograd(X, y, Z, ls, sf2, s2, 1e-6)
+    cb = ggp_amd.CollapsedBound(X.to(engine.device), y.to(engine.device), jitter=1e-6, engine=engine, form="extended")
+    F, g = cb.value_and_grad(Z.to(engine.device), ls.tolist(), sf2, s2, want_gz=True)
+    assert abs(F - float(ref["F"])) / N < 1e-9
+    assert float((g["ls"] - ref["g_ls"]).abs().max()) < 1e-6 * float(ref["g_ls"].abs().max())
+    assert abs(g["sf2"] - ref["g_sf2"]) < 1e-6 * max(1.0, abs(ref["g_sf2"])) and abs(g["s2"] - ref["g_s2"]) < 1e-6 * max(1.0, abs(ref["g_s2"]))
+    assert relerr(g["Z"].cpu().numpy(), ref["g_Z"].numpy()) < 1e-5

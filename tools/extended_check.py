@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""The extended streaming order (sgp_suffstats_fwd_extended) against the whitened order over theta at C5: F per datum through both, the
+streaming order's own error and estimate next to them, and the time of one extended evaluation.  One JSON line per theta."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import ggp_amd  # noqa: E402
+
+N = int(os.environ.get("ROWS", bench.N_TOTAL))
+M = int(os.environ.get("M", bench.M_IND))
+eng = ggp_amd.HipEngine()
+X, y, Z = bench.synth(N, M, bench.DIM)
+Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
+cs = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng)
+cs.streaming_tol = float("inf")
+cw = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="whitened")
+
+
+def extended(ls, sf2, s2):
+    Kuu = eng.kuu(Zd, ls, sf2, bench.JITTER, "rbf")
+    linv, info = eng.kuu_factor(Kuu)
+    packed = eng.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, "rbf")
+    res = eng.bound(Kuu, packed, s2, N, kuu_linv=linv, kuu_info=info, whitened=True)
+    return float(res["out"].cpu()[0]), int(res["info"].cpu()[0])
+
+
+for ls_v in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0):
+    for sn in (0.3, 0.145, 0.05):
+        ls = [ls_v] * bench.DIM
+        Fw, _ = cw.value(Zd, ls, 1.0, sn * sn, raise_on_fail=False)
+        Fs, ps = cs.value(Zd, ls, 1.0, sn * sn, raise_on_fail=False)
+        Fe, ie = extended(ls, 1.0, sn * sn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            extended(ls, 1.0, sn * sn)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate,
+                          "err_streaming": abs(Fs - Fw) / N if ps.get("info", 0) == 0 else None,
+                          "err_extended": abs(Fe - Fw) / N if ie == 0 else None, "info_extended": ie, "extended_ms": round(ms, 2)}), flush=True)
