@@ -444,11 +444,11 @@ def main():
         res["config"]["contraction"] = "fp64 matrix cores"
     res["config"]["streaming_guard"] = {
         "tolerance_per_datum": cb.streaming_tol, "estimate_per_datum": cb.last_estimate, "repeats_in_whitened_order": cb.n_guard_reruns,
-        "direct_whitened_evaluations": cb.n_direct_whitened,
+        "direct_whitened_evaluations": cb.n_direct_whitened, "extended_order_evaluations": cb.n_extended,
         "note": "first-order estimate of |dF| / N of the streaming order (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N), include/sgp.h: "
                 "sgp_streaming_error_estimate), read back with every evaluation; above the tolerance the evaluation is repeated in the "
-                "whitened (PyMC3) order, and so are the evaluations that follow it until the predicted estimate is below half the tolerance "
-                "-- 0 and 0 = every timed step ran the streaming design"}
+                "extended streaming order (estimate <= 128 x tolerance) or the whitened (PyMC3) order, and so are the evaluations that follow "
+                "it until the predicted estimate is below half the tolerance -- 0, 0 and 0 = every timed step ran the streaming design"}
     if world == 1:
         # what an evaluation costs where the guard sends it: the whitened (PyMC3) order on the same shard and theta, a few repetitions
         # outside the timed region (engine.suffstats_whitened_rows + suffstats_bwd_factored)
@@ -468,8 +468,29 @@ def main():
             tw.append((time.perf_counter() - t0) / 3 * 1e3)
         res["config"]["streaming_guard"]["whitened_order"] = {
             "ms_per_evaluation": tw[0], "ms_per_leapfrog": tw[1], "F_minus_streaming_F_per_datum": (Fw - last["F"]) / args.n,
-            "note": "not part of `value`: the cost of one evaluation / one value+gradient in the order the guard falls back to"}
+            "note": "not part of `value`: the cost of one evaluation / one value+gradient in the order the guard falls back to beyond "
+                    "128 x the tolerance"}
         del wb
+        # ... and in the tier between: the extended streaming order (engine.suffstats_extended), estimates up to 128 x the tolerance
+        xb = ggp_amd.CollapsedBound(Xd, yd, kernel="rbf", jitter=JITTER, engine=eng, form="extended")
+        xb._kfu = cb._kfu
+        xv = lambda: xb.value(Zd, ls, sf2, s2)  # noqa: E731
+        xg = lambda: xb.value_and_grad(Zd, ls, sf2, s2, want_gz=False)  # noqa: E731
+        Fx = xv()[0]
+        xg()
+        torch.cuda.synchronize(dev)
+        tx = []
+        for fn in (xv, xg):
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            tx.append((time.perf_counter() - t0) / 3 * 1e3)
+        res["config"]["streaming_guard"]["extended_order"] = {
+            "ms_per_evaluation": tx[0], "ms_per_leapfrog": tx[1], "F_minus_whitened_F_per_datum": (Fx - Fw) / args.n,
+            "note": "not part of `value`: Phi on the integer cores with 34 digit pairs and a double-double fold, W = L^-1 Phi L^-T in "
+                    "double-double, pass 2 from the explicit Phibar"}
+        del xb
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

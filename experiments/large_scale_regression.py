@@ -63,7 +63,8 @@ def main():
                       "leapfrogs_per_sec": trace.n_leapfrog / wall, "step_size": float(steps[0]),
                       "sig_n_mean": float(trace["sig_n"].mean()), "ls_mean": trace["ls"].mean(0).tolist(),
                       # leapfrogs the streaming-order guard sent to the whitened (PyMC3) order
-                      "guard_repeats": int(hmc._hmc_bound().n_guard_reruns), "direct_whitened": int(hmc._hmc_bound().n_direct_whitened), "guard_tolerance_per_datum": hmc._hmc_bound().streaming_tol,
+                      "guard_repeats": int(hmc._hmc_bound().n_guard_reruns), "direct_whitened": int(hmc._hmc_bound().n_direct_whitened),
+                      "extended_order": int(getattr(hmc._hmc_bound(), "n_extended", 0)), "guard_tolerance_per_datum": hmc._hmc_bound().streaming_tol,
                       "guard_last_estimate_per_datum": hmc._hmc_bound().last_estimate, "evaluations": int(hmc._hmc_bound().n_evals)}
     print(json.dumps(out))
 
