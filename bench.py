@@ -315,8 +315,8 @@ def main():
     syrk_traffic, syrk_file = pmc_traffic("sgp::syrk_tile_kernel<") if default_cfg else (None, None)
     kbar_traffic, kbar_file = pmc_traffic("kbar_contract_kernel") if default_cfg else (None, None)
     syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12
-    i8_traffic, i8_file = pmc_traffic("sgp::i8_syrk_tile_kernel(") if default_cfg else (None, None)
-    i8_busy, i8_busy_file = pmc_mfma_busy("sgp::i8_syrk_tile_kernel(") if default_cfg else (None, None)
+    i8_traffic, i8_file = pmc_traffic("sgp::i8_syrk_tile_kernel<6, false>(") if default_cfg else (None, None)
+    i8_busy, i8_busy_file = pmc_mfma_busy("sgp::i8_syrk_tile_kernel<6, false>(") if default_cfg else (None, None)
     syrk_busy, _ = pmc_mfma_busy("sgp::syrk_tile_kernel<") if default_cfg else (None, None)
     kbar_busy, _ = pmc_mfma_busy("sgp::kbar_contract_kernel<") if default_cfg else (None, None)
     q_bytes = 7.0 * ((n_local + 255) // 256 * 256) * Mp          # digit planes: 7 bytes per element of K'_fu
