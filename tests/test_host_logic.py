@@ -549,3 +549,49 @@ def test_three_tier_guard_on_the_cpu_double():
         assert e3.calls.get("suffstats_extended", 0) == 0 and e3.calls["suffstats_whitened_rows"] == 1
     finally:
         pkg.CollapsedBound.WHITENED_MAX_WORK = old
+
+
+def _tier_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ggp_amd as pkg
+    from fake_engine import FactoredOracleEngine
+    X, y, Z = _guard_problem()
+    pkg.CollapsedBound.WHITENED_MAX_WORK = 0
+    lo, hi = pkg.shard_rows(X.shape[0], rank, world)
+    eng = FactoredOracleEngine()
+    cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=1e-6, engine=eng)
+    cb.whitened_rows_min_work = 0
+    out = []
+    for ls, s2 in ((0.8, 0.3), (3.0, 1e-2), (3.0, 1e-2), (5.0, 1e-3), (5.0, 1e-3), (3.0, 1e-2), (0.8, 0.3), (0.8, 0.3)):
+        F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
+        out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns, cb.n_direct_whitened, cb.n_extended, cb.n_collectives,
+                    cb._prefer_whitened, cb._pred_est))
+    q.put((rank, out, eng.calls.get("suffstats_extended", 0), eng.calls["suffstats_whitened_rows"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_three_tier_decisions_are_identical_on_every_rank():
+    """The tier of every evaluation (streaming, extended, whitened), the repeats and the collective counts are functions of replicated
+    numbers: two ranks walking benign -> mid -> far -> mid -> benign theta take them in lockstep and return the same bits."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tier_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[0][1] == outs[1][1] and outs[0][2:] == outs[1][2:]
+    a = outs[0][1]
+    assert a[0][2:5] == (0, 0, 0)                      # benign: streamed
+    assert a[1][4] == 1 and a[2][4] == 2               # mid: the trip's repeat and the next evaluation ran in the extended order
+    assert a[4][4] == a[3][4] and outs[0][3] >= 2      # far: whitened (the extended attempt of the first one was repeated)
+    assert not a[-1][6]                                # the episode has ended
