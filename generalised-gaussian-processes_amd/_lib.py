@@ -101,7 +101,7 @@ PROTOTYPES = {
     "sgp_suffstats_fwd_whitened_rows": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
                                                _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_extended_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "sgp_suffstats_fwd_extended": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
+    "sgp_suffstats_fwd_extended": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -161,9 +161,17 @@ class CollapsedBound:
         self._est_ratio = 1.0
         # Between the two there is the EXTENDED streaming order (engine.suffstats_extended: Phi on the integer cores to 2^-61, the triple
         # product in double-double): what the sandwich amplifies is 2^8 times smaller, so an evaluation whose estimate is within
-        # `extended_range` x the tolerance (2^7: half of that factor kept as margin) is repeated THERE -- one N M^2 contraction, 19.4 ms
-        # at C5 -- and only beyond it in the whitened order (39.6 ms).  n_extended counts the evaluations that ran in it.
-        self.extended_range = 128.0
+        # `extended_range` x the tolerance is repeated THERE -- one N M^2 contraction, 20.3 ms at C5 -- and only beyond it in the whitened
+        # order (39.6 ms).  extended_level 2 = 39 digit pairs, 2^16 less amplified error (range 2^14: a factor 4 kept as margin; measured
+        # at C5 over 27 theta: <= 1.6e-10 per datum against the whitened order up to estimates of 3e-5, profiles/r04_extended_order_c5.jsonl);
+        # level 1 = 34 pairs, 2^8 (0.9 ms cheaper; range 2^7 then).  n_extended counts the evaluations that ran in it.
+        # GRADIENTS are another matter: pass 2 of the extended order takes the explicit Phibar, whose product with K_uf cancels -- against
+        # the factored pass 2 of the whitened order its lengthscale gradients are off by 7e-7 at an estimate of 4e-9, 3e-5 at 8e-8, 3e-2 at
+        # 2e-7 (same file).  A value + gradient evaluation therefore takes the extended order only within `extended_grad_range` x the
+        # tolerance, and the whitened order (which keeps K' L^-T for its factored pass 2) beyond.
+        self.extended_level = 2
+        self.extended_range = 16384.0
+        self.extended_grad_range = 3.0
         self.n_extended = 0
         self._pred_est = float("inf")
 
@@ -285,19 +293,22 @@ class CollapsedBound:
         return (hasattr(e, "suffstats_extended") and self.kernel != "composite" and self.extended_range > 1.0
                 and self._rows_for_form * int(M) >= self.whitened_rows_min_work)
 
-    def _choose_tier(self, M):
+    def _ext_range(self, with_grad):
+        return self.extended_grad_range if with_grad else self.extended_range
+
+    def _choose_tier(self, M, with_grad=False):
         """1 = the extended streaming order, 2 = the whitened order, for an evaluation whose streaming estimate is predicted as _pred_est."""
-        within = self._pred_est <= self.extended_range * self.streaming_tol  # (NaN / inf: the whitened order)
+        within = self._pred_est <= self._ext_range(with_grad) * self.streaming_tol  # (NaN / inf: the whitened order)
         return 1 if within and self._extended_ok(M) else 2
 
-    def _start_whitened(self, M):
+    def _start_whitened(self, M, with_grad=False):
         """0, or the tier (1 extended, 2 whitened) this evaluation should start in without a streaming attempt (the guard tripped
         recently and nothing says it would pass)."""
         if self.form == "extended":
             return 1
         if not (self._prefer_whitened and self._guard_on() and not self._whitened(M)):
             return 0
-        return self._choose_tier(M)
+        return self._choose_tier(M, with_grad)
 
     def _note_whitened(self, res, host):
         """After an extended- or whitened-order evaluation that carries the estimate's upper bound: learn the ratio at the theta where
@@ -318,7 +329,8 @@ class CollapsedBound:
         self._pred_est = self._est_ratio * ub
         if self._pred_est < 0.5 * self.streaming_tol:
             self._prefer_whitened = False
-        return res.get("tier") == 1 and self.form != "extended" and not (self._pred_est <= self.extended_range * self.streaming_tol)
+        return (res.get("tier") == 1 and self.form != "extended"
+                and not (self._pred_est <= self._ext_range(res.get("with_grad", False)) * self.streaming_tol))
 
     def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=0):
         """force_whitened: 0 = by `form`, 1 = the extended streaming order, 2 (or True) = the whitened order."""
@@ -331,14 +343,14 @@ class CollapsedBound:
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
             kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
-            packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu)
+            packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu, level=self.extended_level)
             self._allreduce_stats(packed, int(Z.shape[0]))
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True)
             if self._guard_on() and hasattr(e, "streaming_error_bound"):
                 e.streaming_error_bound(e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf()), sf2, s2, result)
                 res["bounded"] = True
-            res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv, tier=1)
+            res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv, tier=1, with_grad=bool(with_adjoints))
             return res
         if tier == 2 or self._whitened(Z.shape[0]):
             force_whitened = tier == 2
@@ -527,7 +539,7 @@ class CollapsedBound:
             return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
                                  "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
-        direct = 0 if _force_whitened else self._start_whitened(M)
+        direct = 0 if _force_whitened else self._start_whitened(M, with_grad=True)
         if direct:
             self.n_direct_whitened += 1
             _force_whitened = direct
@@ -543,7 +555,7 @@ class CollapsedBound:
             o, info, hh = self._fetch(res, upto=head)
             if self._guard_trips(res, hh):  # before pass 2 is spent on adjoints that cannot be trusted
                 self.n_guard_reruns += 1
-                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M))
+                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M, with_grad=True))
             noted = True
             if self._note_whitened(res, hh):  # an extended-order evaluation beyond that order's range: the whitened order, before pass 2
                 self.n_guard_reruns += 1
@@ -569,7 +581,7 @@ class CollapsedBound:
         o, info, host = self._fetch(res, upto=head + nh + 1)
         if not early and self._guard_trips(res, host):
             self.n_guard_reruns += 1
-            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M))
+            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M, with_grad=True))
         if not noted and self._note_whitened(res, host):
             self.n_guard_reruns += 1
             return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=2)

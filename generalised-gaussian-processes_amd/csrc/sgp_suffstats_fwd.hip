@@ -1051,11 +1051,11 @@ extern "C" size_t sgp_suffstats_extended_workspace_bytes(int64_t N, int M, int d
 }
 extern "C" int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
                                           const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
-                                          const double* kuu_linv, double* W, double* u, double* yy, double* kappa, double* Kfu_out,
-                                          void* ws, size_t ws_bytes, sgp_stream_t stream) {
+                                          const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
+                                          double* Kfu_out, void* ws, size_t ws_bytes, sgp_stream_t stream) {
   if (!Z || !inv_ls || !kuu_linv || !W || !u || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
-  if (kernel_id < 0 || kernel_id >= SGP_KERNEL_COMPOSITE) return SGP_ERR_ARG;
+  if (kernel_id < 0 || kernel_id >= SGP_KERNEL_COMPOSITE || level < 1 || level > 2) return SGP_ERR_ARG;
   if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   StreamPlan p = make_stream_plan(N, M, d);
   const int64_t qrows = p.sc_rows;
@@ -1079,7 +1079,7 @@ extern "C" int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const do
     i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Q, Kfu_out ? Kfu_out + (size_t)r0 * p.Mp : nullptr, w.bpart, st);
     timing_end(TIMING_ASSEMBLE, st);
     timing_begin(TIMING_SYRK, st);
-    if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st, w.slab_lo) != SGP_OK) return SGP_ERR_LAUNCH;
+    if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st, w.slab_lo, level) != SGP_OK) return SGP_ERR_LAUNCH;
     timing_end(TIMING_SYRK, st);
   }
   const int nb32 = p.Mp / 32;

@@ -389,19 +389,24 @@ void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* y
 
 // slab[split][128 x 128 tile of the lower triangle] (+)= this split's part of K'^T K' (without sf2^2), as syrk_tile_kernel
 // leaves it for reduce_phi_kernel.  rows: a multiple of 32; nsplit from i8_nsplit() (the same for every super-chunk).
-int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st, double* slab_lo) {
+int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st, double* slab_lo, int level) {
   Ctx& cx = cur_ctx();
   if (!cx.i8_attr_set) {  // per context, i.e. per device (the attribute belongs to the device's copy of the kernels)
     if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<I8_MINSUM_DEFAULT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             I8_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
             hipSuccess)
       return SGP_ERR_LAUNCH;
     cx.i8_attr_set = true;
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
   const int prio = cx.i8_prio;  // A/B knob SGP_I8_PRIO (read when the context is created; measured a loss)
-  if (slab_lo)  // the extended order: 34 pairs, tiles as hi + lo
+  if (slab_lo && level >= 2)  // the extended order, second level: 39 pairs (p + r >= 4), tiles as hi + lo
+    i8_syrk_tile_kernel<4, true><<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab,
+                                                                             (size_t)(slab_lo - slab), prio);
+  else if (slab_lo)  // the extended order: 34 pairs, tiles as hi + lo
     i8_syrk_tile_kernel<5, true><<<nsplit * ntiles, 512, I8_LDS_BYTES, st>>>(Q, Mp, rows / 32, nsplit, ntiles, ntiles128, accumulate, slab,
                                                                              (size_t)(slab_lo - slab), prio);
   else

@@ -210,10 +210,10 @@ class HipEngine:
         return out
 
     def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out: Optional[torch.Tensor] = None,
-                           kfu: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           kfu: Optional[torch.Tensor] = None, level: int = 1) -> torch.Tensor:
         """The whitened statistics [W | u | yy | kappa] from the EXTENDED streaming order (include/sgp.h: sgp_suffstats_fwd_extended):
         Phi on the integer matrix cores to 2^-61, the triple product in double-double.  ``kfu`` (from ``kfu_buffer``) keeps the fp64
-        K'_fu for ``suffstats_bwd``.  Stationary kernels."""
+        K'_fu for ``suffstats_bwd``.  ``level`` 1: 34 digit pairs (Phi to 2^-61), 2: 39 pairs (2^-69).  Stationary kernels."""
         N, d = X.shape
         M = Z.shape[0]
         self._chk(Z, "Z"), self._chk(kuu_linv, "kuu_linv")
@@ -232,7 +232,7 @@ class HipEngine:
         base = out.data_ptr()
         st = self.lib.sgp_suffstats_fwd_extended(
             self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
-            self._ptr(kuu_linv), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
+            self._ptr(kuu_linv), int(level), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu) if kfu is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
             self._stream())
         _lib.check("sgp_suffstats_fwd_extended", st)

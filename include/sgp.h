@@ -334,11 +334,12 @@ int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, const double* 
  * paying the whitened order's two extra N M^2 products.  Stationary kernels only; the integer contraction is used whatever the context's
  * contraction mode says.  Kfu_out (DEVICE, sgp_kfu_len(N, M) doubles, or NULL): the fp64 K'_fu for sgp_suffstats_bwd with the explicit
  * Phibar that sgp_bound_from_whitened_stats returns (adequate where this order is: the product Phibar K_uf cancels ~600-fold at the
- * estimates in question, not cond(K_uu)-fold).  Same all-reduce as the other two orders.                                              */
+ * estimates in question, not cond(K_uu)-fold).  Same all-reduce as the other two orders.
+ * level: 1 = 34 digit pairs (p + r >= 5, Phi to 2^-61, 14.0 ms of contraction at C5), 2 = 39 pairs (p + r >= 4, 2^-69, 16.3 ms).       */
 size_t sgp_suffstats_extended_workspace_bytes(int64_t N, int M, int d);
 int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y,
                                const double* Z, int64_t ldz, const double* inv_ls, double sf2,
-                               int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
+                               int64_t N, int M, int d, int kernel_id, const double* kuu_linv, int level,
                                double* W, double* u, double* yy, double* kappa, double* Kfu_out,
                                void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_bound_from_whitened_stats(const double* W, const double* u, const double* yy, const double* kappa,

@@ -292,9 +292,10 @@ class FactoredOracleEngine(GuardedOracleEngine):
         self.calls["suffstats_bwd"] = n
         return g
 
-    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None):
+    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None, level=1):
         """sgp_suffstats_fwd_extended: the same whitened statistics (the oracle has one way to compute them), K'_fu kept in `kfu`."""
         self.calls["suffstats_extended"] = self.calls.get("suffstats_extended", 0) + 1
+        self.calls["extended_level_%d" % level] = self.calls.get("extended_level_%d" % level, 0) + 1
         n = self.calls["suffstats_whitened"]
         packed = self.suffstats_whitened(X, y, Z, ls, sf2, kuu_linv, kernel, out)
         self.calls["suffstats_whitened"] = n

@@ -2,7 +2,8 @@
 W = L^-1 Phi L^-T by two double-double products) against the whitened order it stands in for, the oracle, and autograd.  Tolerances: W, u
 against the whitened routine 1e-10 of the largest entry on well-conditioned problems (both are accurate there; the explicit inverse's
 rounding is common to both); F against the PyMC3-order oracle 1e-9 per datum where the streaming order itself is off by 1e-7 .. 1e-6;
-gradients (explicit Phibar on the kept K'_fu) against autograd 1e-6."""
+gradients (explicit Phibar on the kept K'_fu) against autograd 1e-6 (inside the narrow range where a value + gradient evaluation takes this order: beyond an estimate
+of ~3e-9 the explicit Phibar cancels and CollapsedBound sends gradients to the whitened order, profiles/r04_extended_order_c5.jsonl)."""
 import math
 
 import numpy as np
@@ -78,8 +79,8 @@ def test_extended_statistics_accumulate_over_super_chunks(engine):
 
 def test_extended_order_where_the_streaming_order_fails(engine):
     """N = 200 000, M = 512, long lengthscales: the streaming order is off by 1e-7 .. 1e-4 per datum, the extended order agrees with the
-    PyMC3-order oracle to 1e-9 per datum where its range (estimate <= 128 x the tolerance) ends, and the bound built with form="auto"
-    picks the tier by itself."""
+    PyMC3-order oracle to 1e-9 per datum inside its range (estimate <= 2^14 x the tolerance), and the bound built with form="auto" picks
+    the tier by itself."""
     import bench
     import ggp_amd
     from oracle import vfe_oracle as O
@@ -92,17 +93,17 @@ def test_extended_order_where_the_streaming_order_fails(engine):
     ca = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine)
     torch.set_num_threads(max(1, (torch.get_num_threads())))
     seen_tier1 = 0
-    for ls, sn in ((3.0, 0.3), (4.0, 0.3), (5.0, 0.3)):
+    for ls, sn in ((3.0, 0.3), (4.0, 0.3), (5.0, 0.3), (8.0, 0.145)):
         F_ref = float(O.vfe_pymc3_order_chunked(X, y, Z, torch.full((D,), ls, dtype=torch.float64), 1.0, sn, 1e-6))
         Fs, _ = cs.value(Zd, [ls] * D, 1.0, sn * sn)
         est = cs.last_estimate
         Fe, _ = ce.value(Zd, [ls] * D, 1.0, sn * sn)
-        if est <= 128e-9:
+        if est <= 16384e-9:
             assert abs(Fe - F_ref) / N < 1e-9, (ls, sn, est, abs(Fe - F_ref) / N, abs(Fs - F_ref) / N)
         before = ca.n_extended
         Fa, _ = ca.value(Zd, [ls] * D, 1.0, sn * sn)
         assert abs(Fa - F_ref) / N < 1e-8, (ls, sn, est)
-        if 1e-9 < est <= 128e-9 and ca.n_extended > before:
+        if 1e-9 < est <= 16384e-9 and ca.n_extended > before:
             seen_tier1 += 1
     assert seen_tier1 >= 1, "no cell of this sweep ran in the extended tier"
 

@@ -500,10 +500,11 @@ def test_two_rank_gloo_whitened_layouts_may_differ_between_ranks():
 
 
 def test_three_tier_guard_on_the_cpu_double():
-    """Round 4's second tier: a streaming evaluation whose estimate exceeds the tolerance by less than `extended_range` is repeated in the
-    EXTENDED streaming order (engine.suffstats_extended; pass 2 from the explicit Phibar on the K'_fu it kept), beyond that range in the
-    whitened order; the evaluations that follow start in the tier the prediction asks for; an extended evaluation whose own theta turns
-    out to be beyond the range is repeated whitened; the episode ends as before."""
+    """Round 4's second tier: a streaming evaluation whose estimate exceeds the tolerance is repeated in the EXTENDED streaming order
+    (engine.suffstats_extended) while the estimate is within `extended_range` (values) / `extended_grad_range` (value + gradient: pass 2
+    takes the explicit Phibar on the K'_fu it kept) times the tolerance, beyond that in the whitened order; the evaluations that follow
+    start in the tier the prediction asks for; an extended evaluation whose own theta turns out to be beyond the range is repeated
+    whitened; the episode ends as before."""
     import ggp_amd as pkg
     from fake_engine import FactoredOracleEngine
     X, y, Z = _guard_problem()
@@ -513,31 +514,36 @@ def test_three_tier_guard_on_the_cpu_double():
         eng = FactoredOracleEngine()
         cb = pkg.CollapsedBound(X, y, jitter=1e-6, engine=eng)
         cb.whitened_rows_min_work = 0
-        mid, far, benign = ([3.0] * 3, 1.0, 1e-2), ([5.0] * 3, 1.0, 1e-3), ([0.8] * 3, 1.0, 0.3)   # estimates 3.8e-9, 3.2e-7, ~1e-12
+        # estimates: 1.9e-9 (inside the gradient range 3e-9), 3.8e-9 (outside it, inside the value range 1.6e-5), 1.6e-4 (outside both), ~1e-12
+        gmid, mid, far, benign = ([3.0] * 3, 1.0, 2e-2), ([3.0] * 3, 1.0, 1e-2), ([25.0] * 3, 1.0, 1e-5), ([0.8] * 3, 1.0, 0.3)
         ref = pkg.CollapsedBound(X, y, jitter=1e-6, engine=FactoredOracleEngine(), form="whitened")
-        F, g = cb.value_and_grad(Z, *mid, want_gz=True)                                        # trips -> repeated in the extended order
-        assert cb.n_guard_reruns == 1 and cb.n_extended == 1 and eng.calls["suffstats_extended"] == 1
+        F, g = cb.value_and_grad(Z, *gmid, want_gz=True)                                       # trips -> repeated in the extended order
+        assert cb.n_guard_reruns == 1 and cb.n_extended == 1 and eng.calls["suffstats_extended"] == 1 and eng.calls["extended_level_2"] == 1
         assert eng.calls["suffstats_whitened_rows"] == 0 and eng.calls["suffstats_bwd_factored"] == 0 and eng.calls["suffstats_bwd"] == 2
-        Fr, gr = ref.value_and_grad(Z, *mid, want_gz=True)
+        Fr, gr = ref.value_and_grad(Z, *gmid, want_gz=True)
         # explicit against factored adjoint (the double re-expands the factored one through L and L^-1: rounding of that round trip)
         assert F == Fr and (g["ls"] - gr["ls"]).abs().max() < 1e-7 * gr["ls"].abs().max()
         n_stream = eng.calls["suffstats"]
         cb.value(Z, *mid)                                                                       # the episode continues: extended, directly
         assert cb.n_direct_whitened == 1 and cb.n_extended == 2 and eng.calls["suffstats"] == n_stream
-        F2, _ = cb.value(Z, *far)                                # starts extended (it cannot know yet); its bound says: beyond the range
-        assert cb.n_extended == 3 and cb.n_guard_reruns == 2 and eng.calls["suffstats_whitened_rows"] == 1
-        assert F2 == ref.value(Z, *far)[0]
-        cb.value(Z, *far)                                                                       # now predicted: whitened directly
-        assert cb.n_extended == 3 and eng.calls["suffstats_whitened_rows"] == 2 and cb.n_guard_reruns == 2
-        cb.value(Z, *mid)                                        # whitened (the prediction is still `far`), which re-predicts: mid
-        assert eng.calls["suffstats_whitened_rows"] == 3
+        cb.value_and_grad(Z, *mid, want_gz=False)        # a gradient at an estimate of 3.8e-9: beyond the gradient range -> whitened, T handed over
+        assert cb.n_extended == 2 and eng.calls["suffstats_whitened_rows"] == 1 and eng.calls["t_handed_over"] == 1
         cb.value(Z, *mid)
-        assert cb.n_extended == 4
+        assert cb.n_extended == 3
+        F2, _ = cb.value(Z, *far, raise_on_fail=False)           # starts extended (it cannot know yet); its bound says: beyond the range
+        assert cb.n_extended == 4 and cb.n_guard_reruns == 2 and eng.calls["suffstats_whitened_rows"] == 2
+        assert F2 == ref.value(Z, *far, raise_on_fail=False)[0]
+        cb.value(Z, *far, raise_on_fail=False)                                                  # now predicted: whitened directly
+        assert cb.n_extended == 4 and eng.calls["suffstats_whitened_rows"] == 3 and cb.n_guard_reruns == 2
+        cb.value(Z, *mid)                                        # whitened (the prediction is still `far`), which re-predicts: mid
+        assert eng.calls["suffstats_whitened_rows"] == 4
+        cb.value(Z, *mid)
+        assert cb.n_extended == 5
         cb.value(Z, *benign)                                                                    # extended once more, then the episode ends
         assert not cb._prefer_whitened
         n_stream = eng.calls["suffstats"]
         cb.value(Z, *benign)
-        assert eng.calls["suffstats"] == n_stream + 1 and cb.n_extended == 5
+        assert eng.calls["suffstats"] == n_stream + 1 and cb.n_extended == 6
         # form="extended" pins the tier (tools, tests); extended_range = 1 switches it off
         ce = pkg.CollapsedBound(X, y, jitter=1e-6, engine=FactoredOracleEngine(), form="extended")
         assert ce.value(Z, *mid)[0] == ref.value(Z, *mid)[0] and ce.engine.calls["suffstats_extended"] == 1
@@ -567,7 +573,7 @@ def _tier_worker(rank, world, port, q):
     cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=1e-6, engine=eng)
     cb.whitened_rows_min_work = 0
     out = []
-    for ls, s2 in ((0.8, 0.3), (3.0, 1e-2), (3.0, 1e-2), (5.0, 1e-3), (5.0, 1e-3), (3.0, 1e-2), (0.8, 0.3), (0.8, 0.3)):
+    for ls, s2 in ((0.8, 0.3), (3.0, 2e-2), (3.0, 2e-2), (5.0, 1e-3), (5.0, 1e-3), (3.0, 2e-2), (0.8, 0.3), (0.8, 0.3)):
         F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
         out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns, cb.n_direct_whitened, cb.n_extended, cb.n_collectives,
                     cb._prefer_whitened, cb._pred_est))

@@ -14,6 +14,7 @@ import ggp_amd  # noqa: E402
 
 N = int(os.environ.get("ROWS", bench.N_TOTAL))
 M = int(os.environ.get("M", bench.M_IND))
+LEVEL = int(os.environ.get("LEVEL", 1))  # 1: 34 digit pairs, 2: 39
 eng = ggp_amd.HipEngine()
 X, y, Z = bench.synth(N, M, bench.DIM)
 Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
@@ -25,7 +26,7 @@ cw = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="white
 def extended(ls, sf2, s2):
     Kuu = eng.kuu(Zd, ls, sf2, bench.JITTER, "rbf")
     linv, info = eng.kuu_factor(Kuu)
-    packed = eng.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, "rbf")
+    packed = eng.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, "rbf", level=LEVEL)
     res = eng.bound(Kuu, packed, s2, N, kuu_linv=linv, kuu_info=info, whitened=True)
     return float(res["out"].cpu()[0]), int(res["info"].cpu()[0])
 
@@ -42,6 +43,17 @@ for ls_v in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0):
             extended(ls, 1.0, sn * sn)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
-        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate,
+        grad_diff = None
+        if os.environ.get("GRADS", "0") == "1":  # gradients: the explicit Phibar of the extended order against the factored pass 2 of the whitened one
+            cx = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="extended")
+            cx.extended_level = LEVEL
+            _, gx = cx.value_and_grad(Zd, ls, 1.0, sn * sn, want_gz=False, raise_on_fail=False)
+            _, gw = cw.value_and_grad(Zd, ls, 1.0, sn * sn, want_gz=False, raise_on_fail=False)
+            if gx.get("info", 0) == 0 and gw.get("info", 0) == 0:
+                a = torch.cat([gx["ls"], torch.tensor([gx["sf2"], gx["s2"]], dtype=torch.float64)])
+                b = torch.cat([gw["ls"], torch.tensor([gw["sf2"], gw["s2"]], dtype=torch.float64)])
+                grad_diff = float(((a - b).abs() / b.abs().clamp_min(1e-300)).max())
+            del cx
+        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate, "grad_max_rel_diff": grad_diff,
                           "err_streaming": abs(Fs - Fw) / N if ps.get("info", 0) == 0 else None,
-                          "err_extended": abs(Fe - Fw) / N if ie == 0 else None, "info_extended": ie, "extended_ms": round(ms, 2)}), flush=True)
+                          "err_extended": abs(Fe - Fw) / N if ie == 0 else None, "info_extended": ie, "extended_ms": round(ms, 2), "level": LEVEL}), flush=True)
