@@ -1043,7 +1043,8 @@ extern "C" int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, con
 // sgp_suffstats_fwd + sgp_bound_from_stats, so the streaming order's guard (sgp_streaming_error_estimate) passes 256 times later; the cost
 // is 14.0 instead of 11.7 ms of contraction and ~1.5 ms of tail at C5 against the whitened order's two extra N M^2 products.
 // Stationary kernels; rows x Mp^2 of any size (the integer contraction is used whatever the context's contraction mode says).
-// Kfu_out (optional, sgp_kfu_len doubles): the fp64 K'_fu for sgp_suffstats_bwd (explicit Phibar).
+// Kfu_out (optional, sgp_kfu_len doubles): the fp64 K'_fu for sgp_suffstats_bwd (explicit Phibar -- good to ~3 x the tolerance only,
+// include/sgp.h).  level 1: 34 digit pairs, 2: 39.
 extern "C" size_t sgp_suffstats_extended_workspace_bytes(int64_t N, int M, int d) {
   if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   StreamPlan p = make_stream_plan(N, M, d);

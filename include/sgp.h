@@ -329,12 +329,14 @@ int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, const double* 
 /* The EXTENDED streaming order (round 4): the same statistics [W | u | yy | kappa] from the streaming design -- Phi = K_uf K_fu on the
  * integer matrix cores with 34 instead of 28 digit pairs and a double-double fold / reduction (2^-61 of the largest entry instead of
  * fp64's 2^-53), W = L^-1 Phi L^-T by two double-double M^3 products, u = L^-1 (K_uf y) in fp64.  What the explicit-inverse sandwich
- * amplifies is 2^8 times smaller than in sgp_suffstats_fwd + sgp_bound_from_stats: a caller whose sgp_streaming_error_estimate exceeds its
- * tolerance by less than that factor can stay in the streaming design (one N M^2 contraction, 14.0 instead of 11.7 ms at C5) instead of
- * paying the whitened order's two extra N M^2 products.  Stationary kernels only; the integer contraction is used whatever the context's
+ * amplifies is 2^8 (level 1) or 2^16 (level 2) times smaller than in sgp_suffstats_fwd + sgp_bound_from_stats: a caller whose
+ * sgp_streaming_error_estimate exceeds its tolerance by less than that factor can stay in the streaming design for its VALUE (one
+ * N M^2 contraction, 14.0 / 16.3 instead of 11.7 ms at C5) instead of paying the whitened order's two extra N M^2 products.  Stationary kernels only; the integer contraction is used whatever the context's
  * contraction mode says.  Kfu_out (DEVICE, sgp_kfu_len(N, M) doubles, or NULL): the fp64 K'_fu for sgp_suffstats_bwd with the explicit
- * Phibar that sgp_bound_from_whitened_stats returns (adequate where this order is: the product Phibar K_uf cancels ~600-fold at the
- * estimates in question, not cond(K_uu)-fold).  Same all-reduce as the other two orders.
+ * Phibar that sgp_bound_from_whitened_stats returns.  THAT is this order's limit: Phibar K_uf cancels, and against the factored pass 2
+ * of the whitened order the gradients are good to 1e-6 only while the estimate is within ~3 x a 1e-9 tolerance (measured at C5:
+ * 7e-7 at an estimate of 4e-9, 3e-5 at 8e-8, 3e-2 at 2e-7) -- values hold 1.6e-10 per datum up to estimates of 3e-5 (level 2).
+ * Same all-reduce as the other two orders.
  * level: 1 = 34 digit pairs (p + r >= 5, Phi to 2^-61, 14.0 ms of contraction at C5), 2 = 39 pairs (p + r >= 4, 2^-69, 16.3 ms).       */
 size_t sgp_suffstats_extended_workspace_bytes(int64_t N, int M, int d);
 int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y,
