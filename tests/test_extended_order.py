@@ -106,6 +106,12 @@ def test_extended_order_where_the_streaming_order_fails(engine):
         if 1e-9 < est <= 16384e-9 and ca.n_extended > before:
             seen_tier1 += 1
     assert seen_tier1 >= 1, "no cell of this sweep ran in the extended tier"
+    # gradients at such a theta do NOT take the extended order (its explicit Phibar cancels): the same bound sends them to the whitened one
+    before = ca.n_extended
+    Fg, g = ca.value_and_grad(Zd, [4.0] * D, 1.0, 0.09, want_gz=False)
+    cw = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine, form="whitened")
+    Fw, gw = cw.value_and_grad(Zd, [4.0] * D, 1.0, 0.09, want_gz=False)
+    assert ca.n_extended == before and Fg == Fw and torch.equal(g["ls"], gw["ls"])
 
 
 def test_extended_order_gradients_against_autograd(engine):
