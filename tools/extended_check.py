@@ -43,7 +43,7 @@ for ls_v in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0):
             extended(ls, 1.0, sn * sn)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
-        grad_diff = None
+        grad_diff = grad_suite = None
         if os.environ.get("GRADS", "0") == "1":  # gradients: the explicit Phibar of the extended order against the factored pass 2 of the whitened one
             cx = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="extended")
             cx.extended_level = LEVEL
@@ -53,7 +53,10 @@ for ls_v in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0):
                 a = torch.cat([gx["ls"], torch.tensor([gx["sf2"], gx["s2"]], dtype=torch.float64)])
                 b = torch.cat([gw["ls"], torch.tensor([gw["sf2"], gw["s2"]], dtype=torch.float64)])
                 grad_diff = float(((a - b).abs() / b.abs().clamp_min(1e-300)).max())
+                # the parity suite's metric: lengthscale gradients against their largest component, sf2 / s2 against max(1, |ref|)
+                grad_suite = max(float((gx["ls"] - gw["ls"]).abs().max() / gw["ls"].abs().max()),
+                                 abs(gx["sf2"] - gw["sf2"]) / max(1.0, abs(gw["sf2"])), abs(gx["s2"] - gw["s2"]) / max(1.0, abs(gw["s2"])))
             del cx
-        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate, "grad_max_rel_diff": grad_diff,
+        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate, "grad_max_rel_diff": grad_diff, "grad_suite_metric": grad_suite,
                           "err_streaming": abs(Fs - Fw) / N if ps.get("info", 0) == 0 else None,
                           "err_extended": abs(Fe - Fw) / N if ie == 0 else None, "info_extended": ie, "extended_ms": round(ms, 2), "level": LEVEL}), flush=True)

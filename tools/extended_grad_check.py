@@ -1,0 +1,22 @@
+import json, sys, os
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, ggp_amd
+eng = ggp_amd.HipEngine()
+N, M = bench.N_TOTAL, bench.M_IND
+X, y, Z = bench.synth(N, M, bench.DIM)
+Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
+cs = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng); cs.streaming_tol = float("inf")
+cw = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="whitened")
+cx = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="extended")
+thetas = [([3.75, 2.61, 3.38, 5.50, 3.49, 3.17, 2.64, 3.65], 1.0, 0.145), ([4.87, 2.27, 7.04, 6.39, 7.18, 3.35, 2.31, 6.49], 1.0, 0.144),
+          ([2.5] * 8, 1.0, 0.05), ([2.8] * 8, 1.0, 0.1), ([3.0] * 8, 1.0, 0.145), ([2.0, 6.0, 2.0, 6.0, 2.0, 6.0, 2.0, 6.0], 1.0, 0.145), ([3.2] * 8, 1.0, 0.2)]
+for ls, sf, sn in thetas:
+    cs.value(Zd, ls, sf * sf, sn * sn, raise_on_fail=False)
+    est = cs.last_estimate
+    Fx, gx = cx.value_and_grad(Zd, ls, sf * sf, sn * sn, want_gz=False)
+    Fw, gw = cw.value_and_grad(Zd, ls, sf * sf, sn * sn, want_gz=False)
+    a = torch.cat([gx["ls"], torch.tensor([gx["sf2"], gx["s2"]], dtype=torch.float64)])
+    b = torch.cat([gw["ls"], torch.tensor([gw["sf2"], gw["s2"]], dtype=torch.float64)])
+    print(json.dumps({"ls": ls, "sig_n": sn, "estimate": est, "est_times_s2": est * sn * sn, "dF_per_datum": abs(Fx - Fw) / N,
+                      "grad_max_rel_component": float(((a - b).abs() / b.abs()).max()), "grad_rel_norm": float((a - b).norm() / b.norm())}), flush=True)
