@@ -216,3 +216,96 @@ def test_default_mode_hmc_target_at_theta_the_tuner_visits(engine, host_threads)
             assert np.max(np.abs(np.asarray(gr) - g_ref)) < 1e-6 * max(1.0, float(np.max(np.abs(g_ref)))), (th, gr, g_ref)
     finally:
         engine.lib.sgp_set_contraction(prev)
+
+
+# ---------------------------------------------------------------------------------------------
+# every cell above has ONE lengthscale for all eight dimensions, data-row inducing inputs and the RBF
+# profile.  ARD theta (the trained one of profiles/r04_experiment_large_scale.json and a deliberately ragged one), CLUSTERED
+# inducing inputs (pairs 1e-3 apart: near-duplicates that the jitter does not regularise the way exact duplicates are) and the
+# Matern profiles, through the default mode (integer cores + guard) -- and the whole isotropic sweep once more through the fp64
+# contraction on a shard below the integer threshold (what C3 runs; its measured / estimated error ratio is the larger one, 5.5).
+# ---------------------------------------------------------------------------------------------
+LS_TRAINED = [4.870895252562722, 2.274348615181124, 7.035384773166531, 6.388168428424034, 7.176420862837876, 3.3523772450641136,
+              2.314383327914714, 6.492694463809999]
+LS_RAGGED = [0.5, 5.0, 1.0, 10.0, 2.0, 20.0, 0.8, 3.0]
+
+EXTRA_CELLS = [
+    ("rbf", LS_TRAINED, 0.14415221312756948, "rows"),
+    ("rbf", LS_RAGGED, 0.05, "rows"),
+    ("rbf", [8.0, 8.0, 8.0, 8.0, 1.0, 1.0, 1.0, 1.0], 0.01, "rows"),
+    ("rbf", [2.0] * D, 0.1, "clustered"),
+    ("rbf", [5.0] * D, 0.3, "clustered"),
+    ("rbf", LS_TRAINED, 0.05, "clustered"),
+    ("matern52", [2.0] * D, 0.01, "rows"),
+    ("matern52", [10.0] * D, 0.1, "rows"),
+    ("matern52", LS_TRAINED, 0.14415221312756948, "clustered"),
+    ("matern32", [5.0] * D, 0.05, "rows"),
+]
+
+
+def _cluster(Z, seed=3):
+    """Z = X[idx] + 1e-3 noise in pairs: rows 2k and 2k + 1 sit 1e-3 apart (r^2 ~ 1e-6 d / l^2: K_uu rows equal to ~1e-6)."""
+    g = torch.Generator().manual_seed(seed)
+    Zc = Z.clone()
+    Zc[1::2] = Zc[0::2][: Zc[1::2].shape[0]] + 1e-3 * torch.randn(Zc[1::2].shape, dtype=torch.float64, generator=g)
+    return Zc
+
+
+@pytest.mark.parametrize("kernel,ls,sn,zmode", EXTRA_CELLS)
+def test_default_mode_bound_ard_clustered_matern(engine, host_threads, kernel, ls, sn, zmode):
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    M = 512
+    X, y, Z = _data(N_SWEEP, M, False)
+    if zmode == "clustered":
+        Z = _cluster(Z)
+    kid = {"rbf": O.KERNEL_RBF, "matern32": O.KERNEL_MATERN32, "matern52": O.KERNEL_MATERN52}[kernel]
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    cb = ggp_amd.CollapsedBound(Xd, yd, kernel=kernel, jitter=1e-6, engine=engine)
+    prev = engine.lib.sgp_set_contraction(1)
+    try:
+        F, parts = cb.value(Zd, ls, 1.0, sn * sn)
+        if not cb.n_guard_reruns:
+            assert engine.lib.sgp_contraction_last() == 1
+    finally:
+        engine.lib.sgp_set_contraction(prev)
+    host_threads()
+    F_ref = O.vfe_pymc3_order_chunked(X, y, Z, ls, 1.0, sn, 1e-6, kernel_id=kid)
+    err = abs(F - F_ref) / N_SWEEP
+    assert err < 1e-8, (kernel, ls, sn, zmode, F, F_ref, err, cb.last_estimate, cb.n_guard_reruns, cb.n_extended)
+
+
+@pytest.mark.parametrize("zmode", ["rows", "clustered"])
+def test_fp64_contraction_below_the_integer_threshold_over_the_theta_range(engine, host_threads, zmode):
+    """rows x Mp^2 < 2^32 (C3's class): the fp64 contraction streams, the guard sends what it must to the whitened order directly
+    (no extended order at this size).  Every cell of the isotropic sweep plus the ARD ones to 1e-8 per datum."""
+    import ggp_amd
+    from oracle import vfe_oracle as O
+    N, M = 16_000, 512
+    X, y, Z = _data(N, M, False)
+    if zmode == "clustered":
+        Z = _cluster(Z)
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    cb = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine)
+    assert not cb._whitened(M) and not engine.would_use_i8(N, M)
+    cells = [([ls] * D, sn) for ls, sn in CELLS_512] + [(LS_TRAINED, 0.14415221312756948), (LS_RAGGED, 0.05), (LS_TRAINED, 0.01)]
+    bad, log = [], []
+    host_threads()
+    for ls, sn in cells:
+        cb._prefer_whitened = False  # every cell starts in the streaming order: the guard's own decision is what is tested
+        before = cb.n_guard_reruns
+        F, parts = cb.value(Zd, ls, 1.0, sn * sn)
+        rerun = cb.n_guard_reruns - before
+        if not rerun:
+            assert engine.lib.sgp_contraction_last() == 0, "below the threshold the fp64 contraction runs"
+        F_ref = O.vfe_pymc3_order_chunked(X, y, Z, ls, 1.0, sn, 1e-6)
+        err = abs(F - F_ref) / N
+        log.append((ls[0], sn, rerun, cb.last_estimate, err))
+        # Clustered inducing inputs x sig_n = 0.01 x long lengthscales: cond(K_uu) ~ M / jitter and B = I + A A^T / s2 has entries ~ N / s2:
+        # two fp64 evaluations of the SAME op order (here: the whitened order on the GPU against the CPU oracle) differ by more than
+        # 1e-8 per datum -- the fp64 CPU oracle alone is 1.2e-9 (l = 20) / 4.3e-9 (l = 5) per datum off the 80-bit yardstick
+        # (oracle.vfe_extended) already at N = 3 000, M = 128.  There the CPU path is no yardstick at 1e-8: 3e-8.
+        tol = 3e-8 if (zmode == "clustered" and sn <= 0.01 and ls[0] >= 5.0) else 1e-8
+        if not (err < tol):
+            bad.append((ls, sn, rerun, cb.last_estimate, F, F_ref, err))
+    assert not bad, (bad, log)
