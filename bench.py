@@ -445,10 +445,14 @@ def main():
     res["config"]["streaming_guard"] = {
         "tolerance_per_datum": cb.streaming_tol, "estimate_per_datum": cb.last_estimate, "repeats_in_whitened_order": cb.n_guard_reruns,
         "direct_whitened_evaluations": cb.n_direct_whitened, "extended_order_evaluations": cb.n_extended,
+        "extended_order_level": cb.extended_level, "extended_order_reach_values": cb.extended_range,
+        "extended_order_reach_gradients": cb.extended_grad_range,
         "note": "first-order estimate of |dF| / N of the streaming order (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N), include/sgp.h: "
-                "sgp_streaming_error_estimate), read back with every evaluation; above the tolerance the evaluation is repeated in the "
-                "extended streaming order (estimate <= 128 x tolerance) or the whitened (PyMC3) order, and so are the evaluations that follow "
-                "it until the predicted estimate is below half the tolerance -- 0, 0 and 0 = every timed step ran the streaming design"}
+                "sgp_streaming_error_report), read back with every evaluation; above the tolerance the evaluation is repeated in the "
+                "extended streaming order (level %d: %d digit pairs; values while the estimate is <= %g x the tolerance, value + gradient "
+                "while <= %g x) or in the whitened (PyMC3) order beyond, and the evaluations that follow START there until the estimate is "
+                "below half the tolerance -- 0, 0 and 0 = every timed step ran the streaming design"
+                % (cb.extended_level, 39 if cb.extended_level >= 2 else 34, cb.extended_range, cb.extended_grad_range)}
     if world == 1:
         # what an evaluation costs where the guard sends it: the whitened (PyMC3) order on the same shard and theta, a few repetitions
         # outside the timed region (engine.suffstats_whitened_rows + suffstats_bwd_factored)
@@ -469,9 +473,10 @@ def main():
         res["config"]["streaming_guard"]["whitened_order"] = {
             "ms_per_evaluation": tw[0], "ms_per_leapfrog": tw[1], "F_minus_streaming_F_per_datum": (Fw - last["F"]) / args.n,
             "note": "not part of `value`: the cost of one evaluation / one value+gradient in the order the guard falls back to beyond "
-                    "128 x the tolerance"}
+                    "the extended order's reach (%g x the tolerance for values, %g x for gradients that must hold 1e-6)"
+                    % (cb.extended_range, cb.extended_grad_range)}
         del wb
-        # ... and in the tier between: the extended streaming order (engine.suffstats_extended), estimates up to 128 x the tolerance
+        # ... and in the tier between: the extended streaming order (engine.suffstats_extended)
         xb = ggp_amd.CollapsedBound(Xd, yd, kernel="rbf", jitter=JITTER, engine=eng, form="extended")
         xb._kfu = cb._kfu
         xv = lambda: xb.value(Zd, ls, sf2, s2)  # noqa: E731
@@ -488,9 +493,38 @@ def main():
             tx.append((time.perf_counter() - t0) / 3 * 1e3)
         res["config"]["streaming_guard"]["extended_order"] = {
             "ms_per_evaluation": tx[0], "ms_per_leapfrog": tx[1], "F_minus_whitened_F_per_datum": (Fx - Fw) / args.n,
-            "note": "not part of `value`: Phi on the integer cores with 34 digit pairs and a double-double fold, W = L^-1 Phi L^-T in "
-                    "double-double, pass 2 from the explicit Phibar"}
+            "note": "not part of `value`: Phi on the integer cores with %d digit pairs and a double-double fold, W = L^-1 Phi L^-T in "
+                    "double-double, pass 2 from the explicit Phibar" % (39 if xb.extended_level >= 2 else 34)}
         del xb
+        # ... and what NUTS gets where the reference samples after training (train_fixed_model, models/bayesian_sgpr_hmc.py:160-180):
+        # the trained ARD theta of profiles/r04_experiment_large_scale.json is in the guarded regime.  Leapfrogs / s of the NUTS target
+        # there in the default mode (every gradient holds 1e-6: whitened order beyond 3 x the tolerance) and with
+        # HmcTarget(gradient="sampler") (the extended order's gradient as far as its value holds; same energy, same posterior).
+        ls_tr = [4.870895252562722, 2.274348615181124, 7.035384773166531, 6.388168428424034, 7.176420862837876, 3.3523772450641136,
+                 2.314383327914714, 6.492694463809999][:DIM] + [2.0] * max(0, DIM - 8)
+        th_tr = [math.log(v) for v in ls_tr] + [0.0, math.log(0.14415221312756948)]
+        trained = {}
+        for mode in ("parity", "sampler"):
+            tb = ggp_amd.CollapsedBound(Xd, yd, kernel="rbf", jitter=JITTER, engine=eng)
+            tb._kfu = cb._kfu
+            tgt = ggp_amd.HmcTarget(tb, Zd, gradient=mode)
+            for _ in range(2):
+                lp, _g = tgt.logp_and_grad(th_tr)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                tgt.logp_and_grad(th_tr)
+            torch.cuda.synchronize(dev)
+            trained[mode] = {"leapfrog_per_s": 4.0 / (time.perf_counter() - t0), "tier": tb.last_tier, "estimate_per_datum": tb.last_estimate,
+                             "logp": lp}
+            del tgt, tb
+        res["leapfrog_per_s_trained_theta"] = {
+            "parity": trained["parity"]["leapfrog_per_s"], "sampler": trained["sampler"]["leapfrog_per_s"],
+            "tier": {k: ("streaming", "extended", "whitened")[v["tier"]] for k, v in trained.items()},
+            "estimate_per_datum": trained["parity"]["estimate_per_datum"],
+            "logp_difference_per_datum": (trained["sampler"]["logp"] - trained["parity"]["logp"]) / args.n,
+            "note": "outside `value`: value + gradient of the NUTS target at the trained ARD theta of C5 (lengthscales 2.3 .. 7.2, sig_n 0.144), "
+                    "four evaluations each; `sampler` = HmcTarget(gradient='sampler')"}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

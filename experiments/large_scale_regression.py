@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--max_iters", type=int, default=50)
     ap.add_argument("--hmc_samples", type=int, default=0, help="fixed-Z NUTS draws after training (0 = skip)")
     ap.add_argument("--hmc_tune", type=int, default=10)
+    ap.add_argument("--hmc_gradient", choices=["parity", "sampler"], default="parity",
+                    help="core.HmcTarget: 'sampler' lets the extended evaluation order serve gradients as far as values (guarded regime)")
     args = ap.parse_args()
 
     g = torch.Generator().manual_seed(0)
@@ -54,12 +56,13 @@ def main():
         guard_repeats=int(model._bound().n_guard_reruns))
     if args.hmc_samples > 0:
         hmc = BayesianSparseGPR_HMC(Xtr, ytr, GaussianLikelihood(), model.inducing_points.cpu(), jitter=1e-6, seed=1)
+        hmc.hmc_gradient = args.hmc_gradient
         t0 = time.time()
         trace, steps, perf = hmc.train_fixed_model(num_tune=args.hmc_tune, num_samples=args.hmc_samples)
         wall = time.time() - t0
         out["step_sizes"] = [float(v) for v in steps]
         out["perf_times"] = [float(v) for v in perf]
-        out["hmc"] = {"draws": len(trace), "tune": args.hmc_tune, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
+        out["hmc"] = {"gradient_mode": args.hmc_gradient, "draws": len(trace), "tune": args.hmc_tune, "wall_clock_secs": wall, "n_leapfrog": int(trace.n_leapfrog),
                       "leapfrogs_per_sec": trace.n_leapfrog / wall, "step_size": float(steps[0]),
                       "sig_n_mean": float(trace["sig_n"].mean()), "ls_mean": trace["ls"].mean(0).tolist(),
                       # leapfrogs the streaming-order guard sent to the whitened (PyMC3) order

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsgp_hip.so")
 
-SGP_ABI_VERSION = 2
+SGP_ABI_VERSION = 3
 SGP_MAX_DIM = 32
 SGP_MAX_INDUCING = 4096
 KERNEL_IDS = {"rbf": 0, "matern32": 1, "matern52": 2, "composite": 3}
@@ -57,6 +57,21 @@ PROTOTYPES = {
     "sgp_ctx_kuu_factor": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sgp_ctx_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    # ABI version 3: the guard's fallback orders, the factored pass 2 and the whitened bound with a context
+    "sgp_ctx_suffstats_whitened_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32]),
+    "sgp_ctx_suffstats_fwd_whitened": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
+                                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_suffstats_whitened_rows_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32, _i32]),
+    "sgp_ctx_suffstats_fwd_whitened_rows": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp,
+                                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_suffstats_extended_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32]),
+    "sgp_ctx_suffstats_fwd_extended": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
+                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_suffstats_bwd_factored_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32, _i32]),
+    "sgp_ctx_suffstats_bwd_factored": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _dbl, _i64, _i32, _i32, _i32,
+                                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
+                                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_ctx_mixture_predict": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _dp, _dp, _dp, _dbl, _i32, _i32, _i32, _i32,
                                        _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_timing_enable": (None, [_i32]),
@@ -89,6 +104,7 @@ PROTOTYPES = {
     "sgp_kuu_inverse_trace": (_i32, [_vp, _i32, _vp, _vp]),
     "sgp_streaming_error_estimate": (_i32, [_vp, _vp, _dbl, _i64, _i32, _vp, _vp]),
     "sgp_streaming_error_bound": (_i32, [_vp, _dbl, _dbl, _vp, _vp]),
+    "sgp_streaming_error_report": (_i32, [_vp, _i64, _vp, _dbl, _dbl, _i64, _i32, _vp, _vp]),
     "sgp_kuu_factor_len": (_sz, [_i32]),
     "sgp_kuu_factor_workspace_bytes": (_sz, [_i32]),
     "sgp_kuu_factor": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),
@@ -103,6 +119,8 @@ PROTOTYPES = {
     "sgp_suffstats_extended_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_fwd_extended": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_fwd_extended_ex": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats_ex": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,

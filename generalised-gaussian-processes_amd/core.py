@@ -69,6 +69,64 @@ def few_host_threads(fn):
     return wrapped
 
 
+# ---------------------------------------------------------------------------------------------
+# The streaming-order guard, host side.  Three evaluation orders ("tiers") compute the same bound:
+#   0 streaming  Phi = K_uf K_fu streamed, W = L^-1 Phi L^-T in the tail           (the N >> M design; fastest)
+#   1 extended   the same from an exact Phi and a double-double sandwich            (values hold 2^14 x further; its explicit-Phibar
+#                                                                                    gradients 3 x further)
+#   2 whitened   PyMC3's op order, A = L^-1 K_uf first                               (always accurate; two more N M^2 products)
+# Every evaluation reports the library's first-order estimate of the streaming order's error at ITS theta (exact in tiers 0 and 1,
+# which form Phi; tier 2 can only report the upper bound).  `required_tier` -- a pure function -- says which tier that estimate asks
+# for; an evaluation that ran in a lower tier is repeated in the required one.  What is remembered between evaluations (GuardState)
+# only decides where the next one STARTS, so that a sampler sitting in a guarded region does not pay a wasted streaming attempt per
+# leapfrog; it never decides what is accepted.  Consequence, documented in include/sgp.h / INTEGRATION.md: the bits of F(theta) depend
+# on the tier (tiers agree to ~1e-9 per datum), and the tier an evaluation is ACCEPTED in can be higher than required when the
+# previous evaluations suggested it (never lower).  All inputs of these decisions are replicated numbers: ranks decide alike.
+# ---------------------------------------------------------------------------------------------
+TIER_STREAMING, TIER_EXTENDED, TIER_WHITENED = 0, 1, 2
+
+
+def required_tier(estimate, tol, reach, extended_ok):
+    """The cheapest tier that meets `tol` at a theta whose streaming-order error estimate is `estimate`.  `reach`: how many times the
+    tolerance the extended order covers for this kind of evaluation (values / gradients); `extended_ok`: that order exists here."""
+    if estimate <= tol:
+        return TIER_STREAMING
+    if extended_ok and estimate <= reach * tol:  # (NaN / inf fail both comparisons: the whitened order)
+        return TIER_EXTENDED
+    return TIER_WHITENED
+
+
+class GuardState:
+    """All the guard remembers between evaluations."""
+
+    __slots__ = ("open", "predicted", "ratio")
+
+    def __init__(self):
+        self.open = False        # an episode is open: evaluations start in the tier the prediction asks for, without a streaming attempt
+        self.predicted = 0.0     # the streaming-order estimate expected at the next theta
+        self.ratio = 1.0         # estimate / upper bound at the last evaluation that knew both (predicts the estimate from a whitened one)
+
+    def start_tier(self, tol, reach, extended_ok):
+        """Where the next evaluation starts.  Inside an episode never in the streaming order (hysteresis: the episode ends once the
+        prediction is below half the tolerance), so a theta hovering around the tolerance does not pay a repeat every other time."""
+        if not self.open:
+            return TIER_STREAMING
+        return TIER_EXTENDED if (extended_ok and self.predicted <= reach * tol) else TIER_WHITENED
+
+    def note_exact(self, estimate, bound, tol):
+        """After an evaluation that formed Phi (tiers 0, 1): `estimate` is exact at its theta."""
+        if math.isfinite(estimate) and math.isfinite(bound) and bound > 0.0:
+            self.ratio = min(1.0, max(estimate / bound, 0.0))
+        self.predicted = estimate
+        self.open = not (estimate < 0.5 * tol) if self.open else not (estimate <= tol)
+
+    def note_bound(self, bound, tol):
+        """After a whitened-order evaluation: only the upper bound is known; the last ratio turns it into a prediction."""
+        if math.isfinite(bound) and bound > 0.0:
+            self.predicted = self.ratio * bound
+            self.open = not (self.predicted < 0.5 * tol)
+
+
 def _world(group):
     if dist is None or not dist.is_available() or not dist.is_initialized():
         return 1
@@ -143,37 +201,25 @@ class CollapsedBound:
         self.early_check_min_work = 1 << 28  # ... from which value_and_grad reads the status before enqueueing pass 2
         self._side = None
         self._pool = None
-        # Guard of the streaming order (form="auto" only): every streaming evaluation carries the library's first-order estimate
-        # of |dF| / N (include/sgp.h: sgp_streaming_error_estimate; one extra word in the evaluation's one host copy).  Above
-        # this tolerance -- long lengthscales x small noise: W = L^-1 Phi L^-T amplifies the rounding of Phi by 1 / lambda(K_uu)
-        # -- the evaluation is repeated in the whitened (PyMC3) order, A = L^-1 K_uf first.  The estimate is a function of the
-        # replicated tail and the all-reduced statistics, bit for bit the same on every rank: all ranks repeat together.
+        # Guard of the streaming order (form="auto" only; see the block comment above required_tier): the tolerance is per datum on
+        # |dF| / N.  extended_level 2 = 39 digit pairs, what the sandwich amplifies is 2^16 smaller (reach 2^14: a factor 4 kept as margin;
+        # measured at C5 over 27 theta: <= 1.6e-10 per datum against the whitened order up to estimates of 3e-5,
+        # profiles/r04_extended_order_c5.jsonl); level 1 = 34 pairs, 2^8 (0.9 ms cheaper; reach 2^7 then).
+        # GRADIENTS: pass 2 of the extended order takes the explicit Phibar, whose product with K_uf cancels -- against the factored pass 2
+        # of the whitened order its lengthscale gradients are off by 7e-7 at an estimate of 4e-9, 3e-5 at 8e-8, 3e-2 at 2e-7 (same file):
+        # a value + gradient evaluation that must hold 1e-6 takes the extended order within `extended_grad_range` x the tolerance only.
+        # A sampler may ask for more (HmcTarget(gradient="sampler"): the value's reach for the gradient as well, see there).
         self.streaming_tol = 1e-9
-        self.n_guard_reruns = 0
-        self.last_estimate = None
-        # ... and once it has tripped the following evaluations go to the whitened order directly (a sampler that sits in such a
-        # region would otherwise pay a wasted streaming attempt per leapfrog: 86 % of the leapfrogs of NUTS at C5's trained Z,
-        # profiles/r04_experiment_large_scale*.json).  The whitened order reports the estimate's upper bound (max Phi_ii <= N sf2^2);
-        # times the ratio estimate / bound seen where the guard tripped it predicts the streaming estimate, and the streaming order
-        # is tried again once that prediction is below half the tolerance.  Same inputs on every rank, same decision.
-        self.n_direct_whitened = 0
-        self._prefer_whitened = False
-        self._est_ratio = 1.0
-        # Between the two there is the EXTENDED streaming order (engine.suffstats_extended: Phi on the integer cores to 2^-61, the triple
-        # product in double-double): what the sandwich amplifies is 2^8 times smaller, so an evaluation whose estimate is within
-        # `extended_range` x the tolerance is repeated THERE -- one N M^2 contraction, 20.3 ms at C5 -- and only beyond it in the whitened
-        # order (39.6 ms).  extended_level 2 = 39 digit pairs, 2^16 less amplified error (range 2^14: a factor 4 kept as margin; measured
-        # at C5 over 27 theta: <= 1.6e-10 per datum against the whitened order up to estimates of 3e-5, profiles/r04_extended_order_c5.jsonl);
-        # level 1 = 34 pairs, 2^8 (0.9 ms cheaper; range 2^7 then).  n_extended counts the evaluations that ran in it.
-        # GRADIENTS are another matter: pass 2 of the extended order takes the explicit Phibar, whose product with K_uf cancels -- against
-        # the factored pass 2 of the whitened order its lengthscale gradients are off by 7e-7 at an estimate of 4e-9, 3e-5 at 8e-8, 3e-2 at
-        # 2e-7 (same file).  A value + gradient evaluation therefore takes the extended order only within `extended_grad_range` x the
-        # tolerance, and the whitened order (which keeps K' L^-T for its factored pass 2) beyond.
         self.extended_level = 2
         self.extended_range = 16384.0
         self.extended_grad_range = 3.0
-        self.n_extended = 0
-        self._pred_est = float("inf")
+        self.guard = GuardState()
+        self.last_estimate = None   # the estimate (exact, or the bound of a whitened evaluation) of the last guarded evaluation
+        self.last_tier = None       # the tier the last evaluation was accepted in
+        self.n_guard_reruns = 0     # evaluations repeated in a higher tier
+        self.n_direct_whitened = 0  # evaluations that started above the streaming order on the strength of a prediction
+        self.n_extended = 0         # evaluations that ran in the extended order
+        self._phi_diag = None
 
     # ------------------------------------------------------------------ internals
     def _allreduce(self, buf):
@@ -270,22 +316,19 @@ class CollapsedBound:
             self._trace = e.empty(e.lib.sgp_kuu_inverse_trace_len() if hasattr(e, "lib") else 2)
         return self._trace
 
-    def _guard_on(self):
-        return self.form == "auto" and self.streaming_tol > 0.0 and hasattr(self.engine, "streaming_error_estimate")
+    # -- compatibility of the counters' old names (tests, tools)
+    @property
+    def _prefer_whitened(self):
+        return self.guard.open
 
-    def _guard_trips(self, res, host):
-        """True when a streaming-order evaluation must be repeated in the whitened order (see ``streaming_tol``)."""
-        if not res.get("guarded"):
-            return False
-        est = self.engine.read_estimate(host)
-        res["estimate"] = est
-        self.last_estimate = est
-        trips = not (est <= self.streaming_tol)  # NaN trips too
-        if trips:
-            self._prefer_whitened = True
-            self._tripped_estimate = est
-            self._pred_est = est
-        return trips
+    @_prefer_whitened.setter
+    def _prefer_whitened(self, v):
+        self.guard.open = bool(v)
+
+    def _guard_on(self, M):
+        """The guard watches this bound: form="auto" above the size where "auto" means whitened anyway, a tolerance, an engine that reports."""
+        return (self.form == "auto" and self.streaming_tol > 0.0 and hasattr(self.engine, "streaming_error_report")
+                and not self._whitened(M))
 
     def _extended_ok(self, M):
         """The extended order exists for this bound (a rank-invariant statement: the shard size is the largest one of the job)."""
@@ -293,67 +336,64 @@ class CollapsedBound:
         return (hasattr(e, "suffstats_extended") and self.kernel != "composite" and self.extended_range > 1.0
                 and self._rows_for_form * int(M) >= self.whitened_rows_min_work)
 
-    def _ext_range(self, with_grad):
-        return self.extended_grad_range if with_grad else self.extended_range
-
-    def _choose_tier(self, M, with_grad=False):
-        """1 = the extended streaming order, 2 = the whitened order, for an evaluation whose streaming estimate is predicted as _pred_est."""
-        within = self._pred_est <= self._ext_range(with_grad) * self.streaming_tol  # (NaN / inf: the whitened order)
-        return 1 if within and self._extended_ok(M) else 2
-
-    def _start_whitened(self, M, with_grad=False):
-        """0, or the tier (1 extended, 2 whitened) this evaluation should start in without a streaming attempt (the guard tripped
-        recently and nothing says it would pass)."""
+    def _fixed_tier(self, M):
         if self.form == "extended":
-            return 1
-        if not (self._prefer_whitened and self._guard_on() and not self._whitened(M)):
-            return 0
-        return self._choose_tier(M, with_grad)
+            return TIER_EXTENDED
+        return TIER_WHITENED if self._whitened(M) else TIER_STREAMING
 
-    def _note_whitened(self, res, host):
-        """After an extended- or whitened-order evaluation that carries the estimate's upper bound: learn the ratio at the theta where
-        the guard tripped, or -- on later evaluations -- decide whether the streaming order is worth another try.  True when the
-        evaluation ran in the extended order and the prediction for ITS theta is beyond that order's range: repeat it whitened."""
-        if res.get("tier") == 1:
-            self.n_extended += 1
-        if not res.get("bounded"):
-            return False
-        ub = self.engine.read_estimate(host)
-        if not (ub > 0.0) or not math.isfinite(ub):
-            return False
-        tripped = getattr(self, "_tripped_estimate", None)
-        if tripped is not None:  # the repeat right behind the trip: same theta, so estimate / bound is exact here
-            self._est_ratio = min(1.0, tripped / ub) if math.isfinite(tripped) else 1.0
-            self._tripped_estimate = None
-            return False
-        self._pred_est = self._est_ratio * ub
-        if self._pred_est < 0.5 * self.streaming_tol:
-            self._prefer_whitened = False
-        return (res.get("tier") == 1 and self.form != "extended"
-                and not (self._pred_est <= self._ext_range(res.get("with_grad", False)) * self.streaming_tol))
-
-    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, force_whitened=0):
-        """force_whitened: 0 = by `form`, 1 = the extended streaming order, 2 (or True) = the whitened order."""
+    def _review(self, res, host, info, tier, reach, M, strict):
+        """What the evaluation's own numbers say: None = accept, or the tier to repeat it in.  Updates the guard's memory.
+        A failed factorization (info != 0) says nothing about the estimate: the state is left alone and nothing is repeated."""
+        if info != 0 or not res.get("reported"):
+            return None
         e = self.engine
+        est, ub = e.read_estimate(host), e.read_bound(host)
+        tol, ext_ok = self.streaming_tol, self._extended_ok(M)
+        self.last_estimate = est
+        if tier == TIER_WHITENED:
+            self.guard.note_bound(ub, tol)
+            if strict and self.guard.start_tier(tol, reach, ext_ok) < TIER_WHITENED:
+                return self.guard.start_tier(tol, reach, ext_ok)  # a lower tier is predicted to do: it states its exact estimate itself
+            return None
+        need = required_tier(est, tol, reach, ext_ok)
+        self.guard.note_exact(est, ub, tol)
+        if need > tier:
+            self.guard.open = True
+            return need
+        if strict and need < tier:
+            return need
+        return None
+
+    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, tier=TIER_STREAMING, report=False):
+        """One attempt in the given tier: pass 1, the exchange, the tail -- everything enqueued, nothing read back.
+        report: also the streaming-order estimate / bound into the result buffer (sgp_streaming_error_report)."""
+        e = self.engine
+        M = int(Z.shape[0])
         result = e.result_buffer(extra)  # (buf, out, info): everything the host reads back, one allocation
-        tier = 2 if force_whitened is True else int(force_whitened)
-        if tier == 1:
-            # the extended streaming order: the whitened statistics from ONE integer-core contraction (34 digit pairs, double-double fold)
+        if tier == TIER_EXTENDED:
+            # the extended streaming order: the whitened statistics from ONE integer-core contraction (39 digit pairs, double-double fold)
             # and a double-double triple product; pass 2 from the explicit Phibar on the fp64 K'_fu kept here
+            self.n_extended += 1
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
-            kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
-            packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu, level=self.extended_level)
-            self._allreduce_stats(packed, int(Z.shape[0]))
+            kfu = self._kfu_for(M) if with_adjoints else None
+            diag = None
+            if report:
+                if self._phi_diag is None or self._phi_diag.numel() < M:
+                    self._phi_diag = e.empty(M)
+                diag = self._phi_diag
+            packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu, level=self.extended_level,
+                                          **({"phi_diag": diag} if diag is not None else {}))
+            self._allreduce_stats(packed, M)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True)
-            if self._guard_on() and hasattr(e, "streaming_error_bound"):
-                e.streaming_error_bound(e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf()), sf2, s2, result)
-                res["bounded"] = True
-            res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv, tier=1, with_grad=bool(with_adjoints))
+            if report:
+                self._allreduce(diag[:M])  # (ranks hold the diagonal of their own shard's Phi)
+                e.streaming_error_report(diag, 1, e.kuu_inverse_trace(linv, M, out=self._trace_buf()), sf2, s2, self.N, M, result)
+                res["reported"] = True
+            res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv)
             return res
-        if tier == 2 or self._whitened(Z.shape[0]):
-            force_whitened = tier == 2
+        if tier == TIER_WHITENED:
             # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
@@ -361,33 +401,29 @@ class CollapsedBound:
             factored = with_adjoints and self.factored_adjoint and hasattr(e, "suffstats_bwd_factored")
             t_keep = None
             if (hasattr(e, "suffstats_whitened_rows") and self.kernel != "composite"
-                    and int(self.X.shape[0]) * int(Z.shape[0]) >= self.whitened_rows_min_work):
+                    and int(self.X.shape[0]) * M >= self.whitened_rows_min_work):
                 # a large shard (the streaming guard's repeats at 10^6 rows): the streaming layout; T = K'_fu L^-T stays for pass 2
-                t_keep = self._kfu_for(Z.shape[0]) if factored else None
+                t_keep = self._kfu_for(M) if factored else None
                 packed = e.suffstats_whitened_rows(self.X, self.y, Z, ls, sf2, linv, self.kernel, t_out=t_keep)
             else:
                 packed = e.suffstats_whitened(self.X, self.y, Z, ls, sf2, linv, self.kernel)
-            self._allreduce_stats(packed, int(Z.shape[0]))
+            self._allreduce_stats(packed, M)
             kw = {"want_cw": True} if factored else {}
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True, **kw)
-            if force_whitened and self._guard_on() and hasattr(e, "streaming_error_bound") and self.kernel != "composite":
-                e.streaming_error_bound(e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf()), sf2, s2, result)
-                res["bounded"] = True
-            res["packed"] = packed
-            res["kfu"] = None
-            res["t_keep"] = t_keep
-            res["linv"] = linv
-            res["tier"] = 2
+            if report and self.kernel != "composite":
+                e.streaming_error_report(None, 1, e.kuu_inverse_trace(linv, M, out=self._trace_buf()), sf2, s2, self.N, M, result)
+                res["reported"] = True
+            res.update(packed=packed, kfu=None, t_keep=t_keep, linv=linv)
             return res
-        kfu = self._kfu_for(Z.shape[0]) if with_adjoints else None
+        kfu = self._kfu_for(M) if with_adjoints else None
         gate = None
-        guard = self._guard_on()
+        guard = report
         trace = None
         # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
         # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)
         overlap = (self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
-                   and int(self.X.shape[0]) * int(Z.shape[0]) >= self.overlap_min_work)
+                   and int(self.X.shape[0]) * M >= self.overlap_min_work)
         if overlap:
             # chol(Kuu) and its inverse depend on (Z, theta) only: they run on a side stream beside the prologue /
             # kernel assembly of pass 1 (once the SYRK saturates the chip a chain of ~50 dependent small kernels
@@ -403,7 +439,7 @@ class CollapsedBound:
             # graph replay only single-process: with a process group the helper thread enqueues plain launches (same speed),
             # which keeps hipGraph capture away from the collective library's own threads
             use_graph = self.use_graph and self.world == 1 and hasattr(e, "kuu_factor_graph")
-            gr = e.kuu_factor_graph(Z.shape[0]) if use_graph else None
+            gr = e.kuu_factor_graph(M) if use_graph else None
             z_ready = main.record_event()  # Z is materialised on the main stream
             side, jitter, kernel = self._side, self.jitter, self.kernel
 
@@ -420,7 +456,7 @@ class CollapsedBound:
                         K = e.kuu(Z, ls, sf2, jitter, kernel)
                         li = e.kuu_factor(K, info=result[2])[0]
                     ready = side.record_event()  # what pass 1's tail waits for; the guard's tr(Kuu^-1) runs behind it, off the critical path
-                    return K, li, (e.kuu_inverse_trace(li, Z.shape[0], out=self._trace_buf()) if guard and with_trace else None), ready
+                    return K, li, (e.kuu_inverse_trace(li, M, out=self._trace_buf()) if guard and with_trace else None), ready
 
             result[0].record_stream(side)
             # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
@@ -431,19 +467,19 @@ class CollapsedBound:
             # ... and only where the integer cores will actually contract (the library's own rule for this engine's context: a
             # shard below it, a pinned fp64 mode or a composite kernel keeps the helper-thread overlap)
             if (gr is not None and hasattr(e, "would_use_i8") and self.kernel != "composite"
-                    and int(self.X.shape[0]) >= 300 * int(Z.shape[0]) and e.would_use_i8(int(self.X.shape[0]), int(Z.shape[0]))):
+                    and int(self.X.shape[0]) >= 300 * M and e.would_use_i8(int(self.X.shape[0]), M)):
                 chain = side_chain(with_trace=False)  # (this thread is about to enqueue pass 1: the guard's launch waits until it has)
                 gate = chain[3]
                 pending = None
             else:
                 pending = self._pool.submit(side_chain)
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
-        self._allreduce_stats(packed, int(Z.shape[0]))
+        self._allreduce_stats(packed, M)
         if overlap:
             Kuu, linv, trace, ready = pending.result() if pending is not None else chain
             if guard and trace is None:
                 with torch.cuda.stream(self._side):
-                    trace = e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf())
+                    trace = e.kuu_inverse_trace(linv, M, out=self._trace_buf())
             for t in (Kuu, linv):
                 t.record_stream(main)
             main.wait_event(ready)
@@ -454,21 +490,78 @@ class CollapsedBound:
         elif guard and hasattr(e, "kuu_factor"):
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             linv, _ = e.kuu_factor(Kuu, info=result[2])
-            trace = e.kuu_inverse_trace(linv, Z.shape[0], out=self._trace_buf())
+            trace = e.kuu_inverse_trace(linv, M, out=self._trace_buf())
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
         else:
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, result=result)
         if guard and trace is not None:
-            e.streaming_error_estimate(packed, trace, s2, self.N, Z.shape[0], result)
-            res["guarded"] = True
+            e.streaming_error_report(packed, M + 1, trace, sf2, s2, self.N, M, result)
+            res["reported"] = True
         res["packed"] = packed
         res["kfu"] = kfu
         return res
 
+    def _pass2(self, res, Z, ls, sf2, s2, want_gz, g):
+        """Pass 2 on the local rows + the all-reduce of the gradients + the K_uu path, into the packed gradient slice `g`."""
+        e = self.engine
+        # kappabar = dF/dkappa = -1 / (2 s2) needs nothing from the device (same value the tail writes to out)
+        if res.get("Cw") is not None:
+            # whitened order: Phibar's cond(K_uu)-sized entries would cancel in Phibar K_uf -- its factors are applied instead
+            e.suffstats_bwd_factored(self.X, self.y, Z, ls, sf2, res["linv"], res["Cw"], s2, res["bbar"], -1.0 / (2.0 * float(s2)),
+                                     self.kernel, want_gz=want_gz, out=g,
+                                     **({"t_in": res["t_keep"]} if res.get("t_keep") is not None else {}))
+        else:
+            e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
+                            self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
+        self._allreduce(g)
+        e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
+
+    def _evaluate(self, Z, ls, sf2, s2, with_grad=False, want_gz=False, want_factors=False, grad_reach=None, strict=False):
+        """ONE evaluation through the guard -- the driver value / value_and_grad / factors share.  Runs attempts (at most three: every
+        repeat goes to a strictly higher tier, or -- strict -- to the tier the evaluation's own estimate names) until `_review` accepts.
+        Returns (res, out (host), info, host buffer, head) of the accepted attempt; with_grad: the packed gradient sits behind `head`."""
+        e = self.engine
+        M, d = int(Z.shape[0]), int(Z.shape[1])
+        guard = self._guard_on(M)
+        reach = (self.extended_grad_range if grad_reach is None else float(grad_reach)) if with_grad else self.extended_range
+        ext_ok = self._extended_ok(M)
+        if guard:
+            tier = self.guard.start_tier(self.streaming_tol, reach, ext_ok)
+            if tier != TIER_STREAMING:
+                self.n_direct_whitened += 1
+        else:
+            tier = self._fixed_tier(M)
+        nh = (e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d) if with_grad else 0
+        extra = nh + 1 + (M * d if want_gz else 0) if with_grad else 0
+        # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the status and the
+        # gradient -- a failed factorization or a guard repeat then costs a wasted pass 2, which is cheaper than idling the GPU for
+        # a host round trip on every leapfrog.  Big shards check first.  The rule is the job's (largest shard), not this rank's:
+        # ranks must issue the same collectives in the same order.
+        early = with_grad and self._rows_for_form * M >= self.early_check_min_work
+        tried = set()
+        while True:
+            tried.add(tier)
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=with_grad, want_factors=want_factors, extra=extra, tier=tier, report=guard)
+            head = res["buf"].numel() - extra  # [out | status word | estimate | bound | pad], then the packed gradient (16-byte aligned)
+            g = res["buf"][head:] if with_grad else None
+            if with_grad and not early:
+                self._pass2(res, Z, ls, sf2, s2, want_gz, g)
+            o, info, host = self._fetch(res, upto=(head + nh + 1) if (with_grad and not early) else head)
+            nxt = self._review(res, host, info, tier, reach, M, strict) if guard else None
+            if nxt is not None and nxt not in tried:
+                self.n_guard_reruns += 1
+                tier = nxt
+                continue
+            if with_grad and early and info == 0:
+                self._pass2(res, Z, ls, sf2, s2, want_gz, g)
+                _, _, host = self._fetch(res, upto=head + nh + 1)
+            self.last_tier = tier
+            return res, o, info, host, head
+
     # ------------------------------------------------------------------ public
-    def value(self, Z, ls, sf2, s2, raise_on_fail=True):
+    def value(self, Z, ls, sf2, s2, raise_on_fail=True, strict=False):
         """F (not divided by N).  Returns (F, parts) with parts = dict(logmarg, trace_term, info)."""
         Z = self._prep_Z(Z)
         if self._small_ok(Z.shape[0], sf2=sf2):
@@ -481,20 +574,7 @@ class CollapsedBound:
                     raise NotPositiveDefiniteError(info)
                 return float("nan"), {"info": info}
             return float(h[0]), {"logmarg": float(h[nh + 2]), "trace_term": float(h[nh + 3]), "info": 0}
-        direct = self._start_whitened(Z.shape[0])
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=direct)
-        o, info, host = self._fetch(res)
-        if direct:
-            self.n_direct_whitened += 1
-        elif self._guard_trips(res, host):  # the streaming order is not trustworthy at this theta: the extended or PyMC3's order instead
-            self.n_guard_reruns += 1
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=self._choose_tier(Z.shape[0]))
-            o, info, host = self._fetch(res)
-        if self._note_whitened(res, host):  # an extended-order evaluation beyond that order's range
-            self.n_guard_reruns += 1
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, force_whitened=2)
-            o, info, host = self._fetch(res)
-            self._note_whitened(res, host)
+        res, o, info, host, _ = self._evaluate(Z, ls, sf2, s2, strict=strict)
         self.n_evals += 1
         if info != 0:
             if raise_on_fail:
@@ -515,10 +595,13 @@ class CollapsedBound:
             raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), self.d))
         return vals + [float(sf2), float(s2)], None
 
-    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True, _force_whitened=0):
+    def value_and_grad(self, Z, ls, sf2, s2, want_gz=False, raise_on_fail=True, grad_reach=None, strict=False):
         """F and dF/d{lengthscale_j, sf2, s2[, Z]} (natural parameters, not their raw transforms).
 
         Returns (F, grads) with grads = dict(ls=tensor[d] (cpu), sf2=float, s2=float, Z=device tensor or None).
+        grad_reach / strict: see HmcTarget(gradient="sampler") -- how far (x the tolerance) the extended order's explicit-Phibar gradient
+        is accepted (default: `extended_grad_range`, what keeps 1e-6), and whether the accepted tier must be the one the evaluation's own
+        estimate names (so that value and gradient are functions of theta alone).
         """
         e = self.engine
         Z = self._prep_Z(Z)
@@ -539,52 +622,7 @@ class CollapsedBound:
             return float(h[0]), {"ls": h[1:1 + d].clone(), "sf2": float(h[1 + d]), "s2": float(h[2 + d]), "Z": gz, "info": 0,
                                  "logmarg": float(h[d + 3]), "trace_term": float(h[d + 4])}
         nh = e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d  # composite kernels: the parameter block
-        direct = 0 if _force_whitened else self._start_whitened(M, with_grad=True)
-        if direct:
-            self.n_direct_whitened += 1
-            _force_whitened = direct
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=True, extra=nh + 1 + (M * d if want_gz else 0),
-                            force_whitened=_force_whitened)
-        noted = False
-        head = res["out"].numel() + 2  # [out | status word | pad], then the packed gradient (16-byte aligned)
-        # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the
-        # status and the gradient -- a failed factorization then costs a wasted pass 2 (its NaNs are discarded), which
-        # is cheaper than idling the GPU for a host round trip on every leapfrog.  Big shards check the status first.
-        early = int(self.X.shape[0]) * M >= self.early_check_min_work
-        if early:
-            o, info, hh = self._fetch(res, upto=head)
-            if self._guard_trips(res, hh):  # before pass 2 is spent on adjoints that cannot be trusted
-                self.n_guard_reruns += 1
-                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M, with_grad=True))
-            noted = True
-            if self._note_whitened(res, hh):  # an extended-order evaluation beyond that order's range: the whitened order, before pass 2
-                self.n_guard_reruns += 1
-                return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=2)
-            if info != 0:
-                self.n_evals += 1
-                self.n_grads += 1
-                if raise_on_fail:
-                    raise NotPositiveDefiniteError(info)
-                return float("nan"), {"info": info}
-        g = res["buf"][head:]
-        # kappabar = dF/dkappa = -1 / (2 s2) needs nothing from the device (same value the tail writes to out)
-        if res.get("Cw") is not None:
-            # whitened order: Phibar's cond(K_uu)-sized entries would cancel in Phibar K_uf -- its factors are applied instead
-            e.suffstats_bwd_factored(self.X, self.y, Z, ls, sf2, res["linv"], res["Cw"], s2, res["bbar"], -1.0 / (2.0 * float(s2)),
-                                     self.kernel, want_gz=want_gz, out=g,
-                                     **({"t_in": res["t_keep"]} if res.get("t_keep") is not None else {}))
-        else:
-            e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
-                            self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
-        self._allreduce(g)
-        e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
-        o, info, host = self._fetch(res, upto=head + nh + 1)
-        if not early and self._guard_trips(res, host):
-            self.n_guard_reruns += 1
-            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=self._choose_tier(M, with_grad=True))
-        if not noted and self._note_whitened(res, host):
-            self.n_guard_reruns += 1
-            return self.value_and_grad(Z, ls, sf2, s2, want_gz, raise_on_fail, _force_whitened=2)
+        res, o, info, host, head = self._evaluate(Z, ls, sf2, s2, with_grad=True, want_gz=want_gz, grad_reach=grad_reach, strict=strict)
         self.n_evals += 1
         self.n_grads += 1
         if info != 0:
@@ -592,6 +630,7 @@ class CollapsedBound:
                 raise NotPositiveDefiniteError(info)
             return float("nan"), {"info": info}
         gh = host[head:]
+        g = res["buf"][head:]
         grads = {"ls": gh[:nh].clone(), "sf2": float(gh[nh]), "s2": float(o[OUT_S2BAR]),
                  "Z": g[nh + 1:].reshape(M, d) if want_gz else None, "info": 0,
                  "logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE])}
@@ -600,20 +639,7 @@ class CollapsedBound:
     def factors(self, Z, ls, sf2, s2):
         """Device tensor [Linv | G | q] for ``predict`` (computed from the current statistics)."""
         Z = self._prep_Z(Z)
-        direct = self._start_whitened(Z.shape[0])
-        res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=direct)
-        _, info, host = self._fetch(res)
-        if direct:
-            self.n_direct_whitened += 1
-        elif self._guard_trips(res, host):
-            self.n_guard_reruns += 1
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=self._choose_tier(Z.shape[0]))
-            _, info, host = self._fetch(res)
-        if self._note_whitened(res, host):
-            self.n_guard_reruns += 1
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=False, want_factors=True, force_whitened=2)
-            _, info, host = self._fetch(res)
-            self._note_whitened(res, host)
+        res, _, info, _, _ = self._evaluate(Z, ls, sf2, s2, want_factors=True)
         if info != 0:
             raise NotPositiveDefiniteError(info)
         return res["factors"]
@@ -656,11 +682,23 @@ class HmcTarget:
     sampler treats as a divergence, never an exception.
     """
 
-    def __init__(self, bound: CollapsedBound, Z):
+    def __init__(self, bound: CollapsedBound, Z, gradient="parity"):
+        """gradient: "parity" (default) -- every gradient holds 1e-6 against the CPU path (north_star): where the streaming order's error
+        estimate is beyond 3 x its tolerance a leapfrog runs in the whitened order (74 instead of 49 ms at C5).
+        "sampler" -- opt-in for NUTS in such a region: the extended order serves value AND gradient as far as its VALUE holds (2^14 x the
+        tolerance; 55 ms per leapfrog at C5).  The energy still meets 1e-8 per datum; the force is the extended order's explicit-Phibar
+        gradient, off by up to ~1e-4 relative at the far end of that range (profiles/r04_extended_order_c5.jsonl) -- but a deterministic
+        function of theta: the tier of every evaluation is the one its OWN error estimate names (`strict`), never the guard's memory of
+        earlier evaluations.  Leapfrog with a deterministic approximate force is still volume preserving and reversible, and the
+        accept step uses the accurate energy, so the chain still targets the exact posterior (tests/test_posterior_pin.py holds the
+        mode to the same 4 MCSE pin as the default); only the acceptance rate pays for the force error."""
+        if gradient not in ("parity", "sampler"):
+            raise ValueError("gradient must be 'parity' or 'sampler'")
         self.bound = bound
         self.Z = bound._prep_Z(Z)
         self.d = bound.d
         self.ndim = self.d + 2
+        self.gradient = gradient
 
     def start(self):
         """PyMC3's test point in the unconstrained space: Gamma(2,1) -> mean 2, HalfCauchy(1) -> 1."""
@@ -697,7 +735,8 @@ class HmcTarget:
         if self.bound._small_ok(self.Z.shape[0]):
             return self.logp_and_grad(theta)[0]
         p = self.constrain(theta)
-        F, parts = self.bound.value(self.Z, p["ls"], p["sig_f"] ** 2, p["sig_n"] ** 2, raise_on_fail=False)
+        F, parts = self.bound.value(self.Z, p["ls"], p["sig_f"] ** 2, p["sig_n"] ** 2, raise_on_fail=False,
+                                    **({"strict": True} if self.gradient == "sampler" else {}))
         if parts.get("info", 0) != 0 or not math.isfinite(F):
             return -math.inf
         lp, _, _, _ = self._prior(p["ls"], p["sig_f"], p["sig_n"])
@@ -719,7 +758,8 @@ class HmcTarget:
             return lp, [float(v) for v in h[1:1 + self.ndim]]
         p = self.constrain(theta)
         ls, sf, sn = p["ls"], p["sig_f"], p["sig_n"]
-        F, g = self.bound.value_and_grad(self.Z, ls, sf * sf, sn * sn, want_gz=False, raise_on_fail=False)
+        kw = {"grad_reach": self.bound.extended_range, "strict": True} if self.gradient == "sampler" else {}
+        F, g = self.bound.value_and_grad(self.Z, ls, sf * sf, sn * sn, want_gz=False, raise_on_fail=False, **kw)
         if g.get("info", 0) != 0 or not math.isfinite(F):
             return -math.inf, [0.0] * self.ndim
         lp, pg_ls, pg_sf, pg_sn = self._prior(ls, sf, sn)

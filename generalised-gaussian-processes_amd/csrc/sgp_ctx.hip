@@ -160,3 +160,62 @@ extern "C" int sgp_ctx_mixture_predict(sgp_ctx* ctx, const double* X, int64_t ld
   return sgp_mixture_predict(X, ldx, y, N, Xs, ldxs, T, Z, ldz, S, inv_ls, sf2, s2, jitter, M, d, kernel_id, pred_noise, gate_jitter,
                              mean, var, cov, info, gate_info, ws, ws_bytes, stream);
 }
+
+// ---- ABI 3: the remaining option-dependent entry points (the evaluation orders the streaming guard falls back to read the K'_fu
+// budget, the timing slots and the CU budget of the context; the whitened bound's Cholesky reads the CU budget and the conditioning limit) ----
+extern "C" size_t sgp_ctx_suffstats_whitened_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d) {
+  CtxScope scope(const_cast<sgp_ctx*>(ctx));
+  return sgp_suffstats_whitened_workspace_bytes(N, M, d);
+}
+extern "C" int sgp_ctx_suffstats_fwd_whitened(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                              const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                              const double* kuu_linv, double* W, double* u, double* yy, double* kappa, void* ws,
+                                              size_t ws_bytes, sgp_stream_t stream) {
+  CtxScope scope(ctx);
+  return sgp_suffstats_fwd_whitened(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, W, u, yy, kappa, ws, ws_bytes, stream);
+}
+extern "C" size_t sgp_ctx_suffstats_whitened_rows_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_t) {
+  CtxScope scope(const_cast<sgp_ctx*>(ctx));
+  return sgp_suffstats_whitened_rows_workspace_bytes(N, M, d, caller_owns_t);
+}
+extern "C" int sgp_ctx_suffstats_fwd_whitened_rows(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z,
+                                                   int64_t ldz, const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                                   const double* kuu_linv, double* W, double* u, double* yy, double* kappa,
+                                                   double* T_out, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  CtxScope scope(ctx);
+  return sgp_suffstats_fwd_whitened_rows(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, W, u, yy, kappa, T_out, ws,
+                                         ws_bytes, stream);
+}
+extern "C" size_t sgp_ctx_suffstats_extended_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d) {
+  CtxScope scope(const_cast<sgp_ctx*>(ctx));
+  return sgp_suffstats_extended_workspace_bytes(N, M, d);
+}
+extern "C" int sgp_ctx_suffstats_fwd_extended(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                              const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                              const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
+                                              double* Kfu_out, double* phi_diag, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  CtxScope scope(ctx);
+  return sgp_suffstats_fwd_extended_ex(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, level, W, u, yy, kappa, Kfu_out,
+                                       phi_diag, ws, ws_bytes, stream);
+}
+extern "C" size_t sgp_ctx_suffstats_bwd_factored_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_t) {
+  CtxScope scope(const_cast<sgp_ctx*>(ctx));
+  return sgp_suffstats_bwd_factored_workspace_bytes_ex(N, M, d, caller_owns_t);
+}
+extern "C" int sgp_ctx_suffstats_bwd_factored(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                              const double* inv_ls, double sf2, const double* kuu_linv, const double* Cw, double s2,
+                                              const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id,
+                                              const double* T_in, double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
+                                              sgp_stream_t stream) {
+  CtxScope scope(ctx);
+  return sgp_suffstats_bwd_factored_ex(X, ldx, y, Z, ldz, inv_ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, N, M, d, kernel_id, T_in, g_ls,
+                                       g_sf2, g_Z, ws, ws_bytes, stream);
+}
+extern "C" int sgp_ctx_bound_from_whitened_stats(sgp_ctx* ctx, const double* W, const double* u, const double* yy, const double* kappa,
+                                                 double s2, int64_t N, int M, int with_adjoints, double* out, double* Phibar,
+                                                 double* bbar, double* Kuubar, double* factors, const double* kuu_linv, int* info,
+                                                 double* Cw, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  CtxScope scope(ctx);
+  return sgp_bound_from_whitened_stats_ex(W, u, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info,
+                                          Cw, ws, ws_bytes, stream);
+}

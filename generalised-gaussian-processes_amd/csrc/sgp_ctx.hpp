@@ -31,7 +31,6 @@ struct Ctx {
   int ev_ready = 0, ev_used[CTX_TIMING_SLOTS] = {0, 0, 0};
   hipStream_t side = nullptr;       // library-owned side stream of the head + tail A/B (asm_overlap = 1)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool i8_attr_set = false;         // hipFuncSetAttribute(dynamic LDS) done for this context's device
 };
 
 Ctx& default_ctx();

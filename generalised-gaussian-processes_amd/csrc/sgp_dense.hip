@@ -13,6 +13,7 @@
 #include "sgp_dense.hpp"
 #include "sgp_ctx.hpp"
 #include "sgp_potrf.hpp"
+#include "sgp_potrf_chain.hpp"
 #include <cstdlib>
 
 namespace sgp {
@@ -466,6 +467,26 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t 
   potrf_dataflow_body(A, ld, nb, ready, dinv_g, info, info_base, rhs, sol, Linv, sh, blockIdx.x, gridDim.x);
 }
 
+// Round 5: the chain-workgroup factorization (sgp_potrf_chain.hpp).  Workgroup 0 (eight waves) is the chain workgroup; the others
+// keep four waves (the upper four leave at once: the hardware barrier counts live waves only).
+union ChainSharedAll {
+  ChShared ch;
+  DfShared df;
+  __device__ ChainSharedAll() {}
+};
+__global__ __launch_bounds__(CH_THREADS) void potrf_chain_kernel(double* A, int64_t ld, int nb, int* scratch, int* info, int info_base,
+                                                                const double* rhs, double* sol, double* Linv) {
+  __shared__ ChainSharedAll sh;
+  const ChScratch sc = ch_scratch(scratch, nb);
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 256) chain_d_role(A, ld, nb, sc, info, info_base, sh.ch);
+    else chain_s_role(A, ld, nb, sc, sh.ch);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  chain_outside(A, ld, nb, sc, rhs, sol, Linv, sh.df, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+}
+
 // S factorizations side by side: blockIdx.y selects the matrix, its flags / block inverses and its status word
 __global__ __launch_bounds__(256) void potrf_dataflow_batch_kernel(double* A, int64_t ld, int nb, int* scratch, int64_t scratch_ints,
                                                                     int64_t flag_ints, int* info, double* Linv, int64_t stride) {
@@ -481,7 +502,7 @@ __global__ void potrf_timeout_batch_kernel(const int* scratch, int64_t scratch_i
 }
 
 #ifdef SGP_POTRF_STAMPS
-extern "C" int sgp_debug_potrf_stamps(unsigned long long* host_out) {
+extern "C" __attribute__((visibility("default"))) int sgp_debug_potrf_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_potrf_stamps), sizeof(unsigned long long) * 64 * 16);
 }
 #endif
@@ -502,11 +523,13 @@ __global__ void potrf_timeout_kernel(const int* abort_flag, int* info) {
 
 size_t potrf_flag_ints(int Mp) {
   const size_t nb = Mp / DB;
-  return (nb * (nb + 1) / 2 + 1) * DF_FLAG_STRIDE;  // one cache line per tile flag + the abort flag
+  // one cache line per tile flag + the abort flag + (chain-workgroup kernel) per column: two prep flags and four panel counters
+  return ch_flag_slots((int)nb) * DF_FLAG_STRIDE;
 }
 size_t potrf_scratch_ints(int Mp) {
   const size_t nb = Mp / DB;
-  return potrf_flag_ints(Mp) + nb * 1024 * 2;  // + the 16 x 16 block inverses of every diagonal tile (doubles)
+  // + the 16 x 16 block inverses of every diagonal tile + (chain-workgroup kernel) the prep items' partial sums US / UD (doubles)
+  return potrf_flag_ints(Mp) + nb * 1024 * 2 + nb * 4096 * 2 * 5;
 }
 
 const int* potrf_abort_flag(const int* scratch, int Mp) {
@@ -557,6 +580,15 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   if (!caller_managed && !(prepped & 1)) zero_ints(scratch, (int)potrf_flag_ints(Mp), st);
   if (Linv && !(prepped & 2)) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
+  // the chain-workgroup kernel from two block columns on, when at least one other workgroup can be resident beside it
+  static const int use_chain = getenv("SGP_POTRF_CHAIN") ? atoi(getenv("SGP_POTRF_CHAIN")) : 1;  // 0: the round-1 dataflow kernel (A/B)
+  if (use_chain && nb >= 2 && max_wg >= 2) {
+    const int nout_items = ch_tile_items(nb) + (Linv ? nb : 0) + (rhs ? 1 : 0);  // tiles (tile (c+2, c) twice), block inverses, rhs
+    const int nout = nout_items < max_wg - 1 ? nout_items : max_wg - 1;
+    potrf_chain_kernel<<<1 + nout, CH_THREADS, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
+    if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
+    return;
+  }
   potrf_dataflow_kernel<<<nitem < max_wg ? nitem : max_wg, 256, 0, st>>>(
       A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv);
   if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);

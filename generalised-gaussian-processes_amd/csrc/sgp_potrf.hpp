@@ -318,19 +318,31 @@ __device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag, int* d
 }
 
 // acc += P(64 x 64) Q(64 x 64)^T, both row-major with the contraction index contiguous (tiles of L)
-__device__ __forceinline__ void df_mac(const double* P, const double* Q, int64_t ld, DfShared& sh, d4 (&acc)[2][2]) {
+// PL / QL: that operand is the tile held in sh.Ts (row-major, stride TLD) instead of global memory
+template <bool PL = false, bool QL = false>
+__device__ __forceinline__ void df_mac(const double* P, const double* Q, int64_t ld, int64_t ldq, DfShared& sh, d4 (&acc)[2][2]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wi = wave >> 1, wj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const int row = t >> 2, kq = (t & 3) * 4;
   double va[4][4], vb[4][4];  // the whole of both tiles: one round trip to L2, then four LDS chunks
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const double* sa = P + (int64_t)row * ld + c * GK + kq;
-    const double* sb = Q + (int64_t)row * ld + c * GK + kq;
-    const d2 a0 = *reinterpret_cast<const d2*>(sa), a1 = *reinterpret_cast<const d2*>(sa + 2);
-    const d2 b0 = *reinterpret_cast<const d2*>(sb), b1 = *reinterpret_cast<const d2*>(sb + 2);
-    va[c][0] = a0[0]; va[c][1] = a0[1]; va[c][2] = a1[0]; va[c][3] = a1[1];
-    vb[c][0] = b0[0]; vb[c][1] = b0[1]; vb[c][2] = b1[0]; vb[c][3] = b1[1];
+    if constexpr (PL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) va[c][e] = sh.Ts[row][c * GK + kq + e];
+    } else {
+      const double* sa = P + (int64_t)row * ld + c * GK + kq;
+      const d2 a0 = *reinterpret_cast<const d2*>(sa), a1 = *reinterpret_cast<const d2*>(sa + 2);
+      va[c][0] = a0[0]; va[c][1] = a0[1]; va[c][2] = a1[0]; va[c][3] = a1[1];
+    }
+    if constexpr (QL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vb[c][e] = sh.Ts[row][c * GK + kq + e];
+    } else {
+      const double* sb = Q + (int64_t)row * ldq + c * GK + kq;
+      const d2 b0 = *reinterpret_cast<const d2*>(sb), b1 = *reinterpret_cast<const d2*>(sb + 2);
+      vb[c][0] = b0[0]; vb[c][1] = b0[1]; vb[c][2] = b1[0]; vb[c][3] = b1[1];
+    }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -555,10 +567,10 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
       // the diagonal tile's update first: it needs row i only, while for p = j - 1 the other operand of `acc`, tile
       // (j, j - 1), is the X its owner publishes just before it starts to factor (j, j) -- what is still to do after
       // that flag decides whether this item is ready when that factorization ends (stamps, tools/potrf_phases.py)
-      if (head) df_mac(Lip, Lip, ld, sh, accd);
+      if (head) df_mac(Lip, Lip, ld, ld, sh, accd);
       if (!df_wait(ready + tile_no(j, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
       if (head && p == j - 1) SGP_PSTAMP(i, 0);
-      df_mac(Lip, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, sh, acc);
+      df_mac(Lip, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, ld, sh, acc);
     }
     acc_to_ts(acc);
     if (tid < 4) sh.prog[tid] = 0;

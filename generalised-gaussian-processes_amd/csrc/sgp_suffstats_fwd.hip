@@ -757,6 +757,12 @@ __global__ __launch_bounds__(256) void ext_w_out_kernel(const double* __restrict
   }
 }
 
+// phi_diag[i] = scale * Ph[i][i]: what the streaming-order estimate needs from Phi (the extended order returns W, not Phi)
+__global__ void ext_phi_diag_kernel(const double* __restrict__ Ph, int M, int Mp, double scale, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) out[i] = scale * Ph[(size_t)i * Mp + i];
+}
+
 struct ExtWs {
   double *Xs, *ys, *Zs, *slab, *slab_lo, *bpart, *btmp, *yypart, *Ph, *Pl, *Yh, *Yl, *Wh, *Wl, *bpad, *upad;
   uint8_t* Q;
@@ -1037,7 +1043,7 @@ extern "C" int sgp_suffstats_fwd_whitened_rows(const double* X, int64_t ldx, con
 
 // ---- the extended streaming order ---------------------------------------------------------------------------------------------
 // The same whitened statistics [W = A A^T | u = A y | yy | kappa], A = L^-1 K_uf, from the STREAMING design: Phi = K'^T K' on the integer
-// matrix cores with 34 digit pairs and a double-double fold / slab reduction (exact sums of the fixed-point kernel values to 2^-61 of the
+// matrix cores with 34 (level 1) or 39 (level 2: the product's default) digit pairs and a double-double fold / slab reduction (exact sums of the fixed-point kernel values to 2^-61 / 2^-69 of the
 // largest entry instead of fp64's 2^-53), then W = L^-1 Phi L^-T by two double-double products, u = L^-1 b in fp64 (a CPU study finds it
 // harmless, tests/studies/extended_streaming_order.py).  What the explicit-inverse sandwich amplifies is 2^8 times smaller than in
 // sgp_suffstats_fwd + sgp_bound_from_stats, so the streaming order's guard (sgp_streaming_error_estimate) passes 256 times later; the cost
@@ -1054,6 +1060,15 @@ extern "C" int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const do
                                           const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
                                           const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
                                           double* Kfu_out, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  return sgp_suffstats_fwd_extended_ex(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, level, W, u, yy, kappa, Kfu_out,
+                                       nullptr, ws, ws_bytes, stream);
+}
+// ... with one more output (ABI 3): phi_diag (DEVICE, M doubles, or NULL) = diag(K_uf K_fu) of THIS shard, with its amplitude -- what
+// sgp_streaming_error_report needs to state the streaming-order estimate exactly at this theta (ranks add their phi_diag up).
+extern "C" int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                             const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                             const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
+                                             double* Kfu_out, double* phi_diag, void* ws, size_t ws_bytes, sgp_stream_t stream) {
   if (!Z || !inv_ls || !kuu_linv || !W || !u || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id >= SGP_KERNEL_COMPOSITE || level < 1 || level > 2) return SGP_ERR_ARG;
@@ -1089,6 +1104,7 @@ extern "C" int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const do
   dd_gemm_nt_kernel<<<g, 256, 0, st>>>(w.Ph, w.Pl, kuu_linv, p.Mp, w.Yh, w.Yl, 1);  // Y^T = (Phi L^-T)^T
   dd_gemm_nt_kernel<<<g, 256, 0, st>>>(w.Yh, w.Yl, kuu_linv, p.Mp, w.Wh, w.Wl, 0);  // W = Y^T L^-T = L^-1 Phi L^-T (symmetric)
   ext_w_out_kernel<<<1024, 256, 0, st>>>(w.Wh, w.Wl, M, p.Mp, sf2 * sf2, W);
+  if (phi_diag) ext_phi_diag_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.Ph, M, p.Mp, sf2 * sf2, phi_diag);
   // b = K_uf y (fp64, with its amplitude), u = L^-1 b
   fill_zero(w.bpad, p.Mp, st);
   bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);

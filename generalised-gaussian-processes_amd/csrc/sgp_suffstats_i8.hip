@@ -391,7 +391,12 @@ void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* y
 // leaves it for reduce_phi_kernel.  rows: a multiple of 32; nsplit from i8_nsplit() (the same for every super-chunk).
 int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st, double* slab_lo, int level) {
   Ctx& cx = cur_ctx();
-  if (!cx.i8_attr_set) {  // per context, i.e. per device (the attribute belongs to the device's copy of the kernels)
+  // once per DEVICE (the attribute belongs to the device's copy of the kernels), whatever context asks: a context created for another
+  // device, or an entry point running in the default context on a second device, must not inherit the first device's "done"
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SGP_ERR_LAUNCH;
+  if (!attr_done[dev]) {
     if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<I8_MINSUM_DEFAULT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             I8_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
@@ -399,7 +404,7 @@ int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumula
         hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
             hipSuccess)
       return SGP_ERR_LAUNCH;
-    cx.i8_attr_set = true;
+    attr_done[dev] = true;
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
   const int prio = cx.i8_prio;  // A/B knob SGP_I8_PRIO (read when the context is created; measured a loss)

@@ -782,6 +782,35 @@ extern "C" int sgp_streaming_error_bound(const double* trace_inv, double sf2, do
   return check_launch();
 }
 
+// ABI 3: estimate and upper bound in one call, from whatever the evaluation order has of Phi's diagonal:
+//   est[0] = 2^-53 max_i diag[i * stride] tr(K_uu^-1) / (s2 N)   (diag = Phi with stride M + 1, or the extended order's phi_diag with stride 1;
+//                                                                  diag = NULL: est[0] = est[1], all a whitened-order evaluation can say)
+//   est[1] = 2^-53 sf2^2 tr(K_uu^-1) / s2                         (max_i Phi_ii <= N sf2^2)
+__global__ __launch_bounds__(256) void streaming_report_kernel(const double* __restrict__ diag, int64_t stride, int M,
+                                                               const double* __restrict__ tr, double sf2, double s2, double n,
+                                                               double* __restrict__ est) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  if (diag)
+    for (int i = threadIdx.x; i < M; i += 256) mx = fmax(mx, diag[(int64_t)i * stride]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ub = 0x1p-53 * sf2 * sf2 * tr[0] / s2;
+    est[1] = ub;
+    est[0] = diag ? 0x1p-53 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) * tr[0] / (s2 * n) : ub;
+  }
+}
+extern "C" int sgp_streaming_error_report(const double* diag, int64_t stride, const double* trace_inv, double sf2, double s2, int64_t N,
+                                          int M, double* est, sgp_stream_t stream) {
+  if (!trace_inv || !est || M <= 0 || N < 0 || !(s2 > 0.0) || !(sf2 > 0.0) || (diag && stride <= 0)) return SGP_ERR_ARG;
+  if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  streaming_report_kernel<<<1, 256, 0, (hipStream_t)stream>>>(diag, stride, M, trace_inv, sf2, s2, N > 0 ? (double)N : 1.0, est);
+  return check_launch();
+}
+
 extern "C" void sgp_set_cond_limit(double limit) { default_ctx().cond_limit = limit >= 0.0 ? limit : 1e13; }  // deprecated shim
 
 // whitened: Phi / b already are W = A A^T and u = A y with A = L^-1 K_uf (sgp_suffstats_fwd_whitened); kuu_linv required

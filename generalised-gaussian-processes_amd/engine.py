@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from ._lib import COMP_LEN, KERNEL_IDS, OUT_LEN
 
-RESULT_HEAD = OUT_LEN + 2  # doubles ahead of the caller's extras in a result buffer: out, status word, pad
+RESULT_HEAD = OUT_LEN + 4  # doubles ahead of the caller's extras in a result buffer: out, status word, estimate, bound, pad
 
 
 def _kernel_id(kernel) -> int:
@@ -169,13 +169,13 @@ class HipEngine:
             self._chk(X, "X"), self._chk(y, "y")
         if out is None:
             out = self.empty(M * M + M + 2)
-        nbytes = self.lib.sgp_suffstats_whitened_workspace_bytes(N, M, d)
+        nbytes = self.lib.sgp_ctx_suffstats_whitened_workspace_bytes(self._c(), N, M, d)
         if nbytes == 0:
             raise ValueError("unsupported shape N=%d M=%d d=%d" % (N, M, d))
         ws = self._workspace("fwd_whitened", nbytes)
         base = out.data_ptr()
-        st = self.lib.sgp_suffstats_fwd_whitened(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+        st = self.lib.sgp_ctx_suffstats_fwd_whitened(
+            self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             self._ptr(kuu_linv), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_fwd_whitened", st)
@@ -196,13 +196,13 @@ class HipEngine:
             self._chk(t_out, "t_out")
             if t_out.numel() < self.lib.sgp_kfu_len(N, M):
                 raise ValueError("t_out holds %d doubles, sgp_kfu_len(N, M) = %d" % (t_out.numel(), self.lib.sgp_kfu_len(N, M)))
-        nbytes = self.lib.sgp_suffstats_whitened_rows_workspace_bytes(N, M, d, 1 if t_out is not None else 0)
+        nbytes = self.lib.sgp_ctx_suffstats_whitened_rows_workspace_bytes(self._c(), N, M, d, 1 if t_out is not None else 0)
         if nbytes == 0:
             raise ValueError("unsupported shape N=%d M=%d d=%d" % (N, M, d))
         ws = self._workspace("fwd_whitened_rows_t" if t_out is not None else "fwd_whitened_rows", nbytes)
         base = out.data_ptr()
-        st = self.lib.sgp_suffstats_fwd_whitened_rows(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+        st = self.lib.sgp_ctx_suffstats_fwd_whitened_rows(
+            self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             self._ptr(kuu_linv), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(t_out) if t_out is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
             self._stream())
@@ -210,10 +210,11 @@ class HipEngine:
         return out
 
     def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out: Optional[torch.Tensor] = None,
-                           kfu: Optional[torch.Tensor] = None, level: int = 1) -> torch.Tensor:
+                           kfu: Optional[torch.Tensor] = None, level: int = 1, phi_diag: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The whitened statistics [W | u | yy | kappa] from the EXTENDED streaming order (include/sgp.h: sgp_suffstats_fwd_extended):
         Phi on the integer matrix cores to 2^-61, the triple product in double-double.  ``kfu`` (from ``kfu_buffer``) keeps the fp64
-        K'_fu for ``suffstats_bwd``.  ``level`` 1: 34 digit pairs (Phi to 2^-61), 2: 39 pairs (2^-69).  Stationary kernels."""
+        K'_fu for ``suffstats_bwd``.  ``level`` 1: 34 digit pairs (Phi to 2^-61), 2: 39 pairs (2^-69).  Stationary kernels.
+        ``phi_diag`` (M doubles): receives diag(K_uf K_fu) of this shard for ``streaming_error_report`` (ranks add theirs up)."""
         N, d = X.shape
         M = Z.shape[0]
         self._chk(Z, "Z"), self._chk(kuu_linv, "kuu_linv")
@@ -225,16 +226,20 @@ class HipEngine:
             self._chk(kfu, "kfu")
             if kfu.numel() < self.lib.sgp_kfu_len(N, M):
                 raise ValueError("kfu holds %d doubles, sgp_kfu_len(N, M) = %d" % (kfu.numel(), self.lib.sgp_kfu_len(N, M)))
-        nbytes = self.lib.sgp_suffstats_extended_workspace_bytes(N, M, d)
+        nbytes = self.lib.sgp_ctx_suffstats_extended_workspace_bytes(self._c(), N, M, d)
         if nbytes == 0:
             raise ValueError("unsupported shape N=%d M=%d d=%d" % (N, M, d))
         ws = self._workspace("fwd_extended", nbytes)
         base = out.data_ptr()
-        st = self.lib.sgp_suffstats_fwd_extended(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
+        if phi_diag is not None:
+            self._chk(phi_diag, "phi_diag")
+            if phi_diag.numel() < M:
+                raise ValueError("phi_diag holds %d doubles, M = %d" % (phi_diag.numel(), M))
+        st = self.lib.sgp_ctx_suffstats_fwd_extended(
+            self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             self._ptr(kuu_linv), int(level), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
-            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu) if kfu is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
-            self._stream())
+            C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu) if kfu is not None else C.c_void_p(0),
+            self._ptr(phi_diag) if phi_diag is not None else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_fwd_extended", st)
         return out
 
@@ -260,7 +265,8 @@ class HipEngine:
     # ------------------------------------------------------------------ tail
     def result_buffer(self, extra: int = 0):
         """One allocation for everything the host reads back after an evaluation: (buf, out, info) with
-        buf = [out (OUT_LEN doubles) | status word (int32, in the low half of one double) | pad | extra doubles]
+        buf = [out (OUT_LEN doubles) | status word (int32, in the low half of one double) | streaming-order estimate | its upper bound |
+               pad | extra doubles]
         (RESULT_HEAD doubles ahead of the extras: they start 16-byte aligned, collectives run on that slice), so a single
         device-to-host copy of ``buf`` -- and no cast / concatenate launches -- ends the evaluation."""
         buf = self.empty(RESULT_HEAD + extra)
@@ -304,9 +310,22 @@ class HipEngine:
         est = C.c_void_p(result[0].data_ptr() + 8 * (OUT_LEN + 1))
         _lib.check("sgp_streaming_error_bound", self.lib.sgp_streaming_error_bound(self._ptr(trace), float(sf2), float(s2), est, self._stream()))
 
+    def streaming_error_report(self, diag, stride, trace, sf2, s2, N, M, result) -> None:
+        """Estimate AND upper bound into the two words behind the status word of ``result`` (include/sgp.h:
+        sgp_streaming_error_report).  ``diag``: the (all-reduced) packed statistics of the streaming order with ``stride`` M + 1, the
+        (all-reduced) ``phi_diag`` of the extended order with ``stride`` 1, or None (whitened order: the estimate IS the bound)."""
+        est = C.c_void_p(result[0].data_ptr() + 8 * (OUT_LEN + 1))
+        _lib.check("sgp_streaming_error_report",
+                   self.lib.sgp_streaming_error_report(self._ptr(diag) if diag is not None else C.c_void_p(0), int(stride), self._ptr(trace),
+                                                       float(sf2), float(s2), int(N), int(M), est, self._stream()))
+
     @staticmethod
     def read_estimate(host_buf) -> float:
         return float(host_buf[OUT_LEN + 1])
+
+    @staticmethod
+    def read_bound(host_buf) -> float:
+        return float(host_buf[OUT_LEN + 2])
 
     def kuu_factor_graph(self, M: int):
         """The ~50 launches of ``kuu_factor`` captured once per M in a hipGraph over static buffers: replaying it costs
@@ -392,12 +411,11 @@ class HipEngine:
                  C.c_void_p(base + 8 * (M * M + M + 1)))
         tail = (float(s2), int(N), M, 1 if with_adjoints else 0, self._ptr(out), self._ptr(Phibar), self._ptr(bbar),
                 self._ptr(Kuubar), self._ptr(factors), self._ptr(kuu_linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
-        if whitened and want_cw and with_adjoints:
-            res["Cw"] = self.empty(M, M)
-            _lib.check("sgp_bound_from_whitened_stats_ex",
-                       self.lib.sgp_bound_from_whitened_stats_ex(*stats, *tail[:-3], self._ptr(res["Cw"]), *tail[-3:]))
-        elif whitened:
-            _lib.check("sgp_bound_from_whitened_stats", self.lib.sgp_bound_from_whitened_stats(*stats, *tail))
+        if whitened:  # (Cw = NULL: the plain whitened bound)
+            if want_cw and with_adjoints:
+                res["Cw"] = self.empty(M, M)
+            _lib.check("sgp_bound_from_whitened_stats",
+                       self.lib.sgp_ctx_bound_from_whitened_stats(self._c(), *stats, *tail[:-3], self._ptr(res.get("Cw")), *tail[-3:]))
         else:
             _lib.check("sgp_bound_from_stats", self.lib.sgp_ctx_bound_from_stats(self._c(), self._ptr(Kuu), *stats, *tail))
         return res
@@ -583,11 +601,11 @@ class HipEngine:
             out = self.empty(nh + 1 + (M * d if want_gz else 0))
         if t_in is not None:
             self._chk(t_in, "t_in")
-        nbytes = self.lib.sgp_suffstats_bwd_factored_workspace_bytes_ex(N, M, d, 1 if t_in is not None else 0)
+        nbytes = self.lib.sgp_ctx_suffstats_bwd_factored_workspace_bytes(self._c(), N, M, d, 1 if t_in is not None else 0)
         ws = self._workspace("bwd_factored_t" if t_in is not None else "bwd_factored", nbytes)
         base = out.data_ptr()
-        st = self.lib.sgp_suffstats_bwd_factored_ex(
-            self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(kuu_linv),
+        st = self.lib.sgp_ctx_suffstats_bwd_factored(
+            self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), self._ptr(kuu_linv),
             self._ptr(Cw), float(s2), self._ptr(bbar), float(kappabar), N, M, d, _kernel_id(kernel),
             self._ptr(t_in) if t_in is not None else C.c_void_p(0), C.c_void_p(base),
             C.c_void_p(base + 8 * nh), C.c_void_p(base + 8 * (nh + 1)) if want_gz else C.c_void_p(0), self._ptr(ws), ws.numel(),

@@ -154,6 +154,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
         self._seed = seed
         self._n_hmc_calls = 0
         self.device_sampler = True  # NUTS on the device when the problem takes the single-launch path (M <= 128)
+        self.hmc_gradient = "parity"  # or "sampler": see core.HmcTarget (large shards in the streaming-order guard's regime)
         self.batched_theta_loss = True  # ... and the theta-averaged loss of the alternating schedule in one launch
 
     def freeze_kernel_hyperparameters(self):
@@ -170,7 +171,7 @@ class BayesianSparseGPR_HMC(SparseGPR):  # noqa: N801  (reference class name)
     def sample_optimal_variational_hyper_dist(self, n_samples, input_dim, Z_opt, tune, sampler_params=None) -> Trace:
         """NUTS over (ls, sig_f, sig_n) with Z fixed at Z_opt (reference models/bayesian_sgpr_hmc.py:58-80)."""
         Z = torch.as_tensor(np.asarray(Z_opt), dtype=torch.float64)
-        target = HmcTarget(self._hmc_bound(), Z)
+        target = HmcTarget(self._hmc_bound(), Z, gradient=self.hmc_gradient)
         scale = 0.25 if not sampler_params else sampler_params.get('step_scale', 0.25)
         seed = None if self._seed is None else self._seed + self._n_hmc_calls
         self._n_hmc_calls += 1

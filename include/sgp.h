@@ -51,7 +51,9 @@ extern "C" {
 
 typedef void* sgp_stream_t; /* hipStream_t */
 
-#define SGP_ABI_VERSION 2       /* 2: contexts (sgp_ctx_*); the process-wide setters are shims over the default context */
+#define SGP_ABI_VERSION 3       /* 2: contexts (sgp_ctx_*); the process-wide setters are shims over the default context
+                                 * 3: every entry point that reads an option has a sgp_ctx_* twin (the three evaluation orders, the
+                                 *    factored pass 2, the whitened bound); sgp_streaming_error_report; phi_diag of the extended order */
 #define SGP_MAX_DIM 32          /* largest input dimension d the streaming kernels accept */
 #define SGP_MAX_INDUCING 4096   /* largest M */
 
@@ -101,8 +103,8 @@ int sgp_abi_version(void);
 
 /* ---- contexts (ABI version 2) -------------------------------------------------------------------------------------------------
  * A context carries every switch and every piece of library-side state a call consults: which matrix cores contract pass 1, the
- * conditioning limit, the K'_fu budget, the CU budget, the optional timing events, the one-shot pass-1 gate, the per-device kernel
- * attributes.  Environment knobs (SGP_CONTRACTION, SGP_ASM_OVERLAP, SGP_SYRK_*, SGP_I8_PRIO) are read ONCE, when a context is
+ * conditioning limit, the K'_fu budget, the CU budget, the optional timing events, the one-shot pass-1 gate (kernel attributes are
+ * kept per device, not per context).  Environment knobs (SGP_CONTRACTION, SGP_ASM_OVERLAP, SGP_SYRK_*, SGP_I8_PRIO) are read ONCE, when a context is
  * created.  Two contexts in one process are independent (two bounds with different contraction modes on two streams, two devices);
  * one context must not be used from two host threads at the same time.  The caller still owns every buffer and passes the stream:
  * a context owns no user-visible memory.  ctx == NULL everywhere means the DEFAULT context, which is also what every entry point
@@ -128,7 +130,9 @@ int sgp_ctx_contraction_would_use_i8(const sgp_ctx* ctx, int64_t N, int M);
 int sgp_ctx_timing_last_ms(sgp_ctx* ctx, int slot, float* ms);
 int64_t sgp_ctx_timing_last_rows(const sgp_ctx* ctx, int slot);
 /* The entry points whose behaviour depends on an option, with the context as first argument (same arguments, same return values
- * as their namesakes below; everything else is context-free): */
+ * as their namesakes below).  Since ABI version 3 the list is complete: the SVGP and single-launch entry points and the M x M helpers
+ * read no option except the CU budget / conditioning limit of the DEFAULT context (sgp_chol_lower, sgp_svgp_*: use the deprecated
+ * setters, or the context twins of the bound, to change those). */
 size_t sgp_ctx_suffstats_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_kfu);
 int sgp_ctx_suffstats_fwd(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
                           const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id, double* Phi, double* b,
@@ -143,6 +147,32 @@ int sgp_ctx_bound_from_stats(sgp_ctx* ctx, const double* Kuu, const double* Phi,
                              const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out, double* Phibar,
                              double* bbar, double* Kuubar, double* factors, const double* kuu_linv, int* info, void* ws,
                              size_t ws_bytes, sgp_stream_t stream);
+/* ABI version 3: the evaluation orders the streaming-order guard falls back to, the factored pass 2 and the whitened bound (they read
+ * the context's K'_fu budget, timing slots, CU budget and conditioning limit).  sgp_ctx_suffstats_fwd_extended has one output more
+ * than its namesake: phi_diag (DEVICE, M doubles, or NULL) = diag(K_uf K_fu) of this shard, for sgp_streaming_error_report.         */
+size_t sgp_ctx_suffstats_whitened_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d);
+int sgp_ctx_suffstats_fwd_whitened(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                   const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
+                                   double* W, double* u, double* yy, double* kappa, void* ws, size_t ws_bytes, sgp_stream_t stream);
+size_t sgp_ctx_suffstats_whitened_rows_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_t);
+int sgp_ctx_suffstats_fwd_whitened_rows(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                        const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                        const double* kuu_linv, double* W, double* u, double* yy, double* kappa, double* T_out,
+                                        void* ws, size_t ws_bytes, sgp_stream_t stream);
+size_t sgp_ctx_suffstats_extended_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d);
+int sgp_ctx_suffstats_fwd_extended(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                   const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id, const double* kuu_linv,
+                                   int level, double* W, double* u, double* yy, double* kappa, double* Kfu_out, double* phi_diag,
+                                   void* ws, size_t ws_bytes, sgp_stream_t stream);
+size_t sgp_ctx_suffstats_bwd_factored_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_t);
+int sgp_ctx_suffstats_bwd_factored(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                   const double* inv_ls, double sf2, const double* kuu_linv, const double* Cw, double s2,
+                                   const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id, const double* T_in,
+                                   double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_ctx_bound_from_whitened_stats(sgp_ctx* ctx, const double* W, const double* u, const double* yy, const double* kappa, double s2,
+                                      int64_t N, int M, int with_adjoints, double* out, double* Phibar, double* bbar, double* Kuubar,
+                                      double* factors, const double* kuu_linv, int* info, double* Cw, void* ws, size_t ws_bytes,
+                                      sgp_stream_t stream);
 int sgp_ctx_mixture_predict(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, int64_t N, const double* Xs, int64_t ldxs,
                             int64_t T, const double* Z, int64_t ldz, int S, const double* inv_ls, const double* sf2, const double* s2,
                             double jitter, int M, int d, int kernel_id, int pred_noise, double gate_jitter, double* mean, double* var,
@@ -286,6 +316,19 @@ int sgp_streaming_error_estimate(const double* stats, const double* trace_inv, d
  * <= 1) -- for a caller that is evaluating in the WHITENED order and wants to know when the streaming order is worth trying again
  * (core.py multiplies it by the ratio estimate / bound it saw at the theta where the guard tripped). */
 int sgp_streaming_error_bound(const double* trace_inv, double sf2, double s2, double* est, sgp_stream_t stream);
+/* ABI version 3: both numbers in one launch, from whatever an evaluation order holds of Phi's diagonal (est: TWO doubles):
+ *   est[0] = 2^-53 max_i diag[i * stride] tr(K_uu^-1) / (s2 N)  -- diag = the all-reduced Phi with stride M + 1 (streaming order), the
+ *            all-reduced phi_diag of sgp_ctx_suffstats_fwd_extended with stride 1 (extended order), or NULL (whitened order: est[0] = est[1]);
+ *   est[1] = 2^-53 sf2^2 tr(K_uu^-1) / s2                       -- the estimate's upper bound (max_i Phi_ii <= N sf2^2).
+ * The estimate is exact in the two orders that form Phi: the tier an evaluation NEEDS is then a function of its own theta, and what a
+ * caller remembers from earlier evaluations (core.py: estimate / bound of the last evaluation that knew both) only decides where the
+ * next one starts, never what is accepted.
+ * A PROPERTY OF THE BOUND callers must know: the three evaluation orders (sgp_suffstats_fwd + sgp_bound_from_stats; sgp_suffstats_fwd_extended;
+ * sgp_suffstats_fwd_whitened[_rows] + sgp_bound_from_whitened_stats) compute the same scalar to ~1e-9 per datum, NOT to the same bits, and a
+ * guarded caller may accept an evaluation in a higher order than its own estimate requires when its previous evaluations suggested so:
+ * F(theta) from such a caller is a function of theta up to that difference, and of the call history within it ("The guard").  */
+int sgp_streaming_error_report(const double* diag, int64_t stride, const double* trace_inv, double sf2, double s2, int64_t N, int M,
+                               double* est, sgp_stream_t stream);
 size_t sgp_kuu_factor_len(int M);
 size_t sgp_kuu_factor_workspace_bytes(int M);
 int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info,
@@ -344,6 +387,12 @@ int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y,
                                int64_t N, int M, int d, int kernel_id, const double* kuu_linv, int level,
                                double* W, double* u, double* yy, double* kappa, double* Kfu_out,
                                void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* ... with phi_diag (ABI version 3; see sgp_ctx_suffstats_fwd_extended) */
+int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const double* y,
+                                  const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                                  int64_t N, int M, int d, int kernel_id, const double* kuu_linv, int level,
+                                  double* W, double* u, double* yy, double* kappa, double* Kfu_out, double* phi_diag,
+                                  void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_bound_from_whitened_stats(const double* W, const double* u, const double* yy, const double* kappa,
                                   double s2, int64_t N, int M, int with_adjoints, double* out,
                                   double* Phibar, double* bbar, double* Kuubar, double* factors,

@@ -28,7 +28,7 @@ class OracleEngine:
         return torch.empty(*shape, dtype=torch.float64)
 
     def result_buffer(self, extra=0):
-        buf = torch.zeros(OUT_LEN + 2 + extra, dtype=torch.float64)
+        buf = torch.zeros(OUT_LEN + 4 + extra, dtype=torch.float64)  # [out | status word | estimate | bound | pad | extras]
         return buf, buf[:OUT_LEN], buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[:1]
 
     @staticmethod
@@ -233,16 +233,23 @@ class GuardedOracleEngine(OracleEngine):
         t[0] = float((Linv[:M, :M] ** 2).sum()) if Linv.dim() == 2 else float((Linv.reshape(-1) ** 2).sum())
         return t
 
-    def streaming_error_estimate(self, packed, trace, s2, N, M, result):
-        phi_max = float(torch.diagonal(packed[: M * M].reshape(M, M)).max())
-        result[0][OUT_LEN + 1] = 2.0 ** -53 * phi_max * float(trace[0]) / (float(s2) * max(1, int(N)))
-
-    def streaming_error_bound(self, trace, sf2, s2, result):
-        result[0][OUT_LEN + 1] = 2.0 ** -53 * float(sf2) ** 2 * float(trace[0]) / float(s2)
+    def streaming_error_report(self, diag, stride, trace, sf2, s2, N, M, result):
+        """sgp_streaming_error_report: estimate from the diagonal an evaluation order holds of Phi (None: the bound), and the bound."""
+        ub = 2.0 ** -53 * float(sf2) ** 2 * float(trace[0]) / float(s2)
+        result[0][OUT_LEN + 2] = ub
+        if diag is None:
+            result[0][OUT_LEN + 1] = ub
+        else:
+            phi_max = float(diag.reshape(-1)[: (M - 1) * int(stride) + 1: int(stride)].max())
+            result[0][OUT_LEN + 1] = 2.0 ** -53 * phi_max * float(trace[0]) / (float(s2) * max(1, int(N)))
 
     @staticmethod
     def read_estimate(host_buf):
         return float(host_buf[OUT_LEN + 1])
+
+    @staticmethod
+    def read_bound(host_buf):
+        return float(host_buf[OUT_LEN + 2])
 
 
 class FactoredOracleEngine(GuardedOracleEngine):
@@ -292,14 +299,16 @@ class FactoredOracleEngine(GuardedOracleEngine):
         self.calls["suffstats_bwd"] = n
         return g
 
-    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None, level=1):
+    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None, level=1, phi_diag=None):
         """sgp_suffstats_fwd_extended: the same whitened statistics (the oracle has one way to compute them), K'_fu kept in `kfu`."""
         self.calls["suffstats_extended"] = self.calls.get("suffstats_extended", 0) + 1
         self.calls["extended_level_%d" % level] = self.calls.get("extended_level_%d" % level, 0) + 1
         n = self.calls["suffstats_whitened"]
         packed = self.suffstats_whitened(X, y, Z, ls, sf2, kuu_linv, kernel, out)
         self.calls["suffstats_whitened"] = n
+        M, d = Z.shape
         if kfu is not None and X.shape[0] > 0:
-            M, d = Z.shape
             kfu[: X.shape[0] * M] = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel]).reshape(-1)
+        if phi_diag is not None:  # diag(K_uf K_fu) of this shard, with its amplitude
+            phi_diag[:M] = (O.kern(X, Z, self._ls(ls, d), float(sf2), KID[kernel]) ** 2).sum(0) if X.shape[0] > 0 else 0.0
         return packed

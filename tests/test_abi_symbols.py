@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.sgp_abi_version() == 2
+    assert lib.sgp_abi_version() == 3
     assert lib.sgp_status_string(0) == b"ok"
     assert b"workspace" in lib.sgp_status_string(-3)
     assert b"positive definite" in lib.sgp_status_string(7)

@@ -1,4 +1,4 @@
-"""The EXTENDED streaming order (sgp_suffstats_fwd_extended: Phi on the integer matrix cores with 34 digit pairs and a double-double fold,
+"""The EXTENDED streaming order (sgp_suffstats_fwd_extended: Phi on the integer matrix cores with 34 (level 1) or 39 (level 2, what the product runs: reach 2^14 x the tolerance) digit pairs and a double-double fold,
 W = L^-1 Phi L^-T by two double-double products) against the whitened order it stands in for, the oracle, and autograd.  Tolerances: W, u
 against the whitened routine 1e-10 of the largest entry on well-conditioned problems (both are accurate there; the explicit inverse's
 rounding is common to both); F against the PyMC3-order oracle 1e-9 per datum where the streaming order itself is off by 1e-7 .. 1e-6;
@@ -64,14 +64,13 @@ def test_extended_statistics_accumulate_over_super_chunks(engine):
     X, y, Z, ls = problem(9000, 256, 4, 5)
     Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
     linv, _ = engine.kuu_factor(engine.kuu(Zd, ls, 1.0, 1e-6, "rbf"))
+    import ggp_amd
     one = engine.suffstats_extended(Xd, yd, Zd, ls, 1.0, linv, "rbf")
-    try:
-        engine.lib.sgp_set_kfu_budget_bytes(2048 * 256 * 8)            # 2048 rows at a time: 5 super-chunks, the last one short
-        engine._ws.pop("fwd_extended", None)
-        many = engine.suffstats_extended(Xd, yd, Zd, ls, 1.0, linv, "rbf")
-    finally:
-        engine.lib.sgp_set_kfu_budget_bytes(0)
-        engine._ws.pop("fwd_extended", None)
+    # the budget is an option of the CONTEXT the call runs in (ABI version 3: sgp_ctx_suffstats_fwd_extended): an engine of its own
+    small = ggp_amd.HipEngine(own_context=True)
+    small.set_option("kfu_budget_bytes", 2048 * 256 * 8)               # 2048 rows at a time: 5 super-chunks, the last one short
+    many = small.suffstats_extended(Xd, yd, Zd, ls, 1.0, linv, "rbf")
+    assert engine.get_option("kfu_budget_bytes") != small.get_option("kfu_budget_bytes")
     Wa, ua, _, _ = unpack(one, 256)
     Wb, ub, _, _ = unpack(many, 256)
     assert relerr(Wb, Wa) < 1e-14 and relerr(ub, ua) < 1e-13          # the double-double sums differ in their last bits only

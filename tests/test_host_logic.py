@@ -350,7 +350,7 @@ def test_streaming_guard_repeats_in_the_whitened_order_on_the_cpu_double():
         hard = ([25.0] * 3, 1.0, 1e-5)                                  # K_uu at its jitter floor, tiny noise
         F1, _ = cb.value(Z, *hard)
         assert cb.n_guard_reruns == 1 and cb.last_estimate > 1e-9 and eng.calls["suffstats_whitened"] == 1
-        assert cb._prefer_whitened and 0.0 < cb._est_ratio <= 1.0
+        assert cb._prefer_whitened and 0.0 < cb.guard.ratio <= 1.0
         cw = pkg.CollapsedBound(X, y, jitter=1e-6, engine=GuardedOracleEngine(), form="whitened")
         assert F1 == cw.value(Z, *hard)[0]                              # the repeat IS the whitened evaluation
         n_stream = eng.calls["suffstats"]
@@ -392,7 +392,7 @@ def _guard_worker(rank, world, port, q):
     for ls, s2 in ((0.8, 0.3), (25.0, 1e-5), (3.0, 1e-3), (25.0, 1e-5)):
         F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
         out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns + cb.n_direct_whitened, cb.last_estimate, cb.n_collectives,
-                    cb._prefer_whitened, cb._est_ratio))
+                    cb._prefer_whitened, cb.guard.ratio))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -576,7 +576,7 @@ def _tier_worker(rank, world, port, q):
     for ls, s2 in ((0.8, 0.3), (3.0, 2e-2), (3.0, 2e-2), (5.0, 1e-3), (5.0, 1e-3), (3.0, 2e-2), (0.8, 0.3), (0.8, 0.3)):
         F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
         out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns, cb.n_direct_whitened, cb.n_extended, cb.n_collectives,
-                    cb._prefer_whitened, cb._pred_est))
+                    cb._prefer_whitened, cb.guard.predicted))
     q.put((rank, out, eng.calls.get("suffstats_extended", 0), eng.calls["suffstats_whitened_rows"]))
     dist.barrier()
     dist.destroy_process_group()

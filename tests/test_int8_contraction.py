@@ -312,6 +312,28 @@ def test_two_contexts_in_one_process_keep_their_own_contraction_mode(engine):
     bad = engine.kuu(z, [3.0], 2.0e6, 1e-6, "rbf")
     ea.set_option("cond_limit", 0.0)
     assert int(ea.kuu_factor(bad)[1].cpu()[0]) == 0 and int(eb.kuu_factor(bad)[1].cpu()[0]) > 0
+    # ABI version 3: the guard's fallback orders run in the engine's context too.  `ea` gets a K'_fu budget of 4096 rows (its extended
+    # order then accumulates 18 super-chunks), `eb` keeps the default and streams the same shard in one piece -- on two streams at once;
+    # the default context's budget is untouched, and both give the same statistics (double-double sums: last bits only).
+    dflt_budget = engine.get_option("kfu_budget_bytes")
+    ea.set_option("kfu_budget_bytes", 4096 * 256 * 8)
+    linv, _ = engine.kuu_factor(engine.kuu(Z, [1.3] * d, 1.0, 1e-6, "rbf"))
+    torch.cuda.synchronize()
+    ready = torch.cuda.current_stream(engine.device).record_event()
+    with torch.cuda.stream(sa):
+        sa.wait_event(ready)
+        xa = ea.suffstats_extended(X, y, Z, [1.3] * d, 1.0, linv, "rbf", level=2)
+        wa = ea.suffstats_whitened_rows(X, y, Z, [1.3] * d, 1.0, linv, "rbf")
+    with torch.cuda.stream(sb):
+        sb.wait_event(ready)
+        xb = eb.suffstats_extended(X, y, Z, [1.3] * d, 1.0, linv, "rbf", level=2)
+        pb2 = eb.suffstats(X, y, Z, [1.3] * d, 1.0, "rbf")
+    torch.cuda.synchronize()
+    assert engine.get_option("kfu_budget_bytes") == dflt_budget and eb.get_option("kfu_budget_bytes") == dflt_budget
+    assert ea.get_option("kfu_budget_bytes") == 4096 * 256 * 8
+    assert float((xa - xb).abs().max()) < 1e-13 * float(xb.abs().max())
+    assert float((wa - xb)[: M * M].abs().max()) < 1e-9 * float(xb[: M * M].abs().max())   # whitened rows (fp64 T^T T) against the exact-Phi route
+    assert torch.equal(pb2, pb)                                                            # `eb` streamed as before, undisturbed
     del ea, eb
 
 

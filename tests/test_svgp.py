@@ -299,7 +299,9 @@ def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d,
     for k in range(S_hyper):
         one = engine.svgp_elbo(D(X), D(y), D(Z), ls[k].tolist(), float(sf2[k]), float(s2[k]), D(m), D(LS), N_total, jitter=1e-6, kernel=kern,
                                likelihood=lik, with_grads=True)
-        assert abs(float(res["out"][k, 0]) - float(one["out"][0])) < 1e-11 * max(1.0, abs(float(one["out"][0])))
+        # (1e-10, not rounding level: since round 5 a single factorization runs the chain-workgroup Cholesky and the batch the tile-dataflow
+        # one -- two orders of the rank-64 updates, each within 1.1e-15 of LAPACK (tools/potrf_bench.py); cond(K_uu) ~ 1 / jitter does the rest)
+        assert abs(float(res["out"][k, 0]) - float(one["out"][0])) < 1e-10 * max(1.0, abs(float(one["out"][0])))
         for key in ("g_m", "g_LS", "g_Z", "g_ls"):
             assert close(res[key][k], one[key].cpu(), 1e-8), (k, key)
         assert close(res["g_sf2"][k], one["g_sf2"].cpu(), 1e-8)
