@@ -343,8 +343,11 @@ class CollapsedBound:
 
     def _review(self, res, host, info, tier, reach, M, strict):
         """What the evaluation's own numbers say: None = accept, or the tier to repeat it in.  Updates the guard's memory.
-        A failed factorization (info != 0) says nothing about the estimate: the state is left alone and nothing is repeated."""
-        if info != 0 or not res.get("reported"):
+        A failed factorization of K_uu (info in 1 .. M), a time-out or a refusal says nothing about the estimate: the state is left alone
+        and nothing is repeated.  A failed factorization of B (info > M) below the whitened order is the streaming order's own failure
+        mode -- W = L^-1 Phi L^-T so far off that I + W / s2 is not positive definite (l = 20, sig_n = 0.01: profiles/r04_theta_sweep_streaming.jsonl)
+        -- and the estimate, which needs K_uu's factor and Phi only, is valid: it is reviewed like any other."""
+        if not res.get("reported") or (info != 0 and not (info > M and tier < TIER_WHITENED)):
             return None
         e = self.engine
         est, ub = e.read_estimate(host), e.read_bound(host)
@@ -360,6 +363,8 @@ class CollapsedBound:
         if need > tier:
             self.guard.open = True
             return need
+        if info != 0:  # B failed although the estimate is inside this tier's reach: the next tier up, if there is one
+            return tier + 1 if (tier + 1 < TIER_WHITENED and ext_ok) else TIER_WHITENED
         if strict and need < tier:
             return need
         return None

@@ -108,8 +108,12 @@ class OracleEngine:
         info.zero_()
         try:
             r = O.bound_from_stats(Kuu, st, float(s2), with_adjoints=with_adjoints, stats_whitened=whitened)
-        except Exception:  # torch.linalg.cholesky failure -> LAPACK-style info like the HIP path
-            info[0] = 1
+        except Exception:  # torch.linalg.cholesky failure -> LAPACK-style info like the HIP path: 1 .. M = K_uu, M + 1 .. 2 M = B
+            try:
+                torch.linalg.cholesky(Kuu)
+                info[0] = M + 1
+            except Exception:
+                info[0] = 1
             if with_adjoints:
                 res.update(Phibar=torch.zeros(M, M, dtype=torch.float64), bbar=torch.zeros(M, dtype=torch.float64),
                            Kuubar=torch.zeros(M, M, dtype=torch.float64))

@@ -141,6 +141,36 @@ def test_failed_factorization_leaves_the_guard_alone(no_small_whitened):
     assert (cb0.guard.open, cb0.guard.predicted, cb0.guard.ratio, cb0.n_guard_reruns) == (state[0], state[1], state[2], 0)
 
 
+def test_streaming_order_failing_at_B_is_a_guard_trip_not_an_error(no_small_whitened):
+    """l = 20, sig_n = 0.01 on the GPU: W = L^-1 Phi L^-T is so far off that I + W / s2 is not positive definite (info > M).  That IS the
+    streaming order's failure mode: the estimate (K_uu's factor and Phi only) is valid and sends the evaluation up."""
+    from fake_engine import FactoredOracleEngine
+
+    class BrokenB(FactoredOracleEngine):
+        def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, result=None, kuu_linv=None, whitened=False, want_cw=False):
+            res = super().bound(Kuu, packed, s2, N, with_adjoints, want_factors, result, kuu_linv, whitened, want_cw)
+            if not whitened and float(s2) < 1e-3:      # the streaming order "fails" at small noise: B not positive definite
+                res["info"][0] = Kuu.shape[0] + 5
+                res["out"].fill_(float("nan"))
+            return res
+
+    X, y, Z = _problem()
+    eng = BrokenB()
+    cb = _bound(X, y, eng)
+    ref = _bound(X, y, form="whitened")
+    far = ([25.0] * 3, 1.0, 1e-5)
+    F, parts = cb.value(Z, *far)                           # no NotPositiveDefiniteError: repeated in the whitened order
+    assert parts["info"] == 0 and F == ref.value(Z, *far)[0] and cb.n_guard_reruns == 1 and cb.last_tier == 2
+    # ... while a K_uu failure (info <= M) is an error of the matrix, whatever the tier
+    Zbad = Z.clone()
+    Zbad[1] = Zbad[0]
+    c0 = _bound(X, y)
+    c0.jitter = 0.0
+    with pytest.raises(Exception):
+        c0.value(Zbad, [0.8] * 3, 1.0, 0.3)
+    assert c0.n_guard_reruns == 0
+
+
 def _walk(cb, Z, order, with_grad, **kw):
     out = []
     for k in order:

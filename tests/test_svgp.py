@@ -321,7 +321,8 @@ def test_svgp_elbo_batch_vs_oracle_and_single_chains(engine, lik, kern, B, M, d,
     assert info_b.cpu().tolist() == [0] * S_hyper and mu_b.shape == (S_hyper, Tn)
     for k in range(S_hyper):
         mu1, v1, _ = engine.svgp_predict(D(X[:Tn]), D(Z), ls[k].tolist(), float(sf2[k]), D(m), D(LS), jitter=1e-6, kernel=kern)
-        assert float((mu_b[k] - mu1).abs().max()) < 1e-10 and float(((v_b[k] - v1) / v1).abs().max()) < 1e-10
+        # (1e-9: batch and single factorizations run different Cholesky kernels since round 5, see above)
+        assert float((mu_b[k] - mu1).abs().max()) < 1e-9 and float(((v_b[k] - v1) / v1).abs().max()) < 1e-9
     # the test rows travel in chunks (8192 by default; 32 here: three chunks, the last one short): the same numbers
     try:
         engine.SVGP_PREDICT_CHUNK = 32
