@@ -43,7 +43,9 @@ __global__ void bwd_pad_vec_kernel(const double* __restrict__ in, int64_t n, int
     out[i] = i < n ? in[i] : 0.0;
 }
 // Pb (Mp x Mp) <- symmetrised, zero-padded Phibar (M x M)
-__global__ void bwd_pad_sym_kernel(const double* __restrict__ P, int M, int Mp, double* __restrict__ out) {
+// (vec / vout: optionally the padded copy of a vector in the same launch -- block 0)
+__global__ void bwd_pad_sym_kernel(const double* __restrict__ P, int M, int Mp, double* __restrict__ out,
+                                   const double* __restrict__ vec = nullptr, double* __restrict__ vout = nullptr) {
   const int64_t total = (int64_t)Mp * Mp;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
@@ -51,6 +53,8 @@ __global__ void bwd_pad_sym_kernel(const double* __restrict__ P, int M, int Mp, 
     if (r < M && c < M) v = 0.5 * (P[(int64_t)r * M + c] + P[(int64_t)c * M + r]);
     out[e] = v;
   }
+  if (vout && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < Mp; i += blockDim.x) vout[i] = i < M ? vec[i] : 0.0;
 }
 
 // Pb (Mp x Mp) <- scale * P (Mp x Mp in, rows / columns >= M zeroed): no symmetrisation (the factored mode's triangular L^-1)
@@ -518,8 +522,7 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
   ka.d = d;
 
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
-  bwd_pad_sym_kernel<<<2048, 256, 0, st>>>(Phibar, M, p.Mp, w.Pb);
-  bwd_pad_vec_kernel<<<(p.Mp + 255) / 256, 256, 0, st>>>(bbar, M, p.Mp, w.bb);
+  bwd_pad_sym_kernel<<<2048, 256, 0, st>>>(Phibar, M, p.Mp, w.Pb, bbar, w.bb);
 
   const int want_gz = g_Z != nullptr;
   const int grid = p.nmb * p.nsplit_b;

@@ -201,6 +201,32 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, 
   s = block_sum256(s, red);
   if (threadIdx.x == 0) *out = s;
 }
+// The three scalars of s2bar that need a pass over an M x M matrix, row by row in ONE launch (round 5: five launches before --
+// frob_partial, sum256, dot, gemv, dot): one wave per row i writes
+//   rows3[i]          = sum_j Binv[i][j] W[i][j]      -> tr(B^-1 W)     rows3[Mp + i] = (W alpha)_i alpha_i -> alpha^T W alpha
+//   rows3[2 Mp + i]   = u_i alpha_i                   -> u . alpha
+// finalize_bound_kernel adds each array up in a fixed order.
+__global__ __launch_bounds__(256) void adjoint_rows_kernel(const double* __restrict__ Binv, const double* __restrict__ W,
+                                                           const double* __restrict__ alpha, const double* __restrict__ u, int Mp,
+                                                           double* __restrict__ rows3) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= Mp) return;
+  double f = 0.0, wa = 0.0;
+  for (int j = lane; j < Mp; j += 64) {
+    const double w = W[(int64_t)row * Mp + j];
+    f = fma(Binv[(int64_t)row * Mp + j], w, f);
+    wa = fma(w, alpha[j], wa);
+  }
+  f = wave_sum(f);
+  wa = wave_sum(wa);
+  if (lane == 0) {
+    const double a = alpha[row];
+    rows3[row] = f;
+    rows3[Mp + row] = wa * a;
+    rows3[2 * Mp + row] = u[row] * a;
+  }
+}
 // partial[block] = sum over a slice of A o B ; fixed grid of 256 blocks, second stage = sum256_kernel
 __global__ __launch_bounds__(256) void frob_partial_kernel(const double* __restrict__ A, const double* __restrict__ B, int64_t n,
                                                            double* __restrict__ partial) {
@@ -220,9 +246,22 @@ __global__ __launch_bounds__(256) void sum256_kernel(const double* __restrict__ 
 __global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __restrict__ sc, const double* __restrict__ yy,
                                                              const double* __restrict__ kappa, double s2, double Nd, int with_adj,
                                                              const double* __restrict__ LB, const double* __restrict__ q, int Mp,
-                                                             const int* abort_flag, int* info, double* __restrict__ out) {
+                                                             const int* abort_flag, int* info, double* __restrict__ out,
+                                                             const double* __restrict__ rows3) {
   __shared__ double red[4];
   double logdetB = 0.0, qq = 0.0;
+  double trSP = 0.0, aPa = 0.0, ba = 0.0;
+  if (with_adj) {  // the row sums of adjoint_rows_kernel, each added up in one fixed order
+    double s0 = 0.0, s1 = 0.0, s2_ = 0.0;
+    for (int i = threadIdx.x; i < Mp; i += 256) {
+      s0 += rows3[i];
+      s1 += rows3[Mp + i];
+      s2_ += rows3[2 * Mp + i];
+    }
+    trSP = block_sum256(s0, red);
+    aPa = block_sum256(s1, red);
+    ba = block_sum256(s2_, red);
+  }
   if (LB) {
     potrf_scalars(LB, q, Mp, abort_flag, info, red, logdetB, qq);
   } else {
@@ -242,7 +281,6 @@ __global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __res
   out[SGP_OUT_QUAD] = quad;
   out[SGP_OUT_TRW] = trW;
   if (with_adj) {
-    const double trSP = sc[SC_TRSP], ba = sc[SC_BA], aPa = sc[SC_APA];
     const double s22 = s2 * s2;
     out[SGP_OUT_S2BAR] = -0.5 * (-trSP / s22 + Nd / s2 - *yy / s22 + 2.0 * ba / (s22 * s2) - aPa / (s22 * s22)
                                  - *kappa / s22 + trW / s22);
@@ -450,7 +488,7 @@ static int grid_for(int64_t total, int cap = 2048) {
 
 struct BoundWs {
   double *M0, *M1, *M2, *M3, *M4, *M5, *M6, *M7;  // M0 / M4 are the first halves of the two-matrix buffers CS / TT
-  double *bp, *u, *q, *alpha, *t1, *sc, *partial;
+  double *bp, *u, *q, *alpha, *t1, *sc, *partial, *rows3;
   int *flags, *flagsB;  // potrf tile-ready flags: chol(Kuu) (cleared by potrf_lower), chol(B) (cleared by tail_prep_kernel)
   size_t bytes;
 };
@@ -474,6 +512,7 @@ static BoundWs carve_bound(void* ws, int Mp, int with_adj) {
   w.t1 = c.take<double>(Mp);
   w.sc = c.take<double>(SC_N);
   w.partial = c.take<double>(256);
+  w.rows3 = c.take<double>((size_t)3 * Mp);
   w.flags = c.take<int>(potrf_scratch_ints(Mp));
   w.flagsB = c.take<int>(potrf_scratch_ints(Mp));
   w.bytes = c.used();
@@ -905,16 +944,12 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     t2.m = Mp; t2.n = Mp; t2.k = Mp; t2.batch = 2; t2.klo_mask = 1;
     gemm(t2, st);
     // scalars for s2bar (slots keep their names): tr(B^-1 W) = tr(Sigma^-1 Phi), u.g = b.alpha, g^T W g = alpha^T Phi alpha
-    frob_partial_kernel<<<256, 256, 0, st>>>(w.M2, w.M5, (int64_t)mm, w.partial);
-    sum256_kernel<<<1, 256, 0, st>>>(w.partial, w.sc + SC_TRSP);
-    dot_kernel<<<1, 256, 0, st>>>(w.u, w.alpha, Mp, w.sc + SC_BA);
-    gemv(w.M5, ld, Mp, false, w.alpha, w.t1, st);
-    dot_kernel<<<1, 256, 0, st>>>(w.t1, w.alpha, Mp, w.sc + SC_APA);
-    gemv(w.M1, ld, Mp, true, w.alpha, w.t1, st);  // L^-T g (stream order: after the dot product that read t1)
+    adjoint_rows_kernel<<<Mp / 4, 256, 0, st>>>(w.M2, w.M5, w.alpha, w.u, Mp, w.rows3);
+    gemv(w.M1, ld, Mp, true, w.alpha, w.t1, st);  // L^-T g
     adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(CS, w.t1, Mp, M, s2, Phibar, Kuubar, bbar);
   }
   finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, need_G ? nullptr : w.M6, w.q, Mp,
-                                           abort_flag, info, out);
+                                           abort_flag, info, out, w.rows3);
   return check_launch();
 }
 
