@@ -60,8 +60,7 @@ struct ChShared {
     double Ts[DB][TLD];                                           // step boundary: the accumulators of D(j+1) on their way to the D-waves
   };
   double Lt[4][16][DB];    // finished columns of D(j), transposed (followers of the pivot chain)
-  double Xp[2][4][4][4][64];  // X = L(j+1,j) of this step ([j & 1]) and of the previous one: [panel k][row block g][k-step sq][lane] =
-                              // X[16 g + (lane & 15)][16 k + 4 sq + (lane >> 4)] -- both operand layouts of the products it enters
+  double Xp[4][4][4][64];  // X = L(j+1,j): [panel k][row block g][k-step sq][lane] = X[16 g + (lane & 15)][16 k + 4 sq + (lane >> 4)]
   double rdiag[4][16];     // reciprocal pivots (the block inverses are formed behind the chain)
   int prog[4];             // columns of panel pb finished
   int dinv_done[4];
@@ -370,28 +369,13 @@ __device__ __forceinline__ void chain_s_role(double* A, int64_t ld, int nb, ChSc
 #pragma unroll
         for (int e = 0; e < 8; ++e) *reinterpret_cast<d2*>(U + 2 * e) = d2{0.0, 0.0};
       }
-      if (j >= 2) {  // the terms p < j - 1 of US(j) = sum_{p<j} L(j+1,p) L(j,p)^T (EARLY_S item of column j - 1: ready long ago)
+      if (j >= 1) {  // US(j) = sum_{p<j} L(j+1,p) L(j,p)^T from the prep item of this column
         ch_wait_global(sc.preS + (size_t)j * DF_FLAG_STRIDE, 1, sc.abort_flag, &sh.dead);
         const double* up = sc.upre + (size_t)j * 4096 + (size_t)g * 1024 + lane;
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
           for (int sq = 0; sq < 4; ++sq) yb[pb][sq] -= up[(pb * 4 + sq) * 64];
-      }
-      if (j >= 1) {
-        // ... and its last term HERE: L(j+1,j-1) X(j-1)^T with X(j-1) = L(j,j-1) still in LDS from the previous step.  L(j+1,j-1) is the
-        // tile two below the previous diagonal tile; it arrives ~3 us into this step (its last panel step waits for the previous chain's
-        // end).  One hop (that tile) instead of three (tile -> a prep item's product -> its result), profiles/r05_potrf_chain_variants.txt.
-        ch_wait_global(sc.ready + (size_t)tile_no(j + 1, j - 1) * DF_FLAG_STRIDE, 1, sc.abort_flag, &sh.dead);
-        const double* lsrc = A + (int64_t)(j + 1) * DB * ld + (int64_t)(j - 1) * DB + (int64_t)(16 * g + l15) * ld + l4;
-        double lo[16];  // this wave's 16 rows: lo[s] = L(j+1,j-1)[16 g + l15][4 s + l4], the B operand of k-step s
-#pragma unroll
-        for (int s4 = 0; s4 < 16; ++s4) lo[s4] = -lsrc[4 * s4];
-        const double (*xprev)[4][4][64] = sh.Xp[(j & 1) ^ 1];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-          for (int pb = 0; pb < 4; ++pb) yb[pb] = mfma16(xprev[kk >> 2][pb][kk & 3][lane], lo[kk], yb[pb]);
       }
       if (g == 0) CH_STAMP(j, 5);
       d4 dp[3];
@@ -415,7 +399,7 @@ __device__ __forceinline__ void chain_s_role(double* A, int64_t ld, int nb, ChSc
       auto update_ready = [&]() __attribute__((always_inline)) { return lds_flag_load(&sh.xa_done[pending]) >= 4; };
       auto update = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");
-        const double (*xp)[4][64] = sh.Xp[j & 1][pending];
+        const double (*xp)[4][64] = sh.Xp[pending];
 #pragma unroll
         for (int b = 0; b < 3; ++b)
           if (b < nblk) {
@@ -446,7 +430,7 @@ __device__ __forceinline__ void chain_s_role(double* A, int64_t ld, int nb, ChSc
           double* dst = Asj + (int64_t)(16 * g + l15) * ld + 16 * k + l4;
 #pragma unroll
           for (int sq = 0; sq < 4; ++sq) {
-            sh.Xp[j & 1][k][g][sq][lane] = xa[sq];
+            sh.Xp[k][g][sq][lane] = xa[sq];
             dst[4 * sq] = xa[sq];
           }
         }
@@ -520,18 +504,18 @@ __device__ __forceinline__ int df_wait_panels(const int* pready, int pb, int* ab
 }
 
 // The other workgroups (four waves each).  Work items:
-//   EARLY_S(c)               the terms of US(c+1) from the columns p < c -> `upre` (the S-waves add the last one, L(c+2,c) X(c)^T, themselves)
-//   EARLY_D(c)               the terms of UD(c+2) from the columns p < c (ready long before FUSED_D asks)
-//   FUSED_D(c)               tile (c+2, c) (published at once: the S-waves wait for it), then UD(c+2) = early terms + X X^T
+//   EARLY_S(c), EARLY_D(c)   the terms of US(c+1) / UD(c+2) from the columns p < c (needed late, ready early)
+//   FUSED_S(c)               tile (c+2, c) into scratch, then US(c+1) = early terms + L(c+1,c) X^T   -> the chain workgroup's S-waves
+//   FUSED_D(c)               tile (c+2, c) in place (published at once), then UD(c+2) = early terms + X X^T
 //   TILE(i, c), i >= c + 3   rank-64 updates, then the solve panel by panel as the chain workgroup publishes L(c,c)
 //   DINV(e)                  64 x 64 block inverse of L(e,e) -> Linv (level 0 of tri_inverse())
 //   RHS                      sol = L^-1 rhs
 // Two lists, each in dependency order (every dependency of an item is an earlier item of one of the lists or a step of the chain
-// workgroup): the CRITICAL one [FUSED_D(0), FUSED_D(1), ...] is dealt round-robin to the workgroups expected on the chain
+// workgroup): the CRITICAL one [FUSED_S(0), FUSED_D(0), FUSED_S(1), ...] is dealt round-robin to the workgroups expected on the chain
 // workgroup's XCD (blockIdx = 0 mod 8), the other one to the rest; with fewer than eight workgroups there is one list for all.
-enum ChKind { CH_EARLY_S, CH_EARLY_D, CH_FUSED_D, CH_TILE, CH_DINV, CH_RHS, CH_NONE };
+enum ChKind { CH_EARLY_S, CH_EARLY_D, CH_FUSED_S, CH_FUSED_D, CH_TILE, CH_DINV, CH_RHS, CH_NONE };
 struct ChItem { int kind, c, i; };
-__host__ __device__ inline int ch_crit_items(int nb) { return nb >= 3 ? nb - 2 : 0; }
+__host__ __device__ inline int ch_crit_items(int nb) { return nb >= 3 ? 2 * (nb - 2) : 0; }
 __host__ __device__ inline int ch_rest_tile_items(int nb) { return nb >= 3 ? (nb - 2) * (nb + 1) / 2 : 0; }  // per column c: 2 + (nb - 3 - c)
 __host__ __device__ inline int ch_tile_items(int nb) { return ch_crit_items(nb) + ch_rest_tile_items(nb); }
 // item k of the non-critical list (columns c <= nb - 3: [EARLY_S, EARLY_D, TILE(c+3..)], then DINV(0..nb-1) if want_inv, then RHS if want_rhs)
@@ -553,17 +537,18 @@ __device__ __forceinline__ ChItem ch_rest_item(int k, int nb, bool want_inv, boo
   if (want_rhs && k == 0) return ChItem{CH_RHS, 0, 0};
   return ChItem{CH_NONE, 0, 0};
 }
-// item k of the single list (few workgroups): per column [EARLY_S, EARLY_D, FUSED_D, TILE(c+3..)], then DINV, RHS
+// item k of the single list (few workgroups): per column [EARLY_S, EARLY_D, FUSED_S, FUSED_D, TILE(c+3..)], then DINV, RHS
 __device__ __forceinline__ ChItem ch_all_item(int k, int nb, bool want_inv, bool want_rhs) {
   int c = 0, start = 0;
   const int nt = ch_tile_items(nb);
   if (k < nt) {
-    while (k >= start + (nb - c)) { start += nb - c; ++c; }
+    while (k >= start + (nb + 1 - c)) { start += nb + 1 - c; ++c; }
     const int slot = k - start;
     if (slot == 0) return ChItem{CH_EARLY_S, c, c + 2};
     if (slot == 1) return ChItem{CH_EARLY_D, c, c + 2};
-    if (slot == 2) return ChItem{CH_FUSED_D, c, c + 2};
-    return ChItem{CH_TILE, c, c + slot};
+    if (slot == 2) return ChItem{CH_FUSED_S, c, c + 2};
+    if (slot == 3) return ChItem{CH_FUSED_D, c, c + 2};
+    return ChItem{CH_TILE, c, c - 1 + slot};
   }
   return ch_rest_item(k - nt + ch_rest_tile_items(nb), nb, want_inv, want_rhs);
 }
@@ -643,7 +628,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
 
   for (int k = first; k < count; k += stride) {
     const ChItem it = !split ? ch_all_item(k, nb, want_inv, want_rhs)
-                             : (crit_wg ? ChItem{CH_FUSED_D, k, k + 2} : ch_rest_item(k, nb, want_inv, want_rhs));
+                             : (crit_wg ? ChItem{(k & 1) ? CH_FUSED_D : CH_FUSED_S, k >> 1, (k >> 1) + 2} : ch_rest_item(k, nb, want_inv, want_rhs));
     const int kind = it.kind, j = it.c, i = it.i;
     if (kind == CH_NONE) break;
     if (kind == CH_RHS) {
@@ -688,35 +673,23 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
           df_mac(Lip, Lip, ld, ld, sh, acce);
         }
       }
-      if (kind == CH_EARLY_S) {
-        // accumulator (rows: columns of S, columns: rows of S) == the S-waves' register order: straight to `upre`, for the chain workgroup
-        double* up = sc.upre + (size_t)jn * 4096;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) up[(((wj * 2 + v) * 4 + (wi * 2 + u)) * 4 + q) * 64 + lane] = acce[u][v][q];
-        raise(sc.preS + (size_t)jn * DF_FLAG_STRIDE);
-        continue;
-      }
-      double* dste = sc.dpe + (size_t)i * 4096 + (size_t)wave * 1024 + lane;
+      double* dste = (kind == CH_EARLY_S ? sc.upe + (size_t)jn * 4096 : sc.dpe + (size_t)i * 4096) + (size_t)wave * 1024 + lane;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dste[((u * 2 + v) * 4 + q) * 64] = acce[u][v][q];  // the accumulator as it is: the reader is the FUSED_D item's same thread
-      raise(sc.preDE + (size_t)i * DF_FLAG_STRIDE);
+          for (int q = 0; q < 4; ++q) dste[((u * 2 + v) * 4 + q) * 64] = acce[u][v][q];  // the accumulator as it is: the reader is the FUSED item's same thread
+      raise(kind == CH_EARLY_S ? sc.preSE + (size_t)jn * DF_FLAG_STRIDE : sc.preDE + (size_t)i * DF_FLAG_STRIDE);
       continue;
     }
 
-    // ---- a tile (i, j): rank-64 updates, solve panel by panel; the FUSED_D item carries on with the last term of UD(i) ----
-    const bool fused_d = kind == CH_FUSED_D;
-    if (fused_d && !ask_local()) return;
-    const bool lite = fused_d && local;  // read the chain workgroup's light flags, publish to it without a write-back
+    // ---- a tile (i, j): rank-64 updates, solve panel by panel; FUSED items carry on with the last term of their prep sum ----
+    const bool fused_s = kind == CH_FUSED_S, fused_d = kind == CH_FUSED_D;
+    if ((fused_s || fused_d) && !ask_local()) return;
+    const bool lite = (fused_s || fused_d) && local;  // read the chain workgroup's light flags, publish to it without a write-back
     double* Aij = A + (int64_t)i * DB * ld + (int64_t)j * DB;
-    {  // the mirrored tile is the strictly-upper part of the result: zero
+    if (!fused_s) {  // the mirrored tile is the strictly-upper part of the result: zero
       double* U = A + (int64_t)j * DB * ld + (int64_t)i * DB;
       for (int e = tid; e < DB * DB / 2; e += 256) {
         const int rr = e >> 5, cc = (e & 31) * 2;
@@ -725,7 +698,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     }
     d4 acc[2][2];
     zero_acc(acc);
-    if (fused_d && tid == 0) CH_STAMP(j, 10);
+    if (fused_s && tid == 0) CH_STAMP(j, 10);
     d4 yb[4], xb[4];
     {  // this wave's 16 rows of A(i,j) in the accumulator layout: asked for now, wanted after the updates
       const double* src = Aij + (int64_t)(16 * g + l15) * ld + l4;
@@ -741,7 +714,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     }
     acc_to_ts(acc);
     __syncthreads();
-    if (fused_d && tid == 0) CH_STAMP(j, 11);
+    if (fused_s && tid == 0) CH_STAMP(j, 11);
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
@@ -770,7 +743,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
         have = upto;
         __syncthreads();
       }
-      if (pb == 3 && fused_d && tid == 0) CH_STAMP(j, 12);
+      if (pb == 3 && fused_s && tid == 0) CH_STAMP(j, 12);
       d4 xa = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int sq = 0; sq < 4; ++sq) xa = mfma16(sh.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
@@ -780,7 +753,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
 #pragma unroll
         for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-sh.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
     }
-    {
+    if (!fused_s) {
       double* dst = Aij + (int64_t)(16 * g + l15) * ld + l4;
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb)
@@ -791,21 +764,21 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
       raise(ready + (size_t)tile_no(i, j) * DF_FLAG_STRIDE);
       continue;
     }
-    // ---- FUSED_D: the tile goes public at once (the chain workgroup's S-waves and the next column's items wait for it), then the last
-    // term of UD(i) with the X just solved, which stays on chip for it (sh.Ts, row-major) ----
+    // ---- FUSED items: the last term of the prep sum with the X just solved, which stays on chip (sh.Ts, row-major) ----
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
       for (int sq = 0; sq < 4; ++sq) sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4] = xb[pb][sq];
-    raise(ready + (size_t)tile_no(i, j) * DF_FLAG_STRIDE);
-    if (tid == 0) CH_STAMP(j, 13);
-    // the terms from the columns p < j (EARLY_D item of this column, stored thread for thread): asked for now, added behind the product
+    if (fused_d) raise(ready + (size_t)tile_no(i, j) * DF_FLAG_STRIDE);  // the tile itself goes public first: the next column's items wait for it
+    else __syncthreads();
+    if (fused_s && tid == 0) CH_STAMP(j, 13);
+    // the terms from the columns p < j (EARLY items of this column, stored thread for thread): asked for now, added behind the product
     d4 acc2[2][2], early[2][2];
     zero_acc(acc2);
     zero_acc(early);
     if (j > 0) {
-      if (!df_wait(sc.preDE + (size_t)i * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
-      const double* srce = sc.dpe + (size_t)i * 4096 + (size_t)wave * 1024 + lane;
+      if (!df_wait((fused_s ? sc.preSE + (size_t)jn * DF_FLAG_STRIDE : sc.preDE + (size_t)i * DF_FLAG_STRIDE), abort_flag, &sh.dead)) return;
+      const double* srce = (fused_s ? sc.upe + (size_t)jn * 4096 : sc.dpe + (size_t)i * 4096) + (size_t)wave * 1024 + lane;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -813,23 +786,40 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
 #pragma unroll
           for (int q = 0; q < 4; ++q) early[u][v][q] = srce[((u * 2 + v) * 4 + q) * 64];
     }
-    df_mac<true, true>(nullptr, nullptr, 0, 0, sh, acc2);
-    if (tid == 0) CH_STAMP(j, 15);
-    // lower blocks of UD(i) in the order of the S-waves' accumulators
-    double* dpp = sc.dpre + (size_t)i * 4096;
+    if (fused_s) {
+      // US(jn)^T += L(jn,j) X^T: L(jn,j) is the chain workgroup's X of step j (its light flag when we share the L2)
+      if (!df_wait(lite ? sc.xready_l + (size_t)j * DF_FLAG_STRIDE : ready + (size_t)tile_no(jn, j) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      if (tid == 0) CH_STAMP(j, 14);
+      df_mac<false, true>(A + (int64_t)jn * DB * ld + (int64_t)j * DB, nullptr, ld, 0, sh, acc2);
+      if (tid == 0) CH_STAMP(j, 15);
+      // accumulator (rows: columns of S, columns: rows of S) == the S-waves' register order: straight to `upre`
+      double* up = sc.upre + (size_t)jn * 4096;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const int R = wi * 2 + u, Cc = wj * 2 + v;
-        if (R >= Cc) {
-          const int slotb = ch_owner_slot(R, Cc);  // (owner wave) * 3 + (its block index)
+        for (int v = 0; v < 2; ++v)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dpp[slotb * 256 + q * 64 + lane] = acc2[u][v][q] + early[u][v][q];
+          for (int q = 0; q < 4; ++q) up[(((wj * 2 + v) * 4 + (wi * 2 + u)) * 4 + q) * 64 + lane] = acc2[u][v][q] + early[u][v][q];
+      if (lite) raise_light(sc.preS + (size_t)jn * DF_FLAG_STRIDE);
+      else raise(sc.preS + (size_t)jn * DF_FLAG_STRIDE);
+    } else {
+      df_mac<true, true>(nullptr, nullptr, 0, 0, sh, acc2);
+      // lower blocks of UD(i) in the order of the S-waves' accumulators
+      double* dpp = sc.dpre + (size_t)i * 4096;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int R = wi * 2 + u, Cc = wj * 2 + v;
+          if (R >= Cc) {
+            const int slotb = ch_owner_slot(R, Cc);  // (owner wave) * 3 + (its block index)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dpp[slotb * 256 + q * 64 + lane] = acc2[u][v][q] + early[u][v][q];
+          }
         }
-      }
-    if (lite) raise_light(sc.preD + (size_t)i * DF_FLAG_STRIDE);
-    else raise(sc.preD + (size_t)i * DF_FLAG_STRIDE);
+      if (lite) raise_light(sc.preD + (size_t)i * DF_FLAG_STRIDE);
+      else raise(sc.preD + (size_t)i * DF_FLAG_STRIDE);
+    }
   }
 }
 

@@ -1,6 +1,6 @@
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/r05_chain16
+O=gpurun_out/r05_chain19
 mkdir -p $O
 timeout 600 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "chol or pivot or fuzz or potrf or logdiag" > $O/pytest_chol.txt 2>&1
 tail -3 $O/pytest_chol.txt

@@ -3,8 +3,8 @@
 with -DSGP_POTRF_STAMPS:
     SGP_EXTRA_HIPCC_FLAGS=-DSGP_POTRF_STAMPS python3 -c "import sys; sys.path.insert(0, 'generalised-gaussian-processes_amd'); import build; build.build_library(force=True)"
     python3 tools/potrf_chain_phases.py [M]
-Stamps (s_memrealtime, 100 MHz) per step: 0 chain start | 1-4 end of the pivot chain of panel 0-3 | 5 S-wave 0 has S = A - US (tile (j+1,j-1) seen, its product
-with X(j-1) applied) | 9 S-wave 0 has UD(j+1) | 6 last panel step of the solve done | 7 last rank-16 update done | 8 step barrier."""
+Stamps (s_memrealtime, 100 MHz) per step: 0 chain start | 1-4 end of the pivot chain of panel 0-3 | 5 S-wave 0 has S = A - US (the prep
+item's flag seen, loaded) | 9 S-wave 0 has UD(j+1) | 6 last panel step of the solve done | 7 last rank-16 update done | 8 step barrier."""
 import ctypes as C
 import os
 import sys
@@ -35,8 +35,8 @@ for j in range(nb):
         s += " | S ready +%.1f  solve done +%.1f  update done +%.1f" % (v[5] - v[0], v[6] - v[0], v[7] - v[0])
     s += " | panel 3 written back +%.1f | barrier +%.1f" % (v[9] - v[0], v[8] - v[0])
     print(s)
-    if 1 <= j < nb - 1:  # the FUSED_D item of column j - 1 (tile (j+1, j-1), then UD(j+1)), relative to this step's start
-        w = [(buf[(j - 1) * 16 + k] - t0) / 100.0 - v[0] for k in (10, 11, 12, 13, 15)]
-        print("         tile (%d,%d) item: start %+.1f  updates done %+.1f  panel 3 seen %+.1f  tile published %+.1f  X X^T done %+.1f" % ((j + 1, j - 1) + tuple(w)))
+    if 1 <= j < nb - 1:  # the fused item of column j - 1 (tile (j+1, j-1), then US(j)), relative to this step's start
+        w = [(buf[(j - 1) * 16 + k] - t0) / 100.0 - v[0] for k in range(10, 16)]
+        print("         US(%d) item: start %+.1f  updates done %+.1f  panel 3 seen %+.1f  X solved %+.1f  X(j-1) flag seen %+.1f  product done %+.1f" % ((j,) + tuple(w)))
 end = (buf[(nb - 1) * 16 + 8] - t0) / 100.0
 print("total %.1f us for %d block columns = %.2f us per column" % (end, nb, end / nb))
