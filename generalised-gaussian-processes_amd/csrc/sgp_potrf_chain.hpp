@@ -190,7 +190,10 @@ __device__ __forceinline__ void ch_dwave(double (&a)[16], ChShared& sh, int g, i
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
     if (g == pb) {
-      __builtin_amdgcn_s_setprio(3);
+#ifndef SGP_CH_PRIO
+#define SGP_CH_PRIO 3
+#endif
+      __builtin_amdgcn_s_setprio(SGP_CH_PRIO);
       const int base = 16 * pb;
       double p = a[0], lprev = 0.0;
 #pragma unroll
