@@ -44,6 +44,15 @@ CtxScope::~CtxScope() { t_cur = prev; }
 
 using namespace sgp;
 
+// A context belongs to the device it was created for (its side stream, events and timing slots live there): an entry point called
+// with another device current is refused instead of launching on the wrong one (the field was stored and never looked at).
+static bool ctx_on_current_device(const sgp_ctx* ctx) {
+  if (!ctx) return true;  // the default context follows the caller
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return true;  // no device at all: the argument checks and the launch report that
+  return dev == reinterpret_cast<const Ctx*>(ctx)->device;
+}
+
 extern "C" sgp_ctx* sgp_ctx_create(int device) {
   if (device < 0) return nullptr;
   Ctx* c = new (std::nothrow) Ctx();
@@ -127,6 +136,7 @@ extern "C" size_t sgp_ctx_suffstats_workspace_bytes(const sgp_ctx* ctx, int64_t 
 extern "C" int sgp_ctx_suffstats_fwd(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
                                      const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id, double* Phi, double* b,
                                      double* yy, double* kappa, double* Kfu_out, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_suffstats_fwd(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, Phi, b, yy, kappa, Kfu_out, ws, ws_bytes, stream);
 }
@@ -134,12 +144,14 @@ extern "C" int sgp_ctx_suffstats_bwd(sgp_ctx* ctx, const double* X, int64_t ldx,
                                      const double* inv_ls, double sf2, const double* Phibar, const double* bbar, double kappabar,
                                      const double* Kfu_in, int64_t N, int M, int d, int kernel_id, double* g_ls, double* g_sf2,
                                      double* g_Z, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_suffstats_bwd(X, ldx, y, Z, ldz, inv_ls, sf2, Phibar, bbar, kappabar, Kfu_in, N, M, d, kernel_id, g_ls, g_sf2, g_Z, ws,
                            ws_bytes, stream);
 }
 extern "C" int sgp_ctx_kuu_factor(sgp_ctx* ctx, const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
                                   sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_kuu_factor(Kuu, M, Linv_out, info, ws, ws_bytes, stream);
 }
@@ -147,6 +159,7 @@ extern "C" int sgp_ctx_bound_from_stats(sgp_ctx* ctx, const double* Kuu, const d
                                         const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
                                         double* Phibar, double* bbar, double* Kuubar, double* factors, const double* kuu_linv,
                                         int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_bound_from_stats(Kuu, Phi, b, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info, ws,
                               ws_bytes, stream);
@@ -156,6 +169,7 @@ extern "C" int sgp_ctx_mixture_predict(sgp_ctx* ctx, const double* X, int64_t ld
                                        const double* sf2, const double* s2, double jitter, int M, int d, int kernel_id, int pred_noise,
                                        double gate_jitter, double* mean, double* var, double* cov, int* info, int* gate_info, void* ws,
                                        size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_mixture_predict(X, ldx, y, N, Xs, ldxs, T, Z, ldz, S, inv_ls, sf2, s2, jitter, M, d, kernel_id, pred_noise, gate_jitter,
                              mean, var, cov, info, gate_info, ws, ws_bytes, stream);
@@ -171,6 +185,7 @@ extern "C" int sgp_ctx_suffstats_fwd_whitened(sgp_ctx* ctx, const double* X, int
                                               const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
                                               const double* kuu_linv, double* W, double* u, double* yy, double* kappa, void* ws,
                                               size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_suffstats_fwd_whitened(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, W, u, yy, kappa, ws, ws_bytes, stream);
 }
@@ -182,6 +197,7 @@ extern "C" int sgp_ctx_suffstats_fwd_whitened_rows(sgp_ctx* ctx, const double* X
                                                    int64_t ldz, const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
                                                    const double* kuu_linv, double* W, double* u, double* yy, double* kappa,
                                                    double* T_out, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_suffstats_fwd_whitened_rows(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, W, u, yy, kappa, T_out, ws,
                                          ws_bytes, stream);
@@ -194,6 +210,7 @@ extern "C" int sgp_ctx_suffstats_fwd_extended(sgp_ctx* ctx, const double* X, int
                                               const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
                                               const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
                                               double* Kfu_out, double* phi_diag, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_suffstats_fwd_extended_ex(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, level, W, u, yy, kappa, Kfu_out,
                                        phi_diag, ws, ws_bytes, stream);
@@ -207,6 +224,7 @@ extern "C" int sgp_ctx_suffstats_bwd_factored(sgp_ctx* ctx, const double* X, int
                                               const double* bbar, double kappabar, int64_t N, int M, int d, int kernel_id,
                                               const double* T_in, double* g_ls, double* g_sf2, double* g_Z, void* ws, size_t ws_bytes,
                                               sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_suffstats_bwd_factored_ex(X, ldx, y, Z, ldz, inv_ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, N, M, d, kernel_id, T_in, g_ls,
                                        g_sf2, g_Z, ws, ws_bytes, stream);
@@ -215,6 +233,7 @@ extern "C" int sgp_ctx_bound_from_whitened_stats(sgp_ctx* ctx, const double* W, 
                                                  double s2, int64_t N, int M, int with_adjoints, double* out, double* Phibar,
                                                  double* bbar, double* Kuubar, double* factors, const double* kuu_linv, int* info,
                                                  double* Cw, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
   CtxScope scope(ctx);
   return sgp_bound_from_whitened_stats_ex(W, u, yy, kappa, s2, N, M, with_adjoints, out, Phibar, bbar, Kuubar, factors, kuu_linv, info,
                                           Cw, ws, ws_bytes, stream);

@@ -118,7 +118,8 @@ typedef struct sgp_ctx sgp_ctx;
 #define SGP_OPT_COND_LIMIT 3       /* conditioning gate of the explicit-inverse path (default 1e13; 0 disables; < 0 restores) */
 #define SGP_OPT_CU_BUDGET 4        /* CUs the context's launches may occupy (CU-masked streams); 0 = the whole device */
 #define SGP_OPT_TIMING 5           /* != 0: record HIP events around the dominant kernels (sgp_ctx_timing_last_ms) */
-sgp_ctx* sgp_ctx_create(int device); /* device = the HIP device index the context will be used on (the caller selects it) */
+sgp_ctx* sgp_ctx_create(int device); /* device = the HIP device index the context will be used on (the caller selects it); the
+                                        sgp_ctx_* compute entry points return SGP_ERR_ARG when another device is current */
 void sgp_ctx_destroy(sgp_ctx* ctx);
 int sgp_ctx_device(const sgp_ctx* ctx);
 int sgp_ctx_set_option(sgp_ctx* ctx, int option, double value);   /* SGP_OK or SGP_ERR_ARG */

@@ -54,6 +54,33 @@ def test_chol_trsm_logdiag(engine, M):
     assert abs(ld - torch.log(torch.diagonal(L_ref)).sum().item()) < 1e-10 * max(1, M)
 
 
+def test_chain_cholesky_is_the_same_factor_for_any_number_of_workgroups(engine):
+    """Round 5's single-launch factorization (csrc/sgp_potrf_chain.hpp): one chain workgroup + as many others as the CU budget leaves.
+    Every work item does its arithmetic in a fixed order, so the factor must not depend on how many workgroups share the items --
+    2 (one helper: a single list of items), 8 (still one list), 9 and 17 (the critical items get their own workgroups), the whole chip --
+    and it must agree with LAPACK; the tile-dataflow kernel of round 1 (SGP_POTRF_CHAIN=0 in a child process) is the second opinion.
+    Sizes from two block columns (no fused items at all) to thirty-two."""
+    import ggp_amd
+    for M in (128, 192, 320, 512, 1024, 2048):
+        g = torch.Generator().manual_seed(M + 1)
+        R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
+        A = R @ R.T / M + torch.eye(M, dtype=torch.float64)
+        L_ref = torch.linalg.cholesky(A)
+        Ad = A.to(engine.device)
+        L0, info = engine.chol_lower(Ad)
+        assert int(info.item()) == 0 and relerr(torch.tril(L0).cpu(), L_ref) < 1e-12
+        assert float(torch.triu(L0, 1).abs().max()) == 0.0                      # the strictly-upper part is zeroed, every tile of it
+        for budget in (2, 8, 9, 17):
+            e = ggp_amd.HipEngine(own_context=True)
+            # sgp_chol_lower reads the CU budget of the DEFAULT context / the calling thread (include/sgp.h): the per-thread setter
+            engine.lib.sgp_set_cu_budget(budget)
+            try:
+                Lb, info = e.chol_lower(Ad)
+            finally:
+                engine.lib.sgp_set_cu_budget(0)
+            assert int(info.item()) == 0 and torch.equal(Lb, L0), (M, budget)
+
+
 @pytest.mark.parametrize("M,pivot", [(256, 0), (256, 15), (256, 16), (256, 63), (256, 64), (256, 130), (1024, 1023), (1152, 700)])
 def test_chol_reports_first_bad_pivot_of_any_tile_and_panel(engine, M, pivot):
     """LAPACK-style info = index of the first non-positive pivot, whichever work item / wave of the single-launch
