@@ -183,8 +183,9 @@ def main():
     ap.add_argument("--ls", type=float, default=LS, help="lengthscale of the timed theta (default: SURVEY section 8d's 2.0; tests use a long "
                                                          "one to drive the streaming-order guard on several ranks)")
     ap.add_argument("--sig-n", type=float, default=SN, help="noise standard deviation of the timed theta (default 0.3)")
-    ap.add_argument("--side-chain", choices=["graph", "launches", "off"], default="graph",
-                    help="how chol(Kuu) is enqueued on the side stream (A/B knob; default = the product default)")
+    ap.add_argument("--side-chain", choices=["on", "off", "graph", "launches"], default="on",
+                    help="chol(Kuu) on a side stream beside pass 1 (A/B knob; default = the product default; 'graph' / 'launches' are "
+                         "round-4 spellings of 'on': the chain is six plain launches now)")
     args = ap.parse_args()
     LS, SN = float(args.ls), float(args.sig_n)
 
@@ -221,7 +222,6 @@ def main():
     lo, hi = ggp_amd.shard_rows(args.n, rank, world)
     Xd, yd, Zd = X[lo:hi].contiguous().to(dev), y[lo:hi].contiguous().to(dev), Z.to(dev)
     cb = ggp_amd.CollapsedBound(Xd, yd, kernel="rbf", jitter=JITTER, engine=eng)
-    cb.use_graph = args.side_chain == "graph"
     cb.overlap_tail = args.side_chain != "off"
     ls = [LS] * DIM
     sf2, s2 = SF * SF, SN * SN

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "sgp_ctx_suffstats_bwd": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _i64, _i32, _i32, _i32,
                                      _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_ctx_kuu_factor": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_kuu_factor_ex": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_ctx_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     # ABI version 3: the guard's fallback orders, the factored pass 2 and the whitened bound with a context
@@ -108,6 +109,7 @@ PROTOTYPES = {
     "sgp_kuu_factor_len": (_sz, [_i32]),
     "sgp_kuu_factor_workspace_bytes": (_sz, [_i32]),
     "sgp_kuu_factor": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_kuu_factor_ex": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_whitened_workspace_bytes": (_sz, [_i64, _i32, _i32]),

@@ -15,7 +15,6 @@ replicated.  One evaluation =
 from __future__ import annotations
 
 import math
-from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -196,11 +195,10 @@ class CollapsedBound:
         self.fused = True          # single-launch path for small problems (M <= 128, one rank): sgp_small_eval
         self._small = None         # (pinned host theta, device theta, result buffer) of the single-launch path
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
-        self.use_graph = True      # ... replayed from a hipGraph (falls back to plain launches if capture fails)
+        self.use_graph = False     # (no effect since round 5: the chain is six plain launches; kept for callers that set it)
         self.overlap_min_work = 1 << 21  # local rows x inducing points below which everything stays on one stream
         self.early_check_min_work = 1 << 28  # ... from which value_and_grad reads the status before enqueueing pass 2
-        self._side = None
-        self._pool = None
+        self._side = None          # (side stream, (z_ready, ready) events, {M: (Kuu, L^-1) buffers}) of the two-stream path
         # Guard of the streaming order (form="auto" only; see the block comment above required_tier): the tolerance is per datum on
         # |dF| / N.  extended_level 2 = 39 digit pairs, what the sandwich amplifies is 2^16 smaller (reach 2^14: a factor 4 kept as margin;
         # measured at C5 over 27 theta: <= 1.6e-10 per datum against the whitened order up to estimates of 3e-5,
@@ -310,6 +308,20 @@ class CollapsedBound:
             return hasattr(self.engine, "suffstats_whitened") and self._rows_for_form * int(M) <= self.WHITENED_MAX_WORK
         return self.form == "whitened"
 
+    def _side_state(self, M):
+        """(side stream, (z_ready, ready) events, (Kuu, L^-1) buffers for M inducing points) of the two-stream path.  One side stream per
+        engine, shared by every bound built on it; events and buffers are this bound's."""
+        e = self.engine
+        if self._side is None:
+            if getattr(e, "_side_stream", None) is None:
+                e._side_stream = torch.cuda.Stream(device=e.device, priority=-1)  # ahead of queued pass-1 workgroups
+            self._side = (e._side_stream, (torch.cuda.Event(), torch.cuda.Event()), {})
+        bufs = self._side[2].get(M)
+        if bufs is None:
+            self._side[2].clear()  # (one M at a time: a bound whose inducing set changes size does not keep every size)
+            bufs = self._side[2][M] = (e.empty(M, M), e.empty(e.lib.sgp_kuu_factor_len(M)))
+        return self._side[0], self._side[1], bufs
+
     def _trace_buf(self):
         if getattr(self, "_trace", None) is None:  # tr(Kuu^-1) + its scratch: one buffer per bound, reused by every evaluation
             e = self.engine
@@ -380,7 +392,7 @@ class CollapsedBound:
             # and a double-double triple product; pass 2 from the explicit Phibar on the fp64 K'_fu kept here
             self.n_extended += 1
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
-            linv, _ = e.kuu_factor(Kuu, info=result[2])
+            linv, _ = e.kuu_factor(Kuu, info=result[2], trace_out=self._trace_buf() if report else None)
             kfu = self._kfu_for(M) if with_adjoints else None
             diag = None
             if report:
@@ -394,14 +406,15 @@ class CollapsedBound:
                           result=result, whitened=True)
             if report:
                 self._allreduce(diag[:M])  # (ranks hold the diagonal of their own shard's Phi)
-                e.streaming_error_report(diag, 1, e.kuu_inverse_trace(linv, M, out=self._trace_buf()), sf2, s2, self.N, M, result)
+                e.streaming_error_report(diag, 1, self._trace_buf(), sf2, s2, self.N, M, result)
                 res["reported"] = True
             res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv)
             return res
         if tier == TIER_WHITENED:
             # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
-            linv, _ = e.kuu_factor(Kuu, info=result[2])
+            rep = report and self.kernel != "composite"
+            linv, _ = e.kuu_factor(Kuu, info=result[2], trace_out=self._trace_buf() if rep else None)
             # with adjoints: also the whitened core Cw of Phibar, so that pass 2 applies L^-T Cw L^-1 factor by factor
             factored = with_adjoints and self.factored_adjoint and hasattr(e, "suffstats_bwd_factored")
             t_keep = None
@@ -416,86 +429,49 @@ class CollapsedBound:
             kw = {"want_cw": True} if factored else {}
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True, **kw)
-            if report and self.kernel != "composite":
-                e.streaming_error_report(None, 1, e.kuu_inverse_trace(linv, M, out=self._trace_buf()), sf2, s2, self.N, M, result)
+            if rep:
+                e.streaming_error_report(None, 1, self._trace_buf(), sf2, s2, self.N, M, result)
                 res["reported"] = True
             res.update(packed=packed, kfu=None, t_keep=t_keep, linv=linv)
             return res
         kfu = self._kfu_for(M) if with_adjoints else None
         gate = None
         guard = report
-        trace = None
-        # a second stream + helper thread only pays once pass 1 is long enough to hide the Kuu chain under it
-        # (C3-sized and up; at C1 / C2 sizes the hand-over costs more than the 0.1 ms it could hide)
+        trace = self._trace_buf() if guard and hasattr(e, "kuu_factor") else None
+        # a second stream only pays once pass 1 is long enough to hide the Kuu chain under it (C3-sized and up; at C1 / C2 sizes
+        # the hand-over costs more than the 0.1 ms it could hide)
         overlap = (self.overlap_tail and hasattr(e, "kuu_factor") and e.device.type == "cuda"
                    and int(self.X.shape[0]) * M >= self.overlap_min_work)
         if overlap:
-            # chol(Kuu) and its inverse depend on (Z, theta) only: they run on a side stream beside the prologue /
-            # kernel assembly of pass 1 (once the SYRK saturates the chip a chain of ~50 dependent small kernels
-            # would crawl).  Enqueueing that chain costs the host 0.6-1 ms (graph replay or plain launches alike), so
-            # a helper thread does it -- the ctypes call / graph replay drop the GIL -- while this thread enqueues
-            # pass 1: neither stream waits for the host.
+            # chol(Kuu), its inverse, the conditioning gate and tr(Kuu^-1) depend on (Z, theta) only: engine.kuu + engine.kuu_factor, SIX
+            # launches since round 5 (the factorization's launch forms L^-1 itself), on a side stream beside pass 1.  The calling thread
+            # enqueues them first (~25 us; through round 4 the chain was ~50 launches, replayed from a hipGraph by a helper thread whose
+            # wake-up alone cost 70 us: profiles/r05_v2_c3_timeline.txt), into buffers the bound keeps (no allocation, no stream
+            # bookkeeping per evaluation: the previous evaluation's readers are ahead of `z_ready` in the main stream's order).
             main = torch.cuda.current_stream(e.device)
-            if self._side is None:  # one side stream + one helper thread per engine, shared by every bound built on it
-                if getattr(e, "_side_stream", None) is None:
-                    e._side_stream = torch.cuda.Stream(device=e.device, priority=-1)  # ahead of queued pass-1 workgroups
-                    e._side_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sgp-side")
-                self._side, self._pool = e._side_stream, e._side_pool
-            # graph replay only single-process: with a process group the helper thread enqueues plain launches (same speed),
-            # which keeps hipGraph capture away from the collective library's own threads
-            use_graph = self.use_graph and self.world == 1 and hasattr(e, "kuu_factor_graph")
-            gr = e.kuu_factor_graph(M) if use_graph else None
-            z_ready = main.record_event()  # Z is materialised on the main stream
-            side, jitter, kernel = self._side, self.jitter, self.kernel
-
-            def side_chain(with_trace=True):
-                torch.cuda.set_device(e.device)  # the current device is per host thread
-                with torch.cuda.stream(side):
-                    side.wait_event(z_ready)
-                    if gr is not None:
-                        K = e.kuu(Z, ls, sf2, jitter, kernel, out=gr["Kuu"])
-                        gr["graph"].replay()
-                        result[2].copy_(gr["info"])  # the evaluation's status word starts as the Kuu status
-                        li = gr["Linv"]
-                    else:
-                        K = e.kuu(Z, ls, sf2, jitter, kernel)
-                        li = e.kuu_factor(K, info=result[2])[0]
-                    ready = side.record_event()  # what pass 1's tail waits for; the guard's tr(Kuu^-1) runs behind it, off the critical path
-                    return K, li, (e.kuu_inverse_trace(li, M, out=self._trace_buf()) if guard and with_trace else None), ready
-
+            side, (z_ready, ready), (Kuu, linv) = self._side_state(M)
+            z_ready.record(main)  # Z is materialised on the main stream
+            side.wait_event(z_ready)
             result[0].record_stream(side)
-            # Big shards contract on the integer matrix cores, beside which nothing co-schedules: with a
-            # graph (one cheap replay) this thread enqueues the chain itself and the contraction is gated on its end, so the
-            # chain runs beside kernel assembly; otherwise the helper thread enqueues it and it shares the chip with pass 1
-            # (only where assembly outlasts the chain -- 2.0 ms vs 0.6 at N = 1M, M = 1024, but 0.3 vs 0.6 at an eighth of it,
-            # where gating costs 0.1 ms: rows >= 300 M)
-            # ... and only where the integer cores will actually contract (the library's own rule for this engine's context: a
-            # shard below it, a pinned fp64 mode or a composite kernel keeps the helper-thread overlap)
-            if (gr is not None and hasattr(e, "would_use_i8") and self.kernel != "composite"
-                    and int(self.X.shape[0]) >= 300 * M and e.would_use_i8(int(self.X.shape[0]), M)):
-                chain = side_chain(with_trace=False)  # (this thread is about to enqueue pass 1: the guard's launch waits until it has)
-                gate = chain[3]
-                pending = None
-            else:
-                pending = self._pool.submit(side_chain)
+            e.kuu(Z, ls, sf2, self.jitter, self.kernel, out=Kuu, stream=side)
+            e.kuu_factor(Kuu, info=result[2], trace_out=trace, out=linv, stream=side)  # the evaluation's status word starts as the Kuu status
+            ready.record(side)
+            # Big shards contract on the integer matrix cores, beside which nothing co-schedules: the contraction is gated on the
+            # chain's end, so the chain runs beside kernel assembly (only where assembly outlasts the chain -- 2.0 ms vs 0.6 at
+            # N = 1M, M = 1024, but 0.3 vs 0.6 at an eighth of it, where gating costs 0.1 ms: rows >= 300 M) ... and only where the
+            # integer cores will actually contract (the library's own rule for this engine's context)
+            if (hasattr(e, "would_use_i8") and self.kernel != "composite" and int(self.X.shape[0]) >= 300 * M
+                    and e.would_use_i8(int(self.X.shape[0]), M)):
+                gate = ready
         packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
         self._allreduce_stats(packed, M)
         if overlap:
-            Kuu, linv, trace, ready = pending.result() if pending is not None else chain
-            if guard and trace is None:
-                with torch.cuda.stream(self._side):
-                    trace = e.kuu_inverse_trace(linv, M, out=self._trace_buf())
-            for t in (Kuu, linv):
-                t.record_stream(main)
             main.wait_event(ready)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
-            if trace is not None:
-                main.wait_stream(self._side)  # (long done: one single-workgroup kernel behind `ready`)
         elif guard and hasattr(e, "kuu_factor"):
             Kuu = e.kuu(Z, ls, sf2, self.jitter, self.kernel)
-            linv, _ = e.kuu_factor(Kuu, info=result[2])
-            trace = e.kuu_inverse_trace(linv, M, out=self._trace_buf())
+            linv, _ = e.kuu_factor(Kuu, info=result[2], trace_out=trace)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
         else:

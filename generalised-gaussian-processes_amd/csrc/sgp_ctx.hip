@@ -155,6 +155,12 @@ extern "C" int sgp_ctx_kuu_factor(sgp_ctx* ctx, const double* Kuu, int M, double
   CtxScope scope(ctx);
   return sgp_kuu_factor(Kuu, M, Linv_out, info, ws, ws_bytes, stream);
 }
+extern "C" int sgp_ctx_kuu_factor_ex(sgp_ctx* ctx, const double* Kuu, int M, double* Linv_out, int* info, double* trace_out, void* ws,
+                                     size_t ws_bytes, sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
+  CtxScope scope(ctx);
+  return sgp_kuu_factor_ex(Kuu, M, Linv_out, info, trace_out, ws, ws_bytes, stream);
+}
 extern "C" int sgp_ctx_bound_from_stats(sgp_ctx* ctx, const double* Kuu, const double* Phi, const double* b, const double* yy,
                                         const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out,
                                         double* Phibar, double* bbar, double* Kuubar, double* factors, const double* kuu_linv,

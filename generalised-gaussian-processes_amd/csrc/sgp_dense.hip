@@ -529,7 +529,8 @@ size_t potrf_flag_ints(int Mp) {
 size_t potrf_scratch_ints(int Mp) {
   const size_t nb = Mp / DB;
   // + the 16 x 16 block inverses of every diagonal tile + (chain-workgroup kernel) the prep items' partial sums US / UD (doubles)
-  return potrf_flag_ints(Mp) + nb * 1024 * 2 + nb * 4096 * 2 * 5;
+  // + the transposed blocks of L^-1 (chain-workgroup kernel with an inverse wanted)
+  return potrf_flag_ints(Mp) + ch_scratch_doubles((int)nb) * 2;
 }
 
 const int* potrf_abort_flag(const int* scratch, int Mp) {
@@ -571,7 +572,7 @@ int available_cus() {
   return (cu_budget() > 0 && cu_budget() < cus) ? cu_budget() : cus;
 }
 
-void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
+bool potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
                  const double* rhs, double* sol, bool caller_managed, int prepped) {
   const int nb = Mp / DB;
   const int ntile = nb * (nb + 1) / 2;
@@ -583,15 +584,16 @@ void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   // the chain-workgroup kernel from two block columns on, when at least one other workgroup can be resident beside it
   static const int use_chain = getenv("SGP_POTRF_CHAIN") ? atoi(getenv("SGP_POTRF_CHAIN")) : 1;  // 0: the round-1 dataflow kernel (A/B)
   if (use_chain && nb >= 2 && max_wg >= 2) {
-    const int nout_items = ch_tile_items(nb) + (Linv ? nb : 0) + (rhs ? 1 : 0);  // tiles (tile (c+2, c) twice), block inverses, rhs
+    const int nout_items = ch_tile_items(nb) + (Linv ? ch_inv_items(nb) : 0) + (rhs ? 1 : 0);  // tiles (tile (c+2, c) twice), blocks of L^-1, rhs
     const int nout = nout_items < max_wg - 1 ? nout_items : max_wg - 1;
     potrf_chain_kernel<<<1 + nout, CH_THREADS, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
     if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
-    return;
+    return Linv != nullptr;  // the whole of L^-1, not only its diagonal blocks
   }
   potrf_dataflow_kernel<<<nitem < max_wg ? nitem : max_wg, 256, 0, st>>>(
       A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv);
   if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
+  return false;
 }
 
 void potrf_lower_batch(double* A, double* Linv, int64_t ld, int Mp, int S, int64_t stride, int* info, int* scratch, hipStream_t st) {
@@ -771,7 +773,7 @@ extern "C" int sgp_chol_lower(double* A, int64_t lda, int M, int* info, void* ws
   int* flags = c.take<int>(potrf_scratch_ints(Mp));
   zero_ints(info, 1, st);
   pad_copy(A, lda, M, M, Ap, Mp, Mp, Mp, 1.0, st);
-  potrf_lower(Ap, Li, Mp, Mp, info, 0, flags, st);
+  potrf_lower(Ap, nullptr, Mp, Mp, info, 0, flags, st);  // (no inverse wanted: the launch then carries no L^-1 items)
   crop_copy(Ap, Mp, A, lda, M, M, st);
   return check_launch();
 }

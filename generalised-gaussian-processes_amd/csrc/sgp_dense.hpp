@@ -93,7 +93,9 @@ size_t potrf_flag_ints(int Mp);  // the leading part of the scratch that must be
 // (potrf_abort_flag) itself after the launch -- saves two tiny launches on the latency-critical tail.
 // prepped: bit 0 -- the flags part of `scratch` is already zero on this stream, bit 1 -- Linv is already zero (a caller that fills
 // its operand with a kernel of its own clears both there: two launches fewer on the K_uu chain, which IS C3's critical path)
-void potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
+// Returns true when Linv has received the WHOLE inverse (the chain-workgroup kernel forms its blocks inside the launch: sgp_potrf_chain.hpp),
+// false when only the diagonal blocks are there and the caller still has to run tri_inverse().
+bool potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int info_base, int* scratch, hipStream_t st,
                  const double* rhs = nullptr, double* sol = nullptr, bool caller_managed = false, int prepped = 0);
 // the word of `scratch` the dataflow launch raises when it gave up waiting (then info must become SGP_INFO_TIMEOUT)
 const int* potrf_abort_flag(const int* scratch, int Mp);

@@ -21,7 +21,11 @@
 //         UD(j+1) = sum_{p<j}  L(j+1,p) L(j+1,p)^T   -> scratch `dpre`, in the accumulator order, flag preD[j+1]
 //     (never in place: a tile must have ONE writer and no reader before it is published -- the L2s of the eight XCDs are not
 //     coherent with each other for ordinary lines, see df_wait in sgp_potrf.hpp);
-//   * the 64 x 64 block inverses for tri_inverse() and the optional right-hand side are items of their own behind the tiles.
+//   * the blocks of L^-1 (when the caller wants the inverse) are items too, row i of blocks behind column i of tiles: the transposed block
+//         X(i,j)^T = [ -sum_{j<=p<i} X(p,j)^T L(i,p)^T   or   I for i = j ] L(i,i)^-T
+//     is the tiles' own panel-by-panel solve against the panels the chain workgroup publishes, so the whole inverse is complete one
+//     panel step behind the last chain -- tri_inverse()'s log2(nb) levels of two dependent launches each (40 us at M = 512, on the
+//     critical path of C3: profiles/r05_v2_c3_timeline.txt) are gone; the optional right-hand side is the last item.
 // Round-trip costs between CUs decide the rest (profiles/r05_potrf_chain_phases_*.txt: a publication with an agent-scope release fence,
 // i.e. an L2 write-back, 1 - 2.5 us; the consumer's first load of the published lines 1.5 - 2 us when they come from memory): the
 // chain of hops  last panel of L(j-1,j-1) -> tile (j+1,j-1) -> its product with X(j-1) -> US(j) -> the S-waves  is ~10 us long after
@@ -70,9 +74,9 @@ struct ChShared {
   int xpub;                // S-waves that have written back their rows of X (cumulative over the steps)
 };
 
-// scratch layout (ints): [ready: ntile | abort | preS: nb | preD: nb | pready: 4 nb | preSE: nb | preDE: nb | pready_l: 4 nb | xready_l: nb | cwx]
-// x DF_FLAG_STRIDE, then doubles:
-// dinv_g nb x 1024 | upre nb x 4096 | dpre nb x 4096 | lo2 nb x 4096 | upe nb x 4096 | dpe nb x 4096
+// scratch layout (ints): [ready: ntile | abort | preS: nb | preD: nb | pready: 4 nb | preSE: nb | preDE: nb | pready_l: 4 nb | xready_l: nb | cwx |
+// iready: ntile] x DF_FLAG_STRIDE, then doubles:
+// dinv_g nb x 1024 | upre nb x 4096 | dpre nb x 4096 | lo2 nb x 4096 | upe nb x 4096 | dpe nb x 4096 | xt ntile x 4096
 struct ChScratch {
   int* ready;
   int* abort_flag;
@@ -90,8 +94,11 @@ struct ChScratch {
   int* pready_l;  // "light" twins of pready / of the flags of the tiles (j+1, j): the data is in the chain workgroup's L2, not written back
   int* xready_l;
   int* cwx;       // the chain workgroup's XCC id + 1
+  int* iready;    // blocks of L^-1 (same numbering as the tiles)
+  double* xt;     // ... and their transposes X(i,j)^T, row-major 64 x 64: the left operand of the rows below
 };
-__host__ __device__ inline size_t ch_flag_slots(int nb) { return (size_t)nb * (nb + 1) / 2 + 2 + 13 * (size_t)nb; }
+__host__ __device__ inline size_t ch_flag_slots(int nb) { return (size_t)nb * (nb + 1) + 2 + 13 * (size_t)nb; }
+__host__ __device__ inline size_t ch_scratch_doubles(int nb) { return (size_t)nb * 1024 + (size_t)nb * 4096 * 5 + (size_t)nb * (nb + 1) / 2 * 4096; }
 __device__ __forceinline__ ChScratch ch_scratch(int* scratch, int nb) {
   const int ntile = nb * (nb + 1) / 2;
   ChScratch s;
@@ -111,6 +118,8 @@ __device__ __forceinline__ ChScratch ch_scratch(int* scratch, int nb) {
   s.pready_l = s.preDE + (size_t)nb * DF_FLAG_STRIDE;
   s.xready_l = s.pready_l + (size_t)4 * nb * DF_FLAG_STRIDE;
   s.cwx = s.xready_l + (size_t)nb * DF_FLAG_STRIDE;
+  s.iready = s.cwx + DF_FLAG_STRIDE;
+  s.xt = s.dpe + (size_t)nb * 4096;
   return s;
 }
 
@@ -511,49 +520,40 @@ __device__ __forceinline__ int df_wait_panels(const int* pready, int pb, int* ab
 //   FUSED_S(c)               tile (c+2, c) into scratch, then US(c+1) = early terms + L(c+1,c) X^T   -> the chain workgroup's S-waves
 //   FUSED_D(c)               tile (c+2, c) in place (published at once), then UD(c+2) = early terms + X X^T
 //   TILE(i, c), i >= c + 3   rank-64 updates, then the solve panel by panel as the chain workgroup publishes L(c,c)
-//   DINV(e)                  64 x 64 block inverse of L(e,e) -> Linv (level 0 of tri_inverse())
+//   INV(i, j), i >= j          block (i, j) of L^-1 (and its transpose into scratch), behind column i's tiles
 //   RHS                      sol = L^-1 rhs
 // Two lists, each in dependency order (every dependency of an item is an earlier item of one of the lists or a step of the chain
 // workgroup): the CRITICAL one [FUSED_S(0), FUSED_D(0), FUSED_S(1), ...] is dealt round-robin to the workgroups expected on the chain
 // workgroup's XCD (blockIdx = 0 mod 8), the other one to the rest; with fewer than eight workgroups there is one list for all.
-enum ChKind { CH_EARLY_S, CH_EARLY_D, CH_FUSED_S, CH_FUSED_D, CH_TILE, CH_DINV, CH_RHS, CH_NONE };
+enum ChKind { CH_EARLY_S, CH_EARLY_D, CH_FUSED_S, CH_FUSED_D, CH_TILE, CH_INV, CH_RHS, CH_NONE };
 struct ChItem { int kind, c, i; };
 __host__ __device__ inline int ch_crit_items(int nb) { return nb >= 3 ? 2 * (nb - 2) : 0; }
 __host__ __device__ inline int ch_rest_tile_items(int nb) { return nb >= 3 ? (nb - 2) * (nb + 1) / 2 : 0; }  // per column c: 2 + (nb - 3 - c)
 __host__ __device__ inline int ch_tile_items(int nb) { return ch_crit_items(nb) + ch_rest_tile_items(nb); }
-// item k of the non-critical list (columns c <= nb - 3: [EARLY_S, EARLY_D, TILE(c+3..)], then DINV(0..nb-1) if want_inv, then RHS if want_rhs)
-__device__ __forceinline__ ChItem ch_rest_item(int k, int nb, bool want_inv, bool want_rhs) {
-  int c = 0, start = 0;
-  const int nt = ch_rest_tile_items(nb);
-  if (k < nt) {
-    while (k >= start + (nb - 1 - c)) { start += nb - 1 - c; ++c; }
-    const int slot = k - start;
-    if (slot == 0) return ChItem{CH_EARLY_S, c, c + 2};
-    if (slot == 1) return ChItem{CH_EARLY_D, c, c + 2};
-    return ChItem{CH_TILE, c, c + 1 + slot};
-  }
-  k -= nt;
-  if (want_inv) {
-    if (k < nb) return ChItem{CH_DINV, k, k};
-    k -= nb;
+__host__ __device__ inline int ch_inv_items(int nb) { return nb * (nb + 1) / 2; }
+// item k of a list: per column c the tile items ([EARLY_S, EARLY_D, (single list only: FUSED_S, FUSED_D,) TILE(c+3..)], columns c <= nb - 3),
+// then -- want_inv -- row c of L^-1: INV(c, 0 .. c); behind the last column RHS if want_rhs.  `fused`: the single list (few workgroups)
+__device__ __forceinline__ ChItem ch_list_item(int k, int nb, bool want_inv, bool want_rhs, bool fused) {
+  for (int c = 0; c < nb; ++c) {
+    const int nt = c <= nb - 3 ? nb - 1 - c + (fused ? 2 : 0) : 0;
+    if (k < nt) {
+      if (k == 0) return ChItem{CH_EARLY_S, c, c + 2};
+      if (k == 1) return ChItem{CH_EARLY_D, c, c + 2};
+      if (fused) {
+        if (k == 2) return ChItem{CH_FUSED_S, c, c + 2};
+        if (k == 3) return ChItem{CH_FUSED_D, c, c + 2};
+        return ChItem{CH_TILE, c, c - 1 + k};
+      }
+      return ChItem{CH_TILE, c, c + 1 + k};
+    }
+    k -= nt;
+    if (want_inv) {
+      if (k <= c) return ChItem{CH_INV, k, c};
+      k -= c + 1;
+    }
   }
   if (want_rhs && k == 0) return ChItem{CH_RHS, 0, 0};
   return ChItem{CH_NONE, 0, 0};
-}
-// item k of the single list (few workgroups): per column [EARLY_S, EARLY_D, FUSED_S, FUSED_D, TILE(c+3..)], then DINV, RHS
-__device__ __forceinline__ ChItem ch_all_item(int k, int nb, bool want_inv, bool want_rhs) {
-  int c = 0, start = 0;
-  const int nt = ch_tile_items(nb);
-  if (k < nt) {
-    while (k >= start + (nb + 1 - c)) { start += nb + 1 - c; ++c; }
-    const int slot = k - start;
-    if (slot == 0) return ChItem{CH_EARLY_S, c, c + 2};
-    if (slot == 1) return ChItem{CH_EARLY_D, c, c + 2};
-    if (slot == 2) return ChItem{CH_FUSED_S, c, c + 2};
-    if (slot == 3) return ChItem{CH_FUSED_D, c, c + 2};
-    return ChItem{CH_TILE, c, c - 1 + slot};
-  }
-  return ch_rest_item(k - nt + ch_rest_tile_items(nb), nb, want_inv, want_rhs);
 }
 
 __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChScratch sc, const double* rhs, double* sol, double* Linv,
@@ -599,11 +599,11 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
   const bool crit_wg = split && ((ow + 1) & 7) == 0;
   int first, stride, count;
   if (!split) {
-    first = ow; stride = nout; count = ch_tile_items(nb) + (want_inv ? nb : 0) + (want_rhs ? 1 : 0);
+    first = ow; stride = nout; count = ch_tile_items(nb) + (want_inv ? ch_inv_items(nb) : 0) + (want_rhs ? 1 : 0);
   } else if (crit_wg) {
     first = (ow + 1) / 8 - 1; stride = nl; count = ch_crit_items(nb);
   } else {
-    first = ow - (ow + 1) / 8; stride = nout - nl; count = ch_rest_tile_items(nb) + (want_inv ? nb : 0) + (want_rhs ? 1 : 0);
+    first = ow - (ow + 1) / 8; stride = nout - nl; count = ch_rest_tile_items(nb) + (want_inv ? ch_inv_items(nb) : 0) + (want_rhs ? 1 : 0);
   }
   bool local = false;  // same XCD as the chain workgroup (decided once it has said where it runs; asked only by the fused items)
   bool local_known = false;
@@ -629,36 +629,90 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     return true;
   };
 
+  // X = Y L(jd,jd)^-T panel by panel as the chain workgroup publishes L(jd,jd): yb / xb = this wave's 16 rows of Y / X as four 16 x 16
+  // blocks in the accumulator layout.  Panels already public are fetched in one go (an item whose updates end late finds all four
+  // there: one round trip, not four).  false: the launch has been aborted.
+  auto solve_panels = [&](int jd, const int* pready, d4 (&yb)[4], d4 (&xb)[4], bool stamp) __attribute__((always_inline)) {
+    const double* Ljj = A + (int64_t)jd * DB * (ld + 1);
+    const double* dg = sc.dinv_g + (size_t)jd * 1024;
+    auto fetch_panel = [&](int pb) __attribute__((always_inline)) {
+      const double* src = Ljj + (int64_t)r * ld + 16 * pb + 4 * g;  // 64 rows x 16 columns: thread <-> (row, 4 columns)
+      const d2 v0 = *reinterpret_cast<const d2*>(src), v1 = *reinterpret_cast<const d2*>(src + 2);
+      const double dv = dg[pb * 256 + tid];
+      sh.Sp[pb][r][4 * g] = v0[0];
+      sh.Sp[pb][r][4 * g + 1] = v0[1];
+      sh.Sp[pb][r][4 * g + 2] = v1[0];
+      sh.Sp[pb][r][4 * g + 3] = v1[1];
+      sh.Dinv[pb][tid >> 4][tid & 15] = dv;
+    };
+    int have = 0;  // panels in LDS
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      if (pb >= have) {
+        const int upto = df_wait_panels(pready, pb, abort_flag, sh);
+        if (upto < 0) return false;
+        for (int q = pb; q < upto; ++q) fetch_panel(q);
+        have = upto;
+        __syncthreads();
+      }
+      if (pb == 3 && stamp && tid == 0) CH_STAMP(jd, 12);
+      d4 xa = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) xa = mfma16(sh.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
+      xb[pb] = xa;
+#pragma unroll
+      for (int q = pb + 1; q < 4; ++q)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-sh.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
+    }
+    return true;
+  };
+
   for (int k = first; k < count; k += stride) {
-    const ChItem it = !split ? ch_all_item(k, nb, want_inv, want_rhs)
-                             : (crit_wg ? ChItem{(k & 1) ? CH_FUSED_D : CH_FUSED_S, k >> 1, (k >> 1) + 2} : ch_rest_item(k, nb, want_inv, want_rhs));
+    const ChItem it = !split ? ch_list_item(k, nb, want_inv, want_rhs, true)
+                             : (crit_wg ? ChItem{(k & 1) ? CH_FUSED_D : CH_FUSED_S, k >> 1, (k >> 1) + 2} : ch_list_item(k, nb, want_inv, want_rhs, false));
     const int kind = it.kind, j = it.c, i = it.i;
     if (kind == CH_NONE) break;
     if (kind == CH_RHS) {
       df_solve_rhs(A, ld, nb, ready, abort_flag, rhs, sol, sh);
       continue;
     }
-    if (kind == CH_DINV) {
-      const int e = j;
-      if (!df_wait(ready + (size_t)tile_no(e, e) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
-      static_assert(sizeof(sh.Ts) >= sizeof(double) * DB * DLD && sizeof(sh.Sp) >= sizeof(double) * DB * DLD, "LDS reuse");
-      double (*S)[DLD] = reinterpret_cast<double (*)[DLD]>(&sh.Ts[0][0]);
-      double (*Inv)[DLD] = reinterpret_cast<double (*)[DLD]>(&sh.Sp[0][0][0]);
-      const double* src = A + (int64_t)e * DB * (ld + 1) + (int64_t)r * ld + 16 * g;
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const d2 v = *reinterpret_cast<const d2*>(src + 2 * kk);
-        S[r][16 * g + 2 * kk] = (16 * g + 2 * kk <= r) ? v[0] : 0.0;
-        S[r][16 * g + 2 * kk + 1] = (16 * g + 2 * kk + 1 <= r) ? v[1] : 0.0;
-        Inv[r][16 * g + 2 * kk] = 0.0;
-        Inv[r][16 * g + 2 * kk + 1] = 0.0;
+    if (kind == CH_INV) {
+      // block (i, j) of L^-1, formed transposed: Y = X(i,j)^T = [ -(sum_{j<=p<i} X(p,j)^T L(i,p)^T)  or  I ] L(i,i)^-T
+      d4 acci[2][2];
+      zero_acc(acci);
+      for (int p = j; p < i; ++p) {
+        if (!df_wait(sc.iready + (size_t)tile_no(p, j) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+        if (!df_wait(ready + (size_t)tile_no(i, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+        df_mac(sc.xt + (size_t)tile_no(p, j) * 4096, A + (int64_t)i * DB * ld + (int64_t)p * DB, DB, ld, sh, acci);
       }
-      __syncthreads();
-      block_inverse64(S, Inv);
-      double* ldst = Linv + ((int64_t)e * DB + r) * ld + (int64_t)e * DB + 16 * g;
+      d4 yi[4], xi[4];
+      if (i > j) {
+        acc_to_ts(acci);
+        __syncthreads();
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) *reinterpret_cast<d2*>(ldst + 2 * kk) = d2{Inv[r][16 * g + 2 * kk], Inv[r][16 * g + 2 * kk + 1]};
-      __syncthreads();
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int sq = 0; sq < 4; ++sq) yi[pb][sq] = -sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4];
+      } else {
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int sq = 0; sq < 4; ++sq) yi[pb][sq] = (16 * g + l15 == 16 * pb + 4 * sq + l4) ? 1.0 : 0.0;
+      }
+      if (!solve_panels(i, sc.pready + (size_t)4 * i * DF_FLAG_STRIDE, yi, xi, false)) return;
+      // Y[m][n], m = 16 g + l15, n = 16 pb + 4 sq + l4  ->  scratch (as it is) and L^-1[64 i + n][64 j + m] (a diagonal block: lower triangle only)
+      double* xtd = sc.xt + (size_t)tile_no(i, j) * 4096 + (size_t)(16 * g + l15) * DB + l4;
+      double* lid = Linv + ((int64_t)i * DB + l4) * ld + (int64_t)j * DB + 16 * g + l15;
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+          const double v = (i > j || 16 * g + l15 <= 16 * pb + 4 * sq + l4) ? xi[pb][sq] : 0.0;
+          xtd[16 * pb + 4 * sq] = v;
+          lid[(int64_t)(16 * pb + 4 * sq) * ld] = v;
+        }
+      raise(sc.iready + (size_t)tile_no(i, j) * DF_FLAG_STRIDE);
       continue;
     }
     const int jn = j + 1;  // the column whose prep sums the EARLY / FUSED items of column j deliver
@@ -722,40 +776,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
       for (int sq = 0; sq < 4; ++sq) yb[pb][sq] -= sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4];
-    const double* Ljj = A + (int64_t)j * DB * (ld + 1);
-    const double* dg = sc.dinv_g + (size_t)j * 1024;
-    const int* pready = (lite ? sc.pready_l : sc.pready) + (size_t)4 * j * DF_FLAG_STRIDE;
-    // panels already public are fetched in one go (an item whose updates end late finds all four there: one round trip, not four)
-    auto fetch_panel = [&](int pb) __attribute__((always_inline)) {
-      const double* src = Ljj + (int64_t)r * ld + 16 * pb + 4 * g;  // 64 rows x 16 columns: thread <-> (row, 4 columns)
-      const d2 v0 = *reinterpret_cast<const d2*>(src), v1 = *reinterpret_cast<const d2*>(src + 2);
-      const double dv = dg[pb * 256 + tid];
-      sh.Sp[pb][r][4 * g] = v0[0];
-      sh.Sp[pb][r][4 * g + 1] = v0[1];
-      sh.Sp[pb][r][4 * g + 2] = v1[0];
-      sh.Sp[pb][r][4 * g + 3] = v1[1];
-      sh.Dinv[pb][tid >> 4][tid & 15] = dv;
-    };
-    int have = 0;  // panels in LDS
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-      if (pb >= have) {
-        const int upto = df_wait_panels(pready, pb, abort_flag, sh);
-        if (upto < 0) return;
-        for (int q = pb; q < upto; ++q) fetch_panel(q);
-        have = upto;
-        __syncthreads();
-      }
-      if (pb == 3 && fused_s && tid == 0) CH_STAMP(j, 12);
-      d4 xa = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) xa = mfma16(sh.Dinv[pb][l15][4 * sq + l4], yb[pb][sq], xa);
-      xb[pb] = xa;
-#pragma unroll
-      for (int q = pb + 1; q < 4; ++q)
-#pragma unroll
-        for (int sq = 0; sq < 4; ++sq) yb[q] = mfma16(-sh.Sp[pb][16 * q + l15][4 * sq + l4], xa[sq], yb[q]);
-    }
+    if (!solve_panels(j, (lite ? sc.pready_l : sc.pready) + (size_t)4 * j * DF_FLAG_STRIDE, yb, xb, fused_s)) return;
     if (!fused_s) {
       double* dst = Aij + (int64_t)(16 * g + l15) * ld + l4;
 #pragma unroll

@@ -24,6 +24,7 @@ static inline int dp_for(int d) {
 struct StreamPlan {
   int Mp, ntr, ntiles, DP;
   int64_t Npad;     // N rounded up to ASM_ROWS
+  int asm_sub;      // fp64 assembly: workgroups per ASM_ROWS row block (1, or 4 on small shards: 64 rows each, see make_stream_plan)
   int64_t sc_rows;  // rows of K'_fu materialised at a time (multiple of ASM_ROWS)
   int nsplit;       // pass 1: row-range splits per tile (multiple of 8: one XCD per residue)
   int taper[4];     // pass 1: groups of 8 splits at relative sizes 8, 4, 2, 1 (all 0: equal splits), see split_range()
@@ -31,6 +32,10 @@ struct StreamPlan {
   int nsplit_b;     // pass 2: row-range splits per column block
   int taper_b[4];   // pass 2: tapered split sizes (as taper[])
 };
+
+// rows of the partial sums of K'^T y the fp64 assembly leaves (the integer path's assembly and the whitened layout's tpart_kernel keep
+// one per ASM_ROWS; their consumers say so)
+static inline int64_t bpart_rows(const StreamPlan& p) { return p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS * p.asm_sub : 1; }
 
 // chunk range [c0, c1) of split `split` (8 splits per group; group sizes taper 8 : 4 : 2 : 1 when taper[] is set)
 struct SplitMap {
@@ -72,6 +77,10 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.ntiles = p.ntr * (p.ntr + 1) / 2;
   p.DP = dp_for(d);
   p.Npad = N > 0 ? round_up64(N, ASM_ROWS) : 0;
+  // Small shards (C3: 52 row blocks x 2 column groups = 104 workgroups of four waves on 256 CUs, every thread walking 256 rows with one
+  // wave per SIMD: 125 us for 6.8 M kernel values, profiles/r05_v2_c3_timeline.txt): a quarter of the rows per workgroup, four times
+  // the workgroups.  The partials of K'^T y are then per 64 rows (bpart_rows(): the fixed-order reduction behind them takes any count).
+  p.asm_sub = (p.Npad / ASM_ROWS) * ((p.Mp + 255) / 256) < 128 ? 4 : 1;
   int64_t cap = (int64_t)(stream_kfu_budget() / ((size_t)p.Mp * 8)) / ASM_ROWS * ASM_ROWS;
   if (cap < ASM_ROWS) cap = ASM_ROWS;
   p.sc_rows = p.Npad < cap ? p.Npad : cap;

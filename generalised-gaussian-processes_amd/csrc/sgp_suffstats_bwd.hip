@@ -451,7 +451,7 @@ static BwdWs carve_bwd(void* ws, const StreamPlan& p, bool need_kfu) {
   w.gzpart = c.take<double>((size_t)p.nsplit_b * p.Mp * p.DP);
   w.glpart = c.take<double>((size_t)p.nsplit_b * p.nmb * (p.DP + 1));
   w.gacc = c.take<double>((size_t)p.nsplit_b * p.nmb * (2 * p.DP + 1) * 256);
-  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
+  w.bpart = c.take<double>((size_t)bpart_rows(p) * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
   w.bytes = c.used();

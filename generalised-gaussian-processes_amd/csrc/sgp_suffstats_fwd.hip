@@ -104,10 +104,11 @@ __global__ __launch_bounds__(256) void stream_prologue_kernel(const double* __re
 //    grid = (rows / ASM_ROWS, ceil(Mp / 256)): a workgroup owns 256 columns x 256 rows; every wave stores
 //    512 contiguous bytes per data row, a workgroup 2 KB.  bpart[rowblock][m] = sum_n Kfu[n][m] y[n].
 // ---------------------------------------------------------------------------------------------
-template <int DP, int KID>
+template <int DP, int KID, int ROWS>
 __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
                                                            const double* __restrict__ Zs, int64_t row0, int64_t N, int M,
                                                            int Mp, double* __restrict__ Kfu, double* __restrict__ bpart) {
+  constexpr int ASM_ROWS = ROWS;  // rows of this workgroup (sgp::ASM_ROWS, or a quarter of it on small shards: StreamPlan::asm_sub)
   // the block's 256 scaled data rows and targets are staged once in LDS (coalesced) and then read as
   // wave-wide broadcasts: measured 80 % of wave time parked on per-row scalar loads before (SQ_WAIT_ANY)
   __shared__ double xs[ASM_ROWS][DP];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void kfu_assemble_kernel(const double* __restr
     const double* src = Xs + (row0 + rbase) * DP;
     double* dst = &xs[0][0];
     for (int e = threadIdx.x; e < ASM_ROWS * DP; e += 256) dst[e] = src[e];
-    ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
+    if ((int)threadIdx.x < ASM_ROWS) ysh[threadIdx.x] = ys[row0 + rbase + threadIdx.x];
     sgp_exp_tab_load(etab);
   }
   __syncthreads();
@@ -492,27 +493,33 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
   }
 }
 
-template <int DP>
-static void launch_assemble(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
-                            int64_t row0, int64_t N, int M, int Mp, double* Kfu, double* bpart) {
+template <int DP, int ROWS>
+static void launch_assemble_rows(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
+                                 int64_t row0, int64_t N, int M, int Mp, double* Kfu, double* bpart) {
   switch (kid) {
-    case SGP_KERNEL_RBF: kfu_assemble_kernel<DP, SGP_KERNEL_RBF><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
-    case SGP_KERNEL_MATERN32: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN32><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
-    default: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN52><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    case SGP_KERNEL_RBF: kfu_assemble_kernel<DP, SGP_KERNEL_RBF, ROWS><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    case SGP_KERNEL_MATERN32: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN32, ROWS><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
+    default: kfu_assemble_kernel<DP, SGP_KERNEL_MATERN52, ROWS><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart); break;
   }
+}
+template <int DP>
+static void launch_assemble(int kid, int sub, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
+                            int64_t row0, int64_t N, int M, int Mp, double* Kfu, double* bpart) {
+  if (sub == 4) launch_assemble_rows<DP, ASM_ROWS / 4>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
+  else launch_assemble_rows<DP, ASM_ROWS>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
 }
 
 // Assemble rows [row0, row0 + rows) of K'_fu (rows a multiple of ASM_ROWS) into Kfu (which starts at row0).
 void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0,
                      int64_t rows, int64_t N, int M, double* Kfu, double* bpart, hipStream_t st) {
-  dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256);
+  dim3 grid((unsigned)(rows / ASM_ROWS * p.asm_sub), (p.Mp + 255) / 256);
   switch (p.DP) {
-    case 2: launch_assemble<2>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
-    case 4: launch_assemble<4>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
-    case 8: launch_assemble<8>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
-    case 16: launch_assemble<16>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
-    case 24: launch_assemble<24>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
-    default: launch_assemble<32>(kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 2: launch_assemble<2>(kid, p.asm_sub, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 4: launch_assemble<4>(kid, p.asm_sub, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 8: launch_assemble<8>(kid, p.asm_sub, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 16: launch_assemble<16>(kid, p.asm_sub, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    case 24: launch_assemble<24>(kid, p.asm_sub, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
+    default: launch_assemble<32>(kid, p.asm_sub, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Kfu, bpart); break;
   }
 }
 
@@ -605,7 +612,7 @@ static FwdWs carve_fwd(void* ws, const StreamPlan& p, bool need_kfu, int64_t qro
   int nslab = p.nsplit + HEAD_SPLITS_MAX;  // + the head block's splits
   if (qrows > 0 && i8_nsplit(qrows, p.Mp) > nslab) nslab = i8_nsplit(qrows, p.Mp);  // the int8 contraction's own split count
   w.slab = c.take<double>((size_t)nslab * p.ntiles * TILE * TILE);
-  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
+  w.bpart = c.take<double>((size_t)bpart_rows(p) * p.Mp);
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
   w.Kfu = need_kfu ? c.take<double>((size_t)(p.sc_rows > 0 ? p.sc_rows : 1) * p.Mp) : nullptr;
@@ -789,7 +796,7 @@ static ExtWs carve_ext(void* ws, const StreamPlan& p, int64_t qrows) {
   w.Zs = c.take<double>((size_t)p.Mp * p.DP);
   w.slab = c.take<double>(ns);
   w.slab_lo = c.take<double>(ns);
-  w.bpart = c.take<double>((size_t)(p.Npad / ASM_ROWS > 0 ? p.Npad / ASM_ROWS : 1) * p.Mp);
+  w.bpart = c.take<double>((size_t)bpart_rows(p) * p.Mp);
   w.btmp = c.take<double>((size_t)BRED_G * p.Mp);
   w.yypart = c.take<double>(256);
   w.Ph = c.take<double>(mm); w.Pl = c.take<double>(mm);
@@ -983,7 +990,8 @@ extern "C" int sgp_suffstats_fwd(const double* X, int64_t ldx, const double* y, 
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, nslabs, p.ntiles, M, sf2 * sf2, Phi);
-  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS, p.Mp, BRED_G, w.btmp);
+  // (the fp64 assembly leaves asm_sub partials per row block, the integer path's assembly one)
+  bpart_stage1_kernel<<<dim3(p.Mp / 64, BRED_G), 256, 0, st>>>(w.bpart, p.Npad / ASM_ROWS * (use_i8 ? 1 : p.asm_sub), p.Mp, BRED_G, w.btmp);
   finalize_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.btmp, BRED_G, p.Mp, M, w.yypart, 256, sf2,
                                                          sf2 * (double)N, b, yy, kappa);
   return check_launch();

@@ -380,8 +380,7 @@ static void svgp_forward(const SvgpWs& w, const double* Xb, int64_t ldx, int64_t
   zero_ints(info, 1, st);
   sgp_kuu(Z, ldz, inv_ls, sf2, jitter, M, d, kernel_id, w.Kuu, st);
   pad_copy(w.Kuu, M, M, M, w.Kp, Mp, Mp, Mp, 1.0, st);
-  potrf_lower(w.Kp, w.Linv, Mp, Mp, info, 0, w.flags, st);
-  tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st);
+  if (!potrf_lower(w.Kp, w.Linv, Mp, Mp, info, 0, w.flags, st)) tri_inverse(w.Kp, w.Linv, w.tmp, Mp, Mp, st);
   pad_copy(LS, M, M, M, w.LSp, Mp, Mp, Mp, 1.0, st);
   svgp_tril_kernel<<<grid_for_s((int64_t)Mp * Mp), 256, 0, st>>>(w.LSp, Mp, 1.0, 0);
   pad_copy(m, 1, M, 1, w.mp, 1, Mp, 1, 0.0, st);

@@ -741,10 +741,43 @@ __global__ __launch_bounds__(256) void kuu_factor_prep_kernel(const double* __re
   for (int64_t e = e0; e < nflags; e += stride) flags[e] = 0;
   if (e0 == 0) *info = 0;
 }
+// What follows the factorization, in ONE single-workgroup launch (round 5; it was potrf_timeout + cond_gate + tri_rowsq's consumer
+// ordered_sum + a 4-byte copy of the status word: five launches on the K_uu chain, ~30 us of C3's critical path with their gaps):
+//   the dataflow launch gave up           -> info = SGP_INFO_TIMEOUT
+//   the condition estimate is over limit  -> info = row + 1 (while info is still 0; limit <= 0: no gate)
+//   trace_out (optional)                  -> [tr(K_uu^-1) | the M row sums of squares of L^-1]: the same bits sgp_kuu_inverse_trace produces
+//                                            (tri_rowsq_body's rows, ordered_sum_kernel's fixed thread <-> row mapping and tree)
+__global__ __launch_bounds__(256) void kuu_post_kernel(const double* __restrict__ scratch, int M, double limit, const int* __restrict__ abort_flag,
+                                                       int* __restrict__ info, double* __restrict__ trace_out) {
+  __shared__ double red[12];
+  __shared__ int redi[4];
+  const int nb = (M + 63) / 64;
+  const double* rown = scratch + (int64_t)2 * nb * nb * 64;
+  const bool aborted = *abort_flag != 0;
+  if (limit > 0.0 && !aborted) {
+    double lam, inv_min;
+    int at;
+    cond_estimate_block(scratch, M, red, redi, lam, inv_min, at);
+    if (threadIdx.x == 0 && *info == 0 && !(lam * inv_min <= limit)) *info = at + 1;  // (NaN trips as well)
+    __syncthreads();
+  }
+  if (aborted && threadIdx.x == 0) *info = SGP_INFO_TIMEOUT;
+  if (trace_out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) {
+      const double v = rown[i];
+      trace_out[1 + i] = v;
+      s += v;
+    }
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) trace_out[0] = s;
+  }
+}
 // L^-1 of chol(Kuu), padded: the part of the tail that does not depend on the streamed statistics, so a
-// caller can run it on a second stream underneath pass 1.
-extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
-                              sgp_stream_t stream) {
+// caller can run it on a second stream underneath pass 1.  Five launches: prep, the factorization (which forms the whole inverse:
+// sgp_potrf_chain.hpp), the column / row partials, and kuu_post_kernel (M <= 64 or a CU budget of 1: + tri_inverse's).
+static int kuu_factor_impl(const double* Kuu, int M, double* Linv_out, int* info, double* trace_out, void* ws, size_t ws_bytes,
+                           sgp_stream_t stream) {
   if (!Kuu || !Linv_out || !info || M <= 0) return SGP_ERR_ARG;
   if (M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   if (!ws || ws_bytes < sgp_kuu_factor_workspace_bytes(M)) return SGP_ERR_WORKSPACE;
@@ -756,13 +789,20 @@ extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* i
   int* flags = c.take<int>(potrf_scratch_ints(Mp));
   // one launch instead of four: L <- K_uu identity-padded, L^-1's buffer <- 0, the factorization's flags <- 0, status word <- 0
   kuu_factor_prep_kernel<<<grid_for((int64_t)Mp * Mp), 256, 0, st>>>(Kuu, M, Mp, L, Linv_out, flags, (int)potrf_flag_ints(Mp), info);
-  potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st, nullptr, nullptr, false, /*prepped=*/3);
-  tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
-  if (cond_gate_limit() > 0.0) {  // `tmp` is free again: the partials of L's columns and of L^-1's rows live at its start
-    cond_stats(L, Linv_out, Mp, 0, M, 1, tmp, st);
-    cond_gate(tmp, M, 1, cond_gate_limit(), info, st);
-  }
+  if (!potrf_lower(L, Linv_out, Mp, Mp, info, 0, flags, st, nullptr, nullptr, /*caller_managed=*/true, /*prepped=*/3))
+    tri_inverse(L, Linv_out, tmp, Mp, Mp, st);
+  const double limit = cond_gate_limit();
+  // `tmp` is free again: the partials of L's columns and of L^-1's rows live at its start
+  if (limit > 0.0 || trace_out) cond_stats(L, Linv_out, Mp, 0, M, 1, tmp, st);
+  kuu_post_kernel<<<1, 256, 0, st>>>(tmp, M, limit, potrf_abort_flag(flags, Mp), info, trace_out);
   return check_launch();
+}
+extern "C" int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  return kuu_factor_impl(Kuu, M, Linv_out, info, nullptr, ws, ws_bytes, stream);
+}
+extern "C" int sgp_kuu_factor_ex(const double* Kuu, int M, double* Linv_out, int* info, double* trace_out, void* ws, size_t ws_bytes,
+                                 sgp_stream_t stream) {
+  return kuu_factor_impl(Kuu, M, Linv_out, info, trace_out, ws, ws_bytes, stream);
 }
 // ---- guard of the streaming evaluation order -----------------------------------------------------------------------------------
 // Phi = K_uf K_fu carries a rounding of ~2^-53 max_i Phi_ii per entry however it was summed (fp64 or integer cores: the result is a
@@ -880,8 +920,7 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     w.M1 = const_cast<double*>(kuu_linv);
   } else {
     pad_copy(Kuu, M, M, M, w.M0, ld, Mp, Mp, 1.0, st);
-    potrf_lower(w.M0, w.M1, ld, Mp, info, 0, w.flags, st);
-    tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
+    if (!potrf_lower(w.M0, w.M1, ld, Mp, info, 0, w.flags, st)) tri_inverse(w.M0, w.M1, w.M2, ld, Mp, st);
   }
 
   // W = L^-1 Phi L^-T in M5 (V in M4); Phi is used in place when it needs no padding
@@ -909,11 +948,11 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
 
   // B = I + W/s2 in M6 -> LB ; q = LB^-1 u rides along with the factorization; LB^-1 (M7) only when G is wanted
   make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW, need_G ? w.M7 : nullptr);
-  potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flagsB, st, w.u, w.q, /*caller_managed=*/true, /*prepped=*/2);
+  const bool lb_inverted = potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flagsB, st, w.u, w.q, /*caller_managed=*/true, /*prepped=*/2);
   const int* abort_flag = potrf_abort_flag(w.flagsB, Mp);
   if (need_G) {
     post_potrf_kernel<<<1, 256, 0, st>>>(w.M6, w.q, Mp, abort_flag, info, w.sc);
-    tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
+    if (!lb_inverted) tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
   }
 
   if (factors) {

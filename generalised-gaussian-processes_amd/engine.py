@@ -93,8 +93,9 @@ class HipEngine:
             self._ws[name] = buf
         return buf
 
-    def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+    def _stream(self, stream=None):
+        """The HIP stream handle of `stream` (a torch.cuda.Stream), default torch's current one on this device."""
+        return C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
 
     def _chk(self, t: torch.Tensor, name: str) -> torch.Tensor:
         if t.dtype != torch.float64 or t.device != self.device or not t.is_contiguous():
@@ -253,12 +254,14 @@ class HipEngine:
         _lib.check("sgp_stats_unpack_lower", self.lib.sgp_stats_unpack_lower(self._ptr(tri), M, self._ptr(stats), self._stream()))
         return stats
 
-    def kuu(self, Z, ls, sf2, jitter, kernel="rbf", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def kuu(self, Z, ls, sf2, jitter, kernel="rbf", out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+        """K_uu + jitter I.  ``stream``: enqueue there instead of on torch's current stream (the caller orders it against the producers /
+        consumers of Z and ``out`` itself)."""
         M, d = Z.shape
         self._chk(Z, "Z")
         K = out if out is not None else self.empty(M, M)
         st = self.lib.sgp_kuu(self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), float(jitter), M, d, _kernel_id(kernel),
-                              self._ptr(K), self._stream())
+                              self._ptr(K), self._stream(stream))
         _lib.check("sgp_kuu", st)
         return K
 
@@ -277,15 +280,20 @@ class HipEngine:
         """(out, info) from a host copy of a ``result_buffer``."""
         return host_buf[:OUT_LEN], int(host_buf[OUT_LEN:OUT_LEN + 1].view(torch.int32)[0])
 
-    def kuu_factor(self, Kuu, info: Optional[torch.Tensor] = None):
-        """Padded L^-1 of chol(Kuu) and its info flag; independent of the streamed statistics (side-stream work)."""
+    def kuu_factor(self, Kuu, info: Optional[torch.Tensor] = None, trace_out: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, stream=None):
+        """Padded L^-1 of chol(Kuu) and its info flag; independent of the streamed statistics (side-stream work).
+        ``trace_out`` (``sgp_kuu_inverse_trace_len()`` doubles): also tr(K_uu^-1) in trace_out[0], from the call's own last launch
+        (include/sgp.h: sgp_kuu_factor_ex; the same bits as ``kuu_inverse_trace``).  ``out`` (``sgp_kuu_factor_len(M)`` doubles) /
+        ``stream``: a buffer and a stream of the caller's, as for ``kuu``."""
         M = Kuu.shape[0]
-        Linv = self.empty(self.lib.sgp_kuu_factor_len(M))
+        Linv = out if out is not None else self.empty(self.lib.sgp_kuu_factor_len(M))
         if info is None:
             info = torch.empty(1, dtype=torch.int32, device=self.device)  # cleared by the call itself
         ws = self._workspace("kuu_factor", self.lib.sgp_kuu_factor_workspace_bytes(M))
-        st = self.lib.sgp_ctx_kuu_factor(self._c(), self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
-        _lib.check("sgp_kuu_factor", st)
+        st = self.lib.sgp_ctx_kuu_factor_ex(self._c(), self._ptr(Kuu), M, self._ptr(Linv), self._ptr(info), self._ptr(trace_out), self._ptr(ws),
+                                            ws.numel(), self._stream(stream))
+        _lib.check("sgp_kuu_factor_ex", st)
         return Linv, info
 
     def kuu_inverse_trace(self, Linv, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -326,55 +334,6 @@ class HipEngine:
     @staticmethod
     def read_bound(host_buf) -> float:
         return float(host_buf[OUT_LEN + 2])
-
-    def kuu_factor_graph(self, M: int):
-        """The ~50 launches of ``kuu_factor`` captured once per M in a hipGraph over static buffers: replaying it costs
-        the host one launch instead of ~1 ms of enqueueing, so the factorization really runs underneath the start of
-        pass 1.  Returns dict(graph, Kuu, Linv, info) or None when capture is unavailable (callers fall back)."""
-        if not 0 < M <= _lib.SGP_MAX_INDUCING:
-            raise ValueError("M = %d inducing points is outside 1 .. %d" % (M, _lib.SGP_MAX_INDUCING))
-        ent = self._graphs.get(M, False) if hasattr(self, "_graphs") else False
-        # the conditioning gate's limit is a launch argument baked into the captured chain: an option changed since (this engine's
-        # context, or the deprecated process-wide setter on the default one) means a new capture
-        limit = self.lib.sgp_ctx_get_option(self._c(), self.OPTIONS["cond_limit"])
-        if ent and ent.get("cond_limit") != limit:
-            ent = False
-        if ent is not False:
-            return ent
-        if not hasattr(self, "_graphs"):
-            self._graphs = {}
-        try:
-            Kst = torch.eye(M, dtype=torch.float64, device=self.device)
-            Linv = self.empty(self.lib.sgp_kuu_factor_len(M))
-            info = torch.zeros(1, dtype=torch.int32, device=self.device)
-            ws = torch.empty(self.lib.sgp_kuu_factor_workspace_bytes(M), dtype=torch.uint8, device=self.device)
-
-            def run():
-                st = self.lib.sgp_ctx_kuu_factor(self._c(), self._ptr(Kst), M, self._ptr(Linv), self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
-                _lib.check("sgp_kuu_factor", st)
-
-            warm = torch.cuda.Stream(device=self.device)
-            warm.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(warm):
-                run()
-            torch.cuda.current_stream(self.device).wait_stream(warm)
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            # thread_local: another host thread's runtime calls (a collective library's watchdog, the side-chain helper of
-            # another bound) must neither fail nor invalidate this capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                run()
-            ent = {"graph": g, "Kuu": Kst, "Linv": Linv, "info": info, "ws": ws, "cond_limit": limit}
-        except RuntimeError as exc:  # stream capture unavailable / refused: plain launches still work
-            import warnings
-            warnings.warn("hipGraph capture of the Kuu chain failed (%s); falling back to plain launches" % (exc,))
-            try:  # leave no half-open capture behind
-                torch.cuda.synchronize(self.device)
-            except RuntimeError:
-                pass
-            ent = None
-        self._graphs[M] = ent
-        return ent
 
     def bound(self, Kuu, packed, s2, N, with_adjoints=False, want_factors=False, kuu_linv=None, kuu_info=None, result=None,
               whitened=False, want_cw=False):

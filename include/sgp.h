@@ -144,6 +144,8 @@ int sgp_ctx_suffstats_bwd(sgp_ctx* ctx, const double* X, int64_t ldx, const doub
                           void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_ctx_kuu_factor(sgp_ctx* ctx, const double* Kuu, int M, double* Linv_out, int* info, void* ws, size_t ws_bytes,
                        sgp_stream_t stream);
+int sgp_ctx_kuu_factor_ex(sgp_ctx* ctx, const double* Kuu, int M, double* Linv_out, int* info, double* trace_out, void* ws,
+                          size_t ws_bytes, sgp_stream_t stream);
 int sgp_ctx_bound_from_stats(sgp_ctx* ctx, const double* Kuu, const double* Phi, const double* b, const double* yy,
                              const double* kappa, double s2, int64_t N, int M, int with_adjoints, double* out, double* Phibar,
                              double* bbar, double* Kuubar, double* factors, const double* kuu_linv, int* info, void* ws,
@@ -334,6 +336,11 @@ size_t sgp_kuu_factor_len(int M);
 size_t sgp_kuu_factor_workspace_bytes(int M);
 int sgp_kuu_factor(const double* Kuu, int M, double* Linv_out, int* info,
                    void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* The same call with tr(K_uu^-1) delivered by its last launch: trace_out (sgp_kuu_inverse_trace_len() doubles, NULL = not wanted) receives
+ * exactly what sgp_kuu_inverse_trace(Linv_out, M, trace_out) would write (same bits), two launches and their gaps earlier -- the K_uu chain
+ * is on the critical path of small shards.  Five launches in all: L^-1 is formed inside the factorization's launch.   */
+int sgp_kuu_factor_ex(const double* Kuu, int M, double* Linv_out, int* info, double* trace_out,
+                      void* ws, size_t ws_bytes, sgp_stream_t stream);
 int sgp_bound_from_stats(const double* Kuu, const double* Phi, const double* b,
                          const double* yy, const double* kappa, double s2, int64_t N, int M,
                          int with_adjoints, double* out,

@@ -65,8 +65,8 @@ class OracleEngine:
     def kuu(self, Z, ls, sf2, jitter, kernel="rbf"):
         return O.kuu(Z, self._ls(ls, Z.shape[1]), float(sf2), float(jitter), KID[kernel])
 
-    def kuu_factor(self, Kuu, info=None):
-        """(L^-1, info); like the HIP engine the status word is written, never raised."""
+    def kuu_factor(self, Kuu, info=None, trace_out=None):
+        """(L^-1, info); like the HIP engine the status word is written, never raised.  trace_out[0] <- tr(K_uu^-1) (sgp_kuu_factor_ex)."""
         M = Kuu.shape[0]
         if info is None:
             info = torch.zeros(1, dtype=torch.int32)
@@ -75,8 +75,13 @@ class OracleEngine:
             L = torch.linalg.cholesky(Kuu)
         except Exception:
             info[0] = 1
+            if trace_out is not None:
+                trace_out[0] = float(M)
             return torch.eye(M, dtype=torch.float64), info
-        return torch.linalg.solve_triangular(L, torch.eye(M, dtype=torch.float64), upper=False), info
+        Li = torch.linalg.solve_triangular(L, torch.eye(M, dtype=torch.float64), upper=False)
+        if trace_out is not None:
+            trace_out[0] = float((Li ** 2).sum())
+        return Li, info
 
     def suffstats_whitened(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None):
         self.calls["suffstats_whitened"] += 1

@@ -20,8 +20,6 @@ def main():
     X, y, Z = bench.synth(rows, bench.M_IND, bench.DIM)
     cb = ggp_amd.CollapsedBound(X.to(eng.device), y.to(eng.device), jitter=bench.JITTER, engine=eng)
     Zd = Z.to(eng.device)
-    if os.environ.get("SHARD_NO_GRAPH") == "1":  # the enqueue path of a multi-rank job (no hipGraph replay of the K_uu chain)
-        cb.use_graph = False
     fn = (lambda: cb.value_and_grad(Zd, [bench.LS] * bench.DIM, bench.SF ** 2, bench.SN ** 2, want_gz=False)) if grad else \
          (lambda: cb.value(Zd, [bench.LS] * bench.DIM, bench.SF ** 2, bench.SN ** 2))
     for _ in range(5):
