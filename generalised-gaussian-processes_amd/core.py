@@ -452,7 +452,8 @@ class CollapsedBound:
             side, (z_ready, ready), (Kuu, linv) = self._side_state(M)
             z_ready.record(main)  # Z is materialised on the main stream
             side.wait_event(z_ready)
-            result[0].record_stream(side)
+            # (the side stream's accesses to the result buffer and to Kuubar end before events the main stream waits for ahead of its
+            # own last use: no record_stream -- the allocator's per-block event bookkeeping costs the host ~25 us per evaluation)
             e.kuu(Z, ls, sf2, self.jitter, self.kernel, out=Kuu, stream=side)
             e.kuu_factor(Kuu, info=result[2], trace_out=trace, out=linv, stream=side)  # the evaluation's status word starts as the Kuu status
             ready.record(side)
@@ -497,6 +498,8 @@ class CollapsedBound:
             e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
                             self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
         self._allreduce(g)
+        # (measured and dropped, round 5: this launch pair on the side stream beside pass 2 -- it needs Kuubar only -- ends the evaluation no
+        # earlier: pass 2 fills the chip and runs the 28 us longer that the side stream takes from it, profiles/r05_kuu_bwd_side_stream_c3_timeline.txt)
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
 
     def _evaluate(self, Z, ls, sf2, s2, with_grad=False, want_gz=False, want_factors=False, grad_reach=None, strict=False):

@@ -10,6 +10,7 @@
 //            off-diagonal tiles = MFMA rank-64 updates + a 16-column-panel triangular solve); optional L^-1 rhs row
 //   trtri  : recursive doubling on the inverted diagonal blocks, Inv21 = -Inv22 (L21 Inv11), batched GEMMs
 // Triangular structure is exploited by clipping each output tile's k-range (GemmDesc::klo/khi masks).
+#include <type_traits>
 #include "sgp_dense.hpp"
 #include "sgp_ctx.hpp"
 #include "sgp_potrf.hpp"
@@ -121,27 +122,56 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
     for (int v = 0; v < NT; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
   if (klo < khi) {
-    // chunk j of this group starts at klo + (2 j + grp) GK; both groups run the same number of barriers
-    const int nchunk = (khi - klo + GK - 1) / GK, niter = (nchunk + 1) / 2;
-    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+    // This group's k-chunks are klo + (2 q + grp) GK, q = 0, 1, ... (the groups alternate: both run the same number of barriers).
+    // A step takes NS of them: one at T = 64; TWO at T = 32 (round 5), whose 32-column operand image leaves the other half of the
+    // 64-column LDS rows free -- half as many barriers for the latency-bound M <= 512 products (13 - 17 us each at 512^3, a fifth of
+    // it MFMA time: profiles/r05_v3pre_c3_timeline.txt).  Four register sets keep four steps of global loads in flight (two before).
+    // The chunks of a group are still accumulated in increasing order: the same bits as before, and as the other tiling.
+    constexpr int NS = T == 32 ? 2 : 1;
+    const int nchunk = (khi - klo + GK - 1) / GK, niter = ((nchunk + 1) / 2 + NS - 1) / NS;
+    d2 ra0[2], rb0[2], ra1[2], rb1[2], ra2[2], rb2[2], ra3[2], rb3[2];
+    auto chunk_of = [&](int j, int sub) { return 2 * (NS * j + sub) + grp; };
     auto fetch = [&](int j, d2 (&ra)[2], d2 (&rb)[2]) {
-      const int c = 2 * j + grp;
-      if (c < nchunk) {
-        tile_fetch<!TA, T>(A, p.lda, r0, klo + c * GK, tid, ra);
-        tile_fetch<TB, T>(B, p.ldb, c0, klo + c * GK, tid, rb);
+      if constexpr (NS == 1) {
+        const int c = chunk_of(j, 0);
+        if (c < nchunk) {
+          tile_fetch<!TA, T>(A, p.lda, r0, klo + c * GK, tid, ra);
+          tile_fetch<TB, T>(B, p.ldb, c0, klo + c * GK, tid, rb);
+        }
+      } else {
+        // K-contiguous operand: thread = (row, k-quad) over 64 "rows" -- rows 32 .. 63 are rows 0 .. 31 of the step's second chunk;
+        // MN-contiguous operand: thread = (k, column pair), its second 16 bytes are the second chunk's.  Either way the registers and
+        // the LDS image (column + 32) are those of a 64-wide tile: tile_stash<.., 64> stores both chunks.
+        const int c0k = chunk_of(j, 0), c1k = chunk_of(j, 1);
+        auto one = [&](auto kc, const double* P, int64_t ld, int base, d2 (&v)[2]) {
+          if constexpr (decltype(kc)::value) {
+            const int row = tid >> 2, kq = (tid & 3) * 4, c = row < 32 ? c0k : c1k;
+            if (c < nchunk) {
+              const double* sp = P + (int64_t)(base + (row & 31)) * ld + klo + c * GK + kq;
+              v[0] = *reinterpret_cast<const d2*>(sp);
+              v[1] = *reinterpret_cast<const d2*>(sp + 2);
+            }
+          } else {
+            const int kk = tid >> 4, c2 = (tid & 15) * 2;
+            if (c0k < nchunk) v[0] = *reinterpret_cast<const d2*>(P + (int64_t)(klo + c0k * GK + kk) * ld + base + c2);
+            if (c1k < nchunk) v[1] = *reinterpret_cast<const d2*>(P + (int64_t)(klo + c1k * GK + kk) * ld + base + c2);
+          }
+        };
+        one(std::integral_constant<bool, !TA>{}, A, p.lda, r0, ra);
+        one(std::integral_constant<bool, TB>{}, B, p.ldb, c0, rb);
       }
     };
     auto stash = [&](int j, int stage, const d2 (&ra)[2], const d2 (&rb)[2]) {
-      if (2 * j + grp < nchunk) {
-        tile_stash<!TA, T>(sh.As[grp][stage], tid, ra);
-        tile_stash<TB, T>(sh.Bs[grp][stage], tid, rb);
+      if (chunk_of(j, 0) < nchunk) {  // (a missing second chunk leaves stale columns behind that nobody reads)
+        tile_stash<!TA, NS == 2 ? 64 : T>(sh.As[grp][stage], tid, ra);
+        tile_stash<TB, NS == 2 ? 64 : T>(sh.Bs[grp][stage], tid, rb);
       }
     };
-    // r holds chunk j + 1 on entry and chunk j + 3 on exit
+    // r holds step j + 1 on entry and step j + 5 on exit
     auto body = [&](int j, int stage, d2 (&ra)[2], d2 (&rb)[2]) {
-      const bool live = 2 * j + grp < nchunk;
-      double a0[GK / 4], a1[GK / 4], b0[GK / 4], b1[GK / 4];
-      if (live) {  // operands of the whole chunk first: the MFMAs start as soon as the barrier falls
+      const bool live = chunk_of(j, 0) < nchunk, live2 = NS == 2 && chunk_of(j, 1) < nchunk;
+      double a0[NS * GK / 4], a1[GK / 4], b0[NS * GK / 4], b1[GK / 4];
+      if (live) {  // operands of the whole step first: the MFMAs start as soon as the barrier falls
         const double (*As)[GT] = sh.As[grp][stage];
         const double (*Bs)[GT] = sh.Bs[grp][stage];
 #pragma unroll
@@ -152,6 +182,10 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
           if constexpr (NT == 2) {
             a1[ks] = As[kr][(ca + 16 + 4 * ks) & 63];
             b1[ks] = Bs[kr][(cb + 16 + 4 * ks) & 63];
+          }
+          if constexpr (NS == 2) {
+            a0[GK / 4 + ks] = As[kr][(ca + 32 + 4 * ks) & 63];
+            b0[GK / 4 + ks] = Bs[kr][(cb + 32 + 4 * ks) & 63];
           }
         }
       }
@@ -164,23 +198,35 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
         }
       };
       if (live) mac(0);
-      stash(j + 1, stage ^ 1, ra, rb);  // LDS stores and global loads of later chunks issue under the MFMAs
+      stash(j + 1, stage ^ 1, ra, rb);  // LDS stores and global loads of later steps issue under the MFMAs
       if (live) mac(1);
-      fetch(j + 3, ra, rb);
+      fetch(j + 5, ra, rb);
       if (live) {
         mac(2);
         mac(3);
+      }
+      if constexpr (NS == 2) {
+        if (live2) {
+          mac(4);
+          mac(5);
+          mac(6);
+          mac(7);
+        }
       }
       __syncthreads();
     };
     fetch(0, ra0, rb0);
     fetch(1, ra1, rb1);
+    fetch(2, ra2, rb2);
+    fetch(3, ra3, rb3);
     stash(0, 0, ra0, rb0);
-    fetch(2, ra0, rb0);
+    fetch(4, ra0, rb0);
     __syncthreads();
-    for (int j = 0; j < niter; j += 2) {
+    for (int j = 0; j < niter; j += 4) {  // step c lives in register set c mod 4, LDS stage c mod 2
       body(j, 0, ra1, rb1);
-      if (j + 1 < niter) body(j + 1, 1, ra0, rb0);
+      if (j + 1 < niter) body(j + 1, 1, ra2, rb2);
+      if (j + 2 < niter) body(j + 2, 0, ra3, rb3);
+      if (j + 3 < niter) body(j + 3, 1, ra0, rb0);
     }
     // group 1's partial tile -> LDS -> added by group 0
     double* red = &sh.As[0][0][0][0];
@@ -213,7 +259,9 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemmP p) {
         const int col = c0 + wj * (T / 2) + v * 16 + l15;
         double* dst = C + (int64_t)row * p.ldc + col;
         const double val = p.alpha * acc[u][v][r];
-        *dst = (p.beta == 0.0) ? val : fma(p.beta, *dst, val);
+        const double res = (p.beta == 0.0) ? val : fma(p.beta, *dst, val);
+        *dst = res;
+        if (p.lower_only == 2 && bi != bj) C[(int64_t)col * p.ldc + row] = res;  // the mirrored tile of a symmetric product
       }
 }
 
@@ -420,7 +468,7 @@ static int gemm_small_tile_threshold() {
 void gemm(const GemmDesc& g, hipStream_t st) {
   if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return;
   GemmP p{g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.sA, g.sB, g.sC, g.m, g.n, g.k,
-          g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? 1 : 0, g.batch, g.s2A, g.s2B, g.s2C};
+          g.alpha, g.beta, g.klo_mask, g.khi_mask, g.lower_only ? (g.mirror ? 2 : 1) : 0, g.batch, g.s2A, g.s2B, g.s2C};
   if (g.batch2 <= 0) return;
   if (gemm_tall(g, st)) return;
   // fewer 64 x 64 tiles than half the CUs: four times as many 32 x 32 tiles instead (bit-identical results)

@@ -25,6 +25,7 @@ struct GemmDesc {
   bool ta = false, tb = false;
   int klo_mask = 0, khi_mask = 0;
   bool lower_only = false;
+  bool mirror = false;      // with lower_only: every tile below the diagonal is also stored transposed (a symmetric product computed once)
 };
 void gemm(const GemmDesc& g, hipStream_t st);
 // Condition estimate of a factored matrix (sgp_tail.hip): cond_stats fills `scratch` (cond_scratch_doubles(M) doubles per matrix) from

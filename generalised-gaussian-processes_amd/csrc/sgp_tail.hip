@@ -935,10 +935,13 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     GemmDesc g;
     g.A = w.M1; g.lda = ld; g.B = w.M3; g.ldb = ld; g.C = w.M4; g.ldc = ld;
     g.m = Mp; g.n = Mp; g.k = Mp; g.khi_mask = 1;
+    g.lower_only = true;  // W's lower tiles (below) read V's lower tiles only
     gemm(g, st);
     GemmDesc h;
     h.A = w.M4; h.lda = ld; h.B = w.M1; h.ldb = ld; h.tb = true; h.C = w.M5; h.ldc = ld;
     h.m = Mp; h.n = Mp; h.k = Mp; h.khi_mask = 2;
+    h.lower_only = true;  // W is symmetric: the tiles above the diagonal (the long k ranges of this mask) are the mirrored lower ones
+    h.mirror = true;
     gemm(h, st);
   }
 

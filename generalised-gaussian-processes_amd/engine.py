@@ -107,18 +107,26 @@ class HipEngine:
         """Entries of the hyper-parameter gradient: d lengthscales, or the composite kernel's parameter block."""
         return COMP_LEN if _kernel_id(kernel) == KERNEL_IDS["composite"] else d
 
-    @staticmethod
-    def _inv_ls(ls: Sequence[float], d: int, kernel="rbf"):
+    def _inv_ls(self, ls: Sequence[float], d: int, kernel="rbf"):
+        """1 / lengthscale as the C array the entry points take.  An evaluation passes the same list to four or five calls: the last
+        array is kept (the library copies it during the call)."""
+        c = self.__dict__.get("_ils")
+        if c is not None and type(ls) is list and c[1] == d and c[2] == kernel and c[0] == ls:
+            return c[3]
         vals = [float(v) for v in (ls.tolist() if hasattr(ls, "tolist") else ls)]
         if _kernel_id(kernel) == KERNEL_IDS["composite"]:  # the parameter block travels in place of 1 / lengthscale
             if len(vals) != COMP_LEN:
                 raise ValueError("a composite kernel takes a %d-entry parameter block (got %d)" % (COMP_LEN, len(vals)))
-            return (C.c_double * COMP_LEN)(*vals)
-        if len(vals) == 1 and d > 1:
-            vals = vals * d
-        if len(vals) != d:
-            raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), d))
-        return (C.c_double * d)(*[1.0 / v for v in vals])
+            arr = (C.c_double * COMP_LEN)(*vals)
+        else:
+            if len(vals) == 1 and d > 1:
+                vals = vals * d
+            if len(vals) != d:
+                raise ValueError("lengthscale has %d entries, expected %d" % (len(vals), d))
+            arr = (C.c_double * d)(*[1.0 / v for v in vals])
+        if type(ls) is list:
+            self._ils = (list(ls), d, kernel, arr)
+        return arr
 
     @staticmethod
     def _ptr(t: Optional[torch.Tensor]):
