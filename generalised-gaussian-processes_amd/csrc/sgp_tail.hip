@@ -102,6 +102,61 @@ __global__ __launch_bounds__(256) void kuu_bwd_kernel(const double* __restrict__
     else part[(size_t)m * (d + 1) + d] = v;
   }
 }
+// The same sums when dF/dZ is not wanted (every leapfrog of a sampler): only the totals over (m, m') are needed, so the 2 d + 1 wave
+// reductions PER ROW of the kernel above (most of its 28 us at C3) become d + 1 per workgroup: workgroup <-> rows blockIdx, blockIdx +
+// grid, ..., thread <-> columns, one pass, every sum carried in registers.  part[workgroup][0 .. d] in the layout of part[m][.] above:
+// kuu_bwd_reduce_kernel adds the workgroups' rows instead of the matrix rows.  Fixed assignment, fixed order: the same bits on every
+// rank and every call (not the bits of the per-row kernel: the terms are grouped differently).
+template <int KID>
+__global__ __launch_bounds__(256) void kuu_bwd_total_kernel(const double* __restrict__ Z, int64_t ldz, KernArgs ka,
+                                                            const double* __restrict__ Kb, int M, double* __restrict__ part) {
+  __shared__ double red[4][SGP_MAX_DIM + 1];
+  const int d = ka.d;
+  double s2[SGP_MAX_DIM];
+#pragma unroll
+  for (int q = 0; q < SGP_MAX_DIM; ++q) s2[q] = 0.0;
+  double sk = 0.0;
+  for (int m = blockIdx.x; m < M; m += gridDim.x) {
+    double zm[SGP_MAX_DIM];
+#pragma unroll
+    for (int q = 0; q < SGP_MAX_DIM; ++q) zm[q] = q < d ? Z[m * ldz + q] : 0.0;
+    for (int mp = threadIdx.x; mp < M; mp += 256) {
+      double df[SGP_MAX_DIM];
+      double r2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < SGP_MAX_DIM; ++q) {
+        if (q < d) {
+          df[q] = (zm[q] - Z[mp * ldz + q]) * ka.inv_ls[q];
+          r2 = fma(df[q], df[q], r2);
+        }
+      }
+      double kp, hp;
+      kprofile_grad<KID>(r2, kp, hp);
+      const double kb = Kb[(int64_t)m * M + mp];
+      const double E = kb * ka.sf2 * hp;
+      sk = fma(kb, kp, sk);
+#pragma unroll
+      for (int q = 0; q < SGP_MAX_DIM; ++q) {
+        if (q < d) s2[q] = fma(E * df[q], df[q], s2[q]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  sk = wave_sum(sk);
+  if (lane == 0) red[wave][d] = sk;
+#pragma unroll
+  for (int q = 0; q < SGP_MAX_DIM; ++q) {
+    if (q < d) {
+      const double a = wave_sum(s2[q]);
+      if (lane == 0) red[wave][q] = a;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x <= d) {
+    const int t = threadIdx.x;
+    part[(size_t)blockIdx.x * (d + 1) + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  }
+}
 __global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __restrict__ part, const double* __restrict__ gzraw,
                                                              int M, KernArgs ka, double* g_ls, double* g_sf2, double* g_Z) {
   const int d = ka.d;
@@ -601,6 +656,16 @@ extern "C" int sgp_kuu_bwd(const double* Z, int64_t ldz, const double* inv_ls, d
   double* part = c.take<double>((size_t)M * (d + 1));
   double* gzraw = c.take<double>((size_t)M * d);
   const KernArgs ka = make_ka(inv_ls, sf2, d);
+  if (!g_Z) {  // totals only: a quarter of the launch time (see kuu_bwd_total_kernel)
+    const int G = M < 1024 ? M : 1024;
+    switch (kernel_id) {
+      case SGP_KERNEL_RBF: kuu_bwd_total_kernel<SGP_KERNEL_RBF><<<G, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part); break;
+      case SGP_KERNEL_MATERN32: kuu_bwd_total_kernel<SGP_KERNEL_MATERN32><<<G, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part); break;
+      default: kuu_bwd_total_kernel<SGP_KERNEL_MATERN52><<<G, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part); break;
+    }
+    kuu_bwd_reduce_kernel<<<1, 256, 0, st>>>(part, nullptr, G, ka, g_ls, g_sf2, nullptr);
+    return check_launch();
+  }
   switch (kernel_id) {
     case SGP_KERNEL_RBF: kuu_bwd_kernel<SGP_KERNEL_RBF><<<M, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part, gzraw); break;
     case SGP_KERNEL_MATERN32: kuu_bwd_kernel<SGP_KERNEL_MATERN32><<<M, 256, 0, st>>>(Z, ldz, ka, Kuubar, M, part, gzraw); break;
