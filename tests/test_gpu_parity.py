@@ -599,8 +599,8 @@ def test_tapered_splits_match_equal_splits(engine):
 
 
 def test_repeated_evaluations_all_modes_stay_clean(engine):
-    """Regression: many evaluations over several M, fresh CollapsedBound objects (new side streams / helper threads),
-    graph replay / plain launches / single stream.  The single-launch dataflow Cholesky must never report its
+    """Regression: many evaluations over several M, fresh CollapsedBound objects (new side-stream buffers and events), two streams /
+    single stream (`use_graph` is a no-op since round 5).  The single-launch dataflow Cholesky must never report its
     time-out code and every mode must give the same bits (a stale flag word once showed up as info = -7777)."""
     import ggp_amd
     g = torch.Generator().manual_seed(3)
