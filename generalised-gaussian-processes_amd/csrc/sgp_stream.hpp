@@ -156,9 +156,16 @@ void timing_begin(int slot, hipStream_t st);
 void timing_end(int slot, hipStream_t st);
 
 // implemented in sgp_suffstats_fwd.hip
+// pad (optional): a job pass 2 used to launch separately rides along -- out (Mp x Mp) <- (P + P^T) / 2 zero-padded, vout (Mp) <- vec zero-padded
+struct PadSymJob {
+  const double* P = nullptr;
+  double* out = nullptr;
+  const double* vec = nullptr;
+  double* vout = nullptr;
+};
 void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, int64_t ldx, const double* y,
                      const double* Z, int64_t ldz, int64_t N, int M, double* Xs, double* ys, double* Zs, double* yypart,
-                     hipStream_t st);
+                     hipStream_t st, const PadSymJob& pad = PadSymJob());
 void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0,
                      int64_t rows, int64_t N, int M, double* Kfu, double* bpart, hipStream_t st);
 

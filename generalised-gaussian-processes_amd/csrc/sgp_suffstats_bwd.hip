@@ -42,21 +42,7 @@ __global__ void bwd_pad_vec_kernel(const double* __restrict__ in, int64_t n, int
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = i < n ? in[i] : 0.0;
 }
-// Pb (Mp x Mp) <- symmetrised, zero-padded Phibar (M x M)
-// (vec / vout: optionally the padded copy of a vector in the same launch -- block 0)
-__global__ void bwd_pad_sym_kernel(const double* __restrict__ P, int M, int Mp, double* __restrict__ out,
-                                   const double* __restrict__ vec = nullptr, double* __restrict__ vout = nullptr) {
-  const int64_t total = (int64_t)Mp * Mp;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
-    double v = 0.0;
-    if (r < M && c < M) v = 0.5 * (P[(int64_t)r * M + c] + P[(int64_t)c * M + r]);
-    out[e] = v;
-  }
-  if (vout && blockIdx.x == 0)
-    for (int i = threadIdx.x; i < Mp; i += blockDim.x) vout[i] = i < M ? vec[i] : 0.0;
-}
-
+// (Pb <- symmetrised, zero-padded Phibar and the padded bbar: a job of the prologue launch since round 5, sgp_stream.hpp: PadSymJob)
 // Pb (Mp x Mp) <- scale * P (Mp x Mp in, rows / columns >= M zeroed): no symmetrisation (the factored mode's triangular L^-1)
 __global__ void bwd_pad_plain_kernel(const double* __restrict__ P, int M, int Mp, double scale, double* __restrict__ out) {
   const int64_t total = (int64_t)Mp * Mp;
@@ -521,8 +507,11 @@ extern "C" int sgp_suffstats_bwd(const double* X, int64_t ldx, const double* y, 
   ka.sf2 = sf2;
   ka.d = d;
 
-  stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
-  bwd_pad_sym_kernel<<<2048, 256, 0, st>>>(Phibar, M, p.Mp, w.Pb, bbar, w.bb);
+  {  // one launch: the scaled rows of both passes' prologue and pass 2's padded, symmetrised Phibar / bbar
+    PadSymJob pad;
+    pad.P = Phibar; pad.out = w.Pb; pad.vec = bbar; pad.vout = w.bb;
+    stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st, pad);
+  }
 
   const int want_gz = g_Z != nullptr;
   const int grid = p.nmb * p.nsplit_b;

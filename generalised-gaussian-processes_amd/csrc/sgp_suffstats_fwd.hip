@@ -79,9 +79,22 @@ __global__ __launch_bounds__(256) void stream_prologue_kernel(const double* __re
                                                               const double* __restrict__ Z, int64_t ldz, int M, int Mp, int DP, KernArgs ka,
                                                               double* __restrict__ Xs, double* __restrict__ Zs,
                                                               const double* __restrict__ y, double* __restrict__ ys,
-                                                              double* __restrict__ yypart, int gx, int gz) {
+                                                              double* __restrict__ yypart, int gx, int gz, PadSymJob pad, int gp) {
   __shared__ double red[4];
   const int b = blockIdx.x;
+  if (b >= gx + gz + 256) {  // pass 2's padded, symmetrised Phibar (+ bbar): the same element <-> thread mapping as its own launch had
+    const int pb = b - gx - gz - 256;
+    const int64_t total = (int64_t)Mp * Mp;
+    for (int64_t e = (int64_t)pb * 256 + threadIdx.x; e < total; e += (int64_t)gp * 256) {
+      const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+      double v = 0.0;
+      if (r < M && c < M) v = 0.5 * (pad.P[(int64_t)r * M + c] + pad.P[(int64_t)c * M + r]);
+      pad.out[e] = v;
+    }
+    if (pad.vout && pb == 0)
+      for (int i = threadIdx.x; i < Mp; i += 256) pad.vout[i] = i < M ? pad.vec[i] : 0.0;
+    return;
+  }
   if (b < gx) {
     scale_rows_job(X, ldx, N, Npad, DP, ka, Xs, b, gx);
   } else if (b < gx + gz) {
@@ -525,14 +538,19 @@ void stream_assemble(const StreamPlan& p, int kid, const double* Xs, const doubl
 
 void stream_prologue(const StreamPlan& p, const KernArgs& ka, const double* X, int64_t ldx, const double* y,
                      const double* Z, int64_t ldz, int64_t N, int M, double* Xs, double* ys, double* Zs, double* yypart,
-                     hipStream_t st) {
+                     hipStream_t st, const PadSymJob& pad) {
   int gx = 0;
   if (N > 0) {
     const int64_t tot = p.Npad * p.DP;
     gx = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
   }
   const int gz = (p.Mp * p.DP + 255) / 256;
-  stream_prologue_kernel<<<gx + gz + 256, 256, 0, st>>>(X, ldx, N, p.Npad, Z, ldz, M, p.Mp, p.DP, ka, Xs, Zs, y, ys, yypart, gx, gz);
+  int gp = 0;
+  if (pad.P) {
+    const int64_t blocks = ((int64_t)p.Mp * p.Mp + 255) / 256;
+    gp = (int)(blocks < 2048 ? blocks : 2048);
+  }
+  stream_prologue_kernel<<<gx + gz + 256 + gp, 256, 0, st>>>(X, ldx, N, p.Npad, Z, ldz, M, p.Mp, p.DP, ka, Xs, Zs, y, ys, yypart, gx, gz, pad, gp);
 }
 
 static int syrk_grid(int nsplit, int ntiles) { return 8 * ((nsplit >> 3) * ntiles + (((nsplit & 7) * ntiles + 7) >> 3)); }

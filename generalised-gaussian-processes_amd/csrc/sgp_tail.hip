@@ -190,16 +190,26 @@ __global__ __launch_bounds__(256) void kuu_bwd_reduce_kernel(const double* __res
 enum { SC_TRW = 0, SC_LOGDET = 1, SC_QQ = 2, SC_TRSP = 3, SC_BA = 4, SC_APA = 5, SC_N = 8 };
 
 __global__ __launch_bounds__(256) void make_B_kernel(const double* __restrict__ W, int Mp, double inv_s2, double* __restrict__ Bm,
-                                                     double* __restrict__ trW, double* __restrict__ zero_me) {
+                                                     double* __restrict__ trW, double* __restrict__ zero_me, int nB,
+                                                     const double* __restrict__ Li, const double* __restrict__ x, double* __restrict__ y) {
+  if ((int)blockIdx.x >= nB) {  // y = L^-1 x rides along (gemv_rows_kernel's loop and order: one wave per row, four rows per block)
+    const int row = ((int)blockIdx.x - nB) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= Mp) return;
+    double s = 0.0;
+    for (int j = lane; j < Mp; j += 64) s = fma(Li[(int64_t)row * Mp + j], x[j], s);
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s;
+    return;
+  }
   const int64_t total = (int64_t)Mp * Mp;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)nB * 256) {
     const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
     // symmetrise: the two triangles of L^-1 Phi L^-T differ by rounding only
     const double w = 0.5 * (W[e] + W[(int64_t)c * Mp + r]);
     Bm[e] = (r == c ? 1.0 : 0.0) + w * inv_s2;
     if (zero_me) zero_me[e] = 0.0;  // the buffer L_B^-1 grows in (potrf_lower's own clearing launch, folded in)
   }
-  if (blockIdx.x == gridDim.x - 1) {  // tr W rides along (was a launch of its own)
+  if ((int)blockIdx.x == nB - 1) {  // tr W rides along (was a launch of its own)
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < Mp; i += 256) s += W[(int64_t)i * Mp + i];
@@ -228,16 +238,6 @@ __device__ __forceinline__ void potrf_scalars(const double* __restrict__ LB, con
   logdet = 2.0 * block_sum256(s, red);
   qq = block_sum256(t, red);
   if (threadIdx.x == 0 && *abort_flag != 0) *info = SGP_INFO_TIMEOUT;
-}
-__global__ __launch_bounds__(256) void post_potrf_kernel(const double* __restrict__ LB, const double* __restrict__ q, int Mp,
-                                                         const int* abort_flag, int* info, double* __restrict__ sc) {
-  __shared__ double red[4];
-  double logdet, qq;
-  potrf_scalars(LB, q, Mp, abort_flag, info, red, logdet, qq);
-  if (threadIdx.x == 0) {
-    sc[SC_LOGDET] = logdet;
-    sc[SC_QQ] = qq;
-  }
 }
 __global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict__ A, int Mp, int take_log, double scale, double* out) {
   __shared__ double red[4];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void sum256_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) *out = s;
 }
 
-// LB != null (value-only evaluations): the chol(B) scalars are computed here instead of by post_potrf_kernel.
+// LB != null: log det B, q.q and the time-out word are computed here (LB == null: read from sc[SC_LOGDET] / sc[SC_QQ], a caller that has them).
 __global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __restrict__ sc, const double* __restrict__ yy,
                                                              const double* __restrict__ kappa, double s2, double Nd, int with_adj,
                                                              const double* __restrict__ LB, const double* __restrict__ q, int Mp,
@@ -1010,18 +1010,19 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     gemm(h, st);
   }
 
-  // u = L^-1 b
-  gemv(w.M1, ld, Mp, false, w.bp, w.u, st);
   }
 
   // B = I + W/s2 in M6 -> LB ; q = LB^-1 u rides along with the factorization; LB^-1 (M7) only when G is wanted
-  make_B_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW, need_G ? w.M7 : nullptr);
+  {  // (streaming order: u = L^-1 b in the same launch -- ld = Mp here)
+    const int nB = grid_for((int64_t)mm);
+    make_B_kernel<<<nB + (whitened ? 0 : Mp / 4), 256, 0, st>>>(w.M5, Mp, 1.0 / s2, w.M6, w.sc + SC_TRW, need_G ? w.M7 : nullptr, nB, w.M1,
+                                                                w.bp, w.u);
+  }
   const bool lb_inverted = potrf_lower(w.M6, need_G ? w.M7 : nullptr, ld, Mp, info, M, w.flagsB, st, w.u, w.q, /*caller_managed=*/true, /*prepped=*/2);
   const int* abort_flag = potrf_abort_flag(w.flagsB, Mp);
-  if (need_G) {
-    post_potrf_kernel<<<1, 256, 0, st>>>(w.M6, w.q, Mp, abort_flag, info, w.sc);
-    if (!lb_inverted) tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
-  }
+  // (log det B, q.q and the time-out word are finalize_bound_kernel's, from L_B and q, which nothing below overwrites: the launch that
+  // used to take them here, ahead of tri_inverse(), is gone)
+  if (need_G && !lb_inverted) tri_inverse(w.M6, w.M7, w.M2, ld, Mp, st);
 
   if (factors) {
     // what sgp_predict needs: L^-1, LB^-1 and q.  The product G = LB^-1 L^-1 is deliberately NOT formed: on ill-conditioned
@@ -1055,8 +1056,7 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     gemv(w.M1, ld, Mp, true, w.alpha, w.t1, st);  // L^-T g
     adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(CS, w.t1, Mp, M, s2, Phibar, Kuubar, bbar);
   }
-  finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, need_G ? nullptr : w.M6, w.q, Mp,
-                                           abort_flag, info, out, w.rows3);
+  finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, w.M6, w.q, Mp, abort_flag, info, out, w.rows3);
   return check_launch();
 }
 
