@@ -239,71 +239,39 @@ __device__ __forceinline__ void potrf_scalars(const double* __restrict__ LB, con
   qq = block_sum256(t, red);
   if (threadIdx.x == 0 && *abort_flag != 0) *info = SGP_INFO_TIMEOUT;
 }
-__global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict__ A, int Mp, int take_log, double scale, double* out) {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < Mp; i += 256) {
-    const double v = A[(int64_t)i * Mp + i];
-    s += take_log ? log(v) : v;
-  }
-  s = block_sum256(s, red);
-  if (threadIdx.x == 0) *out = s * scale;
-}
-__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, const double* __restrict__ b, int n, double* out) {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s = fma(a[i], b[i], s);
-  s = block_sum256(s, red);
-  if (threadIdx.x == 0) *out = s;
-}
-// The three scalars of s2bar that need a pass over an M x M matrix, row by row in ONE launch (round 5: five launches before --
-// frob_partial, sum256, dot, gemv, dot): one wave per row i writes
+// The three scalars of s2bar that need a pass over an M x M matrix, row by row (round 5: five launches before -- frob_partial, sum256,
+// dot, gemv, dot; now a job of adjoint_mid_kernel): one wave per row i writes
 //   rows3[i]          = sum_j Binv[i][j] W[i][j]      -> tr(B^-1 W)     rows3[Mp + i] = (W alpha)_i alpha_i -> alpha^T W alpha
 //   rows3[2 Mp + i]   = u_i alpha_i                   -> u . alpha
 // finalize_bound_kernel adds each array up in a fixed order.
-__global__ __launch_bounds__(256) void adjoint_rows_kernel(const double* __restrict__ Binv, const double* __restrict__ W,
-                                                           const double* __restrict__ alpha, const double* __restrict__ u, int Mp,
-                                                           double* __restrict__ rows3) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= Mp) return;
-  double f = 0.0, wa = 0.0;
-  for (int j = lane; j < Mp; j += 64) {
-    const double w = W[(int64_t)row * Mp + j];
-    f = fma(Binv[(int64_t)row * Mp + j], w, f);
-    wa = fma(w, alpha[j], wa);
-  }
-  f = wave_sum(f);
-  wa = wave_sum(wa);
-  if (lane == 0) {
-    const double a = alpha[row];
-    rows3[row] = f;
-    rows3[Mp + row] = wa * a;
-    rows3[2 * Mp + row] = u[row] * a;
-  }
-}
-// partial[block] = sum over a slice of A o B ; fixed grid of 256 blocks, second stage = sum256_kernel
-__global__ __launch_bounds__(256) void frob_partial_kernel(const double* __restrict__ A, const double* __restrict__ B, int64_t n,
-                                                           double* __restrict__ partial) {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fma(A[i], B[i], s);
-  s = block_sum256(s, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-__global__ __launch_bounds__(256) void sum256_kernel(const double* __restrict__ partial, double* out) {
-  __shared__ double red[4];
-  double s = block_sum256(partial[threadIdx.x], red);
-  if (threadIdx.x == 0) *out = s;
-}
 
 // LB != null: log det B, q.q and the time-out word are computed here (LB == null: read from sc[SC_LOGDET] / sc[SC_QQ], a caller that has them).
-__global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __restrict__ sc, const double* __restrict__ yy,
-                                                             const double* __restrict__ kappa, double s2, double Nd, int with_adj,
-                                                             const double* __restrict__ LB, const double* __restrict__ q, int Mp,
-                                                             const int* abort_flag, int* info, double* __restrict__ out,
-                                                             const double* __restrict__ rows3) {
-  __shared__ double red[4];
+struct FinalizeArgs {
+  const double* sc;
+  const double* yy;
+  const double* kappa;
+  double s2, Nd;
+  int with_adj;
+  const double* LB;
+  const double* q;
+  int Mp;
+  const int* abort_flag;
+  int* info;
+  double* out;
+  const double* rows3;
+};
+__device__ __forceinline__ void finalize_bound_body(const FinalizeArgs& a, double* red) {
+  const double* __restrict__ sc = a.sc;
+  const double* __restrict__ yy = a.yy;
+  const double* __restrict__ kappa = a.kappa;
+  const double s2 = a.s2, Nd = a.Nd;
+  const int with_adj = a.with_adj, Mp = a.Mp;
+  const double* __restrict__ LB = a.LB;
+  const double* __restrict__ q = a.q;
+  const int* abort_flag = a.abort_flag;
+  int* info = a.info;
+  double* __restrict__ out = a.out;
+  const double* __restrict__ rows3 = a.rows3;
   double logdetB = 0.0, qq = 0.0;
   double trSP = 0.0, aPa = 0.0, ba = 0.0;
   if (with_adj) {  // the row sums of adjoint_rows_kernel, each added up in one fixed order
@@ -345,6 +313,10 @@ __global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __res
     out[SGP_OUT_KAPPABAR] = 0.0;
   }
 }
+__global__ __launch_bounds__(256) void finalize_bound_kernel(FinalizeArgs a) {
+  __shared__ double red[4];
+  finalize_bound_body(a, red);
+}
 
 // Adjoints in the whitened basis (everything between L^-T ... L^-1 is formed from B, B^-1 and g = B^-1 u, whose
 // entries are O(1) however ill-conditioned Kuu is):
@@ -354,30 +326,85 @@ __global__ __launch_bounds__(256) void finalize_bound_kernel(const double* __res
 // with cond(Kuu) ~ 1e8 (inducing inputs closer than the lengthscale) its gradients were off by 1e-2 relative, this
 // form by 1e-9 (tests/studies/logp_noise.py, profiles/r02_logp_noise.json) -- same number of M^3 products.
 // CS = [C | S], two Mp x Mp matrices back to back (one batched GEMM pair sandwiches both).
-__global__ __launch_bounds__(256) void whitened_cs_kernel(const double* __restrict__ W, const double* __restrict__ Binv,
-                                                          const double* __restrict__ g, int Mp, double s2,
-                                                          double* __restrict__ CS) {
-  const int64_t total = (int64_t)Mp * Mp;
-  const double is2 = 1.0 / s2, is22 = 1.0 / (s2 * s2);
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
-    const int64_t pt = (int64_t)c * Mp + r;
-    const double w = 0.5 * (W[e] + W[pt]);
-    const double bi = 0.5 * (Binv[e] + Binv[pt]);
-    const double gg = g[r] * g[c] * is22;
-    const double id = (r == c) ? 1.0 : 0.0;
-    CS[e] = id - bi - gg;
-    CS[total + e] = w * is2 - id + bi + gg;
+// ONE launch (round 5) for the three jobs behind g = B^-1 u that need nothing but W, B^-1, g, u and L^-1 -- they were three launches, two
+// of them on the critical path between the sandwiches' GEMMs (profiles/r05_v3_c3_timeline.txt): blocks [0, nC) form [C | S]
+// (whitened_cs_kernel's job), the next Mp / 16 the three row-wise scalars of s2bar (adjoint_rows_kernel's: a wave per row), the last
+// Mp / 64 t = L^-T g (gemv_cols_kernel's: a block per 64 columns, sixteen waves over the rows, partial sums added in wave order).
+// Every sum keeps its order: the same bits as the three launches.
+__global__ __launch_bounds__(1024) void adjoint_mid_kernel(const double* __restrict__ W, const double* __restrict__ Binv,
+                                                           const double* __restrict__ g, const double* __restrict__ u,
+                                                           const double* __restrict__ Li, int Mp, double s2, int nC,
+                                                           double* __restrict__ CS, double* __restrict__ rows3, double* __restrict__ t) {
+  __shared__ double part[16][64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (b < nC) {
+    const int64_t total = (int64_t)Mp * Mp;
+    const double is2 = 1.0 / s2, is22 = 1.0 / (s2 * s2);
+    for (int64_t e = (int64_t)b * 1024 + threadIdx.x; e < total; e += (int64_t)nC * 1024) {
+      const int r = (int)(e / Mp), c = (int)(e - (int64_t)r * Mp);
+      const int64_t pt = (int64_t)c * Mp + r;
+      const double w = 0.5 * (W[e] + W[pt]);
+      const double bi = 0.5 * (Binv[e] + Binv[pt]);
+      const double gg = g[r] * g[c] * is22;
+      const double id = (r == c) ? 1.0 : 0.0;
+      CS[e] = id - bi - gg;
+      CS[total + e] = w * is2 - id + bi + gg;
+    }
+    return;
+  }
+  if (b < nC + Mp / 16) {
+    const int row = (b - nC) * 16 + wv;
+    double f = 0.0, wa = 0.0;
+    for (int j = lane; j < Mp; j += 64) {
+      const double w = W[(int64_t)row * Mp + j];
+      f = fma(Binv[(int64_t)row * Mp + j], w, f);
+      wa = fma(w, g[j], wa);
+    }
+    f = wave_sum(f);
+    wa = wave_sum(wa);
+    if (lane == 0) {
+      const double a = g[row];
+      rows3[row] = f;
+      rows3[Mp + row] = wa * a;
+      rows3[2 * Mp + row] = u[row] * a;
+    }
+    return;
+  }
+  {
+    const int col = (b - nC - Mp / 16) * 64 + lane;
+    double s0 = 0.0, s1 = 0.0, s2_ = 0.0, s3 = 0.0;
+    int j = wv;
+    for (; j + 48 < Mp; j += 64) {
+      s0 = fma(Li[(int64_t)j * Mp + col], g[j], s0);
+      s1 = fma(Li[(int64_t)(j + 16) * Mp + col], g[j + 16], s1);
+      s2_ = fma(Li[(int64_t)(j + 32) * Mp + col], g[j + 32], s2_);
+      s3 = fma(Li[(int64_t)(j + 48) * Mp + col], g[j + 48], s3);
+    }
+    for (; j < Mp; j += 16) s0 = fma(Li[(int64_t)j * Mp + col], g[j], s0);
+    part[wv][lane] = (s0 + s1) + (s2_ + s3);
+    __syncthreads();
+    if (wv == 0) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += part[k][lane];
+      t[col] = acc;
+    }
   }
 }
 // Phibar = sym(R0) / (2 s2), Kuubar = -sym(R1) / 2 (cropped to M x M, ld M), bbar = t / s2^2 with t = L^-T g
+// (+ one more block: the evaluation's final scalars -- finalize_bound_kernel's job, which needs nothing this launch writes)
 __global__ __launch_bounds__(256) void adjoint_out_kernel(const double* __restrict__ R, const double* __restrict__ t,
                                                           int Mp, int M, double s2, double* __restrict__ Phibar,
-                                                          double* __restrict__ Kuubar, double* __restrict__ bbar) {
+                                                          double* __restrict__ Kuubar, double* __restrict__ bbar, int nA, FinalizeArgs fin) {
+  if ((int)blockIdx.x == nA) {
+    __shared__ double red[4];
+    finalize_bound_body(fin, red);
+    return;
+  }
   const int64_t total = (int64_t)M * M;
   const int64_t mm = (int64_t)Mp * Mp;
   const double h = 0.25 / s2;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)nA * 256) {
     const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
     const int64_t p = (int64_t)r * Mp + c, pt = (int64_t)c * Mp + r;
     Phibar[e] = h * (R[p] + R[pt]);
@@ -1041,7 +1068,10 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     // [C | S] in M0.., [C | S] L^-1 in M4.., L^-T [C | S] L^-1 back in M0..: two batched products for both sandwiches
     double* CS = w.M0;
     double* TT = w.M4;
-    whitened_cs_kernel<<<grid_for((int64_t)mm), 256, 0, st>>>(w.M5, w.M2, w.alpha, Mp, s2, CS);
+    {  // [C | S], the row-wise scalars of s2bar and t = L^-T g: one launch (ld = Mp)
+      const int nC = grid_for((int64_t)mm / 4);
+      adjoint_mid_kernel<<<nC + Mp / 16 + Mp / 64, 1024, 0, st>>>(w.M5, w.M2, w.alpha, w.u, w.M1, Mp, s2, nC, CS, w.rows3, w.t1);
+    }
     if (Cw_out) crop_copy(CS, ld, Cw_out, M, M, M, st);  // C itself, before the sandwich (factored pass 2)
     GemmDesc t1;
     t1.A = CS; t1.lda = ld; t1.sA = (int64_t)mm; t1.B = w.M1; t1.ldb = ld; t1.sB = 0; t1.C = TT; t1.ldc = ld; t1.sC = (int64_t)mm;
@@ -1052,11 +1082,14 @@ static int bound_impl(const double* Kuu, const double* Phi, const double* b, con
     t2.m = Mp; t2.n = Mp; t2.k = Mp; t2.batch = 2; t2.klo_mask = 1;
     gemm(t2, st);
     // scalars for s2bar (slots keep their names): tr(B^-1 W) = tr(Sigma^-1 Phi), u.g = b.alpha, g^T W g = alpha^T Phi alpha
-    adjoint_rows_kernel<<<Mp / 4, 256, 0, st>>>(w.M2, w.M5, w.alpha, w.u, Mp, w.rows3);
-    gemv(w.M1, ld, Mp, true, w.alpha, w.t1, st);  // L^-T g
-    adjoint_out_kernel<<<grid_for((int64_t)M * M), 256, 0, st>>>(CS, w.t1, Mp, M, s2, Phibar, Kuubar, bbar);
   }
-  finalize_bound_kernel<<<1, 256, 0, st>>>(w.sc, yy, kappa, s2, (double)N, with_adjoints, w.M6, w.q, Mp, abort_flag, info, out, w.rows3);
+  const FinalizeArgs fin{w.sc, yy, kappa, s2, (double)N, with_adjoints, w.M6, w.q, Mp, abort_flag, info, out, w.rows3};
+  if (with_adjoints) {  // the last block of the launch writes the evaluation's scalars
+    const int nA = grid_for((int64_t)M * M);
+    adjoint_out_kernel<<<nA + 1, 256, 0, st>>>(w.M0, w.t1, Mp, M, s2, Phibar, Kuubar, bbar, nA, fin);
+  } else {
+    finalize_bound_kernel<<<1, 256, 0, st>>>(fin);
+  }
   return check_launch();
 }
 
