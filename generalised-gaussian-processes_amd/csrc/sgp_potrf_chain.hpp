@@ -40,6 +40,7 @@
 // the prep item of column j, which depends on columns <= j - 2), and all workgroups of the launch are resident.
 #pragma once
 #include "sgp_potrf.hpp"
+#include "sgp_potrf_items.hpp"
 
 namespace sgp {
 
@@ -525,37 +526,6 @@ __device__ __forceinline__ int df_wait_panels(const int* pready, int pb, int* ab
 // Two lists, each in dependency order (every dependency of an item is an earlier item of one of the lists or a step of the chain
 // workgroup): the CRITICAL one [FUSED_S(0), FUSED_D(0), FUSED_S(1), ...] is dealt round-robin to the workgroups expected on the chain
 // workgroup's XCD (blockIdx = 0 mod 8), the other one to the rest; with fewer than eight workgroups there is one list for all.
-enum ChKind { CH_EARLY_S, CH_EARLY_D, CH_FUSED_S, CH_FUSED_D, CH_TILE, CH_INV, CH_RHS, CH_NONE };
-struct ChItem { int kind, c, i; };
-__host__ __device__ inline int ch_crit_items(int nb) { return nb >= 3 ? 2 * (nb - 2) : 0; }
-__host__ __device__ inline int ch_rest_tile_items(int nb) { return nb >= 3 ? (nb - 2) * (nb + 1) / 2 : 0; }  // per column c: 2 + (nb - 3 - c)
-__host__ __device__ inline int ch_tile_items(int nb) { return ch_crit_items(nb) + ch_rest_tile_items(nb); }
-__host__ __device__ inline int ch_inv_items(int nb) { return nb * (nb + 1) / 2; }
-// item k of a list: per column c the tile items ([EARLY_S, EARLY_D, (single list only: FUSED_S, FUSED_D,) TILE(c+3..)], columns c <= nb - 3),
-// then -- want_inv -- row c of L^-1: INV(c, 0 .. c); behind the last column RHS if want_rhs.  `fused`: the single list (few workgroups)
-__device__ __forceinline__ ChItem ch_list_item(int k, int nb, bool want_inv, bool want_rhs, bool fused) {
-  for (int c = 0; c < nb; ++c) {
-    const int nt = c <= nb - 3 ? nb - 1 - c + (fused ? 2 : 0) : 0;
-    if (k < nt) {
-      if (k == 0) return ChItem{CH_EARLY_S, c, c + 2};
-      if (k == 1) return ChItem{CH_EARLY_D, c, c + 2};
-      if (fused) {
-        if (k == 2) return ChItem{CH_FUSED_S, c, c + 2};
-        if (k == 3) return ChItem{CH_FUSED_D, c, c + 2};
-        return ChItem{CH_TILE, c, c - 1 + k};
-      }
-      return ChItem{CH_TILE, c, c + 1 + k};
-    }
-    k -= nt;
-    if (want_inv) {
-      if (k <= c) return ChItem{CH_INV, k, c};
-      k -= c + 1;
-    }
-  }
-  if (want_rhs && k == 0) return ChItem{CH_RHS, 0, 0};
-  return ChItem{CH_NONE, 0, 0};
-}
-
 __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChScratch sc, const double* rhs, double* sol, double* Linv,
                                               DfShared& sh, int ow, int nout) {
   const int tid = threadIdx.x, r = tid & 63;
@@ -594,17 +564,9 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
 
   // ---- which list, and: does this workgroup really share the chain workgroup's L2? ----
   const bool want_inv = Linv != nullptr, want_rhs = rhs != nullptr;
-  const int nl = nout / 8;                       // workgroups expected on the chain workgroup's XCD: ow = 7, 15, ...
-  const bool split = nl > 0 && ch_crit_items(nb) > 0;
-  const bool crit_wg = split && ((ow + 1) & 7) == 0;
-  int first, stride, count;
-  if (!split) {
-    first = ow; stride = nout; count = ch_tile_items(nb) + (want_inv ? ch_inv_items(nb) : 0) + (want_rhs ? 1 : 0);
-  } else if (crit_wg) {
-    first = (ow + 1) / 8 - 1; stride = nl; count = ch_crit_items(nb);
-  } else {
-    first = ow - (ow + 1) / 8; stride = nout - nl; count = ch_rest_tile_items(nb) + (want_inv ? ch_inv_items(nb) : 0) + (want_rhs ? 1 : 0);
-  }
+  const ChDeal deal = ch_deal(ow, nout, nb, want_inv, want_rhs);  // (sgp_potrf_items.hpp)
+  const bool split = deal.split, crit_wg = deal.crit_wg;
+  const int first = deal.first, stride = deal.stride, count = deal.count;
   bool local = false;  // same XCD as the chain workgroup (decided once it has said where it runs; asked only by the fused items)
   bool local_known = false;
   auto ask_local = [&]() __attribute__((always_inline)) {
@@ -669,8 +631,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
   };
 
   for (int k = first; k < count; k += stride) {
-    const ChItem it = !split ? ch_list_item(k, nb, want_inv, want_rhs, true)
-                             : (crit_wg ? ChItem{(k & 1) ? CH_FUSED_D : CH_FUSED_S, k >> 1, (k >> 1) + 2} : ch_list_item(k, nb, want_inv, want_rhs, false));
+    const ChItem it = ch_dealt_item(deal, k, nb, want_inv, want_rhs);
     const int kind = it.kind, j = it.c, i = it.i;
     if (kind == CH_NONE) break;
     if (kind == CH_RHS) {

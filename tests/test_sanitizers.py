@@ -45,3 +45,18 @@ def test_stream_plan_is_clean_under_asan_ubsan(tmp_path):
     for knobs in ({}, {"SGP_SYRK_NSPLIT": "24", "SGP_KBAR_NSPLIT": "40"}):
         out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(_env(), **knobs))
         assert out.returncode == 0 and "0 failures" in out.stdout, (knobs, out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_chain_cholesky_items_are_dealt_once_and_cannot_deadlock(tmp_path):
+    """csrc/sgp_potrf_items.hpp: the work items of the chain-workgroup Cholesky (tiles, the early / fused partial sums, the blocks of
+    L^-1, the right-hand side) and their static deal to the workgroups.  tests/native/chain_items_check.cpp walks block counts 2 ... 64,
+    with / without the inverse and the right-hand side, 1 ... 255 workgroups: every item dealt exactly once, and a simulation of the
+    dataflow (workgroups take their items strictly in order; an item completes only behind the flags the kernel waits for) completes."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "chain_items_asan")
+    subprocess.run([gxx, "-O1", "-std=c++17"] + SAN + ["-I", INC, "-o", exe, os.path.join(ROOT, "tests", "native", "chain_items_check.cpp")],
+                   check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
