@@ -184,7 +184,7 @@ class CompositeHmcTarget:
             lp = float(h[0])
             if info != 0 or not math.isfinite(lp):
                 return -math.inf, [0.0] * self.ndim
-            return lp, [float(v) for v in h[1:1 + self.ndim]]
+            return lp, h[1:1 + self.ndim].tolist()
         vals = [math.exp(v) for v in th[:-1]]
         sigma = math.exp(th[-1])
         kern = self.kernel.with_values(vals)

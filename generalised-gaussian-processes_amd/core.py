@@ -287,10 +287,9 @@ class CollapsedBound:
         if self._small is None or self._small[0].numel() != nt:
             pin = e.device.type == "cuda"
             host = torch.empty(nt, dtype=torch.float64, pin_memory=pin)
-            self._small = (host, torch.empty(nt, dtype=torch.float64, device=e.device), e.small_result(nt - 2)[0])
-        host, dev_theta, buf = self._small
-        for i, v in enumerate(theta_host):
-            host[i] = float(v)
+            self._small = (host, torch.empty(nt, dtype=torch.float64, device=e.device), e.small_result(nt - 2)[0], host.numpy())
+        host, dev_theta, buf, host_np = self._small
+        host_np[:] = theta_host  # one vectorised store into the pinned buffer (element-wise tensor stores cost ~1.5 us each)
         dev_theta.copy_(host, non_blocking=True)
         kw = {"composite": composite} if composite is not None else {}
         out, gz, _ = e.small_eval(self.X, self.y, Z, dev_theta, self.jitter, self.kernel, mode=mode, want_grad=want_grad,
@@ -740,7 +739,7 @@ class HmcTarget:
             lp = float(h[0])
             if info != 0 or not math.isfinite(lp):
                 return -math.inf, [0.0] * self.ndim
-            return lp, [float(v) for v in h[1:1 + self.ndim]]
+            return lp, h[1:1 + self.ndim].tolist()
         p = self.constrain(theta)
         ls, sf, sn = p["ls"], p["sig_f"], p["sig_n"]
         kw = {"grad_reach": self.bound.extended_range, "strict": True} if self.gradient == "sampler" else {}
