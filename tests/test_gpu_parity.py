@@ -106,6 +106,28 @@ def test_chain_cholesky_forms_the_whole_inverse_inside_the_launch(engine):
             assert int(info.item()) == 0 and torch.equal(lb, linv), (M, budget)
 
 
+def test_kuu_factor_ex_delivers_the_bits_of_kuu_inverse_trace(engine):
+    """include/sgp.h: sgp_kuu_factor_ex writes into trace_out exactly what sgp_kuu_inverse_trace(Linv_out, M, trace_out) would -- from the
+    factorization's own last launch (kuu_post_kernel) -- with the conditioning gate on or off, and leaves L^-1 / the status as sgp_kuu_factor does."""
+    import ggp_amd
+    n = engine.lib.sgp_kuu_inverse_trace_len()
+    for M in (65, 100, 512, 1000):
+        g = torch.Generator().manual_seed(M + 11)
+        R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
+        K = (R @ R.T / M + torch.eye(M, dtype=torch.float64)).to(engine.device)
+        plain, info0 = engine.kuu_factor(K)
+        for limit in (None, 0.0):
+            e = ggp_amd.HipEngine(own_context=True)
+            if limit is not None:
+                e.set_option("cond_limit", limit)
+            tr = torch.full((n,), float("nan"), dtype=torch.float64, device=engine.device)
+            linv, info = e.kuu_factor(K, trace_out=tr)
+            ref = e.kuu_inverse_trace(linv, M)
+            assert int(info.item()) == 0 == int(info0.item()) and torch.equal(linv, plain)
+            assert torch.equal(tr[:1 + M], ref[:1 + M]), (M, limit, float(tr[0]), float(ref[0]))
+            assert abs(float(tr[0]) - float(torch.linalg.inv(K.cpu()).trace())) < 1e-10 * float(tr[0])
+
+
 @pytest.mark.parametrize("M,pivot", [(256, 0), (256, 15), (256, 16), (256, 63), (256, 64), (256, 130), (1024, 1023), (1152, 700)])
 def test_chol_reports_first_bad_pivot_of_any_tile_and_panel(engine, M, pivot):
     """LAPACK-style info = index of the first non-positive pivot, whichever work item / wave of the single-launch

@@ -601,3 +601,32 @@ def test_two_rank_gloo_three_tier_decisions_are_identical_on_every_rank():
     assert a[1][4] == 1 and a[2][4] == 2               # mid: the trip's repeat and the next evaluation ran in the extended order
     assert a[4][4] == a[3][4] and outs[0][3] >= 2      # far: whitened (the extended attempt of the first one was repeated)
     assert not a[-1][6]                                # the episode has ended
+
+
+def test_reciprocal_lengthscale_array_is_cached_by_value_not_by_identity():
+    """HipEngine._inv_ls keeps the last C array (an evaluation passes the same list to four or five library calls): a list changed IN PLACE
+    between two evaluations -- what a sampler's loop does -- must give a new array, a tensor argument is never cached, and the composite
+    kernel's parameter block keeps its own length check.  (The method needs no device: it is called on a bare object here.)"""
+    from ggp_amd import engine as E
+
+    class Bare:
+        pass
+
+    b = Bare()
+    ls = [2.0, 4.0]
+    a1 = E.HipEngine._inv_ls(b, ls, 2)
+    assert list(a1) == [0.5, 0.25]
+    assert E.HipEngine._inv_ls(b, ls, 2) is a1                       # same values: the kept array
+    assert E.HipEngine._inv_ls(b, [2.0, 4.0], 2) is a1               # another list object with the same values
+    ls[1] = 8.0                                                      # changed in place
+    a2 = E.HipEngine._inv_ls(b, ls, 2)
+    assert a2 is not a1 and list(a2) == [0.5, 0.125]
+    assert list(E.HipEngine._inv_ls(b, [2.0], 3)) == [0.5, 0.5, 0.5]  # one lengthscale for every dimension
+    assert list(E.HipEngine._inv_ls(b, [2.0, 8.0], 2, "matern52")) == [0.5, 0.125]
+    t = torch.tensor([2.0, 4.0], dtype=torch.float64)
+    a3 = E.HipEngine._inv_ls(b, t, 2)
+    assert list(a3) == [0.5, 0.25] and E.HipEngine._inv_ls(b, t, 2) is not a3
+    with pytest.raises(ValueError):
+        E.HipEngine._inv_ls(b, [1.0, 2.0, 3.0], 2)
+    with pytest.raises(ValueError):
+        E.HipEngine._inv_ls(b, [1.0, 2.0], 2, "composite")

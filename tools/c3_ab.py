@@ -2,6 +2,8 @@ import sys, os, math, time, json, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import ggp_amd
 eng = ggp_amd.HipEngine()
+if os.environ.get("CU_BUDGET"):
+    eng.set_option("cu_budget", int(os.environ["CU_BUDGET"]))
 N, d, M = (int(v) for v in os.environ.get("SHAPE", "13279,18,512").split(","))
 g = torch.Generator().manual_seed(0)
 X = torch.randn(N, d, dtype=torch.float64, generator=g); y = torch.sin(X.sum(1)/math.sqrt(d)) + 0.1*torch.randn(N, dtype=torch.float64, generator=g)
