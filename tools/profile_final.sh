@@ -1,0 +1,40 @@
+#!/bin/bash
+# The digest-matched final set of a round, in one go on the GPU box (from the repo root):   bash tools/profile_final.sh r05_v5
+# bench line + rocprofv3 stats + PMC traffic (profile_round.sh), SQ counters (profile_sq.sh), TCC counters, potrf A/B against the round-1
+# kernel, the smaller configs, the shard sizes of the multi-GPU job, C3 and 125 k-row-shard kernel timelines, the guarded orders' times,
+# NUTS at the mid sizes, and the GPU suite.  Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_*.
+set -u
+TAG=${1:-r05}
+export TMPDIR=/tmp
+O=gpurun_out/$TAG
+mkdir -p "$O"
+bash tools/profile_round.sh "$TAG" > "gpurun_out/${TAG}_round.log" 2>&1
+bash tools/profile_sq.sh "$TAG" > "gpurun_out/${TAG}_sq.log" 2>&1
+ARGS=""
+for C in TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum; do
+  rocprofv3 --kernel-trace --output-format csv --pmc $C -d "$O/tcc_$C" -o run -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2> "$O/tcc_$C.err"
+  ARGS="$ARGS $C=$O/tcc_$C"
+done
+python3 tools/summarise_pmc.py "$O/pmc_tcc_counters.csv" $ARGS
+rm -rf "$O"/tcc_TCC_*
+timeout 300 python3 tools/potrf_bench.py > "$O/potrf_bench.jsonl" 2>/dev/null
+SGP_POTRF_CHAIN=0 timeout 300 python3 tools/potrf_bench.py > "$O/potrf_bench_dataflow_kernel.jsonl" 2>/dev/null
+timeout 300 python3 tools/bench_configs.py > "$O/small_configs.jsonl" 2>/dev/null
+for r in 1000000 500000 250000 125000; do
+  timeout 300 python3 tools/shard_trace.py $r >> "$O/shard_sizes.jsonl" 2>/dev/null
+  timeout 300 python3 tools/shard_trace.py $r grad >> "$O/shard_sizes.jsonl" 2>/dev/null
+done
+rocprofv3 --kernel-trace --output-format csv -d "$O/trc3" -o run -- python3 tools/c3_trace.py > "$O/c3.out" 2> "$O/c3.err"
+python3 tools/last_eval_timeline.py "$(find "$O/trc3" -name '*kernel_trace.csv' | head -1)" kuu_kernel > "$O/c3_timeline.txt" 2>&1
+rm -rf "$O/trc3"
+for mode in "" grad; do
+  tag=${mode:-value}
+  rocprofv3 --kernel-trace --output-format csv -d "$O/trs_$tag" -o run -- python3 tools/shard_trace.py 125000 $mode > /dev/null 2> "$O/shard_$tag.err"
+  python3 tools/last_eval_timeline.py "$(find "$O/trs_$tag" -name '*kernel_trace.csv' | head -1)" kuu_kernel > "$O/shard125k_${tag}_timeline.txt" 2>&1
+  rm -rf "$O/trs_$tag"
+done
+timeout 600 python3 tools/whitened_ms.py > "$O/whitened_ms.json" 2>/dev/null
+timeout 600 python3 tools/nuts_midsize.py 2>/dev/null > "$O/nuts_midsize.jsonl"
+timeout 3000 python3 -m pytest tests -x -q -m gpu > "$O/pytest_gpu.txt" 2>&1
+tail -3 "$O/pytest_gpu.txt"
+cat "$O/potrf_bench.jsonl" "$O/shard_sizes.jsonl"
