@@ -24,7 +24,7 @@ static inline int dp_for(int d) {
 struct StreamPlan {
   int Mp, ntr, ntiles, DP;
   int64_t Npad;     // N rounded up to ASM_ROWS
-  int asm_sub;      // fp64 assembly: workgroups per ASM_ROWS row block (1, or 4 on small shards: 64 rows each, see make_stream_plan)
+  int asm_sub;      // fp64 assembly: workgroups per ASM_ROWS row block (1, or 4 / 8 on small shards: 64 / 32 rows each, see make_stream_plan)
   int64_t sc_rows;  // rows of K'_fu materialised at a time (multiple of ASM_ROWS)
   int nsplit;       // pass 1: row-range splits per tile (multiple of 8: one XCD per residue)
   int taper[4];     // pass 1: groups of 8 splits at relative sizes 8, 4, 2, 1 (all 0: equal splits), see split_range()
@@ -78,9 +78,15 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   p.DP = dp_for(d);
   p.Npad = N > 0 ? round_up64(N, ASM_ROWS) : 0;
   // Small shards (C3: 52 row blocks x 2 column groups = 104 workgroups of four waves on 256 CUs, every thread walking 256 rows with one
-  // wave per SIMD: 125 us for 6.8 M kernel values, profiles/r05_v2_c3_timeline.txt): a quarter of the rows per workgroup, four times
-  // the workgroups.  The partials of K'^T y are then per 64 rows (bpart_rows(): the fixed-order reduction behind them takes any count).
-  p.asm_sub = (p.Npad / ASM_ROWS) * ((p.Mp + 255) / 256) < 128 ? 4 : 1;
+  // wave per SIMD: 125 us for 6.8 M kernel values, profiles/r05_v2_c3_timeline.txt): fewer rows per workgroup, more workgroups -- 64 rows
+  // 47 us, 32 rows 34 us, 16 rows 34 us at C3 (same-box A/B, C3 value 431 -> 414 us from 64 to 32 rows).  The partials of K'^T y are then
+  // per 64 / 32 rows (bpart_rows(): the fixed-order reduction behind them takes any count).
+  {
+    const int64_t base = (p.Npad / ASM_ROWS) * ((p.Mp + 255) / 256);
+    p.asm_sub = base < 128 ? 8 : (base < 256 ? 4 : 1);
+  }
+  static const int asm_sub_override = getenv("SGP_ASM_SUB") ? atoi(getenv("SGP_ASM_SUB")) : 0;  // tuning knob: 1, 4, 8 or 16
+  if (asm_sub_override == 1 || asm_sub_override == 4 || asm_sub_override == 8 || asm_sub_override == 16) p.asm_sub = asm_sub_override;
   int64_t cap = (int64_t)(stream_kfu_budget() / ((size_t)p.Mp * 8)) / ASM_ROWS * ASM_ROWS;
   if (cap < ASM_ROWS) cap = ASM_ROWS;
   p.sc_rows = p.Npad < cap ? p.Npad : cap;

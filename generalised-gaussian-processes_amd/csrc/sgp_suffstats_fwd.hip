@@ -518,7 +518,9 @@ static void launch_assemble_rows(int kid, dim3 grid, hipStream_t st, const doubl
 template <int DP>
 static void launch_assemble(int kid, int sub, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
                             int64_t row0, int64_t N, int M, int Mp, double* Kfu, double* bpart) {
-  if (sub == 4) launch_assemble_rows<DP, ASM_ROWS / 4>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
+  if (sub == 16) launch_assemble_rows<DP, ASM_ROWS / 16>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
+  else if (sub == 8) launch_assemble_rows<DP, ASM_ROWS / 8>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
+  else if (sub == 4) launch_assemble_rows<DP, ASM_ROWS / 4>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
   else launch_assemble_rows<DP, ASM_ROWS>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Kfu, bpart);
 }
 
