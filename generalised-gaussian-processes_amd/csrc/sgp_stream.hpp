@@ -115,8 +115,12 @@ static inline StreamPlan make_stream_plan(int64_t N, int M, int d) {
   // Mid-size shards (C3: 13 279 rows): ~4 waves of workgroups would leave each with a handful of 16-row chunks and a
   // 128 KB slab to write and reduce (2080 workgroups, 272 MB of slabs: contraction 107 us, reduction 70 us).  One round of
   // resident workgroups instead -- 56 splits at M = 512: value 735 -> 628 us, value+gradient 1311 -> 1185 us (same box).
+  // (round 5: 0.8 of a round, rounded DOWN -- the K_uu factorization's workgroups hold a quarter of the CUs' LDS while this kernel runs, and a
+  // launch that does not fit beside them pays a second round: 56 / 48 / 40 / 32 / 24 splits at C3 = 104 / 106 / 89 / 105 / 136 us + a reduction
+  // of 15 / 13 / 11 / 9 / 8 us, rocprofv3, same box)
   if (nchunks / ns < 16 && !getenv("SGP_TARGET_WGS")) {
-    const int64_t one_round = 8 * ((RESIDENT_WGS + 8 * p.ntiles - 1) / (8 * p.ntiles));
+    int64_t one_round = 8 * ((RESIDENT_WGS * 4 / 5) / (8 * p.ntiles));
+    if (one_round < 8) one_round = 8;
     if (one_round < ns) ns = one_round;
   }
   static const int ns_override = getenv("SGP_SYRK_NSPLIT") ? atoi(getenv("SGP_SYRK_NSPLIT")) : 0;  // tuning knob
