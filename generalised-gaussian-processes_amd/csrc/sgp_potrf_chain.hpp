@@ -76,7 +76,7 @@ struct ChShared {
 };
 
 // scratch layout (ints): [ready: ntile | abort | preS: nb | preD: nb | pready: 4 nb | preSE: nb | preDE: nb | pready_l: 4 nb | xready_l: nb | cwx |
-// iready: ntile] x DF_FLAG_STRIDE, then doubles:
+// iready: ntile | lo2r: nb | lo2r_l: nb] x DF_FLAG_STRIDE, then doubles:
 // dinv_g nb x 1024 | upre nb x 4096 | dpre nb x 4096 | lo2 nb x 4096 | upe nb x 4096 | dpe nb x 4096 | xt ntile x 4096
 struct ChScratch {
   int* ready;
@@ -87,7 +87,7 @@ struct ChScratch {
   double* dinv_g;
   double* upre;
   double* dpre;
-  double* lo2;   // the second copy of tile (c+2, c) (slot 2 of column c): nb x 4096
+  double* lo2;   // the ORIGINAL entries of tile (c+2, c), handed from FUSED_D(c) to FUSED_S(c) (flag lo2r[c]): nb x 4096, thread for thread
   double* upe;   // early terms of US / UD (slots 2 / 3), in the accumulator order of the workgroup that adds the last term
   double* dpe;
   int* preSE;
@@ -96,9 +96,11 @@ struct ChScratch {
   int* xready_l;
   int* cwx;       // the chain workgroup's XCC id + 1
   int* iready;    // blocks of L^-1 (same numbering as the tiles)
+  int* lo2r;      // lo2[c] is there (written back) ...
+  int* lo2r_l;    // ... or in the L2 of the chain workgroup's XCD (light twin, as pready_l)
   double* xt;     // ... and their transposes X(i,j)^T, row-major 64 x 64: the left operand of the rows below
 };
-__host__ __device__ inline size_t ch_flag_slots(int nb) { return (size_t)nb * (nb + 1) + 2 + 13 * (size_t)nb; }
+__host__ __device__ inline size_t ch_flag_slots(int nb) { return (size_t)nb * (nb + 1) + 2 + 15 * (size_t)nb; }
 __host__ __device__ inline size_t ch_scratch_doubles(int nb) { return (size_t)nb * 1024 + (size_t)nb * 4096 * 5 + (size_t)nb * (nb + 1) / 2 * 4096; }
 __device__ __forceinline__ ChScratch ch_scratch(int* scratch, int nb) {
   const int ntile = nb * (nb + 1) / 2;
@@ -120,6 +122,8 @@ __device__ __forceinline__ ChScratch ch_scratch(int* scratch, int nb) {
   s.xready_l = s.pready_l + (size_t)4 * nb * DF_FLAG_STRIDE;
   s.cwx = s.xready_l + (size_t)nb * DF_FLAG_STRIDE;
   s.iready = s.cwx + DF_FLAG_STRIDE;
+  s.lo2r = s.iready + (size_t)(nb * (nb + 1) / 2) * DF_FLAG_STRIDE;
+  s.lo2r_l = s.lo2r + (size_t)nb * DF_FLAG_STRIDE;
   s.xt = s.dpe + (size_t)nb * 4096;
   return s;
 }
@@ -518,13 +522,13 @@ __device__ __forceinline__ int df_wait_panels(const int* pready, int pb, int* ab
 
 // The other workgroups (four waves each).  Work items:
 //   EARLY_S(c), EARLY_D(c)   the terms of US(c+1) / UD(c+2) from the columns p < c (needed late, ready early)
-//   FUSED_S(c)               tile (c+2, c) into scratch, then US(c+1) = early terms + L(c+1,c) X^T   -> the chain workgroup's S-waves
-//   FUSED_D(c)               tile (c+2, c) in place (published at once), then UD(c+2) = early terms + X X^T
+//   FUSED_D(c)               tile (c+2, c) in place (its original entries copied to scratch first; published at once), then UD(c+2) = early terms + X X^T
+//   FUSED_S(c)               tile (c+2, c) once more, in registers, from that copy; then US(c+1) = early terms + L(c+1,c) X^T   -> the chain workgroup's S-waves
 //   TILE(i, c), i >= c + 3   rank-64 updates, then the solve panel by panel as the chain workgroup publishes L(c,c)
 //   INV(i, j), i >= j          block (i, j) of L^-1 (and its transpose into scratch), behind column i's tiles
 //   RHS                      sol = L^-1 rhs
 // Two lists, each in dependency order (every dependency of an item is an earlier item of one of the lists or a step of the chain
-// workgroup): the CRITICAL one [FUSED_S(0), FUSED_D(0), FUSED_S(1), ...] is dealt round-robin to the workgroups expected on the chain
+// workgroup): the CRITICAL one [FUSED_D(0), FUSED_S(0), FUSED_D(1), ...] is dealt round-robin to the workgroups expected on the chain
 // workgroup's XCD (blockIdx = 0 mod 8), the other one to the rest; with fewer than eight workgroups there is one list for all.
 __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChScratch sc, const double* rhs, double* sol, double* Linv,
                                               DfShared& sh, int ow, int nout) {
@@ -718,12 +722,27 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     zero_acc(acc);
     if (fused_s && tid == 0) CH_STAMP(j, 10);
     d4 yb[4], xb[4];
-    {  // this wave's 16 rows of A(i,j) in the accumulator layout: asked for now, wanted after the updates
+    if (!fused_s) {  // this wave's 16 rows of A(i,j) in the accumulator layout: asked for now, wanted after the updates
       const double* src = Aij + (int64_t)(16 * g + l15) * ld + l4;
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
         for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = src[16 * pb + 4 * sq];
+    }
+    if (fused_d) {
+      // Tile (c+2, c) is computed twice -- here in place, by FUSED_S(c) into registers only -- from the same ORIGINAL entries, which this
+      // item is about to overwrite.  FUSED_S must therefore never read them in place (it did until tools/potrf_budget_check.py: with few
+      // workgroups it could start after this item had finished and solved the FINAL tile a second time -- factors off by 3e-3 under CU
+      // budgets 3 ... 7 and, now and then, 17 ... 47; the default deal starts both items at once): the entries go to scratch now, thread
+      // for thread, behind a flag of their own.  (Nor does FUSED_S then cache a line of a tile before its publication.)
+      double* cp = sc.lo2 + (size_t)j * 4096 + tid;
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) cp[(pb * 4 + sq) * 256] = yb[pb][sq];
+      // on the chain workgroup's XCD (where the default deal puts every fused item) the copy is handed over through the shared L2 at
+      // once -- no write-back of that L2 in front of this item's work; otherwise both flags follow this item's own release below
+      if (lite) raise_light(sc.lo2r_l + (size_t)j * DF_FLAG_STRIDE);
     }
     for (int p = 0; p < j; ++p) {
       if (!df_wait(ready + (size_t)tile_no(i, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
@@ -731,7 +750,16 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
       df_mac(A + (int64_t)i * DB * ld + (int64_t)p * DB, A + (int64_t)j * DB * ld + (int64_t)p * DB, ld, ld, sh, acc);
     }
     acc_to_ts(acc);
-    __syncthreads();
+    if (fused_s) {  // the original entries of the tile, from FUSED_D(c) (df_wait's barrier also orders the stores to sh.Ts above)
+      if (!df_wait((lite ? sc.lo2r_l : sc.lo2r) + (size_t)j * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      const double* cp = sc.lo2 + (size_t)j * 4096 + tid;
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) yb[pb][sq] = cp[(pb * 4 + sq) * 256];
+    } else {
+      __syncthreads();
+    }
     if (fused_s && tid == 0) CH_STAMP(j, 11);
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb)
@@ -754,7 +782,15 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
       for (int sq = 0; sq < 4; ++sq) sh.Ts[16 * g + l15][16 * pb + 4 * sq + l4] = xb[pb][sq];
-    if (fused_d) raise(ready + (size_t)tile_no(i, j) * DF_FLAG_STRIDE);  // the tile itself goes public first: the next column's items wait for it
+    if (fused_d) {  // the tile itself goes public first: the next column's items wait for it (the same release covers the copy for FUSED_S)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(ready + (size_t)tile_no(i, j) * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sc.lo2r + (size_t)j * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!lite) __hip_atomic_store(sc.lo2r_l + (size_t)j * DF_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     else __syncthreads();
     if (fused_s && tid == 0) CH_STAMP(j, 13);
     // the terms from the columns p < j (EARLY items of this column, stored thread for thread): asked for now, added behind the product

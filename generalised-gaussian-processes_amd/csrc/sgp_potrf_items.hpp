@@ -17,7 +17,8 @@ SGP_HD inline int ch_rest_tile_items(int nb) { return nb >= 3 ? (nb - 2) * (nb +
 SGP_HD inline int ch_tile_items(int nb) { return ch_crit_items(nb) + ch_rest_tile_items(nb); }
 SGP_HD inline int ch_inv_items(int nb) { return nb * (nb + 1) / 2; }
 // item k of a list: per column c the tile items ([EARLY_S, EARLY_D, (single list only: FUSED_S, FUSED_D,) TILE(c+3..)], columns c <= nb - 3),
-// then -- want_inv -- row c of L^-1: INV(c, 0 .. c); behind the last column RHS if want_rhs.  `fused`: the single list (few workgroups)
+// then -- want_inv -- row c of L^-1: INV(c, 0 .. c); behind the last column RHS if want_rhs.  `fused`: the single list (few workgroups),
+// with FUSED_D, FUSED_S in that order
 SGP_HD inline ChItem ch_list_item(int k, int nb, bool want_inv, bool want_rhs, bool fused) {
   for (int c = 0; c < nb; ++c) {
     const int nt = c <= nb - 3 ? nb - 1 - c + (fused ? 2 : 0) : 0;
@@ -25,8 +26,8 @@ SGP_HD inline ChItem ch_list_item(int k, int nb, bool want_inv, bool want_rhs, b
       if (k == 0) return ChItem{CH_EARLY_S, c, c + 2};
       if (k == 1) return ChItem{CH_EARLY_D, c, c + 2};
       if (fused) {
-        if (k == 2) return ChItem{CH_FUSED_S, c, c + 2};
-        if (k == 3) return ChItem{CH_FUSED_D, c, c + 2};
+        if (k == 2) return ChItem{CH_FUSED_D, c, c + 2};  // (ahead of FUSED_S, which waits for the copy of the tile's original entries
+        if (k == 3) return ChItem{CH_FUSED_S, c, c + 2};  //  this item makes when it STARTS: with one workgroup the order must be this one)
         return ChItem{CH_TILE, c, c - 1 + k};
       }
       return ChItem{CH_TILE, c, c + 1 + k};
@@ -41,7 +42,7 @@ SGP_HD inline ChItem ch_list_item(int k, int nb, bool want_inv, bool want_rhs, b
   return ChItem{CH_NONE, 0, 0};
 }
 // The deal: workgroup `ow` of the `nout` non-chain workgroups takes items first, first + stride, ... < count of its list.  With eight
-// workgroups or more the CRITICAL list [FUSED_S(0), FUSED_D(0), FUSED_S(1), ...] goes round-robin to the workgroups expected on the chain
+// workgroups or more the CRITICAL list [FUSED_D(0), FUSED_S(0), FUSED_D(1), ...] goes round-robin to the workgroups expected on the chain
 // workgroup's XCD (ow = 7, 15, ...: blockIdx = 0 mod 8), the other list to the rest; with fewer there is one list for all.
 struct ChDeal {
   bool split, crit_wg;
@@ -65,7 +66,7 @@ SGP_HD inline ChDeal ch_deal(int ow, int nout, int nb, bool want_inv, bool want_
 // item k of the list of a workgroup dealt `d`
 SGP_HD inline ChItem ch_dealt_item(const ChDeal& d, int k, int nb, bool want_inv, bool want_rhs) {
   if (!d.split) return ch_list_item(k, nb, want_inv, want_rhs, true);
-  if (d.crit_wg) return ChItem{(k & 1) ? CH_FUSED_D : CH_FUSED_S, k >> 1, (k >> 1) + 2};
+  if (d.crit_wg) return ChItem{(k & 1) ? CH_FUSED_S : CH_FUSED_D, k >> 1, (k >> 1) + 2};
   return ch_list_item(k, nb, want_inv, want_rhs, false);
 }
 

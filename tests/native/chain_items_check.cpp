@@ -18,6 +18,7 @@ struct Sim {
   int nb;
   bool want_inv, want_rhs;
   std::map<Key, bool> done;   // items
+  std::map<Key, bool> started;  // ... and: its workgroup has reached it (FUSED_D copies the tile's original entries for FUSED_S when it STARTS)
   std::vector<bool> step;     // chain workgroup: step j complete (L(j,j), the tile below it, the next diagonal tile's updates)
   bool has(int kind, int c, int i) const { return done.count(Key(kind, c, i)) != 0; }
   bool is_done(int kind, int c, int i) const {
@@ -46,6 +47,9 @@ struct Sim {
         for (int p = 0; p < c; ++p)
           if (!tile(i, p) || !tile(c, p)) return false;
         if (!step[c]) return false;  // the panels of L(c,c) (and, fused items, the X of the chain workgroup's step c)
+        // the original entries of tile (c+2, c) come from FUSED_D(c): at its start when both items share the chain workgroup's L2, with its
+        // publication of the tile otherwise -- the stronger requirement is the one checked
+        if (kind == CH_FUSED_S && !is_done(CH_FUSED_D, c, i)) return false;
         if (kind == CH_FUSED_S && c > 0 && !is_done(CH_EARLY_S, c, i)) return false;
         if (kind == CH_FUSED_D && c > 0 && !is_done(CH_EARLY_D, c, i)) return false;
         return true;
@@ -103,6 +107,7 @@ static int check(int nb, bool want_inv, bool want_rhs, int nout) {
       ++e->second;
       mine[ow].push_back(key);
       s.done[key] = false;
+      s.started[key] = false;
     }
   }
   for (auto& e : expect)
@@ -122,6 +127,7 @@ static int check(int nb, bool want_inv, bool want_rhs, int nout) {
     for (int ow = 0; ow < nout; ++ow)
       while (at[ow] < mine[ow].size()) {
         const Key& k = mine[ow][at[ow]];
+        if (!s.started[k]) { s.started[k] = true; moved = true; }
         if (!s.item_ready(std::get<0>(k), std::get<1>(k), std::get<2>(k))) break;
         s.done[k] = true;
         ++at[ow];
