@@ -521,6 +521,31 @@ def test_side_stream_tail_overlap_matches_serial(engine):
     assert math.isnan(F) and 1 <= parts["info"] <= 6
 
 
+def test_evaluation_is_the_same_bits_under_any_cu_budget(engine):
+    """The CU budget of a context (SGP_OPT_CU_BUDGET: a caller on a CU-masked stream) only changes how many workgroups share the work
+    items of the two factorizations -- never an evaluation's bits: value and gradients at a C3-like shape (two-stream path, chain Cholesky
+    with the inverse inside, M = 512) for budgets 3 ... 40 against the whole chip."""
+    import ggp_amd
+    g = torch.Generator().manual_seed(21)
+    N, d, M = 6000, 5, 512
+    X = torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.sin(X.sum(1)) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[torch.randperm(N, generator=g)[:M]].clone()
+    ref = None
+    for budget in (0, 3, 4, 5, 7, 9, 17, 40):
+        e = ggp_amd.HipEngine(own_context=True)
+        if budget:
+            e.set_option("cu_budget", budget)
+        cb = ggp_amd.CollapsedBound(X.to(e.device), y.to(e.device), jitter=1e-6, engine=e)
+        for rep in range(3):
+            F, gr = cb.value_and_grad(Z.to(e.device), [1.5] * d, 1.0, 0.05, want_gz=True)
+            cur = (F, gr["ls"].clone(), gr["sf2"], gr["s2"], gr["Z"].cpu().clone())
+            if ref is None:
+                ref = cur
+            assert cur[0] == ref[0] and torch.equal(cur[1], ref[1]) and cur[2] == ref[2] and cur[3] == ref[3] and torch.equal(cur[4], ref[4]), \
+                (budget, rep, cur[0], ref[0])
+
+
 def test_largest_supported_inducing_set(engine):
     """M = SGP_MAX_INDUCING = 4096: 2080 tiles over 256 persistent workgroups in the dataflow Cholesky, the widest
     kernel-matrix rows, and one past the limit is refused."""
