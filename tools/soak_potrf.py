@@ -20,9 +20,12 @@ A = torch.randn(4096, 4096, device=dev)  # (fp32 matmul on another stream: keeps
 t_end = time.time() + budget_s
 calls = bad = 0
 report = {}
+outer = 0
 while time.time() < t_end:
+    outer += 1
     for M in (130, 512, 1000, 1024, 2048):
-        g = torch.Generator().manual_seed(M)
+        # a NEW matrix every round through the same workspaces: a read of anything left in a cache by the previous launch shows
+        g = torch.Generator().manual_seed(M + 7919 * outer)
         R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
         K = (R @ R.T / M + torch.eye(M, dtype=torch.float64)).to(dev)
         ref = None
@@ -30,7 +33,7 @@ while time.time() < t_end:
             e = eng if budget == 0 else ggp_amd.HipEngine(own_context=True)
             if budget:
                 e.set_option("cu_budget", budget)
-            for rep in range(20):
+            for rep in range(6):
                 busy = rep % 2 == 1
                 if busy:
                     with torch.cuda.stream(other):
