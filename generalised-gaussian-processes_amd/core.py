@@ -195,7 +195,6 @@ class CollapsedBound:
         self.fused = True          # single-launch path for small problems (M <= 128, one rank): sgp_small_eval
         self._small = None         # (pinned host theta, device theta, result buffer) of the single-launch path
         self.overlap_tail = True   # factor Kuu on a second HIP stream while pass 1 runs
-        self.use_graph = False     # (no effect since round 5: the chain is six plain launches; kept for callers that set it)
         self.overlap_min_work = 1 << 21  # local rows x inducing points below which everything stays on one stream
         self.early_check_min_work = 1 << 28  # ... from which value_and_grad reads the status before enqueueing pass 2
         self._side = None          # (side stream, (z_ready, ready) events, {M: (Kuu, L^-1) buffers}) of the two-stream path
@@ -365,9 +364,9 @@ class CollapsedBound:
         tol, ext_ok = self.streaming_tol, self._extended_ok(M)
         self.last_estimate = est
         if tier == TIER_WHITENED:
+            # (only the upper bound is known here: nothing this order states can send the evaluation DOWN -- a strict evaluation never
+            # starts in it, see _evaluate, so whatever is accepted here was sent up by a lower tier's exact estimate)
             self.guard.note_bound(ub, tol)
-            if strict and self.guard.start_tier(tol, reach, ext_ok) < TIER_WHITENED:
-                return self.guard.start_tier(tol, reach, ext_ok)  # a lower tier is predicted to do: it states its exact estimate itself
             return None
         need = required_tier(est, tol, reach, ext_ok)
         self.guard.note_exact(est, ub, tol)
@@ -463,10 +462,15 @@ class CollapsedBound:
             if (hasattr(e, "would_use_i8") and self.kernel != "composite" and int(self.X.shape[0]) >= 300 * M
                     and e.would_use_i8(int(self.X.shape[0]), M)):
                 gate = ready
-        packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
-        self._allreduce_stats(packed, M)
+        try:
+            packed = e.suffstats(self.X, self.y, Z, ls, sf2, self.kernel, kfu=kfu, **({"gate": gate} if gate is not None else {}))
+            self._allreduce_stats(packed, M)
+        finally:
+            # the side stream writes `result`, the trace buffer and (Kuu, L^-1) with no record_stream: the main stream must be behind
+            # `ready` before any of them can go back to its allocator pool -- also when pass 1 or the exchange raises
+            if overlap:
+                main.wait_event(ready)
         if overlap:
-            main.wait_event(ready)
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result)
         elif guard and hasattr(e, "kuu_factor"):
@@ -502,8 +506,8 @@ class CollapsedBound:
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
 
     def _evaluate(self, Z, ls, sf2, s2, with_grad=False, want_gz=False, want_factors=False, grad_reach=None, strict=False):
-        """ONE evaluation through the guard -- the driver value / value_and_grad / factors share.  Runs attempts (at most three: every
-        repeat goes to a strictly higher tier, or -- strict -- to the tier the evaluation's own estimate names) until `_review` accepts.
+        """ONE evaluation through the guard -- the driver value / value_and_grad / factors share.  Runs attempts (every repeat goes to a
+        strictly higher tier; strict: once, first, to the LOWER tier the evaluation's own estimate names) until `_review` accepts.
         Returns (res, out (host), info, host buffer, head) of the accepted attempt; with_grad: the packed gradient sits behind `head`."""
         e = self.engine
         M, d = int(Z.shape[0]), int(Z.shape[1])
@@ -512,6 +516,12 @@ class CollapsedBound:
         ext_ok = self._extended_ok(M)
         if guard:
             tier = self.guard.start_tier(self.streaming_tol, reach, ext_ok)
+            if strict and tier == TIER_WHITENED:
+                # strict: the ACCEPTED tier is the one the evaluation's own exact estimate names.  The whitened order states only an upper
+                # bound -- whether it would be left for a lower tier was a matter of the guard's memory (the same theta accepted
+                # in tier 1 on a fresh bound and in tier 2 after some history).  So a strict evaluation starts at most in the highest tier
+                # that states its exact estimate, and reaches the whitened order only when that estimate sends it there.
+                tier = TIER_EXTENDED if ext_ok else TIER_STREAMING
             if tier != TIER_STREAMING:
                 self.n_direct_whitened += 1
         else:
@@ -523,19 +533,32 @@ class CollapsedBound:
         # a host round trip on every leapfrog.  Big shards check first.  The rule is the job's (largest shard), not this rank's:
         # ranks must issue the same collectives in the same order.
         early = with_grad and self._rows_for_form * M >= self.early_check_min_work
-        tried = set()
+        # Repeats: UP whenever the attempt's own estimate asks for a higher tier; DOWN (strict only) at most once, and never again after
+        # it -- so the walk ends after at most four attempts (1 -> 0 -> 1 -> 2) and what is accepted is never an attempt whose own estimate
+        # asked for more (`nxt in tried` used to fall through to the LOWER attempt).  Attempts that are complete (everything
+        # already on the host) are kept, so coming back to a tier costs nothing; an incomplete one (big shards: pass 2 not yet run, and
+        # its K'_fu buffer since overwritten) is run again.
+        done = {}
+        may_go_down = strict
         while True:
-            tried.add(tier)
             res = self._forward(Z, ls, sf2, s2, with_adjoints=with_grad, want_factors=want_factors, extra=extra, tier=tier, report=guard)
             head = res["buf"].numel() - extra  # [out | status word | estimate | bound | pad], then the packed gradient (16-byte aligned)
             g = res["buf"][head:] if with_grad else None
             if with_grad and not early:
                 self._pass2(res, Z, ls, sf2, s2, want_gz, g)
             o, info, host = self._fetch(res, upto=(head + nh + 1) if (with_grad and not early) else head)
-            nxt = self._review(res, host, info, tier, reach, M, strict) if guard else None
-            if nxt is not None and nxt not in tried:
+            nxt = self._review(res, host, info, tier, reach, M, may_go_down) if guard else None
+            if nxt is not None:
+                if not (with_grad and early) and not want_factors:
+                    done[tier] = (res, o, info, host, head)
+                if nxt < tier:
+                    may_go_down = False
                 self.n_guard_reruns += 1
                 tier = nxt
+                if tier in done:
+                    res, o, info, host, head = done[tier]
+                    self.last_tier = tier
+                    return res, o, info, host, head
                 continue
             if with_grad and early and info == 0:
                 self._pass2(res, Z, ls, sf2, s2, want_gz, g)

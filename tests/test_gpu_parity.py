@@ -501,15 +501,14 @@ def test_bayesian_sgpr_hmc_on_device(engine):
 
 
 def test_side_stream_tail_overlap_matches_serial(engine):
-    """Kuu factorised on a second stream under pass 1 (default) vs everything on one stream: same numbers (`use_graph` has had no effect
-    since round 5 -- the chain is six plain launches -- and stays accepted)."""
+    """Kuu factorised on a second stream under pass 1 (default) vs everything on one stream: same numbers."""
     import ggp_amd
     G = load_golden("rbf_d18_mid")
     cb = ggp_amd.CollapsedBound(dev(G["X"], engine), dev(G["y"], engine), jitter=float(G["jitter"]), engine=engine)
     Z = dev(G["Z"], engine)
     outs = []
-    for ov, gr in ((True, True), (False, False), (True, False), (True, True)):
-        cb.overlap_tail, cb.use_graph, cb.overlap_min_work = ov, gr, 0  # force the two-stream path at this small size
+    for ov in (True, False, True, True):
+        cb.overlap_tail, cb.overlap_min_work = ov, 0  # force the two-stream path at this small size
         F, g = cb.value_and_grad(Z, G["ls"], float(G["sf2"]), float(G["s2"]), want_gz=True)
         outs.append((F, g["ls"].clone(), g["Z"].clone()))
     assert outs[0][0] == outs[1][0] == outs[2][0] == outs[3][0]
@@ -651,7 +650,7 @@ def test_tapered_splits_match_equal_splits(engine):
 
 def test_repeated_evaluations_all_modes_stay_clean(engine):
     """Regression: many evaluations over several M, fresh CollapsedBound objects (new side-stream buffers and events), two streams /
-    single stream (`use_graph` is a no-op since round 5).  The single-launch dataflow Cholesky must never report its
+    single stream.  The single-launch dataflow Cholesky must never report its
     time-out code and every mode must give the same bits (a stale flag word once showed up as info = -7777)."""
     import ggp_amd
     g = torch.Generator().manual_seed(3)
@@ -662,8 +661,8 @@ def test_repeated_evaluations_all_modes_stay_clean(engine):
             Z = X[:M].clone()
             cb = ggp_amd.CollapsedBound(X, y, jitter=1e-6, engine=engine)
             vals = []
-            for mode in ((True, True), (True, False), (False, False)):
-                cb.overlap_tail, cb.use_graph, cb.overlap_min_work = mode[0], mode[1], 0  # two-stream path even when tiny
+            for mode in (True, True, False):
+                cb.overlap_tail, cb.overlap_min_work = mode, 0  # two-stream path even when tiny
                 for _ in range(4):
                     F, parts = cb.value(Z, [1.0] * d, 1.0, 0.1, raise_on_fail=False)
                     assert parts["info"] == 0, (rep, N, d, M, mode, parts)

@@ -234,6 +234,66 @@ def test_strict_mode_makes_value_and_gradient_functions_of_theta(no_small_whiten
             assert probe2.last_tier == required_tier(probe2.last_estimate, probe2.streaming_tol, 16384.0, True)
 
 
+def test_strict_mode_with_an_under_predicting_memory_never_accepts_the_lower_attempt(no_small_whitened):
+    """an open episode whose remembered estimate / bound ratio under-predicts (1e-12) used to start a strict evaluation in
+    the whitened order, send it DOWN on the prediction, and -- the lower tier's exact estimate naming the whitened order, already tried --
+    accept the lower attempt: tier 0 with an estimate of 1.6e-4 against a tolerance of 1e-9.  Now whatever the memory holds, the accepted
+    tier is the one the exact estimate names, and the value is the fresh bound's."""
+    from ggp_amd.core import required_tier
+    X, y, Z = _problem()
+    N = X.shape[0]
+    for (ls, s2) in [(25.0, 1e-5), (10.0, 1e-4), (5.0, 1e-3)]:
+        for with_grad in (False, True):
+            for ratio, predicted in [(1e-12, 0.0), (1e-12, 1e-3), (0.5, 1e-12), (1.0, 2e-9)]:
+                for early in (False, True):
+                    cb = _bound(X, y)
+                    cb.guard.open, cb.guard.ratio, cb.guard.predicted = True, ratio, predicted
+                    if early:
+                        cb.early_check_min_work = 0         # big-shard rule: status read before pass 2 (attempts are not kept)
+                    fresh = _bound(X, y)
+                    kw = {"strict": True, "grad_reach": 16384.0} if with_grad else {"strict": True}
+                    if with_grad:
+                        F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, raise_on_fail=False, **kw)
+                        Ff, gf = fresh.value_and_grad(Z, [ls] * 3, 1.0, s2, raise_on_fail=False, **kw)
+                        assert g["ls"].tolist() == gf["ls"].tolist()
+                    else:
+                        F, _ = cb.value(Z, [ls] * 3, 1.0, s2, raise_on_fail=False, **kw)
+                        Ff, _ = fresh.value(Z, [ls] * 3, 1.0, s2, raise_on_fail=False, **kw)
+                    reach = 16384.0
+                    assert cb.last_tier == fresh.last_tier, (ls, s2, with_grad, ratio, predicted, early, cb.last_tier, fresh.last_tier)
+                    if cb.last_tier < 2:
+                        assert cb.last_tier == required_tier(cb.last_estimate, cb.streaming_tol, reach, True)
+                    else:
+                        assert fresh.n_guard_reruns >= 1     # the whitened order is reached through a lower tier's exact estimate only
+                    assert F == Ff and abs(F - Ff) / N == 0.0
+
+
+def test_strict_mode_at_the_reach_boundary_does_not_depend_on_history(no_small_whitened):
+    """ADVICE r5 (medium): at (ls 2, s2 1e-7) the estimate sits just inside the extended order's reach.  A fresh bound accepted tier 1;
+    with an open episode and ratio 1 from history the same theta was accepted in the whitened order (only the upper bound is known there,
+    and whether it is left was the memory's call).  A strict evaluation no longer starts in the whitened order."""
+    X, y, Z = _problem()
+    kw = {"strict": True, "grad_reach": 16384.0}
+    theta = ([2.0] * 3, 1.0, 1e-7)
+    fresh = _bound(X, y)
+    Ff, gf = fresh.value_and_grad(Z, *theta, raise_on_fail=False, **kw)
+    assert fresh.last_tier == 1 and 0.3 * 16384e-9 < fresh.last_estimate <= 16384e-9, (fresh.last_tier, fresh.last_estimate)
+    for ratio, predicted, opened in [(1.0, 1.0, True), (1.0, 1e-3, True), (1e-9, 0.0, True), (1.0, 0.0, False)]:
+        cb = _bound(X, y)
+        cb.guard.open, cb.guard.ratio, cb.guard.predicted = opened, ratio, predicted
+        F, g = cb.value_and_grad(Z, *theta, raise_on_fail=False, **kw)
+        assert cb.last_tier == 1 and F == Ff and g["ls"].tolist() == gf["ls"].tolist(), (ratio, predicted, opened, cb.last_tier)
+        Fv, _ = cb.value(Z, *theta, raise_on_fail=False, strict=True)
+        assert cb.last_tier == 1 and Fv == fresh.value(Z, *theta, raise_on_fail=False, strict=True)[0]
+    # a walk that visits the boundary theta in the middle of an arbitrary history: same tier, same bits
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        hist = _bound(X, y)
+        _walk(hist, Z, rng.integers(0, len(THETAS), size=6).tolist(), bool(trial & 1), **(kw if trial & 1 else {"strict": bool(trial & 2)}))
+        F, g = hist.value_and_grad(Z, *theta, raise_on_fail=False, **kw)
+        assert hist.last_tier == 1 and F == Ff and g["ls"].tolist() == gf["ls"].tolist(), trial
+
+
 def test_hmc_target_sampler_mode_uses_the_extended_order_for_gradients(no_small_whitened):
     import ggp_amd as pkg
     from fake_engine import FactoredOracleEngine

@@ -38,7 +38,6 @@ def main():
         Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
         for k, stride_desc in ((0, "-"), (8, "1 per XCD"), (16, "2 per XCD"), (32, "4 per XCD")):
             cb = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng)
-            cb.use_graph = False  # plain launches from the helper thread (graphs are captured per stream)
             if k:
                 # mask bit i is CU (i // 8) of XCD (i % 8) on this part (probed: bits 0, 32, 64 ... all landed in one XCD and
                 # slowed the contraction by 32 / 24): the first k bits are k / 8 CUs in each of the 8 XCDs
