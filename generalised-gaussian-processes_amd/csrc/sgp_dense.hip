@@ -523,17 +523,30 @@ union ChainSharedAll {
   __device__ ChainSharedAll() {}
 };
 __global__ __launch_bounds__(CH_THREADS) void potrf_chain_kernel(double* A, int64_t ld, int nb, int* scratch, int* info, int info_base,
-                                                                const double* rhs, double* sol, double* Linv) {
+                                                                const double* rhs, double* sol, double* Linv, int mode) {
   __shared__ ChainSharedAll sh;
   const ChScratch sc = ch_scratch(scratch, nb);
   if (blockIdx.x == 0) {
     if (threadIdx.x < 256) chain_d_role(A, ld, nb, sc, info, info_base, sh.ch);
-    else chain_s_role(A, ld, nb, sc, sh.ch);
+    else chain_s_role(A, ld, nb, sc, sh.ch, mode);
     return;
   }
   if (threadIdx.x >= 256) return;
-  chain_outside(A, ld, nb, sc, rhs, sol, Linv, sh.df, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+  chain_outside(A, ld, nb, sc, rhs, sol, Linv, sh.df, (int)blockIdx.x - 1, (int)gridDim.x - 1, mode);
 }
+#ifdef SGP_CH_TRACE
+// (trace build only, tools/potrf_trace_check.py) the wait / raise log of the last chain-workgroup launch: counts[CH_TRACE_WG], then the entries
+extern "C" __attribute__((visibility("default"))) int sgp_debug_potrf_trace(int* host_counts, int* host_entries, int clear) {
+  int st = 0;
+  if (host_counts) st |= (int)hipMemcpyFromSymbol(host_counts, HIP_SYMBOL(g_ch_trace_n), sizeof(int) * CH_TRACE_WG);
+  if (host_entries) st |= (int)hipMemcpyFromSymbol(host_entries, HIP_SYMBOL(g_ch_trace), sizeof(int) * CH_TRACE_WG * CH_TRACE_LEN);
+  if (clear) {
+    static int zeros[CH_TRACE_WG];
+    st |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ch_trace_n), zeros, sizeof(zeros));
+  }
+  return st;
+}
+#endif
 
 // S factorizations side by side: blockIdx.y selects the matrix, its flags / block inverses and its status word
 __global__ __launch_bounds__(256) void potrf_dataflow_batch_kernel(double* A, int64_t ld, int nb, int* scratch, int64_t scratch_ints,
@@ -630,11 +643,26 @@ bool potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   if (Linv && !(prepped & 2)) fill_zero(Linv, (size_t)Mp * ld, st);  // level 0 of tri_inverse(): diagonal-block inverses (written by the
                                                    // diagonal tile owners inside the launch), zero elsewhere
   // the chain-workgroup kernel from two block columns on, when at least one other workgroup can be resident beside it
-  static const int use_chain = getenv("SGP_POTRF_CHAIN") ? atoi(getenv("SGP_POTRF_CHAIN")) : 1;  // 0: the round-1 dataflow kernel (A/B)
-  if (use_chain && nb >= 2 && max_wg >= 2) {
+  static const int use_chain = getenv("SGP_POTRF_CHAIN") ? atoi(getenv("SGP_POTRF_CHAIN")) : 1;  // 0: the round-1 dataflow kernel (A/B); 2: the chain kernel for every nb >= 2
+  // launch modes of the chain kernel (sgp_potrf_chain.hpp: CH_MODE_*), read once
+  static const int env_mode = ((getenv("SGP_POTRF_ACQUIRE") && atoi(getenv("SGP_POTRF_ACQUIRE"))) ? CH_MODE_ACQUIRE : 0) |
+                              ((getenv("SGP_POTRF_LIGHT") && !atoi(getenv("SGP_POTRF_LIGHT"))) ? CH_MODE_NOLIGHT : 0) |
+                              ((getenv("SGP_POTRF_TICKET") && !atoi(getenv("SGP_POTRF_TICKET"))) ? 0 : CH_MODE_TICKET);
+  int mode = env_mode;
+  // The acquire-free consumer side (and the light same-XCD hand-overs) rest on "one writer per cache line, no reader before its flag":
+  // tiles and scratch blocks must not share 128-byte lines.  The scratch blocks never do (potrf_scratch_ints: whole lines per flag, 8 KB+
+  // per block, `scratch` itself checked here); a caller's matrix with an odd leading dimension or base address does -- such a call takes
+  // the acquire mode, which needs neither.
+  if ((ld & 15) != 0 || (reinterpret_cast<uintptr_t>(A) & 127) != 0 || (reinterpret_cast<uintptr_t>(scratch) & 127) != 0 ||
+      (Linv && (reinterpret_cast<uintptr_t>(Linv) & 127) != 0))
+    mode |= CH_MODE_ACQUIRE | CH_MODE_NOLIGHT;
+  // Without an inverse and up to four block columns the round-1 kernel is the faster one (M = 256: 92 against 107 us per call,
+  // profiles/r05_v8_potrf_bench_ab.jsonl; with the inverse the chain kernel wins at every size: 75 against 122 us) -- VERDICT r5 next-4a
+  const bool small_plain = !Linv && nb <= 4 && use_chain != 2;
+  if (use_chain && nb >= 2 && max_wg >= 2 && !small_plain) {
     const int nout_items = ch_tile_items(nb) + (Linv ? ch_inv_items(nb) : 0) + (rhs ? 1 : 0);  // tiles (tile (c+2, c) twice), blocks of L^-1, rhs
     const int nout = nout_items < max_wg - 1 ? nout_items : max_wg - 1;
-    potrf_chain_kernel<<<1 + nout, CH_THREADS, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv);
+    potrf_chain_kernel<<<1 + nout, CH_THREADS, 0, st>>>(A, ld, nb, scratch, info, info_base, rhs, sol, Linv, mode);
     if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
     return Linv != nullptr;  // the whole of L^-1, not only its diagonal blocks
   }

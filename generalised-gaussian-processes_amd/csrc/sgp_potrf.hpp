@@ -299,7 +299,9 @@ __device__ __forceinline__ int df_flag_load(const int* f) {
 // for: occasional 10x slower launches); the others wait at the barrier.  Flags sit DF_FLAG_STRIDE ints apart, one cache
 // line each, so the polls spread over the L2 channels.  Returns false when the launch has been aborted.
 constexpr int DF_FLAG_STRIDE = 32;
-__device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag, int* dead) {
+// `acquire` (the chain-workgroup kernel's SGP_POTRF_ACQUIRE mode only): an agent-scope acquire behind the poll -- the CU's vector cache and
+// the L2's lines of other agents' data are invalidated, so a line fetched before the flag can no longer be read stale behind it.
+__device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag, int* dead, bool acquire = false) {
   if (threadIdx.x == 0) {
     int spins = 0;
     while (df_flag_load(flag) == 0) {
@@ -312,6 +314,7 @@ __device__ __forceinline__ bool df_wait(const int* flag, int* abort_flag, int* d
         break;
       }
     }
+    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   return *dead == 0;
@@ -372,7 +375,7 @@ __device__ __forceinline__ void df_mac(const double* P, const double* Q, int64_t
 //     sol_jb = L(jb,jb)^-1 r                       one wave, lane <-> row, 64 steps of readlane + fma
 // All but the last block are done while later block columns are still being factored.
 __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb, const int* ready, int* abort_flag,
-                                             const double* rhs, double* sol, DfShared& sh) {
+                                             const double* rhs, double* sol, DfShared& sh, bool acquire = false) {
   const int tid = threadIdx.x, row = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* qs = &sh.Ts[0][0];          // the solution so far (<= 4096 doubles fit the T tile)
@@ -381,7 +384,7 @@ __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb
   for (int jb = 0; jb < nb; ++jb) {
     double part = 0.0;
     for (int p = 0; p < jb; ++p) {
-      if (!df_wait(ready + tile_no(jb, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+      if (!df_wait(ready + tile_no(jb, p) * DF_FLAG_STRIDE, abort_flag, &sh.dead, acquire)) return;
       const double* src = A + ((int64_t)jb * DB + row) * ld + (int64_t)p * DB + 16 * g;
       double lv[16], qv[16];
 #pragma unroll
@@ -395,7 +398,7 @@ __device__ __forceinline__ void df_solve_rhs(const double* A, int64_t ld, int nb
       for (int k = 0; k < 16; ++k) part = fma(lv[k], qv[k], part);
     }
     red[g * DB + row] = part;
-    if (!df_wait(ready + tile_no(jb, jb) * DF_FLAG_STRIDE, abort_flag, &sh.dead)) return;
+    if (!df_wait(ready + tile_no(jb, jb) * DF_FLAG_STRIDE, abort_flag, &sh.dead, acquire)) return;
     __syncthreads();
     if (g == 0) {
       double rr = rhs[jb * DB + row] - (red[row] + red[DB + row] + red[2 * DB + row] + red[3 * DB + row]);

@@ -28,6 +28,7 @@
 // group accumulators = 112 accumulator registers.  32-row stages (42 KB) travel global -> LDS by LDS-DMA through a ring of three;
 // the waves run as two groups half a step apart so that one of them always has its operands in registers (see i8_tile_loop).
 // Measured alternatives (register staging, lockstep waves, held-back MFMAs, split-major order): tools/i8_syrk_proto.hip, DESIGN.md 4d.
+#include <atomic>
 #include "sgp_common.hpp"
 #include "sgp_stream.hpp"
 #include "sgp_ctx.hpp"
@@ -393,10 +394,11 @@ int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumula
   Ctx& cx = cur_ctx();
   // once per DEVICE (the attribute belongs to the device's copy of the kernels), whatever context asks: a context created for another
   // device, or an entry point running in the default context on a second device, must not inherit the first device's "done"
-  static bool attr_done[64] = {};
+  // (atomics -- any host thread may enter here; devices beyond the table set the attribute on every call instead of failing)
+  static std::atomic<bool> attr_done[64];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SGP_ERR_LAUNCH;
-  if (!attr_done[dev]) {
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return SGP_ERR_LAUNCH;
+  if (dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<I8_MINSUM_DEFAULT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             I8_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
@@ -404,7 +406,7 @@ int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumula
         hipFuncSetAttribute((const void*)i8_syrk_tile_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS_BYTES) !=
             hipSuccess)
       return SGP_ERR_LAUNCH;
-    attr_done[dev] = true;
+    if (dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   const int nrt = Mp / I8_TR, ntiles = nrt * (nrt + 1), ntiles128 = nrt * (nrt + 1) / 2;
   const int prio = cx.i8_prio;  // A/B knob SGP_I8_PRIO (read when the context is created; measured a loss)

@@ -84,6 +84,96 @@ def test_chain_cholesky_is_the_same_factor_for_any_number_of_workgroups(engine):
                 assert int(info.item()) == 0 and torch.equal(Lb, L0), (M, budget, rep)
 
 
+_CHAIN_CHILD = r"""
+import hashlib, json, os, sys, time
+import torch
+sys.path.insert(0, %(root)r)
+import ggp_amd
+eng = ggp_amd.HipEngine()
+out = {"sha": {}, "calls": 0, "mismatch": 0, "timeouts": 0}
+mats = {}
+for M in %(sizes)r:
+    g = torch.Generator().manual_seed(M + 11)
+    R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
+    mats[M] = (R @ R.T / M + torch.eye(M, dtype=torch.float64)).to(eng.device)
+first = {}
+t_end = time.time() + %(seconds)f
+while True:
+    for M, A in mats.items():
+        linv, info = eng.kuu_factor(A)
+        L, info2 = eng.chol_lower(A)
+        torch.cuda.synchronize()
+        out["calls"] += 2
+        if int(info.item()) == -7777 or int(info2.item()) == -7777:
+            out["timeouts"] += 1
+            continue
+        if M not in first:
+            first[M] = (linv.clone(), L.clone())
+            h = hashlib.sha256(linv.cpu().numpy().tobytes()); h.update(L.cpu().numpy().tobytes())
+            out["sha"][str(M)] = h.hexdigest()
+        elif not (torch.equal(linv, first[M][0]) and torch.equal(L, first[M][1])):
+            out["mismatch"] += 1
+    if time.time() >= t_end:
+        break
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _chain_children(n, sizes, seconds, env_extra=None):
+    """n concurrent fresh processes on the one GPU, each factoring the same matrices (sgp_kuu_factor_ex + sgp_chol_lower) for `seconds`."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, **(env_extra or {}))
+    code = _CHAIN_CHILD % {"root": ROOT, "sizes": tuple(sizes), "seconds": float(seconds)}
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for _ in range(n)]
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        res.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    return res
+
+
+def test_chain_cholesky_modes_reproduce_the_default_launch_bit_for_bit(engine):
+    """Round 6: the items of the chain-workgroup factorization are CLAIMED (a ticket per item from one counter, in the list's own order)
+    instead of dealt statically; SGP_POTRF_TICKET=0 keeps the static deal, SGP_POTRF_ACQUIRE=1 adds an agent-scope acquire behind every
+    flag poll, SGP_POTRF_LIGHT=0 turns the same-XCD light hand-overs off.  An item's arithmetic does not depend on who runs it
+    or on how its operands were published: every mode, in a fresh process each, must return the default launch's bits (factor without
+    inverse and factor + inverse, M from three block columns -- the first fused items -- to thirty-two)."""
+    sizes = (192, 320, 1000, 2048)
+    ref = _chain_children(1, sizes, 0.0)[0]
+    assert ref["timeouts"] == 0 and ref["mismatch"] == 0
+    for M in sizes:   # ... and the default launch is LAPACK's factor
+        g = torch.Generator().manual_seed(M + 11)
+        R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
+        A = R @ R.T / M + torch.eye(M, dtype=torch.float64)
+        L, _ = engine.chol_lower(A.to(engine.device))
+        assert relerr(torch.tril(L).cpu(), torch.linalg.cholesky(A)) < 1e-12
+    for env in ({"SGP_POTRF_TICKET": "0"}, {"SGP_POTRF_ACQUIRE": "1"}, {"SGP_POTRF_LIGHT": "0"}, {"SGP_POTRF_ACQUIRE": "1", "SGP_POTRF_LIGHT": "0", "SGP_POTRF_TICKET": "0"},
+                {"SGP_POTRF_CHAIN": "2"}):
+        got = _chain_children(1, sizes, 1.0, env)[0]
+        assert got["timeouts"] == 0 and got["mismatch"] == 0, (env, got)
+        if "SGP_POTRF_CHAIN" in env:   # the chain kernel also where the product takes the round-1 kernel (no inverse, <= 4 block columns): the inverse's bits
+            continue                   # are the chain kernel's either way, the plain factor is another kernel's there -- LAPACK agreement is asserted above
+        assert got["sha"] == ref["sha"], (env, got["sha"], ref["sha"])
+
+
+def test_two_processes_factorize_on_one_gpu_without_time_outs(engine):
+    """the spin kernels used to need every workgroup of a launch resident at once -- two processes on one GPU
+    (the reference's joblib workers, experiments/regression.py:219-231; two ranks sharing a device) each launching up to 256 spinning
+    workgroups could starve each other into the 2^24-poll time-out.  With the ticketed claim an item is only ever held by a RUNNING
+    workgroup and waits only for earlier tickets: three processes (this one idle, two hammering sgp_kuu_factor_ex / sgp_chol_lower at
+    M = 1024 and 512 for 20 s) finish without a time-out, every call returning the single-process bits."""
+    sizes = (1024, 512)
+    ref = _chain_children(1, sizes, 0.0)[0]
+    res = _chain_children(2, sizes, 20.0)
+    for r in res:
+        assert r["timeouts"] == 0 and r["mismatch"] == 0 and r["sha"] == ref["sha"], (r, ref["sha"])
+        assert r["calls"] >= 200, r["calls"]
+    print("two processes on one GPU: %d + %d factorizations in 20 s, no time-out, reference bits" % (res[0]["calls"], res[1]["calls"]))
+
+
 def test_chain_cholesky_forms_the_whole_inverse_inside_the_launch(engine):
     """sgp_kuu_factor's L^-1 (padded to a multiple of 128, identity in the padding) now comes out of the factorization's own launch
     (csrc/sgp_potrf_chain.hpp: INV items, block row i of L^-1 behind block column i of the factor) instead of tri_inverse()'s
