@@ -99,7 +99,8 @@ struct ChScratch {
   int* lo2r;      // lo2[c] is there (written back) ...
   int* lo2r_l;    // ... or in the L2 of the chain workgroup's XCD (light twin, as pready_l)
   double* xt;     // ... and their transposes X(i,j)^T, row-major 64 x 64: the left operand of the rows below
-  int* ticket;    // claim counter of the ticketed deal
+  int* ticket;    // claim counters of the ticketed deal: the rest list (or the one list of a launch without critical workgroups) ...
+  int* ticket_crit;  // ... and the critical list
   int* base;      // the scratch's first word (flag slot numbers of the trace build)
 };
 // one flag = one 128-byte line; every scratch block (1024 / 4096 doubles) and every tile row segment (64 doubles, ld a multiple of 16 --
@@ -124,6 +125,7 @@ __device__ __forceinline__ ChScratch ch_scratch(int* scratch, int nb) {
   s.lo2r = at(CF_LO2R);
   s.lo2r_l = at(CF_LO2R_L);
   s.ticket = at(CF_TICKET);
+  s.ticket_crit = at(CF_TICKET_CRIT);
   s.base = scratch;
   s.dinv_g = reinterpret_cast<double*>(scratch + ch_flag_slots(nb) * DF_FLAG_STRIDE);
   s.upre = s.dinv_g + (size_t)nb * 1024;
@@ -625,16 +627,51 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
 
   // ---- which list, and: does this workgroup really share the chain workgroup's L2? ----
   const bool want_inv = Linv != nullptr, want_rhs = rhs != nullptr;
-  // Which items: a TICKET (default) -- the merged list of sgp_potrf_items.hpp in its own order, the next entry to whichever workgroup is
-  // free (one agent-scope atomic per item).  An item waits only for earlier entries of that list and for the chain workgroup, and an entry
-  // is claimed by a workgroup that is RUNNING: progress no longer needs every workgroup of the launch to be resident at once (two
-  // processes on one GPU, a CU-masked stream: VERDICT r5 weak-5) -- only the chain workgroup (block 0, dispatched first) and any one
-  // other.  The arithmetic of an item does not depend on who runs it: same bits as the static deal (SGP_POTRF_TICKET=0), which stays
-  // for A/B.
+  // Which items: a TICKETED claim (default; sgp_potrf_items.hpp: ch_claim_next) -- an item is only ever held by a RUNNING workgroup and waits
+  // only for items claimed before it and for the chain workgroup, so progress no longer needs every workgroup of the launch to be resident
+  // at once (two processes on one GPU, a CU-masked stream: VERDICT r5 weak-5).  The arithmetic of an item does not depend on who runs it:
+  // same bits as the static deal (SGP_POTRF_TICKET=0), which stays for A/B.
   const bool ticketed = (mode & CH_MODE_TICKET) != 0;
   const ChDeal deal = ch_deal(ow, nout, nb, want_inv, want_rhs);  // (sgp_potrf_items.hpp)
-  const int first = deal.first, stride = deal.stride;
-  const int count = ticketed ? ch_tile_items(nb) + (want_inv ? ch_inv_items(nb) : 0) + (want_rhs ? 1 : 0) : deal.count;
+  const int first = deal.first, stride = deal.stride, count = deal.count;
+  struct Atomics {   // ch_claim_next's view of the two counters: thread 0 asks, the answer goes round through sh.bad
+    int* ctr[2];
+    DfShared& sh;
+    int tid;
+    __device__ __forceinline__ int bcast(int v) {
+      __syncthreads();  // (sh.bad: its previous readers are behind this barrier)
+      if (tid == 0) sh.bad = v;
+      __syncthreads();
+      const int r = sh.bad;
+      __syncthreads();
+      return r;
+    }
+    __device__ __forceinline__ int take(int list) {
+      int v = 0;
+      if (tid == 0) v = __hip_atomic_fetch_add(ctr[list], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return bcast(v);
+    }
+    __device__ __forceinline__ int take_below(int list, int bound) {
+      int v = -1;
+      if (tid == 0) {
+        int cur = df_flag_load(ctr[list]);
+        // a little patience first (the critical workgroups take their own tickets within the launch's first microseconds: helping then
+        // would only move a critical item away from the chain workgroup's XCD)
+        for (int spins = 0; cur < bound && spins < 64; ++spins) {
+          __builtin_amdgcn_s_sleep(2);
+          cur = df_flag_load(ctr[list]);
+        }
+        while (cur < bound) {
+          if (__hip_atomic_compare_exchange_strong(ctr[list], &cur, cur + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            v = cur;
+            break;
+          }
+        }
+      }
+      return bcast(v);
+    }
+  } atomics{{sc.ticket, sc.ticket_crit}, sh, tid};
+  ChClaim claim;
   bool local = false;  // same XCD as the chain workgroup (decided once it has said where it runs; asked only by the fused items)
   bool local_known = false;
   auto ask_local = [&]() __attribute__((always_inline)) {
@@ -703,15 +740,9 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
   };
 
   for (int k = first;; k += stride) {
-    if (ticketed) {
-      __syncthreads();  // (sh.bad: the previous item's last reader is behind this barrier)
-      if (tid == 0) sh.bad = __hip_atomic_fetch_add(sc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      k = sh.bad;
-      __syncthreads();
-    }
-    if (k >= count) break;
-    const ChItem it = ticketed ? ch_list_item(k, nb, want_inv, want_rhs, true) : ch_dealt_item(deal, k, nb, want_inv, want_rhs);
+    if (!ticketed && k >= count) break;
+    const ChItem it = ticketed ? ch_claim_next(claim, deal.split, deal.crit_wg, nb, want_inv, want_rhs, atomics)
+                               : ch_dealt_item(deal, k, nb, want_inv, want_rhs);
     const int kind = it.kind, j = it.c, i = it.i;
     if (kind == CH_NONE) break;
     if (tid == 0) CH_TR_MARK(trwg, (4 << 28) | (kind << 20) | (j << 10) | i);

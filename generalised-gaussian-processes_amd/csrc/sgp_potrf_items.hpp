@@ -71,6 +71,65 @@ SGP_HD inline ChItem ch_dealt_item(const ChDeal& d, int k, int nb, bool want_inv
   return ch_list_item(k, nb, want_inv, want_rhs, false);
 }
 
+// -------------------------------------------------------------------------------------------------------------------------------------
+// The TICKETED claim (round 6; the default -- the static deal above stays for A/B: SGP_POTRF_TICKET=0).  Items are taken in list order
+// from a counter by whichever workgroup is free, so that an item is only ever held by a workgroup that is RUNNING: progress no longer
+// needs every workgroup of the launch to be resident at once (two processes on one GPU, CU-masked streams).  With critical workgroups
+// (`split`, as in the static deal: the workgroups expected on the chain workgroup's XCD) there are two counters -- the critical list
+// [FUSED_D(0), FUSED_S(0), FUSED_D(1), ...] for them, the rest for the others, each kind carrying on with the other list when its own is
+// exhausted -- and ONE rule that keeps the two lists from starving each other: a rest item of column c is not STARTED before the critical
+// tickets of all columns < c have been taken; a workgroup that finds them missing takes them itself, one after the other, and runs them
+// first (the rest item stays claimed by a workgroup that is working on its dependencies).  The critical workgroups claim unconditionally:
+// should only they be running, their items would wait for rest items nobody can take -- but workgroups are dispatched in index order, so
+// a running critical workgroup (blockIdx = 0 mod 8) implies seven running workgroups of the other kind before it.
+// tests/native/chain_items_check.cpp runs this very function under adversarial delays and with only a prefix of the workgroups ever running.
+// The atomics are the caller's: A::take(list) = fetch_add 1; A::take_below(list, bound) = the same while the counter is below `bound`, else -1.
+struct ChClaim {
+  int have_pending = 0, rest_done = 0, crit_done = 0;
+  ChItem pending{CH_NONE, 0, 0};
+};
+SGP_HD inline int ch_crit_needed(const ChItem& it, int nb) {   // critical tickets that must be out before this rest item may start
+  const int c = it.kind == CH_INV ? it.i - 1 : (it.kind == CH_RHS ? nb : it.c);  // (CH_INV: row it.i of L^-1 reads tiles (i, p), p < i)
+  const int need = 2 * c, all = ch_crit_items(nb);
+  return need < 0 ? 0 : (need > all ? all : need);
+}
+template <class A>
+SGP_HD inline ChItem ch_claim_next(ChClaim& st, bool split, bool crit_wg, int nb, bool want_inv, bool want_rhs, A& a) {
+  const int extra = (want_inv ? ch_inv_items(nb) : 0) + (want_rhs ? 1 : 0);
+  if (!split) {
+    const int k = a.take(0);
+    return k < ch_tile_items(nb) + extra ? ch_list_item(k, nb, want_inv, want_rhs, true) : ChItem{CH_NONE, 0, 0};
+  }
+  const int ncrit = ch_crit_items(nb), nrest = ch_rest_tile_items(nb) + extra;
+  auto crit_item = [](int t) { return ChItem{(t & 1) ? CH_FUSED_S : CH_FUSED_D, t >> 1, (t >> 1) + 2}; };
+  for (;;) {
+    if (st.have_pending) {
+      // ONE atomic step (a compare-and-swap loop): draw the next critical ticket only while the counter is below `need`.  A look followed
+      // by a draw let other workgroups in between, and the ticket drawn could be the pending item's own column's -- FUSED_D(c) waits for
+      // EARLY_D(c): round 6's first version ran it at once and the launch hung on itself (tools/potrf_trace_check.py under a budget of 10).
+      const int t = a.take_below(1, ch_crit_needed(st.pending, nb));
+      if (t < 0) { st.have_pending = 0; return st.pending; }   // every critical ticket of the earlier columns is out
+      return crit_item(t);   // a critical item of an EARLIER column nobody had claimed: this workgroup runs it before its own
+    }
+    if (crit_wg && !st.crit_done) {
+      const int t = a.take(1);
+      if (t < ncrit) return crit_item(t);
+      st.crit_done = 1;
+    }
+    if (!st.rest_done) {
+      const int k = a.take(0);
+      if (k < nrest) { st.pending = ch_list_item(k, nb, want_inv, want_rhs, false); st.have_pending = 1; continue; }
+      st.rest_done = 1;
+    }
+    if (!st.crit_done) {
+      const int t = a.take(1);
+      if (t < ncrit) return crit_item(t);
+      st.crit_done = 1;
+    }
+    return ChItem{CH_NONE, 0, 0};
+  }
+}
+
 // =====================================================================================================================================
 // The ACCESS TABLE of the launch (round 6): for every work item and for the chain workgroup's two roles, the ordered
 // list of what it waits for, reads, writes and raises.  One description for
@@ -82,11 +141,11 @@ SGP_HD inline ChItem ch_dealt_item(const ChDeal& d, int k, int nb, bool want_inv
 // Granularity: a 64 x 64 tile of the matrix (diagonal tiles: their four 16-column panels, which are published one by one), one block
 // of each scratch array.  "ORIG": the caller's entries of a tile, as opposed to the factor's.
 // =====================================================================================================================================
-enum ChFlagKind { CF_READY, CF_ABORT, CF_PRES, CF_PRED, CF_PREADY, CF_PRESE, CF_PREDE, CF_PREADY_L, CF_XREADY_L, CF_CWX, CF_IREADY, CF_LO2R, CF_LO2R_L, CF_TICKET, CF_NKIND };
+enum ChFlagKind { CF_READY, CF_ABORT, CF_PRES, CF_PRED, CF_PREADY, CF_PRESE, CF_PREDE, CF_PREADY_L, CF_XREADY_L, CF_CWX, CF_IREADY, CF_LO2R, CF_LO2R_L, CF_TICKET, CF_TICKET_CRIT, CF_NKIND };
 struct ChFlag { int kind, a, b; };  // READY(i, j) / IREADY(i, j): a = i, b = j; PREADY[_L](j, pb): a = j, b = pb; the others: a = their column / row index
 SGP_HD inline int ch_tile_no(int ti, int tj, int nb) { return tj * nb - (tj * (tj - 1)) / 2 + (ti - tj); }
 // first slot (one slot = DF_FLAG_STRIDE ints = one cache line) of each kind of flag: [ready: ntile | abort | preS: nb | preD: nb | pready: 4 nb |
-// preSE: nb | preDE: nb | pready_l: 4 nb | xready_l: nb | cwx | iready: ntile | lo2r: nb | lo2r_l: nb | ticket]
+// preSE: nb | preDE: nb | pready_l: 4 nb | xready_l: nb | cwx | iready: ntile | lo2r: nb | lo2r_l: nb | ticket | ticket_crit]
 SGP_HD inline int ch_flag_base(int kind, int nb) {
   const int ntile = nb * (nb + 1) / 2;
   switch (kind) {
@@ -103,15 +162,16 @@ SGP_HD inline int ch_flag_base(int kind, int nb) {
     case CF_IREADY: return ntile + 2 + 13 * nb;
     case CF_LO2R: return 2 * ntile + 2 + 13 * nb;
     case CF_LO2R_L: return 2 * ntile + 2 + 14 * nb;
-    case CF_TICKET: return 2 * ntile + 2 + 15 * nb;   // the claim counter of the ticketed deal (not a flag: nobody waits for it)
-    default: return 2 * ntile + 3 + 15 * nb;  // = the number of slots
+    case CF_TICKET: return 2 * ntile + 2 + 15 * nb;   // the claim counters of the ticketed deal (not flags: nobody waits for them)
+    case CF_TICKET_CRIT: return 2 * ntile + 3 + 15 * nb;
+    default: return 2 * ntile + 4 + 15 * nb;  // = the number of slots
   }
 }
 SGP_HD inline int ch_flag_slot(const ChFlag& f, int nb) {
   switch (f.kind) {
     case CF_READY: case CF_IREADY: return ch_flag_base(f.kind, nb) + ch_tile_no(f.a, f.b, nb);
     case CF_PREADY: case CF_PREADY_L: return ch_flag_base(f.kind, nb) + 4 * f.a + f.b;
-    case CF_ABORT: case CF_CWX: case CF_TICKET: return ch_flag_base(f.kind, nb);
+    case CF_ABORT: case CF_CWX: case CF_TICKET: case CF_TICKET_CRIT: return ch_flag_base(f.kind, nb);
     default: return ch_flag_base(f.kind, nb) + f.a;
   }
 }

@@ -362,29 +362,27 @@ static int build_deal_threads(int nb, bool want_inv, bool want_rhs, int nout, in
   return failures;
 }
 
-// Ticketed claim: `nwg` workgroups take the items of the list(s) in order from a shared counter.  Which workgroup gets which ticket
-// depends on timing: the adversary here picks, whenever a workgroup is free, WHICH free workgroup claims next (random), and runs
-// workgroups in random order; since a claimed item only ever waits for earlier tickets or the chain workgroup, every such run must
-// complete.  `lists`: 1 = one list for all; 2 = the critical list for the first `ncrit` workgroups, the rest for the others.
-static int run_ticketed(int nb, bool want_inv, bool want_rhs, int nwg, int lite_policy, unsigned seed, const char* tag) {
+// Ticketed claim (sgp_potrf_items.hpp: ch_claim_next -- the very function the kernel runs, with host counters): `nwg` workgroups are
+// launched, but only the first `running` of them ever run (workgroups are dispatched in index order: the resident set of a launch that
+// shares the GPU is a prefix), and the adversary delays any of those -- and the chain workgroup -- at random.  Every item must be run
+// exactly once and the launch must complete.
+struct HostAtomics {
+  std::vector<int>* ctr;
+  int take(int list) { return (*ctr)[list]++; }
+  int take_below(int list, int bound) { return (*ctr)[list] < bound ? (*ctr)[list]++ : -1; }   // (one atomic step on the GPU too: a CAS loop)
+};
+static int run_ticketed(int nb, bool want_inv, bool want_rhs, int nwg, int running, int lite_policy, unsigned seed, const char* tag) {
   std::map<LocKey, int> loc_ids;
   std::vector<Thread> chain(2);
   chain_threads(nb, loc_ids, chain[0], chain[1]);
-  const std::vector<ChItem> items = all_items(nb, want_inv, want_rhs, false);
-  std::vector<std::vector<Op>> prog(items.size());
-  for (size_t n = 0; n < items.size(); ++n) {
-    Thread t;
-    Recorder r{nb, &loc_ids, &t};
-    ChProgramOptions o;
-    o.lite = lite_of(items[n], lite_policy);
-    ch_item_program(items[n], nb, o, r);
-    prog[n] = t.ops;
-  }
   std::mt19937 rng(seed);
-  std::vector<int> count(nslots_of(nb), 0);
-  size_t next_ticket = 0;
-  struct Wg { int item = -1; size_t at = 0; };
-  std::vector<Wg> wg(nwg);
+  std::vector<int> count(nslots_of(nb), 0), ctr(2, 0);
+  HostAtomics at{&ctr};
+  std::map<std::tuple<int, int, int>, int> ran;
+  for (const ChItem& it : all_items(nb, want_inv, want_rhs, false)) ran[std::make_tuple(it.kind, it.c, it.i)] = 0;
+  struct Wg { ChClaim claim; bool busy = false, finished = false; std::vector<Op> ops; size_t at = 0; ChDeal deal; };
+  std::vector<Wg> wg(running);
+  for (int w = 0; w < running; ++w) wg[w].deal = ch_deal(w, nwg, nb, want_inv, want_rhs);
   std::vector<size_t> cat(2, 0);
   auto step_chain = [&]() {
     bool moved = false;
@@ -405,57 +403,64 @@ static int run_ticketed(int nb, bool want_inv, bool want_rhs, int nwg, int lite_
       }
     return moved;
   };
-  for (;;) {
+  int failures = 0;
+  auto step_wg = [&](Wg& g) {
     bool moved = false;
-    // the adversary: a random subset of the workgroups gets to run this round (the others are "delayed"); the chain workgroup too
-    if (rng() % 4 != 0) moved = step_chain() || moved;
-    std::vector<int> order(nwg);
-    for (int w = 0; w < nwg; ++w) order[w] = w;
-    std::shuffle(order.begin(), order.end(), rng);
-    for (int w : order) {
-      if (rng() % 3 == 0) continue;  // delayed
-      Wg& g = wg[w];
-      if (g.item < 0) {
-        if (next_ticket >= items.size()) continue;
-        g.item = (int)next_ticket++;
-        g.at = 0;
+    for (;;) {
+      if (!g.busy) {
+        if (g.finished) return moved;
+        const ChItem it = ch_claim_next(g.claim, g.deal.split, g.deal.crit_wg, nb, want_inv, want_rhs, at);
         moved = true;
+        if (it.kind == CH_NONE) { g.finished = true; return moved; }
+        auto e = ran.find(std::make_tuple(it.kind, it.c, it.i));
+        if (e == ran.end()) { std::printf("%s: claimed an item that is not in the launch (%s, %d, %d)\n", tag, kind_name(it.kind), it.c, it.i); ++failures; g.finished = true; return moved; }
+        ++e->second;
+        Thread t;
+        Recorder r{nb, &loc_ids, &t};
+        ChProgramOptions o;
+        o.lite = lite_of(it, lite_policy);
+        ch_item_program(it, nb, o, r);
+        g.ops = t.ops;
+        g.at = 0;
+        g.busy = true;
       }
-      const std::vector<Op>& p = prog[g.item];
-      while (g.at < p.size()) {
-        const Op& o = p[g.at];
-        if (o.kind == OP_WAIT && count[o.key] < o.arg) break;
+      while (g.at < g.ops.size()) {
+        const Op& o = g.ops[g.at];
+        if (o.kind == OP_WAIT && count[o.key] < o.arg) return moved;
         if (o.kind == OP_RAISE) ++count[o.key];
         ++g.at;
         moved = true;
       }
-      if (g.at == p.size()) g.item = -1;
+      g.busy = false;
     }
-    bool all_done = next_ticket >= items.size() && cat[0] == chain[0].ops.size() && cat[1] == chain[1].ops.size();
-    for (const Wg& g : wg) all_done = all_done && g.item < 0;
-    if (all_done) return 0;
-    if (!moved) {
-      // nobody ran this round by the adversary's choice, or a real deadlock: run everybody once without delays to tell
-      bool m2 = step_chain();
-      for (Wg& g : wg) {
-        if (g.item < 0 && next_ticket < items.size()) { g.item = (int)next_ticket++; g.at = 0; m2 = true; }
-        if (g.item < 0) continue;
-        const std::vector<Op>& p = prog[g.item];
-        while (g.at < p.size()) {
-          const Op& o = p[g.at];
-          if (o.kind == OP_WAIT && count[o.key] < o.arg) break;
-          if (o.kind == OP_RAISE) ++count[o.key];
-          ++g.at;
-          m2 = true;
-        }
-        if (g.at == p.size()) g.item = -1;
-      }
-      if (!m2) {
-        std::printf("%s: ticketed claim deadlocks with %d workgroups (seed %u), next ticket %zu of %zu\n", tag, nwg, seed, next_ticket, items.size());
-        return 1;
-      }
+  };
+  for (int idle_rounds = 0;;) {
+    bool moved = false;
+    const bool everyone = idle_rounds > 0;  // nothing moved under the adversary's choice: one round without delays tells a deadlock from bad luck
+    if (everyone || rng() % 4 != 0) moved = step_chain() || moved;
+    std::vector<int> order(running);
+    for (int w = 0; w < running; ++w) order[w] = w;
+    std::shuffle(order.begin(), order.end(), rng);
+    for (int w : order) {
+      if (!everyone && rng() % 3 == 0) continue;  // delayed
+      moved = step_wg(wg[w]) || moved;
+    }
+    bool all_done = cat[0] == chain[0].ops.size() && cat[1] == chain[1].ops.size();
+    for (const Wg& g : wg) all_done = all_done && g.finished;
+    if (all_done) break;
+    if (moved) { idle_rounds = 0; continue; }
+    if (++idle_rounds >= 2) {
+      std::printf("%s: ticketed claim deadlocks, %d of %d workgroups running (seed %u); counters %d / %d\n", tag, running, nwg, seed, ctr[0], ctr[1]);
+      return failures + 1;
     }
   }
+  for (auto& e : ran)
+    if (e.second != 1) {
+      std::printf("%s: ticketed claim, %d of %d workgroups: item (%s, %d, %d) run %d times\n", tag, running, nwg, kind_name(std::get<0>(e.first)), std::get<1>(e.first),
+                  std::get<2>(e.first), e.second);
+      if (++failures > 3) break;
+    }
+  return failures;
 }
 
 // Versioned-memory replay of the static deal under a schedule: policy 0 = round-robin one op at a time (everything starts together, the
@@ -586,12 +591,18 @@ int main(int argc, char** argv) {
     for (int inv = 0; inv < 2; ++inv)
       for (int rhs = 0; rhs < 2; ++rhs) {
         if (ch_tile_items(nb) + (inv ? ch_inv_items(nb) : 0) + rhs == 0) continue;
-        for (int nwg : {1, 2, 3, 7, 8, 31, 255})
-          for (unsigned seed = 1; seed <= 3; ++seed) {
-            std::snprintf(tag, sizeof tag, "ticket nb %d inv %d rhs %d", nb, inv, rhs);
-            failures += run_ticketed(nb, inv != 0, rhs != 0, nwg, (int)(seed % 3), seed * 7919u + (unsigned)nb, tag);
-            ++ticket_cases;
+        for (int nwg : {1, 2, 3, 7, 8, 9, 31, 64, 255}) {
+          const int items = ch_tile_items(nb) + (inv ? ch_inv_items(nb) : 0) + rhs;
+          if (nwg > items && nwg != 1) continue;
+          for (int running : {1, 2, 7, 8, 9, 16, nwg}) {
+            if (running > nwg) continue;
+            for (unsigned seed = 1; seed <= 2; ++seed) {
+              std::snprintf(tag, sizeof tag, "ticket nb %d inv %d rhs %d nwg %d", nb, inv, rhs, nwg);
+              failures += run_ticketed(nb, inv != 0, rhs != 0, nwg, running, (int)(seed % 3), seed * 7919u + (unsigned)nb + 31u * (unsigned)running, tag);
+              ++ticket_cases;
+            }
           }
+        }
       }
   // ---- HAZARDS on the happens-before order, items as independent threads (any deal, any schedule)
   for (int nb = 2; nb <= nb_max_hazard; nb = nb < 12 ? nb + 1 : nb + 4)

@@ -84,6 +84,11 @@ MUTATIONS = [
      "      if (fs) v.read(", "H3"),
     ("a block of L^-1 waits for a LATER block of its column (deadlock)", "        v.wait(ChFlag{CF_IREADY, p, c}, 1);",
      "        v.wait(ChFlag{CF_IREADY, p + 1 <= i ? p + 1 : p, c}, 1);", "stuck"),
+    ("the ticketed claim starts a rest item without the critical tickets of the columns before it (starvation)",
+     "      if (t < 0) { st.have_pending = 0; return st.pending; }", "      if (t < 0 || true) { st.have_pending = 0; return st.pending; }", "ticketed claim deadlocks"),
+    ("a helper runs ANY critical ticket it draws, also its own column's (round 6's first version: a look, then a draw -- hung on the GPU)",
+     "      const int t = a.take_below(1, ch_crit_needed(st.pending, nb));", "      const int t = a.take_below(1, ch_crit_needed(st.pending, nb) + 1);",
+     "ticketed claim deadlocks"),
     ("EARLY_D publishes twice", "      else { v.write(ChLoc{CL_DPE, i, 0}); v.raise(ChFlag{CF_PREDE, i, 0}, false); }",
      "      else { v.write(ChLoc{CL_DPE, i, 0}); v.raise(ChFlag{CF_PREDE, i, 0}, false); v.raise(ChFlag{CF_PREDE, i, 0}, false); }", "raised 2 times"),
 ]

@@ -68,16 +68,38 @@ def decode(code):
 
 
 total_items = total_steps = bad = 0
-for M, inv in ((192, False), (192, True), (384, True), (512, False), (512, True), (1024, True), (1024, False), (2048, True)):
+BUDGET = int(os.environ.get("BUDGET", "0"))      # workgroups of the launch (sgp_set_cu_budget): few workgroups, many items each
+CASES = ((192, False), (192, True), (384, True), (512, False), (512, True), (1024, True), (1024, False), (2048, True))
+if os.environ.get("CASES"):
+    CASES = tuple((int(c.split(":")[0]), c.split(":")[1] == "1") for c in os.environ["CASES"].split(","))
+for M, inv in CASES:
     g = torch.Generator().manual_seed(M)
     R = torch.randn(M, M + 3, dtype=torch.float64, generator=g)
     K = (R @ R.T / M + torch.eye(M, dtype=torch.float64)).to(eng.device)
     fetch()  # clear
-    if inv:
-        eng.kuu_factor(K)
-    else:
-        eng.chol_lower(K)
+    lib.sgp_set_cu_budget(BUDGET)
+    try:
+        _, info = eng.kuu_factor(K) if inv else eng.chol_lower(K)
+    finally:
+        lib.sgp_set_cu_budget(0)
     logs, longest = fetch()
+    if int(info.item()) != 0:
+        bad += 1
+        print("M %d inv %d budget %d: info %d" % (M, inv, BUDGET, int(info.item())))
+        if os.environ.get("VERBOSE"):
+            names = ["ES", "ED", "FS", "FD", "T", "INV", "RHS"]
+            for w in range(0, 258):
+                if logs[w]:
+                    out = []
+                    for code in logs[w]:
+                        tag = (code >> 28) & 15
+                        if tag == 4:
+                            out.append("| %s(%d,%d)" % (names[(code >> 20) & 255], (code >> 10) & 1023, code & 1023))
+                        elif tag == 6:
+                            out.append("| step %d" % (code & 0xFFFF))
+                        elif tag in (1, 2):
+                            out.append(decode(code))
+                    print("  wg %3d: %s" % (w, " ".join(out[-40:])))
     assert longest < LEN, "trace buffer too short"
     nb = (M + 127) // 128 * 2
     items, chain, cwx = table(nb, inv)
