@@ -16,7 +16,7 @@ SGP_MAX_DIM = 32
 SGP_MAX_INDUCING = 4096
 KERNEL_IDS = {"rbf": 0, "matern32": 1, "matern52": 2, "composite": 3}
 COMP_LEN = 33  # SGP_COMP_LEN: doubles in a composite-kernel parameter block (include/sgp.h)
-OPT_CONTRACTION, OPT_ASM_OVERLAP, OPT_KFU_BUDGET_BYTES, OPT_COND_LIMIT, OPT_CU_BUDGET, OPT_TIMING = range(6)
+OPT_CONTRACTION, OPT_ASM_OVERLAP, OPT_KFU_BUDGET_BYTES, OPT_COND_LIMIT, OPT_CU_BUDGET, OPT_TIMING, OPT_SHARED_DEVICE = range(7)
 OUT_F, OUT_LOGMARG, OUT_TRACE, OUT_LOGDETB, OUT_QUAD, OUT_TRW, OUT_S2BAR, OUT_KAPPABAR, OUT_LEN = range(9)
 
 
@@ -44,6 +44,7 @@ PROTOTYPES = {
     "sgp_ctx_device": (_i32, [_vp]),
     "sgp_ctx_set_option": (_i32, [_vp, _i32, _dbl]),
     "sgp_ctx_get_option": (_dbl, [_vp, _i32]),
+    "sgp_ctx_bind_thread": (None, [_vp]),
     "sgp_ctx_set_pass1_gate": (None, [_vp, _vp]),
     "sgp_ctx_contraction_last": (_i32, [_vp]),
     "sgp_ctx_contraction_would_use_i8": (_i32, [_vp, _i64, _i32]),
@@ -123,6 +124,8 @@ PROTOTYPES = {
                                           _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_fwd_extended_ex": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_phibar_dd_workspace_bytes": (_sz, [_i32]),
+    "sgp_phibar_dd": (_i32, [_vp, _vp, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats_ex": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,

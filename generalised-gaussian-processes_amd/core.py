@@ -210,12 +210,14 @@ class CollapsedBound:
         self.extended_level = 2
         self.extended_range = 16384.0
         self.extended_grad_range = 3.0
+        self.extended_dd_phibar = True   # the extended order's explicit Phibar formed in double-double (sgp_phibar_dd)
         self.guard = GuardState()
         self.last_estimate = None   # the estimate (exact, or the bound of a whitened evaluation) of the last guarded evaluation
         self.last_tier = None       # the tier the last evaluation was accepted in
         self.n_guard_reruns = 0     # evaluations repeated in a higher tier
         self.n_direct_whitened = 0  # evaluations that started above the streaming order on the strength of a prediction
         self.n_extended = 0         # evaluations that ran in the extended order
+        self.n_timeout_retries = 0  # evaluations repeated behind a device time-out (the engine switched to the shared-device mode)
         self._phi_diag = None
 
     # ------------------------------------------------------------------ internals
@@ -400,8 +402,15 @@ class CollapsedBound:
             packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu, level=self.extended_level,
                                           **({"phi_diag": diag} if diag is not None else {}))
             self._allreduce_stats(packed, M)
+            # pass 2 of this order takes the explicit Phibar = L^-T C L^-1 / (2 s2); formed by two fp64 products its own rounding
+            # (eps |L^-T| |C| |L^-1| >> eps |Phibar|) is what limits the gradients -- formed in double-double from the whitened core C the
+            # bound returns they are 5-15 x closer (tests/studies/explicit_phibar_pass2.py; +1.3 ms at M = 1024)
+            dd = with_adjoints and self.extended_dd_phibar and hasattr(e, "phibar_dd")
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
-                          result=result, whitened=True)
+                          result=result, whitened=True, **({"want_cw": True} if dd else {}))
+            if dd:
+                res["Phibar"], _ = e.phibar_dd(res["Cw"], linv, s2)
+                res["Cw"] = None   # (pass 2 of this order is the explicit one: _pass2 takes the factored route when a core is handed on)
             if report:
                 self._allreduce(diag[:M])  # (ranks hold the diagonal of their own shard's Phi)
                 e.streaming_error_report(diag, 1, self._trace_buf(), sf2, s2, self.N, M, result)
@@ -505,7 +514,23 @@ class CollapsedBound:
         # earlier: pass 2 fills the chip and runs the 28 us longer that the side stream takes from it, profiles/r05_kuu_bwd_side_stream_c3_timeline.txt)
         e.kuu_bwd(Z, ls, sf2, res["Kuubar"], g, self.kernel, want_gz=want_gz)
 
-    def _evaluate(self, Z, ls, sf2, s2, with_grad=False, want_gz=False, want_factors=False, grad_reach=None, strict=False):
+    def _evaluate(self, *args, **kw):
+        """`_evaluate_once`, and ONE more attempt behind a device time-out: the single-launch Cholesky deals its work items statically
+        and needs all its workgroups resident (the fast way while this process has the GPU to itself); a second process on the same
+        device -- joblib workers as in the reference's experiments/regression.py:219-231, ranks sharing a GPU -- can starve such a launch
+        into SGP_INFO_TIMEOUT.  The first time-out switches this engine's context to SGP_OPT_SHARED_DEVICE (items claimed by ticket, by
+        workgroups that are running: include/sgp.h) for good and the evaluation is repeated; a second time-out is raised."""
+        try:
+            return self._evaluate_once(*args, **kw)
+        except SgpTimeoutError:
+            e = self.engine
+            if "shared_device" not in getattr(e, "OPTIONS", {}) or e.get_option("shared_device") != 0:
+                raise
+            e.set_option("shared_device", 1)
+            self.n_timeout_retries += 1
+            return self._evaluate_once(*args, **kw)
+
+    def _evaluate_once(self, Z, ls, sf2, s2, with_grad=False, want_gz=False, want_factors=False, grad_reach=None, strict=False):
         """ONE evaluation through the guard -- the driver value / value_and_grad / factors share.  Runs attempts (every repeat goes to a
         strictly higher tier; strict: once, first, to the LOWER tier the evaluation's own estimate names) until `_review` accepts.
         Returns (res, out (host), info, host buffer, head) of the accepted attempt; with_grad: the packed gradient sits behind `head`."""

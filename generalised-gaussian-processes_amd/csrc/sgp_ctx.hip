@@ -22,6 +22,7 @@ static void ctx_init(Ctx& c, int device) {
   c.syrk_waves = env_int("SGP_SYRK_WAVES", 4);
   c.syrk_glds = env_int("SGP_SYRK_GLDS", 0);
   c.i8_prio = env_int("SGP_I8_PRIO", 0);
+  c.shared_device = env_int("SGP_SHARED_DEVICE", 0) != 0 ? 1 : 0;
 }
 
 Ctx& default_ctx() {
@@ -35,8 +36,10 @@ Ctx& default_ctx() {
   return *c;
 }
 
-static thread_local Ctx* t_cur = nullptr;
-Ctx& cur_ctx() { return t_cur ? *t_cur : default_ctx(); }
+static thread_local Ctx* t_cur = nullptr;    // installed by a sgp_ctx_* entry point for its own duration (CtxScope)
+static thread_local Ctx* t_bound = nullptr;  // sgp_ctx_bind_thread: what the context-free entry points of this thread run in
+Ctx& cur_ctx() { return t_cur ? *t_cur : (t_bound ? *t_bound : default_ctx()); }
+void bind_thread_ctx(void* ctx) { t_bound = static_cast<Ctx*>(ctx); }
 CtxScope::CtxScope(void* ctx) : prev(t_cur) { t_cur = ctx ? static_cast<Ctx*>(ctx) : &default_ctx(); }
 CtxScope::~CtxScope() { t_cur = prev; }
 
@@ -100,6 +103,9 @@ extern "C" int sgp_ctx_set_option(sgp_ctx* ctx, int option, double value) {
     case SGP_OPT_TIMING:
       c.timing = value != 0.0 ? 1 : 0;
       return SGP_OK;
+    case SGP_OPT_SHARED_DEVICE:
+      c.shared_device = value != 0.0 ? 1 : 0;
+      return SGP_OK;
     default:
       return SGP_ERR_ARG;
   }
@@ -114,9 +120,12 @@ extern "C" double sgp_ctx_get_option(const sgp_ctx* ctx, int option) {
     case SGP_OPT_COND_LIMIT: return c.cond_limit;
     case SGP_OPT_CU_BUDGET: return (double)c.cu_budget;
     case SGP_OPT_TIMING: return (double)c.timing;
+    case SGP_OPT_SHARED_DEVICE: return (double)c.shared_device;
     default: return -1.0;
   }
 }
+
+extern "C" void sgp_ctx_bind_thread(sgp_ctx* ctx) { sgp::bind_thread_ctx(ctx); }
 
 extern "C" int sgp_ctx_device(const sgp_ctx* ctx) { return (ctx ? *reinterpret_cast<const Ctx*>(ctx) : default_ctx()).device; }
 

@@ -21,6 +21,7 @@ struct Ctx {
   double cond_limit = 1e13;     // SGP_OPT_COND_LIMIT
   int cu_budget = 0;            // SGP_OPT_CU_BUDGET (0 = the whole device)
   int timing = 0;               // SGP_OPT_TIMING
+  int shared_device = 0;        // SGP_OPT_SHARED_DEVICE: ticketed claim in the chain-workgroup Cholesky (env SGP_SHARED_DEVICE at creation)
   // ---- tuning knobs of the environment, read ONCE when the context is created ----
   int syrk_skip_upper = 1, syrk_waves = 4, syrk_glds = 0, i8_prio = 0;
   // ---- state ----
@@ -34,7 +35,10 @@ struct Ctx {
 };
 
 Ctx& default_ctx();
-Ctx& cur_ctx();  // the context of the entry point running on this host thread (the default context outside a sgp_ctx_* call)
+Ctx& cur_ctx();  // the context of the entry point running on this host thread: a sgp_ctx_* call's own, else the one bound to the thread
+                 // (sgp_ctx_bind_thread), else the default context
+
+void bind_thread_ctx(void* ctx);
 
 struct CtxScope {
   Ctx* prev;

@@ -647,8 +647,9 @@ bool potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
   // launch modes of the chain kernel (sgp_potrf_chain.hpp: CH_MODE_*), read once
   static const int env_mode = ((getenv("SGP_POTRF_ACQUIRE") && atoi(getenv("SGP_POTRF_ACQUIRE"))) ? CH_MODE_ACQUIRE : 0) |
                               ((getenv("SGP_POTRF_LIGHT") && !atoi(getenv("SGP_POTRF_LIGHT"))) ? CH_MODE_NOLIGHT : 0) |
-                              ((getenv("SGP_POTRF_TICKET") && !atoi(getenv("SGP_POTRF_TICKET"))) ? 0 : CH_MODE_TICKET);
-  int mode = env_mode;
+                              ((getenv("SGP_POTRF_TICKET") && atoi(getenv("SGP_POTRF_TICKET"))) ? CH_MODE_TICKET : 0);
+  // the ticketed claim where the caller says the GPU is shared (SGP_OPT_SHARED_DEVICE of the call's context; SGP_POTRF_TICKET=1 forces it)
+  int mode = env_mode | (cur_ctx().shared_device ? CH_MODE_TICKET : 0);
   // The acquire-free consumer side (and the light same-XCD hand-overs) rest on "one writer per cache line, no reader before its flag":
   // tiles and scratch blocks must not share 128-byte lines.  The scratch blocks never do (potrf_scratch_ints: whole lines per flag, 8 KB+
   // per block, `scratch` itself checked here); a caller's matrix with an odd leading dimension or base address does -- such a call takes

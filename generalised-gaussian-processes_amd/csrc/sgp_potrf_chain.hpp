@@ -137,11 +137,11 @@ __device__ __forceinline__ ChScratch ch_scratch(int* scratch, int nb) {
   return s;
 }
 
-// Launch modes (potrf_lower: environment knobs read once; A/B and diagnosis, the default is 0 | CH_MODE_TICKET)
+// Launch modes (potrf_lower: environment knobs read once, A/B and diagnosis; the ticketed claim is SGP_OPT_SHARED_DEVICE of the call's context)
 constexpr int CH_MODE_ACQUIRE = 1;   // SGP_POTRF_ACQUIRE=1: an agent-scope acquire (buffer_inv sc1) behind every successful flag poll -- drops the
                                      // "never touched before its publication" invariant the consumer side otherwise relies on (checker: H4)
 constexpr int CH_MODE_NOLIGHT = 2;   // SGP_POTRF_LIGHT=0: no same-XCD light flags / publications, every hand-over takes the ordinary release path
-constexpr int CH_MODE_TICKET = 4;    // SGP_POTRF_TICKET=0 clears it: the static deal of sgp_potrf_items.hpp instead of the ticketed claim
+constexpr int CH_MODE_TICKET = 4;    // SGP_OPT_SHARED_DEVICE (or SGP_POTRF_TICKET=1): the ticketed claim of sgp_potrf_items.hpp instead of the static deal
 
 // Trace build (-DSGP_CH_TRACE, tools/potrf_trace_check.py): every wait that returned and every flag raised, per workgroup, in the flag
 // numbering of the access table -- the kernel's real synchronisation held against ch_item_program / ch_chain_*_program.
@@ -627,10 +627,10 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
 
   // ---- which list, and: does this workgroup really share the chain workgroup's L2? ----
   const bool want_inv = Linv != nullptr, want_rhs = rhs != nullptr;
-  // Which items: a TICKETED claim (default; sgp_potrf_items.hpp: ch_claim_next) -- an item is only ever held by a RUNNING workgroup and waits
-  // only for items claimed before it and for the chain workgroup, so progress no longer needs every workgroup of the launch to be resident
-  // at once (two processes on one GPU, a CU-masked stream: VERDICT r5 weak-5).  The arithmetic of an item does not depend on who runs it:
-  // same bits as the static deal (SGP_POTRF_TICKET=0), which stays for A/B.
+  // Which items: the static deal (default: fastest when the launch has the device to itself -- C3 0.41 against 0.45 ms per evaluation),
+  // or a TICKETED claim (SGP_OPT_SHARED_DEVICE; sgp_potrf_items.hpp: ch_claim_next) -- an item is only ever held by a RUNNING workgroup and
+  // waits only for items claimed before it and for the chain workgroup, so progress no longer needs every workgroup of the launch to be
+  // resident at once (two processes on one GPU: VERDICT r5 weak-5).  The arithmetic of an item does not depend on who runs it: same bits.
   const bool ticketed = (mode & CH_MODE_TICKET) != 0;
   const ChDeal deal = ch_deal(ow, nout, nb, want_inv, want_rhs);  // (sgp_potrf_items.hpp)
   const int first = deal.first, stride = deal.stride, count = deal.count;
@@ -638,6 +638,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
     int* ctr[2];
     DfShared& sh;
     int tid;
+    int first_wave;   // critical tickets the critical workgroups draw by themselves when they start
     __device__ __forceinline__ int bcast(int v) {
       __syncthreads();  // (sh.bad: its previous readers are behind this barrier)
       if (tid == 0) sh.bad = v;
@@ -655,9 +656,11 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
       int v = -1;
       if (tid == 0) {
         int cur = df_flag_load(ctr[list]);
-        // a little patience first (the critical workgroups take their own tickets within the launch's first microseconds: helping then
-        // would only move a critical item away from the chain workgroup's XCD)
-        for (int spins = 0; cur < bound && spins < 64; ++spins) {
+        // Patience, but only while the launch is still starting: the critical workgroups (blockIdx 8, 16, ...) are dispatched behind the
+        // others and draw their first tickets a few microseconds into the launch -- a helper that steps in before that only moves a
+        // critical item away from the chain workgroup's XCD (first version, 64 polls of patience: 10 of 28 critical items at M = 1024 ran
+        // elsewhere).  Once `first_wave` tickets are out the counter says what it says: no waiting.
+        for (int spins = 0; cur < bound && cur < first_wave && spins < 512; ++spins) {
           __builtin_amdgcn_s_sleep(2);
           cur = df_flag_load(ctr[list]);
         }
@@ -670,7 +673,7 @@ __device__ __forceinline__ void chain_outside(double* A, int64_t ld, int nb, ChS
       }
       return bcast(v);
     }
-  } atomics{{sc.ticket, sc.ticket_crit}, sh, tid};
+  } atomics{{sc.ticket, sc.ticket_crit}, sh, tid, nout / 8 < ch_crit_items(nb) ? nout / 8 : ch_crit_items(nb)};
   ChClaim claim;
   bool local = false;  // same XCD as the chain workgroup (decided once it has said where it runs; asked only by the fused items)
   bool local_known = false;

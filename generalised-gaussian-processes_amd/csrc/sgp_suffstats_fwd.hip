@@ -785,6 +785,61 @@ __global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restric
       Clo[o] = l;
     }
 }
+// ---- Phibar in double-double (round 6; tests/studies/explicit_phibar_pass2.py) ---------------------------------
+// The extended order's pass 2 takes the EXPLICIT Phibar = L^-T (C / 2 s2) L^-1, whose cond(K_uu)-sized entries cancel in Kbar = 2 K Phibar.
+// The study separates three error sources against an 80-bit yardstick: the fp64 FORMATION of Phibar (two MFMA products whose own
+// rounding is eps |L^-T| |C| |L^-1| >> eps |Phibar|) is what dominates today (a long-double product with the fp64-formed matrix is no
+// better than the fp64 product); formed in double-double and rounded to one word the gradients are 5-15 x closer; with the low word
+// applied as well (a 3-digit product suffices) 35-700 x.  This routine is the formation: Cs = C / (2 s2) padded, G = (L^-1)^T,
+// Y^T = (Cs G^T)^T = (Cs L^-1)^T and Phibar = Y^T G^T = L^-T Cs L^-1 by the double-double VALU GEMM above (0.6 ms each at M = 1024).
+__global__ __launch_bounds__(256) void phibar_dd_prep_kernel(const double* __restrict__ Cw, int M, int Mp, double scale,
+                                                             const double* __restrict__ Linv, double* __restrict__ Cs,
+                                                             double* __restrict__ zeros, double* __restrict__ G) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.y * 32, bj = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = 0; k < 4; ++k) {
+    const int i = bi + ty + 8 * k, j = bj + tx;
+    Cs[(size_t)i * Mp + j] = (i < M && j < M) ? scale * Cw[(size_t)i * M + j] : 0.0;
+    zeros[(size_t)i * Mp + j] = 0.0;
+    tile[ty + 8 * k][tx] = Linv[(size_t)i * Mp + j];
+  }
+  __syncthreads();
+  for (int k = 0; k < 4; ++k) G[(size_t)(bj + ty + 8 * k) * Mp + bi + tx] = tile[tx][ty + 8 * k];
+}
+// (hi, lo) of the lower triangle on both sides, cropped to M x M (ld M)
+__global__ __launch_bounds__(256) void phibar_dd_out_kernel(const double* __restrict__ Ph, const double* __restrict__ Pl, int M, int Mp,
+                                                            double* __restrict__ out_hi, double* __restrict__ out_lo) {
+  const int64_t total = (int64_t)M * M;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+    const int64_t p = r >= c ? (int64_t)r * Mp + c : (int64_t)c * Mp + r;
+    out_hi[e] = Ph[p];
+    if (out_lo) out_lo[e] = Pl[p];
+  }
+}
+extern "C" size_t sgp_phibar_dd_workspace_bytes(int M) {
+  if (M <= 0 || M > SGP_MAX_INDUCING) return 0;
+  const size_t Mp = (size_t)(M + 127) / 128 * 128;
+  return 7 * Mp * Mp * sizeof(double) + 256;
+}
+extern "C" int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, double s2, double* Phibar_hi, double* Phibar_lo, void* ws,
+                             size_t ws_bytes, sgp_stream_t stream) {
+  if (!Cw || !kuu_linv || !Phibar_hi || !(s2 > 0.0)) return SGP_ERR_ARG;
+  if (M <= 0 || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (!ws || ws_bytes < sgp_phibar_dd_workspace_bytes(M)) return SGP_ERR_WORKSPACE;
+  const int Mp = (M + 127) / 128 * 128;
+  const size_t mm = (size_t)Mp * Mp;
+  double* base = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+  double *Cs = base, *zeros = Cs + mm, *G = zeros + mm, *Yh = G + mm, *Yl = Yh + mm, *Ph = Yl + mm, *Pl = Ph + mm;
+  hipStream_t st = (hipStream_t)stream;
+  phibar_dd_prep_kernel<<<dim3(Mp / 32, Mp / 32), 256, 0, st>>>(Cw, M, Mp, 0.5 / s2, kuu_linv, Cs, zeros, G);
+  const dim3 g(Mp / DDT, Mp / DDT);
+  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(Cs, zeros, G, Mp, Yh, Yl, 1);   // Y^T = (Cs L^-1)^T
+  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(Yh, Yl, G, Mp, Ph, Pl, 0);      // Phibar = Y^T (L^-1) = L^-T Cs L^-1
+  phibar_dd_out_kernel<<<1024, 256, 0, st>>>(Ph, Pl, M, Mp, Phibar_hi, Phibar_lo);
+  return check_launch();
+}
+
 // W (M x M, ld M) = scale * (Wh + Wl), the lower triangle's value on both sides (the two products round the two triangles differently)
 __global__ __launch_bounds__(256) void ext_w_out_kernel(const double* __restrict__ Wh, const double* __restrict__ Wl, int M, int Mp,
                                                         double scale, double* __restrict__ W) {

@@ -41,7 +41,8 @@ class HipEngine:
     process-wide setters (``lib.sgp_set_contraction`` ...) act on."""
 
     OPTIONS = {"contraction": _lib.OPT_CONTRACTION, "asm_overlap": _lib.OPT_ASM_OVERLAP, "kfu_budget_bytes": _lib.OPT_KFU_BUDGET_BYTES,
-               "cond_limit": _lib.OPT_COND_LIMIT, "cu_budget": _lib.OPT_CU_BUDGET, "timing": _lib.OPT_TIMING}
+               "cond_limit": _lib.OPT_COND_LIMIT, "cu_budget": _lib.OPT_CU_BUDGET, "timing": _lib.OPT_TIMING,
+               "shared_device": _lib.OPT_SHARED_DEVICE}
 
     def __init__(self, device: Optional[torch.device] = None, own_context: bool = False):
         self.lib = _lib.load_library()
@@ -65,6 +66,37 @@ class HipEngine:
                 pass
 
     # ------------------------------------------------------------------ context
+    class _ContextFree:
+        """The entry points that take no context argument (sgp_chol_lower, sgp_predict, the sgp_svgp_* and sgp_small_* families), called
+        with this engine's context bound to the calling thread for the duration of the call (include/sgp.h: sgp_ctx_bind_thread), so
+        that they read ITS options -- CU budget, conditioning limit, shared-device mode.  An engine on the default context calls straight
+        through."""
+
+        def __init__(self, eng):
+            self._eng = eng
+
+        def __getattr__(self, name):
+            eng = self._eng
+            fn = getattr(eng.lib, name)
+            if not eng._ctx:
+                return fn
+            bind = eng.lib.sgp_ctx_bind_thread
+
+            def call(*a):
+                bind(C.c_void_p(eng._ctx))
+                try:
+                    return fn(*a)
+                finally:
+                    bind(C.c_void_p(0))
+            return call
+
+    @property
+    def _cf(self):
+        cf = self.__dict__.get("_cf_obj")
+        if cf is None:
+            cf = self.__dict__["_cf_obj"] = HipEngine._ContextFree(self)
+        return cf
+
     def _c(self):
         return C.c_void_p(self._ctx) if self._ctx else C.c_void_p(0)
 
@@ -252,6 +284,19 @@ class HipEngine:
         _lib.check("sgp_suffstats_fwd_extended", st)
         return out
 
+    def phibar_dd(self, Cw: torch.Tensor, kuu_linv: torch.Tensor, s2: float, want_lo: bool = False):
+        """Phibar = L^-T (Cw / 2 s2) L^-1 formed in double-double (include/sgp.h: sgp_phibar_dd): (leading word, trailing word or None),
+        M x M each.  The leading word replaces the fp64-formed Phibar of ``bound(..., whitened=True)`` in the extended order's pass 2."""
+        M = Cw.shape[0]
+        self._chk(Cw, "Cw"), self._chk(kuu_linv, "kuu_linv")
+        hi = self.empty(M, M)
+        lo = self.empty(M, M) if want_lo else None
+        ws = self._workspace("phibar_dd", self.lib.sgp_phibar_dd_workspace_bytes(M))
+        st = self.lib.sgp_phibar_dd(self._ptr(Cw), self._ptr(kuu_linv), M, float(s2), self._ptr(hi), self._ptr(lo) if want_lo else C.c_void_p(0),
+                                    self._ptr(ws), ws.numel(), self._stream())
+        _lib.check("sgp_phibar_dd", st)
+        return hi, lo
+
     def pack_lower(self, stats: torch.Tensor, M: int) -> torch.Tensor:
         """[lower triangle of Phi | b | yy | kappa]: what crosses xGMI (half the bytes of ``stats``)."""
         tri = self.empty(self.lib.sgp_stats_packed_len(M))
@@ -389,7 +434,7 @@ class HipEngine:
 
     # ------------------------------------------------------------------ single-launch path for small problems
     def small_supported(self, N: int, M: int, d: int, kernel="rbf") -> bool:
-        return bool(self.lib.sgp_small_supported(int(N), int(M), int(d), _kernel_id(kernel)))
+        return bool(self._cf.sgp_small_supported(int(N), int(M), int(d), _kernel_id(kernel)))
 
     def _small_ws(self, N, M, d):
         nbytes = self.lib.sgp_small_workspace_bytes(N, M, d)
@@ -449,13 +494,13 @@ class HipEngine:
             if want_gz:
                 raise ValueError("the single-launch path has no dF/dZ for composite kernels")
             cargs = self._composite_args(composite, bool(mode))
-            st = self.lib.sgp_small_eval_composite(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), *cargs, N, M, d,
+            st = self._cf.sgp_small_eval_composite(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), *cargs, N, M, d,
                                                    float(jitter), int(mode), 1 if want_grad else 0, self._ptr(out),
                                                    C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
             _lib.check("sgp_small_eval_composite", st)
             return out, None, info
         gz = self.empty(M, d) if (want_grad and want_gz) else None
-        st = self.lib.sgp_small_eval(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), N, M, d, _kernel_id(kernel),
+        st = self._cf.sgp_small_eval(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(theta), N, M, d, _kernel_id(kernel),
                                      float(jitter), int(mode), 1 if want_grad else 0, self._ptr(out), self._ptr(gz),
                                      C.c_void_p(info.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_small_eval", st)
@@ -476,7 +521,7 @@ class HipEngine:
         gz = self.empty(S, M, d) if (want_grad and want_gz) else None
         infos = torch.zeros(S, dtype=torch.int32, device=self.device)
         scratch = self.empty(d + 2)
-        st = self.lib.sgp_small_eval_batch(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(thetas), S, N, M, d,
+        st = self._cf.sgp_small_eval_batch(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._ptr(thetas), S, N, M, d,
                                            _kernel_id(kernel), float(jitter), int(mode), 1 if want_grad else 0, self._ptr(scratch),
                                            self._ptr(outs), self._ptr(gz), C.c_void_p(infos.data_ptr()), self._ptr(ws), ws.numel(),
                                            self._stream())
@@ -514,9 +559,9 @@ class HipEngine:
                 self._stream())
         if is_comp:
             cargs = self._composite_args(composite, True)
-            _lib.check("sgp_small_nuts_composite", self.lib.sgp_small_nuts_composite(*head, *cargs, N, M, d, *tail))
+            _lib.check("sgp_small_nuts_composite", self._cf.sgp_small_nuts_composite(*head, *cargs, N, M, d, *tail))
         else:
-            _lib.check("sgp_small_nuts", self.lib.sgp_small_nuts(*head, N, M, d, _kernel_id(kernel), *tail))
+            _lib.check("sgp_small_nuts", self._cf.sgp_small_nuts(*head, N, M, d, _kernel_id(kernel), *tail))
         h = stats.to("cpu")
         c = counters.to("cpu")
         res = {"samples": samples.to("cpu"), "stats": h[: n_draws * (cols - 1)].reshape(n_draws, cols - 1),
@@ -603,7 +648,7 @@ class HipEngine:
         cov = self.empty(T, T) if full_cov else None
         nbytes = self.lib.sgp_predict_workspace_bytes(T, M, d, 1 if full_cov else 0)
         ws = self._workspace("predict", nbytes)
-        st = self.lib.sgp_predict(
+        st = self._cf.sgp_predict(
             self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), float(s2), self._ptr(factors), M, d,
             _kernel_id(kernel), 1 if pred_noise else 0, self._ptr(mean), self._ptr(var), self._ptr(cov),
             self._ptr(ws), ws.numel(), self._stream())
@@ -632,7 +677,7 @@ class HipEngine:
         if nbytes == 0:
             raise ValueError("unsupported SVGP shape B=%d M=%d d=%d" % (B, M, d))
         ws = self._workspace("svgp", nbytes)
-        st = self.lib.sgp_svgp_elbo(
+        st = self._cf.sgp_svgp_elbo(
             self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(s2), float(jitter),
             self._ptr(m), self._ptr(LS), int(N_total), M, d, _kernel_id(kernel), lik, 1 if with_grads else 0, self._ptr(out),
             self._ptr(g.get("g_m")), self._ptr(g.get("g_LS")), self._ptr(g.get("g_Z")), self._ptr(g.get("g_ls")),
@@ -675,20 +720,20 @@ class HipEngine:
             # between, so that they reach the host while the device is still busy with the gradients)
             head = (self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, S, inv, sf2c, s2c, float(jitter), self._ptr(m), self._ptr(LS),
                     int(N_total), M, d, _kernel_id(kernel), lik)
-            st = self.lib.sgp_svgp_elbo_batch_forward(*head, self._ptr(out), self._ptr(g["g_s2"]), self._ptr(info), self._ptr(ws),
+            st = self._cf.sgp_svgp_elbo_batch_forward(*head, self._ptr(out), self._ptr(g["g_s2"]), self._ptr(info), self._ptr(ws),
                                                       ws.numel(), self._stream())
             _lib.check("sgp_svgp_elbo_batch_forward", st)
             keep = (Xb, yb, Z, m, LS, ws)  # the buffers the deferred call reads
 
             def reverse():
-                st2 = self.lib.sgp_svgp_elbo_batch_reverse(*head, self._ptr(g["g_m"]), self._ptr(g["g_LS"]), self._ptr(g["g_Z"]),
+                st2 = self._cf.sgp_svgp_elbo_batch_reverse(*head, self._ptr(g["g_m"]), self._ptr(g["g_LS"]), self._ptr(g["g_Z"]),
                                                            self._ptr(g["g_ls"]), self._ptr(g["g_sf2"]), self._ptr(keep[5]), keep[5].numel(),
                                                            self._stream())
                 _lib.check("sgp_svgp_elbo_batch_reverse", st2)
 
             res["reverse"] = reverse
             return res
-        st = self.lib.sgp_svgp_elbo_batch(
+        st = self._cf.sgp_svgp_elbo_batch(
             self._ptr(Xb), d, self._ptr(yb), B, self._ptr(Z), d, S, inv, sf2c, s2c, float(jitter), self._ptr(m), self._ptr(LS),
             int(N_total), M, d, _kernel_id(kernel), lik, 1 if with_grads else 0, self._ptr(out),
             self._ptr(g.get("g_m")), self._ptr(g.get("g_LS")), self._ptr(g.get("g_Z")), self._ptr(g.get("g_ls")),
@@ -722,7 +767,7 @@ class HipEngine:
                 whole = tn == T
                 mc, vc = (mean[s0:s0 + n], var[s0:s0 + n]) if whole else (self.empty(n, tn), self.empty(n, tn))
                 ic = info[s0:s0 + n] if whole else torch.empty(n, dtype=torch.int32, device=self.device)
-                st = self.lib.sgp_svgp_predict_batch(self._ptr(Xs[t0:t0 + tn]), d, tn, self._ptr(Z), d, n, inv, sf2c, float(jitter),
+                st = self._cf.sgp_svgp_predict_batch(self._ptr(Xs[t0:t0 + tn]), d, tn, self._ptr(Z), d, n, inv, sf2c, float(jitter),
                                                      self._ptr(m), self._ptr(LS), M, d, _kernel_id(kernel), self._ptr(mc), self._ptr(vc),
                                                      C.c_void_p(ic.data_ptr()), self._ptr(ws), ws.numel(), self._stream())
                 _lib.check("sgp_svgp_predict_batch", st)
@@ -791,7 +836,7 @@ class HipEngine:
         mean, var = self.empty(T), self.empty(T)
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
         ws = self._workspace("svgp", self.lib.sgp_svgp_workspace_bytes(T, M, d))
-        st = self.lib.sgp_svgp_predict(self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(jitter),
+        st = self._cf.sgp_svgp_predict(self._ptr(Xs), d, T, self._ptr(Z), d, self._inv_ls(ls, d), float(sf2), float(jitter),
                                        self._ptr(m), self._ptr(LS), M, d, _kernel_id(kernel), self._ptr(mean), self._ptr(var),
                                        self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_svgp_predict", st)
@@ -803,7 +848,7 @@ class HipEngine:
         A = A.clone().contiguous()
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
         ws = self._workspace("chol", self.lib.sgp_chol_workspace_bytes(M))
-        st = self.lib.sgp_chol_lower(self._ptr(A), M, M, self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
+        st = self._cf.sgp_chol_lower(self._ptr(A), M, M, self._ptr(info), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_chol_lower", st)
         return A, info
 
@@ -811,7 +856,7 @@ class HipEngine:
         M, k = B.shape
         B = B.clone().contiguous()
         ws = self._workspace("trsm", self.lib.sgp_trsm_workspace_bytes(M, k))
-        st = self.lib.sgp_trsm_lower(self._ptr(L), M, self._ptr(B), k, 1 if trans else 0, M, k, self._ptr(ws), ws.numel(),
+        st = self._cf.sgp_trsm_lower(self._ptr(L), M, self._ptr(B), k, 1 if trans else 0, M, k, self._ptr(ws), ws.numel(),
                                      self._stream())
         _lib.check("sgp_trsm_lower", st)
         return B

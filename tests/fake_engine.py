@@ -293,6 +293,18 @@ class FactoredOracleEngine(GuardedOracleEngine):
             res["Cw"] = 2.0 * float(s2) * (L.T @ res["Phibar"] @ L)   # 2 s2 Phibar = L^-T Cw L^-1
         return res
 
+    def phibar_dd(self, Cw, kuu_linv, s2, want_lo=False):
+        """sgp_phibar_dd: L^-T (Cw / 2 s2) L^-1 formed with extra precision (x87 long double standing in for double-double), split in two words."""
+        import numpy as np
+        self.calls["phibar_dd"] = self.calls.get("phibar_dd", 0) + 1
+        M = Cw.shape[0]
+        Li = kuu_linv.view(-1)[: M * M].view(M, M).numpy().astype(np.longdouble) if kuu_linv.dim() == 1 else kuu_linv[:M, :M].numpy().astype(np.longdouble)
+        P = Li.T @ (Cw.numpy().astype(np.longdouble) / (2 * np.longdouble(float(s2)))) @ Li
+        P = np.tril(P) + np.tril(P, -1).T
+        hi = np.asarray(P, dtype=np.float64)
+        lo = np.asarray(P - hi.astype(np.longdouble), dtype=np.float64)
+        return torch.from_numpy(hi), (torch.from_numpy(lo) if want_lo else None)
+
     def suffstats_bwd_factored(self, X, y, Z, ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, kernel="rbf", want_gz=False, out=None,
                                t_in=None):
         self.calls["suffstats_bwd_factored"] += 1

@@ -74,14 +74,11 @@ def test_chain_cholesky_is_the_same_factor_for_any_number_of_workgroups(engine):
         # it -- factors off by 3e-3, found by tools/potrf_budget_check.py in round 5; 17, 33: two / four workgroups for the critical items)
         for budget in (2, 3, 4, 5, 6, 7, 8, 9, 17, 33):
             e = ggp_amd.HipEngine(own_context=True)
+            e.set_option("cu_budget", budget)   # (sgp_chol_lower takes no context: the engine binds its own to the thread around the call)
             for rep in range(3 if M >= 1024 else 1):
-                # sgp_chol_lower reads the CU budget of the DEFAULT context / the calling thread (include/sgp.h): the per-thread setter
-                engine.lib.sgp_set_cu_budget(budget)
-                try:
-                    Lb, info = e.chol_lower(Ad)
-                finally:
-                    engine.lib.sgp_set_cu_budget(0)
+                Lb, info = e.chol_lower(Ad)
                 assert int(info.item()) == 0 and torch.equal(Lb, L0), (M, budget, rep)
+                e.set_option("shared_device", rep & 1)   # the ticketed claim and the static deal: the same bits
 
 
 _CHAIN_CHILD = r"""
@@ -136,9 +133,9 @@ def _chain_children(n, sizes, seconds, env_extra=None):
 
 
 def test_chain_cholesky_modes_reproduce_the_default_launch_bit_for_bit(engine):
-    """Round 6: the items of the chain-workgroup factorization are CLAIMED (a ticket per item from one counter, in the list's own order)
-    instead of dealt statically; SGP_POTRF_TICKET=0 keeps the static deal, SGP_POTRF_ACQUIRE=1 adds an agent-scope acquire behind every
-    flag poll, SGP_POTRF_LIGHT=0 turns the same-XCD light hand-overs off.  An item's arithmetic does not depend on who runs it
+    """Round 6: with SGP_OPT_SHARED_DEVICE (environment: SGP_SHARED_DEVICE=1) the items of the chain-workgroup factorization are CLAIMED by
+    ticket instead of dealt statically; SGP_POTRF_ACQUIRE=1 adds an agent-scope acquire behind every flag poll, SGP_POTRF_LIGHT=0 turns the
+    same-XCD light hand-overs off.  An item's arithmetic does not depend on who runs it
     or on how its operands were published: every mode, in a fresh process each, must return the default launch's bits (factor without
     inverse and factor + inverse, M from three block columns -- the first fused items -- to thirty-two)."""
     sizes = (192, 320, 1000, 2048)
@@ -150,7 +147,7 @@ def test_chain_cholesky_modes_reproduce_the_default_launch_bit_for_bit(engine):
         A = R @ R.T / M + torch.eye(M, dtype=torch.float64)
         L, _ = engine.chol_lower(A.to(engine.device))
         assert relerr(torch.tril(L).cpu(), torch.linalg.cholesky(A)) < 1e-12
-    for env in ({"SGP_POTRF_TICKET": "0"}, {"SGP_POTRF_ACQUIRE": "1"}, {"SGP_POTRF_LIGHT": "0"}, {"SGP_POTRF_ACQUIRE": "1", "SGP_POTRF_LIGHT": "0", "SGP_POTRF_TICKET": "0"},
+    for env in ({"SGP_SHARED_DEVICE": "1"}, {"SGP_POTRF_ACQUIRE": "1"}, {"SGP_POTRF_LIGHT": "0"}, {"SGP_POTRF_ACQUIRE": "1", "SGP_POTRF_LIGHT": "0", "SGP_SHARED_DEVICE": "1"},
                 {"SGP_POTRF_CHAIN": "2"}):
         got = _chain_children(1, sizes, 1.0, env)[0]
         assert got["timeouts"] == 0 and got["mismatch"] == 0, (env, got)
@@ -162,12 +159,12 @@ def test_chain_cholesky_modes_reproduce_the_default_launch_bit_for_bit(engine):
 def test_two_processes_factorize_on_one_gpu_without_time_outs(engine):
     """the spin kernels used to need every workgroup of a launch resident at once -- two processes on one GPU
     (the reference's joblib workers, experiments/regression.py:219-231; two ranks sharing a device) each launching up to 256 spinning
-    workgroups could starve each other into the 2^24-poll time-out.  With the ticketed claim an item is only ever held by a RUNNING
-    workgroup and waits only for earlier tickets: three processes (this one idle, two hammering sgp_kuu_factor_ex / sgp_chol_lower at
+    workgroups could starve each other into the 2^24-poll time-out.  With SGP_OPT_SHARED_DEVICE (the ticketed claim) an item is only ever held
+    by a RUNNING workgroup and waits only for earlier tickets: three processes (this one idle, two hammering sgp_kuu_factor_ex / sgp_chol_lower at
     M = 1024 and 512 for 20 s) finish without a time-out, every call returning the single-process bits."""
     sizes = (1024, 512)
     ref = _chain_children(1, sizes, 0.0)[0]
-    res = _chain_children(2, sizes, 20.0)
+    res = _chain_children(2, sizes, 20.0, {"SGP_SHARED_DEVICE": "1"})
     for r in res:
         assert r["timeouts"] == 0 and r["mismatch"] == 0 and r["sha"] == ref["sha"], (r, ref["sha"])
         assert r["calls"] >= 200, r["calls"]

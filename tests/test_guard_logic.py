@@ -294,6 +294,47 @@ def test_strict_mode_at_the_reach_boundary_does_not_depend_on_history(no_small_w
         assert hist.last_tier == 1 and F == Ff and g["ls"].tolist() == gf["ls"].tolist(), trial
 
 
+def test_a_device_time_out_switches_to_the_shared_device_mode_and_repeats_once(no_small_whitened):
+    """Round 6: SGP_INFO_TIMEOUT from the single-launch Cholesky (two processes on one GPU starving each other's
+    spinning workgroups) used to be raised at once.  The first one now sets SGP_OPT_SHARED_DEVICE on the engine's context -- the ticketed
+    claim, whose progress does not need the whole launch resident -- and the evaluation is repeated; a second one is raised."""
+    import ggp_amd as pkg
+    from fake_engine import FactoredOracleEngine
+    from ggp_amd.core import SgpTimeoutError
+
+    class Starved(FactoredOracleEngine):
+        OPTIONS = {"shared_device": 6}
+
+        def __init__(self, heals):
+            super().__init__()
+            self.opt, self.heals = {"shared_device": 0.0}, heals
+
+        def set_option(self, name, value):
+            prev, self.opt[name] = self.opt[name], float(value)
+            return prev
+
+        def get_option(self, name):
+            return self.opt[name]
+
+        def bound(self, *a, **k):
+            res = super().bound(*a, **k)
+            if self.opt["shared_device"] == 0.0 or not self.heals:
+                res["info"][0] = -7777     # the status word a starved launch leaves
+            return res
+
+    X, y, Z = _problem()
+    ref = _bound(X, y).value(Z, [0.8] * 3, 1.0, 0.3)[0]
+    eng = Starved(heals=True)
+    cb = _bound(X, y, eng)
+    assert cb.value(Z, [0.8] * 3, 1.0, 0.3)[0] == ref and cb.n_timeout_retries == 1 and eng.get_option("shared_device") == 1.0
+    F, g = cb.value_and_grad(Z, [0.8] * 3, 1.0, 0.3)
+    assert F == ref and cb.n_timeout_retries == 1          # (no further retries: the mode stays)
+    bad = _bound(X, y, Starved(heals=False))
+    with pytest.raises(SgpTimeoutError):
+        bad.value(Z, [0.8] * 3, 1.0, 0.3)
+    assert bad.n_timeout_retries == 1
+
+
 def test_hmc_target_sampler_mode_uses_the_extended_order_for_gradients(no_small_whitened):
     import ggp_amd as pkg
     from fake_engine import FactoredOracleEngine
