@@ -126,6 +126,8 @@ PROTOTYPES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_phibar_dd_workspace_bytes": (_sz, [_i32]),
     "sgp_phibar_dd": (_i32, [_vp, _vp, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_bwd_lo_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sgp_suffstats_bwd_lo": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats_ex": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libsgp_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["sgp_ctx.hip", "sgp_suffstats_fwd.hip", "sgp_suffstats_i8.hip", "sgp_suffstats_bwd.hip", "sgp_dense.hip", "sgp_tail.hip", "sgp_svgp.hip", "sgp_composite.hip", "sgp_small.hip"]
+SOURCES = ["sgp_ctx.hip", "sgp_suffstats_fwd.hip", "sgp_suffstats_i8.hip", "sgp_suffstats_bwd.hip", "sgp_suffstats_bwd_lo.hip", "sgp_dense.hip", "sgp_tail.hip", "sgp_svgp.hip", "sgp_composite.hip", "sgp_small.hip"]
 VERSION_SCRIPT = "libsgp.map"
 PUBLIC_HEADER = os.path.join("..", "..", "include", "sgp.h")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]  # only the SGP_API symbols of include/sgp.h leave the library

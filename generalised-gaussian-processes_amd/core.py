@@ -210,7 +210,18 @@ class CollapsedBound:
         self.extended_level = 2
         self.extended_range = 16384.0
         self.extended_grad_range = 3.0
-        self.extended_dd_phibar = True   # the extended order's explicit Phibar formed in double-double (sgp_phibar_dd)
+        self.extended_dd_phibar = True   # the extended order's explicit Phibar formed in double-double (sgp_phibar_dd) ...
+        self.extended_lo = True            # ... with its trailing word applied in pass 2 where that exists (RBF, d <= 8, K'_fu kept)
+        # ... and its reach with the trailing word applied in pass 2 (sgp_suffstats_bwd_lo).  Calibrated at C5 over 34 theta against the factored
+        # pass 2 of the whitened order (profiles/r06_extended_order_gradients_dd_phibar.jsonl, ..._ard_...): with both words every cell
+        # whose estimate is <= 1e-6 AND whose correction is <= 1e-4 of the gradient is within 6e-7 (the trained ARD thetas of C5: 3e-9 and
+        # 2.6e-8 where the leading word alone is off by 1.3e-6 / 4.5e-5 and the fp64-formed matrix by 4.6e-6 / 4.4e-4); isotropic l = 5 is
+        # the counter-example that makes the second condition necessary (estimate 1.8e-7, correction 5.5e-4, 8e-6 left).
+        self.extended_grad_range_lo = 1000.0
+        self.extended_lo_max_correction = 1e-4
+        self.lo_reject_estimate = float("inf")   # the smallest estimate at which that check has failed (where gradient evaluations START: memory only)
+        self.last_lo_correction = None
+        self.n_lo_rejections = 0
         self.guard = GuardState()
         self.last_estimate = None   # the estimate (exact, or the bound of a whitened evaluation) of the last guarded evaluation
         self.last_tier = None       # the tier the last evaluation was accepted in
@@ -348,6 +359,23 @@ class CollapsedBound:
         return (hasattr(e, "suffstats_extended") and self.kernel != "composite" and self.extended_range > 1.0
                 and self._rows_for_form * int(M) >= self.whitened_rows_min_work)
 
+    def _bwd_lo_ok(self, M):
+        """Pass 2 of the extended order can apply the trailing word of the double-double Phibar here (RBF, d <= 8, K'_fu kept): a
+        rank-invariant statement, like `_extended_ok`."""
+        e = self.engine
+        return (self.extended_dd_phibar and self.extended_lo and hasattr(e, "suffstats_bwd_lo") and hasattr(e, "phibar_dd")
+                and e.bwd_lo_supported(self._rows_for_form, int(M), self.d, self.kernel)
+                and ((self._rows_for_form + 255) // 256 * 256) * ((int(M) + 127) // 128 * 128) * 8 <= self.kfu_budget_bytes)
+
+    def _lo_correction_small(self, host, head, nh, lo_slots):
+        """The a-posteriori check of the extended order's gradient: the trailing word's correction [d lengthscales | sf2] (tail of the
+        buffer) against the gradient it went into, in the parity suite's metric -- lengthscales against their largest component,
+        the amplitude against max(1, |g_sf2|)."""
+        g = host[head:head + nh + 1].tolist()
+        dl = host[host.numel() - lo_slots:].tolist()
+        self.last_lo_correction = max(max(abs(v) for v in dl[:nh]) / max(1.0, max(abs(v) for v in g[:nh])), abs(dl[nh]) / max(1.0, abs(g[nh])))
+        return self.last_lo_correction <= self.extended_lo_max_correction
+
     def _fixed_tier(self, M):
         if self.form == "extended":
             return TIER_EXTENDED
@@ -409,7 +437,9 @@ class CollapsedBound:
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True, **({"want_cw": True} if dd else {}))
             if dd:
-                res["Phibar"], _ = e.phibar_dd(res["Cw"], linv, s2)
+                # ... and 35-700 x closer with the trailing word applied as well: a bf16 product K' Phibar_lo beside the fp64 one (_pass2)
+                lo = kfu is not None and self._bwd_lo_ok(M)
+                res["Phibar"], res["Phibar_lo"] = e.phibar_dd(res["Cw"], linv, s2, want_lo=lo)
                 res["Cw"] = None   # (pass 2 of this order is the explicit one: _pass2 takes the factored route when a core is handed on)
             if report:
                 self._allreduce(diag[:M])  # (ranks hold the diagonal of their own shard's Phi)
@@ -509,6 +539,12 @@ class CollapsedBound:
         else:
             e.suffstats_bwd(self.X, self.y, Z, ls, sf2, res["Phibar"], res["bbar"], -1.0 / (2.0 * float(s2)),
                             self.kernel, want_gz=want_gz, out=g, kfu=res["kfu"])
+            if res.get("Phibar_lo") is not None:   # the extended order: the trailing word of its double-double Phibar (lengthscales, amplitude)
+                n_lo = int(res.get("lo_slots", 0))   # (the correction itself goes to the tail of `g`: all-reduced with it, read back with it)
+                e.suffstats_bwd_lo(self.X, self.y, Z, ls, sf2, res["Phibar_lo"], res["kfu"], g, self.kernel,
+                                   **({"delta": g[g.numel() - n_lo:]} if n_lo else {}))
+        if int(res.get("lo_slots", 0)) and res.get("Phibar_lo") is None:
+            g[g.numel() - int(res["lo_slots"]):].zero_()   # (the correction's slots travel with g: nothing undefined into the all-reduce)
         self._allreduce(g)
         # (measured and dropped, round 5: this launch pair on the side stream beside pass 2 -- it needs Kuubar only -- ends the evaluation no
         # earlier: pass 2 fills the chip and runs the 28 us longer that the side stream takes from it, profiles/r05_kuu_bwd_side_stream_c3_timeline.txt)
@@ -537,7 +573,9 @@ class CollapsedBound:
         e = self.engine
         M, d = int(Z.shape[0]), int(Z.shape[1])
         guard = self._guard_on(M)
-        reach = (self.extended_grad_range if grad_reach is None else float(grad_reach)) if with_grad else self.extended_range
+        reach = self.extended_range
+        if with_grad:   # (how far the extended order's gradient holds 1e-6: further with both words of its double-double Phibar)
+            reach = float(grad_reach) if grad_reach is not None else (self.extended_grad_range_lo if self._bwd_lo_ok(M) else self.extended_grad_range)
         ext_ok = self._extended_ok(M)
         if guard:
             tier = self.guard.start_tier(self.streaming_tol, reach, ext_ok)
@@ -552,7 +590,11 @@ class CollapsedBound:
         else:
             tier = self._fixed_tier(M)
         nh = (e.hyper_len(self.kernel, d) if hasattr(e, "hyper_len") else d) if with_grad else 0
-        extra = nh + 1 + (M * d if want_gz else 0) if with_grad else 0
+        # (behind the packed gradient: d + 1 slots for the trailing word's correction, which decides whether the explicit pass 2 is trusted)
+        lo_slots = (nh + 1) if (with_grad and guard and ext_ok and self._bwd_lo_ok(M)) else 0
+        extra = nh + 1 + (M * d if want_gz else 0) + lo_slots if with_grad else 0
+        if guard and with_grad and tier == TIER_EXTENDED and grad_reach is None and self.guard.predicted >= 0.7 * self.lo_reject_estimate:
+            tier = TIER_WHITENED   # (the correction was too large the last time the estimate was about this: no wasted attempt per leapfrog)
         # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the status and the
         # gradient -- a failed factorization or a guard repeat then costs a wasted pass 2, which is cheaper than idling the GPU for
         # a host round trip on every leapfrog.  Big shards check first.  The rule is the job's (largest shard), not this rank's:
@@ -569,9 +611,11 @@ class CollapsedBound:
             res = self._forward(Z, ls, sf2, s2, with_adjoints=with_grad, want_factors=want_factors, extra=extra, tier=tier, report=guard)
             head = res["buf"].numel() - extra  # [out | status word | estimate | bound | pad], then the packed gradient (16-byte aligned)
             g = res["buf"][head:] if with_grad else None
+            res["lo_slots"] = lo_slots
+            grad_upto = None if lo_slots else head + nh + 1   # (with the correction's slots: the whole buffer -- they sit at its end)
             if with_grad and not early:
                 self._pass2(res, Z, ls, sf2, s2, want_gz, g)
-            o, info, host = self._fetch(res, upto=(head + nh + 1) if (with_grad and not early) else head)
+            o, info, host = self._fetch(res, upto=grad_upto if (with_grad and not early) else head)
             nxt = self._review(res, host, info, tier, reach, M, may_go_down) if guard else None
             if nxt is not None:
                 if not (with_grad and early) and not want_factors:
@@ -587,7 +631,16 @@ class CollapsedBound:
                 continue
             if with_grad and early and info == 0:
                 self._pass2(res, Z, ls, sf2, s2, want_gz, g)
-                _, _, host = self._fetch(res, upto=head + nh + 1)
+                _, _, host = self._fetch(res, upto=grad_upto)
+            if (with_grad and info == 0 and tier == TIER_EXTENDED and res.get("Phibar_lo") is not None and lo_slots and grad_reach is None
+                    and not self._lo_correction_small(host, head, nh, lo_slots)):
+                # The explicit pass 2 of this order is trusted only while its trailing-word correction is small against the gradient (what is
+                # left behind the correction is a few per cent of it: profiles/r06_extended_order_gradients_*): repeated in the whitened order
+                self.n_guard_reruns += 1
+                self.n_lo_rejections += 1
+                self.lo_reject_estimate = min(self.lo_reject_estimate, self.last_estimate if self.last_estimate is not None else 0.0)
+                tier = TIER_WHITENED
+                continue
             self.last_tier = tier
             return res, o, info, host, head
 
@@ -665,7 +718,7 @@ class CollapsedBound:
         gh = host[head:]
         g = res["buf"][head:]
         grads = {"ls": gh[:nh].clone(), "sf2": float(gh[nh]), "s2": float(o[OUT_S2BAR]),
-                 "Z": g[nh + 1:].reshape(M, d) if want_gz else None, "info": 0,
+                 "Z": g[nh + 1:nh + 1 + M * d].reshape(M, d) if want_gz else None, "info": 0,
                  "logmarg": float(o[OUT_LOGMARG]), "trace_term": float(o[OUT_TRACE])}
         return float(o[OUT_F]), grads
 

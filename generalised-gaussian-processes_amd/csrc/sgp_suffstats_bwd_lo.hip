@@ -1,0 +1,285 @@
+// Pass 2, the LOW WORD of a double-double Phibar (round 6; tests/studies/explicit_phibar_pass2.py).
+//
+// The extended evaluation order's pass 2 contracts the materialised K'_fu with the EXPLICIT Phibar = L^-T (C / 2 s2) L^-1, whose
+// cond(K_uu)-sized entries cancel in Kbar = 2 K Phibar.  Against an 80-bit yardstick the error of that gradient is, in this order: the
+// fp64 FORMATION of Phibar (cured by sgp_phibar_dd: two double-double products), then the ROUNDING of the formed matrix to one fp64 word
+// -- a fixed perturbation eps |Phibar| that every data row sees alike, so its effect grows like N where the rounding of the N M^2
+// accumulation grows like sqrt(N) -- and only then the fp64 accumulation.  The rounding is cured by keeping the second word:
+//
+//     Kbar = 2 K' (Phibar_hi + Phibar_lo),     |Phibar_lo| <= 2^-53 |Phibar_hi|
+//
+// and the product with the low word needs three significant digits only.  This file is that product and its contraction with dK:
+//
+//     dC[n, m]  = sum_m' K'[n, m'] Phibar_lo[m', m]                         fp16 operands, fp32 accumulation: v_mfma_f32_32x32x16_f16
+//                 (K' lies in [0, 1]; every row of the symmetric Phibar_lo is scaled by a power of two into fp16's range and the scale
+//                 taken out again per output column.  bf16 -- the first version -- left 1-2 % of the correction behind, which showed
+//                 at the far end of the range: 1.1e-5 where the leading word alone is off by 5.5e-4; fp16's 11 bits leave 0.1 %)
+//     S_0       = sum_nm dC k'           S_j = sum_nm dC k' (z~_mj - x~_nj)^2          (fp64, k' read back from the fp64 K'_fu)
+//     g_sf2    += 2 sf2 S_0              g_ls[j] += 2 inv_ls_j sf2^2 S_j               (RBF: dk'/dr2 = -k'/2; the signs as kbar_contract_kernel)
+//
+// i.e. exactly what kbar_contract_kernel's epilogue would add had its C = K' Phibar carried the low word.  2 N M^2 flop on the fp16 / bf16
+// matrix cores (2.5 PFLOP/s dense) against the same count on the fp64 ones for the leading word: a few per cent of a leapfrog.
+// Layout: workgroup <-> (128 data rows, 128 inducing columns), four waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32, 64 fp32 accumulators);
+// 32-deep k-chunks: K' fp64 -> fp16 on the way into LDS (registers hold the next chunk while this one is multiplied), the fp16 image of
+// the symmetric Phibar_lo read ROW-wise as B^T (so both fragments are 16 contiguous bytes of LDS).  The eight column blocks of a row block
+// share an XCD (ids 8 apart), whose L2 serves seven of the eight reads of every K' row block.
+// Reference: this is the reverse pass of pm.gp.MarginalSparse's logp (models/bayesian_sgpr_hmc.py:66-78) at a precision Theano's fp64
+// graph has by construction (it never forms Phibar); no counterpart in the reference's code.
+#include "sgp_common.hpp"
+#include "sgp_stream.hpp"
+#include "sgp_dense.hpp"
+#include <cstdint>
+
+namespace sgp {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 lo_h8;
+typedef __attribute__((ext_vector_type(16))) float lo_f32x16;
+
+constexpr int LO_T = 128;     // tile edge (rows and columns)
+constexpr int LO_BK = 32;     // k-chunk (two MFMA k-steps of 16)
+constexpr int LO_LD = 40;     // fp16 elements per LDS row: 80 bytes -- 16-byte aligned fragments, rows 20 banks apart
+
+__device__ __forceinline__ uint32_t lo_h16(float f) {   // round to nearest even (v_cvt_f16_f32)
+  const _Float16 hv = (_Float16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, hv);
+}
+__device__ __forceinline__ uint32_t lo_pack2(double a, double b) { return lo_h16((float)a) | (lo_h16((float)b) << 16); }
+
+// fp16 image of the symmetric M x M low word, zero-padded to Mp x Mp: row r scaled by 2^sh(r) so that its largest entry lies in
+// [2^13, 2^14) (fp16: normal down to 2^-14, 65504 at the top), unscale[r] = 2^-sh(r).  One workgroup per row.
+__global__ __launch_bounds__(256) void lo_prep_kernel(const double* __restrict__ Plo, int M, int Mp, uint16_t* __restrict__ out,
+                                                      double* __restrict__ unscale) {
+  __shared__ double red[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  double mx = 0.0;
+  if (r < M)
+    for (int c = tid; c < M; c += 256) mx = fmax(mx, fabs(Plo[(size_t)r * M + c]));
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  int ex = 0;
+  if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);   // mx = f 2^ex, f in [0.5, 1)
+  const int sh = (mx > 0.0 && mx < 1e300) ? 14 - ex : 0;
+  if (tid == 0) unscale[r] = ldexp(1.0, -sh);
+  for (int c = tid; c < Mp; c += 256)
+    out[(size_t)r * Mp + c] = (r < M && c < M) ? (uint16_t)lo_h16((float)ldexp(Plo[(size_t)r * M + c], sh)) : (uint16_t)0;
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restrict__ Kfu, const uint16_t* __restrict__ Pl,
+                                                      const double* __restrict__ unscale, const double* __restrict__ Xs,
+                                                      const double* __restrict__ Zs, int Mp, int64_t nrb, int ncb,
+                                                      double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) uint16_t ABs[2][LO_T][LO_LD];   // (one array: the epilogue reuses it as four 32 x 33 fp32 images)
+  uint16_t (*As)[LO_LD] = ABs[0];
+  uint16_t (*Bs)[LO_LD] = ABs[1];
+  __shared__ double Xl[LO_T][DP], Zl[LO_T][DP];
+  __shared__ double red[4][DP + 1];
+  // id -> (xcd, column block, row block): the ncb column blocks of a row block share id % 8, i.e. one XCD under round-robin dispatch
+  const int xcd = blockIdx.x & 7;
+  const int64_t jj = blockIdx.x >> 3;
+  const int cb = (int)(jj % ncb);
+  const int64_t rb = (jj / ncb) * 8 + xcd;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* mypart = part + (size_t)blockIdx.x * (DP + 1);
+  if (rb >= nrb) {  // (the grid is rounded up to whole groups of eight row blocks)
+    if (tid <= DP) mypart[tid] = 0.0;
+    return;
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r31 = lane & 31, h = lane >> 5;
+  const int64_t n0 = rb * LO_T;
+  const int m0 = cb * LO_T;
+
+  // staging roles: thread <-> (row, half of the chunk): 16 consecutive k
+  const int srow = tid >> 1, skh = (tid & 1) * 16;
+  const double* asrc = Kfu + (size_t)(n0 + srow) * Mp + skh;
+  const uint16_t* bsrc = Pl + (size_t)(m0 + srow) * Mp + skh;
+  double2 areg[8];
+  uint4 breg[2];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const double2*>(asrc + k0 + 2 * q);
+    breg[0] = *reinterpret_cast<const uint4*>(bsrc + k0);
+    breg[1] = *reinterpret_cast<const uint4*>(bsrc + k0 + 8);
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+    uint4 a0, a1;
+    a0.x = lo_pack2(areg[0].x, areg[0].y); a0.y = lo_pack2(areg[1].x, areg[1].y);
+    a0.z = lo_pack2(areg[2].x, areg[2].y); a0.w = lo_pack2(areg[3].x, areg[3].y);
+    a1.x = lo_pack2(areg[4].x, areg[4].y); a1.y = lo_pack2(areg[5].x, areg[5].y);
+    a1.z = lo_pack2(areg[6].x, areg[6].y); a1.w = lo_pack2(areg[7].x, areg[7].y);
+    *reinterpret_cast<uint4*>(&As[srow][skh]) = a0;
+    *reinterpret_cast<uint4*>(&As[srow][skh + 8]) = a1;
+    *reinterpret_cast<uint4*>(&Bs[srow][skh]) = breg[0];
+    *reinterpret_cast<uint4*>(&Bs[srow][skh + 8]) = breg[1];
+  };
+
+  lo_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // the scaled inputs of this tile's rows and columns, for the epilogue
+  for (int e = tid; e < LO_T * DP; e += 256) {
+    Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
+    Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
+  }
+
+  fetch(0);
+  for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
+    stash();
+    __syncthreads();
+    if (k0 + LO_BK < Mp) fetch(k0 + LO_BK);   // in flight under this chunk's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      lo_h8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const lo_h8*>(&As[wr * 64 + i * 32 + r31][ks * 16 + 8 * h]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const lo_h8*>(&Bs[wc * 64 + j * 32 + r31][ks * 16 + 8 * h]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue.  Accumulator element (reg e of a 32 x 32 tile): row = (e & 3) + 8 (e >> 2) + 4 h, column = r31 (C/D layout of the 32 x 32 forms).
+  // The four tiles of a wave go through a wave-private 32 x 33 LDS image one after the other, so that the contraction is a ROLLED loop
+  // over rows (straight from the registers it is 64 unrolled elements whose loads the compiler hoists: 512 VGPRs, 150 spilled).
+  float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(&As[0][0]) + wave * 32 * 33);   // 4 x 4224 B inside As (10 KB) + Bs
+  static_assert(4 * 32 * 33 * sizeof(float) <= 2 * LO_T * LO_LD * sizeof(uint16_t), "the staging images fit in the main-loop buffers");
+  double S[DP + 1];
+#pragma unroll
+  for (int q = 0; q <= DP; ++q) S[q] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wc * 64 + j * 32 + r31;
+    const double us = unscale[m0 + col];   // this column's row of the (symmetric) low word was scaled by 1 / us
+    double z[DP];
+#pragma unroll
+    for (int q = 0; q < DP; ++q) z[q] = Zl[col][q];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Cl[(e & 3) + 8 * (e >> 2) + 4 * h][r31] = acc[i][j][e];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int rbase = wr * 64 + i * 32 + 16 * h;
+      const double* kcol = Kfu + (size_t)(n0 + rbase) * Mp + m0 + col;
+#pragma unroll 4
+      for (int rr = 0; rr < 16; ++rr) {
+        const double kp = kcol[(size_t)rr * Mp];   // (zero in the padding: padded rows / columns add nothing)
+        const double w = (double)Cl[16 * h + rr][r31] * (kp * us);
+        S[DP] += w;
+#pragma unroll
+        for (int q = 0; q < DP; ++q) {
+          const double df = z[q] - Xl[rbase + rr][q];
+          S[q] = fma(w * df, df, S[q]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int q = 0; q <= DP; ++q) {
+    const double v = wave_sum(S[q]);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (tid <= DP) mypart[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// g_ls[j] += 2 inv_ls_j sf2^2 sum_parts S_j ; g_sf2 += 2 sf2 sum_parts S_DP -- one block, a fixed thread <-> partial mapping and a fixed tree
+// delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
+// the explicit pass 2 can be trusted at this theta (core.py: extended_lo_max_correction)
+__global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict__ part, int nparts, int DP, KernArgs ka,
+                                                        double* __restrict__ g_ls, double* __restrict__ g_sf2, double* __restrict__ delta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = wave; q <= ka.d; q += 4) {
+    const int slot = q == ka.d ? DP : q;
+    double s = 0.0;
+    for (int p = lane; p < nparts; p += 64) s += part[(size_t)p * (DP + 1) + slot];
+    s = wave_sum(s);
+    if (lane == 0) {
+      const double c = q == ka.d ? 2.0 * ka.sf2 * s : 2.0 * ka.inv_ls[q] * ka.sf2 * ka.sf2 * s;
+      if (q == ka.d) *g_sf2 += c;
+      else g_ls[q] += c;
+      if (delta) delta[q] = c;
+    }
+  }
+}
+
+struct LoWs {
+  double *Xs, *ys, *Zs, *yypart, *part, *unscale;
+  uint16_t* Pl;
+  size_t bytes;
+  int grid;
+};
+static LoWs carve_lo(void* ws, const StreamPlan& p) {
+  Carver c(ws);
+  LoWs w;
+  w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
+  w.ys = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1));
+  w.Zs = c.take<double>((size_t)p.Mp * p.DP);
+  w.yypart = c.take<double>(256);
+  const int64_t nrb = p.Npad / LO_T;
+  const int ncb = p.Mp / LO_T;
+  w.grid = (int)(((nrb + 7) / 8) * 8 * ncb);
+  w.part = c.take<double>((size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1));
+  w.Pl = c.take<uint16_t>((size_t)p.Mp * p.Mp);
+  w.unscale = c.take<double>((size_t)p.Mp);
+  w.bytes = c.used();
+  return w;
+}
+
+}  // namespace sgp
+
+using namespace sgp;
+
+extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d) {
+  if (N < 0 || M <= 0 || d <= 0 || d > 8 || M > SGP_MAX_INDUCING) return 0;
+  return carve_lo(nullptr, make_stream_plan(N, M, d)).bytes;
+}
+
+// Adds the low word's contribution to g_ls (d doubles) and g_sf2 IN PLACE, behind sgp_suffstats_bwd on the same stream with the same
+// inputs and Phibar = the leading word.  Kfu_in: the fp64 K'_fu of this shard (sgp_kfu_len doubles) as pass 1 left it.  RBF, d <= 8
+// (SGP_ERR_ARG / SGP_ERR_DIM otherwise: the caller then keeps the leading word's gradient); g_Z is not corrected.  delta (optional,
+// d + 1 doubles): receives the correction itself.
+extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls,
+                                    double sf2, const double* Phibar_lo, const double* Kfu_in, int64_t N, int M, int d, int kernel_id,
+                                    double* g_ls, double* g_sf2, double* delta, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  if (!Z || !inv_ls || !Phibar_lo || !Kfu_in || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
+  if (kernel_id != SGP_KERNEL_RBF) return SGP_ERR_ARG;
+  if (d > 8 || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (N == 0) {
+    if (delta) fill_zero(delta, (size_t)d + 1, (hipStream_t)stream);
+    return check_launch();
+  }
+  StreamPlan p = make_stream_plan(N, M, d);
+  LoWs w = carve_lo(ws, p);
+  if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  KernArgs ka;
+  for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
+  ka.sf2 = sf2;
+  ka.d = d;
+  stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
+  lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, w.Pl, w.unscale);
+  const int64_t nrb = p.Npad / LO_T;
+  const int ncb = p.Mp / LO_T;
+  switch (p.DP) {
+    case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+    case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+    default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+  }
+  lo_reduce_kernel<<<1, 256, 0, st>>>(w.part, w.grid, p.DP, ka, g_ls, g_sf2, delta);
+  return check_launch();
+}

@@ -297,6 +297,26 @@ class HipEngine:
         _lib.check("sgp_phibar_dd", st)
         return hi, lo
 
+    def bwd_lo_supported(self, N: int, M: int, d: int, kernel="rbf") -> bool:
+        """``suffstats_bwd_lo`` exists for this shape: RBF, d <= 8."""
+        return kernel == "rbf" and self.lib.sgp_suffstats_bwd_lo_workspace_bytes(int(N), int(M), int(d)) > 0
+
+    def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads: torch.Tensor, kernel="rbf", delta: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Adds the trailing word's share of pass 2 into the packed gradients ``suffstats_bwd`` wrote (include/sgp.h: sgp_suffstats_bwd_lo);
+        ``delta`` (d + 1 doubles) receives the correction itself."""
+        N, d = X.shape
+        M = Z.shape[0]
+        self._chk(Phibar_lo, "Phibar_lo"), self._chk(kfu, "kfu")
+        nh = self.hyper_len(kernel, d)
+        ws = self._workspace("bwd_lo", self.lib.sgp_suffstats_bwd_lo_workspace_bytes(N, M, d))
+        base = grads.data_ptr()
+        st = self.lib.sgp_suffstats_bwd_lo(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2),
+                                           self._ptr(Phibar_lo), self._ptr(kfu), N, M, d, _kernel_id(kernel), C.c_void_p(base),
+                                           C.c_void_p(base + 8 * nh), self._ptr(delta) if delta is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
+                                           self._stream())
+        _lib.check("sgp_suffstats_bwd_lo", st)
+        return grads
+
     def pack_lower(self, stats: torch.Tensor, M: int) -> torch.Tensor:
         """[lower triangle of Phi | b | yy | kappa]: what crosses xGMI (half the bytes of ``stats``)."""
         tri = self.empty(self.lib.sgp_stats_packed_len(M))

@@ -417,6 +417,18 @@ int sgp_suffstats_fwd_extended(const double* X, int64_t ldx, const double* y,
 size_t sgp_phibar_dd_workspace_bytes(int M);
 int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, double s2, double* Phibar_hi, double* Phibar_lo, void* ws,
                   size_t ws_bytes, sgp_stream_t stream);
+/* ... and the pass-2 contribution of the trailing word: g_ls (d doubles) and g_sf2 receive, IN PLACE, what sgp_suffstats_bwd would have added
+ * had its Phibar carried Phibar_lo as well -- dC = K' Phibar_lo on the bf16 matrix cores (three digits are all a 2^-53-relative term
+ * needs), contracted with dK in fp64.  Call it behind sgp_suffstats_bwd (same stream, same inputs, Phibar = the leading word, the same
+ * caller-owned fp64 K'_fu as Kfu_in) and before the gradients are all-reduced.  RBF kernel, d <= 8 (SGP_ERR_ARG / SGP_ERR_DIM otherwise);
+ * dF/dZ is not corrected.  delta (DEVICE, d + 1 doubles, or NULL) receives the correction itself, [d lengthscales | sf2]: its size against
+ * the gradient is the a-posteriori check a caller applies before trusting the explicit pass 2 at a theta (measured at C5 over 34 theta
+ * against the factored pass 2 of the whitened order: what is left after the correction is <= 5 % of it while the streaming-order
+ * estimate is <= 1e-6 -- profiles/r06_extended_order_gradients_*; core.py accepts corrections up to 1e-4 of the gradient).            */
+size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d);
+int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                         const double* Phibar_lo, const double* Kfu_in, int64_t N, int M, int d, int kernel_id, double* g_ls,
+                         double* g_sf2, double* delta, void* ws, size_t ws_bytes, sgp_stream_t stream);
 /* ... with phi_diag (ABI version 3; see sgp_ctx_suffstats_fwd_extended) */
 int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const double* y,
                                   const double* Z, int64_t ldz, const double* inv_ls, double sf2,

@@ -157,7 +157,7 @@ class OracleEngine:
         parts = [g_ls, g_sf2.reshape(1)] + ([g_Z.reshape(-1)] if want_gz else [])
         packed = torch.cat(parts)
         if out is not None:
-            out.copy_(packed)
+            out[: packed.numel()].copy_(packed)   # (the caller's buffer may carry more behind the gradient: the correction's slots)
             return out
         return packed
 
@@ -174,7 +174,7 @@ class OracleEngine:
         grads[:d] += -2.0 * (Eu[:, :, None] * diffu * diffu).sum((0, 1)) / lst
         grads[d] += (Kuubar * Ku).sum() / sf2
         if want_gz:
-            grads[d + 1:] += (2.0 * ((Eu + Eu.T)[:, :, None] * diffu).sum(1) / lst).reshape(-1)
+            grads[d + 1:d + 1 + M * d] += (2.0 * ((Eu + Eu.T)[:, :, None] * diffu).sum(1) / lst).reshape(-1)   # (more may follow: the correction's slots)
         return grads
 
     def predict(self, Xs, Z, ls, sf2, s2, factors, kernel="rbf", pred_noise=True, full_cov=False):
@@ -304,6 +304,21 @@ class FactoredOracleEngine(GuardedOracleEngine):
         hi = np.asarray(P, dtype=np.float64)
         lo = np.asarray(P - hi.astype(np.longdouble), dtype=np.float64)
         return torch.from_numpy(hi), (torch.from_numpy(lo) if want_lo else None)
+
+    def bwd_lo_supported(self, N, M, d, kernel="rbf"):
+        return kernel == "rbf" and d <= 8
+
+    def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads, kernel="rbf", delta=None):
+        """sgp_suffstats_bwd_lo: what pass 2 would have added had its Phibar carried the trailing word (lengthscales and amplitude only)."""
+        self.calls["suffstats_bwd_lo"] = self.calls.get("suffstats_bwd_lo", 0) + 1
+        d = Z.shape[1]
+        n = self.calls["suffstats_bwd"]
+        corr = self.suffstats_bwd(X, y, Z, ls, sf2, Phibar_lo, torch.zeros(Z.shape[0], dtype=torch.float64), 0.0, kernel, False, None)
+        self.calls["suffstats_bwd"] = n
+        grads[: d + 1] += corr[: d + 1]
+        if delta is not None:
+            delta[: d + 1] = corr[: d + 1] * getattr(self, "lo_delta_scale", 1.0)   # (tests inflate it to exercise the a-posteriori check)
+        return grads
 
     def suffstats_bwd_factored(self, X, y, Z, ls, sf2, kuu_linv, Cw, s2, bbar, kappabar, kernel="rbf", want_gz=False, out=None,
                                t_in=None):

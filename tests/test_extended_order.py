@@ -130,3 +130,44 @@ def test_extended_order_gradients_against_autograd(engine):
     assert float((g["ls"] - ref["g_ls"]).abs().max()) < 1e-6 * float(ref["g_ls"].abs().max())
     assert abs(g["sf2"] - ref["g_sf2"]) < 1e-6 * max(1.0, abs(ref["g_sf2"])) and abs(g["s2"] - ref["g_s2"]) < 1e-6 * max(1.0, abs(ref["g_s2"]))
     assert relerr(g["Z"].cpu().numpy(), ref["g_Z"].numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
+    """Round 6.  sgp_phibar_dd forms Phibar = L^-T (C / 2 s2) L^-1 in double-double: (i) its two words against an x87
+    long-double product of the same inputs; (ii) sgp_suffstats_bwd_lo -- dC = K' Phibar_lo on the fp16 matrix cores (rows scaled by powers of two), contracted with dK
+    in fp64 -- against the fp64 pass 2 run on the trailing word itself (what it approximates: three digits are asked for, 3e-3 is held);
+    (iii) a matrix that is NOT small handed over as `Phibar_lo` (the kernel is a plain fp16 product + contraction: 3e-3 of the fp64 result
+    there too, ragged shapes, padded rows and columns adding nothing)."""
+    import numpy as np
+    import ggp_amd
+    for (N, M, d) in ((3000, 200, 3), (20000, 384, 8), (777, 130, 1)):
+        g = torch.Generator().manual_seed(N + M)
+        X = torch.randn(N, d, dtype=torch.float64, generator=g)
+        y = torch.randn(N, dtype=torch.float64, generator=g)
+        Z = X[:M].clone()
+        ls, sf2, s2 = [1.5 + 0.2 * j for j in range(d)], 1.3, 0.05
+        Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+        Kuu = engine.kuu(Zd, ls, sf2, 1e-6, "rbf")
+        linv, info = engine.kuu_factor(Kuu)
+        Mp = (M + 127) // 128 * 128
+        Cw = torch.randn(M, M, dtype=torch.float64, generator=g)
+        Cw = (Cw + Cw.T) / 2
+        hi, lo = engine.phibar_dd(Cw.to(engine.device), linv, s2, want_lo=True)
+        Li = linv.view(Mp, Mp)[:M, :M].cpu().numpy().astype(np.longdouble)
+        ref = Li.T @ (Cw.numpy().astype(np.longdouble) / (2 * np.longdouble(s2))) @ Li
+        got = hi.cpu().numpy().astype(np.longdouble) + lo.cpu().numpy().astype(np.longdouble)
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) < 1e-17 * scale * M, (N, M, float(np.abs(got - ref).max()) / scale)   # (long double itself: 5e-20 per operation)
+        assert float(np.abs(hi.cpu().numpy() - np.asarray(ref, dtype=np.float64)).max()) <= 2.3e-16 * scale          # the leading word IS the rounded matrix
+        assert float(lo.abs().max()) <= 1.2e-16 * float(hi.abs().max())
+        kfu = engine.kfu_buffer(N, M)
+        engine.suffstats(Xd, yd, Zd, ls, sf2, "rbf", kfu=kfu)
+        zero = torch.zeros(M, dtype=torch.float64, device=engine.device)
+        for P in (lo, hi * 1e-3):
+            exact = engine.suffstats_bwd(Xd, yd, Zd, ls, sf2, P, zero, 0.0, "rbf", want_gz=False, kfu=kfu).cpu()
+            acc = torch.zeros(d + 1, dtype=torch.float64, device=engine.device)
+            engine.suffstats_bwd_lo(Xd, yd, Zd, ls, sf2, P, kfu, acc, "rbf")
+            acc = acc.cpu()
+            assert float((acc - exact).abs().max()) <= 3e-3 * float(exact.abs().max()), (N, M, d, acc, exact)
+    assert not engine.bwd_lo_supported(1000, 64, 9) and not engine.bwd_lo_supported(1000, 64, 3, "matern32")

@@ -335,6 +335,46 @@ def test_a_device_time_out_switches_to_the_shared_device_mode_and_repeats_once(n
     assert bad.n_timeout_retries == 1
 
 
+def test_extended_gradient_is_trusted_by_its_own_trailing_word_correction(no_small_whitened):
+    """Round 6: with the double-double Phibar and its trailing word applied in pass 2 (sgp_phibar_dd, sgp_suffstats_bwd_lo)
+    a value + gradient evaluation takes the extended order up to `extended_grad_range_lo` x the tolerance -- and is ACCEPTED there only while
+    the correction the trailing word made is small against the gradient (`extended_lo_max_correction`); otherwise it is repeated in the
+    whitened order, and the next gradient evaluations at such estimates start there."""
+    from fake_engine import FactoredOracleEngine
+    X, y, Z = _problem()
+    theta = ([3.0] * 3, 1.0, 5e-3)        # estimate between 3 x (the old gradient range) and 1000 x the tolerance
+    ref = _bound(X, y, form="whitened")
+    Fw, gw = ref.value_and_grad(Z, *theta)
+    eng = FactoredOracleEngine()
+    cb = _bound(X, y, eng)
+    F, g = cb.value_and_grad(Z, *theta)
+    assert 3.0 * cb.streaming_tol < cb.last_estimate <= cb.extended_grad_range_lo * cb.streaming_tol, cb.last_estimate
+    assert cb.last_tier == 1 and eng.calls["phibar_dd"] == 1 and eng.calls["suffstats_bwd_lo"] == 1 and eng.calls["suffstats_bwd_factored"] == 0
+    assert cb.last_lo_correction is not None and cb.last_lo_correction <= cb.extended_lo_max_correction and cb.n_lo_rejections == 0
+    assert abs(F - Fw) / X.shape[0] < 2e-9 and np.max(np.abs(g["ls"].numpy() - gw["ls"].numpy())) <= 1e-6 * max(1.0, float(gw["ls"].abs().max()))
+    # without the trailing word (another kernel, d > 8, no K'_fu kept) the old range holds: the same theta goes to the whitened order
+    e2 = FactoredOracleEngine()
+    c2 = _bound(X, y, e2)
+    c2.extended_lo = False
+    c2.value_and_grad(Z, *theta)
+    assert c2.last_tier == 2 and e2.calls["suffstats_bwd_factored"] == 1
+    # a correction that is NOT small: the evaluation is repeated in the whitened order, the whitened gradient is what comes back ...
+    e3 = FactoredOracleEngine()
+    e3.lo_delta_scale = 1e12
+    c3 = _bound(X, y, e3)
+    F3, g3 = c3.value_and_grad(Z, *theta)
+    assert c3.last_tier == 2 and c3.n_lo_rejections == 1 and e3.calls["suffstats_bwd_factored"] == 1 and g3["ls"].tolist() == gw["ls"].tolist()
+    # ... and the next gradient evaluation there does not try the extended order again (values still take it: their reach is their own)
+    n_ext = c3.n_extended
+    c3.value_and_grad(Z, *theta)
+    assert c3.n_extended == n_ext and c3.last_tier == 2 and c3.n_lo_rejections == 1
+    c3.value(Z, *theta)
+    assert c3.last_tier == 1
+    # the sampler mode takes the extended order's gradient as far as its value holds, whatever the correction says
+    F4, g4 = c3.value_and_grad(Z, *theta, grad_reach=16384.0, strict=True)
+    assert c3.last_tier == 1 and c3.n_lo_rejections == 1
+
+
 def test_hmc_target_sampler_mode_uses_the_extended_order_for_gradients(no_small_whitened):
     import ggp_amd as pkg
     from fake_engine import FactoredOracleEngine
@@ -342,15 +382,16 @@ def test_hmc_target_sampler_mode_uses_the_extended_order_for_gradients(no_small_
     X, y, Z = _problem()
     with pytest.raises(ValueError):
         pkg.HmcTarget(_bound(X, y), Z, gradient="fast")
-    # theta with an estimate inside the value reach but beyond the gradient range of the parity mode
-    th = [math.log(3.0)] * 3 + [0.0, math.log(0.1)]
+    # theta with an estimate inside the value reach but beyond the gradient range of the parity mode (1000 x the tolerance since round 6:
+    # the double-double Phibar with its trailing word in pass 2)
+    th = [math.log(5.0)] * 3 + [0.0, math.log(0.015)]
     ep, es = FactoredOracleEngine(), FactoredOracleEngine()
     parity = pkg.HmcTarget(_bound(X, y, ep), Z)
     sampler = pkg.HmcTarget(_bound(X, y, es), Z, gradient="sampler")
     lp_p, g_p = parity.logp_and_grad(th)
     lp_s, g_s = sampler.logp_and_grad(th)
     est = sampler.bound.last_estimate
-    assert 3.0 * 1e-9 < est <= 16384.0 * 1e-9, est
+    assert 1000.0 * 1e-9 < est <= 16384.0 * 1e-9, est
     assert ep.calls["suffstats_whitened_rows"] == 1 and ep.calls["suffstats_bwd_factored"] == 1    # parity: the whitened order
     assert es.calls["suffstats_whitened_rows"] == 0 and es.calls.get("suffstats_extended", 0) == 1   # sampler: the extended order
     lp_ref, g_ref = O.hmc_logp(torch.tensor(th, dtype=torch.float64), X, y, Z, 1e-6, with_grad=True)

@@ -514,6 +514,8 @@ def test_three_tier_guard_on_the_cpu_double():
         eng = FactoredOracleEngine()
         cb = pkg.CollapsedBound(X, y, jitter=1e-6, engine=eng)
         cb.whitened_rows_min_work = 0
+        cb.extended_lo = False   # (the gradient range of the leading word alone -- another kernel, d > 8: the trailing-word path has its
+        #                           own test, test_guard_logic.py::test_extended_gradient_is_trusted_by_its_own_trailing_word_correction)
         # estimates: 1.9e-9 (inside the gradient range 3e-9), 3.8e-9 (outside it, inside the value range 1.6e-5), 1.6e-4 (outside both), ~1e-12
         gmid, mid, far, benign = ([3.0] * 3, 1.0, 2e-2), ([3.0] * 3, 1.0, 1e-2), ([25.0] * 3, 1.0, 1e-5), ([0.8] * 3, 1.0, 0.3)
         ref = pkg.CollapsedBound(X, y, jitter=1e-6, engine=FactoredOracleEngine(), form="whitened")
@@ -573,7 +575,7 @@ def _tier_worker(rank, world, port, q):
     cb = pkg.CollapsedBound(X[lo:hi], y[lo:hi], jitter=1e-6, engine=eng)
     cb.whitened_rows_min_work = 0
     out = []
-    for ls, s2 in ((0.8, 0.3), (3.0, 2e-2), (3.0, 2e-2), (5.0, 1e-3), (5.0, 1e-3), (3.0, 2e-2), (0.8, 0.3), (0.8, 0.3)):
+    for ls, s2 in ((0.8, 0.3), (3.0, 2e-2), (3.0, 2e-2), (25.0, 1e-5), (25.0, 1e-5), (3.0, 2e-2), (0.8, 0.3), (0.8, 0.3)):   # (far: beyond the gradient range of the double-double Phibar too)
         F, g = cb.value_and_grad(Z, [ls] * 3, 1.0, s2, want_gz=False)
         out.append((F, g["ls"].numpy().tolist(), cb.n_guard_reruns, cb.n_direct_whitened, cb.n_extended, cb.n_collectives,
                     cb._prefer_whitened, cb.guard.predicted))

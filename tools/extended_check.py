@@ -43,13 +43,13 @@ for ls_v in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0):
             extended(ls, 1.0, sn * sn)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
-        grad_diff = grad_suite = grad_suite_fp64_formed = None
+        grad_diff = grad_suite = grad_suite_fp64_formed = grad_suite_hi_only = None
         if os.environ.get("GRADS", "0") == "1":  # gradients: the explicit Phibar of the extended order against the factored pass 2 of the whitened one
             _, gw = cw.value_and_grad(Zd, ls, 1.0, sn * sn, want_gz=False, raise_on_fail=False)
-            for dd in (True, False):   # Phibar formed in double-double (round 6, sgp_phibar_dd) / by two fp64 products (rounds 4-5)
+            for dd, lo in ((True, True), (True, False), (False, False)):   # Phibar in double-double with / without its trailing word in pass 2 (round 6); by two fp64 products (rounds 4-5)
                 cx = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=eng, form="extended")
                 cx.extended_level = LEVEL
-                cx.extended_dd_phibar = dd
+                cx.extended_dd_phibar, cx.extended_lo = dd, lo
                 _, gx = cx.value_and_grad(Zd, ls, 1.0, sn * sn, want_gz=False, raise_on_fail=False)
                 if gx.get("info", 0) == 0 and gw.get("info", 0) == 0:
                     a = torch.cat([gx["ls"], torch.tensor([gx["sf2"], gx["s2"]], dtype=torch.float64)])
@@ -57,12 +57,14 @@ for ls_v in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0):
                     # the parity suite's metric: lengthscale gradients against their largest component, sf2 / s2 against max(1, |ref|)
                     suite = max(float((gx["ls"] - gw["ls"]).abs().max() / gw["ls"].abs().max()),
                                 abs(gx["sf2"] - gw["sf2"]) / max(1.0, abs(gw["sf2"])), abs(gx["s2"] - gw["s2"]) / max(1.0, abs(gw["s2"])))
-                    if dd:
+                    if dd and lo:
                         grad_diff = float(((a - b).abs() / b.abs().clamp_min(1e-300)).max())
                         grad_suite = suite
+                    elif dd:
+                        grad_suite_hi_only = suite
                     else:
                         grad_suite_fp64_formed = suite
                 del cx
-        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate, "grad_max_rel_diff": grad_diff, "grad_suite_metric": grad_suite, "grad_suite_metric_fp64_formed_phibar": grad_suite_fp64_formed,
+        print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "estimate": cs.last_estimate, "grad_max_rel_diff": grad_diff, "grad_suite_metric": grad_suite, "grad_suite_metric_dd_leading_word_only": grad_suite_hi_only, "grad_suite_metric_fp64_formed_phibar": grad_suite_fp64_formed,
                           "err_streaming": abs(Fs - Fw) / N if ps.get("info", 0) == 0 else None,
                           "err_extended": abs(Fe - Fw) / N if ie == 0 else None, "info_extended": ie, "extended_ms": round(ms, 2), "level": LEVEL}), flush=True)
