@@ -409,7 +409,7 @@ class CollapsedBound:
             return need
         return None
 
-    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, tier=TIER_STREAMING, report=False):
+    def _forward(self, Z, ls, sf2, s2, with_adjoints, want_factors=False, extra=0, tier=TIER_STREAMING, report=False, want_lo=True):
         """One attempt in the given tier: pass 1, the exchange, the tail -- everything enqueued, nothing read back.
         report: also the streaming-order estimate / bound into the result buffer (sgp_streaming_error_report)."""
         e = self.engine
@@ -438,7 +438,7 @@ class CollapsedBound:
                           result=result, whitened=True, **({"want_cw": True} if dd else {}))
             if dd:
                 # ... and 35-700 x closer with the trailing word applied as well: a bf16 product K' Phibar_lo beside the fp64 one (_pass2)
-                lo = kfu is not None and self._bwd_lo_ok(M)
+                lo = want_lo and kfu is not None and self._bwd_lo_ok(M)   # (not for the sampler mode: it takes this order's gradient as it is)
                 res["Phibar"], res["Phibar_lo"] = e.phibar_dd(res["Cw"], linv, s2, want_lo=lo)
                 res["Cw"] = None   # (pass 2 of this order is the explicit one: _pass2 takes the factored route when a core is handed on)
             if report:
@@ -608,7 +608,8 @@ class CollapsedBound:
         done = {}
         may_go_down = strict
         while True:
-            res = self._forward(Z, ls, sf2, s2, with_adjoints=with_grad, want_factors=want_factors, extra=extra, tier=tier, report=guard)
+            res = self._forward(Z, ls, sf2, s2, with_adjoints=with_grad, want_factors=want_factors, extra=extra, tier=tier, report=guard,
+                                want_lo=grad_reach is None)
             head = res["buf"].numel() - extra  # [out | status word | estimate | bound | pad], then the packed gradient (16-byte aligned)
             g = res["buf"][head:] if with_grad else None
             res["lo_slots"] = lo_slots

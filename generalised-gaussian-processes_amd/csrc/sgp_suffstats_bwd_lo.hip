@@ -20,7 +20,7 @@
 // i.e. exactly what kbar_contract_kernel's epilogue would add had its C = K' Phibar carried the low word.  2 N M^2 flop on the fp16 / bf16
 // matrix cores (2.5 PFLOP/s dense) against the same count on the fp64 ones for the leading word: a few per cent of a leapfrog.
 // Layout: workgroup <-> (128 data rows, 128 inducing columns), four waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32, 64 fp32 accumulators);
-// 32-deep k-chunks: K' fp64 -> fp16 on the way into LDS (registers hold the next chunk while this one is multiplied), the fp16 image of
+// 32-deep k-chunks of the fp16 image of K' (made once per call) through LDS (registers hold the next chunk while this one is multiplied), the fp16 image of
 // the symmetric Phibar_lo read ROW-wise as B^T (so both fragments are 16 contiguous bytes of LDS).  The eight column blocks of a row block
 // share an XCD (ids 8 apart), whose L2 serves seven of the eight reads of every K' row block.
 // Reference: this is the reverse pass of pm.gp.MarginalSparse's logp (models/bayesian_sgpr_hmc.py:66-78) at a precision Theano's fp64
@@ -29,6 +29,7 @@
 #include "sgp_stream.hpp"
 #include "sgp_dense.hpp"
 #include <cstdint>
+#include <cstdlib>
 
 namespace sgp {
 
@@ -36,8 +37,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 lo_h8;
 typedef __attribute__((ext_vector_type(16))) float lo_f32x16;
 
 constexpr int LO_T = 128;     // tile edge (rows and columns)
-constexpr int LO_BK = 32;     // k-chunk (two MFMA k-steps of 16)
-constexpr int LO_LD = 40;     // fp16 elements per LDS row: 80 bytes -- 16-byte aligned fragments, rows 20 banks apart
+constexpr int LO_BK = 128;    // k-chunk: eight MFMA k-steps of 16 between two barriers (first version: 32 -- the next chunk's loads were issued 256
+                              // cycles ahead of their use, a tenth of the memory latency: 13.7 ms, 6 % of the matrix peak)
+constexpr int LO_LD = LO_BK + 8;  // fp16 elements per LDS row: 272 bytes -- 16-byte aligned fragments, consecutive rows 4 banks apart
 
 __device__ __forceinline__ uint32_t lo_h16(float f) {   // round to nearest even (v_cvt_f16_f32)
   const _Float16 hv = (_Float16)f;
@@ -66,16 +68,35 @@ __global__ __launch_bounds__(256) void lo_prep_kernel(const double* __restrict__
     out[(size_t)r * Mp + c] = (r < M && c < M) ? (uint16_t)lo_h16((float)ldexp(Plo[(size_t)r * M + c], sh)) : (uint16_t)0;
 }
 
+// fp16 image of K'_fu, once per call (first version: converted on the fly by each of the Mp / 128 column-block workgroups that read a row
+// block -- 65 GB of fp64 through the L2s for an 8 GB matrix: 13.7 ms at C5; with the image the product reads 2 GB eight times)
+__global__ __launch_bounds__(256) void lo_kfu_f16_kernel(const double* __restrict__ Kfu, int64_t n8, uint4* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+    const double2* src = reinterpret_cast<const double2*>(Kfu) + 4 * e;
+    const double2 a = src[0], b = src[1], c = src[2], d = src[3];
+    uint4 o;
+    o.x = lo_pack2(a.x, a.y); o.y = lo_pack2(b.x, b.y); o.z = lo_pack2(c.x, c.y); o.w = lo_pack2(d.x, d.y);
+    out[e] = o;
+  }
+}
+
 template <int DP>
-__global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restrict__ Kfu, const uint16_t* __restrict__ Pl,
+__global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restrict__ Kfu, const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
                                                       const double* __restrict__ unscale, const double* __restrict__ Xs,
                                                       const double* __restrict__ Zs, int Mp, int64_t nrb, int ncb,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ part, int dbg) {
   __shared__ __attribute__((aligned(16))) uint16_t ABs[2][LO_T][LO_LD];   // (one array: the epilogue reuses it as four 32 x 33 fp32 images)
   uint16_t (*As)[LO_LD] = ABs[0];
   uint16_t (*Bs)[LO_LD] = ABs[1];
-  __shared__ double Xl[LO_T][DP], Zl[LO_T][DP];
   __shared__ double red[4][DP + 1];
+  // (epilogue images inside the main-loop buffers: four wave-private 32 x 33 fp32 tiles, then the scaled rows / columns of this tile)
+  // and the fp16 image of this tile's own K' block (the contraction needs k' to three digits only; read back from the fp64 matrix it was
+  // sixteen dependent HBM round trips per wave -- 14.4 of the kernel's first 17 ms)
+  static_assert(4 * 32 * 33 * sizeof(float) + 2 * LO_T * DP * sizeof(double) + LO_T * LO_LD * sizeof(uint16_t) <= 2 * LO_T * LO_LD * sizeof(uint16_t),
+                "epilogue images fit");
+  double (*Xl)[DP] = reinterpret_cast<double (*)[DP]>(reinterpret_cast<char*>(&ABs[0][0][0]) + 4 * 32 * 33 * sizeof(float));
+  double (*Zl)[DP] = Xl + LO_T;
+  _Float16 (*Kt)[LO_LD] = reinterpret_cast<_Float16 (*)[LO_LD]>(Zl + LO_T);
   // id -> (xcd, column block, row block): the ncb column blocks of a row block share id % 8, i.e. one XCD under round-robin dispatch
   const int xcd = blockIdx.x & 7;
   const int64_t jj = blockIdx.x >> 3;
@@ -92,28 +113,25 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   const int64_t n0 = rb * LO_T;
   const int m0 = cb * LO_T;
 
-  // staging roles: thread <-> (row, half of the chunk): 16 consecutive k
-  const int srow = tid >> 1, skh = (tid & 1) * 16;
-  const double* asrc = Kfu + (size_t)(n0 + srow) * Mp + skh;
+  // staging roles: thread <-> (row, half of the chunk): LO_BK / 2 consecutive k, 16 bytes at a time
+  constexpr int NV = LO_BK / 16;   // uint4 per thread and operand
+  const int srow = tid >> 1, skh = (tid & 1) * (LO_BK / 2);
+  const uint16_t* asrc = Kh + (size_t)(n0 + srow) * Mp + skh;
   const uint16_t* bsrc = Pl + (size_t)(m0 + srow) * Mp + skh;
-  double2 areg[8];
-  uint4 breg[2];
+  uint4 areg[NV], breg[NV];
   auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const double2*>(asrc + k0 + 2 * q);
-    breg[0] = *reinterpret_cast<const uint4*>(bsrc + k0);
-    breg[1] = *reinterpret_cast<const uint4*>(bsrc + k0 + 8);
+    for (int q = 0; q < NV; ++q) {
+      areg[q] = *reinterpret_cast<const uint4*>(asrc + k0 + 8 * q);
+      breg[q] = *reinterpret_cast<const uint4*>(bsrc + k0 + 8 * q);
+    }
   };
   auto stash = [&]() __attribute__((always_inline)) {
-    uint4 a0, a1;
-    a0.x = lo_pack2(areg[0].x, areg[0].y); a0.y = lo_pack2(areg[1].x, areg[1].y);
-    a0.z = lo_pack2(areg[2].x, areg[2].y); a0.w = lo_pack2(areg[3].x, areg[3].y);
-    a1.x = lo_pack2(areg[4].x, areg[4].y); a1.y = lo_pack2(areg[5].x, areg[5].y);
-    a1.z = lo_pack2(areg[6].x, areg[6].y); a1.w = lo_pack2(areg[7].x, areg[7].y);
-    *reinterpret_cast<uint4*>(&As[srow][skh]) = a0;
-    *reinterpret_cast<uint4*>(&As[srow][skh + 8]) = a1;
-    *reinterpret_cast<uint4*>(&Bs[srow][skh]) = breg[0];
-    *reinterpret_cast<uint4*>(&Bs[srow][skh + 8]) = breg[1];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      *reinterpret_cast<uint4*>(&As[srow][skh + 8 * q]) = areg[q];
+      *reinterpret_cast<uint4*>(&Bs[srow][skh + 8 * q]) = breg[q];
+    }
   };
 
   lo_f32x16 acc[2][2];
@@ -124,19 +142,14 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // the scaled inputs of this tile's rows and columns, for the epilogue
-  for (int e = tid; e < LO_T * DP; e += 256) {
-    Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
-    Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
-  }
-
   fetch(0);
   for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
-    stash();
+    if (!(dbg & 4)) stash();
     __syncthreads();
     if (k0 + LO_BK < Mp) fetch(k0 + LO_BK);   // in flight under this chunk's MFMAs
+    if (!(dbg & 2))
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < LO_BK / 16; ++ks) {
       lo_h8 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const lo_h8*>(&As[wr * 64 + i * 32 + r31][ks * 16 + 8 * h]);
@@ -153,8 +166,25 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   // epilogue.  Accumulator element (reg e of a 32 x 32 tile): row = (e & 3) + 8 (e >> 2) + 4 h, column = r31 (C/D layout of the 32 x 32 forms).
   // The four tiles of a wave go through a wave-private 32 x 33 LDS image one after the other, so that the contraction is a ROLLED loop
   // over rows (straight from the registers it is 64 unrolled elements whose loads the compiler hoists: 512 VGPRs, 150 spilled).
-  float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(&As[0][0]) + wave * 32 * 33);   // 4 x 4224 B inside As (10 KB) + Bs
-  static_assert(4 * 32 * 33 * sizeof(float) <= 2 * LO_T * LO_LD * sizeof(uint16_t), "the staging images fit in the main-loop buffers");
+  if (dbg & 1) {   // (diagnosis, SGP_LO_DBG: the main loop alone)
+    if (tid <= DP) mypart[tid] = (double)acc[0][0][0] + (double)areg[0].x;
+    return;
+  }
+  float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(&ABs[0][0][0]) + wave * 32 * 33);
+  // the scaled inputs of this tile's rows and columns (the main loop's last barrier is behind every wave)
+  {
+    uint4 kt[LO_T / 16];   // this thread's share of the 128 x 128 fp16 block: row srow, 64 columns (all loads in flight together)
+    const uint16_t* ksrc = Kh + (size_t)(n0 + srow) * Mp + m0 + (tid & 1) * (LO_T / 2);
+#pragma unroll
+    for (int q = 0; q < LO_T / 16; ++q) kt[q] = *reinterpret_cast<const uint4*>(ksrc + 8 * q);
+    for (int e = tid; e < LO_T * DP; e += 256) {
+      Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
+      Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
+    }
+#pragma unroll
+    for (int q = 0; q < LO_T / 16; ++q) *reinterpret_cast<uint4*>(&Kt[srow][(tid & 1) * (LO_T / 2) + 8 * q]) = kt[q];
+  }
+  __syncthreads();
   double S[DP + 1];
 #pragma unroll
   for (int q = 0; q <= DP; ++q) S[q] = 0.0;
@@ -172,10 +202,9 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const int rbase = wr * 64 + i * 32 + 16 * h;
-      const double* kcol = Kfu + (size_t)(n0 + rbase) * Mp + m0 + col;
 #pragma unroll 4
       for (int rr = 0; rr < 16; ++rr) {
-        const double kp = kcol[(size_t)rr * Mp];   // (zero in the padding: padded rows / columns add nothing)
+        const double kp = (double)Kt[rbase + rr][col];   // (zero in the padding: padded rows / columns add nothing)
         const double w = (double)Cl[16 * h + rr][r31] * (kp * us);
         S[DP] += w;
 #pragma unroll
@@ -199,15 +228,21 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
 // g_ls[j] += 2 inv_ls_j sf2^2 sum_parts S_j ; g_sf2 += 2 sf2 sum_parts S_DP -- one block, a fixed thread <-> partial mapping and a fixed tree
 // delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
 // the explicit pass 2 can be trusted at this theta (core.py: extended_lo_max_correction)
+// (one workgroup per slot: 256 threads stride over the partials -- 62 500 of them at C5 --, wave sums, four wave totals added in order)
 __global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict__ part, int nparts, int DP, KernArgs ka,
                                                         double* __restrict__ g_ls, double* __restrict__ g_sf2, double* __restrict__ delta) {
+  __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int q = wave; q <= ka.d; q += 4) {
+  {
+    const int q = blockIdx.x;
     const int slot = q == ka.d ? DP : q;
     double s = 0.0;
-    for (int p = lane; p < nparts; p += 64) s += part[(size_t)p * (DP + 1) + slot];
+    for (int p = threadIdx.x; p < nparts; p += 256) s += part[(size_t)p * (DP + 1) + slot];
     s = wave_sum(s);
-    if (lane == 0) {
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
       const double c = q == ka.d ? 2.0 * ka.sf2 * s : 2.0 * ka.inv_ls[q] * ka.sf2 * ka.sf2 * s;
       if (q == ka.d) *g_sf2 += c;
       else g_ls[q] += c;
@@ -218,7 +253,7 @@ __global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict
 
 struct LoWs {
   double *Xs, *ys, *Zs, *yypart, *part, *unscale;
-  uint16_t* Pl;
+  uint16_t *Pl, *Kh;
   size_t bytes;
   int grid;
 };
@@ -235,6 +270,7 @@ static LoWs carve_lo(void* ws, const StreamPlan& p) {
   w.part = c.take<double>((size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1));
   w.Pl = c.take<uint16_t>((size_t)p.Mp * p.Mp);
   w.unscale = c.take<double>((size_t)p.Mp);
+  w.Kh = c.take<uint16_t>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp);
   w.bytes = c.used();
   return w;
 }
@@ -275,11 +311,13 @@ extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* 
   lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, w.Pl, w.unscale);
   const int64_t nrb = p.Npad / LO_T;
   const int ncb = p.Mp / LO_T;
+  static const int dbg = getenv("SGP_LO_DBG") ? atoi(getenv("SGP_LO_DBG")) : 0;   // diagnosis only: 1 no epilogue, 2 no MFMA, 4 no LDS staging
+  lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
   switch (p.DP) {
-    case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
-    case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
-    default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+    case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
+    case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
+    default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
   }
-  lo_reduce_kernel<<<1, 256, 0, st>>>(w.part, w.grid, p.DP, ka, g_ls, g_sf2, delta);
+  lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, w.grid, p.DP, ka, g_ls, g_sf2, delta);
   return check_launch();
 }

@@ -89,19 +89,29 @@ def test_c5_trained_theta_gradients_rows_layout_with_t_handover_and_extended_ord
     check("whitened rows layout + T hand-over", Fw, gw)
     del cw
 
-    # (2) form="auto": whatever tier the guard picks for a value + gradient evaluation has to meet both tolerances
+    # (2) form="auto": at this theta the estimate is far beyond the old gradient range of the extended order (3 x the tolerance) -- since
+    # round 6 a value + gradient evaluation takes that order all the same (asserted), with its Phibar formed in double-double and the
+    # trailing word applied in pass 2 (sgp_phibar_dd, sgp_suffstats_bwd_lo), accepted on the size of the trailing word's correction
     ca = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=engine)
     Fa, ga = ca.value_and_grad(Zd, LS_TRAINED, SF_TRAINED ** 2, SN_TRAINED ** 2, want_gz=False)
     est = ca.last_estimate
     check("auto (estimate %.3g, reruns %d, extended %d)" % (est or -1.0, ca.n_guard_reruns, ca.n_extended), Fa, ga)
-    within = est is not None and est <= ca.extended_grad_range * ca.streaming_tol
+    assert est > 10.0 * ca.extended_grad_range * ca.streaming_tol, est
+    assert ca.last_tier == 1 and ca.n_lo_rejections == 0 and ca.last_lo_correction <= ca.extended_lo_max_correction, (ca.last_tier, ca.last_lo_correction)
     del ca
 
-    # (3) the extended order's explicit-Phibar gradient: held to 1e-6 inside its range (beyond it the product code never uses it)
-    ce = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=engine, form="extended")
-    Fe, ge = ce.value_and_grad(Zd, LS_TRAINED, SF_TRAINED ** 2, SN_TRAINED ** 2, want_gz=False)
-    assert abs(Fe - ref["F"]) / GR < 1e-8, (Fe, ref["F"])
-    err = float((ge["ls"] - ref["g_ls"]).abs().max()) / max(1.0, float(ref["g_ls"].abs().max()))
-    print("extended-order gradient: estimate %.3g (range %.3g), max rel. error %.3g" % (est or -1.0, 3e-9, err))
-    if within:
-        check("extended", Fe, ge)
+    # (3) the three generations of the extended order's explicit-Phibar gradient against autograd: both words of the double-double matrix
+    # (held to 1e-6: the product's route), its leading word alone, the fp64-formed matrix of rounds 4-5 (reported)
+    errs = {}
+    for tag, dd, lo in (("both words", True, True), ("leading word", True, False), ("fp64-formed", False, False)):
+        ce = ggp_amd.CollapsedBound(Xd, yd, jitter=bench.JITTER, engine=engine, form="extended")
+        ce.extended_dd_phibar, ce.extended_lo = dd, lo
+        Fe, ge = ce.value_and_grad(Zd, LS_TRAINED, SF_TRAINED ** 2, SN_TRAINED ** 2, want_gz=False)
+        assert abs(Fe - ref["F"]) / GR < 1e-8, (Fe, ref["F"])
+        errs[tag] = max(float((ge["ls"] - ref["g_ls"]).abs().max()) / max(1.0, float(ref["g_ls"].abs().max())),
+                        abs(ge["sf2"] - ref["g_sf2"]) / max(1.0, abs(ref["g_sf2"])))
+        if dd and lo:
+            check("extended, both words of the double-double Phibar", Fe, ge)
+        del ce
+    print("extended-order gradient against autograd at an estimate of %.3g: %s" % (est, ", ".join("%s %.3g" % kv for kv in errs.items())))
+    assert errs["both words"] < 0.2 * errs["fp64-formed"]

@@ -105,12 +105,21 @@ def test_extended_order_where_the_streaming_order_fails(engine):
         if 1e-9 < est <= 16384e-9 and ca.n_extended > before:
             seen_tier1 += 1
     assert seen_tier1 >= 1, "no cell of this sweep ran in the extended tier"
-    # gradients at such a theta do NOT take the extended order (its explicit Phibar cancels): the same bound sends them to the whitened one
+    # Gradients at such a theta: through round 5 the same bound sent them to the whitened order (the explicit Phibar of this order cancels).
+    # Since round 6 they take this order too -- Phibar formed in double-double, its trailing word applied in pass 2 -- as long as the
+    # trailing word's correction stays small against the gradient, and agree with the whitened order's factored pass 2 to 1e-6; with the
+    # trailing word switched off (what another kernel or d > 8 gets) the old rule holds.
     before = ca.n_extended
     Fg, g = ca.value_and_grad(Zd, [4.0] * D, 1.0, 0.09, want_gz=False)
     cw = ggp_amd.CollapsedBound(Xd, yd, jitter=1e-6, engine=engine, form="whitened")
     Fw, gw = cw.value_and_grad(Zd, [4.0] * D, 1.0, 0.09, want_gz=False)
-    assert ca.n_extended == before and Fg == Fw and torch.equal(g["ls"], gw["ls"])
+    assert ca.n_extended == before + 1 and ca.last_tier == 1 and ca.last_lo_correction <= ca.extended_lo_max_correction
+    assert abs(Fg - Fw) / N < 1e-9 and float((g["ls"] - gw["ls"]).abs().max()) < 1e-6 * max(1.0, float(gw["ls"].abs().max()))
+    assert abs(g["sf2"] - gw["sf2"]) < 1e-6 * max(1.0, abs(gw["sf2"])) and abs(g["s2"] - gw["s2"]) < 1e-6 * max(1.0, abs(gw["s2"]))
+    ca.extended_lo = False
+    before = ca.n_extended
+    Fg, g = ca.value_and_grad(Zd, [4.0] * D, 1.0, 0.09, want_gz=False)
+    assert ca.n_extended == before and ca.last_tier == 2 and Fg == Fw and torch.equal(g["ls"], gw["ls"])
 
 
 def test_extended_order_gradients_against_autograd(engine):
@@ -137,8 +146,9 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
     """Round 6.  sgp_phibar_dd forms Phibar = L^-T (C / 2 s2) L^-1 in double-double: (i) its two words against an x87
     long-double product of the same inputs; (ii) sgp_suffstats_bwd_lo -- dC = K' Phibar_lo on the fp16 matrix cores (rows scaled by powers of two), contracted with dK
     in fp64 -- against the fp64 pass 2 run on the trailing word itself (what it approximates: three digits are asked for, 3e-3 is held);
-    (iii) a matrix that is NOT small handed over as `Phibar_lo` (the kernel is a plain fp16 product + contraction: 3e-3 of the fp64 result
-    there too, ragged shapes, padded rows and columns adding nothing)."""
+    (iii) the same for a symmetric matrix whose rows span ten decades (the per-row power-of-two scaling; ragged shapes, padded rows and columns
+    adding nothing).  The kernel is a three-digit product: it is NOT asked to resolve cancellation, which the trailing word -- rounding
+    residuals -- does not have."""
     import numpy as np
     import ggp_amd
     for (N, M, d) in ((3000, 200, 3), (20000, 384, 8), (777, 130, 1)):
@@ -164,7 +174,9 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
         kfu = engine.kfu_buffer(N, M)
         engine.suffstats(Xd, yd, Zd, ls, sf2, "rbf", kfu=kfu)
         zero = torch.zeros(M, dtype=torch.float64, device=engine.device)
-        for P in (lo, hi * 1e-3):
+        Pr = torch.randn(M, M, dtype=torch.float64, generator=g)
+        Pr = ((Pr + Pr.T) * torch.logspace(-14, -9, M, dtype=torch.float64)[:, None] * torch.logspace(-14, -9, M, dtype=torch.float64)[None, :]).to(engine.device)
+        for P in (lo, Pr):   # (the trailing word; a symmetric matrix whose rows span ten decades -- no cancellation to resolve in either)
             exact = engine.suffstats_bwd(Xd, yd, Zd, ls, sf2, P, zero, 0.0, "rbf", want_gz=False, kfu=kfu).cpu()
             acc = torch.zeros(d + 1, dtype=torch.float64, device=engine.device)
             engine.suffstats_bwd_lo(Xd, yd, Zd, ls, sf2, P, kfu, acc, "rbf")

@@ -17,10 +17,10 @@ X, y, Z = bench.synth(N, M, d)
 Xd, yd, Zd = X.to(eng.device), y.to(eng.device), Z.to(eng.device)
 ls, sf2, s2 = [3.0] * d, 1.0, 0.145 ** 2
 Kuu = eng.kuu(Zd, ls, sf2, bench.JITTER, "rbf")
-linv, _ = eng.kuu_factor(Kuu)
+linv, _info = eng.kuu_factor(Kuu)
 kfu = eng.kfu_buffer(N, M)
 packed = eng.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, "rbf", kfu=kfu, level=2)
-res = eng.bound(Kuu, packed, s2, N, with_adjoints=True, kuu_linv=linv, whitened=True, want_cw=True)
+res = eng.bound(Kuu, packed, s2, N, with_adjoints=True, kuu_linv=linv, kuu_info=_info, whitened=True, want_cw=True)
 g = eng.empty(d + 1)
 
 
