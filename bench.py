@@ -446,13 +446,16 @@ def main():
         "tolerance_per_datum": cb.streaming_tol, "estimate_per_datum": cb.last_estimate, "repeats_in_whitened_order": cb.n_guard_reruns,
         "direct_whitened_evaluations": cb.n_direct_whitened, "extended_order_evaluations": cb.n_extended,
         "extended_order_level": cb.extended_level, "extended_order_reach_values": cb.extended_range,
-        "extended_order_reach_gradients": cb.extended_grad_range,
+        "extended_order_reach_gradients": (cb.extended_grad_range_lo if cb._bwd_lo_ok(args.m) else cb.extended_grad_range),
+        "extended_order_gradient_check": "both words of a double-double Phibar in pass 2 (sgp_phibar_dd, sgp_suffstats_bwd_lo); accepted while the "
+                                         "trailing word's correction is <= %g of the gradient, else repeated in the whitened order" % cb.extended_lo_max_correction,
         "note": "first-order estimate of |dF| / N of the streaming order (2^-53 max Phi_ii tr(Kuu^-1) / (s2 N), include/sgp.h: "
                 "sgp_streaming_error_report), read back with every evaluation; above the tolerance the evaluation is repeated in the "
                 "extended streaming order (level %d: %d digit pairs; values while the estimate is <= %g x the tolerance, value + gradient "
                 "while <= %g x) or in the whitened (PyMC3) order beyond, and the evaluations that follow START there until the estimate is "
                 "below half the tolerance -- 0, 0 and 0 = every timed step ran the streaming design"
-                % (cb.extended_level, 39 if cb.extended_level >= 2 else 34, cb.extended_range, cb.extended_grad_range)}
+                % (cb.extended_level, 39 if cb.extended_level >= 2 else 34, cb.extended_range,
+                   cb.extended_grad_range_lo if cb._bwd_lo_ok(args.m) else cb.extended_grad_range)}
     if world == 1:
         # what an evaluation costs where the guard sends it: the whitened (PyMC3) order on the same shard and theta, a few repetitions
         # outside the timed region (engine.suffstats_whitened_rows + suffstats_bwd_factored)
@@ -473,8 +476,9 @@ def main():
         res["config"]["streaming_guard"]["whitened_order"] = {
             "ms_per_evaluation": tw[0], "ms_per_leapfrog": tw[1], "F_minus_streaming_F_per_datum": (Fw - last["F"]) / args.n,
             "note": "not part of `value`: the cost of one evaluation / one value+gradient in the order the guard falls back to beyond "
-                    "the extended order's reach (%g x the tolerance for values, %g x for gradients that must hold 1e-6)"
-                    % (cb.extended_range, cb.extended_grad_range)}
+                    "the extended order's reach (%g x the tolerance for values, %g x for gradients that must hold 1e-6 -- and wherever "
+                    "the trailing-word check rejects the extended order's gradient)"
+                    % (cb.extended_range, cb.extended_grad_range_lo if cb._bwd_lo_ok(args.m) else cb.extended_grad_range)}
         del wb
         # ... and in the tier between: the extended streaming order (engine.suffstats_extended)
         xb = ggp_amd.CollapsedBound(Xd, yd, kernel="rbf", jitter=JITTER, engine=eng, form="extended")
@@ -494,7 +498,8 @@ def main():
         res["config"]["streaming_guard"]["extended_order"] = {
             "ms_per_evaluation": tx[0], "ms_per_leapfrog": tx[1], "F_minus_whitened_F_per_datum": (Fx - Fw) / args.n,
             "note": "not part of `value`: Phi on the integer cores with %d digit pairs and a double-double fold, W = L^-1 Phi L^-T in "
-                    "double-double, pass 2 from the explicit Phibar" % (39 if xb.extended_level >= 2 else 34)}
+                    "double-double, pass 2 from the explicit Phibar -- formed in double-double, its leading word on the fp64 matrix cores, "
+                    "its trailing word on the fp16 ones (round 6)" % (39 if xb.extended_level >= 2 else 34)}
         del xb
         # ... and what NUTS gets where the reference samples after training (train_fixed_model, models/bayesian_sgpr_hmc.py:160-180):
         # the trained ARD theta of profiles/r04_experiment_large_scale.json is in the guarded regime.  Leapfrogs / s of the NUTS target
@@ -516,15 +521,19 @@ def main():
                 tgt.logp_and_grad(th_tr)
             torch.cuda.synchronize(dev)
             trained[mode] = {"leapfrog_per_s": 4.0 / (time.perf_counter() - t0), "tier": tb.last_tier, "estimate_per_datum": tb.last_estimate,
-                             "logp": lp}
+                             "logp": lp, "lo_correction": tb.last_lo_correction, "lo_rejections": tb.n_lo_rejections}
             del tgt, tb
         res["leapfrog_per_s_trained_theta"] = {
             "parity": trained["parity"]["leapfrog_per_s"], "sampler": trained["sampler"]["leapfrog_per_s"],
             "tier": {k: ("streaming", "extended", "whitened")[v["tier"]] for k, v in trained.items()},
             "estimate_per_datum": trained["parity"]["estimate_per_datum"],
             "logp_difference_per_datum": (trained["sampler"]["logp"] - trained["parity"]["logp"]) / args.n,
+            "parity_trailing_word_correction_over_gradient": trained["parity"]["lo_correction"],
+            "parity_trailing_word_rejections": trained["parity"]["lo_rejections"],
             "note": "outside `value`: value + gradient of the NUTS target at the trained ARD theta of C5 (lengthscales 2.3 .. 7.2, sig_n 0.144), "
-                    "four evaluations each; `sampler` = HmcTarget(gradient='sampler')"}
+                    "four evaluations each; `parity` (default): every gradient holds 1e-6 -- since round 6 in the extended order with both words "
+                    "of a double-double Phibar while the trailing word's correction stays small (13.4 / s in the whitened order through round 5); "
+                    "`sampler` = HmcTarget(gradient='sampler'): the leading word only"}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         res["cpu_baseline"] = cpu_baseline(X, y, Z, min(args.cpu_sample, args.n), args.cpu_full)
     if rank == 0:

@@ -156,8 +156,8 @@ def test_gpu_samplers_reproduce_the_exact_posterior(engine):
 # ---------------------------------------------------------------------------------------------
 # HmcTarget(gradient="sampler") -- VERDICT r4 next-3.  The d = 1 fixture sits in the streaming-order guard's regime all by itself once
 # the multi-launch path is forced (estimates over the posterior: 3e-10 .. 1.5e-6, median 1.9e-8, against the tolerance 1e-9): the
-# default mode sends ~85 % of the leapfrogs to the whitened order, the sampler mode runs them in the extended order with its
-# explicit-Phibar gradient.  Same pin as every other sampler: means and variances within 4 MCSE of the quadrature.
+# default mode sent ~85 % of the leapfrogs to the whitened order through round 5 (since round 6: to the extended order with both words of a
+# double-double Phibar), the sampler mode runs them in the extended order with its explicit-Phibar gradient as it is.  Same pin as every other sampler: means and variances within 4 MCSE of the quadrature.
 # ---------------------------------------------------------------------------------------------
 def _guarded_target(P, engine, gradient, to_dev=None):
     T = (lambda a: torch.as_tensor(a, dtype=torch.float64)) if to_dev is None else to_dev
@@ -201,6 +201,9 @@ def test_sampler_gradient_mode_reproduces_the_exact_posterior_on_the_gpu(engine,
                       float(np.asarray(tr.get_sampler_stats("step_size"))[-1]))
         assert np.asarray(tr.get_sampler_stats("diverging")).mean() <= 0.01
         check_moments(unconstrained(tr), P, "sample_nuts, HmcTarget(gradient=%r) / HIP multi-launch path" % mode)
-    assert runs["sampler"][1] > 0.7 and runs["parity"][1] < 0.5, (runs["sampler"][1], runs["parity"][1])
+    # (through round 5 the default mode sent ~85 % of these leapfrogs to the whitened order; since round 6 its gradients take the extended
+    # order too -- double-double Phibar, trailing word in pass 2 -- wherever the trailing word's correction stays small: both modes mostly
+    # run there now, the default one with the parity-grade gradient)
+    assert runs["sampler"][1] > 0.7 and runs["parity"][1] > 0.5, (runs["sampler"][1], runs["parity"][1])
     acc_s, acc_p, eps_s, eps_p = runs["sampler"][2], runs["parity"][2], runs["sampler"][3], runs["parity"][3]
     assert abs(acc_s - acc_p) < 0.1 * acc_p and abs(eps_s - eps_p) < 0.1 * eps_p, (acc_s, acc_p, eps_s, eps_p)
