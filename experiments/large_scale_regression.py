@@ -68,6 +68,8 @@ def main():
                       # leapfrogs the streaming-order guard sent to the whitened (PyMC3) order
                       "guard_repeats": int(hmc._hmc_bound().n_guard_reruns), "direct_whitened": int(hmc._hmc_bound().n_direct_whitened),
                       "extended_order": int(getattr(hmc._hmc_bound(), "n_extended", 0)), "guard_tolerance_per_datum": hmc._hmc_bound().streaming_tol,
+                      "trailing_word_rejections": int(getattr(hmc._hmc_bound(), "n_lo_rejections", 0)),
+                      "trailing_word_last_correction": getattr(hmc._hmc_bound(), "last_lo_correction", None),
                       "guard_last_estimate_per_datum": hmc._hmc_bound().last_estimate, "evaluations": int(hmc._hmc_bound().n_evals)}
     print(json.dumps(out))
 

@@ -219,7 +219,7 @@ class CollapsedBound:
         # the counter-example that makes the second condition necessary (estimate 1.8e-7, correction 5.5e-4, 8e-6 left).
         self.extended_grad_range_lo = 1000.0
         self.extended_lo_max_correction = 1e-4
-        self.lo_reject_estimate = float("inf")   # the smallest estimate at which that check has failed (where gradient evaluations START: memory only)
+        self._lo_skip, self._lo_pause = 0, 0     # gradient evaluations still to start in the whitened order behind a rejection / the current pause (memory only)
         self.last_lo_correction = None
         self.n_lo_rejections = 0
         self.guard = GuardState()
@@ -593,8 +593,11 @@ class CollapsedBound:
         # (behind the packed gradient: d + 1 slots for the trailing word's correction, which decides whether the explicit pass 2 is trusted)
         lo_slots = (nh + 1) if (with_grad and guard and ext_ok and self._bwd_lo_ok(M)) else 0
         extra = nh + 1 + (M * d if want_gz else 0) + lo_slots if with_grad else 0
-        if guard and with_grad and tier == TIER_EXTENDED and grad_reach is None and self.guard.predicted >= 0.7 * self.lo_reject_estimate:
-            tier = TIER_WHITENED   # (the correction was too large the last time the estimate was about this: no wasted attempt per leapfrog)
+        if guard and with_grad and tier == TIER_EXTENDED and grad_reach is None and self._lo_skip > 0:
+            # the trailing word's correction was too large a moment ago: the next few gradient evaluations go straight to the whitened order (no
+            # wasted attempt per leapfrog); the pause doubles with every rejection in a row (8, 16, 32) and ends with the first acceptance
+            self._lo_skip -= 1
+            tier = TIER_WHITENED
         # Small shards: pass 2 is enqueued straight behind the tail and ONE copy at the very end brings back F, the status and the
         # gradient -- a failed factorization or a guard repeat then costs a wasted pass 2, which is cheaper than idling the GPU for
         # a host round trip on every leapfrog.  Big shards check first.  The rule is the job's (largest shard), not this rank's:
@@ -639,9 +642,12 @@ class CollapsedBound:
                 # left behind the correction is a few per cent of it: profiles/r06_extended_order_gradients_*): repeated in the whitened order
                 self.n_guard_reruns += 1
                 self.n_lo_rejections += 1
-                self.lo_reject_estimate = min(self.lo_reject_estimate, self.last_estimate if self.last_estimate is not None else 0.0)
+                self._lo_pause = min(32, 2 * self._lo_pause) if self._lo_pause else 8
+                self._lo_skip = self._lo_pause
                 tier = TIER_WHITENED
                 continue
+            if with_grad and tier == TIER_EXTENDED and res.get("Phibar_lo") is not None and lo_slots and grad_reach is None:
+                self._lo_pause = 0   # accepted: the next rejection starts with the short pause again
             self.last_tier = tier
             return res, o, info, host, head
 

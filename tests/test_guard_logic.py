@@ -364,15 +364,25 @@ def test_extended_gradient_is_trusted_by_its_own_trailing_word_correction(no_sma
     c3 = _bound(X, y, e3)
     F3, g3 = c3.value_and_grad(Z, *theta)
     assert c3.last_tier == 2 and c3.n_lo_rejections == 1 and e3.calls["suffstats_bwd_factored"] == 1 and g3["ls"].tolist() == gw["ls"].tolist()
-    # ... and the next gradient evaluation there does not try the extended order again (values still take it: their reach is their own)
+    # ... and the next EIGHT gradient evaluations do not try the extended order again (values still take it: their reach is their own);
+    # the ninth does, is rejected again, and the pause doubles
     n_ext = c3.n_extended
-    c3.value_and_grad(Z, *theta)
-    assert c3.n_extended == n_ext and c3.last_tier == 2 and c3.n_lo_rejections == 1
+    for _ in range(8):
+        c3.value_and_grad(Z, *theta)
+        assert c3.n_extended == n_ext and c3.last_tier == 2 and c3.n_lo_rejections == 1
     c3.value(Z, *theta)
     assert c3.last_tier == 1
+    n_ext = c3.n_extended
+    c3.value_and_grad(Z, *theta)
+    assert c3.n_extended == n_ext + 1 and c3.last_tier == 2 and c3.n_lo_rejections == 2 and c3._lo_skip == 16
+    e3.lo_delta_scale = 1.0                      # the correction is small again: after the pause the extended order is back, the pause forgotten
+    c3._lo_skip = 0
+    c3.value_and_grad(Z, *theta)
+    assert c3.last_tier == 1 and c3._lo_pause == 0
     # the sampler mode takes the extended order's gradient as far as its value holds, whatever the correction says
+    e3.lo_delta_scale = 1e12
     F4, g4 = c3.value_and_grad(Z, *theta, grad_reach=16384.0, strict=True)
-    assert c3.last_tier == 1 and c3.n_lo_rejections == 1
+    assert c3.last_tier == 1 and c3.n_lo_rejections == 2
 
 
 def test_hmc_target_sampler_mode_uses_the_extended_order_for_gradients(no_small_whitened):
