@@ -205,6 +205,9 @@ def main():
     backend = os.environ.get("SGP_BENCH_BACKEND", "nccl")
     if os.environ.get("SGP_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+        # several processes on one device: the single-launch Cholesky claims its work items by ticket (include/sgp.h: SGP_OPT_SHARED_DEVICE;
+        # read when the engine's context is created) -- two statically dealt spinning launches can starve each other into a time-out
+        os.environ.setdefault("SGP_SHARED_DEVICE", "1")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
