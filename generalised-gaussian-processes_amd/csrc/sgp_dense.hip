@@ -509,10 +509,12 @@ void tri_diag_inverse(const double* L, double* Linv, int64_t ld, int Mp, hipStre
   tri_diag_inv_kernel<<<Mp / DB, 256, 0, st>>>(L, Linv, ld);
 }
 
+// ticketed: the items are drawn from the scratch's claim counter (sgp_potrf_items.hpp: CF_TICKET, zeroed with the flags) instead of dealt
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(double* A, int64_t ld, int nb, int* ready, double* dinv_g, int* info,
-                                                              int info_base, const double* rhs, double* sol, double* Linv) {
+                                                              int info_base, const double* rhs, double* sol, double* Linv, int ticketed) {
   __shared__ DfShared sh;
-  potrf_dataflow_body(A, ld, nb, ready, dinv_g, info, info_base, rhs, sol, Linv, sh, blockIdx.x, gridDim.x);
+  potrf_dataflow_body(A, ld, nb, ready, dinv_g, info, info_base, rhs, sol, Linv, sh, blockIdx.x, gridDim.x,
+                      ticketed ? ready + (size_t)ch_flag_base(CF_TICKET, nb) * DF_FLAG_STRIDE : nullptr);
 }
 
 // Round 5: the chain-workgroup factorization (sgp_potrf_chain.hpp).  Workgroup 0 (eight waves) is the chain workgroup; the others
@@ -550,12 +552,13 @@ extern "C" __attribute__((visibility("default"))) int sgp_debug_potrf_trace(int*
 
 // S factorizations side by side: blockIdx.y selects the matrix, its flags / block inverses and its status word
 __global__ __launch_bounds__(256) void potrf_dataflow_batch_kernel(double* A, int64_t ld, int nb, int* scratch, int64_t scratch_ints,
-                                                                    int64_t flag_ints, int* info, double* Linv, int64_t stride) {
+                                                                    int64_t flag_ints, int* info, double* Linv, int64_t stride, int ticketed) {
   __shared__ DfShared sh;
   const int64_t s = blockIdx.y;
   int* ready = scratch + s * scratch_ints;
   potrf_dataflow_body(A + s * stride, ld, nb, ready, reinterpret_cast<double*>(ready + flag_ints), info + s, 0, nullptr, nullptr,
-                      Linv ? Linv + s * stride : nullptr, sh, blockIdx.x, gridDim.x);
+                      Linv ? Linv + s * stride : nullptr, sh, blockIdx.x, gridDim.x,
+                      ticketed ? ready + (size_t)ch_flag_base(CF_TICKET, nb) * DF_FLAG_STRIDE : nullptr);
 }
 __global__ void potrf_timeout_batch_kernel(const int* scratch, int64_t scratch_ints, int abort_off, int* info, int S) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -668,7 +671,7 @@ bool potrf_lower(double* A, double* Linv, int64_t ld, int Mp, int* info, int inf
     return Linv != nullptr;  // the whole of L^-1, not only its diagonal blocks
   }
   potrf_dataflow_kernel<<<nitem < max_wg ? nitem : max_wg, 256, 0, st>>>(
-      A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv);
+      A, ld, nb, scratch, reinterpret_cast<double*>(scratch + potrf_flag_ints(Mp)), info, info_base, rhs, sol, Linv, (mode & CH_MODE_TICKET) ? 1 : 0);
   if (!caller_managed) potrf_timeout_kernel<<<1, 64, 0, st>>>(scratch + ntile * DF_FLAG_STRIDE, info);
   return false;
 }
@@ -682,7 +685,8 @@ void potrf_lower_batch(double* A, double* Linv, int64_t ld, int Mp, int S, int64
   if (per < 1) per = 1;
   zero_ints(scratch, (int)(sints * S), st);
   if (Linv) fill_zero(Linv, (size_t)stride * (S - 1) + (size_t)Mp * ld, st);
-  potrf_dataflow_batch_kernel<<<dim3(ntile < per ? ntile : per, S), 256, 0, st>>>(A, ld, nb, scratch, sints, fints, info, Linv, stride);
+  potrf_dataflow_batch_kernel<<<dim3(ntile < per ? ntile : per, S), 256, 0, st>>>(A, ld, nb, scratch, sints, fints, info, Linv, stride,
+                                                                                cur_ctx().shared_device ? 1 : 0);
   potrf_timeout_batch_kernel<<<1, 64, 0, st>>>(scratch, sints, ntile * DF_FLAG_STRIDE, info, S);
 }
 

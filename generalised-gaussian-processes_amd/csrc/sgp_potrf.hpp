@@ -285,6 +285,7 @@ struct DfShared {
   double rdiag3[16];       // reciprocal pivots of the last panel (for wave 0's block inverse behind the chain)
   int bad;
   int dead;
+  int ticket;              // (ticketed claim: the item number thread 0 drew, for the other waves)
 };
 
 __device__ __forceinline__ int df_flag_load(const int* f) {
@@ -451,7 +452,7 @@ __device__ __forceinline__ void df_mac_lds(const double (*Xs)[TLD], d4 (&acc)[2]
 // flag an item waits for has then been raised by the same workgroup earlier).
 __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int nb, int* ready, double* dinv_g, int* info,
                                                     int info_base, const double* rhs, double* sol, double* Linv,
-                                                    DfShared& sh, int wg, int nwg) {
+                                                    DfShared& sh, int wg, int nwg, int* ticket = nullptr) {
   const int tid = threadIdx.x, r = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, wave = tid >> 6;
@@ -525,8 +526,18 @@ __device__ __forceinline__ void potrf_dataflow_body(double* A, int64_t ld, int n
     }
   };
 
+  // Items in their own (dependency) order: dealt statically -- workgroup wg takes wg, wg + nwg, ... -- or, with `ticket` (a zeroed counter:
+  // SGP_OPT_SHARED_DEVICE), drawn from it by whichever workgroup is free, so that an item is only ever held by a workgroup that is running
+  // and waits only for items drawn before it (two processes on one GPU can otherwise starve each other's spinning launches).
   int j = 0, start = 0;  // column of the current tile and number of the first tile of that column
-  for (int t = wg; t < nitem; t += nwg) {
+  for (int t = wg;; t += nwg) {
+    if (ticket) {
+      __syncthreads();
+      if (tid == 0) sh.ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      t = sh.ticket;
+    }
+    if (t >= nitem) break;
     if (t == ntile) {  // the last work item: sol = L^-1 rhs, 64 entries at a time, trailing the factorization
       df_solve_rhs(A, ld, nb, ready, abort_flag, rhs, sol, sh);
       break;

@@ -225,6 +225,153 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   if (tid <= DP) mypart[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
+// The same product on 256 x 256 tiles (eight waves of 64 x 128: 2 x 4 MFMA tiles, 128 fp32 accumulators): the operands are re-read
+// 2 N M K (1/256 + 1/256) = 16 GB instead of 32 -- the 128 x 128 kernel above is bound by exactly that traffic (its global loads alone take
+// 5.9 of its 8.5 ms at C5).  One workgroup per CU (139 KB of LDS).  The epilogue runs in two phases of two tile columns per wave,
+// because the fp16 image of the tile's own K' block (128 KB) does not fit beside the other images: phase p holds columns 64 p ... 64 p + 63 of
+// either 128-column half.  Mp must be a multiple of 256 (the caller falls back to the 128 x 128 kernel otherwise).
+constexpr int LO2_T = 256;
+template <int DP>
+__global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
+                                                         const double* __restrict__ unscale, const double* __restrict__ Xs,
+                                                         const double* __restrict__ Zs, int Mp, int64_t nrb, int ncb,
+                                                         double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) uint16_t ABs[2][LO2_T][LO_LD];
+  __shared__ double red[8][DP + 1];
+  uint16_t (*As)[LO_LD] = ABs[0];
+  uint16_t (*Bs)[LO_LD] = ABs[1];
+  // epilogue images inside the main-loop buffers: eight wave-private 32 x 33 fp32 tiles | Xl | Zl | Kt (256 rows x (2 x 64) columns of fp16)
+  constexpr size_t CL_BYTES = 8 * 32 * 33 * sizeof(float), XZ_BYTES = (size_t)LO2_T * DP * sizeof(double);
+  static_assert(CL_BYTES + 2 * XZ_BYTES + (size_t)LO2_T * LO_LD * sizeof(uint16_t) <= 2 * (size_t)LO2_T * LO_LD * sizeof(uint16_t), "epilogue images fit");
+  char* lbase = reinterpret_cast<char*>(&ABs[0][0][0]);
+  double (*Xl)[DP] = reinterpret_cast<double (*)[DP]>(lbase + CL_BYTES);
+  double (*Zl)[DP] = reinterpret_cast<double (*)[DP]>(lbase + CL_BYTES + XZ_BYTES);
+  _Float16 (*Kt)[LO_LD] = reinterpret_cast<_Float16 (*)[LO_LD]>(lbase + CL_BYTES + 2 * XZ_BYTES);
+
+  const int xcd = blockIdx.x & 7;
+  const int64_t jj = blockIdx.x >> 3;
+  const int cb = (int)(jj % ncb);
+  const int64_t rb = (jj / ncb) * 8 + xcd;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* mypart = part + (size_t)blockIdx.x * (DP + 1);
+  if (rb >= nrb) {
+    if (tid <= DP) mypart[tid] = 0.0;
+    return;
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r31 = lane & 31, h = lane >> 5;
+  const int64_t n0 = rb * LO2_T;
+  const int m0 = cb * LO2_T;
+
+  constexpr int NV = LO_BK / 16;
+  const int srow = tid >> 1, skh = (tid & 1) * (LO_BK / 2);
+  const uint16_t* asrc = Kh + (size_t)(n0 + srow) * Mp + skh;
+  const uint16_t* bsrc = Pl + (size_t)(m0 + srow) * Mp + skh;
+  uint4 areg[NV], breg[NV];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      areg[q] = *reinterpret_cast<const uint4*>(asrc + k0 + 8 * q);
+      breg[q] = *reinterpret_cast<const uint4*>(bsrc + k0 + 8 * q);
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      *reinterpret_cast<uint4*>(&As[srow][skh + 8 * q]) = areg[q];
+      *reinterpret_cast<uint4*>(&Bs[srow][skh + 8 * q]) = breg[q];
+    }
+  };
+
+  lo_f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  fetch(0);
+  for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
+    stash();
+    __syncthreads();
+    if (k0 + LO_BK < Mp) fetch(k0 + LO_BK);
+#pragma unroll
+    for (int ks = 0; ks < LO_BK / 16; ++ks) {
+      lo_h8 a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const lo_h8*>(&As[wr * 64 + i * 32 + r31][ks * 16 + 8 * h]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const lo_h8*>(&Bs[wc * 128 + j * 32 + r31][ks * 16 + 8 * h]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(lbase) + wave * 32 * 33);
+  double S[DP + 1];
+#pragma unroll
+  for (int q = 0; q <= DP; ++q) S[q] = 0.0;
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    {  // this phase's fp16 block of K': thread <-> (row, 128-column half): columns m0 + 128 half + 64 ph ... + 63
+      uint4 kt[8];
+      const uint16_t* ksrc = Kh + (size_t)(n0 + srow) * Mp + m0 + (tid & 1) * 128 + 64 * ph;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kt[q] = *reinterpret_cast<const uint4*>(ksrc + 8 * q);
+      if (ph == 0)
+        for (int e = tid; e < LO2_T * DP; e += 512) {
+          Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
+          Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
+        }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4*>(&Kt[srow][(tid & 1) * 64 + 8 * q]) = kt[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl) {
+      const int j = 2 * ph + jl;
+      const int col = wc * 128 + j * 32 + r31;          // column inside the 256-wide tile
+      const int kcol = wc * 64 + jl * 32 + r31;          // ... and inside this phase's K' image
+      const double us = unscale[m0 + col];
+      double z[DP];
+#pragma unroll
+      for (int q = 0; q < DP; ++q) z[q] = Zl[col][q];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Cl[(e & 3) + 8 * (e >> 2) + 4 * h][r31] = acc[i][j][e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int rbase = wr * 64 + i * 32 + 16 * h;
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+          const double kp = (double)Kt[rbase + rr][kcol];
+          const double w = (double)Cl[16 * h + rr][r31] * (kp * us);
+          S[DP] += w;
+#pragma unroll
+          for (int q = 0; q < DP; ++q) {
+            const double df = z[q] - Xl[rbase + rr][q];
+            S[q] = fma(w * df, df, S[q]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();   // (the next phase overwrites the K' image)
+  }
+#pragma unroll
+  for (int q = 0; q <= DP; ++q) {
+    const double v = wave_sum(S[q]);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (tid <= DP) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+}
+
 // g_ls[j] += 2 inv_ls_j sf2^2 sum_parts S_j ; g_sf2 += 2 sf2 sum_parts S_DP -- one block, a fixed thread <-> partial mapping and a fixed tree
 // delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
 // the explicit pass 2 can be trusted at this theta (core.py: extended_lo_max_correction)
@@ -313,11 +460,24 @@ extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* 
   const int ncb = p.Mp / LO_T;
   static const int dbg = getenv("SGP_LO_DBG") ? atoi(getenv("SGP_LO_DBG")) : 0;   // diagnosis only: 1 no epilogue, 2 no MFMA, 4 no LDS staging
   lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
+  static const int tile128 = getenv("SGP_LO_TILE128") ? atoi(getenv("SGP_LO_TILE128")) : 0;   // A/B: the 128 x 128 kernel also where 256 divides Mp
+  int nparts = w.grid;
+  if (p.Mp % LO2_T == 0 && !tile128 && !dbg) {
+    const int64_t nrb2 = p.Npad / LO2_T;
+    const int ncb2 = p.Mp / LO2_T;
+    nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
+    switch (p.DP) {
+      case 2: kphi_lo256_kernel<2><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
+      case 4: kphi_lo256_kernel<4><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
+      default: kphi_lo256_kernel<8><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
+    }
+  } else {
   switch (p.DP) {
     case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
     case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
     default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
   }
-  lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, w.grid, p.DP, ka, g_ls, g_sf2, delta);
+  }
+  lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, nparts, p.DP, ka, g_ls, g_sf2, delta);
   return check_launch();
 }
