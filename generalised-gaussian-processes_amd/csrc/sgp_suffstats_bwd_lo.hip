@@ -35,6 +35,7 @@ namespace sgp {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 lo_h8;
 typedef __attribute__((ext_vector_type(16))) float lo_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int lo_u4;   // (a native vector: arrays of HIP's uint4 struct were kept in scratch)
 
 constexpr int LO_T = 128;     // tile edge (rows and columns)
 constexpr int LO_BK = 128;    // k-chunk: eight MFMA k-steps of 16 between two barriers (first version: 32 -- the next chunk's loads were issued 256
@@ -84,7 +85,7 @@ template <int DP>
 __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restrict__ Kfu, const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
                                                       const double* __restrict__ unscale, const double* __restrict__ Xs,
                                                       const double* __restrict__ Zs, int Mp, int64_t nrb, int ncb,
-                                                      double* __restrict__ part, int dbg) {
+                                                      double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) uint16_t ABs[2][LO_T][LO_LD];   // (one array: the epilogue reuses it as four 32 x 33 fp32 images)
   uint16_t (*As)[LO_LD] = ABs[0];
   uint16_t (*Bs)[LO_LD] = ABs[1];
@@ -118,21 +119,19 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   const int srow = tid >> 1, skh = (tid & 1) * (LO_BK / 2);
   const uint16_t* asrc = Kh + (size_t)(n0 + srow) * Mp + skh;
   const uint16_t* bsrc = Pl + (size_t)(m0 + srow) * Mp + skh;
-  uint4 areg[NV], breg[NV];
-  auto fetch = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      areg[q] = *reinterpret_cast<const uint4*>(asrc + k0 + 8 * q);
-      breg[q] = *reinterpret_cast<const uint4*>(bsrc + k0 + 8 * q);
-    }
-  };
-  auto stash = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      *reinterpret_cast<uint4*>(&As[srow][skh + 8 * q]) = areg[q];
-      *reinterpret_cast<uint4*>(&Bs[srow][skh + 8 * q]) = breg[q];
-    }
-  };
+  // (plain macros, no lambdas, no conditions around them: with either the compiler kept this 256-byte register ring in SCRATCH -- 16 GB of
+  // private-memory traffic per call at C5, WRITE_SIZE 9.0 GB where the kernel writes 4.5 MB: profiles/r06_lo_pmc_counters.csv)
+  lo_u4 areg[NV], breg[NV];
+#define LO_FETCH(K0)                                                                        \
+  _Pragma("unroll") for (int q = 0; q < NV; ++q) {                                          \
+    areg[q] = *reinterpret_cast<const lo_u4*>(asrc + (K0) + 8 * q);                         \
+    breg[q] = *reinterpret_cast<const lo_u4*>(bsrc + (K0) + 8 * q);                         \
+  }
+#define LO_STASH()                                                                          \
+  _Pragma("unroll") for (int q = 0; q < NV; ++q) {                                          \
+    *reinterpret_cast<lo_u4*>(&As[srow][skh + 8 * q]) = areg[q];                            \
+    *reinterpret_cast<lo_u4*>(&Bs[srow][skh + 8 * q]) = breg[q];                            \
+  }
 
   lo_f32x16 acc[2][2];
 #pragma unroll
@@ -142,12 +141,14 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  fetch(0);
+  LO_FETCH(0)
   for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
-    if (!(dbg & 4)) stash();
+    LO_STASH()
     __syncthreads();
-    if (k0 + LO_BK < Mp) fetch(k0 + LO_BK);   // in flight under this chunk's MFMAs
-    if (!(dbg & 2))
+    {  // the next chunk, in flight under this chunk's MFMAs (the last trip re-reads the last chunk: no condition around the ring)
+      const int kn = k0 + LO_BK < Mp ? k0 + LO_BK : k0;
+      LO_FETCH(kn)
+    }
 #pragma unroll
     for (int ks = 0; ks < LO_BK / 16; ++ks) {
       lo_h8 a[2], b[2];
@@ -166,23 +167,23 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   // epilogue.  Accumulator element (reg e of a 32 x 32 tile): row = (e & 3) + 8 (e >> 2) + 4 h, column = r31 (C/D layout of the 32 x 32 forms).
   // The four tiles of a wave go through a wave-private 32 x 33 LDS image one after the other, so that the contraction is a ROLLED loop
   // over rows (straight from the registers it is 64 unrolled elements whose loads the compiler hoists: 512 VGPRs, 150 spilled).
-  if (dbg & 1) {   // (diagnosis, SGP_LO_DBG: the main loop alone)
-    if (tid <= DP) mypart[tid] = (double)acc[0][0][0] + (double)areg[0].x;
-    return;
-  }
+#undef LO_FETCH
+#undef LO_STASH
   float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(&ABs[0][0][0]) + wave * 32 * 33);
   // the scaled inputs of this tile's rows and columns (the main loop's last barrier is behind every wave)
   {
-    uint4 kt[LO_T / 16];   // this thread's share of the 128 x 128 fp16 block: row srow, 64 columns (all loads in flight together)
+    lo_u4 kt[LO_T / 16];   // this thread's share of the 128 x 128 fp16 block: row srow, 64 columns (all loads in flight together)
     const uint16_t* ksrc = Kh + (size_t)(n0 + srow) * Mp + m0 + (tid & 1) * (LO_T / 2);
 #pragma unroll
-    for (int q = 0; q < LO_T / 16; ++q) kt[q] = *reinterpret_cast<const uint4*>(ksrc + 8 * q);
-    for (int e = tid; e < LO_T * DP; e += 256) {
+    for (int q = 0; q < LO_T / 16; ++q) kt[q] = *reinterpret_cast<const lo_u4*>(ksrc + 8 * q);
+#pragma unroll
+    for (int q = 0; q < LO_T / 16; ++q) *reinterpret_cast<lo_u4*>(&Kt[srow][(tid & 1) * (LO_T / 2) + 8 * q]) = kt[q];
+#pragma unroll
+    for (int e0 = 0; e0 < LO_T * DP; e0 += 256) {   // (LO_T DP is a multiple of 256 for DP = 2, 4, 8)
+      const int e = e0 + tid;
       Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
       Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
     }
-#pragma unroll
-    for (int q = 0; q < LO_T / 16; ++q) *reinterpret_cast<uint4*>(&Kt[srow][(tid & 1) * (LO_T / 2) + 8 * q]) = kt[q];
   }
   __syncthreads();
   double S[DP + 1];
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   if (tid <= DP) mypart[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
+// g_ls[j] += 2 inv_ls_j sf2^2 sum_parts S_j ; g_sf2 += 2 sf2 sum_parts S_DP -- one block, a fixed thread <-> partial mapping and a fixed tree
 // The same product on 256 x 256 tiles (eight waves of 64 x 128: 2 x 4 MFMA tiles, 128 fp32 accumulators): the operands are re-read
-// 2 N M K (1/256 + 1/256) = 16 GB instead of 32 -- the 128 x 128 kernel above is bound by exactly that traffic (its global loads alone take
-// 5.9 of its 8.5 ms at C5).  One workgroup per CU (139 KB of LDS).  The epilogue runs in two phases of two tile columns per wave,
+// 2 N M K (1/256 + 1/256) = 16 GB instead of 32 -- the 128 x 128 kernel above is bound by that traffic once its register ring really lives in registers.  One workgroup per CU (139 KB of LDS).  The epilogue runs in two phases of two tile columns per wave,
 // because the fp16 image of the tile's own K' block (128 KB) does not fit beside the other images: phase p holds columns 64 p ... 64 p + 63 of
 // either 128-column half.  Mp must be a multiple of 256 (the caller falls back to the 128 x 128 kernel otherwise).
 constexpr int LO2_T = 256;
@@ -267,21 +268,17 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
   const int srow = tid >> 1, skh = (tid & 1) * (LO_BK / 2);
   const uint16_t* asrc = Kh + (size_t)(n0 + srow) * Mp + skh;
   const uint16_t* bsrc = Pl + (size_t)(m0 + srow) * Mp + skh;
-  uint4 areg[NV], breg[NV];
-  auto fetch = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      areg[q] = *reinterpret_cast<const uint4*>(asrc + k0 + 8 * q);
-      breg[q] = *reinterpret_cast<const uint4*>(bsrc + k0 + 8 * q);
-    }
-  };
-  auto stash = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      *reinterpret_cast<uint4*>(&As[srow][skh + 8 * q]) = areg[q];
-      *reinterpret_cast<uint4*>(&Bs[srow][skh + 8 * q]) = breg[q];
-    }
-  };
+  lo_u4 areg[NV], breg[NV];
+#define LO_FETCH(K0)                                                                        \
+  _Pragma("unroll") for (int q = 0; q < NV; ++q) {                                          \
+    areg[q] = *reinterpret_cast<const lo_u4*>(asrc + (K0) + 8 * q);                         \
+    breg[q] = *reinterpret_cast<const lo_u4*>(bsrc + (K0) + 8 * q);                         \
+  }
+#define LO_STASH()                                                                          \
+  _Pragma("unroll") for (int q = 0; q < NV; ++q) {                                          \
+    *reinterpret_cast<lo_u4*>(&As[srow][skh + 8 * q]) = areg[q];                            \
+    *reinterpret_cast<lo_u4*>(&Bs[srow][skh + 8 * q]) = breg[q];                            \
+  }
 
   lo_f32x16 acc[2][4];
 #pragma unroll
@@ -291,11 +288,14 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  fetch(0);
+  LO_FETCH(0)
   for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
-    stash();
+    LO_STASH()
     __syncthreads();
-    if (k0 + LO_BK < Mp) fetch(k0 + LO_BK);
+    {
+      const int kn = k0 + LO_BK < Mp ? k0 + LO_BK : k0;
+      LO_FETCH(kn)
+    }
 #pragma unroll
     for (int ks = 0; ks < LO_BK / 16; ++ks) {
       lo_h8 a[2], b[4];
@@ -311,6 +311,8 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
     __syncthreads();
   }
 
+#undef LO_FETCH
+#undef LO_STASH
   float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(lbase) + wave * 32 * 33);
   double S[DP + 1];
 #pragma unroll
@@ -318,17 +320,20 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
 #pragma unroll
   for (int ph = 0; ph < 2; ++ph) {
     {  // this phase's fp16 block of K': thread <-> (row, 128-column half): columns m0 + 128 half + 64 ph ... + 63
-      uint4 kt[8];
+      lo_u4 kt[8];
       const uint16_t* ksrc = Kh + (size_t)(n0 + srow) * Mp + m0 + (tid & 1) * 128 + 64 * ph;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) kt[q] = *reinterpret_cast<const uint4*>(ksrc + 8 * q);
-      if (ph == 0)
-        for (int e = tid; e < LO2_T * DP; e += 512) {
+      for (int q = 0; q < 8; ++q) kt[q] = *reinterpret_cast<const lo_u4*>(ksrc + 8 * q);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<lo_u4*>(&Kt[srow][(tid & 1) * 64 + 8 * q]) = kt[q];
+      if (ph == 0) {
+#pragma unroll
+        for (int e0 = 0; e0 < LO2_T * DP; e0 += 512) {
+          const int e = e0 + tid;
           Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
           Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
         }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4*>(&Kt[srow][(tid & 1) * 64 + 8 * q]) = kt[q];
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -372,7 +377,6 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
   if (tid <= DP) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
 }
 
-// g_ls[j] += 2 inv_ls_j sf2^2 sum_parts S_j ; g_sf2 += 2 sf2 sum_parts S_DP -- one block, a fixed thread <-> partial mapping and a fixed tree
 // delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
 // the explicit pass 2 can be trusted at this theta (core.py: extended_lo_max_correction)
 // (one workgroup per slot: 256 threads stride over the partials -- 62 500 of them at C5 --, wave sums, four wave totals added in order)
@@ -458,11 +462,10 @@ extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* 
   lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, w.Pl, w.unscale);
   const int64_t nrb = p.Npad / LO_T;
   const int ncb = p.Mp / LO_T;
-  static const int dbg = getenv("SGP_LO_DBG") ? atoi(getenv("SGP_LO_DBG")) : 0;   // diagnosis only: 1 no epilogue, 2 no MFMA, 4 no LDS staging
   lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
   static const int tile128 = getenv("SGP_LO_TILE128") ? atoi(getenv("SGP_LO_TILE128")) : 0;   // A/B: the 128 x 128 kernel also where 256 divides Mp
   int nparts = w.grid;
-  if (p.Mp % LO2_T == 0 && !tile128 && !dbg) {
+  if (p.Mp % LO2_T == 0 && !tile128) {
     const int64_t nrb2 = p.Npad / LO2_T;
     const int ncb2 = p.Mp / LO2_T;
     nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
@@ -472,11 +475,11 @@ extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* 
       default: kphi_lo256_kernel<8><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
     }
   } else {
-  switch (p.DP) {
-    case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
-    case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
-    default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part, dbg); break;
-  }
+    switch (p.DP) {
+      case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+      case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+      default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+    }
   }
   lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, nparts, p.DP, ka, g_ls, g_sf2, delta);
   return check_launch();
