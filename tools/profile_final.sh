@@ -46,11 +46,13 @@ timeout 900 bash tools/potrf_trace_check.sh < /dev/null > "$O/potrf_trace_check.
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/lo_prof" -o run -- python3 tools/lo_kernel_ms.py < /dev/null > "$O/lo_kernel_ms.json" 2> "$O/lo.err"
 f=$(find "$O/lo_prof" -name "*kernel_stats*" | head -1); if [ -n "$f" ]; then grep -E "Name|lo_|kphi|dd_gemm|phibar|kbar_contract" "$f" | sed 's/(.*)"/"/' > "$O/lo_kernel_stats.csv"; fi
 rm -rf "$O/lo_prof"
+for t in 0 1 0 1; do echo "SGP_LO_TILE128=$t"; SGP_LO_TILE128=$t timeout 300 python3 tools/lo_kernel_ms.py < /dev/null 2>/dev/null; done > "$O/lo_tile_256_vs_128_ab.txt"
 GRADS=1 LEVEL=2 timeout 900 python3 tools/extended_check.py < /dev/null > "$O/extended_order_gradients_dd_phibar.jsonl" 2>/dev/null
 timeout 600 python3 tools/extended_grad_check.py < /dev/null > "$O/extended_order_gradients_ard_dd_phibar.jsonl" 2>/dev/null
 timeout 900 python3 tools/lo_threshold_probe.py < /dev/null > "$O/lo_threshold_probe.jsonl" 2>/dev/null
 timeout 900 python3 experiments/large_scale_regression.py --max_iters 30 --hmc_samples 30 --hmc_tune 30 < /dev/null > "$O/experiment_large_scale_parity.json" 2> "$O/exp_p.err"
 timeout 600 python3 tools/nuts_midsize.py 2>/dev/null > "$O/nuts_midsize.jsonl"
+timeout 600 python3 __graft_entry__.py --smoke < /dev/null > "$O/smoke.txt" 2>&1
 timeout 3000 python3 -m pytest tests -x -q -m gpu < /dev/null > "$O/pytest_gpu.txt" 2>&1
 tail -3 "$O/pytest_gpu.txt"
 cat "$O/potrf_bench.jsonl" "$O/shard_sizes.jsonl"
