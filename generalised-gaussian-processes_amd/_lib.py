@@ -69,6 +69,8 @@ PROTOTYPES = {
     "sgp_ctx_suffstats_extended_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32]),
     "sgp_ctx_suffstats_fwd_extended": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_ctx_suffstats_fwd_extended_f16": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
+                                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_ctx_suffstats_bwd_factored_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32, _i32]),
     "sgp_ctx_suffstats_bwd_factored": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _dbl, _vp, _dbl, _i64, _i32, _i32, _i32,
                                               _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -128,6 +130,10 @@ PROTOTYPES = {
     "sgp_phibar_dd": (_i32, [_vp, _vp, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "sgp_suffstats_bwd_lo_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sgp_suffstats_bwd_lo": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_bwd_lo_workspace_bytes_ex": (_sz, [_i64, _i32, _i32, _i32]),
+    "sgp_suffstats_bwd_lo_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgp_suffstats_fwd_extended_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _dp, _dbl, _i64, _i32, _i32, _i32, _vp, _i32,
+                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgp_bound_from_whitened_stats_ex": (_i32, [_vp, _vp, _vp, _vp, _dbl, _i64, _i32, _i32, _vp,

@@ -188,6 +188,7 @@ class CollapsedBound:
         # fits the budget (default 64 GiB of the 288 GB HBM); otherwise the library streams it in
         # 16 GiB super-chunks and pass 2 re-assembles.
         self._kfu = None
+        self._kfu_f16 = None
         self.kfu_budget_bytes = 64 << 30
         # local rows x inducing points from which the whitened order runs in the streaming layout (engine.suffstats_whitened_rows)
         self.whitened_rows_min_work = 1 << 26
@@ -278,6 +279,20 @@ class CollapsedBound:
         if self._kfu is None or self._kfu.numel() < need:
             self._kfu = e.kfu_buffer(n_local, M)
         return self._kfu
+
+    def _kfu_f16_for(self, M):
+        """The fp16 image of K'_fu beside the fp64 block (the extended order's trailing-word product reads it; written by the assembly
+        kernel, which spares sgp_suffstats_bwd_lo a conversion pass over the fp64 block: 2.0 of 4.6 ms at C5)."""
+        e = self.engine
+        if not hasattr(e, "kfu_f16_buffer"):
+            return None
+        n_local = int(self.X.shape[0])
+        need = ((max(n_local, 1) + 255) // 256 * 256) * ((M + 127) // 128 * 128)
+        if need * 10 > self.kfu_budget_bytes:
+            return None
+        if self._kfu_f16 is None or self._kfu_f16.numel() < need:
+            self._kfu_f16 = e.kfu_f16_buffer(n_local, M)
+        return self._kfu_f16
 
     # ------------------------------------------------------------------ single-launch path (small problems)
     def _small_ok(self, M, want_gz=False, sf2=1.0):
@@ -373,6 +388,9 @@ class CollapsedBound:
         the amplitude against max(1, |g_sf2|)."""
         g = host[head:head + nh + 1].tolist()
         dl = host[host.numel() - lo_slots:].tolist()
+        if any(v != v for v in dl):   # NaN: the product's inputs were beyond its fp16 format (an inducing point > 128 lengthscales out) -- no correction was added
+            self.last_lo_correction = float("inf")
+            return False
         self.last_lo_correction = max(max(abs(v) for v in dl[:nh]) / max(1.0, max(abs(v) for v in g[:nh])), abs(dl[nh]) / max(1.0, abs(g[nh])))
         return self.last_lo_correction <= self.extended_lo_max_correction
 
@@ -427,25 +445,26 @@ class CollapsedBound:
                 if self._phi_diag is None or self._phi_diag.numel() < M:
                     self._phi_diag = e.empty(M)
                 diag = self._phi_diag
+            dd = with_adjoints and self.extended_dd_phibar and hasattr(e, "phibar_dd")
+            lo = dd and want_lo and kfu is not None and self._bwd_lo_ok(M)   # (not for the sampler mode: it takes this order's gradient as it is)
+            kfu_f16 = self._kfu_f16_for(M) if lo else None
             packed = e.suffstats_extended(self.X, self.y, Z, ls, sf2, linv, self.kernel, kfu=kfu, level=self.extended_level,
-                                          **({"phi_diag": diag} if diag is not None else {}))
+                                          **({"phi_diag": diag} if diag is not None else {}), **({"kfu_f16": kfu_f16} if kfu_f16 is not None else {}))
             self._allreduce_stats(packed, M)
             # pass 2 of this order takes the explicit Phibar = L^-T C L^-1 / (2 s2); formed by two fp64 products its own rounding
             # (eps |L^-T| |C| |L^-1| >> eps |Phibar|) is what limits the gradients -- formed in double-double from the whitened core C the
             # bound returns they are 5-15 x closer (tests/studies/explicit_phibar_pass2.py; +1.3 ms at M = 1024)
-            dd = with_adjoints and self.extended_dd_phibar and hasattr(e, "phibar_dd")
             res = e.bound(Kuu, packed, s2, self.N, with_adjoints=with_adjoints, want_factors=want_factors, kuu_linv=linv,
                           result=result, whitened=True, **({"want_cw": True} if dd else {}))
             if dd:
-                # ... and 35-700 x closer with the trailing word applied as well: a bf16 product K' Phibar_lo beside the fp64 one (_pass2)
-                lo = want_lo and kfu is not None and self._bwd_lo_ok(M)   # (not for the sampler mode: it takes this order's gradient as it is)
+                # ... and 35-700 x closer with the trailing word applied as well: an fp16 product K' Phibar_lo beside the fp64 one (_pass2)
                 res["Phibar"], res["Phibar_lo"] = e.phibar_dd(res["Cw"], linv, s2, want_lo=lo)
                 res["Cw"] = None   # (pass 2 of this order is the explicit one: _pass2 takes the factored route when a core is handed on)
             if report:
                 self._allreduce(diag[:M])  # (ranks hold the diagonal of their own shard's Phi)
                 e.streaming_error_report(diag, 1, self._trace_buf(), sf2, s2, self.N, M, result)
                 res["reported"] = True
-            res.update(packed=packed, kfu=kfu, t_keep=None, linv=linv)
+            res.update(packed=packed, kfu=kfu, kfu_f16=kfu_f16, t_keep=None, linv=linv)
             return res
         if tier == TIER_WHITENED:
             # PyMC3 op order: chol(Kuu) first, then A = L^-1 K_uf, W = A A^T (one stream; these shards are small)
@@ -542,7 +561,8 @@ class CollapsedBound:
             if res.get("Phibar_lo") is not None:   # the extended order: the trailing word of its double-double Phibar (lengthscales, amplitude)
                 n_lo = int(res.get("lo_slots", 0))   # (the correction itself goes to the tail of `g`: all-reduced with it, read back with it)
                 e.suffstats_bwd_lo(self.X, self.y, Z, ls, sf2, res["Phibar_lo"], res["kfu"], g, self.kernel,
-                                   **({"delta": g[g.numel() - n_lo:]} if n_lo else {}))
+                                   **({"delta": g[g.numel() - n_lo:]} if n_lo else {}),
+                                   **({"kfu_f16": res["kfu_f16"]} if res.get("kfu_f16") is not None else {}))
         if int(res.get("lo_slots", 0)) and res.get("Phibar_lo") is None:
             g[g.numel() - int(res["lo_slots"]):].zero_()   # (the correction's slots travel with g: nothing undefined into the all-reduce)
         self._allreduce(g)

@@ -230,6 +230,16 @@ extern "C" int sgp_ctx_suffstats_fwd_extended(sgp_ctx* ctx, const double* X, int
   return sgp_suffstats_fwd_extended_ex(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, level, W, u, yy, kappa, Kfu_out,
                                        phi_diag, ws, ws_bytes, stream);
 }
+extern "C" int sgp_ctx_suffstats_fwd_extended_f16(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                                  const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                                  const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
+                                                  double* Kfu_out, uint16_t* Kfu_f16_out, double* phi_diag, void* ws, size_t ws_bytes,
+                                                  sgp_stream_t stream) {
+  if (!ctx_on_current_device(ctx)) return SGP_ERR_ARG;
+  CtxScope scope(ctx);
+  return sgp_suffstats_fwd_extended_f16(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, level, W, u, yy, kappa, Kfu_out,
+                                        Kfu_f16_out, phi_diag, ws, ws_bytes, stream);
+}
 extern "C" size_t sgp_ctx_suffstats_bwd_factored_workspace_bytes(const sgp_ctx* ctx, int64_t N, int M, int d, int caller_owns_t) {
   CtxScope scope(const_cast<sgp_ctx*>(ctx));
   return sgp_suffstats_bwd_factored_workspace_bytes_ex(N, M, d, caller_owns_t);

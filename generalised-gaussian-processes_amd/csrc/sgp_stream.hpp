@@ -211,7 +211,8 @@ __host__ __device__ inline void i8_split_steps(int64_t nsteps, int nsplit, int s
   if (c1 > nsteps) c1 = nsteps;
 }
 void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0, int64_t rows,
-                 int64_t N, int M, uint8_t* Q, double* Kfu /* optional: the fp64 block too */, double* bpart, hipStream_t st);
+                 int64_t N, int M, uint8_t* Q, double* Kfu /* optional: the fp64 block too */, double* bpart, hipStream_t st,
+                 uint16_t* Kh = nullptr /* optional, with Kfu: its fp16 image too */);
 // slab_lo (optional): the extended contraction -- 34 digit pairs, every tile as an unevaluated sum slab + slab_lo (sgp_suffstats_fwd_extended)
 // level (with slab_lo): 1 = the pairs p + r >= 5 (34), 2 = p + r >= 4 (39)
 int i8_contract(const uint8_t* Q, int Mp, int64_t rows, int nsplit, int accumulate, double* slab, hipStream_t st, double* slab_lo = nullptr,

@@ -29,7 +29,9 @@
 #include "sgp_stream.hpp"
 #include "sgp_dense.hpp"
 #include <cstdint>
+#include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace sgp {
 
@@ -49,8 +51,9 @@ __device__ __forceinline__ uint32_t lo_h16(float f) {   // round to nearest even
 __device__ __forceinline__ uint32_t lo_pack2(double a, double b) { return lo_h16((float)a) | (lo_h16((float)b) << 16); }
 
 // fp16 image of the symmetric M x M low word, zero-padded to Mp x Mp: row r scaled by 2^sh(r) so that its largest entry lies in
-// [2^13, 2^14) (fp16: normal down to 2^-14, 65504 at the top), unscale[r] = 2^-sh(r).  One workgroup per row.
-__global__ __launch_bounds__(256) void lo_prep_kernel(const double* __restrict__ Plo, int M, int Mp, uint16_t* __restrict__ out,
+// [2^(target_exp - 1), 2^target_exp) (fp16: normal down to 2^-14, 65504 at the top; 14 for the kernels that keep dC in fp32, 3 for the one
+// that rounds dC <= 8 Mp to fp16), unscale[r] = 2^-sh(r).  One workgroup per row.
+__global__ __launch_bounds__(256) void lo_prep_kernel(const double* __restrict__ Plo, int M, int Mp, int target_exp, uint16_t* __restrict__ out,
                                                       double* __restrict__ unscale) {
   __shared__ double red[4];
   const int r = blockIdx.x, tid = threadIdx.x;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void lo_prep_kernel(const double* __restrict__
   mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
   int ex = 0;
   if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);   // mx = f 2^ex, f in [0.5, 1)
-  const int sh = (mx > 0.0 && mx < 1e300) ? 14 - ex : 0;
+  const int sh = (mx > 0.0 && mx < 1e300) ? target_exp - ex : 0;   // largest entry in [2^(target_exp - 1), 2^target_exp)
   if (tid == 0) unscale[r] = ldexp(1.0, -sh);
   for (int c = tid; c < Mp; c += 256)
     out[(size_t)r * Mp + c] = (r < M && c < M) ? (uint16_t)lo_h16((float)ldexp(Plo[(size_t)r * M + c], sh)) : (uint16_t)0;
@@ -289,7 +292,11 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   LO_FETCH(0)
+#ifdef SGP_AB_LO_NO_MAIN
+  for (int k0 = 0; k0 < LO_BK; k0 += LO_BK) {
+#else
   for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
+#endif
     LO_STASH()
     __syncthreads();
     {
@@ -317,8 +324,14 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
   double S[DP + 1];
 #pragma unroll
   for (int q = 0; q <= DP; ++q) S[q] = 0.0;
+#ifdef SGP_AB_LO_NO_EPI
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) S[DP] += (double)acc[i][j][e];
+#pragma unroll
+  for (int ph = 0; ph < 0; ++ph) {
+#else
 #pragma unroll
   for (int ph = 0; ph < 2; ++ph) {
+#endif
     {  // this phase's fp16 block of K': thread <-> (row, 128-column half): columns m0 + 128 half + 64 ph ... + 63
       lo_u4 kt[8];
       const uint16_t* ksrc = Kh + (size_t)(n0 + srow) * Mp + m0 + (tid & 1) * 128 + 64 * ph;
@@ -377,10 +390,296 @@ __global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restr
   if (tid <= DP) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Third version (round 6, after the split A/B profiles/r06_lo_split_ab.txt: of the 256 x 256 kernel's 5.0 ms the main loop took 3.0 and the
+// fp64 contraction behind it 2.0 -- one workgroup per CU, so neither hides behind the other).
+//
+// Main loop: the same 256 x 256 tile and eight waves of 64 x 128, but the operands travel global -> LDS by LDS-DMA in full 128-byte lines
+// (64-deep stages, 64 KB each, two of them): no register ring, no ds_write pass (128 KB per chunk at ~79 B / clk had the matrix pipe idle a
+// quarter of the time), stage t + 1 in flight under the 32 MFMAs per wave of stage t, one raw barrier per stage.  An LDS-DMA instruction
+// writes 1 KB contiguously (lane l -> base + 16 l), so a piece is 8 rows x 128 B and the image is unpadded; the bank spread comes from an
+// XOR on the SOURCE side: 16-byte slot c of row R holds k-segment c ^ ((R >> 1) & 7), and the fragment reads apply the same XOR -- a
+// ds_read_b128 lane group (16 rows, distinct mod 16) then covers all 64 banks.
+//
+// Contraction: with w = dC k' (this tile's product times the kernel value, per element)
+//     S_j = sum_m us_m [ z_mj^2 A0_m  -  2 z_mj A1_mj  +  A2_mj ],   A0_m = sum_n w_nm,  A1_mj = sum_n w_nm x_nj,  A2_mj = sum_n w_nm x_nj^2
+// and A1, A2 are one more matrix product, W^T [x | x^2], whose A operand the accumulators ALREADY hold in the right lanes: lane (column m,
+// half h) of a 32 x 32 accumulator tile owns rows {4 h + (e & 3) + 8 (e >> 2)}, and the k order of an MFMA is free as long as both operands
+// use the same one -- so registers 8 s .. 8 s + 7, rounded to fp16 and multiplied by k', ARE the A fragment of k-step s, and the B fragment
+// [x_hi | x_lo | (x^2)_hi | (x^2)_lo] x 8 dimensions = 32 columns is prepared once per call in that row order (lo_bx_kernel).  fp16 pairs
+// (hi + lo: 22 bits) because the expansion cancels where |z - x| << |z|; inputs are centred on the mean inducing point first.  A0 by
+// v_dot2c_f32_f16 from the same rounded w (the three terms must see the same w).  Per 32 x 32 tile and lane: 16 two-byte loads of k'
+// (fp16 image, L2), 8 v_cvt_pk_f16_f32, 8 v_pk_mul_f16, 8 v_dot2c, 2 MFMAs -- against 16 x 27 fp64 operations before.
+// Range: rows of the low word are scaled into [4, 8) (lo_prep_kernel, target_exp 3), so |dC| <= 8 Mp <= 2^15 fits fp16; |x~ - c| is
+// clamped to 255 (beyond it k' is zero against every inducing point with |z~ - c| <= 128; an inducing point further out raises `flag`
+// and the call reports NaN corrections -- the caller then keeps the whitened order, core.py).
+constexpr int L3_T = 256;
+constexpr int L3_BK = 64;
+constexpr int L3_OPB = L3_T * L3_BK * 2;   // bytes per operand and stage
+constexpr int L3_STAGE = 2 * L3_OPB;       // 65 536
+constexpr int L3_TTS = 36;                 // floats per column of the factor table: [-2 z us (8) | us (8) | z^2 us (8) | 0 (12)]; 144-byte rows
+                                           // keep 16-byte reads of 16 consecutive rows on distinct banks (36 r mod 64 = 4 (9 r mod 16))
+typedef _Float16 lo_h2 __attribute__((ext_vector_type(2)));
+typedef float lo_f2 __attribute__((ext_vector_type(2)));
+typedef float lo_f4 __attribute__((ext_vector_type(4)));
+
+// c_q = mean over the inducing points of z~_q (fixed order); clears the range flag
+__global__ __launch_bounds__(256) void lo3_centre_kernel(const double* __restrict__ Zs, int M, int DP, double* __restrict__ centre, int* __restrict__ flag) {
+  __shared__ double red[32][8];
+  const int q = threadIdx.x & 7, part = threadIdx.x >> 3;
+  double s = 0.0;
+  if (q < DP)
+    for (int m = part; m < M; m += 32) s += Zs[(size_t)m * DP + q];
+  red[part][q] = s;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double t = 0.0;
+    for (int p2 = 0; p2 < 32; ++p2) t += red[p2][threadIdx.x];
+    centre[threadIdx.x] = t / (double)M;
+  }
+  if (threadIdx.x == 0) *flag = 0;
+}
+
+// factor table, one thread per padded column (behind lo_prep_kernel: needs unscale)
+__global__ __launch_bounds__(256) void lo3_tt_kernel(const double* __restrict__ Zs, const double* __restrict__ unscale, const double* __restrict__ centre,
+                                                     int M, int Mp, int DP, float* __restrict__ TT, int* __restrict__ flag) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mp) return;
+  float* row = TT + (size_t)m * L3_TTS;
+  const double us = unscale[m];
+  bool far = false;
+  for (int q = 0; q < 8; ++q) {
+    double zc = (m < M && q < DP) ? Zs[(size_t)m * DP + q] - centre[q] : 0.0;
+    if (!(fabs(zc) <= 128.0)) { far = true; zc = 0.0; }   // (also a NaN coordinate)
+    row[q] = (float)(-2.0 * zc * us);
+    row[8 + q] = (float)us;
+    row[16 + q] = (float)(zc * zc * us);
+  }
+  for (int q = 24; q < L3_TTS; ++q) row[q] = 0.0f;
+  if (far) atomicOr(flag, 1);
+}
+
+// B operand of the contraction product.  16-byte vector v = (((rt 2 + s) 2 + h) 32 + c): data rows n = 32 rt + 16 s + 4 h + (t & 3) + 8 (t >> 2),
+// t = 0 .. 7 (the rows lane half h of an accumulator tile holds in registers 8 s .. 8 s + 7); column c = 8 kind + q.
+__global__ __launch_bounds__(256) void lo_bx_kernel(const double* __restrict__ Xs, const double* __restrict__ centre, int64_t nvec, int DP,
+                                                    lo_u4* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvec) return;
+  const int c = (int)(v & 31), hh = (int)((v >> 5) & 1), s = (int)((v >> 6) & 1);
+  const int64_t rt = v >> 7;
+  const int kind = c >> 3, q = c & 7;
+  const double cq = centre[q];
+  uint32_t w[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    uint32_t pr[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = 2 * u + b;
+      const int64_t n = rt * 32 + 16 * s + 4 * hh + (t & 3) + 8 * (t >> 2);
+      double xc = q < DP ? Xs[(size_t)n * DP + q] - cq : 0.0;
+      xc = xc > 255.0 ? 255.0 : (xc < -255.0 ? -255.0 : xc);
+      if (!(xc == xc)) xc = 0.0;   // (a NaN coordinate: its row of K' is NaN already and the leading word's gradient with it)
+      const double val = kind < 2 ? xc : xc * xc;
+      const _Float16 hi = (_Float16)(float)val;
+      const _Float16 pick = (kind & 1) ? (_Float16)(float)(val - (double)(float)hi) : hi;
+      pr[b] = (uint32_t)__builtin_bit_cast(uint16_t, pick);
+    }
+    w[u] = pr[0] | (pr[1] << 16);
+  }
+  lo_u4 o;
+  o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
+  out[v] = o;
+}
+
+__device__ __forceinline__ void lo3_glds(const char* g, uint8_t* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int PF>
+__global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
+                                                       const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int64_t nrb,
+                                                       int ncb, double* __restrict__ part) {
+  // (dynamic: with a static array hipcc knows that the LDS-DMA and the fragment reads touch one object and drains the DMA -- vmcnt(0) --
+  // before the first read behind it, i.e. before the MFMAs it was to hide under)
+  extern __shared__ __attribute__((aligned(1024))) uint8_t l3[];
+  __shared__ double red[8][9];
+  const int xcd = blockIdx.x & 7;
+  const int64_t jj = blockIdx.x >> 3;
+  const int cb = (int)(jj % ncb);
+  const int64_t rb = (jj / ncb) * 8 + xcd;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* mypart = part + (size_t)blockIdx.x * 9;
+  if (rb >= nrb) {
+    if (tid < 9) mypart[tid] = 0.0;
+    return;
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r31 = lane & 31, h = lane >> 5;
+  const int64_t n0 = rb * L3_T;
+  const int m0 = cb * L3_T;
+
+  // LDS-DMA roles: wave w moves pieces 4 w .. 4 w + 3 (rows 32 w .. 32 w + 31) of either operand; lane l of piece p: row R = 32 w + 8 p + l / 8,
+  // slot l % 8 <- k-segment (l % 8) ^ ((R >> 1) & 7)
+  const char* abase = reinterpret_cast<const char*>(Kh + (size_t)n0 * Mp);
+  const char* bbase = reinterpret_cast<const char*>(Pl + (size_t)m0 * Mp);
+  unsigned goff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int R = 32 * wave + 8 * p + (lane >> 3);
+    const int kseg = (lane & 7) ^ ((R >> 1) & 7);
+    goff[p] = (unsigned)(R * Mp + kseg * 8) * 2u;
+  }
+  auto issue = [&](int t, int buf) {
+    const char* ab = abase + (size_t)t * (L3_BK * 2);
+    const char* bb = bbase + (size_t)t * (L3_BK * 2);
+    uint8_t* dst = l3 + buf * L3_STAGE + wave * 4096;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) lo3_glds(ab + goff[p], dst + p * 1024);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) lo3_glds(bb + goff[p], dst + L3_OPB + p * 1024);
+  };
+  auto issue_tt = [&](int buf) {   // this column block's 36 KB of the factor table, a linear copy
+    const char* src = reinterpret_cast<const char*>(TT + (size_t)m0 * L3_TTS) + lane * 16;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int P = wave + 8 * k;
+      if (P < (L3_T * L3_TTS * 4) / 1024) lo3_glds(src + P * 1024, l3 + buf * L3_STAGE + P * 1024);
+    }
+  };
+
+  // fragment reads: row R of an operand image lives at R * 128 + ((kseg ^ ((R >> 1) & 7)) * 16, kseg = 2 ks + h
+  const int tsw = ((r31 >> 1) & 7) ^ h;
+  const int arow0 = (wr * 64 + r31) * 128;
+  const int brow0 = L3_OPB + (wc * 128 + r31) * 128;
+
+  lo_f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int T = Mp / L3_BK;
+  auto step = [&](int t, auto buf_tag) {
+    constexpr int B = decltype(buf_tag)::value;
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0): my pieces of stage t have landed
+    __builtin_amdgcn_s_barrier();                            // ... everybody's have, and stage t - 1 has been read by all
+    asm volatile("" ::: "memory");
+    if (t + 1 < T) issue(t + 1, B ^ 1);
+    else issue_tt(B ^ 1);
+    const uint8_t* sb = l3 + B * L3_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < L3_BK / 16; ++ks) {
+      const int ko = ((2 * ks) ^ tsw) << 4;
+      lo_h8 a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const lo_h8*>(sb + arow0 + i * 4096 + ko);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const lo_h8*>(sb + brow0 + j * 4096 + ko);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  issue(0, 0);
+  for (int t = 0; t < T; t += 2) {   // (T is a multiple of 4: Mp of 256)
+    step(t, std::integral_constant<int, 0>());
+    step(t + 1, std::integral_constant<int, 1>());
+  }
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const float* ttl = reinterpret_cast<const float*>(l3);   // the factor table went into stage buffer 0 (the last stage computed from buffer 1)
+
+  // ---- contraction
+  lo_h8 bx[2][2];
+  {
+    const lo_h8* bxg = reinterpret_cast<const lo_h8*>(Bx);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bx[i][s] = bxg[((((size_t)rb * 8 + 2 * wr + i) * 2 + s) * 2 + h) * 32 + r31];
+  }
+  const uint16_t* kb = Kh + (size_t)(n0 + wr * 64 + 4 * h) * Mp + m0 + wc * 128 + r31;
+  uint32_t raw[16];
+#define L3_LOADKP(I, J)                                                                                        \
+  _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                               \
+    raw[e] = kb[(size_t)((I) * 32 + (e & 3) + 8 * (e >> 2)) * Mp + (J) * 32];
+  L3_LOADKP(0, 0)
+  const int oc = (r31 >> 4) ? 8 + (r31 & 7) : (r31 & 7);
+  const lo_h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+  float P = 0.0f, S0 = 0.0f, Sz[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) Sz[q] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lo_f32x16 out2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out2[e] = 0.0f;
+    float a0 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint32_t pk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pk[u] = raw[2 * u] | (raw[2 * u + 1] << 16);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 0) { L3_LOADKP(1, j) }
+      else if (j < 3) { L3_LOADKP(0, j + 1) }
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const lo_f2 v2 = {acc[i][j][2 * u], acc[i][j][2 * u + 1]};
+        const lo_h2 w2 = __builtin_convertvector(v2, lo_h2) * __builtin_bit_cast(lo_h2, pk[u]);
+        a0 = __builtin_amdgcn_fdot2(w2, ones, a0, false);
+        wv[u] = __builtin_bit_cast(uint32_t, w2);
+      }
+      lo_u4 f0, f1;
+      f0[0] = wv[0]; f0[1] = wv[1]; f0[2] = wv[2]; f0[3] = wv[3];
+      f1[0] = wv[4]; f1[1] = wv[5]; f1[2] = wv[6]; f1[3] = wv[7];
+      out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lo_h8, f0), bx[i][0], out2, 0, 0, 0);
+      out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lo_h8, f1), bx[i][1], out2, 0, 0, 0);
+    }
+    const int mb = wc * 128 + j * 32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) P = fmaf(out2[e], ttl[(mb + (e & 3) + 8 * (e >> 2) + 4 * h) * L3_TTS + oc], P);
+    const float* tm = ttl + (mb + r31) * L3_TTS;
+    const lo_f4 z0 = *reinterpret_cast<const lo_f4*>(tm + 16), z1 = *reinterpret_cast<const lo_f4*>(tm + 20);
+    S0 = fmaf(a0, tm[8], S0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Sz[q] = fmaf(a0, z0[q], Sz[q]);
+      Sz[4 + q] = fmaf(a0, z1[q], Sz[4 + q]);
+    }
+  }
+#undef L3_LOADKP
+  P += __shfl_xor(P, 8, 64);
+  P += __shfl_xor(P, 16, 64);
+  P += __shfl_xor(P, 32, 64);   // lanes 0 .. 7: the product part of S_q, q = lane
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double v = wave_sum((double)Sz[q]);
+    if (lane == 0) red[wave][q] = v;
+  }
+  {
+    const double v = wave_sum((double)S0);
+    if (lane == 0) red[wave][8] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 8) red[wave][lane] += (double)P;
+  __syncthreads();
+  if (tid < 9) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+}
+
 // delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
 // the explicit pass 2 can be trusted at this theta (core.py: extended_lo_max_correction)
 // (one workgroup per slot: 256 threads stride over the partials -- 62 500 of them at C5 --, wave sums, four wave totals added in order)
-__global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict__ part, int nparts, int DP, KernArgs ka,
+__global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict__ part, int nparts, int DP, KernArgs ka, const int* __restrict__ flag,
                                                         double* __restrict__ g_ls, double* __restrict__ g_sf2, double* __restrict__ delta) {
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -395,20 +694,27 @@ __global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict
     s = (red[0] + red[1]) + (red[2] + red[3]);
     if (threadIdx.x == 0) {
       const double c = q == ka.d ? 2.0 * ka.sf2 * s : 2.0 * ka.inv_ls[q] * ka.sf2 * ka.sf2 * s;
-      if (q == ka.d) *g_sf2 += c;
-      else g_ls[q] += c;
-      if (delta) delta[q] = c;
+      if (flag && *flag) {   // an inducing point beyond the fp16 range of the contraction's inputs: no correction, and the caller is told
+        if (delta) delta[q] = __builtin_nan("");
+      } else {
+        if (q == ka.d) *g_sf2 += c;
+        else g_ls[q] += c;
+        if (delta) delta[q] = c;
+      }
     }
   }
 }
 
 struct LoWs {
-  double *Xs, *ys, *Zs, *yypart, *part, *unscale;
+  double *Xs, *ys, *Zs, *yypart, *part, *unscale, *centre;
   uint16_t *Pl, *Kh;
+  lo_u4* Bx;
+  float* TT;
+  int* flag;
   size_t bytes;
   int grid;
 };
-static LoWs carve_lo(void* ws, const StreamPlan& p) {
+static LoWs carve_lo(void* ws, const StreamPlan& p, bool have_f16 = false) {
   Carver c(ws);
   LoWs w;
   w.Xs = c.take<double>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.DP);
@@ -418,10 +724,18 @@ static LoWs carve_lo(void* ws, const StreamPlan& p) {
   const int64_t nrb = p.Npad / LO_T;
   const int ncb = p.Mp / LO_T;
   w.grid = (int)(((nrb + 7) / 8) * 8 * ncb);
-  w.part = c.take<double>((size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1));
+  {
+    const size_t g256 = (size_t)((p.Npad / 256 + 7) / 8) * 8 * (size_t)((p.Mp + 255) / 256);   // the 256 x 256 kernels' grid, nine slots each
+    const size_t a = (size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1), b = g256 * 9;
+    w.part = c.take<double>(a > b ? a : b);
+  }
   w.Pl = c.take<uint16_t>((size_t)p.Mp * p.Mp);
   w.unscale = c.take<double>((size_t)p.Mp);
-  w.Kh = c.take<uint16_t>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp);
+  w.centre = c.take<double>(8);
+  w.flag = c.take<int>(4);
+  w.TT = c.take<float>((size_t)p.Mp * L3_TTS);
+  w.Bx = c.take<lo_u4>((size_t)(p.Npad > 0 ? p.Npad : 1) * 4);   // Npad / 32 row tiles x 128 vectors of 16 bytes
+  w.Kh = have_f16 ? nullptr : c.take<uint16_t>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp);   // (last: a caller that brings the image saves it)
   w.bytes = c.used();
   return w;
 }
@@ -430,10 +744,11 @@ static LoWs carve_lo(void* ws, const StreamPlan& p) {
 
 using namespace sgp;
 
-extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d) {
+extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes_ex(int64_t N, int M, int d, int have_f16) {
   if (N < 0 || M <= 0 || d <= 0 || d > 8 || M > SGP_MAX_INDUCING) return 0;
-  return carve_lo(nullptr, make_stream_plan(N, M, d)).bytes;
+  return carve_lo(nullptr, make_stream_plan(N, M, d), have_f16 != 0).bytes;
 }
+extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d) { return sgp_suffstats_bwd_lo_workspace_bytes_ex(N, M, d, 0); }
 
 // Adds the low word's contribution to g_ls (d doubles) and g_sf2 IN PLACE, behind sgp_suffstats_bwd on the same stream with the same
 // inputs and Phibar = the leading word.  Kfu_in: the fp64 K'_fu of this shard (sgp_kfu_len doubles) as pass 1 left it.  RBF, d <= 8
@@ -442,7 +757,16 @@ extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d) 
 extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls,
                                     double sf2, const double* Phibar_lo, const double* Kfu_in, int64_t N, int M, int d, int kernel_id,
                                     double* g_ls, double* g_sf2, double* delta, void* ws, size_t ws_bytes, sgp_stream_t stream) {
-  if (!Z || !inv_ls || !Phibar_lo || !Kfu_in || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
+  return sgp_suffstats_bwd_lo_f16(X, ldx, y, Z, ldz, inv_ls, sf2, Phibar_lo, Kfu_in, nullptr, N, M, d, kernel_id, g_ls, g_sf2, delta, ws, ws_bytes,
+                                  stream);
+}
+// ... with the fp16 image of K'_fu from sgp_suffstats_fwd_extended_f16 (Kfu_f16_in; Kfu_in may then be NULL and the workspace is the _ex
+// size with have_f16 = 1): the 10 GB conversion pass at C5 (2.0 of 4.6 ms) is not run.
+extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls,
+                                        double sf2, const double* Phibar_lo, const double* Kfu_in, const uint16_t* Kfu_f16_in, int64_t N,
+                                        int M, int d, int kernel_id, double* g_ls, double* g_sf2, double* delta, void* ws, size_t ws_bytes,
+                                        sgp_stream_t stream) {
+  if (!Z || !inv_ls || !Phibar_lo || (!Kfu_in && !Kfu_f16_in) || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id != SGP_KERNEL_RBF) return SGP_ERR_ARG;
   if (d > 8 || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
@@ -451,36 +775,59 @@ extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* 
     return check_launch();
   }
   StreamPlan p = make_stream_plan(N, M, d);
-  LoWs w = carve_lo(ws, p);
+  LoWs w = carve_lo(ws, p, Kfu_f16_in != nullptr);
   if (!ws || ws_bytes < w.bytes) return SGP_ERR_WORKSPACE;
+  const uint16_t* Kh = Kfu_f16_in ? Kfu_f16_in : w.Kh;
   hipStream_t st = (hipStream_t)stream;
   KernArgs ka;
   for (int j = 0; j < SGP_MAX_DIM; ++j) ka.inv_ls[j] = j < d ? inv_ls[j] : 0.0;
   ka.sf2 = sf2;
   ka.d = d;
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
-  lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, w.Pl, w.unscale);
+  static const int lo_kernel = getenv("SGP_LO_KERNEL") ? atoi(getenv("SGP_LO_KERNEL")) : 3;   // A/B: 1 = 128 x 128 tiles, 2 = 256 x 256 with the fp64 contraction
+  static const int lo_pf = getenv("SGP_LO_PREFETCH") ? atoi(getenv("SGP_LO_PREFETCH")) : 0;
+  const bool v3 = p.Mp % L3_T == 0 && lo_kernel == 3;
+  if (v3) lo3_centre_kernel<<<1, 256, 0, st>>>(w.Zs, M, p.DP, w.centre, w.flag);
+  lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, v3 ? 3 : 14, w.Pl, w.unscale);
   const int64_t nrb = p.Npad / LO_T;
   const int ncb = p.Mp / LO_T;
-  lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
-  static const int tile128 = getenv("SGP_LO_TILE128") ? atoi(getenv("SGP_LO_TILE128")) : 0;   // A/B: the 128 x 128 kernel also where 256 divides Mp
-  int nparts = w.grid;
-  if (p.Mp % LO2_T == 0 && !tile128) {
+  if (!Kfu_f16_in) lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
+  int nparts = w.grid, part_dp = p.DP;
+  if (v3) {
+    lo3_tt_kernel<<<(p.Mp + 255) / 256, 256, 0, st>>>(w.Zs, w.unscale, w.centre, M, p.Mp, p.DP, w.TT, w.flag);
+    const int64_t nvec = p.Npad * 4;
+    lo_bx_kernel<<<(unsigned)((nvec + 255) / 256), 256, 0, st>>>(w.Xs, w.centre, nvec, p.DP, w.Bx);
+    const int64_t nrb2 = p.Npad / L3_T;
+    const int ncb2 = p.Mp / L3_T;
+    nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
+    part_dp = 8;
+    static std::atomic<bool> attr_done[64];   // per device, as i8_contract
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return SGP_ERR_LAUNCH;
+    if (dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+      if (hipFuncSetAttribute((const void*)kphi_lo3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * L3_STAGE) != hipSuccess ||
+          hipFuncSetAttribute((const void*)kphi_lo3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * L3_STAGE) != hipSuccess)
+        return SGP_ERR_LAUNCH;
+      if (dev < 64) attr_done[dev].store(true, std::memory_order_release);
+    }
+    if (lo_pf) kphi_lo3_kernel<1><<<nparts, 512, 2 * L3_STAGE, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, nrb2, ncb2, w.part);
+    else kphi_lo3_kernel<0><<<nparts, 512, 2 * L3_STAGE, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, nrb2, ncb2, w.part);
+  } else if (p.Mp % LO2_T == 0 && lo_kernel == 2) {
     const int64_t nrb2 = p.Npad / LO2_T;
     const int ncb2 = p.Mp / LO2_T;
     nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
     switch (p.DP) {
-      case 2: kphi_lo256_kernel<2><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
-      case 4: kphi_lo256_kernel<4><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
-      default: kphi_lo256_kernel<8><<<nparts, 512, 0, st>>>(w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
+      case 2: kphi_lo256_kernel<2><<<nparts, 512, 0, st>>>(Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
+      case 4: kphi_lo256_kernel<4><<<nparts, 512, 0, st>>>(Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
+      default: kphi_lo256_kernel<8><<<nparts, 512, 0, st>>>(Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
     }
   } else {
     switch (p.DP) {
-      case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
-      case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
-      default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, w.Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+      case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+      case 4: kphi_lo_kernel<4><<<w.grid, 256, 0, st>>>(Kfu_in, Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
+      default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
     }
   }
-  lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, nparts, p.DP, ka, g_ls, g_sf2, delta);
+  lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, nparts, part_dp, ka, v3 ? w.flag : nullptr, g_ls, g_sf2, delta);
   return check_launch();
 }

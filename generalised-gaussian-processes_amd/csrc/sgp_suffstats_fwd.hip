@@ -1164,6 +1164,17 @@ extern "C" int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const
                                              const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
                                              const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
                                              double* Kfu_out, double* phi_diag, void* ws, size_t ws_bytes, sgp_stream_t stream) {
+  return sgp_suffstats_fwd_extended_f16(X, ldx, y, Z, ldz, inv_ls, sf2, N, M, d, kernel_id, kuu_linv, level, W, u, yy, kappa, Kfu_out, nullptr,
+                                        phi_diag, ws, ws_bytes, stream);
+}
+// ... and one more (round 6): Kfu_f16_out (DEVICE, sgp_kfu_len(N, M) 16-bit words, or NULL; needs Kfu_out): the fp16 image of K'_fu that
+// sgp_suffstats_bwd_lo_f16 multiplies, written by the assembly kernel that has every value in registers anyway.
+extern "C" int sgp_suffstats_fwd_extended_f16(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz,
+                                              const double* inv_ls, double sf2, int64_t N, int M, int d, int kernel_id,
+                                              const double* kuu_linv, int level, double* W, double* u, double* yy, double* kappa,
+                                              double* Kfu_out, uint16_t* Kfu_f16_out, double* phi_diag, void* ws, size_t ws_bytes,
+                                              sgp_stream_t stream) {
+  if (Kfu_f16_out && !Kfu_out) return SGP_ERR_ARG;
   if (!Z || !inv_ls || !kuu_linv || !W || !u || !yy || !kappa || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id < 0 || kernel_id >= SGP_KERNEL_COMPOSITE || level < 1 || level > 2) return SGP_ERR_ARG;
@@ -1187,7 +1198,8 @@ extern "C" int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const
   for (int64_t r0 = 0; r0 < p.Npad; r0 += qrows) {
     const int64_t rows = (p.Npad - r0) < qrows ? (p.Npad - r0) : qrows;
     timing_begin(TIMING_ASSEMBLE, st);
-    i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Q, Kfu_out ? Kfu_out + (size_t)r0 * p.Mp : nullptr, w.bpart, st);
+    i8_assemble(p, kernel_id, w.Xs, w.ys, w.Zs, r0, rows, N, M, w.Q, Kfu_out ? Kfu_out + (size_t)r0 * p.Mp : nullptr, w.bpart, st,
+                Kfu_f16_out ? Kfu_f16_out + (size_t)r0 * p.Mp : nullptr);
     timing_end(TIMING_ASSEMBLE, st);
     timing_begin(TIMING_SYRK, st);
     if (i8_contract(w.Q, p.Mp, rows, ns, r0 > 0 ? 1 : 0, w.slab, st, w.slab_lo, level) != SGP_OK) return SGP_ERR_LAUNCH;

@@ -55,11 +55,12 @@ constexpr int I8_LDS_BYTES = I8_NSTAGE * I8_STAGE_BYTES;  // 129 024
 //    bpart[rowblock][m] = sum_n k'(x_n, z_m) y_n falls out of the same loop in fp64 (the digits are not involved).
 // ---------------------------------------------------------------------------------------------
 //    WK: the fp64 block K'_fu is written as well (a value + gradient evaluation: pass 2 reads it) -- 15 instead of 7 bytes per
-//    element, which puts the kernel back at the HBM-write ceiling.
+//    element, which puts the kernel back at the HBM-write ceiling.  Kh (optional, with WK): its fp16 image too (17 bytes).
 template <int DP, int KID, bool WK>
 __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restrict__ Xs, const double* __restrict__ ys,
                                                          const double* __restrict__ Zs, int64_t row0, int64_t N, int M, int Mp,
-                                                         uint8_t* __restrict__ Q, double* __restrict__ Kfu, double* __restrict__ bpart) {
+                                                         uint8_t* __restrict__ Q, double* __restrict__ Kfu, uint16_t* __restrict__ Kh,
+                                                         double* __restrict__ bpart) {
   __shared__ double xs[ASM_ROWS][DP];
   __shared__ double ysh[ASM_ROWS];
   __shared__ double etab[EXP_TAB_N];
@@ -105,7 +106,16 @@ __global__ __launch_bounds__(256) void kfu_digits_kernel(const double* __restric
       double kv = kprofile_tab<KID>(r2, etab);
       if constexpr (MASKED) kv *= (n < N ? zmask : 0.0);
       bacc = fma(kv, ysh[i], bacc);
-      if constexpr (WK) __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);
+      if constexpr (WK) {
+        __builtin_nontemporal_store(kv, &Kfu[(rbase + i) * Mp + m]);
+        // (round 6) the fp16 image of the same block for sgp_suffstats_bwd_lo_f16, rounded as lo_kfu_f16_kernel rounds it: 2 more bytes per
+        // element here instead of a 10 GB pass of its own there
+        if (Kh) {
+          float kf = (float)kv;
+          asm volatile("" : "+v"(kf));   // (two roundings, as lo_kfu_f16_kernel: left alone hipcc folds them into ONE software double -> half conversion)
+          Kh[(rbase + i) * Mp + m] = __builtin_bit_cast(uint16_t, (_Float16)kf);
+        }
+      }
       // q = rint(kv 2^54) without a 64-bit convert: hi = rint(kv 2^22) and the SIGNED remainder r = rint(kv 2^54 - hi 2^32) in
       // [-2^31, 2^31], each read off the mantissa of a magic-constant sum (all four operations exact).  r sits in the low 33
       // mantissa bits of tl as a two's-complement number: q = (hi - bit32) 2^32 + low32 -- also at the ties r = +-2^31, which a
@@ -357,35 +367,35 @@ __global__ __launch_bounds__(512, 1) void i8_syrk_tile_kernel(const uint8_t* __r
 // ---------------------------------------------------------------------------------------------
 template <int DP, bool WK>
 static void launch_digits(int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs, int64_t row0,
-                          int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, double* bpart) {
+                          int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, uint16_t* Kh, double* bpart) {
   switch (kid) {
-    case SGP_KERNEL_RBF: kfu_digits_kernel<DP, SGP_KERNEL_RBF, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    case SGP_KERNEL_MATERN32: kfu_digits_kernel<DP, SGP_KERNEL_MATERN32, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    default: kfu_digits_kernel<DP, SGP_KERNEL_MATERN52, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case SGP_KERNEL_RBF: kfu_digits_kernel<DP, SGP_KERNEL_RBF, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    case SGP_KERNEL_MATERN32: kfu_digits_kernel<DP, SGP_KERNEL_MATERN32, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    default: kfu_digits_kernel<DP, SGP_KERNEL_MATERN52, WK><<<grid, 256, 0, st>>>(Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
   }
 }
 template <bool WK>
 static void launch_digits_dp(int DP, int kid, dim3 grid, hipStream_t st, const double* Xs, const double* ys, const double* Zs,
-                             int64_t row0, int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, double* bpart) {
+                             int64_t row0, int64_t N, int M, int Mp, uint8_t* Q, double* Kfu, uint16_t* Kh, double* bpart) {
   switch (DP) {
-    case 2: launch_digits<2, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    case 4: launch_digits<4, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    case 8: launch_digits<8, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    case 16: launch_digits<16, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    case 24: launch_digits<24, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
-    default: launch_digits<32, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, bpart); break;
+    case 2: launch_digits<2, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    case 4: launch_digits<4, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    case 8: launch_digits<8, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    case 16: launch_digits<16, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    case 24: launch_digits<24, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
+    default: launch_digits<32, WK>(kid, grid, st, Xs, ys, Zs, row0, N, M, Mp, Q, Kfu, Kh, bpart); break;
   }
 }
 
 // Digit planes of rows [row0, row0 + rows) (rows a multiple of ASM_ROWS) into Q (which starts at row0); Kfu (optional, starts at
-// row0 as well): the fp64 block of the same rows.
+// row0 as well): the fp64 block of the same rows; Kh (optional, with Kfu, starts at row0): its fp16 image.
 void i8_assemble(const StreamPlan& p, int kid, const double* Xs, const double* ys, const double* Zs, int64_t row0, int64_t rows,
-                 int64_t N, int M, uint8_t* Q, double* Kfu, double* bpart, hipStream_t st) {
+                 int64_t N, int M, uint8_t* Q, double* Kfu, double* bpart, hipStream_t st, uint16_t* Kh) {
   dim3 grid((unsigned)(rows / ASM_ROWS), (p.Mp + 255) / 256);
   if (Kfu)
-    launch_digits_dp<true>(p.DP, kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, Kfu, bpart);
+    launch_digits_dp<true>(p.DP, kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, Kfu, Kh, bpart);
   else
-    launch_digits_dp<false>(p.DP, kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, nullptr, bpart);
+    launch_digits_dp<false>(p.DP, kid, grid, st, Xs, ys, Zs, row0, N, M, p.Mp, Q, nullptr, nullptr, bpart);
 }
 
 // slab[split][128 x 128 tile of the lower triangle] (+)= this split's part of K'^T K' (without sf2^2), as syrk_tile_kernel

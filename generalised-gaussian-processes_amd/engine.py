@@ -172,6 +172,10 @@ class HipEngine:
         """Caller-owned K'_fu block (see include/sgp.h: sgp_kfu_len) for ``suffstats(..., kfu=)``."""
         return self.empty(self.lib.sgp_kfu_len(N, M))
 
+    def kfu_f16_buffer(self, N: int, M: int) -> torch.Tensor:
+        """Caller-owned fp16 image of K'_fu (sgp_kfu_len 16-bit words) for ``suffstats_extended(..., kfu_f16=)`` / ``suffstats_bwd_lo(..., kfu_f16=)``."""
+        return torch.empty(self.lib.sgp_kfu_len(N, M), dtype=torch.float16, device=self.device)
+
     def suffstats(self, X, y, Z, ls, sf2, kernel="rbf", out: Optional[torch.Tensor] = None,
                   kfu: Optional[torch.Tensor] = None, gate: Optional[torch.cuda.Event] = None) -> torch.Tensor:
         """Packed local statistics [Phi (M*M) | b (M) | yy | kappa] -- the buffer the all-reduce sums.
@@ -251,11 +255,13 @@ class HipEngine:
         return out
 
     def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out: Optional[torch.Tensor] = None,
-                           kfu: Optional[torch.Tensor] = None, level: int = 1, phi_diag: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           kfu: Optional[torch.Tensor] = None, level: int = 1, phi_diag: Optional[torch.Tensor] = None,
+                           kfu_f16: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The whitened statistics [W | u | yy | kappa] from the EXTENDED streaming order (include/sgp.h: sgp_suffstats_fwd_extended):
         Phi on the integer matrix cores to 2^-61, the triple product in double-double.  ``kfu`` (from ``kfu_buffer``) keeps the fp64
         K'_fu for ``suffstats_bwd``.  ``level`` 1: 34 digit pairs (Phi to 2^-61), 2: 39 pairs (2^-69).  Stationary kernels.
-        ``phi_diag`` (M doubles): receives diag(K_uf K_fu) of this shard for ``streaming_error_report`` (ranks add theirs up)."""
+        ``phi_diag`` (M doubles): receives diag(K_uf K_fu) of this shard for ``streaming_error_report`` (ranks add theirs up).
+        ``kfu_f16`` (from ``kfu_f16_buffer``, with ``kfu``): receives the fp16 image of K'_fu for ``suffstats_bwd_lo``."""
         N, d = X.shape
         M = Z.shape[0]
         self._chk(Z, "Z"), self._chk(kuu_linv, "kuu_linv")
@@ -276,10 +282,15 @@ class HipEngine:
             self._chk(phi_diag, "phi_diag")
             if phi_diag.numel() < M:
                 raise ValueError("phi_diag holds %d doubles, M = %d" % (phi_diag.numel(), M))
-        st = self.lib.sgp_ctx_suffstats_fwd_extended(
+        if kfu_f16 is not None:
+            if kfu is None or kfu_f16.dtype != torch.float16 or not kfu_f16.is_contiguous() or kfu_f16.device != self.device \
+                    or kfu_f16.numel() < self.lib.sgp_kfu_len(N, M):
+                raise ValueError("kfu_f16: a contiguous float16 tensor of sgp_kfu_len(N, M) elements on this device, together with kfu")
+        st = self.lib.sgp_ctx_suffstats_fwd_extended_f16(
             self._c(), self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2), N, M, d, _kernel_id(kernel),
             self._ptr(kuu_linv), int(level), C.c_void_p(base), C.c_void_p(base + 8 * M * M), C.c_void_p(base + 8 * (M * M + M)),
             C.c_void_p(base + 8 * (M * M + M + 1)), self._ptr(kfu) if kfu is not None else C.c_void_p(0),
+            C.c_void_p(kfu_f16.data_ptr()) if kfu_f16 is not None else C.c_void_p(0),
             self._ptr(phi_diag) if phi_diag is not None else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_fwd_extended", st)
         return out
@@ -301,19 +312,28 @@ class HipEngine:
         """``suffstats_bwd_lo`` exists for this shape: RBF, d <= 8."""
         return kernel == "rbf" and self.lib.sgp_suffstats_bwd_lo_workspace_bytes(int(N), int(M), int(d)) > 0
 
-    def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads: torch.Tensor, kernel="rbf", delta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads: torch.Tensor, kernel="rbf", delta: Optional[torch.Tensor] = None,
+                         kfu_f16: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Adds the trailing word's share of pass 2 into the packed gradients ``suffstats_bwd`` wrote (include/sgp.h: sgp_suffstats_bwd_lo);
-        ``delta`` (d + 1 doubles) receives the correction itself."""
+        ``delta`` (d + 1 doubles) receives the correction itself.  ``kfu_f16``: the fp16 image ``suffstats_extended(..., kfu_f16=)`` left
+        (the conversion pass is skipped; ``kfu`` may then be None)."""
         N, d = X.shape
         M = Z.shape[0]
-        self._chk(Phibar_lo, "Phibar_lo"), self._chk(kfu, "kfu")
+        self._chk(Phibar_lo, "Phibar_lo")
+        if kfu is not None:
+            self._chk(kfu, "kfu")
+        elif kfu_f16 is None:
+            raise ValueError("suffstats_bwd_lo needs kfu or kfu_f16")
+        if kfu_f16 is not None and (kfu_f16.dtype != torch.float16 or kfu_f16.device != self.device or kfu_f16.numel() < self.lib.sgp_kfu_len(N, M)):
+            raise ValueError("kfu_f16: a float16 tensor of sgp_kfu_len(N, M) elements on this device")
         nh = self.hyper_len(kernel, d)
-        ws = self._workspace("bwd_lo", self.lib.sgp_suffstats_bwd_lo_workspace_bytes(N, M, d))
+        ws = self._workspace("bwd_lo", self.lib.sgp_suffstats_bwd_lo_workspace_bytes_ex(N, M, d, 1 if kfu_f16 is not None else 0))
         base = grads.data_ptr()
-        st = self.lib.sgp_suffstats_bwd_lo(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2),
-                                           self._ptr(Phibar_lo), self._ptr(kfu), N, M, d, _kernel_id(kernel), C.c_void_p(base),
-                                           C.c_void_p(base + 8 * nh), self._ptr(delta) if delta is not None else C.c_void_p(0), self._ptr(ws), ws.numel(),
-                                           self._stream())
+        st = self.lib.sgp_suffstats_bwd_lo_f16(self._ptr(X), d, self._ptr(y), self._ptr(Z), d, self._inv_ls(ls, d, kernel), float(sf2),
+                                               self._ptr(Phibar_lo), self._ptr(kfu) if kfu is not None else C.c_void_p(0),
+                                               C.c_void_p(kfu_f16.data_ptr()) if kfu_f16 is not None else C.c_void_p(0), N, M, d,
+                                               _kernel_id(kernel), C.c_void_p(base), C.c_void_p(base + 8 * nh),
+                                               self._ptr(delta) if delta is not None else C.c_void_p(0), self._ptr(ws), ws.numel(), self._stream())
         _lib.check("sgp_suffstats_bwd_lo", st)
         return grads
 

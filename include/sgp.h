@@ -418,8 +418,9 @@ size_t sgp_phibar_dd_workspace_bytes(int M);
 int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, double s2, double* Phibar_hi, double* Phibar_lo, void* ws,
                   size_t ws_bytes, sgp_stream_t stream);
 /* ... and the pass-2 contribution of the trailing word: g_ls (d doubles) and g_sf2 receive, IN PLACE, what sgp_suffstats_bwd would have added
- * had its Phibar carried Phibar_lo as well -- dC = K' Phibar_lo on the bf16 matrix cores (three digits are all a 2^-53-relative term
- * needs), contracted with dK in fp64.  Call it behind sgp_suffstats_bwd (same stream, same inputs, Phibar = the leading word, the same
+ * had its Phibar carried Phibar_lo as well -- dC = K' Phibar_lo on the fp16 matrix cores (three digits are all a 2^-53-relative term
+ * needs), contracted with dK there as well (hi + lo fp16 pairs of the centred inputs; an inducing point more than 128 lengthscales from the
+ * mean inducing point is beyond that format: delta then receives NaN and nothing is added).  Call it behind sgp_suffstats_bwd (same stream, same inputs, Phibar = the leading word, the same
  * caller-owned fp64 K'_fu as Kfu_in) and before the gradients are all-reduced.  RBF kernel, d <= 8 (SGP_ERR_ARG / SGP_ERR_DIM otherwise);
  * dF/dZ is not corrected.  delta (DEVICE, d + 1 doubles, or NULL) receives the correction itself, [d lengthscales | sf2]: its size against
  * the gradient is the a-posteriori check a caller applies before trusting the explicit pass 2 at a theta (measured at C5 over 34 theta
@@ -429,6 +430,24 @@ size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d);
 int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls, double sf2,
                          const double* Phibar_lo, const double* Kfu_in, int64_t N, int M, int d, int kernel_id, double* g_ls,
                          double* g_sf2, double* delta, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* ... with the fp16 image of K'_fu that sgp_suffstats_fwd_extended_f16 / sgp_ctx_suffstats_fwd_extended_f16 leave in Kfu_f16_out (DEVICE,
+ * sgp_kfu_len(N, M) 16-bit words): the conversion pass (2.0 of 4.6 ms at C5) is not run, Kfu_in may be NULL and the workspace is the _ex
+ * size with have_f16 = 1 (2 bytes per element of K'_fu smaller).  Same results, bit for bit.                                              */
+size_t sgp_suffstats_bwd_lo_workspace_bytes_ex(int64_t N, int M, int d, int have_f16);
+int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                             const double* Phibar_lo, const double* Kfu_in, const uint16_t* Kfu_f16_in, int64_t N, int M, int d,
+                             int kernel_id, double* g_ls, double* g_sf2, double* delta, void* ws, size_t ws_bytes, sgp_stream_t stream);
+/* sgp_suffstats_fwd_extended_ex with one output more: Kfu_f16_out (DEVICE, sgp_kfu_len(N, M) 16-bit words, or NULL; needs Kfu_out) */
+int sgp_suffstats_fwd_extended_f16(const double* X, int64_t ldx, const double* y,
+                                   const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                                   int64_t N, int M, int d, int kernel_id, const double* kuu_linv, int level,
+                                   double* W, double* u, double* yy, double* kappa, double* Kfu_out, uint16_t* Kfu_f16_out,
+                                   double* phi_diag, void* ws, size_t ws_bytes, sgp_stream_t stream);
+int sgp_ctx_suffstats_fwd_extended_f16(sgp_ctx* ctx, const double* X, int64_t ldx, const double* y,
+                                       const double* Z, int64_t ldz, const double* inv_ls, double sf2,
+                                       int64_t N, int M, int d, int kernel_id, const double* kuu_linv, int level,
+                                       double* W, double* u, double* yy, double* kappa, double* Kfu_out, uint16_t* Kfu_f16_out,
+                                       double* phi_diag, void* ws, size_t ws_bytes, sgp_stream_t stream);
 /* ... with phi_diag (ABI version 3; see sgp_ctx_suffstats_fwd_extended) */
 int sgp_suffstats_fwd_extended_ex(const double* X, int64_t ldx, const double* y,
                                   const double* Z, int64_t ldz, const double* inv_ls, double sf2,

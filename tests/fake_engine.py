@@ -273,6 +273,9 @@ class FactoredOracleEngine(GuardedOracleEngine):
     def kfu_buffer(self, N, M):
         return torch.full((max(1, int(N)) * int(M),), float("nan"), dtype=torch.float64)
 
+    def kfu_f16_buffer(self, N, M):
+        return torch.full((max(1, int(N)) * int(M),), float("nan"), dtype=torch.float16)
+
     def suffstats_whitened_rows(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, t_out=None):
         self.calls["suffstats_whitened_rows"] += 1
         n = self.calls["suffstats_whitened"]
@@ -308,10 +311,15 @@ class FactoredOracleEngine(GuardedOracleEngine):
     def bwd_lo_supported(self, N, M, d, kernel="rbf"):
         return kernel == "rbf" and d <= 8
 
-    def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads, kernel="rbf", delta=None):
+    def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads, kernel="rbf", delta=None, kfu_f16=None):
         """sgp_suffstats_bwd_lo: what pass 2 would have added had its Phibar carried the trailing word (lengthscales and amplitude only)."""
         self.calls["suffstats_bwd_lo"] = self.calls.get("suffstats_bwd_lo", 0) + 1
         d = Z.shape[1]
+        if kfu_f16 is not None:   # the image the forward pass of THIS theta left
+            self.calls["f16_handed_over"] = self.calls.get("f16_handed_over", 0) + 1
+            if X.shape[0] > 0:
+                Kp = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel])
+                assert torch.equal(kfu_f16[: X.shape[0] * Z.shape[0]], Kp.reshape(-1).to(torch.float16)), "the trailing-word product was handed a stale fp16 image"
         n = self.calls["suffstats_bwd"]
         corr = self.suffstats_bwd(X, y, Z, ls, sf2, Phibar_lo, torch.zeros(Z.shape[0], dtype=torch.float64), 0.0, kernel, False, None)
         self.calls["suffstats_bwd"] = n
@@ -335,7 +343,7 @@ class FactoredOracleEngine(GuardedOracleEngine):
         self.calls["suffstats_bwd"] = n
         return g
 
-    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None, level=1, phi_diag=None):
+    def suffstats_extended(self, X, y, Z, ls, sf2, kuu_linv, kernel="rbf", out=None, kfu=None, level=1, phi_diag=None, kfu_f16=None):
         """sgp_suffstats_fwd_extended: the same whitened statistics (the oracle has one way to compute them), K'_fu kept in `kfu`."""
         self.calls["suffstats_extended"] = self.calls.get("suffstats_extended", 0) + 1
         self.calls["extended_level_%d" % level] = self.calls.get("extended_level_%d" % level, 0) + 1
@@ -345,6 +353,10 @@ class FactoredOracleEngine(GuardedOracleEngine):
         M, d = Z.shape
         if kfu is not None and X.shape[0] > 0:
             kfu[: X.shape[0] * M] = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel]).reshape(-1)
+        if kfu_f16 is not None:
+            assert kfu is not None
+            if X.shape[0] > 0:
+                kfu_f16[: X.shape[0] * M] = O.kern(X, Z, self._ls(ls, d), 1.0, KID[kernel]).reshape(-1).to(torch.float16)
         if phi_diag is not None:  # diag(K_uf K_fu) of this shard, with its amplitude
             phi_diag[:M] = (O.kern(X, Z, self._ls(ls, d), float(sf2), KID[kernel]) ** 2).sum(0) if X.shape[0] > 0 else 0.0
         return packed

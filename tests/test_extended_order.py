@@ -147,11 +147,11 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
     long-double product of the same inputs; (ii) sgp_suffstats_bwd_lo -- dC = K' Phibar_lo on the fp16 matrix cores (rows scaled by powers of two), contracted with dK
     in fp64 -- against the fp64 pass 2 run on the trailing word itself (what it approximates: three digits are asked for, 3e-3 is held);
     (iii) the same for a symmetric matrix whose rows span ten decades (the per-row power-of-two scaling; ragged shapes, padded rows and columns
-    adding nothing).  The kernel is a three-digit product: it is NOT asked to resolve cancellation, which the trailing word -- rounding
+    adding nothing); (iv) the fp16 image of K'_fu from the assembly kernel; (v) inputs beyond the contraction's fp16 format.  The kernel is a three-digit product: it is NOT asked to resolve cancellation, which the trailing word -- rounding
     residuals -- does not have."""
     import numpy as np
     import ggp_amd
-    for (N, M, d) in ((3000, 200, 3), (20000, 384, 8), (777, 130, 1)):
+    for (N, M, d) in ((3000, 200, 3), (20000, 384, 8), (777, 130, 1), (6000, 1024, 8)):
         g = torch.Generator().manual_seed(N + M)
         X = torch.randn(N, d, dtype=torch.float64, generator=g)
         y = torch.randn(N, dtype=torch.float64, generator=g)
@@ -182,4 +182,33 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
             engine.suffstats_bwd_lo(Xd, yd, Zd, ls, sf2, P, kfu, acc, "rbf")
             acc = acc.cpu()
             assert float((acc - exact).abs().max()) <= 3e-3 * float(exact.abs().max()), (N, M, d, acc, exact)
+        # (iv) the fp16 image of K'_fu written by the assembly kernel of the extended order is the image the product would have made itself:
+        # the same correction bit for bit with and without it, and without the fp64 block at all
+        kfu2, kh = engine.kfu_buffer(N, M), engine.kfu_f16_buffer(N, M)
+        engine.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, "rbf", kfu=kfu2, level=2, kfu_f16=kh)
+        n_el = ((N + 255) // 256 * 256) * Mp
+        assert torch.equal(kh[:n_el], kfu2[:n_el].to(torch.float32).to(torch.float16))
+        outs = []
+        for kw in (dict(kfu=kfu2), dict(kfu=kfu2, kfu_f16=kh), dict(kfu=None, kfu_f16=kh)):
+            acc = torch.zeros(d + 1, dtype=torch.float64, device=engine.device)
+            engine.suffstats_bwd_lo(Xd, yd, Zd, ls, sf2, lo, kw.pop("kfu"), acc, "rbf", **kw)
+            outs.append(acc.cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (N, M, d, outs)
+    # (v) inputs beyond the fp16 format of the contraction (an inducing point more than 128 lengthscales from the mean inducing point): nothing is
+    # added and the correction is reported as NaN -- the caller (core.py) then repeats the evaluation in the whitened order
+    N, M, d = 2000, 256, 2
+    g = torch.Generator().manual_seed(5)
+    X = 30.0 * torch.randn(N, d, dtype=torch.float64, generator=g)
+    y = torch.randn(N, dtype=torch.float64, generator=g)
+    Z = X[:M].clone()
+    Xd, yd, Zd = X.to(engine.device), y.to(engine.device), Z.to(engine.device)
+    ls = [0.1, 0.1]
+    kfu = engine.kfu_buffer(N, M)
+    engine.suffstats(Xd, yd, Zd, ls, 1.0, "rbf", kfu=kfu)
+    P = torch.randn(M, M, dtype=torch.float64, generator=g)
+    P = (1e-12 * (P + P.T)).to(engine.device)
+    acc = torch.ones(d + 1, dtype=torch.float64, device=engine.device)
+    delta = torch.zeros(d + 1, dtype=torch.float64, device=engine.device)
+    engine.suffstats_bwd_lo(Xd, yd, Zd, ls, 1.0, P, kfu, acc, "rbf", delta=delta)
+    assert bool(torch.isnan(delta).all()) and bool((acc == 1.0).all())
     assert not engine.bwd_lo_supported(1000, 64, 9) and not engine.bwd_lo_supported(1000, 64, 3, "matern32")

@@ -350,6 +350,7 @@ def test_extended_gradient_is_trusted_by_its_own_trailing_word_correction(no_sma
     F, g = cb.value_and_grad(Z, *theta)
     assert 3.0 * cb.streaming_tol < cb.last_estimate <= cb.extended_grad_range_lo * cb.streaming_tol, cb.last_estimate
     assert cb.last_tier == 1 and eng.calls["phibar_dd"] == 1 and eng.calls["suffstats_bwd_lo"] == 1 and eng.calls["suffstats_bwd_factored"] == 0
+    assert eng.calls["f16_handed_over"] == 1   # the fp16 image the assembly left is what the trailing-word product multiplies (checked current there)
     assert cb.last_lo_correction is not None and cb.last_lo_correction <= cb.extended_lo_max_correction and cb.n_lo_rejections == 0
     assert abs(F - Fw) / X.shape[0] < 2e-9 and np.max(np.abs(g["ls"].numpy() - gw["ls"].numpy())) <= 1e-6 * max(1.0, float(gw["ls"].abs().max()))
     # without the trailing word (another kernel, d > 8, no K'_fu kept) the old range holds: the same theta goes to the whitened order
