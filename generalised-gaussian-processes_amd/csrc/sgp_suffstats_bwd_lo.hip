@@ -417,8 +417,10 @@ constexpr int L3_T = 256;
 constexpr int L3_BK = 64;
 constexpr int L3_OPB = L3_T * L3_BK * 2;   // bytes per operand and stage
 constexpr int L3_STAGE = 2 * L3_OPB;       // 65 536
-constexpr int L3_TTS = 36;                 // floats per column of the factor table: [-2 z us (8) | us (8) | z^2 us (8) | 0 (12)]; 144-byte rows
-                                           // keep 16-byte reads of 16 consecutive rows on distinct banks (36 r mod 64 = 4 (9 r mod 16))
+constexpr int L3_TTS = 28;                 // floats per column of the factor table: [-2 z us (8) | us (8) | z^2 us (8) | 0 (4)]; 112-byte rows
+                                           // keep 16-byte reads of 16 consecutive rows on distinct banks (28 r mod 64 = 4 (7 r mod 16))
+constexpr int L3_TT_BYTES = L3_T * L3_TTS * 4;   // 28 672: behind the two stages (the table is loaded once, at the start)
+constexpr int L3_LDS_BYTES = 2 * L3_STAGE + L3_TT_BYTES;   // 159 744 of 163 840
 typedef _Float16 lo_h2 __attribute__((ext_vector_type(2)));
 typedef float lo_f2 __attribute__((ext_vector_type(2)));
 typedef float lo_f4 __attribute__((ext_vector_type(4)));
@@ -496,7 +498,14 @@ __device__ __forceinline__ void lo3_glds(const char* g, uint8_t* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int PF>
+// VAR (A/B instruments in the same binary, SGP_LO_VARIANT): 0 = the product; 1 = without the contraction; 2 = two stages only.
+// Measured and dropped (profiles/r06_lo_v3_variants_*.txt, whole call at C5):
+// touching the A operand's lines one / two stages ahead (HBM -> L2) 2.82 / 2.83 against 2.71 ms; all eight DMAs up front behind the barrier
+// 2.69 against 2.71; nobody waiting for the DMAs at all (wrong results, timing only) 2.54 against 2.62 and every workgroup reading row
+// block 0 2.59 against 2.62 -- the loop is not waiting for memory; two fragment sets with the loop rotated by one k-step (a stage's last
+// MFMAs issued behind the next stage's barrier and first reads) 2.65 against 2.64 -- nor for its LDS reads: 1 080 TFLOP/s of fp16 MFMA on
+// these operands is what is left of the clock.
+template <int VAR>
 __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
                                                        const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int64_t nrb,
                                                        int ncb, double* __restrict__ part) {
@@ -531,24 +540,30 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
     const int kseg = (lane & 7) ^ ((R >> 1) & 7);
     goff[p] = (unsigned)(R * Mp + kseg * 8) * 2u;
   }
-  auto issue = [&](int t, int buf) {
-    const char* ab = abase + (size_t)t * (L3_BK * 2);
-    const char* bb = bbase + (size_t)t * (L3_BK * 2);
-    uint8_t* dst = l3 + buf * L3_STAGE + wave * 4096;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) lo3_glds(ab + goff[p], dst + p * 1024);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) lo3_glds(bb + goff[p], dst + L3_OPB + p * 1024);
+  auto issue1 = [&](int t, int buf, int q) {   // DMA q of this wave's eight of stage t: A pieces 0 .. 3, B pieces 4 .. 7
+    const char* gb = (q < 4 ? abase : bbase) + (size_t)t * (L3_BK * 2);
+    lo3_glds(gb + goff[q & 3], l3 + buf * L3_STAGE + wave * 4096 + (q < 4 ? 0 : L3_OPB) + (q & 3) * 1024);
   };
-  auto issue_tt = [&](int buf) {   // this column block's 36 KB of the factor table, a linear copy
+  auto issue = [&](int t, int buf) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue1(t, buf, q);
+  };
+  auto issue_tt = [&]() {   // this column block's 28 KB of the factor table, a linear copy into its own region
     const char* src = reinterpret_cast<const char*>(TT + (size_t)m0 * L3_TTS) + lane * 16;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 4; ++k) {
       const int P = wave + 8 * k;
-      if (P < (L3_T * L3_TTS * 4) / 1024) lo3_glds(src + P * 1024, l3 + buf * L3_STAGE + P * 1024);
+      if (P < L3_TT_BYTES / 1024) lo3_glds(src + P * 1024, l3 + 2 * L3_STAGE + P * 1024);
     }
   };
-
+  // the fp16 block of K' this wave's accumulators are multiplied with, in two halves of 64 columns: 64 rows x 128 bytes = 8 pieces of
+  // 8 rows, wave-private (its own 8 KB of a stage buffer: ordered by the wave's own vmcnt, no barrier)
+  const char* kbase = reinterpret_cast<const char*>(Kh + (size_t)(n0 + wr * 64) * Mp + m0 + wc * 128);
+  auto issue_kp = [&](int half, int buf) {
+#pragma unroll
+    for (int p2 = 0; p2 < 8; ++p2)
+      lo3_glds(kbase + (size_t)(8 * p2 + (lane >> 3)) * Mp * 2 + half * 128 + (lane & 7) * 16, l3 + buf * L3_STAGE + wave * 8192 + p2 * 1024);
+  };
   // fragment reads: row R of an operand image lives at R * 128 + ((kseg ^ ((R >> 1) & 7)) * 16, kseg = 2 ks + h
   const int tsw = ((r31 >> 1) & 7) ^ h;
   const int arow0 = (wr * 64 + r31) * 128;
@@ -562,14 +577,15 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  const int T = Mp / L3_BK;
+  const int T = VAR == 2 ? 2 : Mp / L3_BK;
   auto step = [&](int t, auto buf_tag) {
     constexpr int B = decltype(buf_tag)::value;
-    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0): my pieces of stage t have landed
+    // my pieces of stage t have landed; my reads of the buffer about to be restaged have returned
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));
     __builtin_amdgcn_s_barrier();                            // ... everybody's have, and stage t - 1 has been read by all
     asm volatile("" ::: "memory");
-    if (t + 1 < T) issue(t + 1, B ^ 1);
-    else issue_tt(B ^ 1);
+    const bool more = t + 1 < T;
+    if (!more) issue_kp(0, B ^ 1);   // the last stage: the other buffer is free -- the first half of the K' block lands under these MFMAs
     const uint8_t* sb = l3 + B * L3_STAGE;
 #pragma unroll
     for (int ks = 0; ks < L3_BK / 16; ++ks) {
@@ -583,19 +599,17 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+      // two DMAs of the next stage in the shadow of this k-step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        issue1(t + 1, B ^ 1, 2 * ks);
+        issue1(t + 1, B ^ 1, 2 * ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  issue(0, 0);
-  for (int t = 0; t < T; t += 2) {   // (T is a multiple of 4: Mp of 256)
-    step(t, std::integral_constant<int, 0>());
-    step(t + 1, std::integral_constant<int, 1>());
-  }
-  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  const float* ttl = reinterpret_cast<const float*>(l3);   // the factor table went into stage buffer 0 (the last stage computed from buffer 1)
-
-  // ---- contraction
+  // the contraction's B fragments: loaded here, ahead of every LDS-DMA (behind one, hipcc waits vmcnt(0) at their first use and would
+  // drain the second half of the K' block before the first half's arithmetic)
   lo_h8 bx[2][2];
   {
     const lo_h8* bxg = reinterpret_cast<const lo_h8*>(Bx);
@@ -604,11 +618,38 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 #pragma unroll
       for (int s = 0; s < 2; ++s) bx[i][s] = bxg[((((size_t)rb * 8 + 2 * wr + i) * 2 + s) * 2 + h) * 32 + r31];
   }
-  const uint16_t* kb = Kh + (size_t)(n0 + wr * 64 + 4 * h) * Mp + m0 + wc * 128 + r31;
+  issue_tt();
+  issue(0, 0);
+  for (int t = 0; t < T; t += 2) {   // (T is a multiple of 4: Mp of 256)
+    step(t, std::integral_constant<int, 0>());
+    step(t + 1, std::integral_constant<int, 1>());
+  }
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));
+  __builtin_amdgcn_s_barrier();   // (every wave is through with the last stage's buffer -- buffer 1, T is even -- and the factor table is everybody's)
+  asm volatile("" ::: "memory");
+  const float* ttl = reinterpret_cast<const float*>(l3 + 2 * L3_STAGE);
+  if (VAR == 1) {   // (keep the accumulators alive)
+    float sacc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    const double v = wave_sum((double)sacc);
+    if (lane == 0) red[wave][0] = v;
+    __syncthreads();
+    if (tid < 9) mypart[tid] = tid == 0 ? red[0][0] + red[1][0] + red[2][0] + red[3][0] + red[4][0] + red[5][0] + red[6][0] + red[7][0] : 0.0;
+    return;
+  }
+  // ---- contraction
+  if (VAR != 1) issue_kp(1, 1);   // the second half, under the first half's arithmetic
+  // lane (column r31 of a 32-column block, half h) reads rows 4 h + (e & 3) + 8 (e >> 2) (+ 32 i) of its column: two bytes each
+  const uint8_t* kpl = l3 + wave * 8192 + (4 * h) * 128 + r31 * 2;
   uint32_t raw[16];
 #define L3_LOADKP(I, J)                                                                                        \
   _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                               \
-    raw[e] = kb[(size_t)((I) * 32 + (e & 3) + 8 * (e >> 2)) * Mp + (J) * 32];
+    raw[e] = *reinterpret_cast<const uint16_t*>(kpl + ((J) >> 1) * L3_STAGE + ((I) * 32 + (e & 3) + 8 * (e >> 2)) * 128 + ((J) & 1) * 64);
   L3_LOADKP(0, 0)
   const int oc = (r31 >> 4) ? 8 + (r31 & 7) : (r31 & 7);
   const lo_h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
@@ -628,7 +669,10 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
       for (int u = 0; u < 8; ++u) pk[u] = raw[2 * u] | (raw[2 * u + 1] << 16);
       __builtin_amdgcn_sched_barrier(0);
       if (i == 0) { L3_LOADKP(1, j) }
-      else if (j < 3) { L3_LOADKP(0, j + 1) }
+      else if (j < 3) {
+        if (j == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // the second half of the K' block (this wave's own DMAs)
+        L3_LOADKP(0, j + 1)
+      }
       __builtin_amdgcn_sched_barrier(0);
       uint32_t wv[8];
 #pragma unroll
@@ -657,21 +701,25 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
     }
   }
 #undef L3_LOADKP
-  P += __shfl_xor(P, 8, 64);
-  P += __shfl_xor(P, 16, 64);
-  P += __shfl_xor(P, 32, 64);   // lanes 0 .. 7: the product part of S_q, q = lane
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const double v = wave_sum((double)Sz[q]);
-    if (lane == 0) red[wave][q] = v;
-  }
+  // ten butterflies side by side (one after the other, as nine wave_sum() calls on doubles, they were 54 dependent ds_bpermute round trips:
+  // most of this contraction's time); P only over the lanes that share lane % 8
   {
-    const double v = wave_sum((double)S0);
-    if (lane == 0) red[wave][8] = v;
+    float v[9];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = Sz[q];
+    v[8] = S0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) v[q] += __shfl_xor(v[q], o, 64);
+      if (o >= 8) P += __shfl_xor(P, o, 64);
+    }
+    // lane q < 8: S_q = the A0 part (every lane holds it) + the product part (lanes = q mod 8 hold it); lane 8: S_0
+    float mine = v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mine = lane == q ? v[q] + P : mine;
+    if (lane < 9) red[wave][lane] = (double)mine;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 8) red[wave][lane] += (double)P;
   __syncthreads();
   if (tid < 9) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
 }
@@ -785,7 +833,6 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
   ka.d = d;
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
   static const int lo_kernel = getenv("SGP_LO_KERNEL") ? atoi(getenv("SGP_LO_KERNEL")) : 3;   // A/B: 1 = 128 x 128 tiles, 2 = 256 x 256 with the fp64 contraction
-  static const int lo_pf = getenv("SGP_LO_PREFETCH") ? atoi(getenv("SGP_LO_PREFETCH")) : 0;
   const bool v3 = p.Mp % L3_T == 0 && lo_kernel == 3;
   if (v3) lo3_centre_kernel<<<1, 256, 0, st>>>(w.Zs, M, p.DP, w.centre, w.flag);
   lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, v3 ? 3 : 14, w.Pl, w.unscale);
@@ -801,17 +848,20 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
     const int ncb2 = p.Mp / L3_T;
     nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
     part_dp = 8;
+    static const int lo_var = getenv("SGP_LO_VARIANT") ? atoi(getenv("SGP_LO_VARIANT")) : 0;
+    typedef void (*lo3_fn)(const uint16_t*, const uint16_t*, const lo_u4*, const float*, int, int64_t, int, double*);
+    static const lo3_fn fns[3] = {kphi_lo3_kernel<0>, kphi_lo3_kernel<1>, kphi_lo3_kernel<2>};
+    const lo3_fn fn = fns[lo_var < 0 || lo_var > 2 ? 0 : lo_var];
+    constexpr int lds_bytes = L3_LDS_BYTES;
     static std::atomic<bool> attr_done[64];   // per device, as i8_contract
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return SGP_ERR_LAUNCH;
     if (dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
-      if (hipFuncSetAttribute((const void*)kphi_lo3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * L3_STAGE) != hipSuccess ||
-          hipFuncSetAttribute((const void*)kphi_lo3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * L3_STAGE) != hipSuccess)
-        return SGP_ERR_LAUNCH;
+      for (int b = 0; b < 3; ++b)
+        if (hipFuncSetAttribute((const void*)fns[b], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return SGP_ERR_LAUNCH;
       if (dev < 64) attr_done[dev].store(true, std::memory_order_release);
     }
-    if (lo_pf) kphi_lo3_kernel<1><<<nparts, 512, 2 * L3_STAGE, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, nrb2, ncb2, w.part);
-    else kphi_lo3_kernel<0><<<nparts, 512, 2 * L3_STAGE, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, nrb2, ncb2, w.part);
+    fn<<<nparts, 512, lds_bytes, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, nrb2, ncb2, w.part);
   } else if (p.Mp % LO2_T == 0 && lo_kernel == 2) {
     const int64_t nrb2 = p.Npad / LO2_T;
     const int ncb2 = p.Mp / LO2_T;
