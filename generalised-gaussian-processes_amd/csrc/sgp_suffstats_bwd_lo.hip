@@ -229,170 +229,10 @@ __global__ __launch_bounds__(256, 2) void kphi_lo_kernel(const double* __restric
   if (tid <= DP) mypart[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-// g_ls[j] += 2 inv_ls_j sf2^2 sum_parts S_j ; g_sf2 += 2 sf2 sum_parts S_DP -- one block, a fixed thread <-> partial mapping and a fixed tree
-// The same product on 256 x 256 tiles (eight waves of 64 x 128: 2 x 4 MFMA tiles, 128 fp32 accumulators): the operands are re-read
-// 2 N M K (1/256 + 1/256) = 16 GB instead of 32 -- the 128 x 128 kernel above is bound by that traffic once its register ring really lives in registers.  One workgroup per CU (139 KB of LDS).  The epilogue runs in two phases of two tile columns per wave,
-// because the fp16 image of the tile's own K' block (128 KB) does not fit beside the other images: phase p holds columns 64 p ... 64 p + 63 of
-// either 128-column half.  Mp must be a multiple of 256 (the caller falls back to the 128 x 128 kernel otherwise).
-constexpr int LO2_T = 256;
-template <int DP>
-__global__ __launch_bounds__(512) void kphi_lo256_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
-                                                         const double* __restrict__ unscale, const double* __restrict__ Xs,
-                                                         const double* __restrict__ Zs, int Mp, int64_t nrb, int ncb,
-                                                         double* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) uint16_t ABs[2][LO2_T][LO_LD];
-  __shared__ double red[8][DP + 1];
-  uint16_t (*As)[LO_LD] = ABs[0];
-  uint16_t (*Bs)[LO_LD] = ABs[1];
-  // epilogue images inside the main-loop buffers: eight wave-private 32 x 33 fp32 tiles | Xl | Zl | Kt (256 rows x (2 x 64) columns of fp16)
-  constexpr size_t CL_BYTES = 8 * 32 * 33 * sizeof(float), XZ_BYTES = (size_t)LO2_T * DP * sizeof(double);
-  static_assert(CL_BYTES + 2 * XZ_BYTES + (size_t)LO2_T * LO_LD * sizeof(uint16_t) <= 2 * (size_t)LO2_T * LO_LD * sizeof(uint16_t), "epilogue images fit");
-  char* lbase = reinterpret_cast<char*>(&ABs[0][0][0]);
-  double (*Xl)[DP] = reinterpret_cast<double (*)[DP]>(lbase + CL_BYTES);
-  double (*Zl)[DP] = reinterpret_cast<double (*)[DP]>(lbase + CL_BYTES + XZ_BYTES);
-  _Float16 (*Kt)[LO_LD] = reinterpret_cast<_Float16 (*)[LO_LD]>(lbase + CL_BYTES + 2 * XZ_BYTES);
-
-  const int xcd = blockIdx.x & 7;
-  const int64_t jj = blockIdx.x >> 3;
-  const int cb = (int)(jj % ncb);
-  const int64_t rb = (jj / ncb) * 8 + xcd;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* mypart = part + (size_t)blockIdx.x * (DP + 1);
-  if (rb >= nrb) {
-    if (tid <= DP) mypart[tid] = 0.0;
-    return;
-  }
-  const int wr = wave >> 1, wc = wave & 1;
-  const int r31 = lane & 31, h = lane >> 5;
-  const int64_t n0 = rb * LO2_T;
-  const int m0 = cb * LO2_T;
-
-  constexpr int NV = LO_BK / 16;
-  const int srow = tid >> 1, skh = (tid & 1) * (LO_BK / 2);
-  const uint16_t* asrc = Kh + (size_t)(n0 + srow) * Mp + skh;
-  const uint16_t* bsrc = Pl + (size_t)(m0 + srow) * Mp + skh;
-  lo_u4 areg[NV], breg[NV];
-#define LO_FETCH(K0)                                                                        \
-  _Pragma("unroll") for (int q = 0; q < NV; ++q) {                                          \
-    areg[q] = *reinterpret_cast<const lo_u4*>(asrc + (K0) + 8 * q);                         \
-    breg[q] = *reinterpret_cast<const lo_u4*>(bsrc + (K0) + 8 * q);                         \
-  }
-#define LO_STASH()                                                                          \
-  _Pragma("unroll") for (int q = 0; q < NV; ++q) {                                          \
-    *reinterpret_cast<lo_u4*>(&As[srow][skh + 8 * q]) = areg[q];                            \
-    *reinterpret_cast<lo_u4*>(&Bs[srow][skh + 8 * q]) = breg[q];                            \
-  }
-
-  lo_f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  LO_FETCH(0)
-#ifdef SGP_AB_LO_NO_MAIN
-  for (int k0 = 0; k0 < LO_BK; k0 += LO_BK) {
-#else
-  for (int k0 = 0; k0 < Mp; k0 += LO_BK) {
-#endif
-    LO_STASH()
-    __syncthreads();
-    {
-      const int kn = k0 + LO_BK < Mp ? k0 + LO_BK : k0;
-      LO_FETCH(kn)
-    }
-#pragma unroll
-    for (int ks = 0; ks < LO_BK / 16; ++ks) {
-      lo_h8 a[2], b[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const lo_h8*>(&As[wr * 64 + i * 32 + r31][ks * 16 + 8 * h]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const lo_h8*>(&Bs[wc * 128 + j * 32 + r31][ks * 16 + 8 * h]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-#undef LO_FETCH
-#undef LO_STASH
-  float (*Cl)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float*>(lbase) + wave * 32 * 33);
-  double S[DP + 1];
-#pragma unroll
-  for (int q = 0; q <= DP; ++q) S[q] = 0.0;
-#ifdef SGP_AB_LO_NO_EPI
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) S[DP] += (double)acc[i][j][e];
-#pragma unroll
-  for (int ph = 0; ph < 0; ++ph) {
-#else
-#pragma unroll
-  for (int ph = 0; ph < 2; ++ph) {
-#endif
-    {  // this phase's fp16 block of K': thread <-> (row, 128-column half): columns m0 + 128 half + 64 ph ... + 63
-      lo_u4 kt[8];
-      const uint16_t* ksrc = Kh + (size_t)(n0 + srow) * Mp + m0 + (tid & 1) * 128 + 64 * ph;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) kt[q] = *reinterpret_cast<const lo_u4*>(ksrc + 8 * q);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) *reinterpret_cast<lo_u4*>(&Kt[srow][(tid & 1) * 64 + 8 * q]) = kt[q];
-      if (ph == 0) {
-#pragma unroll
-        for (int e0 = 0; e0 < LO2_T * DP; e0 += 512) {
-          const int e = e0 + tid;
-          Xl[e / DP][e % DP] = Xs[(size_t)n0 * DP + e];
-          Zl[e / DP][e % DP] = Zs[(size_t)m0 * DP + e];
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jl = 0; jl < 2; ++jl) {
-      const int j = 2 * ph + jl;
-      const int col = wc * 128 + j * 32 + r31;          // column inside the 256-wide tile
-      const int kcol = wc * 64 + jl * 32 + r31;          // ... and inside this phase's K' image
-      const double us = unscale[m0 + col];
-      double z[DP];
-#pragma unroll
-      for (int q = 0; q < DP; ++q) z[q] = Zl[col][q];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Cl[(e & 3) + 8 * (e >> 2) + 4 * h][r31] = acc[i][j][e];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int rbase = wr * 64 + i * 32 + 16 * h;
-#pragma unroll 4
-        for (int rr = 0; rr < 16; ++rr) {
-          const double kp = (double)Kt[rbase + rr][kcol];
-          const double w = (double)Cl[16 * h + rr][r31] * (kp * us);
-          S[DP] += w;
-#pragma unroll
-          for (int q = 0; q < DP; ++q) {
-            const double df = z[q] - Xl[rbase + rr][q];
-            S[q] = fma(w * df, df, S[q]);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    __syncthreads();   // (the next phase overwrites the K' image)
-  }
-#pragma unroll
-  for (int q = 0; q <= DP; ++q) {
-    const double v = wave_sum(S[q]);
-    if (lane == 0) red[wave][q] = v;
-  }
-  __syncthreads();
-  if (tid <= DP) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Third version (round 6, after the split A/B profiles/r06_lo_split_ab.txt: of the 256 x 256 kernel's 5.0 ms the main loop took 3.0 and the
-// fp64 contraction behind it 2.0 -- one workgroup per CU, so neither hides behind the other).
+// Third version (round 6.  The second -- this tile shape with the first version's register ring and fp64 contraction, 5.0 ms at C5 -- is in
+// the history (8505ef4); its split A/B, profiles/r06_lo_split_ab.txt: main loop 3.0 ms, contraction 2.0, one workgroup per CU, so neither
+// hides behind the other).
 //
 // Main loop: the same 256 x 256 tile and eight waves of 64 x 128, but the operands travel global -> LDS by LDS-DMA in full 128-byte lines
 // (64-deep stages, 64 KB each, two of them): no register ring, no ds_write pass (128 KB per chunk at ~79 B / clk had the matrix pipe idle a
@@ -507,7 +347,7 @@ __device__ __forceinline__ void lo3_glds(const char* g, uint8_t* l) {
 // these operands is what is left of the clock.
 template <int VAR>
 __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
-                                                       const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int64_t nrb,
+                                                       const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int Mp2, int64_t nrb,
                                                        int ncb, double* __restrict__ part) {
   // (dynamic: with a static array hipcc knows that the LDS-DMA and the fragment reads touch one object and drains the DMA -- vmcnt(0) --
   // before the first read behind it, i.e. before the MFMAs it was to hide under)
@@ -532,17 +372,22 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
   // LDS-DMA roles: wave w moves pieces 4 w .. 4 w + 3 (rows 32 w .. 32 w + 31) of either operand; lane l of piece p: row R = 32 w + 8 p + l / 8,
   // slot l % 8 <- k-segment (l % 8) ^ ((R >> 1) & 7)
   const char* abase = reinterpret_cast<const char*>(Kh + (size_t)n0 * Mp);
-  const char* bbase = reinterpret_cast<const char*>(Pl + (size_t)m0 * Mp);
-  unsigned goff[4];
+  // (Mp2 = Mp rounded up to 256: the image of the low word and the factor table are padded with zeros to it; the image of K' is not -- its
+  // rows are Mp long, and for the k beyond them (two stages, where Mp is an odd multiple of 128) the A operand re-reads the two stages
+  // before, against zeros of the B operand; likewise the K' block of output columns beyond Mp, whose dC is zero)
+  const char* bbase = reinterpret_cast<const char*>(Pl + (size_t)m0 * Mp2);
+  unsigned goff[4], goffb[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int R = 32 * wave + 8 * p + (lane >> 3);
     const int kseg = (lane & 7) ^ ((R >> 1) & 7);
     goff[p] = (unsigned)(R * Mp + kseg * 8) * 2u;
+    goffb[p] = (unsigned)(R * Mp2 + kseg * 8) * 2u;
   }
+  const int ta_last = Mp / L3_BK;   // stages of the A operand that exist
   auto issue1 = [&](int t, int buf, int q) {   // DMA q of this wave's eight of stage t: A pieces 0 .. 3, B pieces 4 .. 7
-    const char* gb = (q < 4 ? abase : bbase) + (size_t)t * (L3_BK * 2);
-    lo3_glds(gb + goff[q & 3], l3 + buf * L3_STAGE + wave * 4096 + (q < 4 ? 0 : L3_OPB) + (q & 3) * 1024);
+    const char* gb = q < 4 ? abase + (size_t)(t < ta_last ? t : t - 2) * (L3_BK * 2) + goff[q & 3] : bbase + (size_t)t * (L3_BK * 2) + goffb[q & 3];
+    lo3_glds(gb, l3 + buf * L3_STAGE + wave * 4096 + (q < 4 ? 0 : L3_OPB) + (q & 3) * 1024);
   };
   auto issue = [&](int t, int buf) {
 #pragma unroll
@@ -558,7 +403,7 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
   };
   // the fp16 block of K' this wave's accumulators are multiplied with, in two halves of 64 columns: 64 rows x 128 bytes = 8 pieces of
   // 8 rows, wave-private (its own 8 KB of a stage buffer: ordered by the wave's own vmcnt, no barrier)
-  const char* kbase = reinterpret_cast<const char*>(Kh + (size_t)(n0 + wr * 64) * Mp + m0 + wc * 128);
+  const char* kbase = reinterpret_cast<const char*>(Kh + (size_t)(n0 + wr * 64) * Mp + (m0 + wc * 128 < Mp ? m0 + wc * 128 : m0 + wc * 128 - 128));
   auto issue_kp = [&](int half, int buf) {
 #pragma unroll
     for (int p2 = 0; p2 < 8; ++p2)
@@ -577,7 +422,7 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  const int T = VAR == 2 ? 2 : Mp / L3_BK;
+  const int T = VAR == 2 ? 2 : Mp2 / L3_BK;
   auto step = [&](int t, auto buf_tag) {
     constexpr int B = decltype(buf_tag)::value;
     // my pieces of stage t have landed; my reads of the buffer about to be restaged have returned
@@ -620,7 +465,7 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
   }
   issue_tt();
   issue(0, 0);
-  for (int t = 0; t < T; t += 2) {   // (T is a multiple of 4: Mp of 256)
+  for (int t = 0; t < T; t += 2) {   // (T is a multiple of 4: Mp2 of 256)
     step(t, std::integral_constant<int, 0>());
     step(t + 1, std::integral_constant<int, 1>());
   }
@@ -777,11 +622,12 @@ static LoWs carve_lo(void* ws, const StreamPlan& p, bool have_f16 = false) {
     const size_t a = (size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1), b = g256 * 9;
     w.part = c.take<double>(a > b ? a : b);
   }
-  w.Pl = c.take<uint16_t>((size_t)p.Mp * p.Mp);
-  w.unscale = c.take<double>((size_t)p.Mp);
+  const size_t mp2 = (size_t)(p.Mp + 255) / 256 * 256;   // (the 256 x 256 kernel's padding)
+  w.Pl = c.take<uint16_t>(mp2 * mp2);
+  w.unscale = c.take<double>(mp2);
   w.centre = c.take<double>(8);
   w.flag = c.take<int>(4);
-  w.TT = c.take<float>((size_t)p.Mp * L3_TTS);
+  w.TT = c.take<float>(mp2 * L3_TTS);
   w.Bx = c.take<lo_u4>((size_t)(p.Npad > 0 ? p.Npad : 1) * 4);   // Npad / 32 row tiles x 128 vectors of 16 bytes
   w.Kh = have_f16 ? nullptr : c.take<uint16_t>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp);   // (last: a caller that brings the image saves it)
   w.bytes = c.used();
@@ -832,24 +678,25 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
   ka.sf2 = sf2;
   ka.d = d;
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
-  static const int lo_kernel = getenv("SGP_LO_KERNEL") ? atoi(getenv("SGP_LO_KERNEL")) : 3;   // A/B: 1 = 128 x 128 tiles, 2 = 256 x 256 with the fp64 contraction
-  const bool v3 = p.Mp % L3_T == 0 && lo_kernel == 3;
+  static const int lo_kernel = getenv("SGP_LO_KERNEL") ? atoi(getenv("SGP_LO_KERNEL")) : 3;   // A/B: 1 = the first version (128 x 128 tiles, register ring, fp64 contraction)
+  const bool v3 = lo_kernel == 3;
+  const int Mp2 = (p.Mp + L3_T - 1) / L3_T * L3_T, plm = v3 ? Mp2 : p.Mp;   // the padded edge of the low word's image
   if (v3) lo3_centre_kernel<<<1, 256, 0, st>>>(w.Zs, M, p.DP, w.centre, w.flag);
-  lo_prep_kernel<<<p.Mp, 256, 0, st>>>(Phibar_lo, M, p.Mp, v3 ? 3 : 14, w.Pl, w.unscale);
+  lo_prep_kernel<<<plm, 256, 0, st>>>(Phibar_lo, M, plm, v3 ? 3 : 14, w.Pl, w.unscale);
   const int64_t nrb = p.Npad / LO_T;
   const int ncb = p.Mp / LO_T;
   if (!Kfu_f16_in) lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
   int nparts = w.grid, part_dp = p.DP;
   if (v3) {
-    lo3_tt_kernel<<<(p.Mp + 255) / 256, 256, 0, st>>>(w.Zs, w.unscale, w.centre, M, p.Mp, p.DP, w.TT, w.flag);
+    lo3_tt_kernel<<<(Mp2 + 255) / 256, 256, 0, st>>>(w.Zs, w.unscale, w.centre, M, Mp2, p.DP, w.TT, w.flag);
     const int64_t nvec = p.Npad * 4;
     lo_bx_kernel<<<(unsigned)((nvec + 255) / 256), 256, 0, st>>>(w.Xs, w.centre, nvec, p.DP, w.Bx);
     const int64_t nrb2 = p.Npad / L3_T;
-    const int ncb2 = p.Mp / L3_T;
+    const int ncb2 = Mp2 / L3_T;
     nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
     part_dp = 8;
     static const int lo_var = getenv("SGP_LO_VARIANT") ? atoi(getenv("SGP_LO_VARIANT")) : 0;
-    typedef void (*lo3_fn)(const uint16_t*, const uint16_t*, const lo_u4*, const float*, int, int64_t, int, double*);
+    typedef void (*lo3_fn)(const uint16_t*, const uint16_t*, const lo_u4*, const float*, int, int, int64_t, int, double*);
     static const lo3_fn fns[3] = {kphi_lo3_kernel<0>, kphi_lo3_kernel<1>, kphi_lo3_kernel<2>};
     const lo3_fn fn = fns[lo_var < 0 || lo_var > 2 ? 0 : lo_var];
     constexpr int lds_bytes = L3_LDS_BYTES;
@@ -861,16 +708,7 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
         if (hipFuncSetAttribute((const void*)fns[b], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return SGP_ERR_LAUNCH;
       if (dev < 64) attr_done[dev].store(true, std::memory_order_release);
     }
-    fn<<<nparts, 512, lds_bytes, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, nrb2, ncb2, w.part);
-  } else if (p.Mp % LO2_T == 0 && lo_kernel == 2) {
-    const int64_t nrb2 = p.Npad / LO2_T;
-    const int ncb2 = p.Mp / LO2_T;
-    nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
-    switch (p.DP) {
-      case 2: kphi_lo256_kernel<2><<<nparts, 512, 0, st>>>(Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
-      case 4: kphi_lo256_kernel<4><<<nparts, 512, 0, st>>>(Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
-      default: kphi_lo256_kernel<8><<<nparts, 512, 0, st>>>(Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb2, ncb2, w.part); break;
-    }
+    fn<<<nparts, 512, lds_bytes, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, Mp2, nrb2, ncb2, w.part);
   } else {
     switch (p.DP) {
       case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;

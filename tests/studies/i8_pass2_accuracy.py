@@ -82,5 +82,26 @@ for S in (3, 4, 5, 6, 7):
                  "g_ls_rel_err": float(np.abs(g[0] - g_ref[0]).max() / np.abs(g_ref[0]).max()),
                  "g_sf2_rel_err": abs(g[1] - g_ref[1]) / abs(g_ref[1])})
     print(json.dumps(rows[-1]), flush=True)
+# Round 6: ASYMMETRIC digit budgets.  The rounding of K' is a fresh random error in every data row (the gradient sums over n: it grows like
+# sqrt(N)); the rounding of Pb is ONE perturbation that every row sees (it grows like N -- tests/studies/explicit_phibar_pass2.py).  So K' may
+# keep fewer digits than Pb: SA digits of K', all seven of Pb, pairs of depth da + db < S.
+if os.environ.get("ASYM", "1") == "1":
+    for SA, S in ((2, 7), (3, 7), (3, 8), (3, 9), (4, 7), (4, 8), (4, 9), (4, 10), (5, 9)):
+        C = np.zeros_like(C_ref)
+        npairs = 0
+        for da in range(SA):
+            for db in range(NB):
+                if da + db >= S:
+                    continue
+                pa, pb = 6 - da, NB - 1 - db
+                prod = a[pa].astype(np.float64) @ bd[pb].astype(np.float64).T
+                C += prod * np.ldexp(1.0, 8 * pa - 54) * (np.ldexp(1.0, 8 * pb) / scale)[None, :]
+                npairs += 1
+        g = grads(C)
+        err = np.abs(C - C_ref)
+        print(json.dumps({"digits_of_Kprime": SA, "depth_cut": S, "pairs": npairs,
+                          "max_elem_err_rel_Cmax": float(err.max() / np.abs(C_ref).max()),
+                          "g_ls_rel_err": float(np.abs(g[0] - g_ref[0]).max() / np.abs(g_ref[0]).max()),
+                          "g_sf2_rel_err": abs(g[1] - g_ref[1]) / abs(g_ref[1])}), flush=True)
 print(json.dumps({"N": N, "M": M, "ls": ls_v, "sig_n": sn, "Pb_absmax": float(np.abs(Pb).max()), "C_absmax": float(np.abs(C_ref).max()),
                   "cancellation_rowmax_over_C": float(np.ldexp(1.0, ex).max() / np.abs(C_ref).max())}))

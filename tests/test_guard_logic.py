@@ -380,6 +380,12 @@ def test_extended_gradient_is_trusted_by_its_own_trailing_word_correction(no_sma
     c3._lo_skip = 0
     c3.value_and_grad(Z, *theta)
     assert c3.last_tier == 1 and c3._lo_pause == 0
+    # a correction reported as NaN (the product's fp16 inputs could not hold this theta: nothing was added) is a rejection, not a pass
+    e5 = FactoredOracleEngine()
+    e5.lo_delta_scale = float("nan")
+    c5 = _bound(X, y, e5)
+    F5, g5 = c5.value_and_grad(Z, *theta)
+    assert c5.last_tier == 2 and c5.n_lo_rejections == 1 and c5.last_lo_correction == float("inf") and g5["ls"].tolist() == gw["ls"].tolist()
     # the sampler mode takes the extended order's gradient as far as its value holds, whatever the correction says
     e3.lo_delta_scale = 1e12
     F4, g4 = c3.value_and_grad(Z, *theta, grad_reach=16384.0, strict=True)

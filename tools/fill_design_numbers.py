@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fills the @@...@@ placeholders of DESIGN.md section 0 / 4i / 8 from a digest-matched final set (gpurun_out/<tag>/ of tools/profile_final.sh)."""
+"""Fills the @@...@@ placeholders of DESIGN.md section 0 / 4i / 8 and of README.md from a digest-matched final set (gpurun_out/<tag>/ of tools/profile_final.sh)."""
 import json
 import re
 import sys
@@ -19,11 +19,19 @@ vals = {
     "PARITY": "%.1f" % t["parity"], "SAMPLER": "%.1f" % t["sampler"], "LOMS": "%.1f" % lo["suffstats_bwd_lo_ms"],
     "GPUSUITE": re.sub(r" in [0-9.]+s.*", "", suite.replace("=", "").strip()),
     "CPUSUITE": sys.argv[2] if len(sys.argv) > 2 else "139 passed",
+    "PARITYMS": "%.1f" % (1000.0 / t["parity"]),
     "CPUBASE": "%s = %.4f evaluations / s on %d host threads" % (re.search(r"all \d+ rows: ([0-9.]+ s)", cb["sample"]).group(1), cb["value"], cb["cores"]),
 }
-s = open("DESIGN.md").read()
-for k, v in vals.items():
-    s = s.replace("@@%s@@" % k, v)
-left = re.findall(r"@@[A-Z]+@@", s)
-open("DESIGN.md", "w").write(s)
-print(vals, "unfilled:", left)
+import csv
+for row in csv.reader(open(O + "lo_kernel_stats.csv")):
+    if row and "kphi_lo3_kernel" in row[0]:
+        ms = float(row[3]) / 1e6
+        vals.update(LO3MS="%.2f" % ms, LO3TF="%.0f" % (2.0 * 1e6 * 1024 * 1024 / (ms * 1e-3) / 1e12), LO3FRAC="%.2f" % (2.0 * 1e6 * 1024 * 1024 / (ms * 1e-3) / 2.5e15))
+for name in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+    s = open(name).read()
+    for k, v in vals.items():
+        s = s.replace("@@%s@@" % k, v)
+    left = re.findall(r"@@[A-Z0-9]+@@", s)
+    open(name, "w").write(s)
+    print(name, "unfilled:", left)
+print(vals)

@@ -46,7 +46,13 @@ timeout 900 bash tools/potrf_trace_check.sh < /dev/null > "$O/potrf_trace_check.
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/lo_prof" -o run -- python3 tools/lo_kernel_ms.py < /dev/null > "$O/lo_kernel_ms.json" 2> "$O/lo.err"
 f=$(find "$O/lo_prof" -name "*kernel_stats*" | head -1); if [ -n "$f" ]; then grep -E "Name|lo_|kphi|dd_gemm|phibar|kbar_contract" "$f" | sed 's/(.*)"/"/' > "$O/lo_kernel_stats.csv"; fi
 rm -rf "$O/lo_prof"
-for t in 0 1 0 1; do echo "SGP_LO_TILE128=$t"; SGP_LO_TILE128=$t timeout 300 python3 tools/lo_kernel_ms.py < /dev/null 2>/dev/null; done > "$O/lo_tile_256_vs_128_ab.txt"
+# the trailing-word product: first version against the product; without the assembly kernel's fp16 image; the instruments (no contraction / two stages)
+for c in "3 0 1" "1 0 1" "3 0 0" "3 1 1" "3 2 1" "3 0 1" "1 0 1" "3 0 0"; do
+  set -- $c
+  echo "SGP_LO_KERNEL=$1 SGP_LO_VARIANT=$2 LO_F16_IMAGE=$3"
+  SGP_LO_KERNEL=$1 SGP_LO_VARIANT=$2 LO_F16_IMAGE=$3 timeout 300 python3 tools/lo_kernel_ms.py < /dev/null 2>/dev/null
+done > "$O/lo_versions_ab.txt"
+timeout 600 python3 tools/lo_v3_check.py < /dev/null > "$O/lo_v3_check.jsonl" 2>/dev/null
 GRADS=1 LEVEL=2 timeout 900 python3 tools/extended_check.py < /dev/null > "$O/extended_order_gradients_dd_phibar.jsonl" 2>/dev/null
 timeout 600 python3 tools/extended_grad_check.py < /dev/null > "$O/extended_order_gradients_ard_dd_phibar.jsonl" 2>/dev/null
 timeout 900 python3 tools/lo_threshold_probe.py < /dev/null > "$O/lo_threshold_probe.jsonl" 2>/dev/null
