@@ -342,9 +342,11 @@ __device__ __forceinline__ void lo3_glds(const char* g, uint8_t* l) {
 // Measured and dropped (profiles/r06_lo_v3_variants_*.txt, whole call at C5):
 // touching the A operand's lines one / two stages ahead (HBM -> L2) 2.82 / 2.83 against 2.71 ms; all eight DMAs up front behind the barrier
 // 2.69 against 2.71; nobody waiting for the DMAs at all (wrong results, timing only) 2.54 against 2.62 and every workgroup reading row
-// block 0 2.59 against 2.62 -- the loop is not waiting for memory; two fragment sets with the loop rotated by one k-step (a stage's last
-// MFMAs issued behind the next stage's barrier and first reads) 2.65 against 2.64 -- nor for its LDS reads: 1 080 TFLOP/s of fp16 MFMA on
-// these operands is what is left of the clock.
+// block 0 2.59 against 2.62; two fragment sets with the loop rotated by one k-step (a stage's last MFMAs issued behind the next stage's
+// barrier and first reads) 2.65 against 2.64.  What the loop does wait for, by removal (timing-only builds, profiles/r06_lo_v3_loop_components.txt,
+// whole call): without the loop's DMAs 2.08 against 2.55 ms, without its fragment reads 2.50, with neither 1.94 -- the ISSUE of the LDS-DMAs is
+// what the waves stand in (64 KB per CU and stage through the L2 -> LDS path: 33 GB/s per CU, 8.5 TB/s over the chip; the matrix pipe is 0.46
+// busy at 2.03 GHz, SQ counters of the bench run), not their latency and not the LDS.
 template <int VAR>
 __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
                                                        const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int Mp2, int64_t nrb,
