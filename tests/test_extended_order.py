@@ -194,6 +194,10 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
             engine.suffstats_bwd_lo(Xd, yd, Zd, ls, sf2, lo, kw.pop("kfu"), acc, "rbf", **kw)
             outs.append(acc.cpu())
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (N, M, d, outs)
+    with pytest.raises(ValueError):   # the image is written beside the fp64 block, never alone
+        engine.suffstats_extended(Xd, yd, Zd, ls, sf2, linv, "rbf", kfu=None, level=2, kfu_f16=kh)
+    with pytest.raises(ValueError):   # the product needs one of the two
+        engine.suffstats_bwd_lo(Xd, yd, Zd, ls, sf2, lo, None, torch.zeros(d + 1, dtype=torch.float64, device=engine.device), "rbf")
     # (v) inputs beyond the fp16 format of the contraction (an inducing point more than 128 lengthscales from the mean inducing point): nothing is
     # added and the correction is reported as NaN -- the caller (core.py) then repeats the evaluation in the whitened order
     N, M, d = 2000, 256, 2

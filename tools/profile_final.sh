@@ -53,6 +53,8 @@ for c in "3 0 1" "1 0 1" "3 0 0" "3 1 1" "3 2 1" "3 0 1" "1 0 1" "3 0 0"; do
   SGP_LO_KERNEL=$1 SGP_LO_VARIANT=$2 LO_F16_IMAGE=$3 timeout 300 python3 tools/lo_kernel_ms.py < /dev/null 2>/dev/null
 done > "$O/lo_versions_ab.txt"
 timeout 600 python3 tools/lo_v3_check.py < /dev/null > "$O/lo_v3_check.jsonl" 2>/dev/null
+timeout 900 python3 tools/soak_lo.py 300 < /dev/null > "$O/soak_lo.txt" 2>&1
+timeout 900 bash tools/profile_lo_pmc.sh "$TAG" > "$O/lo_pmc.log" 2>&1
 GRADS=1 LEVEL=2 timeout 900 python3 tools/extended_check.py < /dev/null > "$O/extended_order_gradients_dd_phibar.jsonl" 2>/dev/null
 timeout 600 python3 tools/extended_grad_check.py < /dev/null > "$O/extended_order_gradients_ard_dd_phibar.jsonl" 2>/dev/null
 timeout 900 python3 tools/lo_threshold_probe.py < /dev/null > "$O/lo_threshold_probe.jsonl" 2>/dev/null
