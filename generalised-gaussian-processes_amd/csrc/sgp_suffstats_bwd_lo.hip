@@ -303,35 +303,39 @@ __global__ __launch_bounds__(256) void lo3_tt_kernel(const double* __restrict__ 
 
 // B operand of the contraction product.  16-byte vector v = (((rt 2 + s) 2 + h) 32 + c): data rows n = 32 rt + 16 s + 4 h + (t & 3) + 8 (t >> 2),
 // t = 0 .. 7 (the rows lane half h of an accumulator tile holds in registers 8 s .. 8 s + 7); column c = 8 kind + q.
-__global__ __launch_bounds__(256) void lo_bx_kernel(const double* __restrict__ Xs, const double* __restrict__ centre, int64_t nvec, int DP,
+__global__ __launch_bounds__(256) void lo_bx_kernel(const double* __restrict__ Xs, const double* __restrict__ centre, int64_t ngroups, int DP,
                                                     lo_u4* __restrict__ out) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v >= nvec) return;
-  const int c = (int)(v & 31), hh = (int)((v >> 5) & 1), s = (int)((v >> 6) & 1);
-  const int64_t rt = v >> 7;
-  const int kind = c >> 3, q = c & 7;
+  // thread <-> (row tile rt, k-step s, lane half h, dimension q): its eight rows once, the four kinds of column from them
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= ngroups * 8) return;
+  const int q = (int)(u & 7), hh = (int)((u >> 3) & 1), s = (int)((u >> 4) & 1);
+  const int64_t rt = u >> 5;
   const double cq = centre[q];
-  uint32_t w[4];
+  uint32_t w[4][4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    uint32_t pr[2];
+  for (int t = 0; t < 8; ++t) {
+    const int64_t n = rt * 32 + 16 * s + 4 * hh + (t & 3) + 8 * (t >> 2);
+    double xc = q < DP ? Xs[(size_t)n * DP + q] - cq : 0.0;
+    xc = xc > 255.0 ? 255.0 : (xc < -255.0 ? -255.0 : xc);
+    if (!(xc == xc)) xc = 0.0;   // (a NaN coordinate: its row of K' is NaN already and the leading word's gradient with it)
+    const double x2 = xc * xc;
+    const _Float16 xh = (_Float16)(float)xc, qh = (_Float16)(float)x2;
+    const _Float16 xl = (_Float16)(float)(xc - (double)(float)xh), ql = (_Float16)(float)(x2 - (double)(float)qh);
+    const _Float16 v4[4] = {xh, xl, qh, ql};
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int t = 2 * u + b;
-      const int64_t n = rt * 32 + 16 * s + 4 * hh + (t & 3) + 8 * (t >> 2);
-      double xc = q < DP ? Xs[(size_t)n * DP + q] - cq : 0.0;
-      xc = xc > 255.0 ? 255.0 : (xc < -255.0 ? -255.0 : xc);
-      if (!(xc == xc)) xc = 0.0;   // (a NaN coordinate: its row of K' is NaN already and the leading word's gradient with it)
-      const double val = kind < 2 ? xc : xc * xc;
-      const _Float16 hi = (_Float16)(float)val;
-      const _Float16 pick = (kind & 1) ? (_Float16)(float)(val - (double)(float)hi) : hi;
-      pr[b] = (uint32_t)__builtin_bit_cast(uint16_t, pick);
+    for (int kind = 0; kind < 4; ++kind) {
+      const uint32_t bits = (uint32_t)__builtin_bit_cast(uint16_t, v4[kind]);
+      if (t & 1) w[kind][t >> 1] |= bits << 16;
+      else w[kind][t >> 1] = bits;
     }
-    w[u] = pr[0] | (pr[1] << 16);
   }
-  lo_u4 o;
-  o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
-  out[v] = o;
+  lo_u4* dst = out + (u >> 3) * 32 + q;   // vector (((rt 2 + s) 2 + h) 32 + 8 kind + q)
+#pragma unroll
+  for (int kind = 0; kind < 4; ++kind) {
+    lo_u4 o;
+    o[0] = w[kind][0]; o[1] = w[kind][1]; o[2] = w[kind][2]; o[3] = w[kind][3];
+    dst[8 * kind] = o;
+  }
 }
 
 __device__ __forceinline__ void lo3_glds(const char* g, uint8_t* l) {
@@ -573,20 +577,21 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 
 // delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
 // the explicit pass 2 can be trusted at this theta (core.py: extended_lo_max_correction)
-// (one workgroup per slot: 256 threads stride over the partials -- 62 500 of them at C5 --, wave sums, four wave totals added in order)
-__global__ __launch_bounds__(256) void lo_reduce_kernel(const double* __restrict__ part, int nparts, int DP, KernArgs ka, const int* __restrict__ flag,
-                                                        double* __restrict__ g_ls, double* __restrict__ g_sf2, double* __restrict__ delta) {
-  __shared__ double red[4];
+// (one workgroup per slot: 1024 threads stride over the partials, wave sums, sixteen wave totals added in order)
+__global__ __launch_bounds__(1024) void lo_reduce_kernel(const double* __restrict__ part, int nparts, int DP, KernArgs ka, const int* __restrict__ flag,
+                                                         double* __restrict__ g_ls, double* __restrict__ g_sf2, double* __restrict__ delta) {
+  __shared__ double red[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
     const int q = blockIdx.x;
     const int slot = q == ka.d ? DP : q;
     double s = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 256) s += part[(size_t)p * (DP + 1) + slot];
+    for (int p = threadIdx.x; p < nparts; p += 1024) s += part[(size_t)p * (DP + 1) + slot];   // (15 dependent loads per thread at C5; 61 with 256 threads: 32 us)
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
+    s = 0.0;
+    for (int w2 = 0; w2 < 16; ++w2) s += red[w2];
     if (threadIdx.x == 0) {
       const double c = q == ka.d ? 2.0 * ka.sf2 * s : 2.0 * ka.inv_ls[q] * ka.sf2 * ka.sf2 * s;
       if (flag && *flag) {   // an inducing point beyond the fp16 range of the contraction's inputs: no correction, and the caller is told
@@ -691,8 +696,8 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
   int nparts = w.grid, part_dp = p.DP;
   if (v3) {
     lo3_tt_kernel<<<(Mp2 + 255) / 256, 256, 0, st>>>(w.Zs, w.unscale, w.centre, M, Mp2, p.DP, w.TT, w.flag);
-    const int64_t nvec = p.Npad * 4;
-    lo_bx_kernel<<<(unsigned)((nvec + 255) / 256), 256, 0, st>>>(w.Xs, w.centre, nvec, p.DP, w.Bx);
+    const int64_t ngroups = p.Npad / 8;   // (row tile, k-step, lane half): 32 vectors each
+    lo_bx_kernel<<<(unsigned)((ngroups * 8 + 255) / 256), 256, 0, st>>>(w.Xs, w.centre, ngroups, p.DP, w.Bx);
     const int64_t nrb2 = p.Npad / L3_T;
     const int ncb2 = Mp2 / L3_T;
     nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
@@ -718,6 +723,6 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
       default: kphi_lo_kernel<8><<<w.grid, 256, 0, st>>>(Kfu_in, Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;
     }
   }
-  lo_reduce_kernel<<<d + 1, 256, 0, st>>>(w.part, nparts, part_dp, ka, v3 ? w.flag : nullptr, g_ls, g_sf2, delta);
+  lo_reduce_kernel<<<d + 1, 1024, 0, st>>>(w.part, nparts, part_dp, ka, v3 ? w.flag : nullptr, g_ls, g_sf2, delta);
   return check_launch();
 }

@@ -734,35 +734,44 @@ __global__ __launch_bounds__(256) void reduce_phi_dd_kernel(const double* __rest
 // C (double-double) = A (double-double, n x n) B^T (fp64, n x n), all ld n, n a multiple of 64; tr: C is written transposed.  Plain fp64
 // VALU: two_prod by fma, two_sum, no contraction -- 64 x 64 tiles of 256 threads, 4 x 4 outputs per thread, 16-deep k-chunks through
 // LDS (tools/dd_gemm_proto.hip: both products of W = L^-1 Phi L^-T in 1.14 ms at n = 1024, 3e-18 of max |W| against long doubles).
+// NI x NJ outputs per thread (tile 16 NI x 16 NJ).  Round 6: 4 x 4 (64 x 64 tiles: 256 workgroups at n = 1024, ONE wave per SIMD) -> 2 x 2,
+// four waves per SIMD (dd_launch below; every output is still accumulated over k in order: the same bits).
 constexpr int DDT = 64, DDK = 16;
+template <int NI, int NJ>
 __global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restrict__ Ahi, const double* __restrict__ Alo,
                                                          const double* __restrict__ B, int n, double* __restrict__ Chi,
                                                          double* __restrict__ Clo, int tr) {
 #pragma clang fp contract(off)
-  __shared__ double sAh[DDK][DDT + 1], sAl[DDK][DDT + 1], sB[DDK][DDT + 1];
-  const int i0 = blockIdx.y * DDT, j0 = blockIdx.x * DDT, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  double hi[4][4], lo[4][4];
+  constexpr int TI = 16 * NI, TJ = 16 * NJ;
+  __shared__ double sAh[DDK][TI + 1], sAl[DDK][TI + 1], sB[DDK][TJ + 1];
+  const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double hi[NI][NJ], lo[NI][NJ];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) hi[a][b] = lo[a][b] = 0.0;
+    for (int b = 0; b < NJ; ++b) hi[a][b] = lo[a][b] = 0.0;
   for (int k0 = 0; k0 < n; k0 += DDK) {
-    for (int e = tid; e < DDT * DDK; e += 256) {
+    for (int e = tid; e < TI * DDK; e += 256) {
       const int r = e / DDK, kk = e % DDK;
       sAh[kk][r] = Ahi[(size_t)(i0 + r) * n + k0 + kk];
       sAl[kk][r] = Alo[(size_t)(i0 + r) * n + k0 + kk];
+    }
+    for (int e = tid; e < TJ * DDK; e += 256) {
+      const int r = e / DDK, kk = e % DDK;
       sB[kk][r] = B[(size_t)(j0 + r) * n + k0 + kk];
     }
     __syncthreads();
 #pragma unroll 4
     for (int kk = 0; kk < DDK; ++kk) {
-      double ah[4], al[4], bv[4];
+      double ah[NI], al[NI], bv[NJ];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) { ah[a] = sAh[kk][ti + 16 * a]; al[a] = sAl[kk][ti + 16 * a]; bv[a] = sB[kk][tj + 16 * a]; }
+      for (int a = 0; a < NI; ++a) { ah[a] = sAh[kk][ti + 16 * a]; al[a] = sAl[kk][ti + 16 * a]; }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < NJ; ++b) bv[b] = sB[kk][tj + 16 * b];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) {
           const double pr = ah[a] * bv[b];
           const double e = fma(ah[a], bv[b], -pr) + al[a] * bv[b];
           const double sum = hi[a][b] + pr;
@@ -774,9 +783,9 @@ __global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restric
     __syncthreads();
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NJ; ++b) {
       const double sum = hi[a][b] + lo[a][b];
       const double l = lo[a][b] - (sum - hi[a][b]);
       const int i = i0 + ti + 16 * a, j = j0 + tj + 16 * b;
@@ -784,6 +793,13 @@ __global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restric
       Chi[o] = sum;
       Clo[o] = l;
     }
+}
+static void dd_launch(const double* Ahi, const double* Alo, const double* B, int n, double* Chi, double* Clo, int tr, hipStream_t st) {
+  // SGP_DD_TILE=44: the 64 x 64 tiles of rounds 4-5.  Same box, Phibar's two products at n = 1024: 1.39-1.40 ms (64 x 64), 1.14-1.16 (64 x 32),
+  // 1.06-1.07 (32 x 32: four waves per SIMD) -- profiles/r06_dd_gemm_tile_ab.txt
+  static const int shape = getenv("SGP_DD_TILE") ? atoi(getenv("SGP_DD_TILE")) : 22;
+  if (shape == 44) dd_gemm_nt_kernel<4, 4><<<dim3(n / 64, n / 64), 256, 0, st>>>(Ahi, Alo, B, n, Chi, Clo, tr);
+  else dd_gemm_nt_kernel<2, 2><<<dim3(n / 32, n / 32), 256, 0, st>>>(Ahi, Alo, B, n, Chi, Clo, tr);
 }
 // ---- Phibar in double-double (round 6; tests/studies/explicit_phibar_pass2.py) ---------------------------------
 // The extended order's pass 2 takes the EXPLICIT Phibar = L^-T (C / 2 s2) L^-1, whose cond(K_uu)-sized entries cancel in Kbar = 2 K Phibar.
@@ -833,9 +849,8 @@ extern "C" int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, do
   double *Cs = base, *zeros = Cs + mm, *G = zeros + mm, *Yh = G + mm, *Yl = Yh + mm, *Ph = Yl + mm, *Pl = Ph + mm;
   hipStream_t st = (hipStream_t)stream;
   phibar_dd_prep_kernel<<<dim3(Mp / 32, Mp / 32), 256, 0, st>>>(Cw, M, Mp, 0.5 / s2, kuu_linv, Cs, zeros, G);
-  const dim3 g(Mp / DDT, Mp / DDT);
-  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(Cs, zeros, G, Mp, Yh, Yl, 1);   // Y^T = (Cs L^-1)^T
-  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(Yh, Yl, G, Mp, Ph, Pl, 0);      // Phibar = Y^T (L^-1) = L^-T Cs L^-1
+  dd_launch(Cs, zeros, G, Mp, Yh, Yl, 1, st);   // Y^T = (Cs L^-1)^T
+  dd_launch(Yh, Yl, G, Mp, Ph, Pl, 0, st);      // Phibar = Y^T (L^-1) = L^-T Cs L^-1
   phibar_dd_out_kernel<<<1024, 256, 0, st>>>(Ph, Pl, M, Mp, Phibar_hi, Phibar_lo);
   return check_launch();
 }
@@ -1207,9 +1222,8 @@ extern "C" int sgp_suffstats_fwd_extended_f16(const double* X, int64_t ldx, cons
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_dd_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, w.slab_lo, ns, p.ntiles, p.Mp, w.Ph, w.Pl);
-  const dim3 g(p.Mp / DDT, p.Mp / DDT);
-  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(w.Ph, w.Pl, kuu_linv, p.Mp, w.Yh, w.Yl, 1);  // Y^T = (Phi L^-T)^T
-  dd_gemm_nt_kernel<<<g, 256, 0, st>>>(w.Yh, w.Yl, kuu_linv, p.Mp, w.Wh, w.Wl, 0);  // W = Y^T L^-T = L^-1 Phi L^-T (symmetric)
+  dd_launch(w.Ph, w.Pl, kuu_linv, p.Mp, w.Yh, w.Yl, 1, st);  // Y^T = (Phi L^-T)^T
+  dd_launch(w.Yh, w.Yl, kuu_linv, p.Mp, w.Wh, w.Wl, 0, st);  // W = Y^T L^-T = L^-1 Phi L^-T (symmetric)
   ext_w_out_kernel<<<1024, 256, 0, st>>>(w.Wh, w.Wl, M, p.Mp, sf2 * sf2, W);
   if (phi_diag) ext_phi_diag_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.Ph, M, p.Mp, sf2 * sf2, phi_diag);
   // b = K_uf y (fp64, with its amplitude), u = L^-1 b
