@@ -212,7 +212,7 @@ class CollapsedBound:
         self.extended_range = 16384.0
         self.extended_grad_range = 3.0
         self.extended_dd_phibar = True   # the extended order's explicit Phibar formed in double-double (sgp_phibar_dd) ...
-        self.extended_lo = True            # ... with its trailing word applied in pass 2 where that exists (RBF, d <= 8, K'_fu kept)
+        self.extended_lo = True            # ... with its trailing word applied in pass 2 where that exists (RBF, K'_fu kept)
         # ... and its reach with the trailing word applied in pass 2 (sgp_suffstats_bwd_lo).  Calibrated at C5 over 34 theta against the factored
         # pass 2 of the whitened order (profiles/r06_extended_order_gradients_dd_phibar.jsonl, ..._ard_...): with both words every cell
         # whose estimate is <= 1e-6 AND whose correction is <= 1e-4 of the gradient is within 6e-7 (the trained ARD thetas of C5: 3e-9 and
@@ -375,7 +375,7 @@ class CollapsedBound:
                 and self._rows_for_form * int(M) >= self.whitened_rows_min_work)
 
     def _bwd_lo_ok(self, M):
-        """Pass 2 of the extended order can apply the trailing word of the double-double Phibar here (RBF, d <= 8, K'_fu kept): a
+        """Pass 2 of the extended order can apply the trailing word of the double-double Phibar here (RBF, K'_fu kept): a
         rank-invariant statement, like `_extended_ok`."""
         e = self.engine
         return (self.extended_dd_phibar and self.extended_lo and hasattr(e, "suffstats_bwd_lo") and hasattr(e, "phibar_dd")

@@ -265,52 +265,59 @@ typedef _Float16 lo_h2 __attribute__((ext_vector_type(2)));
 typedef float lo_f2 __attribute__((ext_vector_type(2)));
 typedef float lo_f4 __attribute__((ext_vector_type(4)));
 
-// c_q = mean over the inducing points of z~_q (fixed order); clears the range flag
+// c_q = mean over the inducing points of z~_q (fixed order; q < 32); clears the range flag
 __global__ __launch_bounds__(256) void lo3_centre_kernel(const double* __restrict__ Zs, int M, int DP, double* __restrict__ centre, int* __restrict__ flag) {
-  __shared__ double red[32][8];
-  const int q = threadIdx.x & 7, part = threadIdx.x >> 3;
+  __shared__ double red[8][32];
+  const int q = threadIdx.x & 31, part = threadIdx.x >> 5;
   double s = 0.0;
   if (q < DP)
-    for (int m = part; m < M; m += 32) s += Zs[(size_t)m * DP + q];
+    for (int m = part; m < M; m += 8) s += Zs[(size_t)m * DP + q];
   red[part][q] = s;
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < 32) {
     double t = 0.0;
-    for (int p2 = 0; p2 < 32; ++p2) t += red[p2][threadIdx.x];
+    for (int p2 = 0; p2 < 8; ++p2) t += red[p2][threadIdx.x];
     centre[threadIdx.x] = t / (double)M;
   }
   if (threadIdx.x == 0) *flag = 0;
 }
 
-// factor table, one thread per padded column (behind lo_prep_kernel: needs unscale)
+// factor tables, one per group of eight dimensions (TT + g Mp 28 floats: the kernel holds one group's table at a time); one thread per padded column
+// (behind lo_prep_kernel: needs unscale)
 __global__ __launch_bounds__(256) void lo3_tt_kernel(const double* __restrict__ Zs, const double* __restrict__ unscale, const double* __restrict__ centre,
-                                                     int M, int Mp, int DP, float* __restrict__ TT, int* __restrict__ flag) {
+                                                     int M, int Mp, int DP, int NG, float* __restrict__ TT, int* __restrict__ flag) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= Mp) return;
-  float* row = TT + (size_t)m * L3_TTS;
   const double us = unscale[m];
   bool far = false;
-  for (int q = 0; q < 8; ++q) {
-    double zc = (m < M && q < DP) ? Zs[(size_t)m * DP + q] - centre[q] : 0.0;
-    if (!(fabs(zc) <= 128.0)) { far = true; zc = 0.0; }   // (also a NaN coordinate)
-    row[q] = (float)(-2.0 * zc * us);
-    row[8 + q] = (float)us;
-    row[16 + q] = (float)(zc * zc * us);
+  for (int g = 0; g < NG; ++g) {
+    float* row = TT + ((size_t)g * Mp + m) * L3_TTS;
+    for (int q = 0; q < 8; ++q) {
+      const int qq = 8 * g + q;
+      double zc = (m < M && qq < DP) ? Zs[(size_t)m * DP + qq] - centre[qq] : 0.0;
+      if (!(fabs(zc) <= 128.0)) { far = true; zc = 0.0; }   // (also a NaN coordinate)
+      row[q] = (float)(-2.0 * zc * us);
+      row[8 + q] = (float)us;
+      row[16 + q] = (float)(zc * zc * us);
+    }
+    for (int q = 24; q < L3_TTS; ++q) row[q] = 0.0f;
   }
-  for (int q = 24; q < L3_TTS; ++q) row[q] = 0.0f;
   if (far) atomicOr(flag, 1);
 }
 
 // B operand of the contraction product.  16-byte vector v = (((rt 2 + s) 2 + h) 32 + c): data rows n = 32 rt + 16 s + 4 h + (t & 3) + 8 (t >> 2),
 // t = 0 .. 7 (the rows lane half h of an accumulator tile holds in registers 8 s .. 8 s + 7); column c = 8 kind + q.
-__global__ __launch_bounds__(256) void lo_bx_kernel(const double* __restrict__ Xs, const double* __restrict__ centre, int64_t ngroups, int DP,
+__global__ __launch_bounds__(256) void lo_bx_kernel(const double* __restrict__ Xs, const double* __restrict__ centre, int64_t ngroups, int DP, int NG,
                                                     lo_u4* __restrict__ out) {
-  // thread <-> (row tile rt, k-step s, lane half h, dimension q): its eight rows once, the four kinds of column from them
+  // thread <-> (row tile rt, k-step s, lane half h, dimension q < 8 NG): its eight rows once, the four kinds of column from them
   const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (u >= ngroups * 8) return;
-  const int q = (int)(u & 7), hh = (int)((u >> 3) & 1), s = (int)((u >> 4) & 1);
-  const int64_t rt = u >> 5;
-  const double cq = centre[q];
+  const int nq = 8 * NG;
+  if (u >= ngroups * nq) return;
+  const int q = (int)(u % nq);
+  const int64_t grp = u / nq;   // (rt 2 + s) 2 + h
+  const int hh = (int)(grp & 1), s = (int)((grp >> 1) & 1);
+  const int64_t rt = grp >> 2;
+  const double cq = q < DP ? centre[q] : 0.0;
   uint32_t w[4][4];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -329,7 +336,8 @@ __global__ __launch_bounds__(256) void lo_bx_kernel(const double* __restrict__ X
       else w[kind][t >> 1] = bits;
     }
   }
-  lo_u4* dst = out + (u >> 3) * 32 + q;   // vector (((rt 2 + s) 2 + h) 32 + 8 kind + q)
+  // vector ((((rt NG + g) 2 + s) 2 + h) 32 + 8 kind + (q % 8)), g = q / 8
+  lo_u4* dst = out + ((((rt * NG + (q >> 3)) * 2 + s) * 2 + hh) * 32 + (q & 7));
 #pragma unroll
   for (int kind = 0; kind < 4; ++kind) {
     lo_u4 o;
@@ -353,21 +361,22 @@ __device__ __forceinline__ void lo3_glds(const char* g, uint8_t* l) {
 // busy at 2.03 GHz, SQ counters of the bench run), not their latency and not the LDS.
 template <int VAR>
 __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restrict__ Kh, const uint16_t* __restrict__ Pl,
-                                                       const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int Mp2, int64_t nrb,
+                                                       const lo_u4* __restrict__ Bx, const float* __restrict__ TT, int Mp, int Mp2, int NG, int64_t nrb,
                                                        int ncb, double* __restrict__ part) {
   // (dynamic: with a static array hipcc knows that the LDS-DMA and the fragment reads touch one object and drains the DMA -- vmcnt(0) --
   // before the first read behind it, i.e. before the MFMAs it was to hide under)
   extern __shared__ __attribute__((aligned(1024))) uint8_t l3[];
-  __shared__ double red[8][9];
+  __shared__ double red[8][33];
   const int xcd = blockIdx.x & 7;
   const int64_t jj = blockIdx.x >> 3;
   const int cb = (int)(jj % ncb);
   const int64_t rb = (jj / ncb) * 8 + xcd;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* mypart = part + (size_t)blockIdx.x * 9;
+  const int nslot = 8 * NG + 1;   // [8 NG dimensions | S_0]
+  double* mypart = part + (size_t)blockIdx.x * nslot;
   if (rb >= nrb) {
-    if (tid < 9) mypart[tid] = 0.0;
+    if (tid < nslot) mypart[tid] = 0.0;
     return;
   }
   const int wr = wave >> 1, wc = wave & 1;
@@ -399,8 +408,8 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue1(t, buf, q);
   };
-  auto issue_tt = [&]() {   // this column block's 28 KB of the factor table, a linear copy into its own region
-    const char* src = reinterpret_cast<const char*>(TT + (size_t)m0 * L3_TTS) + lane * 16;
+  auto issue_tt = [&](int gq) {   // this column block's 28 KB of dimension group gq's factor table, a linear copy into its own region
+    const char* src = reinterpret_cast<const char*>(TT + ((size_t)gq * Mp2 + m0) * L3_TTS) + lane * 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int P = wave + 8 * k;
@@ -467,9 +476,9 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) bx[i][s] = bxg[((((size_t)rb * 8 + 2 * wr + i) * 2 + s) * 2 + h) * 32 + r31];
+      for (int s = 0; s < 2; ++s) bx[i][s] = bxg[(((((size_t)rb * 8 + 2 * wr + i) * NG + 0) * 2 + s) * 2 + h) * 32 + r31];
   }
-  issue_tt();
+  issue_tt(0);
   issue(0, 0);
   for (int t = 0; t < T; t += 2) {   // (T is a multiple of 4: Mp2 of 256)
     step(t, std::integral_constant<int, 0>());
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
     const double v = wave_sum((double)sacc);
     if (lane == 0) red[wave][0] = v;
     __syncthreads();
-    if (tid < 9) mypart[tid] = tid == 0 ? red[0][0] + red[1][0] + red[2][0] + red[3][0] + red[4][0] + red[5][0] + red[6][0] + red[7][0] : 0.0;
+    if (tid < nslot) mypart[tid] = tid == 0 ? red[0][0] + red[1][0] + red[2][0] + red[3][0] + red[4][0] + red[5][0] + red[6][0] + red[7][0] : 0.0;
     return;
   }
   // ---- contraction
@@ -501,78 +510,96 @@ __global__ __launch_bounds__(512) void kphi_lo3_kernel(const uint16_t* __restric
 #define L3_LOADKP(I, J)                                                                                        \
   _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                               \
     raw[e] = *reinterpret_cast<const uint16_t*>(kpl + ((J) >> 1) * L3_STAGE + ((I) * 32 + (e & 3) + 8 * (e >> 2)) * 128 + ((J) & 1) * 64);
-  L3_LOADKP(0, 0)
   const int oc = (r31 >> 4) ? 8 + (r31 & 7) : (r31 & 7);
   const lo_h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
-  float P = 0.0f, S0 = 0.0f, Sz[8];
+  // one pass over the accumulators per group of eight dimensions (d <= 8: one): the group's B fragments and factor table, w recomputed
+  for (int gq = 0; gq < NG; ++gq) {
+    if (gq > 0) {
+      __syncthreads();   // every wave is through with the previous group's factor table
+      {
+        const lo_h8* bxg = reinterpret_cast<const lo_h8*>(Bx);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) Sz[q] = 0.0f;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    lo_f32x16 out2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) out2[e] = 0.0f;
-    float a0 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint32_t pk[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pk[u] = raw[2 * u] | (raw[2 * u + 1] << 16);
-      __builtin_amdgcn_sched_barrier(0);
-      if (i == 0) { L3_LOADKP(1, j) }
-      else if (j < 3) {
-        if (j == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // the second half of the K' block (this wave's own DMAs)
-        L3_LOADKP(0, j + 1)
+          for (int s = 0; s < 2; ++s) bx[i][s] = bxg[(((((size_t)rb * 8 + 2 * wr + i) * NG + gq) * 2 + s) * 2 + h) * 32 + r31];
       }
-      __builtin_amdgcn_sched_barrier(0);
-      uint32_t wv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const lo_f2 v2 = {acc[i][j][2 * u], acc[i][j][2 * u + 1]};
-        const lo_h2 w2 = __builtin_convertvector(v2, lo_h2) * __builtin_bit_cast(lo_h2, pk[u]);
-        a0 = __builtin_amdgcn_fdot2(w2, ones, a0, false);
-        wv[u] = __builtin_bit_cast(uint32_t, w2);
-      }
-      lo_u4 f0, f1;
-      f0[0] = wv[0]; f0[1] = wv[1]; f0[2] = wv[2]; f0[3] = wv[3];
-      f1[0] = wv[4]; f1[1] = wv[5]; f1[2] = wv[6]; f1[3] = wv[7];
-      out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lo_h8, f0), bx[i][0], out2, 0, 0, 0);
-      out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lo_h8, f1), bx[i][1], out2, 0, 0, 0);
+      issue_tt(gq);
+      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-    const int mb = wc * 128 + j * 32;
+    L3_LOADKP(0, 0)
+    float P = 0.0f, S0 = 0.0f, Sz[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) P = fmaf(out2[e], ttl[(mb + (e & 3) + 8 * (e >> 2) + 4 * h) * L3_TTS + oc], P);
-    const float* tm = ttl + (mb + r31) * L3_TTS;
-    const lo_f4 z0 = *reinterpret_cast<const lo_f4*>(tm + 16), z1 = *reinterpret_cast<const lo_f4*>(tm + 20);
-    S0 = fmaf(a0, tm[8], S0);
+    for (int q = 0; q < 8; ++q) Sz[q] = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      Sz[q] = fmaf(a0, z0[q], Sz[q]);
-      Sz[4 + q] = fmaf(a0, z1[q], Sz[4 + q]);
+    for (int j = 0; j < 4; ++j) {
+      lo_f32x16 out2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out2[e] = 0.0f;
+      float a0 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pk[u] = raw[2 * u] | (raw[2 * u + 1] << 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) { L3_LOADKP(1, j) }
+        else if (j < 3) {
+          if (j == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // the second half of the K' block (this wave's own DMAs)
+          L3_LOADKP(0, j + 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const lo_f2 v2 = {acc[i][j][2 * u], acc[i][j][2 * u + 1]};
+          const lo_h2 w2 = __builtin_convertvector(v2, lo_h2) * __builtin_bit_cast(lo_h2, pk[u]);
+          a0 = __builtin_amdgcn_fdot2(w2, ones, a0, false);
+          wv[u] = __builtin_bit_cast(uint32_t, w2);
+        }
+        lo_u4 f0, f1;
+        f0[0] = wv[0]; f0[1] = wv[1]; f0[2] = wv[2]; f0[3] = wv[3];
+        f1[0] = wv[4]; f1[1] = wv[5]; f1[2] = wv[6]; f1[3] = wv[7];
+        out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lo_h8, f0), bx[i][0], out2, 0, 0, 0);
+        out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lo_h8, f1), bx[i][1], out2, 0, 0, 0);
+      }
+      const int mb = wc * 128 + j * 32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) P = fmaf(out2[e], ttl[(mb + (e & 3) + 8 * (e >> 2) + 4 * h) * L3_TTS + oc], P);
+      const float* tm = ttl + (mb + r31) * L3_TTS;
+      const lo_f4 z0 = *reinterpret_cast<const lo_f4*>(tm + 16), z1 = *reinterpret_cast<const lo_f4*>(tm + 20);
+      S0 = fmaf(a0, tm[8], S0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Sz[q] = fmaf(a0, z0[q], Sz[q]);
+        Sz[4 + q] = fmaf(a0, z1[q], Sz[4 + q]);
+      }
+    }
+    // ten butterflies side by side (one after the other, as nine wave_sum() calls on doubles, they were 54 dependent ds_bpermute round trips:
+    // most of this contraction's time); P only over the lanes that share lane % 8
+    {
+      float v[9];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = Sz[q];
+      v[8] = S0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v[q] += __shfl_xor(v[q], o, 64);
+        if (o >= 8) P += __shfl_xor(P, o, 64);
+      }
+      // lane q < 8: S_q = the A0 part (every lane holds it) + the product part (lanes = q mod 8 hold it); lane 8: S_0 (the same in every group)
+      float mine = v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mine = lane == q ? v[q] + P : mine;
+      if (lane < 8) red[wave][8 * gq + lane] = (double)mine;
+      if (lane == 8 && gq == 0) red[wave][8 * NG] = (double)mine;
     }
   }
 #undef L3_LOADKP
-  // ten butterflies side by side (one after the other, as nine wave_sum() calls on doubles, they were 54 dependent ds_bpermute round trips:
-  // most of this contraction's time); P only over the lanes that share lane % 8
-  {
-    float v[9];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = Sz[q];
-    v[8] = S0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int q = 0; q < 9; ++q) v[q] += __shfl_xor(v[q], o, 64);
-      if (o >= 8) P += __shfl_xor(P, o, 64);
-    }
-    // lane q < 8: S_q = the A0 part (every lane holds it) + the product part (lanes = q mod 8 hold it); lane 8: S_0
-    float mine = v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) mine = lane == q ? v[q] + P : mine;
-    if (lane < 9) red[wave][lane] = (double)mine;
-  }
   __syncthreads();
-  if (tid < 9) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+  if (tid < nslot) mypart[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
 }
 
 // delta (optional, d + 1 doubles): the correction itself [d lengthscales | sf2] -- what the caller holds against the gradient to decide whether
@@ -625,17 +652,18 @@ static LoWs carve_lo(void* ws, const StreamPlan& p, bool have_f16 = false) {
   const int ncb = p.Mp / LO_T;
   w.grid = (int)(((nrb + 7) / 8) * 8 * ncb);
   {
-    const size_t g256 = (size_t)((p.Npad / 256 + 7) / 8) * 8 * (size_t)((p.Mp + 255) / 256);   // the 256 x 256 kernels' grid, nine slots each
-    const size_t a = (size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1), b = g256 * 9;
+    const size_t g256 = (size_t)((p.Npad / 256 + 7) / 8) * 8 * (size_t)((p.Mp + 255) / 256);   // the 256 x 256 kernel's grid, 8 NG + 1 slots each
+    const size_t a = (size_t)(w.grid > 0 ? w.grid : 1) * (p.DP + 1), b = g256 * (size_t)(8 * ((p.DP + 7) / 8) + 1);
     w.part = c.take<double>(a > b ? a : b);
   }
   const size_t mp2 = (size_t)(p.Mp + 255) / 256 * 256;   // (the 256 x 256 kernel's padding)
   w.Pl = c.take<uint16_t>(mp2 * mp2);
   w.unscale = c.take<double>(mp2);
-  w.centre = c.take<double>(8);
+  w.centre = c.take<double>(32);
   w.flag = c.take<int>(4);
-  w.TT = c.take<float>(mp2 * L3_TTS);
-  w.Bx = c.take<lo_u4>((size_t)(p.Npad > 0 ? p.Npad : 1) * 4);   // Npad / 32 row tiles x 128 vectors of 16 bytes
+  const size_t ng = (size_t)(p.DP + 7) / 8;   // groups of eight dimensions
+  w.TT = c.take<float>(mp2 * L3_TTS * ng);
+  w.Bx = c.take<lo_u4>((size_t)(p.Npad > 0 ? p.Npad : 1) * 4 * ng);   // Npad / 32 row tiles x NG groups x 128 vectors of 16 bytes
   w.Kh = have_f16 ? nullptr : c.take<uint16_t>((size_t)(p.Npad > 0 ? p.Npad : 1) * p.Mp);   // (last: a caller that brings the image saves it)
   w.bytes = c.used();
   return w;
@@ -646,13 +674,13 @@ static LoWs carve_lo(void* ws, const StreamPlan& p, bool have_f16 = false) {
 using namespace sgp;
 
 extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes_ex(int64_t N, int M, int d, int have_f16) {
-  if (N < 0 || M <= 0 || d <= 0 || d > 8 || M > SGP_MAX_INDUCING) return 0;
+  if (N < 0 || M <= 0 || d <= 0 || d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return 0;
   return carve_lo(nullptr, make_stream_plan(N, M, d), have_f16 != 0).bytes;
 }
 extern "C" size_t sgp_suffstats_bwd_lo_workspace_bytes(int64_t N, int M, int d) { return sgp_suffstats_bwd_lo_workspace_bytes_ex(N, M, d, 0); }
 
 // Adds the low word's contribution to g_ls (d doubles) and g_sf2 IN PLACE, behind sgp_suffstats_bwd on the same stream with the same
-// inputs and Phibar = the leading word.  Kfu_in: the fp64 K'_fu of this shard (sgp_kfu_len doubles) as pass 1 left it.  RBF, d <= 8
+// inputs and Phibar = the leading word.  Kfu_in: the fp64 K'_fu of this shard (sgp_kfu_len doubles) as pass 1 left it.  RBF (d <= 8 for the first version's kernel)
 // (SGP_ERR_ARG / SGP_ERR_DIM otherwise: the caller then keeps the leading word's gradient); g_Z is not corrected.  delta (optional,
 // d + 1 doubles): receives the correction itself.
 extern "C" int sgp_suffstats_bwd_lo(const double* X, int64_t ldx, const double* y, const double* Z, int64_t ldz, const double* inv_ls,
@@ -670,7 +698,7 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
   if (!Z || !inv_ls || !Phibar_lo || (!Kfu_in && !Kfu_f16_in) || !g_ls || !g_sf2 || N < 0 || M <= 0 || d <= 0 || ldz < d) return SGP_ERR_ARG;
   if (N > 0 && (!X || !y || ldx < d)) return SGP_ERR_ARG;
   if (kernel_id != SGP_KERNEL_RBF) return SGP_ERR_ARG;
-  if (d > 8 || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
+  if (d > SGP_MAX_DIM || M > SGP_MAX_INDUCING) return SGP_ERR_DIM;
   if (N == 0) {
     if (delta) fill_zero(delta, (size_t)d + 1, (hipStream_t)stream);
     return check_launch();
@@ -686,7 +714,9 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
   ka.d = d;
   stream_prologue(p, ka, X, ldx, y, Z, ldz, N, M, w.Xs, w.ys, w.Zs, w.yypart, st);
   static const int lo_kernel = getenv("SGP_LO_KERNEL") ? atoi(getenv("SGP_LO_KERNEL")) : 3;   // A/B: 1 = the first version (128 x 128 tiles, register ring, fp64 contraction)
+  if (lo_kernel != 3 && d > 8) return SGP_ERR_DIM;   // (the first version's kernel: d <= 8)
   const bool v3 = lo_kernel == 3;
+  const int NG = (p.DP + 7) / 8;
   const int Mp2 = (p.Mp + L3_T - 1) / L3_T * L3_T, plm = v3 ? Mp2 : p.Mp;   // the padded edge of the low word's image
   if (v3) lo3_centre_kernel<<<1, 256, 0, st>>>(w.Zs, M, p.DP, w.centre, w.flag);
   lo_prep_kernel<<<plm, 256, 0, st>>>(Phibar_lo, M, plm, v3 ? 3 : 14, w.Pl, w.unscale);
@@ -695,15 +725,15 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
   if (!Kfu_f16_in) lo_kfu_f16_kernel<<<4096, 256, 0, st>>>(Kfu_in, (int64_t)p.Npad * p.Mp / 8, reinterpret_cast<uint4*>(w.Kh));
   int nparts = w.grid, part_dp = p.DP;
   if (v3) {
-    lo3_tt_kernel<<<(Mp2 + 255) / 256, 256, 0, st>>>(w.Zs, w.unscale, w.centre, M, Mp2, p.DP, w.TT, w.flag);
-    const int64_t ngroups = p.Npad / 8;   // (row tile, k-step, lane half): 32 vectors each
-    lo_bx_kernel<<<(unsigned)((ngroups * 8 + 255) / 256), 256, 0, st>>>(w.Xs, w.centre, ngroups, p.DP, w.Bx);
+    lo3_tt_kernel<<<(Mp2 + 255) / 256, 256, 0, st>>>(w.Zs, w.unscale, w.centre, M, Mp2, p.DP, NG, w.TT, w.flag);
+    const int64_t ngroups = p.Npad / 8;   // (row tile, k-step, lane half): 32 vectors per group of dimensions each
+    lo_bx_kernel<<<(unsigned)((ngroups * 8 * NG + 255) / 256), 256, 0, st>>>(w.Xs, w.centre, ngroups, p.DP, NG, w.Bx);
     const int64_t nrb2 = p.Npad / L3_T;
     const int ncb2 = Mp2 / L3_T;
     nparts = (int)(((nrb2 + 7) / 8) * 8 * ncb2);
-    part_dp = 8;
+    part_dp = 8 * NG;
     static const int lo_var = getenv("SGP_LO_VARIANT") ? atoi(getenv("SGP_LO_VARIANT")) : 0;
-    typedef void (*lo3_fn)(const uint16_t*, const uint16_t*, const lo_u4*, const float*, int, int, int64_t, int, double*);
+    typedef void (*lo3_fn)(const uint16_t*, const uint16_t*, const lo_u4*, const float*, int, int, int, int64_t, int, double*);
     static const lo3_fn fns[3] = {kphi_lo3_kernel<0>, kphi_lo3_kernel<1>, kphi_lo3_kernel<2>};
     const lo3_fn fn = fns[lo_var < 0 || lo_var > 2 ? 0 : lo_var];
     constexpr int lds_bytes = L3_LDS_BYTES;
@@ -715,7 +745,7 @@ extern "C" int sgp_suffstats_bwd_lo_f16(const double* X, int64_t ldx, const doub
         if (hipFuncSetAttribute((const void*)fns[b], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return SGP_ERR_LAUNCH;
       if (dev < 64) attr_done[dev].store(true, std::memory_order_release);
     }
-    fn<<<nparts, 512, lds_bytes, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, Mp2, nrb2, ncb2, w.part);
+    fn<<<nparts, 512, lds_bytes, st>>>(Kh, w.Pl, w.Bx, w.TT, p.Mp, Mp2, NG, nrb2, ncb2, w.part);
   } else {
     switch (p.DP) {
       case 2: kphi_lo_kernel<2><<<w.grid, 256, 0, st>>>(Kfu_in, Kh, w.Pl, w.unscale, w.Xs, w.Zs, p.Mp, nrb, ncb, w.part); break;

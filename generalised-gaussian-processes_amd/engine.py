@@ -309,7 +309,7 @@ class HipEngine:
         return hi, lo
 
     def bwd_lo_supported(self, N: int, M: int, d: int, kernel="rbf") -> bool:
-        """``suffstats_bwd_lo`` exists for this shape: RBF, d <= 8."""
+        """``suffstats_bwd_lo`` exists for this shape: RBF (any d the streaming kernels take)."""
         return kernel == "rbf" and self.lib.sgp_suffstats_bwd_lo_workspace_bytes(int(N), int(M), int(d)) > 0
 
     def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads: torch.Tensor, kernel="rbf", delta: Optional[torch.Tensor] = None,

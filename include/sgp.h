@@ -421,7 +421,7 @@ int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, double s2, do
  * had its Phibar carried Phibar_lo as well -- dC = K' Phibar_lo on the fp16 matrix cores (three digits are all a 2^-53-relative term
  * needs), contracted with dK there as well (hi + lo fp16 pairs of the centred inputs; an inducing point more than 128 lengthscales from the
  * mean inducing point is beyond that format: delta then receives NaN and nothing is added).  Call it behind sgp_suffstats_bwd (same stream, same inputs, Phibar = the leading word, the same
- * caller-owned fp64 K'_fu as Kfu_in) and before the gradients are all-reduced.  RBF kernel, d <= 8 (SGP_ERR_ARG / SGP_ERR_DIM otherwise);
+ * caller-owned fp64 K'_fu as Kfu_in) and before the gradients are all-reduced.  RBF kernel (SGP_ERR_ARG otherwise), any d <= SGP_MAX_DIM (groups of eight dimensions);
  * dF/dZ is not corrected.  delta (DEVICE, d + 1 doubles, or NULL) receives the correction itself, [d lengthscales | sf2]: its size against
  * the gradient is the a-posteriori check a caller applies before trusting the explicit pass 2 at a theta (measured at C5 over 34 theta
  * against the factored pass 2 of the whitened order: what is left after the correction is <= 5 % of it while the streaming-order

@@ -309,7 +309,7 @@ class FactoredOracleEngine(GuardedOracleEngine):
         return torch.from_numpy(hi), (torch.from_numpy(lo) if want_lo else None)
 
     def bwd_lo_supported(self, N, M, d, kernel="rbf"):
-        return kernel == "rbf" and d <= 8
+        return kernel == "rbf" and d <= 32
 
     def suffstats_bwd_lo(self, X, y, Z, ls, sf2, Phibar_lo, kfu, grads, kernel="rbf", delta=None, kfu_f16=None):
         """sgp_suffstats_bwd_lo: what pass 2 would have added had its Phibar carried the trailing word (lengthscales and amplitude only)."""

@@ -151,7 +151,7 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
     residuals -- does not have."""
     import numpy as np
     import ggp_amd
-    for (N, M, d) in ((3000, 200, 3), (20000, 384, 8), (777, 130, 1), (6000, 1024, 8)):
+    for (N, M, d) in ((3000, 200, 3), (20000, 384, 8), (777, 130, 1), (6000, 1024, 8), (4000, 256, 18), (3000, 300, 32), (2500, 200, 9)):
         g = torch.Generator().manual_seed(N + M)
         X = torch.randn(N, d, dtype=torch.float64, generator=g)
         y = torch.randn(N, dtype=torch.float64, generator=g)
@@ -215,4 +215,4 @@ def test_double_double_phibar_and_its_trailing_word_in_pass_2(engine):
     delta = torch.zeros(d + 1, dtype=torch.float64, device=engine.device)
     engine.suffstats_bwd_lo(Xd, yd, Zd, ls, 1.0, P, kfu, acc, "rbf", delta=delta)
     assert bool(torch.isnan(delta).all()) and bool((acc == 1.0).all())
-    assert not engine.bwd_lo_supported(1000, 64, 9) and not engine.bwd_lo_supported(1000, 64, 3, "matern32")
+    assert engine.bwd_lo_supported(1000, 64, 9) and not engine.bwd_lo_supported(1000, 64, 33) and not engine.bwd_lo_supported(1000, 64, 3, "matern32")

@@ -13,7 +13,7 @@ import ggp_amd  # noqa: E402
 eng = ggp_amd.HipEngine()
 worst = 0.0
 for (N, M, d, shift, lsv, spread) in ((3000, 200, 3, 0.0, 1.5, 1.0), (5000, 1024, 8, 0.0, 2.0, 1.0), (5000, 256, 8, 40.0, 2.0, 1.0), (4000, 256, 2, -300.0, 0.3, 1.0),
-                                      (6000, 512, 4, 5.0, 0.5, 20.0), (777, 130, 1, 0.0, 1.0, 1.0), (4000, 300, 3, 0.0, 1.5, 1.0), (900, 100, 2, 0.0, 1.0, 1.0), (5000, 640, 8, 0.0, 2.5, 1.0), (3000, 896, 6, 0.0, 2.0, 1.0), (20000, 1024, 8, 0.0, 3.0, 1.0), (2500, 256, 5, 1000.0, 0.05, 3.0)):
+                                      (6000, 512, 4, 5.0, 0.5, 20.0), (777, 130, 1, 0.0, 1.0, 1.0), (4000, 300, 3, 0.0, 1.5, 1.0), (900, 100, 2, 0.0, 1.0, 1.0), (5000, 640, 8, 0.0, 2.5, 1.0), (3000, 896, 6, 0.0, 2.0, 1.0), (6000, 512, 18, 0.0, 3.0, 1.0), (4000, 256, 32, 2.0, 4.0, 1.0), (5000, 1024, 9, 0.0, 2.5, 1.0), (3000, 256, 16, -5.0, 3.0, 1.0), (20000, 1024, 8, 0.0, 3.0, 1.0), (2500, 256, 5, 1000.0, 0.05, 3.0)):
     g = torch.Generator().manual_seed(N + M)
     X = spread * torch.randn(N, d, dtype=torch.float64, generator=g) + shift
     y = torch.randn(N, dtype=torch.float64, generator=g)
