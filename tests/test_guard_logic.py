@@ -392,6 +392,27 @@ def test_extended_gradient_is_trusted_by_its_own_trailing_word_correction(no_sma
     assert c3.last_tier == 1 and c3.n_lo_rejections == 2
 
 
+def test_trailing_word_path_is_taken_for_more_than_eight_dimensions(no_small_whitened):
+    """The trailing-word product runs eight dimensions per pass over its accumulators (round 6): d > 8 is no longer a reason to fall back to
+    the leading word's 3 x gradient range -- the same rule, the same check, the fp16 image handed over."""
+    from fake_engine import FactoredOracleEngine
+    X, y, Z = _problem(d=11)
+    eng = FactoredOracleEngine()
+    cb = _bound(X, y, eng)
+    assert cb._bwd_lo_ok(Z.shape[0])
+    # a theta whose estimate lies between the old gradient range (3 x) and the new one (1000 x the tolerance)
+    for lsv, s2 in ((6.0, 5e-3), (8.0, 5e-3), (10.0, 2e-3), (14.0, 1e-3), (20.0, 1e-3)):
+        F, g = cb.value_and_grad(Z, [lsv] * 11, 1.0, s2)
+        if 3.0 * cb.streaming_tol < cb.last_estimate <= cb.extended_grad_range_lo * cb.streaming_tol and cb.last_tier == 1:
+            break
+    else:
+        pytest.skip("no theta of the sweep landed between the two ranges")
+    assert eng.calls["suffstats_bwd_lo"] >= 1 and eng.calls["f16_handed_over"] >= 1 and cb.n_lo_rejections == 0
+    ref = _bound(X, y, form="whitened")
+    Fw, gw = ref.value_and_grad(Z, [lsv] * 11, 1.0, s2)
+    assert abs(F - Fw) / X.shape[0] < 2e-9 and np.max(np.abs(g["ls"].numpy() - gw["ls"].numpy())) <= 1e-6 * max(1.0, float(gw["ls"].abs().max()))
+
+
 def test_hmc_target_sampler_mode_uses_the_extended_order_for_gradients(no_small_whitened):
     import ggp_amd as pkg
     from fake_engine import FactoredOracleEngine
