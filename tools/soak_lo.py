@@ -17,7 +17,7 @@ eng = ggp_amd.HipEngine()
 side = torch.cuda.Stream(device=eng.device)
 noise = torch.randn(4096, 4096, device=eng.device)
 bad_total = 0
-for (N, M, d) in ((1000000, 1024, 8), (200000, 1024, 8), (60000, 512, 4), (30000, 384, 3), (9000, 200, 2), (5000, 896, 6)):
+for (N, M, d) in ((1000000, 1024, 8), (200000, 1024, 8), (60000, 512, 4), (30000, 384, 3), (9000, 200, 2), (5000, 896, 6), (20000, 512, 18), (8000, 256, 32)):
     g = torch.Generator().manual_seed(N + M)
     X = torch.randn(N, d, dtype=torch.float64, generator=g)
     y = torch.randn(N, dtype=torch.float64, generator=g)
