@@ -2,7 +2,8 @@
 # The digest-matched final set of a round, in one go on the GPU box (from the repo root):   bash tools/profile_final.sh r05_v5
 # bench line + rocprofv3 stats + PMC traffic (profile_round.sh), SQ counters (profile_sq.sh), TCC counters, potrf A/B against the round-1
 # kernel, the smaller configs, the shard sizes of the multi-GPU job, C3 and 125 k-row-shard kernel timelines, the guarded orders' times,
-# NUTS at the mid sizes, and the GPU suite.  Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_*.
+# NUTS at the mid sizes, the chain Cholesky's budget sweep / soak / trace check, the trailing-word product's pieces, versions, accuracy sweep, race
+# screen and counters, the experiment driver, smoke and the GPU suite.  Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_*.
 set -u
 TAG=${1:-r05}
 export TMPDIR=/tmp
