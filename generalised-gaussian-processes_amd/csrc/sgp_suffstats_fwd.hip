@@ -740,17 +740,27 @@ constexpr int DDT = 64, DDK = 16;
 template <int NI, int NJ>
 __global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restrict__ Ahi, const double* __restrict__ Alo,
                                                          const double* __restrict__ B, int n, double* __restrict__ Chi,
-                                                         double* __restrict__ Clo, int tr) {
+                                                         double* __restrict__ Clo, int tr, int kmode, int lower_only) {
 #pragma clang fp contract(off)
   constexpr int TI = 16 * NI, TJ = 16 * NJ;
   __shared__ double sAh[DDK][TI + 1], sAl[DDK][TI + 1], sB[DDK][TJ + 1];
-  const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  // (column block rotated by a quarter of the grid per quarter of the rows: the workgroups a CU holds together -- ids 256 apart, i.e. the same
+  // blockIdx.x, rows gridDim.y / 4 apart at n = 1024 -- then have k ranges of four different lengths; unrotated they all had the same one and
+  // the triangular skipping below shortened the launch by 8 % for half the work)
+  const int jrot = (int)((blockIdx.x + (gridDim.x / 4) * (blockIdx.y / (gridDim.y / 4 > 0 ? gridDim.y / 4 : 1))) % gridDim.x);
+  const int i0 = blockIdx.y * TI, j0 = jrot * TJ, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  // Both uses multiply by a TRIANGULAR B (L^-1 or its transpose) and read only the lower triangle of their second product (round 6):
+  // kmode 1: B[j][k] = 0 for k < j -- the k loop starts at this tile's first column; kmode 2: B[j][k] = 0 for k > j -- it ends behind its
+  // last one; lower_only: tiles strictly above the diagonal are not computed.  The skipped terms are exact zeros: the same bits.
+  if (lower_only && i0 + TI <= j0) return;
+  const int kbeg = kmode == 1 ? (j0 / DDK) * DDK : 0;
+  const int kend = kmode == 2 ? ((j0 + TJ + DDK - 1) / DDK * DDK < n ? (j0 + TJ + DDK - 1) / DDK * DDK : n) : n;
   double hi[NI][NJ], lo[NI][NJ];
 #pragma unroll
   for (int a = 0; a < NI; ++a)
 #pragma unroll
     for (int b = 0; b < NJ; ++b) hi[a][b] = lo[a][b] = 0.0;
-  for (int k0 = 0; k0 < n; k0 += DDK) {
+  for (int k0 = kbeg; k0 < kend; k0 += DDK) {
     for (int e = tid; e < TI * DDK; e += 256) {
       const int r = e / DDK, kk = e % DDK;
       sAh[kk][r] = Ahi[(size_t)(i0 + r) * n + k0 + kk];
@@ -794,12 +804,15 @@ __global__ __launch_bounds__(256) void dd_gemm_nt_kernel(const double* __restric
       Clo[o] = l;
     }
 }
-static void dd_launch(const double* Ahi, const double* Alo, const double* B, int n, double* Chi, double* Clo, int tr, hipStream_t st) {
+static void dd_launch(const double* Ahi, const double* Alo, const double* B, int n, double* Chi, double* Clo, int tr, hipStream_t st, int kmode,
+                      int lower_only) {
+  static const int full = getenv("SGP_DD_FULL") ? atoi(getenv("SGP_DD_FULL")) : 0;   // A/B: the whole product, every tile (rounds 4-5)
+  if (full) { kmode = 0; lower_only = 0; }
   // SGP_DD_TILE=44: the 64 x 64 tiles of rounds 4-5.  Same box, Phibar's two products at n = 1024: 1.39-1.40 ms (64 x 64), 1.14-1.16 (64 x 32),
   // 1.06-1.07 (32 x 32: four waves per SIMD) -- profiles/r06_dd_gemm_tile_ab.txt
   static const int shape = getenv("SGP_DD_TILE") ? atoi(getenv("SGP_DD_TILE")) : 22;
-  if (shape == 44) dd_gemm_nt_kernel<4, 4><<<dim3(n / 64, n / 64), 256, 0, st>>>(Ahi, Alo, B, n, Chi, Clo, tr);
-  else dd_gemm_nt_kernel<2, 2><<<dim3(n / 32, n / 32), 256, 0, st>>>(Ahi, Alo, B, n, Chi, Clo, tr);
+  if (shape == 44) dd_gemm_nt_kernel<4, 4><<<dim3(n / 64, n / 64), 256, 0, st>>>(Ahi, Alo, B, n, Chi, Clo, tr, kmode, lower_only);
+  else dd_gemm_nt_kernel<2, 2><<<dim3(n / 32, n / 32), 256, 0, st>>>(Ahi, Alo, B, n, Chi, Clo, tr, kmode, lower_only);
 }
 // ---- Phibar in double-double (round 6; tests/studies/explicit_phibar_pass2.py) ---------------------------------
 // The extended order's pass 2 takes the EXPLICIT Phibar = L^-T (C / 2 s2) L^-1, whose cond(K_uu)-sized entries cancel in Kbar = 2 K Phibar.
@@ -849,8 +862,8 @@ extern "C" int sgp_phibar_dd(const double* Cw, const double* kuu_linv, int M, do
   double *Cs = base, *zeros = Cs + mm, *G = zeros + mm, *Yh = G + mm, *Yl = Yh + mm, *Ph = Yl + mm, *Pl = Ph + mm;
   hipStream_t st = (hipStream_t)stream;
   phibar_dd_prep_kernel<<<dim3(Mp / 32, Mp / 32), 256, 0, st>>>(Cw, M, Mp, 0.5 / s2, kuu_linv, Cs, zeros, G);
-  dd_launch(Cs, zeros, G, Mp, Yh, Yl, 1, st);   // Y^T = (Cs L^-1)^T
-  dd_launch(Yh, Yl, G, Mp, Ph, Pl, 0, st);      // Phibar = Y^T (L^-1) = L^-T Cs L^-1
+  dd_launch(Cs, zeros, G, Mp, Yh, Yl, 1, st, 1, 0);   // Y^T = (Cs L^-1)^T          (G[j][k] = L^-1[k][j]: zero for k < j)
+  dd_launch(Yh, Yl, G, Mp, Ph, Pl, 0, st, 1, 1);      // Phibar = Y^T (L^-1) = L^-T Cs L^-1   (phibar_dd_out_kernel reads its lower triangle)
   phibar_dd_out_kernel<<<1024, 256, 0, st>>>(Ph, Pl, M, Mp, Phibar_hi, Phibar_lo);
   return check_launch();
 }
@@ -1222,8 +1235,8 @@ extern "C" int sgp_suffstats_fwd_extended_f16(const double* X, int64_t ldx, cons
   }
   const int nb32 = p.Mp / 32;
   reduce_phi_dd_kernel<<<nb32 * (nb32 + 1) / 2, 256, 0, st>>>(w.slab, w.slab_lo, ns, p.ntiles, p.Mp, w.Ph, w.Pl);
-  dd_launch(w.Ph, w.Pl, kuu_linv, p.Mp, w.Yh, w.Yl, 1, st);  // Y^T = (Phi L^-T)^T
-  dd_launch(w.Yh, w.Yl, kuu_linv, p.Mp, w.Wh, w.Wl, 0, st);  // W = Y^T L^-T = L^-1 Phi L^-T (symmetric)
+  dd_launch(w.Ph, w.Pl, kuu_linv, p.Mp, w.Yh, w.Yl, 1, st, 2, 0);  // Y^T = (Phi L^-T)^T     (L^-1[j][k]: zero for k > j)
+  dd_launch(w.Yh, w.Yl, kuu_linv, p.Mp, w.Wh, w.Wl, 0, st, 2, 1);  // W = Y^T L^-T = L^-1 Phi L^-T (symmetric: ext_w_out_kernel reads the lower triangle)
   ext_w_out_kernel<<<1024, 256, 0, st>>>(w.Wh, w.Wl, M, p.Mp, sf2 * sf2, W);
   if (phi_diag) ext_phi_diag_kernel<<<(M + 255) / 256, 256, 0, st>>>(w.Ph, M, p.Mp, sf2 * sf2, phi_diag);
   // b = K_uf y (fp64, with its amplitude), u = L^-1 b
